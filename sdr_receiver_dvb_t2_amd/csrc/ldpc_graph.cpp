@@ -1,0 +1,82 @@
+// ldpc_graph.cpp -- see ldpc_graph.h. Pure host code (no HIP), also compiled into the schedule emulator of tests/.
+#include "ldpc_graph.h"
+#include "tables/ldpc_tables_data.h"
+#include <algorithm>
+#include <map>
+
+namespace t2gpu {
+
+static const int GROUP = 360;
+
+bool ldpc_build_graph(int code_id, LdpcGraph &g)
+{
+    if (code_id < 0 || code_id >= T2_LDPC_NUM_CODES) return false;
+    const t2_ldpc_table_t &t = T2_LDPC_TABLES[code_id];
+    g = LdpcGraph();
+    g.id = code_id; g.n = t.n; g.k = t.k; g.r = t.n - t.k; g.q = g.r / GROUP;
+
+    struct Ent { int group, shift; };
+    std::vector<std::vector<Ent>> per_layer(g.q);
+    const uint16_t *a = t.addr;
+    for (int grp = 0; grp < t.n_groups; ++grp) {
+        for (int e = 0; e < t.group_deg[grp]; ++e) {
+            int x = a[e];
+            per_layer[x % g.q].push_back({grp, x / g.q});
+        }
+        a += t.group_deg[grp];
+    }
+
+    g.layers.resize(g.q);
+    g.levels.assign((size_t)g.q * GROUP, 1);
+    for (int i = 0; i < g.q; ++i) {
+        std::vector<Ent> &ents = per_layer[i];
+        std::map<int, int> mult;
+        for (const Ent &e : ents) mult[e.group]++;
+        // conflict entries first (stable), so the kernel finds them in fixed link slots
+        std::stable_sort(ents.begin(), ents.end(), [&](const Ent &x, const Ent &y) {
+            bool cx = mult[x.group] > 1, cy = mult[y.group] > 1;
+            if (cx != cy) return cx;
+            if (x.group != y.group) return x.group < y.group;
+            return x.shift < y.shift;
+        });
+        LdpcLayer &L = g.layers[i];
+        L.first_entry = (int)g.entries.size();
+        L.cnt = (int)ents.size();
+        L.n_conflict = 0;
+        for (const Ent &e : ents) {
+            if (mult[e.group] > 1) L.n_conflict++;
+            g.entries.push_back((uint32_t)(e.group * GROUP) | ((uint32_t)e.shift << 16));
+        }
+        g.max_cnt = std::max(g.max_cnt, L.cnt);
+        // dependency levels: node j depends on every earlier node sharing one of its bits
+        uint8_t *lev = &g.levels[(size_t)i * GROUP];
+        int lmax = 1;
+        if (L.n_conflict) {
+            for (int j = 0; j < GROUP; ++j) {
+                int lv = 1;
+                for (int x = 0; x < L.n_conflict; ++x)
+                    for (int y = 0; y < L.n_conflict; ++y) {
+                        if (x == y || ents[x].group != ents[y].group) continue;
+                        // node j reaches bit m through entry x; the same bit reaches node j2 through entry y
+                        int m = ((j - ents[x].shift) % GROUP + GROUP) % GROUP;
+                        int j2 = (ents[y].shift + m) % GROUP;
+                        if (j2 < j) lv = std::max(lv, lev[j2] + 1);
+                    }
+                lev[j] = (uint8_t)lv;
+                lmax = std::max(lmax, lv);
+            }
+        }
+        L.lmax = lmax;
+        g.total_levels += lmax;
+        g.links_total += GROUP * (L.cnt + 2) - (i == 0 ? 1 : 0);
+    }
+    return true;
+}
+
+int ldpc_k_bch(int code_id)
+{
+    static const int kb[12] = {7032, 9552, 10632, 11712, 12432, 13152, 32208, 38688, 43040, 48408, 51648, 53840};
+    return (code_id >= 0 && code_id < 12) ? kb[code_id] : -1;
+}
+
+}  // namespace t2gpu

@@ -1,0 +1,176 @@
+// t2gpu_ldpc.cpp -- C-ABI of the LDPC stage (include/t2gpu.h). Host side only: builds the graph, owns the device
+// buffers, sizes the persistent grid and launches ldpc_kernel.hip. There is no CPU decode path in this library.
+#include "../../include/t2gpu.h"
+#include "ldpc_graph.h"
+#include "ldpc_kernel.h"
+#include "t2gpu_common.h"
+#include <vector>
+
+using namespace t2gpu;
+
+struct t2gpu_ldpc {
+    LdpcGraph g;
+    int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
+    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0;
+    LdpcLayerDev *d_layers = nullptr;
+    uint32_t *d_entries = nullptr;
+    uint8_t *d_levels = nullptr;
+    uint2 *d_state = nullptr;
+    size_t state_blocks = 0;
+    unsigned *d_sync = nullptr;
+    size_t sync_words = 0;
+    int *d_error = nullptr;
+    // host-call staging
+    int8_t *d_in = nullptr;
+    uint8_t *d_out = nullptr;
+    int *d_trials = nullptr;
+    int last_status = 0;
+};
+
+static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->blocks_per_cu; }
+
+extern "C" int t2gpu_ldpc_graph_stats(int fec_type, int code_rate, int *links_total, int *layers,
+                                      int *levels_total, int *max_cnt)
+{
+    LdpcGraph g;
+    if (!ldpc_build_graph(ldpc_code_id(fec_type, code_rate), g)) { set_error("unknown LDPC code"); return -1; }
+    if (links_total) *links_total = g.links_total;
+    if (layers) *layers = g.q;
+    if (levels_total) *levels_total = g.total_levels;
+    if (max_cnt) *max_cnt = g.max_cnt;
+    return 0;
+}
+
+extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_frames, int device)
+{
+    int id = ldpc_code_id(fec_type, code_rate);
+    if (id < 0 || max_frames < 1) { set_error("t2gpu_ldpc_create: bad arguments"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_error("t2gpu_ldpc_create: no such HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    t2gpu_ldpc *h = new t2gpu_ldpc();
+    h->device = device; h->max_frames = max_frames;
+    if (!ldpc_build_graph(id, h->g)) { delete h; set_error("graph build failed"); return nullptr; }
+    auto fail = [&](const char *what, hipError_t e) -> t2gpu_ldpc * {
+        hip_ok(e, what);
+        t2gpu_ldpc_destroy(h);
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    h->num_cu = prop.multiProcessorCount;
+    h->lds_ctl_offset = (h->g.n + 15) & ~15;
+    h->lds_bytes = h->lds_ctl_offset + 64;
+    if ((e = ldpc_kernel_attributes(h->lds_bytes, &h->blocks_per_cu)) != hipSuccess) return fail("kernel attributes", e);
+    if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
+
+    std::vector<LdpcLayerDev> ld(h->g.q);
+    for (int i = 0; i < h->g.q; ++i)
+        ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict};
+    if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&h->d_entries, h->g.entries.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&h->d_levels, h->g.levels.size())) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemcpy(h->d_layers, ld.data(), ld.size() * sizeof(LdpcLayerDev), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    if ((e = hipMemcpy(h->d_entries, h->g.entries.data(), h->g.entries.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    if ((e = hipMemcpy(h->d_levels, h->g.levels.data(), h->g.levels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+
+    h->state_blocks = (size_t)resident_blocks(h);
+    if ((e = hipMalloc(&h->d_state, h->state_blocks * h->g.q * 360 * sizeof(uint2))) != hipSuccess) return fail("hipMalloc state", e);
+    h->sync_words = (size_t)(max_frames + 1) * 64;   // enough for group >= 1 and max_trials <= 63
+    if ((e = hipMalloc(&h->d_sync, h->sync_words * 4)) != hipSuccess) return fail("hipMalloc sync", e);
+    if ((e = hipMalloc(&h->d_error, 4)) != hipSuccess) return fail("hipMalloc", e);
+    return h;
+}
+
+extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
+{
+    if (!h) return;
+    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_levels); hipFree(h->d_state);
+    hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
+    delete h;
+}
+
+extern "C" int t2gpu_ldpc_configure(t2gpu_ldpc *h, int group, int max_trials)
+{
+    if (!h || group < 1 || max_trials < 0 || max_trials > 63) { set_error("t2gpu_ldpc_configure: bad arguments"); return -1; }
+    if (group > 1 && resident_blocks(h) < group) { set_error("device cannot keep one batch resident"); return -1; }
+    h->group = group; h->max_trials = max_trials;
+    return 0;
+}
+
+extern "C" int t2gpu_ldpc_info(const t2gpu_ldpc *h, int *fec_size, int *k_ldpc, int *q_ldpc, int *k_bch)
+{
+    if (!h) return -1;
+    if (fec_size) *fec_size = h->g.n;
+    if (k_ldpc) *k_ldpc = h->g.k;
+    if (q_ldpc) *q_ldpc = h->g.q;
+    if (k_bch) *k_bch = ldpc_k_bch(h->g.id);
+    return 0;
+}
+
+extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uint8_t *d_bits,
+                                      int8_t *d_llr_out, int *d_trials_left, void *stream)
+{
+    if (!h || !d_llr || !d_trials_left || n_frames < 1 || n_frames > h->max_frames) {
+        set_error("t2gpu_ldpc_execute_dev: bad arguments");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int group = h->group;
+    const int nbatches = (n_frames + group - 1) / group;
+    int maxslots = resident_blocks(h) / group;
+    if (maxslots < 1) { set_error("device cannot keep one batch resident"); return -1; }
+    int nslots = nbatches < maxslots ? nbatches : maxslots;
+    int grid = nslots * group;
+    if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }
+
+    T2_HIP(hipMemsetAsync(h->d_sync, 0, (size_t)nbatches * (h->max_trials + 1) * 4, s));
+    T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
+    LdpcKernelParams p;
+    p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
+    p.layers = h->d_layers; p.entries = h->d_entries; p.levels = h->d_levels;
+    p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
+    p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
+    p.state = h->d_state; p.sync = h->d_sync; p.error = h->d_error;
+    p.spin_timeout_ticks = 200000000LL;   // 2 s at 100 MHz
+    p.lds_ctl_offset = h->lds_ctl_offset;
+    T2_HIP(ldpc_kernel_launch(p, grid, h->lds_bytes, s));
+    return 0;
+}
+
+extern "C" int t2gpu_ldpc_status(t2gpu_ldpc *h)
+{
+    if (!h) return -1;
+    int e = 0;
+    T2_HIP(hipMemcpy(&e, h->d_error, 4, hipMemcpyDeviceToHost));
+    h->last_status = e;
+    if (e) set_error("LDPC batch rendezvous timed out");
+    return e;
+}
+
+extern "C" int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out, int *trials_left)
+{
+    if (!h || !in || !out || !trials_left || len_in < h->g.n || len_in % h->g.n) {
+        set_error("t2gpu_ldpc_execute: bad arguments");
+        return -1;
+    }
+    const int n_frames = len_in / h->g.n;
+    if (n_frames > h->max_frames) { set_error("t2gpu_ldpc_execute: more frames than max_frames"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (!h->d_in) {
+        T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_frames * h->g.n));
+        T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_frames * h->g.k));
+        T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
+    }
+    const int nbatches = (n_frames + h->group - 1) / h->group;
+    T2_HIP(hipMemcpy(h->d_in, in, (size_t)len_in, hipMemcpyHostToDevice));
+    if (t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, nullptr)) return -1;
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost));
+    T2_HIP(hipMemcpy(trials_left, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost));
+    return t2gpu_ldpc_status(h) ? -1 : 0;
+}
