@@ -1,0 +1,63 @@
+"""ctypes loader for libt2gpu.so (built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class T2GpuError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libt2gpu.so")
+
+
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every function include/t2gpu.h declares (tests/test_capi_symbols.py).
+PROTOTYPES = {
+    "t2gpu_version": (ctypes.c_int, []),
+    "t2gpu_last_error": (ctypes.c_char_p, []),
+    "t2gpu_device_count": (ctypes.c_int, []),
+    "t2gpu_ldpc_create": (_vp, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "t2gpu_ldpc_destroy": (None, [_vp]),
+    "t2gpu_ldpc_configure": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "t2gpu_ldpc_info": (ctypes.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "t2gpu_ldpc_graph_stats": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _ip, _ip, _ip, _ip]),
+    "t2gpu_ldpc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libt2gpu.so once. Raises T2GpuError (never falls back) when the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise T2GpuError(
+                "%s is missing: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)"
+                % path)
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's). Import torch first so that the
+        # process holds exactly one runtime -- the one that owns the tensors whose pointers cross this ABI.
+        import torch  # noqa: F401
+        l = ctypes.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().t2gpu_last_error()
+        raise T2GpuError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

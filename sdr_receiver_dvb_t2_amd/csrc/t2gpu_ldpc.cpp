@@ -46,8 +46,10 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     int id = ldpc_code_id(fec_type, code_rate);
     if (id < 0 || max_frames < 1) { set_error("t2gpu_ldpc_create: bad arguments"); return nullptr; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-        set_error("t2gpu_ldpc_create: no such HIP device (this library has no CPU path)");
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || device < 0 || device >= ndev) {
+        set_error(std::string("t2gpu_ldpc_create: no usable HIP device (this library has no CPU path): device ") +
+                  std::to_string(device) + " of " + std::to_string(ndev) + ", hipGetDeviceCount: " + hipGetErrorString(de));
         return nullptr;
     }
     t2gpu_ldpc *h = new t2gpu_ldpc();

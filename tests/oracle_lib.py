@@ -1,0 +1,128 @@
+"""Test-side bindings of the CPU checker: oracle/liboracle.so (our C restatement), oracle/_ref/libref_ldpc.so
+(the reference's own LDPC headers compiled by oracle/Makefile, absent when never built) and the schedule emulator
+tests/emu (host replay of the kernel's schedule). TEST INFRASTRUCTURE: nothing in the product imports this."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_i8p = ctypes.POINTER(ctypes.c_int8)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+_cache = {}
+
+
+def _make_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def oracle():
+    if "ora" not in _cache:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            _make_oracle()
+        _cache["ora"] = ctypes.CDLL(path)
+    return _cache["ora"]
+
+
+def ref():
+    """The compiled reference LDPC (or None when oracle/_ref was never built on this machine)."""
+    if "ref" not in _cache:
+        path = os.path.join(ROOT, "oracle", "_ref", "libref_ldpc.so")
+        try:
+            _cache["ref"] = ctypes.CDLL(path) if os.path.exists(path) else None
+        except OSError:
+            _cache["ref"] = None
+    return _cache["ref"]
+
+
+def emu():
+    if "emu" not in _cache:
+        bdir = os.path.join(ROOT, "tests", "_build")
+        os.makedirs(bdir, exist_ok=True)
+        path = os.path.join(bdir, "libemu.so")
+        srcs = [os.path.join(ROOT, "tests", "emu", "ldpc_emu.cpp"),
+                os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "csrc", "ldpc_graph.cpp")]
+        deps = srcs + [os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "csrc", "ldpc_cn.h")]
+        if not os.path.exists(path) or any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", path] + srcs)
+        _cache["emu"] = ctypes.CDLL(path)
+    return _cache["emu"]
+
+
+def code_id(fec_type, code_rate):
+    return fec_type * 6 + code_rate
+
+
+def ldpc_params(cid):
+    n, k, q, lt = (ctypes.c_int() for _ in range(4))
+    assert oracle().ora_ldpc_params(cid, ctypes.byref(n), ctypes.byref(k), ctypes.byref(q), ctypes.byref(lt)) == 0
+    return n.value, k.value, q.value, lt.value
+
+
+def ldpc_encode(cid, info):
+    n, k, _, _ = ldpc_params(cid)
+    info = np.ascontiguousarray(info, dtype=np.uint8).reshape(-1, k)
+    cw = np.zeros((info.shape[0], n), dtype=np.uint8)
+    for b in range(info.shape[0]):
+        oracle().ora_ldpc_encode(cid, info[b].ctypes.data_as(_u8p), cw[b].ctypes.data_as(_u8p))
+    return cw
+
+
+def make_llr(cid, frames, sigma, seed, scale=8.0):
+    """Random codewords through a BPSK/AWGN channel, quantised to the int8 LLR format the demapper produces
+    (positive = bit 0). Returns (info bits, int8 LLRs)."""
+    n, k, _, _ = ldpc_params(cid)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    info = rng.integers(0, 2, size=(frames, k), dtype=np.uint8)
+    cw = ldpc_encode(cid, info)
+    y = (1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.shape)
+    llr = np.clip(np.rint(y * scale), -127, 127).astype(np.int8)
+    return info, llr
+
+
+def _decode(fn, cid, llr, trials):
+    n, k, _, _ = ldpc_params(cid)
+    llr = np.ascontiguousarray(llr, dtype=np.int8).reshape(-1, n)
+    blocks = llr.shape[0]
+    bits = np.full((blocks, k), 255, dtype=np.uint8)
+    lo = np.zeros((blocks, n), dtype=np.int8)
+    r = fn(cid, llr.ctypes.data_as(_i8p), blocks, trials, bits.ctypes.data_as(_u8p), lo.ctypes.data_as(_i8p))
+    return r, bits, lo
+
+
+def ora_decode(cid, llr, trials=25):
+    """One reference-style batch (all frames stop together). Returns (trials_left, bits[blocks][k], llr_out)."""
+    return _decode(oracle().ora_ldpc_decode, cid, llr, trials)
+
+
+def ref_decode(cid, llr, trials=25):
+    return _decode(ref().ref_ldpc_decode, cid, llr, trials)
+
+
+def emu_decode(cid, llr, trials=25):
+    n, k, _, _ = ldpc_params(cid)
+    llr = np.ascontiguousarray(llr, dtype=np.int8).reshape(-1, n)
+    blocks = llr.shape[0]
+    bits = np.full((blocks, k), 255, dtype=np.uint8)
+    lo = np.zeros((blocks, n), dtype=np.int8)
+    races = ctypes.c_int(0)
+    r = emu().emu_ldpc_decode(cid, llr.ctypes.data_as(_i8p), blocks, trials, bits.ctypes.data_as(_u8p),
+                              lo.ctypes.data_as(_i8p), ctypes.byref(races))
+    return r, bits, lo, races.value
+
+
+def ora_decode_batched(cid, llr, group=32, trials=25):
+    """Decode [frames][n] in reference batches of `group`; returns (trials_left[batches], bits, llr_out)."""
+    n, k, _, _ = ldpc_params(cid)
+    llr = np.ascontiguousarray(llr, dtype=np.int8).reshape(-1, n)
+    frames = llr.shape[0]
+    tl, bits, lo = [], np.zeros((frames, k), np.uint8), np.zeros((frames, n), np.int8)
+    for b0 in range(0, frames, group):
+        r, b, l = ora_decode(cid, llr[b0:b0 + group], trials)
+        tl.append(r)
+        lo[b0:b0 + group] = l
+        bits[b0:b0 + group] = (l[:, :k] < 0)
+    return np.array(tl, np.int32), bits, lo

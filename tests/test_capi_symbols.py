@@ -1,0 +1,69 @@
+"""CPU tier: the C-ABI library loads without a GPU, exports every function include/t2gpu.h declares, and its
+host-side graph construction agrees with the reference's table statistics. No compute entry point is called."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if fn.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", fn)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names += re.findall(r"\b(t2gpu_\w+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import sdr_receiver_dvb_t2_amd as pkg
+    from sdr_receiver_dvb_t2_amd._lib import PROTOTYPES
+    l = ctypes.CDLL(pkg.library_path())
+    decl = declared_functions()
+    assert len(decl) >= 10
+    for name in decl:
+        assert hasattr(l, name), "libt2gpu.so does not export " + name
+        assert name in PROTOTYPES, "python binding misses " + name
+    assert pkg.lib().t2gpu_version() >= 100
+
+
+def test_no_oracle_in_product_library(built):
+    """The product library must not link or embed the CPU checker."""
+    import subprocess
+    import sdr_receiver_dvb_t2_amd as pkg
+    out = subprocess.run(["nm", "-D", pkg.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "ora_" not in out and "ref_ldpc" not in out and "emu_" not in out
+    ldd = subprocess.run(["ldd", pkg.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    assert "liboracle" not in ldd and "libref" not in ldd
+
+
+# LINKS_TOTAL of the reference tables (LDPC/dvb_t2_tables.hh) and q = (N-K)/360 (ldpc_decoder.cpp:177-246)
+EXPECT = {
+    (1, 0): (226799, 90), (1, 1): (285119, 72), (1, 2): (215999, 60), (1, 3): (226799, 45), (1, 4): (233279, 36),
+    (1, 5): (237599, 30), (0, 0): (48599, 25), (0, 1): (58319, 18), (0, 2): (53999, 15), (0, 3): (47519, 12),
+    (0, 4): (44999, 10), (0, 5): (49319, 8),
+}
+
+
+@pytest.mark.parametrize("code", sorted(EXPECT))
+def test_graph_statistics(built, code):
+    import sdr_receiver_dvb_t2_amd as pkg
+    l = pkg.lib()
+    links, layers, levels, maxc = (ctypes.c_int() for _ in range(4))
+    assert l.t2gpu_ldpc_graph_stats(code[0], code[1], ctypes.byref(links), ctypes.byref(layers),
+                                    ctypes.byref(levels), ctypes.byref(maxc)) == 0
+    assert (links.value, layers.value) == EXPECT[code]
+    assert levels.value >= layers.value and 1 <= maxc.value <= 20
+
+
+def test_create_without_gpu_fails_loudly(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import sdr_receiver_dvb_t2_amd as pkg
+    with pytest.raises(pkg.T2GpuError):
+        pkg.ldpc_decoder(1, 3)

@@ -1,0 +1,123 @@
+"""GPU tier: the HIP LDPC decoder, called through the C ABI, against the CPU oracle (oracle/ldpc_oracle.c, pinned to the
+reference in test_oracle_ldpc.py). Integer work: every comparison is bit-exact -- hard bits, trials-left per SIMD batch
+and every final a-posteriori LLR."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ldpc_golden.npz"))
+CASES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _run(torch, cid, llr, group=32, trials=25, want_llr=True):
+    import sdr_receiver_dvb_t2_amd as pkg
+    dec = pkg.ldpc_decoder(cid // 6, cid % 6, max_frames=llr.shape[0], group=group, trials=trials)
+    out = dec.execute_dev(torch.from_numpy(np.ascontiguousarray(llr)).cuda(), want_llr=want_llr)
+    torch.cuda.synchronize()
+    assert dec.status() == 0
+    res = [o.cpu().numpy() if o is not None else None for o in out]
+    dec.close()
+    return res
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_vectors(torch_cuda, name):
+    """Reference-generated fixtures: one batch, frames stop together."""
+    import hashlib
+    cid = int(GOLD[name + "/cid"])
+    llr = GOLD[name + "/llr"]
+    n, k, _, _ = ol.ldpc_params(cid)
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=32)
+    assert int(trials[0]) == int(GOLD[name + "/trials_left"])
+    assert hashlib.sha256(lo.tobytes()).digest() == GOLD[name + "/llr_sha256"].tobytes()
+    assert np.array_equal(np.packbits(bits, axis=1), GOLD[name + "/hard"])
+
+
+@pytest.mark.parametrize("cid,sigma", [(9, 0.61), (8, 0.66), (0, 0.92), (6, 0.87), (11, 0.50), (3, 0.62)])
+def test_simd_batches_match_oracle(torch_cuda, cid, sigma):
+    """Several reference batches of 32 (+ a ragged last batch) in one call: per-batch trials-left and all LLRs."""
+    frames = 32 * 2 + 9
+    info, llr = ol.make_llr(cid, frames, sigma, seed=4242 + cid)
+    want_t, want_bits, want_llr = ol.ora_decode_batched(cid, llr, group=32)
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=32)
+    assert np.array_equal(trials, want_t)
+    assert np.array_equal(lo, want_llr)
+    assert np.array_equal(bits, want_bits)
+
+
+def test_non_converging_batch_is_reported(torch_cuda):
+    """One hopeless frame makes the reference drop the whole batch (-1) while its neighbours keep iterating."""
+    cid = 0
+    info, llr = ol.make_llr(cid, 64, 0.85, seed=5)
+    rng = np.random.Generator(np.random.PCG64(9))
+    llr[40] = rng.integers(-20, 20, size=llr.shape[1]).astype(np.int8)      # pure noise in batch 1
+    want_t, want_bits, want_llr = ol.ora_decode_batched(cid, llr, group=32)
+    assert want_t[0] >= 0 and want_t[1] == -1
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=32)
+    assert np.array_equal(trials, want_t)
+    assert np.array_equal(lo, want_llr)
+
+
+def test_independent_frames_group1(torch_cuda):
+    cid = 9
+    info, llr = ol.make_llr(cid, 12, 0.61, seed=31)
+    want_t, want_bits, want_llr = ol.ora_decode_batched(cid, llr, group=1)
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=1)
+    assert np.array_equal(trials, want_t)
+    assert np.array_equal(lo, want_llr)
+    assert np.array_equal(bits, info)
+
+
+def test_trial_limit_parameter(torch_cuda):
+    cid = 0
+    info, llr = ol.make_llr(cid, 32, 0.92, seed=8)
+    for trials in (0, 3, 50):
+        want_t, _, want_llr = ol.ora_decode_batched(cid, llr, group=32, trials=trials)
+        _, got_t, lo = _run(torch_cuda, cid, llr, group=32, trials=trials)
+        assert np.array_equal(got_t, want_t)
+        assert np.array_equal(lo, want_llr)
+
+
+def test_host_buffer_entry_point(torch_cuda):
+    """t2gpu_ldpc_execute: the reference-shaped call on host buffers (len_in = fec_size * 32)."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    cid = 3
+    info, llr = ol.make_llr(cid, 32, 0.60, seed=77)
+    want_t, want_bits, _ = ol.ora_decode_batched(cid, llr, group=32)
+    dec = pkg.ldpc_decoder(0, 3, max_frames=32)
+    out = dec.execute([0] * 32, llr.size, llr)
+    assert len(out) == 1 and want_t[0] >= 0
+    assert np.array_equal(out[0], want_bits)
+    dec.close()
+
+
+def test_full_size_round_trip(torch_cuda):
+    """BASELINE size (64800, r=3/4), 2048 frames: encode -> AWGN -> decode returns the sent bits and every decoded
+    frame is a codeword (re-encoding the decoded information reproduces the hard decisions of the parity LLRs)."""
+    cid = 9
+    n, k, _, _ = ol.ldpc_params(cid)
+    base_info, base_llr = ol.make_llr(cid, 64, 0.60, seed=123)
+    reps = 32
+    llr = np.tile(base_llr, (reps, 1))
+    rng = np.random.Generator(np.random.PCG64(1))
+    perm = rng.permutation(llr.shape[0])
+    llr = np.ascontiguousarray(llr[perm])
+    info = np.tile(base_info, (reps, 1))[perm]
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=32)
+    assert (trials >= 0).all()
+    assert np.array_equal(bits, info)
+    idx = rng.choice(llr.shape[0], 16, replace=False)
+    cw = ol.ldpc_encode(cid, bits[idx])
+    assert np.array_equal(cw, (lo[idx] < 0).astype(np.uint8))
