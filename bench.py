@@ -22,6 +22,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600   # LLR in + 1-bit-per-byte hard decisions out
+# Memory-side traffic of one launch, from the committed PMC passes (profiles/r01_ldpc_v3_pmc.txt, 4096 frames, ~10.4
+# sweeps per frame): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes per
+# frame. It is dominated by the 8-byte check-node records streamed once per sweep (L2 / Infinity Cache), not by LLR I/O.
+LDPC_MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 2.625e6 + 5.955e6) * 1024 / 4096
 SAMPLES_PER_FRAME = 33024.0 / (27404.0 / 8100.0)   # CFG-A: input IQ samples per FEC frame
 
 
@@ -141,7 +145,9 @@ def main():
                        "equivalent_iq_msamples_per_s": round(cw_per_s * SAMPLES_PER_FRAME / 1e6, 2),
                        "parallelism": "frame-shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": round(LDPC_MEASURED_TRAFFIC_BYTES_PER_FRAME * (hi - lo)),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_ldpc_v3_pmc.txt (bytes per launch, scaled by frames)",
                          "kernel": "ldpc_decode_kernel", "avg_launch_ms": round(avg_launch_s * 1e3, 3),
                          "note": "LDPC is LDS/VALU-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once"},
         }

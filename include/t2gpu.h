@@ -60,6 +60,10 @@ int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uin
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);
+/* diagnostics: the first call arms per-phase cycle counters inside the kernel (off by default); later calls return the
+ * sums over all workgroups of the last launch: [0] parity check, [1] batch rendezvous, [2] PLAIN, [3] PAIR, [4] GENERIC
+ * layers (shader clock cycles of wave 0). out8 may be NULL. */
+int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8);
 /* after a synchronised execute: 0 = clean, 1 = a batch rendezvous timed out (results invalid) */
 int t2gpu_ldpc_status(t2gpu_ldpc *h);
 

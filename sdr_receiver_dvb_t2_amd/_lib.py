@@ -31,6 +31,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
+    "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
 }
 
 _lib = None

@@ -1,5 +1,6 @@
-// ldpc_cn.h -- check-node arithmetic of the layered int8 offset-min-sum decoder, written once for the HIP kernel and
-// for the host-side schedule emulator in tests/ (it is arithmetic only: no memory model, no parallelism).
+// ldpc_cn.h -- check-node arithmetic and per-layer schedule of the layered int8 offset-min-sum decoder, written once
+// for the HIP kernel (ldpc_kernel.hip) and for the host-side schedule emulator in tests/emu (which replays the same
+// phases thread by thread, in adversarial thread orders, to prove the schedule is race-free and LLR-exact).
 //
 // Semantics follow the reference bit for bit:
 //   LDPCDecoder::update   /root/reference/src/DVB_T2/LDPC/layered_decoder.hh:83-110
@@ -7,15 +8,26 @@
 //   int8 primitives       LDPC/avx2.hh:379-385 (adds), :443-449 (subs), :459-465 (subs_epu8), :491-497 (vqabs),
 //                         :535-541 (vsign)
 //
-// The reference stores one int8 message per link (bnl[], 226 799 bytes for N=64800 r=3/4). Here a check node keeps
-// only what is needed to regenerate those messages exactly: the two smallest magnitudes clamped to 32, the slot of
-// the smallest, and one sign bit per link:  msg_c = sign_c ? -m : min(m, 31),  m = (c == idx ? min1 : min0),
-// which equals clamp(out_c, -32, 31) of algorithms.hh:290 because out_c = +-(mag_c == min0 ? min1 : min0) and equal
-// minima make the slot choice immaterial. The a-posteriori update uses the unclamped value, as the reference does.
+// Message storage. The reference keeps one int8 message per link (bnl[], 226 799 bytes for N=64800 r=3/4). Here a
+// check node keeps only what regenerates those messages exactly: the two smallest magnitudes clamped to 32 (A, B) and a
+// 2-bit code per link ("held the minimum", sign):   msg_c = min(31, sign_c ? -m : m),  m = ismin_c ? B : A,
+// which equals clamp(out_c, -32, 31) of algorithms.hh:290 because out_c = +-(mag_c == min0 ? min1 : min0). (A sign bit
+// set on a zero magnitude is harmless: -0 == 0.) The a-posteriori update uses the unclamped value, as the reference does.
+//
+// Order. The reference visits the 360 nodes of a layer in ascending j. Nodes sharing a bit inside a layer (ldpc_graph.h)
+// must observe that order; everything else is free. Three layer kinds:
+//   PLAIN   no shared bits: every node reads, computes, writes; one barrier.
+//   PAIR    one 360-bit group entered through two shifts s0, s1 with (s1 - s0) mod 360 = step <= 180. Node j's slot 1
+//           bit is node (j - step)'s slot 0 bit: chains j, j+step, j+2*step, ... The value handed down a chain is a
+//           scalar recurrence  X' = sat(in0 + sgn * min(E, mag(sat(X - msg1))))  -- one lane walks one chain with X in a
+//           register (no LDS round trip, no barrier per step), then all nodes finish in parallel.
+//   GENERIC anything else: dependency levels (ldpc_graph.h); per level only the conflict slots are recomputed and
+//           written, the remaining slots of every node are finished in parallel afterwards.
 #pragma once
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define T2_HD __host__ __device__ __forceinline__
 #else
 #define T2_HD inline
@@ -23,12 +35,28 @@
 
 namespace t2gpu {
 
+enum { T2_LAYER_PLAIN = 0, T2_LAYER_PAIR = 1, T2_LAYER_GENERIC = 2 };
+enum { T2_LDPC_NC_MAX = 10 };   // most conflict slots of any layer of the twelve T2 codes: 9 (short 5/6, layer 4)
+
 struct CnState {
-    uint32_t w0;   // min0c (bits 0..7) | min1c (8..15) | idx (16..23)
-    uint32_t w1;   // sign bit per link slot
+    uint32_t w0;   // 2-bit code per link slot 0..15: bit 2c = sign of the stored message, bit 2c+1 = "slot held the minimum"
+    uint32_t w1;   // codes of slots 16..21 (bits 0..11) | A = min(f(min0), 32) << 16 | B = min(f(min1), 32) << 24
 };
 
-T2_HD int t2_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// median of three. On the GPU this is pinned to one v_med3_i32: left to itself the compiler turns the int8 saturation
+// idiom into shift / 16-bit saturating op / shift (4 instructions instead of 2 per saturating add).
+T2_HD int t2_med3(int a, int b, int c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    int lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+#endif
+}
+T2_HD int t2_clamp(int v, int lo, int hi) { return t2_med3(v, lo, hi); }
 
 // Address of the information bit that node j reaches through table entry `e` (base | shift<<16).
 T2_HD int t2_link_addr(uint32_t e, int j)
@@ -38,50 +66,161 @@ T2_HD int t2_link_addr(uint32_t e, int j)
     return (int)(e & 0xffffu) + m;
 }
 
-// One check-node update. L: byte-addressable LLR store with ld(addr)/st(addr, v).
-//   CNT     information-bit links (link slots 0..CNT-1 in entry order)
-//   slot CNT   = own parity bit      pty[360*i + j]                     (always present)
-//   slot CNT+1 = previous parity bit pty[360*(i-1) + j], or pty[360*(q-1) + j - 1] for i == 0, absent for (0,0)
-template <int CNT, class LMEM>
-T2_HD void t2_cn_update(LMEM &L, const uint32_t *__restrict__ ent, int j, int a_p0, int a_p1, CnState &st)
+// f(|v|): vqabs (cap at 127) then uint8 saturating subtraction of beta = 1. Monotone, so the two smallest of f(|in_c|)
+// are f of the two smallest |in_c|: the decoder tracks raw magnitudes per link and applies f twice per node.
+T2_HD int t2_f(int a)
 {
-    constexpr int DEG = CNT + 2;
-    int addr[DEG], in[DEG], mag[DEG];
-    const int min0c = (int)(st.w0 & 0xff), min1c = (int)((st.w0 >> 8) & 0xff), idx = (int)((st.w0 >> 16) & 0xff);
-    const uint32_t signs = st.w1;
-    int m0 = 255, m1 = 255, mi = 0, sx = 0;
-#pragma unroll
-    for (int c = 0; c < DEG; ++c) {
-        int a = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0], j) : (c == CNT ? a_p0 : a_p1);
-        addr[c] = a;
-        const bool present = (c <= CNT) || (a >= 0);
-        int lc = present ? (int)L.ld(a) : 0;
-        int mm = (c == idx) ? min1c : min0c;
-        int msg = ((signs >> c) & 1u) ? -mm : (mm > 31 ? 31 : mm);
-        int v = present ? t2_clamp(lc - msg, -128, 127) : 0;      // alg.sub: saturating
-        in[c] = v;
-        int av = v < 0 ? -v : v;                                   // vqabs(max(v,-127)) then uint8 sat-sub of beta=1
-        av = av > 127 ? 127 : av;
-        av = av > 0 ? av - 1 : 0;
-        av = present ? av : 255;
-        mag[c] = av;
-        if (av < m0) { m1 = m0; m0 = av; mi = c; }
-        else if (av < m1) { m1 = av; }
-        sx ^= v;
+    a = a > 127 ? 127 : a;
+    return a > 0 ? a - 1 : 0;
+}
+
+// Per-thread registers of one check node (link slots 0..CNT-1 information bits in entry order, slot CNT own parity
+// bit pty[360*i+j], slot CNT+1 previous parity bit -- absent for node (0,0), address < 0).
+template <int CNT>
+struct CnRegs {
+    static constexpr int DEG = CNT + 2;
+    int addr[DEG], in[DEG];     // in = sat(L - old message); the absent slot holds 0
+    uint32_t lut;               // old messages by code: byte0 = min(A,31), byte1 = -A, byte2 = min(B,31), byte3 = -B
+    uint32_t c0, c1;            // old codes
+    int p0, p1, psx;            // two smallest raw magnitudes / sign xor over the non-conflict slots
+    int m0, m0f, m1f, sx;       // over all slots: raw minimum, f(min0), f(min1), sign xor
+    uint32_t n0, n1;            // new codes
+};
+
+template <int CNT>
+T2_HD bool t2_present(const CnRegs<CNT> &r, int c) { return c <= CNT || r.addr[c] >= 0; }
+
+// byte `code` (0..3) of lut, sign-extended. One v_perm_b32 on the GPU.
+T2_HD int t2_lut_byte(uint32_t lut, uint32_t code)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(int8_t)__builtin_amdgcn_perm(0u, lut, code | 0x0c0c0c00u);
+#else
+    return (int)(int8_t)((lut >> (8 * code)) & 0xffu);
+#endif
+}
+
+// message stored for slot c by the previous sweep: clamp(out_c, -32, 31) (algorithms.hh:288-291)
+template <int CNT>
+T2_HD int t2_old_msg(const CnRegs<CNT> &r, int c)
+{
+    uint32_t code = (c < 16) ? ((r.c0 >> (2 * (c & 15))) & 3u) : ((r.c1 >> (2 * (c & 15))) & 3u);
+    return t2_lut_byte(r.lut, code);
+}
+
+// (re)read slot c: in = sat(L - old message) (alg.sub), raw magnitude
+template <int CNT, class LMEM>
+T2_HD void t2_read_slot(const LMEM &L, CnRegs<CNT> &r, int c)
+{
+    const bool present = t2_present(r, c);
+    int lc = present ? (int)L.ld(r.addr[c]) : 0;
+    int v = present ? t2_clamp(lc - t2_old_msg(r, c), -128, 127) : 0;
+    r.in[c] = v;
+}
+
+// raw magnitude |in| (0..128) of slot c; 255 for the absent slot so that it never wins a minimum
+template <int CNT>
+T2_HD int t2_rawmag(const CnRegs<CNT> &r, int c)
+{
+    int v = r.in[c], nv = -v;
+    int a = v > nv ? v : nv;
+    return t2_present(r, c) ? a : 255;
+}
+
+template <int CNT, class LMEM>
+T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, int a_p0, int a_p1, const CnState &st,
+                      CnRegs<CNT> &r)
+{
+    r.c0 = st.w0; r.c1 = st.w1;
+    {
+        const int A = (int)((st.w1 >> 16) & 0xffu), B = (int)(st.w1 >> 24);
+        r.lut = (uint32_t)(A > 31 ? 31 : A) | ((uint32_t)((-A) & 0xff) << 8) | ((uint32_t)(B > 31 ? 31 : B) << 16) |
+                ((uint32_t)((-B) & 0xff) << 24);
     }
-    uint32_t nsigns = 0;
+    r.n0 = 0; r.n1 = 0;
 #pragma unroll
-    for (int c = 0; c < DEG; ++c) {
-        const bool present = (c <= CNT) || (addr[c] >= 0);
-        int other = (mag[c] == m0) ? m1 : m0;
-        bool neg = ((sx ^ in[c]) < 0);
-        int out = neg ? -other : other;
-        int ln = t2_clamp(in[c] + out, -128, 127);                 // alg.add: saturating
-        if (present) L.st(addr[c], (int8_t)ln);
-        nsigns |= ((neg && other != 0 && present) ? 1u : 0u) << c;
+    for (int c = 0; c < CNT + 2; ++c) {
+        r.addr[c] = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0], j) : (c == CNT ? a_p0 : a_p1);
+        t2_read_slot<CNT>(L, r, c);
     }
-    st.w0 = (uint32_t)(m0 > 32 ? 32 : m0) | ((uint32_t)(m1 > 32 ? 32 : m1) << 8) | ((uint32_t)mi << 16);
-    st.w1 = nsigns;
+}
+
+// second smallest of {m0 <= m1, a} is the median; smallest is the min
+T2_HD void t2_min2(int a, int &m0, int &m1)
+{
+    m1 = t2_med3(m0, m1, a);       // second smallest of (m0 <= m1, a) is their median
+    m0 = m0 < a ? m0 : a;
+}
+
+// two smallest raw magnitudes / sign xor over slots >= nc
+template <int CNT>
+T2_HD void t2_cn_partial(CnRegs<CNT> &r, int nc)
+{
+    int m0 = 255, m1 = 255, sx = 0;
+#pragma unroll
+    for (int c = 0; c < CNT + 2; ++c)
+        if (c >= nc) { t2_min2(t2_rawmag<CNT>(r, c), m0, m1); sx ^= r.in[c]; }
+    r.p0 = m0; r.p1 = m1; r.psx = sx;
+}
+
+// fold the conflict slots (< nc) into the partial result and apply f
+template <int CNT>
+T2_HD void t2_cn_merge(CnRegs<CNT> &r, int nc)
+{
+    int m0 = r.p0, m1 = r.p1, sx = r.psx;
+#pragma unroll
+    for (int c = 0; c < T2_LDPC_NC_MAX; ++c)
+        if (c < CNT && c < nc) { t2_min2(t2_rawmag<CNT>(r, c), m0, m1); sx ^= r.in[c]; }
+    r.m0 = m0; r.m0f = t2_f(m0); r.m1f = t2_f(m1); r.sx = sx;
+}
+
+// output of slot c, a-posteriori update L = sat(in + out) (alg.add), sign / is-min bits of the new message.
+// `other` = (mag_c == min0 ? min1 : min0) on f-values equals the same selection on raw magnitudes (see t2_f).
+template <int CNT, class LMEM>
+T2_HD void t2_write_slot(LMEM &L, CnRegs<CNT> &r, int c, bool store)
+{
+    const bool present = t2_present(r, c);
+    const bool eq = present && (r.in[c] == r.m0 || r.in[c] == -r.m0);    // |in_c| == raw minimum
+    int other = eq ? r.m1f : r.m0f;
+    int sm = (r.sx ^ r.in[c]) >> 31;                 // 0 / -1: sign of the product of the other inputs
+    int out = (other ^ sm) - sm;
+    int ln = t2_clamp(r.in[c] + out, -128, 127);
+    if (present && store) L.st(r.addr[c], (int8_t)ln);
+    if (c < 16) r.n0 |= ((uint32_t)sm & (1u << (2 * (c & 15)))) | (eq ? (2u << (2 * (c & 15))) : 0u);
+    else r.n1 |= ((uint32_t)sm & (1u << (2 * (c & 15)))) | (eq ? (2u << (2 * (c & 15))) : 0u);
+}
+
+template <int CNT>
+T2_HD void t2_cn_pack(const CnRegs<CNT> &r, CnState &st)
+{
+    st.w0 = r.n0;
+    st.w1 = (r.n1 & 0xfffu) | ((uint32_t)(r.m0f > 32 ? 32 : r.m0f) << 16) | ((uint32_t)(r.m1f > 32 ? 32 : r.m1f) << 24);
+}
+
+// ---- PAIR layers -------------------------------------------------------------------------------------------------
+// Record a chain walker needs from a node that has both a predecessor and a successor:
+//   byte0 msg1 (old message of slot 1), byte1 cap = min(126, f(E)) with E the smallest raw magnitude of the slots other
+//   than 0 and 1, byte2 in0 (input of slot 0), bit 24 = sign parity of those other slots.
+template <int CNT>
+T2_HD uint32_t t2_pair_record(const CnRegs<CNT> &r)
+{
+    int cap = t2_f(r.p0);
+    return (uint32_t)(t2_old_msg(r, 1) & 0xff) | ((uint32_t)cap << 8) | ((uint32_t)(r.in[0] & 0xff) << 16) |
+           ((r.psx < 0) ? (1u << 24) : 0u);
+}
+
+// One step down a chain. X = LLR of the shared bit after the predecessor; returns it after this node:
+//   X' = sat(in0 + s * min(f(E), f(|sat(X - msg1)|))),  s = sign parity of the others * sign(X - msg1).
+// f(|sat(u)|) = med3(|u| - 1, 0, 126) also without the saturation (|u| <= 160), so the chain is sub, max, med3, sign, add, sat.
+T2_HD int t2_pair_step(uint32_t rec, int X)
+{
+    const int msg1 = (int)(int8_t)(rec & 0xff), cap = (int)((rec >> 8) & 0xff), in0 = (int)(int8_t)((rec >> 16) & 0xff);
+    const int psm = -(int)((rec >> 24) & 1u);           // 0 / -1
+    const int u = X - msg1;
+    const int a1 = (u > -u ? u : -u) - 1;
+    const int t = t2_clamp(a1, 0, cap);
+    const int sm = (u >> 31) ^ psm;
+    return t2_clamp(in0 + ((t ^ sm) - sm), -128, 127);
 }
 
 // Parity check of node j on the current LLRs (LDPCDecoder::bad, layered_decoder.hh:65-82): the node is bad when
@@ -103,20 +242,121 @@ T2_HD bool t2_cn_bad(const LMEM &L, const uint32_t *__restrict__ ent, int j, int
     return zero || (sx < 0);
 }
 
+// ---- one layer, phase by phase ------------------------------------------------------------------------------------
+// `SYNC` provides barrier(): the HIP kernel passes the workgroup barrier, the emulator records an epoch boundary and is
+// driven phase by phase instead (see tests/emu). Every thread of the workgroup calls these in the same order.
+struct LayerDesc {
+    const uint32_t *ent;
+    int cnt, lmax, nc, kind, step;
+};
+
+// phase A: every node loads; PLAIN nodes and chain-start / level-free nodes finish at once
+template <int CNT, class LMEM>
+T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_p1, CnState &st, CnRegs<CNT> &r,
+                            uint32_t *pair_rec)
+{
+    t2_cn_load<CNT>(L, d.ent, j, a_p0, a_p1, st, r);
+    if (d.kind == T2_LAYER_PLAIN) {
+        t2_cn_partial<CNT>(r, 0);
+        r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;
+#pragma unroll
+        for (int c = 0; c < CNT + 2; ++c) t2_write_slot<CNT>(L, r, c, true);
+        t2_cn_pack<CNT>(r, st);
+    } else if (d.kind == T2_LAYER_PAIR) {
+        t2_cn_partial<CNT>(r, 2);
+        if (j < d.step) {                       // chain start: nothing earlier touches its bits
+            t2_cn_merge<CNT>(r, 2);
+#pragma unroll
+            for (int c = 0; c < CNT + 2; ++c) t2_write_slot<CNT>(L, r, c, true);
+            t2_cn_pack<CNT>(r, st);
+        } else {
+            pair_rec[j] = t2_pair_record<CNT>(r);
+        }
+    } else {
+        t2_cn_partial<CNT>(r, d.nc);
+    }
+}
+
+// PAIR phase B: lane `lane` < step walks chain lane, lane+step, ... (all nodes that have a successor). Records are
+// fetched four steps ahead so that only the scalar recurrence (X in a register) is on the critical path.
+template <class LMEM>
+T2_HD void t2_pair_walk(LMEM &L, const LayerDesc &d, int lane, const uint32_t *pair_rec)
+{
+    const uint32_t e0 = d.ent[0];
+    const int base = (int)(e0 & 0xffffu), s0 = (int)(e0 >> 16), step = d.step;
+    int m = lane - s0;                                   // position of the shared bit inside its 360-bit group
+    m += (m < 0) ? 360 : 0;
+    int X = (int)L.ld(base + m);
+    for (int jj = lane + step; jj + step < 360; jj += 4 * step) {
+        uint32_t rec[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rec[u] = (jj + (u + 1) * step < 360) ? pair_rec[jj + u * step] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jj + (u + 1) * step < 360) {
+                m += step;
+                m -= (m >= 360) ? 360 : 0;
+                X = t2_pair_step(rec[u], X);
+                L.st(base + m, (int8_t)X);
+            }
+        }
+    }
+}
+
+// PAIR phase C: every node that is not a chain start finishes (slot 1 always re-read, slot 0 when it is a chain end)
+template <int CNT, class LMEM>
+T2_HD void t2_pair_finish(LMEM &L, const LayerDesc &d, int j, CnState &st, CnRegs<CNT> &r)
+{
+    if (j < d.step) return;
+    const bool has_succ = j + d.step < 360;
+    t2_read_slot<CNT>(L, r, 1);
+    if (!has_succ) t2_read_slot<CNT>(L, r, 0);
+    t2_cn_merge<CNT>(r, 2);
+#pragma unroll
+    for (int c = 0; c < CNT + 2; ++c) t2_write_slot<CNT>(L, r, c, !(c == 0 && has_succ));
+    t2_cn_pack<CNT>(r, st);
+}
+
+// GENERIC level step lv (1-based): nodes of that level settle their conflict slots. All conflict slots are re-read
+// (batched, branch-free): a slot nobody touched earlier still holds the value read in phase A.
+template <int CNT, class LMEM>
+T2_HD void t2_generic_level(LMEM &L, const LayerDesc &d, int lv, uint32_t info, CnRegs<CNT> &r)
+{
+    if ((int)(info & 0xff) != lv) return;
+    if (lv > 1) {
+#pragma unroll
+        for (int c = 0; c < T2_LDPC_NC_MAX; ++c)
+            if (c < CNT && c < d.nc) t2_read_slot<CNT>(L, r, c);
+    }
+    t2_cn_merge<CNT>(r, d.nc);
+#pragma unroll
+    for (int c = 0; c < T2_LDPC_NC_MAX; ++c)
+        if (c < CNT && c < d.nc) t2_write_slot<CNT>(L, r, c, true);
+}
+
+// GENERIC last phase: the private slots
+template <int CNT, class LMEM>
+T2_HD void t2_generic_finish(LMEM &L, const LayerDesc &d, CnState &st, CnRegs<CNT> &r)
+{
+#pragma unroll
+    for (int c = 0; c < CNT + 2; ++c)
+        if (c >= d.nc) t2_write_slot<CNT>(L, r, c, true);
+    t2_cn_pack<CNT>(r, st);
+}
+
 // Dispatch a runtime per-layer link count to the unrolled instance. Counts present in the twelve T2 codes: 2..20.
-#define T2_LDPC_DISPATCH_CNT(cnt, CALL)                                                                         \
+// LO/HI (compile-time) restrict the instances a kernel variant carries, so register allocation and code size follow
+// the code family actually being decoded.
+#define T2_CASE_(n, LO, HI, CALL) case n: if constexpr ((LO) <= n && n <= (HI)) { constexpr int CNT = n; CALL; } break;
+#define T2_LDPC_DISPATCH_RANGE(cnt, LO, HI, CALL)                                                               \
     switch (cnt) {                                                                                              \
-    case 1: { constexpr int CNT = 1; CALL; } break;   case 2: { constexpr int CNT = 2; CALL; } break;           \
-    case 3: { constexpr int CNT = 3; CALL; } break;   case 4: { constexpr int CNT = 4; CALL; } break;           \
-    case 5: { constexpr int CNT = 5; CALL; } break;   case 6: { constexpr int CNT = 6; CALL; } break;           \
-    case 7: { constexpr int CNT = 7; CALL; } break;   case 8: { constexpr int CNT = 8; CALL; } break;           \
-    case 9: { constexpr int CNT = 9; CALL; } break;   case 10: { constexpr int CNT = 10; CALL; } break;         \
-    case 11: { constexpr int CNT = 11; CALL; } break; case 12: { constexpr int CNT = 12; CALL; } break;         \
-    case 13: { constexpr int CNT = 13; CALL; } break; case 14: { constexpr int CNT = 14; CALL; } break;         \
-    case 15: { constexpr int CNT = 15; CALL; } break; case 16: { constexpr int CNT = 16; CALL; } break;         \
-    case 17: { constexpr int CNT = 17; CALL; } break; case 18: { constexpr int CNT = 18; CALL; } break;         \
-    case 19: { constexpr int CNT = 19; CALL; } break; case 20: { constexpr int CNT = 20; CALL; } break;         \
+        T2_CASE_(1, LO, HI, CALL) T2_CASE_(2, LO, HI, CALL) T2_CASE_(3, LO, HI, CALL) T2_CASE_(4, LO, HI, CALL)     \
+        T2_CASE_(5, LO, HI, CALL) T2_CASE_(6, LO, HI, CALL) T2_CASE_(7, LO, HI, CALL) T2_CASE_(8, LO, HI, CALL)     \
+        T2_CASE_(9, LO, HI, CALL) T2_CASE_(10, LO, HI, CALL) T2_CASE_(11, LO, HI, CALL) T2_CASE_(12, LO, HI, CALL)  \
+        T2_CASE_(13, LO, HI, CALL) T2_CASE_(14, LO, HI, CALL) T2_CASE_(15, LO, HI, CALL) T2_CASE_(16, LO, HI, CALL) \
+        T2_CASE_(17, LO, HI, CALL) T2_CASE_(18, LO, HI, CALL) T2_CASE_(19, LO, HI, CALL) T2_CASE_(20, LO, HI, CALL) \
     default: break;                                                                                             \
     }
+#define T2_LDPC_DISPATCH_CNT(cnt, CALL) T2_LDPC_DISPATCH_RANGE(cnt, 1, 20, CALL)
 
 }  // namespace t2gpu

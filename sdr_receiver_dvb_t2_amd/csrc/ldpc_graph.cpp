@@ -1,5 +1,6 @@
 // ldpc_graph.cpp -- see ldpc_graph.h. Pure host code (no HIP), also compiled into the schedule emulator of tests/.
 #include "ldpc_graph.h"
+#include "ldpc_cn.h"
 #include "tables/ldpc_tables_data.h"
 #include <algorithm>
 #include <map>
@@ -28,6 +29,7 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
 
     g.layers.resize(g.q);
     g.levels.assign((size_t)g.q * GROUP, 1);
+    g.cninfo.assign((size_t)g.q * GROUP, 1);
     for (int i = 0; i < g.q; ++i) {
         std::vector<Ent> &ents = per_layer[i];
         std::map<int, int> mult;
@@ -43,31 +45,43 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
         L.first_entry = (int)g.entries.size();
         L.cnt = (int)ents.size();
         L.n_conflict = 0;
-        for (const Ent &e : ents) {
+        for (const Ent &e : ents)
             if (mult[e.group] > 1) L.n_conflict++;
-            g.entries.push_back((uint32_t)(e.group * GROUP) | ((uint32_t)e.shift << 16));
+        L.kind = L.n_conflict == 0 ? T2_LAYER_PLAIN : (L.n_conflict == 2 ? T2_LAYER_PAIR : T2_LAYER_GENERIC);
+        L.step = 0;
+        if (L.kind == T2_LAYER_PAIR) {
+            // slot 0 = the shift whose bit is shared with the LATER node j+step, slot 1 = with the earlier j-step
+            int d = ents[1].shift - ents[0].shift;          // sorted: > 0
+            if (d > 180) { std::swap(ents[0], ents[1]); d = 360 - d; }
+            L.step = d;
         }
+        for (const Ent &e : ents) g.entries.push_back((uint32_t)(e.group * GROUP) | ((uint32_t)e.shift << 16));
         g.max_cnt = std::max(g.max_cnt, L.cnt);
+        g.min_cnt = std::min(g.min_cnt, L.cnt);
         // dependency levels: node j depends on every earlier node sharing one of its bits
         uint8_t *lev = &g.levels[(size_t)i * GROUP];
         int lmax = 1;
         if (L.n_conflict) {
             for (int j = 0; j < GROUP; ++j) {
                 int lv = 1;
+                uint32_t dep = 0;
                 for (int x = 0; x < L.n_conflict; ++x)
                     for (int y = 0; y < L.n_conflict; ++y) {
                         if (x == y || ents[x].group != ents[y].group) continue;
                         // node j reaches bit m through entry x; the same bit reaches node j2 through entry y
                         int m = ((j - ents[x].shift) % GROUP + GROUP) % GROUP;
                         int j2 = (ents[y].shift + m) % GROUP;
-                        if (j2 < j) lv = std::max(lv, lev[j2] + 1);
+                        if (j2 < j) { lv = std::max(lv, lev[j2] + 1); dep |= 1u << x; }
                     }
                 lev[j] = (uint8_t)lv;
+                g.cninfo[(size_t)i * GROUP + j] = (uint32_t)lv | (dep << 8);
                 lmax = std::max(lmax, lv);
             }
         }
         L.lmax = lmax;
         g.total_levels += lmax;
+        if (L.kind == T2_LAYER_PAIR) g.serial_steps += std::max(0, (GROUP - 1) / L.step - 1);
+        else if (L.kind == T2_LAYER_GENERIC) g.serial_steps += lmax;
         g.links_total += GROUP * (L.cnt + 2) - (i == 0 ? 1 : 0);
     }
     return true;

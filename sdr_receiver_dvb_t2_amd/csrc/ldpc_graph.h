@@ -22,16 +22,20 @@ struct LdpcLayer {
     int cnt;           // information-bit links per node in this layer (reference: cnc[i])
     int lmax;          // number of dependency levels (1 = conflict-free layer)
     int n_conflict;    // leading entries that belong to a group appearing more than once in this layer
+    int kind;          // T2_LAYER_PLAIN / PAIR / GENERIC (ldpc_cn.h)
+    int step;          // PAIR: (shift of slot 1 - shift of slot 0) mod 360, 1..180
 };
 
 struct LdpcGraph {
     int id = -1, n = 0, k = 0, r = 0, q = 0;
-    int max_cnt = 0;
+    int max_cnt = 0, min_cnt = 1 << 30;
     int links_total = 0;
     int total_levels = 0;
     std::vector<LdpcLayer> layers;     // [q]
     std::vector<uint32_t> entries;     // packed: base (bits 0..15) | shift (bits 16..24)
     std::vector<uint8_t> levels;       // [q*360], values 1..lmax
+    std::vector<uint32_t> cninfo;      // [q*360]: level (bits 0..7) | dependent-conflict-slot mask << 8 (GENERIC layers)
+    int serial_steps = 0;              // sum over layers of sequential steps a sweep needs (chain walks + level steps)
 };
 
 // fec_type / code_rate use the reference enums (dvbt2_definition.h:60-67,85-88): fec_type 0 = short (16200),

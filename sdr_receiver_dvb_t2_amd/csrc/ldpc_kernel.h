@@ -8,7 +8,7 @@
 namespace t2gpu {
 
 struct LdpcLayerDev {
-    int first_entry, cnt, lmax, n_conflict;
+    int first_entry, cnt, lmax, nc, kind, step, pad0, pad1;
 };
 
 struct LdpcKernelParams {
@@ -16,7 +16,7 @@ struct LdpcKernelParams {
     int n, k, q;
     const LdpcLayerDev *layers;   // [q]
     const uint32_t *entries;      // packed base | shift<<16
-    const uint8_t *levels;        // [q*360]
+    const uint32_t *cninfo;       // [q*360] level | dependent-slot mask << 8 (GENERIC layers)
     // job
     const int8_t *llr;            // [n_frames][n] received LLRs, transmitted order
     int n_frames;
@@ -31,9 +31,12 @@ struct LdpcKernelParams {
     int *error;                   // zeroed before launch; 1 = batch rendezvous timed out
     long long spin_timeout_ticks; // wall_clock64 ticks (100 MHz)
     int lds_ctl_offset;           // byte offset of the control words behind the LLR array
+    int lds_rec_offset;           // byte offset of the 360 chain-walk records (PAIR layers)
+    int lds_sign_offset;          // byte offset of the packed sign words (13 dwords per 360-bit group)
+    long long *prof;              // optional [grid][8] cycle counters (diagnostics; null in production)
 };
 
-hipError_t ldpc_kernel_attributes(int lds_bytes, int *blocks_per_cu);
-hipError_t ldpc_kernel_launch(const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);
+hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu);
+hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);
 
 }  // namespace t2gpu

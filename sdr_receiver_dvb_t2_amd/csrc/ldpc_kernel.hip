@@ -9,9 +9,9 @@
 //   * thread j owns check node (i, j) of every layer i: a wavefront of consecutive j reads/writes consecutive LLR
 //     bytes of a 360-bit group (quasi-cyclic shift) -> conflict-free ds_read_u8 / ds_write_b8;
 //   * the per-link messages of the reference (226 799 bytes) are replaced by an 8-byte record per check node
-//     (ldpc_cn.h) that streams through L2, coalesced;
-//   * layers whose nodes share bits are executed level by level (ldpc_graph.h) so every node sees exactly the LLRs
-//     the reference's sequential j loop would show it: results are LLR-exact, not merely codeword-exact;
+//     (ldpc_cn.h) that streams through L2, coalesced, prefetched one layer ahead and never waited for at a barrier;
+//   * layers whose nodes share bits keep the reference's ascending-j order exactly (ldpc_cn.h: PAIR chains walked in
+//     registers, GENERIC levels): results are LLR-exact, not merely codeword-exact;
 //   * the reference decodes SIMD batches of 32 frames that stop together (all 32 parity-clean, or 25 updates). The
 //     32 workgroups of such a batch are co-resident (persistent grid) and agree on every stop decision through one
 //     atomic word per (batch, trial).
@@ -30,17 +30,132 @@ struct LdsMem {
 
 static constexpr int kThreads = T2GPU_LDPC_THREADS;   // 6 wavefronts; 360 of 384 lanes own a check node
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() would also drain the vector-memory queue
+// (s_waitcnt vmcnt(0)) and so expose the L2 round trip of the record loads/stores at every layer; those records are
+// private to one thread, nothing another wave reads, so they may stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int parity_prev_addr(int k, int q, int i, int j)
 {
     if (i > 0) return k + 360 * (i - 1) + j;
     return j > 0 ? k + 360 * (q - 1) + j - 1 : -1;
 }
 
-__global__ __launch_bounds__(kThreads) void ldpc_decode_kernel(LdpcKernelParams p)
+// ---- bit-parallel parity check (LDPCDecoder::bad, layered_decoder.hh:65-82) ------------------------------------------
+// The sign bits of all N LLRs are packed, 360-bit group by 360-bit group, into 13 dwords per group: bits 0..359 of the
+// group, followed by a copy of bits 0..55 (so any 32-bit window starting at bit m < 360 can be read without wrapping).
+// The 360 parity checks of a layer are then the XOR of 32-bit windows -- one per table entry, shifted by the entry's
+// shift -- plus the two parity-bit windows: 32 check nodes per lane per XOR instead of one. A frame is also bad when
+// any LLR is exactly zero (vsign zeroes the product), detected on the packed bytes while building the sign words.
+__device__ __forceinline__ uint32_t sign_nibble(uint32_t v)
+{
+    uint32_t t = (v >> 7) & 0x01010101u;
+    t |= t >> 7;
+    t |= t >> 14;
+    return t & 0xfu;
+}
+__device__ __forceinline__ uint32_t has_zero_byte(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+
+__device__ __forceinline__ uint32_t sign_window(const uint32_t *S2, int g, int m)
+{
+    const uint32_t *w = S2 + g * 13 + (m >> 5);
+    return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)(m & 31));
+}
+
+// returns nonzero (per thread) if this thread saw a zero LLR or a failing check
+__device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, const LdpcLayerDev *__restrict__ layers,
+                                                const uint32_t *__restrict__ entries, int n, int k, int q, int tid)
+{
+    const int ngroups = n / 360;
+    uint32_t zero = 0;
+    for (int task = tid; task < ngroups * 12; task += kThreads) {
+        const int g = task / 12, kk = task - g * 12;
+        const uint2 *src = reinterpret_cast<const uint2 *>(Lm + g * 360 + 32 * kk);
+        const int nb = (kk == 11) ? 1 : 4;          // dword 11 holds only bits 352..359
+        uint32_t word = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (x < nb) {
+                uint2 v = src[x];
+                zero |= has_zero_byte(v.x) | has_zero_byte(v.y);
+                word |= (sign_nibble(v.x) | (sign_nibble(v.y) << 4)) << (8 * x);
+            }
+        S2[g * 13 + kk] = word;
+    }
+    lds_barrier();
+    for (int g = tid; g < ngroups; g += kThreads) {
+        const uint32_t d0 = S2[g * 13], d1 = S2[g * 13 + 1];
+        S2[g * 13 + 11] |= d0 << 8;
+        S2[g * 13 + 12] = (d0 >> 24) | (d1 << 8);
+    }
+    lds_barrier();
+    uint32_t bad = zero;
+    const int gp0 = k / 360;
+    for (int task = tid; task < q * 12; task += kThreads) {
+        const int i = task / 12, tj = task - i * 12, j0 = 32 * tj;
+        const LdpcLayerDev ly = layers[i];
+        const uint32_t *ent = entries + ly.first_entry;
+        uint32_t syn = S2[(gp0 + i) * 13 + tj];                                   // own parity bits pty[360*i + j]
+        if (i > 0) syn ^= S2[(gp0 + i - 1) * 13 + tj];                            // pty[360*(i-1) + j]
+        else syn ^= (tj == 0) ? (S2[(gp0 + q - 1) * 13] << 1)                     // pty[360*(q-1) + j - 1], none for j = 0
+                              : sign_window(S2, gp0 + q - 1, j0 - 1);
+        for (int c = 0; c < ly.cnt; ++c) {
+            const uint32_t e = ent[c];
+            const int g = (int)__umulhi(e & 0xffffu, 11930465u);                 // base / 360 (base is a multiple of 360)
+            int m = j0 - (int)(e >> 16);
+            m += (m < 0) ? 360 : 0;
+            syn ^= sign_window(S2, g, m);
+        }
+        bad |= syn & ((tj == 11) ? 0xffu : 0xffffffffu);
+    }
+    return bad != 0;
+}
+
+template <int CNT>
+__device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int j, bool active, int a0, int a1,
+                                             CnState &st, uint32_t info, uint32_t *pair_rec)
+{
+    CnRegs<CNT> r;
+    if (active) t2_layer_phase_a<CNT>(L, d, j, a0, a1, st, r, pair_rec);
+    // The sequential parts (chain walks, level steps) keep only a few lanes busy and sit on the workgroup's critical
+    // path while the co-resident workgroup is usually in a throughput phase: give them issue priority.
+    if (d.kind == T2_LAYER_PAIR) {
+        lds_barrier();
+        __builtin_amdgcn_s_setprio(3);
+        if (j < d.step) t2_pair_walk(L, d, j, pair_rec);
+        __builtin_amdgcn_s_setprio(0);
+        lds_barrier();
+        if (active) t2_pair_finish<CNT>(L, d, j, st, r);
+    } else if (d.kind == T2_LAYER_GENERIC) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int lv = 1; lv <= d.lmax; ++lv) {
+            if (active) t2_generic_level<CNT>(L, d, lv, info, r);
+            lds_barrier();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (active) t2_generic_finish<CNT>(L, d, st, r);
+    }
+    lds_barrier();
+}
+
+#define T2_PROF_T(var) long long var = p.prof ? (long long)__builtin_readcyclecounter() : 0
+#define T2_PROF_ADD(slot, t0)                                                                                   \
+    do {                                                                                                        \
+        if (p.prof && threadIdx.x == 0) p.prof[blockIdx.x * 8 + (slot)] += (long long)__builtin_readcyclecounter() - (t0); \
+    } while (0)
+
+template <int LO, int HI>
+__global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
+                                                                  const uint32_t *__restrict__ cninfo, LdpcKernelParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *Lm = lds;
     int *s_ctl = reinterpret_cast<int *>(lds + p.lds_ctl_offset);
+    uint32_t *pair_rec = reinterpret_cast<uint32_t *>(lds + p.lds_rec_offset);
+    uint32_t *S2 = reinterpret_cast<uint32_t *>(lds + p.lds_sign_offset);
     LdsMem L{Lm};
 
     const int tid = threadIdx.x;
@@ -52,6 +167,7 @@ __global__ __launch_bounds__(kThreads) void ldpc_decode_kernel(LdpcKernelParams 
     const int nbatches = (p.n_frames + group - 1) / group;
     uint2 *state = p.state + (size_t)blockIdx.x * p.q * 360;
 
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 6] = wall_clock64();
     for (int batch = slot; batch < nbatches; batch += nslots) {
         const int frame = batch * group + member;
         const bool have = frame < p.n_frames;
@@ -71,17 +187,12 @@ __global__ __launch_bounds__(kThreads) void ldpc_decode_kernel(LdpcKernelParams 
         int result;
         for (int t = 0;; ++t) {
             // ---- parity check of the whole frame (LDPCDecoder::bad)
-            int bad = 0;
-            if (have && active) {
-                for (int i = 0; i < p.q && !bad; ++i) {
-                    const LdpcLayerDev ly = p.layers[i];
-                    const uint32_t *ent = p.entries + ly.first_entry;
-                    const int a0 = p.k + 360 * i + j, a1 = parity_prev_addr(p.k, p.q, i, j);
-                    T2_LDPC_DISPATCH_CNT(ly.cnt, bad = t2_cn_bad<CNT>(L, ent, j, a0, a1));
-                }
-            }
+            T2_PROF_T(tp0);
+            int bad = have ? frame_parity_bad(Lm, S2, layers, entries, p.n, p.k, p.q, tid) : 0;
             int frame_bad = __syncthreads_or(bad);
             int all_ok = !frame_bad;
+            T2_PROF_ADD(0, tp0);
+            T2_PROF_T(tp1);
             if (group > 1 && have) {
                 // one word per (batch, trial): high half counts arrivals, low half counts parity-clean frames
                 if (tid == 0) {
@@ -108,27 +219,27 @@ __global__ __launch_bounds__(kThreads) void ldpc_decode_kernel(LdpcKernelParams 
                 if (verdict < 0) { result = -3; break; }   // sync failure: reported through p.error
                 all_ok = verdict;
             }
+            T2_PROF_ADD(1, tp1);
             if (all_ok) { result = trials; break; }
             if (--trials < 0) { result = -1; break; }
 
             // ---- one layered update sweep (LDPCDecoder::update)
             if (have) {
+                uint2 nxt = active ? state[j] : make_uint2(0u, 0u);
                 for (int i = 0; i < p.q; ++i) {
-                    const LdpcLayerDev ly = p.layers[i];
-                    const uint32_t *ent = p.entries + ly.first_entry;
+                    const LdpcLayerDev ly = layers[i];
+                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step};
                     const int a0 = p.k + 360 * i + j, a1 = parity_prev_addr(p.k, p.q, i, j);
-                    const int lvl = active ? (ly.lmax > 1 ? (int)p.levels[i * 360 + j] : 1) : 0;
-                    for (int lv = 1; lv <= ly.lmax; ++lv) {
-                        if (lvl == lv) {
-                            uint2 raw = state[i * 360 + j];
-                            CnState st{raw.x, raw.y};
-                            T2_LDPC_DISPATCH_CNT(ly.cnt, t2_cn_update<CNT>(L, ent, j, a0, a1, st));
-                            state[i * 360 + j] = make_uint2(st.w0, st.w1);
-                        }
-                        __syncthreads();
-                    }
+                    CnState st{nxt.x, nxt.y};
+                    if (active && i + 1 < p.q) nxt = state[(i + 1) * 360 + j];      // prefetch the next layer's record
+                    const uint32_t info = (active && ly.kind == T2_LAYER_GENERIC) ? cninfo[i * 360 + j] : 0u;
+                    T2_PROF_T(tp2);
+                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, layer_update<CNT>(L, d, j, active, a0, a1, st, info, pair_rec));
+                    T2_PROF_ADD(2 + ly.kind, tp2);
+                    if (active) state[i * 360 + j] = make_uint2(st.w0, st.w1);
                 }
             }
+            __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep
         }
 
         // ---- outputs: hard decision of the information bits (ldpc_decoder.cpp:270-277), one bit per byte
@@ -148,19 +259,43 @@ __global__ __launch_bounds__(kThreads) void ldpc_decode_kernel(LdpcKernelParams 
         }
         __syncthreads();
     }
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 7] = wall_clock64();
 }
 
-hipError_t ldpc_kernel_attributes(int lds_bytes, int *blocks_per_cu)
+// Kernel variants by range of information-bit links per check node: the twelve T2 codes fall into four families.
+typedef void (*ldpc_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, LdpcKernelParams);
+static ldpc_kernel_fn pick_kernel(int min_cnt, int max_cnt)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ldpc_decode_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (min_cnt == max_cnt) {      // the six normal-frame codes have one link count each
+        switch (max_cnt) {
+        case 5: return ldpc_decode_kernel<5, 5>;
+        case 8: return ldpc_decode_kernel<8, 8>;
+        case 9: return ldpc_decode_kernel<9, 9>;
+        case 12: return ldpc_decode_kernel<12, 12>;
+        case 16: return ldpc_decode_kernel<16, 16>;
+        case 20: return ldpc_decode_kernel<20, 20>;
+        default: break;
+        }
+    }
+    if (max_cnt <= 8) return ldpc_decode_kernel<1, 8>;
+    if (min_cnt >= 7 && max_cnt <= 12) return ldpc_decode_kernel<7, 12>;
+    if (min_cnt >= 13 && max_cnt <= 17) return ldpc_decode_kernel<13, 17>;
+    if (min_cnt >= 16 && max_cnt <= 20) return ldpc_decode_kernel<16, 20>;
+    return ldpc_decode_kernel<1, 20>;
+}
+
+hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu)
+{
+    ldpc_kernel_fn fn = pick_kernel(min_cnt, max_cnt);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, ldpc_decode_kernel, kThreads, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads, lds_bytes);
 }
 
-hipError_t ldpc_kernel_launch(const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
+hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ldpc_decode_kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
+    ldpc_kernel_fn fn = pick_kernel(min_cnt, max_cnt);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes, stream, p.layers, p.entries, p.cninfo, p);
     return hipGetLastError();
 }
 

@@ -11,15 +11,16 @@ using namespace t2gpu;
 struct t2gpu_ldpc {
     LdpcGraph g;
     int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
-    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0;
+    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0;
     LdpcLayerDev *d_layers = nullptr;
     uint32_t *d_entries = nullptr;
-    uint8_t *d_levels = nullptr;
+    uint32_t *d_cninfo = nullptr;
     uint2 *d_state = nullptr;
     size_t state_blocks = 0;
     unsigned *d_sync = nullptr;
     size_t sync_words = 0;
     int *d_error = nullptr;
+    long long *d_prof = nullptr;   // diagnostics, allocated by t2gpu_ldpc_profile()
     // host-call staging
     int8_t *d_in = nullptr;
     uint8_t *d_out = nullptr;
@@ -66,19 +67,22 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     h->num_cu = prop.multiProcessorCount;
     h->lds_ctl_offset = (h->g.n + 15) & ~15;
-    h->lds_bytes = h->lds_ctl_offset + 64;
-    if ((e = ldpc_kernel_attributes(h->lds_bytes, &h->blocks_per_cu)) != hipSuccess) return fail("kernel attributes", e);
+    h->lds_rec_offset = h->lds_ctl_offset + 64;
+    h->lds_sign_offset = h->lds_rec_offset + 360 * 4;
+    h->lds_bytes = h->lds_sign_offset + (h->g.n / 360) * 13 * 4;
+    if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu)) != hipSuccess) return fail("kernel attributes", e);
     if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
 
     std::vector<LdpcLayerDev> ld(h->g.q);
     for (int i = 0; i < h->g.q; ++i)
-        ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict};
+        ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict,
+                             h->g.layers[i].kind, h->g.layers[i].step, 0, 0};
     if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_entries, h->g.entries.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipMalloc(&h->d_levels, h->g.levels.size())) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemcpy(h->d_layers, ld.data(), ld.size() * sizeof(LdpcLayerDev), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
     if ((e = hipMemcpy(h->d_entries, h->g.entries.data(), h->g.entries.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
-    if ((e = hipMemcpy(h->d_levels, h->g.levels.data(), h->g.levels.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    if ((e = hipMemcpy(h->d_cninfo, h->g.cninfo.data(), h->g.cninfo.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
 
     h->state_blocks = (size_t)resident_blocks(h);
     if ((e = hipMalloc(&h->d_state, h->state_blocks * h->g.q * 360 * sizeof(uint2))) != hipSuccess) return fail("hipMalloc state", e);
@@ -91,8 +95,8 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
-    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_levels); hipFree(h->d_state);
-    hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
+    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_cninfo); hipFree(h->d_state);
+    hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     delete h;
 }
 
@@ -134,13 +138,48 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
-    p.layers = h->d_layers; p.entries = h->d_entries; p.levels = h->d_levels;
+    p.layers = h->d_layers; p.entries = h->d_entries; p.cninfo = h->d_cninfo;
     p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
     p.state = h->d_state; p.sync = h->d_sync; p.error = h->d_error;
     p.spin_timeout_ticks = 200000000LL;   // 2 s at 100 MHz
     p.lds_ctl_offset = h->lds_ctl_offset;
-    T2_HIP(ldpc_kernel_launch(p, grid, h->lds_bytes, s));
+    p.lds_rec_offset = h->lds_rec_offset;
+    p.lds_sign_offset = h->lds_sign_offset;
+    p.prof = h->d_prof;
+    if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long), s));
+    T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
+    return 0;
+}
+
+extern "C" int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8)
+{
+    if (!h) return -1;
+    if (!h->d_prof) {           // first call arms the counters for subsequent launches
+        T2_HIP(hipMalloc(&h->d_prof, h->state_blocks * 8 * sizeof(long long)));
+        T2_HIP(hipMemset(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long)));
+    }
+    if (out8) {
+        std::vector<long long> v(h->state_blocks * 8);
+        T2_HIP(hipMemcpy(v.data(), h->d_prof, v.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 6; ++k) {
+            long long sum = 0;
+            for (size_t b = 0; b < h->state_blocks; ++b) sum += v[b * 8 + k];
+            out8[k] = sum;
+        }
+        // [6] = sum of workgroup lifetimes, [7] = span first start .. last end (100 MHz wall clock ticks)
+        long long life = 0, t_min = 0, t_max = 0;
+        bool first = true;
+        for (size_t b = 0; b < h->state_blocks; ++b) {
+            long long a = v[b * 8 + 6], z = v[b * 8 + 7];
+            if (!a || !z) continue;
+            life += z - a;
+            if (first || a < t_min) t_min = a;
+            if (first || z > t_max) t_max = z;
+            first = false;
+        }
+        out8[6] = life; out8[7] = t_max - t_min;
+    }
     return 0;
 }
 

@@ -1,11 +1,16 @@
 // tests/emu/ldpc_emu.cpp -- TEST HELPER (not part of the product library, never shipped in libt2gpu.so).
 //
-// Replays, sequentially on the host, exactly the schedule the HIP kernel (csrc/ldpc_kernel.hip) executes: same graph
-// (csrc/ldpc_graph.cpp), same check-node arithmetic and state compression (csrc/ldpc_cn.h), same level order. It lets
-// the CPU-only test tier compare "what the kernel is going to compute" with the oracle before a GPU is involved, and
-// it flags any two nodes of one level that touch the same LLR byte (which on the GPU would be a data race).
+// Replays on the host exactly the per-layer schedule the HIP kernel (csrc/ldpc_kernel.hip) executes: same graph
+// (csrc/ldpc_graph.cpp), same phase functions and state compression (csrc/ldpc_cn.h). Everything between two workgroup
+// barriers of the kernel is an "epoch": inside an epoch the 360 node-threads are run to completion one after the
+// other in a caller-chosen order (ascending, descending or a seeded shuffle). If the result is identical to the oracle
+// for every order, the schedule neither depends on intra-epoch timing (= no data race the GPU could expose) nor
+// deviates from the reference's sequential order. This lets the CPU-only test tier validate the kernel's logic.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <numeric>
+#include <random>
 #include <vector>
 #include "../../sdr_receiver_dvb_t2_amd/csrc/ldpc_cn.h"
 #include "../../sdr_receiver_dvb_t2_amd/csrc/ldpc_graph.h"
@@ -13,38 +18,68 @@
 using namespace t2gpu;
 
 namespace {
-struct TrackMem {
+struct Mem {
     int8_t *p;
-    int *owner;      // last node that touched each byte in the current level step (-1 = none)
-    int node;
-    int *races;
-    int8_t ld(int a) const { touch(a); return p[a]; }
-    void st(int a, int8_t v) { touch(a); p[a] = v; }
-    void touch(int a) const
-    {
-        if (!owner) return;
-        if (owner[a] >= 0 && owner[a] != node) ++*races;
-        owner[a] = node;
-    }
+    int8_t ld(int a) const { return p[a]; }
+    void st(int a, int8_t v) { p[a] = v; }
 };
 int prev_addr(int k, int q, int i, int j) { return i > 0 ? k + 360 * (i - 1) + j : (j > 0 ? k + 360 * (q - 1) + j - 1 : -1); }
-}
 
+struct Order {
+    int mode; std::mt19937 rng;
+    std::vector<int> make()
+    {
+        std::vector<int> o(360);
+        std::iota(o.begin(), o.end(), 0);
+        if (mode == 1) std::reverse(o.begin(), o.end());
+        else if (mode >= 2) std::shuffle(o.begin(), o.end(), rng);
+        return o;
+    }
+};
+
+template <int CNT>
+void emu_layer(Mem &L, const LdpcGraph &g, int i, CnState *st, Order &ord)
+{
+    const LdpcLayer &ly = g.layers[i];
+    LayerDesc d{&g.entries[ly.first_entry], ly.cnt, ly.lmax, ly.n_conflict, ly.kind, ly.step};
+    std::vector<CnRegs<CNT>> regs(360);
+    std::vector<uint32_t> rec(360, 0xdeadbeefu);
+    auto a0 = [&](int j) { return g.k + 360 * i + j; };
+    auto a1 = [&](int j) { return prev_addr(g.k, g.q, i, j); };
+    if (d.kind == T2_LAYER_GENERIC) {
+        for (int j : ord.make()) {       // epoch 1: phase A immediately followed by level step 1 (no barrier between)
+            t2_layer_phase_a<CNT>(L, d, j, a0(j), a1(j), st[j], regs[j], rec.data());
+            t2_generic_level<CNT>(L, d, 1, g.cninfo[(size_t)i * 360 + j], regs[j]);
+        }
+        for (int lv = 2; lv <= d.lmax; ++lv)
+            for (int j : ord.make()) t2_generic_level<CNT>(L, d, lv, g.cninfo[(size_t)i * 360 + j], regs[j]);
+        for (int j : ord.make()) t2_generic_finish<CNT>(L, d, st[j], regs[j]);
+        return;
+    }
+    for (int j : ord.make()) t2_layer_phase_a<CNT>(L, d, j, a0(j), a1(j), st[j], regs[j], rec.data());
+    if (d.kind == T2_LAYER_PAIR) {
+        for (int j : ord.make())
+            if (j < d.step) t2_pair_walk(L, d, j, rec.data());
+        for (int j : ord.make()) t2_pair_finish<CNT>(L, d, j, st[j], regs[j]);
+    }
+}
+}  // namespace
+
+// order_mode: 0 ascending thread order inside every epoch, 1 descending, >= 2 seeded shuffles
 extern "C" int emu_ldpc_decode(int code_id, const int8_t *llr_in, int blocks, int max_trials, uint8_t *bits_out,
-                               int8_t *llr_out, int *races_out)
+                               int8_t *llr_out, int order_mode)
 {
     LdpcGraph g;
     if (!ldpc_build_graph(code_id, g)) return -2;
-    std::vector<std::vector<int8_t>> L(blocks, std::vector<int8_t>(g.n));
+    std::vector<std::vector<int8_t>> Lv(blocks, std::vector<int8_t>(g.n));
     std::vector<std::vector<CnState>> S(blocks, std::vector<CnState>((size_t)g.q * 360, CnState{0, 0}));
-    for (int b = 0; b < blocks; ++b) memcpy(L[b].data(), llr_in + (size_t)b * g.n, g.n);
-    std::vector<int> owner(g.n);
-    int races = 0;
+    for (int b = 0; b < blocks; ++b) memcpy(Lv[b].data(), llr_in + (size_t)b * g.n, g.n);
+    Order ord{order_mode, std::mt19937(1234u + order_mode)};
     int trials = max_trials;
     for (;;) {
         bool bad = false;
         for (int b = 0; b < blocks && !bad; ++b) {
-            TrackMem M{L[b].data(), nullptr, 0, &races};
+            Mem M{Lv[b].data()};
             for (int i = 0; i < g.q && !bad; ++i) {
                 const LdpcLayer &ly = g.layers[i];
                 const uint32_t *ent = &g.entries[ly.first_entry];
@@ -57,28 +92,27 @@ extern "C" int emu_ldpc_decode(int code_id, const int8_t *llr_in, int blocks, in
         if (!bad) break;
         if (--trials < 0) break;
         for (int b = 0; b < blocks; ++b) {
+            Mem M{Lv[b].data()};
             for (int i = 0; i < g.q; ++i) {
-                const LdpcLayer &ly = g.layers[i];
-                const uint32_t *ent = &g.entries[ly.first_entry];
-                for (int lv = 1; lv <= ly.lmax; ++lv) {
-                    std::fill(owner.begin(), owner.end(), -1);
-                    // descending j inside a level: if the level assignment were wrong, this order would expose it
-                    for (int j = 359; j >= 0; --j) {
-                        if (g.levels[(size_t)i * 360 + j] != lv) continue;
-                        TrackMem M{L[b].data(), b == 0 ? owner.data() : nullptr, j, &races};
-                        int a0 = g.k + 360 * i + j, a1 = prev_addr(g.k, g.q, i, j);
-                        CnState &st = S[b][(size_t)i * 360 + j];
-                        T2_LDPC_DISPATCH_CNT(ly.cnt, t2_cn_update<CNT>(M, ent, j, a0, a1, st));
-                    }
-                }
+                CnState *st = &S[b][(size_t)i * 360];
+                T2_LDPC_DISPATCH_CNT(g.layers[i].cnt, emu_layer<CNT>(M, g, i, st, ord));
             }
         }
     }
     for (int b = 0; b < blocks; ++b) {
-        if (llr_out) memcpy(llr_out + (size_t)b * g.n, L[b].data(), g.n);
+        if (llr_out) memcpy(llr_out + (size_t)b * g.n, Lv[b].data(), g.n);
         if (bits_out)
-            for (int i = 0; i < g.k; ++i) bits_out[(size_t)b * g.k + i] = L[b][i] < 0;
+            for (int i = 0; i < g.k; ++i) bits_out[(size_t)b * g.k + i] = Lv[b][i] < 0;
     }
-    if (races_out) *races_out = races;
     return trials;
+}
+
+extern "C" int emu_ldpc_graph_summary(int code_id, int *n_plain, int *n_pair, int *n_generic, int *serial_steps)
+{
+    LdpcGraph g;
+    if (!ldpc_build_graph(code_id, g)) return -1;
+    int c[3] = {0, 0, 0};
+    for (const LdpcLayer &l : g.layers) c[l.kind]++;
+    *n_plain = c[0]; *n_pair = c[1]; *n_generic = c[2]; *serial_steps = g.serial_steps;
+    return 0;
 }

@@ -102,16 +102,17 @@ def ref_decode(cid, llr, trials=25):
     return _decode(ref().ref_ldpc_decode, cid, llr, trials)
 
 
-def emu_decode(cid, llr, trials=25):
+def emu_decode(cid, llr, trials=25, order_mode=0):
+    """Host replay of the kernel schedule; order_mode picks the thread order inside every barrier epoch
+    (0 ascending, 1 descending, >= 2 seeded shuffles)."""
     n, k, _, _ = ldpc_params(cid)
     llr = np.ascontiguousarray(llr, dtype=np.int8).reshape(-1, n)
     blocks = llr.shape[0]
     bits = np.full((blocks, k), 255, dtype=np.uint8)
     lo = np.zeros((blocks, n), dtype=np.int8)
-    races = ctypes.c_int(0)
     r = emu().emu_ldpc_decode(cid, llr.ctypes.data_as(_i8p), blocks, trials, bits.ctypes.data_as(_u8p),
-                              lo.ctypes.data_as(_i8p), ctypes.byref(races))
-    return r, bits, lo, races.value
+                              lo.ctypes.data_as(_i8p), order_mode)
+    return r, bits, lo
 
 
 def ora_decode_batched(cid, llr, group=32, trials=25):

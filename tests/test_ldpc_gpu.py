@@ -121,3 +121,36 @@ def test_full_size_round_trip(torch_cuda):
     idx = rng.choice(llr.shape[0], 16, replace=False)
     cw = ol.ldpc_encode(cid, bits[idx])
     assert np.array_equal(cw, (lo[idx] < 0).astype(np.uint8))
+
+
+@pytest.mark.parametrize("cid", [0, 9])
+def test_zero_llr_counts_as_failed_check(torch_cuda, cid):
+    """A single exactly-zero LLR (information, own-parity or wrap-around parity position) makes the frame 'bad' although
+    every sign agrees (layered_decoder.hh:65-82 through vsign); one update repairs it."""
+    n, k, q, _ = ol.ldpc_params(cid)
+    cw = ol.ldpc_encode(cid, np.zeros((1, k), np.uint8) + np.arange(k, dtype=np.uint8)[None, :] % 2)
+    base = (40 * (1 - 2 * cw.astype(np.int32))).astype(np.int8)
+    positions = [0, 5, 359, 360, k - 1, k, k + 1, k + 359, k + 360 * (q - 1), n - 1]
+    llr = np.repeat(base, len(positions) + 1, axis=0)
+    for f, pos in enumerate(positions):
+        llr[f, pos] = 0
+    want = [ol.ora_decode(cid, llr[f:f + 1])[0] for f in range(llr.shape[0])]
+    assert want[-1] == 25 and all(w == 24 for w in want[:-1])
+    _, trials, lo = _run(torch_cuda, cid, llr, group=1)
+    assert trials.tolist() == want
+
+
+def test_parity_check_sees_every_single_bit_error(torch_cuda):
+    """Flip the sign of one strong LLR at a time (every 97th position + the group / layer borders): the bit-parallel
+    syndrome must flag each of them; with max_trials = 0 the frame is reported bad (-1) and untouched."""
+    cid = 9
+    n, k, q, _ = ol.ldpc_params(cid)
+    cw = ol.ldpc_encode(cid, (np.arange(k) % 3 == 0).astype(np.uint8)[None, :])
+    base = (50 * (1 - 2 * cw.astype(np.int32))).astype(np.int8)
+    positions = sorted(set(list(range(0, n, 97)) + [359, 360, 719, k - 1, k, k + 359, k + 360, n - 360, n - 1]))
+    llr = np.repeat(base, len(positions) + 1, axis=0)
+    for f, pos in enumerate(positions):
+        llr[f, pos] = -llr[f, pos]
+    _, trials, lo = _run(torch_cuda, cid, llr, group=1, trials=0)
+    assert trials[-1] == 0 and (trials[:-1] == -1).all()
+    assert np.array_equal(lo, llr)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the LDPC kernel (wave 0 of every workgroup), via t2gpu_ldpc_profile."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import sdr_receiver_dvb_t2_amd as pkg
+import oracle_lib as ol
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+group = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+cid = 9
+info, llr = ol.make_llr(cid, min(frames, 256), 0.60, 1)
+llr = np.tile(llr, ((frames + 255) // 256, 1))[:frames]
+x = torch.from_numpy(np.ascontiguousarray(llr)).cuda()
+dec = pkg.ldpc_decoder(1, 3, max_frames=frames, group=group)
+dec.execute_dev(x); torch.cuda.synchronize()
+pkg.lib().t2gpu_ldpc_profile(dec._h, None)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); bits, trials = dec.execute_dev(x); e1.record(); torch.cuda.synchronize()
+out = (ctypes.c_longlong * 8)()
+pkg.lib().t2gpu_ldpc_profile(dec._h, out)
+names = ["parity check", "rendezvous", "PLAIN layers", "PAIR layers", "GENERIC layers"]
+tot = sum(out[:5])
+print("launch %.3f ms, frames %d, avg updates %.2f" % (e0.elapsed_time(e1), frames, float((25 - trials.float()).mean())))
+for n, v in zip(names, out):
+    print("%-16s %14d cycles  %5.1f %%" % (n, v, 100.0 * v / max(tot, 1)))
+print("workgroup lifetime sum %.3f ms over span %.3f ms -> average %.1f workgroups alive" % (out[6] / 1e5, out[7] / 1e5, out[6] / max(out[7], 1)))
