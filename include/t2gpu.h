@@ -67,6 +67,60 @@ int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8);
 /* after a synchronised execute: 0 = clean, 1 = a batch rendezvous timed out (results invalid) */
 int t2gpu_ldpc_status(t2gpu_ldpc *h);
 
+/* ---------------------------------------------------------------- LLR demapper + bit de-interleaver ---------------
+ * Replaces  void llr_demapper::execute(int ti_block_size, complex* time_deint_cell, int plp_id, l1_postsignalling)
+ *           (src/DVB_T2/llr_demapper.h:44-45, llr_demapper.cpp:132-158) and qpsk/qam16/qam64/qam256 (:160-768).
+ * mod / fec_type / code_rate / rotation are l1_post.plp[plp_id].{plp_mod, plp_fec_type, plp_cod, plp_rotation}
+ * (mod: 0 QPSK, 1 16-QAM, 2 64-QAM, 3 256-QAM). Input: one TI block of cells, complex float interleaved (re, im).
+ * Output: int8 LLRs [n_frames][fec_size] in LDPC input order (n_frames = n_cells / cells per FEC block, returned), and
+ * sums3 = {sum_s, sum_e, precision}: the hard-decision signal / error energies the reference derives its LLR scale
+ * 8*norm*sum_s/sum_e from (SNR readout: 20*log10(sum_s/sum_e), llr_demapper.cpp:659). The reference de-rotates its input
+ * buffer in place; this implementation de-rotates on the fly and leaves the input untouched.
+ * precision_override > 0 fixes the LLR scale instead of measuring it (used by parity tests; 0 = reference behaviour).
+ * Grouping the frames into SIMD batches of 32 for the LDPC stage (static `blocks`, llr_demapper.cpp:549-552) is the
+ * caller's business: frames leave in arrival order. */
+typedef struct t2gpu_demap t2gpu_demap;
+t2gpu_demap *t2gpu_demap_create(int mod, int fec_type, int code_rate, int rotation, int max_cells, int device);
+void t2gpu_demap_destroy(t2gpu_demap *h);
+int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, int8_t *d_llr,
+                            float *d_sums3 /* 3 floats on the device, or NULL */, void *stream);
+int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3 /* or NULL */);
+
+/* ---------------------------------------------------------------- time / cell de-interleaver ----------------------
+ * Replaces  void time_deinterleaver::execute(int len, complex* cells) / l1_dyn_execute(l1_post, len, cells)
+ *           (src/DVB_T2/time_deinterleaver.h:33,44-45; time_deinterleaver.cpp:268-376) for one PLP with one TI block
+ *           per T2 frame (TIME_IL_TYPE 0, TIME_IL_LENGTH 1 -- the reference's tested configuration):
+ * time de-interleaving (N_split = 5), cell de-interleaving and removal of the cyclic Q delay in one scatter.
+ * t2gpu_ti_begin(num_blocks) is the geometry step of l1_dyn_execute (PLP_NUM_BLOCKS of this frame); cells are then
+ * pushed in arrival order, any number per call (the reference pushes one OFDM symbol at a time; the P2 symbol's
+ * L1 cells are skipped by the caller, time_deinterleaver.cpp:296-300). out is the caller's TI buffer of
+ * num_blocks * cells_per_fec complex cells (the reference's A/B buffer): a push returns 1 when the TI block is complete
+ * -- the moment the reference emits ti_block -- else 0. */
+typedef struct t2gpu_ti t2gpu_ti;
+t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, int device);
+void t2gpu_ti_destroy(t2gpu_ti *h);
+int t2gpu_ti_cells_per_fec(const t2gpu_ti *h);
+int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks);
+int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream);
+int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
+
+/* ---------------------------------------------------------------- BB descrambler (the reference's BCH stage) ------
+ * Replaces  void bch_decoder::execute(int* idx_plp_simd, l1_postsignalling, int len_in, uint8_t* in)
+ *           (src/DVB_T2/bch_decoder.h:41, bch_decoder.cpp:63-164). The reference performs no BCH decoding (:136): it
+ * keeps the first k_bch bits of every k_ldpc block and XORs the BB scrambling sequence (:50-61). in: [n_frames][k_ldpc]
+ * one bit per byte; out: [n_frames][k_bch]. Returns k_bch. */
+int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
+int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
+
+/* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
+ * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
+ * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),
+ * cell de-interleaver permutation (time_deinterleaver::address_cell_deinterleaving, time_deinterleaver.cpp:174-266),
+ * BB scrambler sequence (bch_decoder::init_descrambler, bch_decoder.cpp:50-61). Return the number of entries written. */
+int t2gpu_table_bitdeint(int mod, int fec_type, int code_rate, uint16_t *out /* [fec_size] */);
+int t2gpu_table_cell_deint(int num_blocks, int cells_per_fec, int32_t *out /* [num_blocks * cells_per_fec] */);
+int t2gpu_table_bb_prbs(uint8_t *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,21 @@ PROTOTYPES = {
     "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),
+    "t2gpu_demap_destroy": (None, [_vp]),
+    "t2gpu_demap_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp]),
+    "t2gpu_demap_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_ti_create": (_vp, [ctypes.c_int] * 4),
+    "t2gpu_ti_destroy": (None, [_vp]),
+    "t2gpu_ti_cells_per_fec": (ctypes.c_int, [_vp]),
+    "t2gpu_ti_begin": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_ti_push_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_ti_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_bch_descramble_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "t2gpu_table_bitdeint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "t2gpu_table_cell_deint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
+    "t2gpu_table_bb_prbs": (ctypes.c_int, [_vp, ctypes.c_int]),
 }
 
 _lib = None

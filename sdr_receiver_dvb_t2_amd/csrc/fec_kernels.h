@@ -1,0 +1,37 @@
+// fec_kernels.h -- launch interface of the FEC-side kernels other than the LDPC decoder.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace t2gpu {
+
+// K-descramble: out[f][i] = in[f][i] ^ prbs[i], i < k_bch (bch_decoder.cpp:136-142)
+hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs, uint8_t *out,
+                                 hipStream_t s);
+
+struct DemapParams {
+    int mod;                 // 0 QPSK, 1 16-QAM, 2 64-QAM, 3 256-QAM
+    int fec_size, bits_per_cell, cells_per_fec;
+    int rotate;              // de-rotate by e^{-j ROT} first
+    float rot_c, rot_s;      // cos(-ROT), sin(-ROT) as floats
+    float d;                 // normalisation factor
+    const uint16_t *address; // [fec_size] bit de-interleaver (null for QPSK)
+};
+// K-snr-reduce: sums[0] = sum |s|^2, sums[1] = sum |e|^2 over the hard decisions of n_snr cells (device doubles),
+// partial[] = scratch of 2*blocks doubles. Second stage folds them and writes float sums[0..2] (s, e, precision).
+hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
+                              float precision_override, hipStream_t s);
+// K-demap-bdi: one workgroup per FEC frame; LLRs staged in LDS in LDPC order, written out coalesced.
+hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s);
+
+// K-ti-cdi-qdelay: scatter cells n0 .. n0+n-1 of a TI block (time + cell de-interleave + cyclic Q delay removal)
+struct TiParams {
+    int cells_per_fec, rows, cols, ti_block_size;
+    const int32_t *perm;
+};
+hipError_t launch_ti_scatter(const TiParams &p, const float2 *cells, int n0, int n, float2 *out, float *first_q, hipStream_t s);
+// held-Q fix-up after the last cell of the TI block: block order / lost flags are static per geometry (see t2gpu_fec.cpp)
+hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_t *lost, int num_blocks, const float *first_q,
+                           float2 *out, hipStream_t s);
+
+}  // namespace t2gpu

@@ -1,0 +1,223 @@
+// fec_kernels.hip -- FEC-side streaming kernels for gfx950: BB descrambler (BCH stub), LLR demapper + bit de-interleaver,
+// time / cell de-interleaver with cyclic Q-delay removal. All HBM-bound gather/scatter work; no matrix cores involved.
+#include "fec_kernels.h"
+
+// The reference is built without FMA (-mavx2 only): every product and sum rounds on its own. HIP's mul_r/add_r
+// are header-defined plain operators carrying the default "contract" flag, i.e. the compiler still fuses them; the
+// helpers below are defined under contract(off) instead (and the Makefile adds -ffp-contract=off for this file).
+#pragma clang fp contract(off)
+
+namespace t2gpu {
+
+__device__ __forceinline__ float mul_r(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_r(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_r(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_r(float a, float b) { return a / b; }
+
+// ---------------------------------------------------------------------------------------------------- K-descramble
+// Replaces bch_decoder::execute (/root/reference/src/DVB_T2/bch_decoder.cpp:63-164): the reference does no BCH decoding
+// (":136 // TODO BCH decode"); it drops the parity tail of each k_ldpc block and XORs the BB scrambling sequence.
+__global__ __launch_bounds__(256) void bch_descramble_kernel(const uint8_t *__restrict__ bits, int n_frames, int k_ldpc,
+                                                            int k_bch, const uint8_t *__restrict__ prbs, uint8_t *__restrict__ out)
+{
+    const int words = k_bch / 4;             // every k_bch and k_ldpc of DVB-T2 is a multiple of 8
+    const int f = blockIdx.y;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(bits + (size_t)f * k_ldpc);
+    const uint32_t *pr = reinterpret_cast<const uint32_t *>(prbs);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)f * k_bch);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = src[i] ^ pr[i];
+}
+
+hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs, uint8_t *out,
+                                 hipStream_t s)
+{
+    dim3 grid((k_bch / 4 + 255) / 256 > 16 ? 16 : (k_bch / 4 + 255) / 256, n_frames);
+    hipLaunchKernelGGL(bch_descramble_kernel, grid, dim3(256), 0, s, bits, n_frames, k_ldpc, k_bch, prbs, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------- demapper
+// Replaces llr_demapper::execute and qpsk/qam16/qam64/qam256 (/root/reference/src/DVB_T2/llr_demapper.cpp:132-158,
+// 160-228, 230-364, 366-535, 537-768). Floating-point products and sums are written with the non-contracting
+// intrinsics so that the LLR arithmetic (x*p, (|x|-c)*p, round-to-nearest-even, truncating int8 cast) is the
+// reference's operation for operation; only the order of the sum_s / sum_e reduction differs (tolerance in DESIGN.md).
+__device__ __forceinline__ float2 derotate(float2 v, float c, float s)
+{
+    // (re + j im) * (c + j s), products and sums rounded separately as std::complex<float> operator*= does without FMA
+    return make_float2(sub_r(mul_r(v.x, c), mul_r(v.y, s)), add_r(mul_r(v.x, s), mul_r(v.y, c)));
+}
+
+__device__ __forceinline__ float slice_axis(int mod, float x, float d)
+{
+    const float x2 = d * 2.0f, x4 = d * 4.0f, x6 = d * 6.0f;
+    if (mod == 0) return x > 0 ? d : -d;
+    if (mod == 1) {
+        if (x > 0) return (x > x2) ? d * 3.0f : d;
+        return (x < -x2) ? -(d * 3.0f) : -d;
+    }
+    if (mod == 2) {
+        if (x > 0) {
+            if (x > x4) return (x > x6) ? d * 7.0f : d * 5.0f;
+            return (x > x2) ? d * 3.0f : d;
+        }
+        if (x < -x4) return (x > x6) ? -(d * 7.0f) : -(d * 5.0f);     // llr_demapper.cpp:407,427: '>' as written
+        return (x < -x2) ? -(d * 3.0f) : -d;
+    }
+    const float x8 = d * 8.0f, x10 = d * 10.0f, x12 = d * 12.0f, x14 = d * 14.0f;
+    if (x > 0) {
+        if (x > x8) {
+            if (x > x12) return (x > x14) ? d * 15.0f : d * 13.0f;
+            return (x > x10) ? d * 11.0f : d * 9.0f;
+        }
+        if (x > x4) return (x > x6) ? d * 7.0f : d * 5.0f;
+        return (x > x2) ? d * 3.0f : d;
+    }
+    if (x < -x8) {
+        if (x < -x12) return (x < -x14) ? -(d * 15.0f) : -(d * 13.0f);
+        return (x < -x10) ? -(d * 11.0f) : -(d * 9.0f);
+    }
+    if (x < -x4) return (x < -x6) ? -(d * 7.0f) : -(d * 5.0f);
+    return (x < -x2) ? -(d * 3.0f) : -d;
+}
+
+__global__ __launch_bounds__(256) void demap_stats_kernel(DemapParams p, const float2 *__restrict__ cells, int n_snr,
+                                                         double *__restrict__ partial)
+{
+    double ss = 0.0, se = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_snr; i += gridDim.x * blockDim.x) {
+        float2 v = cells[i];
+        if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
+        const float sr = slice_axis(p.mod, v.x, p.d), si = slice_axis(p.mod, v.y, p.d);
+        const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
+        ss += (double)add_r(mul_r(sr, sr), mul_r(si, si));      // std::norm(s), float as in the reference
+        se += (double)add_r(mul_r(er, er), mul_r(ei, ei));
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = ss; sh[1][threadIdx.x] = se;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+
+__global__ void demap_stats_final_kernel(const double *__restrict__ partial, int blocks, float d, float precision_override,
+                                         float *__restrict__ sums)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double ss = 0.0, se = 0.0;
+    for (int b = 0; b < blocks; ++b) { ss += partial[2 * b]; se += partial[2 * b + 1]; }      // fixed order: deterministic
+    const float fs = (float)ss, fe = (float)se;
+    float precision = div_r(mul_r(mul_r(8.0f, d), fs), fe);        // 8.0f * NORM * sum_s / sum_e
+    if (precision_override > 0.0f) precision = precision_override;
+    sums[0] = fs; sums[1] = fe; sums[2] = precision;
+}
+
+hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
+                              float precision_override, hipStream_t s)
+{
+    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n_snr, partial);
+    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ int8_t cast_i8_trunc(float v)
+{
+    return (int8_t)(uint8_t)((int)v & 0xff);      // cvttss2si + low byte, no saturation (16/64/256-QAM paths)
+}
+
+__global__ __launch_bounds__(256) void demap_llr_kernel(DemapParams p, const float2 *__restrict__ cells,
+                                                       const float *__restrict__ sums, int8_t *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t stage[];        // one FEC frame in LDPC input order
+    const int f = blockIdx.x;
+    const float precision = sums[2];
+    const float2 *src = cells + (size_t)f * p.cells_per_fec;
+    const int levels = p.mod + 1;
+    for (int c = threadIdx.x; c < p.cells_per_fec; c += blockDim.x) {
+        float2 v = src[c];
+        if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
+        if (p.mod == 0) {                                                  // quantize(): clamps (llr_demapper.cpp:770-776)
+            float a = rintf(mul_r(v.x, precision)), b = rintf(mul_r(v.y, precision));
+            a = fminf(fmaxf(a, -128.0f), 127.0f); b = fminf(fmaxf(b, -128.0f), 127.0f);
+            stage[2 * c] = (int8_t)a; stage[2 * c + 1] = (int8_t)b;
+            continue;
+        }
+        const uint16_t *a = p.address + c * p.bits_per_cell;
+        float thr = p.d * (float)(1 << p.mod);
+        for (int l = 0; l < levels; ++l) {
+            stage[a[2 * l]] = cast_i8_trunc(rintf(mul_r(v.x, precision)));
+            stage[a[2 * l + 1]] = cast_i8_trunc(rintf(mul_r(v.y, precision)));
+            v.x = sub_r(fabsf(v.x), thr);
+            v.y = sub_r(fabsf(v.y), thr);
+            thr *= 0.5f;
+        }
+    }
+    __syncthreads();
+    const uint2 *s2 = reinterpret_cast<const uint2 *>(stage);
+    uint2 *dst = reinterpret_cast<uint2 *>(out + (size_t)f * p.fec_size);
+    for (int i = threadIdx.x; i < p.fec_size / 8; i += blockDim.x) dst[i] = s2[i];
+}
+
+hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demap_llr_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64800);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(256), p.fec_size, s, p, cells, sums, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------- time de-interleaver
+// Replaces the per-cell loop of time_deinterleaver::execute (/root/reference/src/DVB_T2/time_deinterleaver.cpp:316-345).
+// Cell n of the TI block sits at row-column address d = (n mod cols)*rows + n div cols of the interleaver memory;
+// perm[d] is its cell-de-interleaved position. I goes there, Q goes one cell earlier (cyclic inside the FEC block):
+// the Q of a block's first cell is parked in first_q[block] and placed on the block's last cell by the fix-up kernel.
+__global__ __launch_bounds__(256) void ti_scatter_kernel(TiParams p, const float2 *__restrict__ cells, int n0, int n,
+                                                        float2 *__restrict__ out, float *__restrict__ first_q)
+{
+    float *o = reinterpret_cast<float *>(out);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int nn = n0 + i;
+        const int row = nn / p.cols, col = nn - row * p.cols;
+        const int ia = p.perm[col * p.rows + row];
+        const float2 v = cells[i];
+        o[2 * (size_t)ia] = v.x;
+        const int blk = ia / p.cells_per_fec;
+        if (ia - blk * p.cells_per_fec == 0) first_q[blk] = v.y;
+        else o[2 * (size_t)(ia - 1) + 1] = v.y;
+    }
+}
+
+hipError_t launch_ti_scatter(const TiParams &p, const float2 *cells, int n0, int n, float2 *out, float *first_q, hipStream_t s)
+{
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ti_scatter_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n0, n, out, first_q);
+    return hipGetLastError();
+}
+
+__global__ void ti_fixup_kernel(TiParams p, const int32_t *__restrict__ order, const uint8_t *__restrict__ lost, int num_blocks,
+                                const float *__restrict__ first_q, float2 *__restrict__ out)
+{
+    float *o = reinterpret_cast<float *>(out);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < num_blocks; k += gridDim.x * blockDim.x) {
+        if (lost[k]) continue;            // the reference overwrites this held value before ever storing it
+        const int blk = order[k];
+        o[2 * ((size_t)blk * p.cells_per_fec + p.cells_per_fec - 1) + 1] = first_q[blk];
+    }
+}
+
+hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_t *lost, int num_blocks, const float *first_q,
+                           float2 *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ti_fixup_kernel, dim3((num_blocks + 255) / 256), dim3(256), 0, s, p, order, lost, num_blocks, first_q, out);
+    return hipGetLastError();
+}
+
+}  // namespace t2gpu

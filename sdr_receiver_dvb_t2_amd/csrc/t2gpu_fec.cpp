@@ -1,0 +1,302 @@
+// t2gpu_fec.cpp -- C-ABI of the FEC-side stages around the LDPC decoder (include/t2gpu.h): LLR demapper + bit
+// de-interleaver, time / cell de-interleaver, BB descrambler (the reference's BCH stub). Host side only; the compute is
+// in fec_kernels.hip and this library has no CPU fallback.
+#include "../../include/t2gpu.h"
+#include "fec_kernels.h"
+#include "fec_tables.h"
+#include "ldpc_graph.h"
+#include "t2gpu_common.h"
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace t2gpu;
+
+static bool have_device(int device, const char *who)
+{
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || device < 0 || device >= ndev) {
+        set_error(std::string(who) + ": no usable HIP device (this library has no CPU path)");
+        return false;
+    }
+    return hipSetDevice(device) == hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------ tables (host only)
+extern "C" int t2gpu_table_bitdeint(int mod, int fec_type, int code_rate, uint16_t *out)
+{
+    std::vector<uint16_t> a;
+    if (!out || !bitdeint_address(mod, fec_type, code_rate, a)) { set_error("t2gpu_table_bitdeint: no such mode"); return -1; }
+    std::copy(a.begin(), a.end(), out);
+    return (int)a.size();
+}
+extern "C" int t2gpu_table_cell_deint(int num_blocks, int cells_per_fec, int32_t *out)
+{
+    if (!out || num_blocks < 1 || cells_per_fec < 1024 || cells_per_fec > 32768) { set_error("t2gpu_table_cell_deint: bad arguments"); return -1; }
+    std::vector<int32_t> p;
+    cell_deint_permutation(num_blocks, cells_per_fec, p);
+    std::copy(p.begin(), p.end(), out);
+    return (int)p.size();
+}
+extern "C" int t2gpu_table_bb_prbs(uint8_t *out, int n)
+{
+    if (!out || n < 1) return -1;
+    std::vector<uint8_t> b;
+    bb_prbs(b, n);
+    std::copy(b.begin(), b.end(), out);
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ demapper
+struct t2gpu_demap {
+    DemapParams p{};
+    int device = 0, max_cells = 0, stats_blocks = 0;
+    uint16_t *d_address = nullptr;
+    double *d_partial = nullptr;
+    float *d_sums = nullptr;
+    float *d_cells = nullptr;      // host-call staging
+    int8_t *d_llr = nullptr;
+};
+
+extern "C" t2gpu_demap *t2gpu_demap_create(int mod, int fec_type, int code_rate, int rotation, int max_cells, int device)
+{
+    static const float ROT[4] = {0.506145483f, 0.293215314f, 0.150098316f, 0.062418810f};     // dvbt2_definition.h:45-48
+    static const float NORM[4] = {0.707106781f, 0.316227766f, 0.15430335f, 0.076696499f};     // dvbt2_definition.h:49-52
+    if (mod < 0 || mod > 3 || fec_type < 0 || fec_type > 1 || code_rate < 0 || code_rate > 5 || max_cells < 1) {
+        set_error("t2gpu_demap_create: bad arguments");
+        return nullptr;
+    }
+    if (!have_device(device, "t2gpu_demap_create")) return nullptr;
+    t2gpu_demap *h = new t2gpu_demap();
+    h->device = device; h->max_cells = max_cells;
+    h->p.mod = mod;
+    h->p.fec_size = fec_size_of(fec_type);
+    h->p.bits_per_cell = 2 * (mod + 1);
+    h->p.cells_per_fec = h->p.fec_size / h->p.bits_per_cell;
+    h->p.rotate = rotation ? 1 : 0;
+    h->p.rot_c = (float)std::cos(-(double)ROT[mod]);
+    h->p.rot_s = (float)std::sin(-(double)ROT[mod]);
+    h->p.d = NORM[mod];
+    h->stats_blocks = 1024;
+    bool ok = true;
+    if (mod > 0) {
+        std::vector<uint16_t> addr;
+        if (!bitdeint_address(mod, fec_type, code_rate, addr)) { delete h; set_error("no bit interleaver for this mode"); return nullptr; }
+        ok = ok && hip_ok(hipMalloc(&h->d_address, addr.size() * 2), "hipMalloc");
+        ok = ok && hip_ok(hipMemcpy(h->d_address, addr.data(), addr.size() * 2, hipMemcpyHostToDevice), "hipMemcpy");
+        h->p.address = h->d_address;
+    }
+    ok = ok && hip_ok(hipMalloc(&h->d_partial, sizeof(double) * 2 * h->stats_blocks), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc(&h->d_sums, sizeof(float) * 4), "hipMalloc");
+    if (!ok) { t2gpu_demap_destroy(h); return nullptr; }
+    return h;
+}
+
+extern "C" void t2gpu_demap_destroy(t2gpu_demap *h)
+{
+    if (!h) return;
+    hipFree(h->d_address); hipFree(h->d_partial); hipFree(h->d_sums); hipFree(h->d_cells); hipFree(h->d_llr);
+    delete h;
+}
+
+extern "C" int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override,
+                                       int8_t *d_llr, float *d_sums3, void *stream)
+{
+    if (!h || !d_cells || !d_llr || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_execute_dev: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const float2 *cells = reinterpret_cast<const float2 *>(d_cells);
+    float *sums = d_sums3 ? d_sums3 : h->d_sums;
+    const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;       // llr_demapper.cpp:184 (QPSK: first 2048 cells)
+    int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
+    T2_HIP(launch_demap_stats(h->p, cells, n_snr, h->d_partial, blocks, sums, precision_override, s));
+    const int n_frames = n_cells / h->p.cells_per_fec;
+    if (n_frames > 0) T2_HIP(launch_demap_llr(h->p, cells, n_frames, sums, d_llr, s));
+    return n_frames;
+}
+
+extern "C" int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3)
+{
+    if (!h || !cells || !llr || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_execute: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (!h->d_cells) {
+        T2_HIP(hipMalloc(&h->d_cells, (size_t)h->max_cells * 8));
+        T2_HIP(hipMalloc(&h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell));
+    }
+    T2_HIP(hipMemcpy(h->d_cells, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice));
+    int nf = t2gpu_demap_execute_dev(h, h->d_cells, n_cells, 0.0f, h->d_llr, nullptr, nullptr);
+    if (nf < 0) return -1;
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(llr, h->d_llr, (size_t)nf * h->p.fec_size, hipMemcpyDeviceToHost));
+    if (sums3) T2_HIP(hipMemcpy(sums3, h->d_sums, 12, hipMemcpyDeviceToHost));
+    return nf;
+}
+
+// ------------------------------------------------------------------------------------------------ time de-interleaver
+struct t2gpu_ti {
+    int device = 0, cells_per_fec = 0, num_blocks_max = 0, num_blocks = 0, pos = 0;
+    TiParams p{};
+    std::vector<int32_t> perm;         // host copy, for the per-geometry event order
+    int32_t *d_perm = nullptr, *d_order = nullptr;
+    uint8_t *d_lost = nullptr;
+    float *d_first_q = nullptr;
+    float *d_in = nullptr, *d_out = nullptr;   // host-call staging
+    std::map<int, std::pair<std::vector<int32_t>, std::vector<uint8_t>>> geom;   // num_blocks -> (order, lost)
+};
+
+extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, int device)
+{
+    if (mod < 0 || mod > 3 || fec_type < 0 || fec_type > 1 || num_blocks_max < 1 || num_blocks_max > 1023) {
+        set_error("t2gpu_ti_create: bad arguments");
+        return nullptr;
+    }
+    if (!have_device(device, "t2gpu_ti_create")) return nullptr;
+    t2gpu_ti *h = new t2gpu_ti();
+    h->device = device; h->num_blocks_max = num_blocks_max;
+    h->cells_per_fec = fec_size_of(fec_type) / (2 * (mod + 1));
+    cell_deint_permutation(num_blocks_max, h->cells_per_fec, h->perm);
+    bool ok = hip_ok(hipMalloc(&h->d_perm, h->perm.size() * 4), "hipMalloc");
+    ok = ok && hip_ok(hipMemcpy(h->d_perm, h->perm.data(), h->perm.size() * 4, hipMemcpyHostToDevice), "hipMemcpy");
+    ok = ok && hip_ok(hipMalloc(&h->d_order, num_blocks_max * 4), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc(&h->d_lost, num_blocks_max), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc(&h->d_first_q, num_blocks_max * 4), "hipMalloc");
+    if (!ok) { t2gpu_ti_destroy(h); return nullptr; }
+    h->p.cells_per_fec = h->cells_per_fec;
+    h->p.rows = h->cells_per_fec / 5;                 // N_split = 5 columns per FEC block (time_deinterleaver.cpp:69-113)
+    h->p.perm = h->d_perm;
+    return h;
+}
+
+extern "C" void t2gpu_ti_destroy(t2gpu_ti *h)
+{
+    if (!h) return;
+    hipFree(h->d_perm); hipFree(h->d_order); hipFree(h->d_lost); hipFree(h->d_first_q); hipFree(h->d_in); hipFree(h->d_out);
+    delete h;
+}
+
+extern "C" int t2gpu_ti_cells_per_fec(const t2gpu_ti *h) { return h ? h->cells_per_fec : -1; }
+
+// l1_dyn_execute (time_deinterleaver.cpp:268-286): the TI block of this T2 frame holds num_blocks FEC blocks
+extern "C" int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks)
+{
+    if (!h || num_blocks < 1 || num_blocks > h->num_blocks_max) { set_error("t2gpu_ti_begin: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    h->num_blocks = num_blocks; h->pos = 0;
+    h->p.cols = 5 * num_blocks;
+    h->p.ti_block_size = h->p.cols * h->p.rows;
+    auto it = h->geom.find(num_blocks);
+    if (it == h->geom.end()) {
+        // Order in which the first cells of the FEC blocks arrive, and which of their parked Q values the reference
+        // loses: a parked value is stored when the next block-start arrives (unless that is block 0) or at the end of
+        // the interleaver row; it is overwritten unsaved when block 0's start follows in the same row (:321-336).
+        const int n = h->cells_per_fec, rows = h->p.rows, cols = h->p.cols;
+        std::vector<int32_t> inv((size_t)num_blocks * n);
+        for (int d = 0; d < num_blocks * n; ++d) inv[h->perm[d]] = d;
+        std::vector<std::pair<int64_t, int>> ev;
+        for (int b = 0; b < num_blocks; ++b) {
+            const int d = inv[(size_t)b * n];
+            const int col = d / rows, row = d % rows;
+            ev.push_back({(int64_t)row * cols + col, b});
+        }
+        std::sort(ev.begin(), ev.end());
+        std::vector<int32_t> order(num_blocks);
+        std::vector<uint8_t> lost(num_blocks, 0);
+        for (int k = 0; k < num_blocks; ++k) {
+            order[k] = ev[k].second;
+            if (k + 1 < num_blocks && ev[k + 1].second == 0 && ev[k].first / cols == ev[k + 1].first / cols) lost[k] = 1;
+        }
+        it = h->geom.emplace(num_blocks, std::make_pair(order, lost)).first;
+    }
+    T2_HIP(hipMemcpy(h->d_order, it->second.first.data(), num_blocks * 4, hipMemcpyHostToDevice));
+    T2_HIP(hipMemcpy(h->d_lost, it->second.second.data(), num_blocks, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream)
+{
+    if (!h || !d_cells || !d_out || n_cells < 0 || !h->num_blocks || h->pos + n_cells > h->p.ti_block_size) {
+        set_error("t2gpu_ti_push_dev: bad arguments (t2gpu_ti_begin first; a push may not cross the TI block end)");
+        return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (n_cells)
+        T2_HIP(launch_ti_scatter(h->p, reinterpret_cast<const float2 *>(d_cells), h->pos, n_cells, reinterpret_cast<float2 *>(d_out),
+                                 h->d_first_q, s));
+    h->pos += n_cells;
+    if (h->pos == h->p.ti_block_size) {
+        T2_HIP(launch_ti_fixup(h->p, h->d_order, h->d_lost, h->num_blocks, h->d_first_q, reinterpret_cast<float2 *>(d_out), s));
+        h->pos = 0;
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out)
+{
+    if (!h || !cells || !out || !h->num_blocks) { set_error("t2gpu_ti_push: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    const size_t cap = (size_t)h->num_blocks_max * h->cells_per_fec * 8;
+    if (!h->d_in) { T2_HIP(hipMalloc(&h->d_in, cap)); T2_HIP(hipMalloc(&h->d_out, cap)); }
+    const size_t blk = (size_t)h->p.ti_block_size * 8;
+    T2_HIP(hipMemcpy(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice));
+    T2_HIP(hipMemcpy(h->d_out, out, blk, hipMemcpyHostToDevice));          // the caller's A/B buffer keeps its history
+    int done = t2gpu_ti_push_dev(h, h->d_in, n_cells, h->d_out, nullptr);
+    if (done < 0) return -1;
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
+    return done;
+}
+
+// ------------------------------------------------------------------------------------------------ BB descrambler / BCH stub
+static std::mutex g_prbs_mutex;
+static std::map<int, uint8_t *> g_prbs;      // per device
+
+static const uint8_t *prbs_on_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_prbs_mutex);
+    auto it = g_prbs.find(device);
+    if (it != g_prbs.end()) return it->second;
+    std::vector<uint8_t> bits;
+    bb_prbs(bits, 54000);
+    uint8_t *d = nullptr;
+    if (!hip_ok(hipMalloc(&d, 54000), "hipMalloc") || !hip_ok(hipMemcpy(d, bits.data(), 54000, hipMemcpyHostToDevice), "hipMemcpy"))
+        return nullptr;
+    g_prbs[device] = d;
+    return d;
+}
+
+extern "C" int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out,
+                                        void *stream)
+{
+    const int id = ldpc_code_id(fec_type, code_rate);
+    if (id < 0 || !d_bits || !d_out || n_frames < 1) { set_error("t2gpu_bch_descramble_dev: bad arguments"); return -1; }
+    int device = 0;
+    T2_HIP(hipGetDevice(&device));
+    const uint8_t *prbs = prbs_on_device(device);
+    if (!prbs) return -1;
+    static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
+    T2_HIP(launch_bch_descramble(d_bits, n_frames, k_ldpc[id], ldpc_k_bch(id), prbs, d_out, (hipStream_t)stream));
+    return ldpc_k_bch(id);
+}
+
+extern "C" int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out)
+{
+    const int id = ldpc_code_id(fec_type, code_rate);
+    if (id < 0 || !bits || !out || n_frames < 1) { set_error("t2gpu_bch_descramble: bad arguments"); return -1; }
+    if (!have_device(0, "t2gpu_bch_descramble")) return -1;
+    static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    const size_t in_b = (size_t)n_frames * k_ldpc[id], out_b = (size_t)n_frames * ldpc_k_bch(id);
+    T2_HIP(hipMalloc(&d_in, in_b));
+    T2_HIP(hipMalloc(&d_out, out_b));
+    T2_HIP(hipMemcpy(d_in, bits, in_b, hipMemcpyHostToDevice));
+    int kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, d_out, nullptr);
+    if (kb > 0) {
+        T2_HIP(hipDeviceSynchronize());
+        T2_HIP(hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_in); hipFree(d_out);
+    return kb;
+}

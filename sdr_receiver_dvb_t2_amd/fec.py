@@ -1,0 +1,132 @@
+"""Host-side mirrors of the reference's FEC-side stage objects around the LDPC decoder (the C ABI does the work).
+
+``llr_demapper``       /root/reference/src/DVB_T2/llr_demapper.h:28-124      (execute :44-45, llr_demapper.cpp:132-158)
+``time_deinterleaver`` /root/reference/src/DVB_T2/time_deinterleaver.h:27-102 (start / l1_dyn_execute / execute)
+``bch_decoder``        /root/reference/src/DVB_T2/bch_decoder.h:26-59         (execute :41, bch_decoder.cpp:63-164)
+
+The Qt slots take their mode from ``l1_post.plp[plp_id]``; here the same four integers (plp_mod, plp_fec_type, plp_cod,
+plp_rotation) are constructor arguments. Buffers are torch CUDA tensors for the ``*_dev`` forms (no copies, current
+stream) and numpy arrays for the reference-shaped host forms.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check, T2GpuError
+
+MOD_QPSK, MOD_16QAM, MOD_64QAM, MOD_256QAM = range(4)   # dvbt2_constellation_t (dvbt2_definition.h:69-74)
+
+
+class llr_demapper(object):
+    def __init__(self, plp_mod, plp_fec_type, plp_cod, plp_rotation, max_cells, device=0):
+        self._l = lib()
+        self._h = self._l.t2gpu_demap_create(plp_mod, plp_fec_type, plp_cod, plp_rotation, max_cells, device)
+        if not self._h:
+            raise T2GpuError("t2gpu_demap_create: " + self._l.t2gpu_last_error().decode())
+        self.fec_size = 64800 if plp_fec_type == 1 else 16200
+        self.bits_per_cell = 2 * (plp_mod + 1)
+        self.cells_per_fec = self.fec_size // self.bits_per_cell
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.t2gpu_demap_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def execute_dev(self, cells, precision_override=0.0):
+        """cells: CUDA float32 [n_cells, 2] (re, im). Returns (llr int8 [n_frames, fec_size], sums float32[3])."""
+        import torch
+        assert cells.is_cuda and cells.dtype == torch.float32 and cells.is_contiguous()
+        n_cells = cells.numel() // 2
+        n_frames = n_cells // self.cells_per_fec
+        llr = torch.empty((n_frames, self.fec_size), dtype=torch.int8, device=cells.device)
+        sums = torch.empty((3,), dtype=torch.float32, device=cells.device)
+        stream = torch.cuda.current_stream(cells.device).cuda_stream
+        rc = self._l.t2gpu_demap_execute_dev(self._h, cells.data_ptr(), n_cells, float(precision_override), llr.data_ptr(),
+                                             sums.data_ptr(), stream)
+        if rc < 0:
+            check(rc, "t2gpu_demap_execute_dev")
+        return llr, sums
+
+    def execute(self, ti_block_size, time_deint_cell):
+        """Reference call shape on host buffers; returns (llr [n_frames][fec_size], (sum_s, sum_e, precision))."""
+        cells = np.ascontiguousarray(time_deint_cell, dtype=np.complex64).reshape(-1)[:ti_block_size]
+        n_frames = ti_block_size // self.cells_per_fec
+        llr = np.empty((n_frames, self.fec_size), dtype=np.int8)
+        sums = np.empty(3, dtype=np.float32)
+        rc = self._l.t2gpu_demap_execute(self._h, cells.ctypes.data, ti_block_size, llr.ctypes.data, sums.ctypes.data)
+        if rc < 0:
+            check(rc, "t2gpu_demap_execute")
+        return llr, sums
+
+
+class time_deinterleaver(object):
+    def __init__(self, plp_mod, plp_fec_type, plp_num_blocks_max, device=0):
+        self._l = lib()
+        self._h = self._l.t2gpu_ti_create(plp_mod, plp_fec_type, plp_num_blocks_max, device)
+        if not self._h:
+            raise T2GpuError("t2gpu_ti_create: " + self._l.t2gpu_last_error().decode())
+        self.cells_per_fec = self._l.t2gpu_ti_cells_per_fec(self._h)
+        self.num_blocks = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.t2gpu_ti_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def l1_dyn(self, plp_num_blocks):
+        """Geometry step of l1_dyn_execute (time_deinterleaver.cpp:268-286) for this T2 frame."""
+        check(self._l.t2gpu_ti_begin(self._h, plp_num_blocks), "t2gpu_ti_begin")
+        self.num_blocks = plp_num_blocks
+        return plp_num_blocks * self.cells_per_fec
+
+    def execute_dev(self, cells, out):
+        import torch
+        assert cells.is_cuda and out.is_cuda and cells.dtype == torch.float32 and out.dtype == torch.float32
+        stream = torch.cuda.current_stream(cells.device).cuda_stream
+        rc = self._l.t2gpu_ti_push_dev(self._h, cells.data_ptr(), cells.numel() // 2, out.data_ptr(), stream)
+        if rc < 0:
+            check(rc, "t2gpu_ti_push_dev")
+        return rc == 1
+
+    def execute(self, cells, out):
+        cells = np.ascontiguousarray(cells, dtype=np.complex64).reshape(-1)
+        assert out.dtype == np.complex64 and out.flags.c_contiguous
+        rc = self._l.t2gpu_ti_push(self._h, cells.ctypes.data, cells.size, out.ctypes.data)
+        if rc < 0:
+            check(rc, "t2gpu_ti_push")
+        return rc == 1
+
+
+class bch_decoder(object):
+    """The reference's BCH stage is a parity strip + BB descrambler (bch_decoder.cpp:136-142)."""
+
+    def __init__(self, plp_fec_type, plp_cod):
+        self._l = lib()
+        self.fec_type, self.cod = plp_fec_type, plp_cod
+
+    def execute_dev(self, bits):
+        import torch
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous()
+        n_frames = bits.shape[0]
+        k_bch = {0: (7032, 9552, 10632, 11712, 12432, 13152), 1: (32208, 38688, 43040, 48408, 51648, 53840)}[self.fec_type][self.cod]
+        out = torch.empty((n_frames, k_bch), dtype=torch.uint8, device=bits.device)
+        stream = torch.cuda.current_stream(bits.device).cuda_stream
+        rc = self._l.t2gpu_bch_descramble_dev(self.fec_type, self.cod, bits.data_ptr(), n_frames, out.data_ptr(), stream)
+        if rc < 0:
+            check(rc, "t2gpu_bch_descramble_dev")
+        return out
+
+    def execute(self, len_in, _in):
+        bits = np.ascontiguousarray(_in, dtype=np.uint8).reshape(-1)[:len_in]
+        k_ldpc = {0: (7200, 9720, 10800, 11880, 12600, 13320), 1: (32400, 38880, 43200, 48600, 51840, 54000)}[self.fec_type][self.cod]
+        n_frames = len_in // k_ldpc
+        k_bch = {0: (7032, 9552, 10632, 11712, 12432, 13152), 1: (32208, 38688, 43040, 48408, 51648, 53840)}[self.fec_type][self.cod]
+        out = np.empty((n_frames, k_bch), dtype=np.uint8)
+        rc = self._l.t2gpu_bch_descramble(self.fec_type, self.cod, bits.ctypes.data, n_frames, out.ctypes.data)
+        if rc < 0:
+            check(rc, "t2gpu_bch_descramble")
+        return out

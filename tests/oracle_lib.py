@@ -127,3 +127,71 @@ def ora_decode_batched(cid, llr, group=32, trials=25):
         lo[b0:b0 + group] = l
         bits[b0:b0 + group] = (l[:, :k] < 0)
     return np.array(tl, np.int32), bits, lo
+
+
+# ------------------------------------------------------------------------------------------------ FEC-side stages
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def ora_bb_prbs(n):
+    out = np.zeros(n, np.uint8)
+    oracle().ora_bb_prbs(out.ctypes.data_as(_u8p), n)
+    return out
+
+
+def ora_bch_descramble(cid, bits):
+    n, k, _, _ = ldpc_params(cid)
+    bits = np.ascontiguousarray(bits, np.uint8).reshape(-1, k)
+    kb = [7032, 9552, 10632, 11712, 12432, 13152, 32208, 38688, 43040, 48408, 51648, 53840][cid]
+    out = np.zeros((bits.shape[0], kb), np.uint8)
+    assert oracle().ora_bch_descramble(cid, bits.ctypes.data_as(_u8p), bits.shape[0], out.ctypes.data_as(_u8p)) == kb
+    return out
+
+
+def ora_bitdeint_address(mod, fec_type, code_rate):
+    size = 64800 if fec_type == 1 else 16200
+    a = np.zeros(size, np.int32)
+    assert oracle().ora_bitdeint_address(mod, fec_type, code_rate, a.ctypes.data_as(_ip)) == size
+    return a
+
+
+def ora_demap(mod, fec_type, code_rate, rotation, cells, precision_override=0.0):
+    """cells complex64 [n]; returns (llr [frames][fec_size], sums[3], derotated cells)."""
+    c = np.ascontiguousarray(cells, np.complex64).copy()
+    size = 64800 if fec_type == 1 else 16200
+    cpf = size // (2 * (mod + 1))
+    frames = c.size // cpf
+    out = np.zeros((frames, size), np.int8)
+    sums = np.zeros(3, np.float32)
+    fn = oracle().ora_demap
+    fn.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float]
+    r = fn(mod, fec_type, code_rate, rotation, c.ctypes.data, c.size, out.ctypes.data, sums.ctypes.data, precision_override)
+    assert r == frames
+    return out, sums, c
+
+
+def ora_cell_perm(num_blocks, cells_per_fec):
+    p = np.zeros(num_blocks * cells_per_fec, np.int32)
+    oracle().ora_cell_perm(num_blocks, cells_per_fec, p.ctypes.data_as(_ip))
+    return p
+
+
+class OraTi(object):
+    def __init__(self, cells_per_fec, num_blocks_max):
+        o = oracle()
+        o.ora_ti_create.restype = ctypes.c_void_p
+        o.ora_ti_begin.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        o.ora_ti_push.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        o.ora_ti_destroy.argtypes = [ctypes.c_void_p]
+        self._o, self._h = o, o.ora_ti_create(cells_per_fec, num_blocks_max)
+
+    def begin(self, num_blocks):
+        self._o.ora_ti_begin(self._h, num_blocks)
+
+    def push(self, cells, out):
+        cells = np.ascontiguousarray(cells, np.complex64)
+        return self._o.ora_ti_push(self._h, cells.ctypes.data, cells.size, out.ctypes.data)
+
+    def __del__(self):
+        self._o.ora_ti_destroy(self._h)
