@@ -112,6 +112,44 @@ int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
 int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
 int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
 
+/* ---------------------------------------------------------------- OFDM side: FFT and data-symbol equaliser ----------
+ * Mode arguments are the reference's dvbt2_parameters fields (src/DVB_T2/dvbt2_definition.h:215-248): fft_mode
+ * (dvbt2_fft_mode_t: FFTSIZE_16K = 4, FFTSIZE_32K = 5, and their _T2GI twins 11 / 7), carrier_mode (0 normal, 1 extended),
+ * pilot_pattern (PP1..PP8 = 0..7), guard_interval_mode (dvbt2_guardinterval_t), papr_mode (dvbt2_papr_t), n_data
+ * (NUM_DATA_SYMBOLS of L1-pre). Supported: 16K and 32K, SISO -- the reference's own scope (README.md:17-23).
+ *
+ * t2gpu_fft_execute replaces  complex* fast_fourier_transform::execute()  (src/DSP/fast_fourier_transform.h:62-70): forward
+ * DFT of fft_size complex samples per symbol (guard interval already removed), output fft-shifted (DC at fft_size/2),
+ * batched over n_symbols symbols laid out back to back (complex float, re/im interleaved).
+ *
+ * t2gpu_eq_data_execute replaces  complex* data_symbol::execute(int idx_symbol, complex* ofdm_cell, float& sample_rate_offset,
+ * float& phase_offset)  (src/DVB_T2/data_symbol.h:31-32, data_symbol.cpp:108-335): pilot-based channel estimate, per-carrier
+ * equalisation and frequency de-interleaving of one data symbol: fft_size shifted FFT bins in, c_data cells out (returned
+ * count), plus the two synchronisation feedback values. idx_symbol counts the symbols of the T2 frame after P1 (P2 = 0).
+ * The _dev form takes a batch: symbols [n][fft_size], d_symbol_index[n], cells [n][c_data], sync [n][2] = (phase_offset,
+ * sample_rate_offset) per symbol (may be NULL). */
+typedef struct t2gpu_ofdm t2gpu_ofdm;
+t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                              int n_data, int max_symbols, int device);
+void t2gpu_ofdm_destroy(t2gpu_ofdm *h);
+int t2gpu_fft_execute_dev(t2gpu_ofdm *h, const float *d_in, float *d_out, int n_symbols, void *stream);
+int t2gpu_fft_execute(t2gpu_ofdm *h, const float *in, float *out, int n_symbols);
+int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32_t *d_symbol_index, int n_symbols,
+                              float *d_cells, float *d_sync, void *stream);
+int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
+                          float *phase_offset);
+/* host only: {fft_size, k_total, k_ext, k_offset, l_nulls, c_p2, c_data, n_fc, c_fc, l_fc, len_frame, guard_interval_size}
+ * (dvbt2_{p2,bwt_ext,data}_parameters_init, src/DVB_T2/dvbt2_definition.cpp:20-648) */
+int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,
+                         int *out12);
+/* host only: carrier-type map (dvbt2_carrier_type_t values) and signed pilot reference of symbol idx_symbol, k_total entries
+ * (pilot_generator, src/DVB_T2/pilot_generator.cpp:69-132,2093-2166); receiver frequency de-interleaver tables, kind 0 = P2,
+ * 1 = data, 2 = frame closing (address_freq_deinterleaver.cpp:136-209). Return the number of entries. */
+int t2gpu_table_symbol_carriers(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                                int n_data, int idx_symbol, uint8_t *map, float *refer);
+int t2gpu_table_freq_deint(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,
+                           int kind, int32_t *h_even, int32_t *h_odd);
+
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
  * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),

@@ -9,5 +9,6 @@ from ._lib import lib, T2GpuError, library_path  # noqa: F401
 from .ldpc import ldpc_decoder, FECFRAME_SHORT, FEC_FRAME_NORMAL, C1_2, C3_5, C2_3, C3_4, C4_5, C5_6  # noqa: F401
 
 from .fec import llr_demapper, time_deinterleaver, bch_decoder  # noqa: F401
+from .ofdm import t2_ofdm  # noqa: F401
 
-__all__ = ["lib", "T2GpuError", "library_path", "ldpc_decoder", "llr_demapper", "time_deinterleaver", "bch_decoder"]
+__all__ = ["lib", "T2GpuError", "library_path", "ldpc_decoder", "llr_demapper", "time_deinterleaver", "bch_decoder", "t2_ofdm"]

@@ -44,6 +44,15 @@ PROTOTYPES = {
     "t2gpu_ti_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_bch_descramble_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "t2gpu_ofdm_create": (_vp, [ctypes.c_int] * 8),
+    "t2gpu_ofdm_destroy": (None, [_vp]),
+    "t2gpu_fft_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_fft_execute": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    "t2gpu_eq_data_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_eq_data_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "t2gpu_ofdm_mode_info": (ctypes.c_int, [ctypes.c_int] * 6 + [_vp]),
+    "t2gpu_table_symbol_carriers": (ctypes.c_int, [ctypes.c_int] * 7 + [_vp, _vp]),
+    "t2gpu_table_freq_deint": (ctypes.c_int, [ctypes.c_int] * 7 + [_vp, _vp]),
     "t2gpu_table_bitdeint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "t2gpu_table_cell_deint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "t2gpu_table_bb_prbs": (ctypes.c_int, [_vp, ctypes.c_int]),

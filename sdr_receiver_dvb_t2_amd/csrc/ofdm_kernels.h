@@ -1,0 +1,26 @@
+// ofdm_kernels.h -- launch interface of the OFDM-side kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ofdm_tables.h"
+
+namespace t2gpu {
+
+// twiddle[m] = exp(-j*2*pi*m/N), m in [0, N)
+hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
+                      hipStream_t s);
+
+struct EqParams {
+    int fft_size, l_nulls, k_total, c_data, n_p2, max_seg;
+    float amp_sp, amp_cp;
+    const uint8_t *map;        // [rows][k_total] carrier types of every data symbol of the frame
+    const float *refer;        // [rows][k_total] signed pilot reference
+    const int4 *segs;          // [rows][max_seg] (left pilot, right pilot, first de-interleaver index, data cells)
+    const int32_t *seg_count;  // [rows]
+    const int32_t *h_even, *h_odd;
+    const float *lut_sin, *lut_cos;   // 65536-entry tables of DSP/fast_math.h
+};
+hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
+                          float4 *pilot_scratch, float2 *sync, hipStream_t s);
+
+}  // namespace t2gpu

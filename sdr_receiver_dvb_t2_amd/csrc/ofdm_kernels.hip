@@ -1,0 +1,275 @@
+// ofdm_kernels.hip -- OFDM-side kernels for gfx950: batched 32K / 16K forward FFT with fftshift, and the data-symbol
+// channel estimator / equaliser fused with the frequency de-interleaver. HBM-bound streaming work; no matrix cores.
+#include "ofdm_kernels.h"
+
+// data_symbol.cpp arithmetic is restated operation for operation (the reference is built without FMA)
+#pragma clang fp contract(off)
+
+namespace t2gpu {
+
+// ====================================================================================================== FFT
+// Replaces fast_fourier_transform::execute (/root/reference/src/DSP/fast_fourier_transform.h:62-70): forward complex DFT
+// (FFTW3f there), unnormalised, followed by the two half-buffer memcpys that put DC at index N/2.
+//
+// One workgroup transforms one symbol in a single pass over HBM (read N, write N complex floats): the N = 32*32*R points
+// live in registers (32 per lane), three in-register radix-32 / radix-R stages are separated by two all-to-all
+// exchanges through LDS (real and imaginary planes one after the other: 128 KiB each for 32K), twiddles come from an
+// L2-resident table of W_N^m. Lane-to-address maps are chosen so that every global access of a wavefront is one
+// contiguous 512-byte run and every LDS access is bank-conflict free (row pitch 33).
+struct cf { float x, y; };
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// in-register radix-2 decimation-in-frequency FFT of R points (R = 32 or 16); output in bit-reversed order
+template <int R>
+__device__ __forceinline__ void fft_reg(cf (&v)[32])
+{
+    constexpr float TW_C[16] = {1.0f, 0.98078528040323f, 0.92387953251129f, 0.83146961230255f, 0.70710678118655f,
+                                0.55557023301960f, 0.38268343236509f, 0.19509032201613f, 0.0f, -0.19509032201613f,
+                                -0.38268343236509f, -0.55557023301960f, -0.70710678118655f, -0.83146961230255f,
+                                -0.92387953251129f, -0.98078528040323f};
+    constexpr float TW_S[16] = {0.0f, 0.19509032201613f, 0.38268343236509f, 0.55557023301960f, 0.70710678118655f,
+                                0.83146961230255f, 0.92387953251129f, 0.98078528040323f, 1.0f, 0.98078528040323f,
+                                0.92387953251129f, 0.83146961230255f, 0.70710678118655f, 0.55557023301960f,
+                                0.38268343236509f, 0.19509032201613f};          // W_32^m = C[m] - j S[m]
+#pragma unroll
+    for (int half = R / 2; half >= 1; half >>= 1) {
+#pragma unroll
+        for (int base = 0; base < R; base += 2 * half) {
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const cf a = v[base + i], b = v[base + i + half];
+                v[base + i] = {a.x + b.x, a.y + b.y};
+                const cf d = {a.x - b.x, a.y - b.y};
+                const int m = i * (16 / half);                                   // exponent of W_32
+                v[base + i + half] = (m == 0) ? d : cmul(d, cf{TW_C[m], -TW_S[m]});
+            }
+        }
+    }
+}
+template <int R> __device__ __forceinline__ constexpr int bitrev(int i)
+{
+    int r = 0;
+    for (int b = 1, s = R >> 1; s >= 1; b <<= 1, s >>= 1) if (i & b) r |= s;
+    return r;
+}
+
+// T2 = 32: N = 32768, 1024 threads. T2 = 16: N = 16384, 512 threads.
+template <int T2>
+__global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                               const float2 *__restrict__ twiddle, int n_symbols)
+{
+    constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    for (int sym = blockIdx.x; sym < n_symbols; sym += gridDim.x) {
+        const float2 *x = in + (size_t)sym * N;
+        float2 *y = out + (size_t)sym * N;
+        cf v[32];
+        // ---- stage A: thread t holds x[t + T*j]; 32-point DFT over j -> index k1 (bit-reversed in registers)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { const float2 a = x[tid + T * j]; v[j] = {a.x, a.y}; }
+        fft_reg<32>(v);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {                       // twiddle W_N^(t*k1), k1 = bitrev(r)
+            const int k1 = bitrev<32>(r);
+            if (k1) { const float2 w = twiddle[(tid * k1) & (N - 1)]; v[r] = cmul(v[r], cf{w.x, w.y}); }
+        }
+        // ---- exchange 1: thread (k1, t1) := id k1*T2 + t1 collects y_k1[t1 + T2*t2], t2 = 0..31
+        cf u[32];
+        const int k1n = tid / T2, t1n = tid % T2;
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) lds[bitrev<32>(r) * T + tid] = plane ? v[r].y : v[r].x;
+            __syncthreads();
+#pragma unroll
+            for (int t2 = 0; t2 < 32; ++t2) {
+                const float f = lds[k1n * T + t1n + T2 * t2];
+                if (plane) u[t2].y = f; else u[t2].x = f;
+            }
+        }
+        // ---- stage B: 32-point DFT over t2 -> q1; twiddle W_T^(t1*q1) = W_N^(32*t1*q1)
+        fft_reg<32>(u);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int q1 = bitrev<32>(r);
+            if (q1) { const float2 w = twiddle[(32 * t1n * q1) & (N - 1)]; u[r] = cmul(u[r], cf{w.x, w.y}); }
+        }
+        // ---- exchange 2: rows (q1, k1) of T2 values over t1, pitch 33. New thread id' -> pairs (q1, k1) with k1 fastest:
+        //      32K: one pair per thread (q1 = id'/32, k1 = id'%32), 32 values; 16K: two pairs per thread, 16 values each.
+        cf w2[32];
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) lds[(bitrev<32>(r) * 32 + k1n) * PITCH + t1n] = plane ? u[r].y : u[r].x;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const int pair = (T2 == 32) ? tid : tid + T * (e / T2);          // (q1, k1) pair index = q1*32 + k1
+                const float f = lds[pair * PITCH + (e % T2)];
+                if (plane) w2[e].y = f; else w2[e].x = f;
+            }
+        }
+        // ---- stage C: T2-point DFT over t1 -> q2; output bin k = k1 + 32*q1 + 1024*q2, stored fft-shifted
+        if (T2 == 32) {
+            fft_reg<32>(w2);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int k = tid + 1024 * bitrev<32>(r);                         // tid = q1*32 + k1 = k1 + 32*q1
+                const int ks = (k + N / 2) & (N - 1);
+                y[ks] = make_float2(w2[r].x, w2[r].y);
+            }
+        } else {
+            cf a[32], b[32];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a[e] = w2[e]; b[e] = w2[16 + e]; }
+            fft_reg<16>(a);
+            fft_reg<16>(b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q2 = bitrev<16>(r);
+                const int ka = tid + 1024 * q2, kb = tid + T + 1024 * q2;        // second pair index = tid + 512
+                y[(ka + N / 2) & (N - 1)] = make_float2(a[r].x, a[r].y);
+                y[(kb + N / 2) & (N - 1)] = make_float2(b[r].x, b[r].y);
+            }
+        }
+    }
+}
+
+hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
+                      hipStream_t s)
+{
+    const int blocks = n_symbols < max_blocks ? n_symbols : max_blocks;
+    if (fft_size == 32768) {
+        const int lds_bytes = 32 * 1024 * 4 > 32 * 32 * 33 * 4 ? 32 * 1024 * 4 : 32 * 32 * 33 * 4;
+        static bool set = false;
+        if (!set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_fwd_shift_kernel<32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+            set = true;
+        }
+        hipLaunchKernelGGL(fft_fwd_shift_kernel<32>, dim3(blocks), dim3(1024), lds_bytes, s, in, out, twiddle, n_symbols);
+    } else if (fft_size == 16384) {
+        const int lds_bytes = 32 * 32 * 33 * 4;      // >= 32*512*4
+        static bool set = false;
+        if (!set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_fwd_shift_kernel<16>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+            set = true;
+        }
+        hipLaunchKernelGGL(fft_fwd_shift_kernel<16>, dim3(blocks), dim3(512), lds_bytes, s, in, out, twiddle, n_symbols);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ====================================================================================================== equaliser
+// Replaces data_symbol::execute (/root/reference/src/DVB_T2/data_symbol.cpp:108-335). Between two consecutive pilots the
+// reference interpolates phase and amplitude linearly by repeated float addition and de-rotates every data cell with a
+// LUT cos/sin divided by the amplitude; segments between pilots are independent, so one lane walks one segment with
+// exactly the reference's sequence of float operations. The frequency de-interleaver (out[h[d]]) is fused in.
+__device__ __forceinline__ float atan2_approx_dev(float y, float x)         // DSP/fast_math.h:61-81
+{
+    const float PI = 3.14159274101257324219f, PI_2 = 1.57079637050628662109f;
+    if (x == 0.0f) return y > 0.0f ? PI_2 : -PI_2;
+    if (y == 0.0f) return x > 0.0f ? 0.0f : -PI;
+    const float abs_x = fabsf(x), abs_y = fabsf(y);
+    const bool min_x = abs_x < abs_y;
+    const float a = min_x ? abs_x / abs_y : abs_y / abs_x;
+    const float s = a * a;
+    float r = ((-4.6496475e-2f * s + 1.5931422e-1f) * s - 3.2762276e-1f) * s * a + a;
+    if (min_x) r = PI_2 - r;
+    if (x < 0.0f) r = PI - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+struct PilotEst { float angle, amp, er, ei; };
+
+__device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, float amp_pilot)
+{
+    PilotEst p;
+    p.er = cell.x * refer; p.ei = cell.y * refer;                              // est_pilot = cell * pilot_refer
+    p.angle = atan2_approx_dev(p.ei, p.er);
+    p.amp = sqrtf(cell.x * cell.x + cell.y * cell.y) / amp_pilot;              // sqrt(norm(cell)) / amp_pilot
+    return p;
+}
+
+__global__ __launch_bounds__(128) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
+                                                     const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
+                                                     float4 *__restrict__ pilot_scratch)
+{
+    const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
+    const float PI = 3.14159274101257324219f;
+    const int b = blockIdx.y;                                                   // symbol of the batch
+    const int idx_symbol = symbol_index[b];                                     // position in the T2 frame (P2 = 0)
+    const int row = idx_symbol - p.n_p2;                                        // data-symbol table row
+    const int nseg = p.seg_count[row];
+    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= nseg) return;
+    const float2 *cell = symbols + (size_t)b * p.fft_size + p.l_nulls;
+    const uint8_t *map = p.map + (size_t)row * p.k_total;
+    const float *refer = p.refer + (size_t)row * p.k_total;
+    const int32_t *h = (idx_symbol & 1) ? p.h_even : p.h_odd;                   // data_symbol.cpp:148-149
+    float2 *o = out + (size_t)b * p.c_data;
+    const int4 sg = p.segs[(size_t)row * p.max_seg + seg];                      // left pilot, right pilot, d start, data count
+    const int pl = sg.x, pr = sg.y, n = sg.w;
+    int d = sg.z;
+    // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED)
+    const PilotEst L = pilot_estimate(cell[pl], refer[pl], map[pl] == T2_CONTINUAL ? p.amp_cp : p.amp_sp);
+    const PilotEst R = pilot_estimate(cell[pr], refer[pr], map[pr] == T2_CONTINUAL ? p.amp_cp : p.amp_sp);
+    float dif_angle = R.angle - L.angle;
+    if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                      // as written in the reference (:189-191)
+    else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
+    const float delta_angle = dif_angle / (float)(n + 1);
+    const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
+    float angle_est = L.angle, amp_est = L.amp;
+    for (int i = pl + 1; i < pr; ++i) {
+        if (map[i] != T2_DATA) continue;                                        // reserved tones / the unused centre pilot
+        angle_est += delta_angle;
+        amp_est += delta_amp;
+        const int li = (int)(angle_est * K_TABLE + 32767) & 65535;
+        const float dr = p.lut_cos[li] / amp_est, di = p.lut_sin[li] / amp_est;
+        const float2 c = cell[i];
+        o[h[d]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);        // buffer_cell[j] * conj(derotate)
+        ++d;
+    }
+    // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
+    float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
+    if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);                  // first pilot: no angle term (:153-162)
+    ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
+}
+
+// phase_offset = atan2(sum_pilot_2) + atan2(sum_pilot_1), sample_rate_offset = sum_angle_2 - sum_angle_1 (:319-324)
+__global__ void eq_sync_kernel(EqParams p, const int32_t *__restrict__ symbol_index, const float4 *__restrict__ pilot_scratch,
+                               float2 *__restrict__ sync, int n_symbols)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_symbols) return;
+    const int nseg = p.seg_count[symbol_index[b] - p.n_p2];
+    const float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
+    float s1r = 0, s1i = 0, s2r = 0, s2i = 0, a1 = 0, a2 = 0;
+    s1r += ps[0].x; s1i += ps[0].y;
+    for (int k = 1; k <= nseg; ++k) {
+        const float4 v = ps[k];
+        if (v.w == 0.0f) { s1r += v.x; s1i += v.y; a1 += v.z; }
+        else { s2r += v.x; s2i += v.y; a2 += v.z; }
+    }
+    sync[b] = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
+}
+
+hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
+                          float4 *pilot_scratch, float2 *sync, hipStream_t s)
+{
+    dim3 grid((p.max_seg + 127) / 128, n_symbols);
+    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(128), 0, s, p, symbols, symbol_index, out, pilot_scratch);
+    if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3((n_symbols + 63) / 64), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
+    return hipGetLastError();
+}
+
+}  // namespace t2gpu

@@ -1,0 +1,236 @@
+// t2gpu_ofdm.cpp -- C-ABI of the OFDM-side stages (include/t2gpu.h): batched FFT + fftshift, data-symbol equaliser +
+// frequency de-interleaver, and the host-only mode tables behind them. Compute is in ofdm_kernels.hip; no CPU fallback.
+#define _GNU_SOURCE
+#include "../../include/t2gpu.h"
+#include "ofdm_kernels.h"
+#include "ofdm_tables.h"
+#include "t2gpu_common.h"
+#include <cmath>
+#include <vector>
+
+using namespace t2gpu;
+
+static bool mode_from_args(T2Mode &m, int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                           int n_data)
+{
+    m = T2Mode();
+    m.fft_mode = fft_mode; m.carrier_mode = carrier_mode; m.pilot_pattern = pilot_pattern;
+    m.guard_interval_mode = guard_interval_mode; m.papr_mode = papr_mode; m.n_data = n_data;
+    if (n_data < 1 || n_data > 2098) return false;
+    return t2_mode_init(m);
+}
+
+extern "C" int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                                    int n_data, int *out12)
+{
+    T2Mode m;
+    if (!out12 || !mode_from_args(m, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data)) {
+        set_error("t2gpu_ofdm_mode_info: unsupported mode (16K / 32K SISO only)");
+        return -1;
+    }
+    const int v[12] = {m.fft_size, m.k_total, m.k_ext, m.k_offset, m.l_nulls, m.c_p2, m.c_data, m.n_fc, m.c_fc, m.l_fc,
+                       m.len_frame, m.guard_interval_size};
+    for (int i = 0; i < 12; ++i) out12[i] = v[i];
+    return 0;
+}
+
+extern "C" int t2gpu_table_symbol_carriers(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode,
+                                           int papr_mode, int n_data, int idx_symbol, uint8_t *map, float *refer)
+{
+    T2Mode m;
+    if (!map || !refer || !mode_from_args(m, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data) ||
+        idx_symbol < 0 || idx_symbol >= m.len_frame) {
+        set_error("t2gpu_table_symbol_carriers: bad arguments");
+        return -1;
+    }
+    std::vector<uint8_t> mp; std::vector<float> rf;
+    t2_symbol_carriers(m, idx_symbol, mp, rf);
+    std::copy(mp.begin(), mp.end(), map);
+    std::copy(rf.begin(), rf.end(), refer);
+    return m.k_total;
+}
+
+extern "C" int t2gpu_table_freq_deint(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                                      int n_data, int kind, int32_t *h_even, int32_t *h_odd)
+{
+    T2Mode m;
+    if (!h_even || !h_odd || kind < 0 || kind > 2 ||
+        !mode_from_args(m, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data)) {
+        set_error("t2gpu_table_freq_deint: bad arguments");
+        return -1;
+    }
+    std::vector<int32_t> he, ho;
+    t2_freq_deint(m, kind, he, ho);
+    std::copy(he.begin(), he.end(), h_even);
+    std::copy(ho.begin(), ho.end(), h_odd);
+    return (int)he.size();
+}
+
+struct t2gpu_ofdm {
+    T2Mode m;
+    int device = 0, max_symbols = 0, rows = 0, num_cu = 256;
+    EqParams eq{};
+    float2 *d_twiddle = nullptr;
+    uint8_t *d_map = nullptr;
+    float *d_refer = nullptr, *d_lut = nullptr;
+    int4 *d_segs = nullptr;
+    int32_t *d_seg_count = nullptr, *d_h_even = nullptr, *d_h_odd = nullptr;
+    float4 *d_pilot_scratch = nullptr;
+    // host-call staging
+    float2 *d_in = nullptr, *d_out = nullptr, *d_sync = nullptr;
+    int32_t *d_index = nullptr;
+};
+
+extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
+                                         int n_data, int max_symbols, int device)
+{
+    T2Mode m;
+    if (max_symbols < 1 || !mode_from_args(m, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data)) {
+        set_error("t2gpu_ofdm_create: unsupported mode (16K / 32K SISO only) or bad arguments");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+        set_error("t2gpu_ofdm_create: no usable HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    t2gpu_ofdm *h = new t2gpu_ofdm();
+    h->m = m; h->device = device; h->max_symbols = max_symbols;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+    const int N = m.fft_size, K = m.k_total;
+    // FFT twiddles W_N^m in double, stored as float
+    std::vector<float2> tw(N);
+    for (int i = 0; i < N; ++i) {
+        const double a = -2.0 * M_PI * (double)i / (double)N;
+        tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    // LUT of DSP/fast_math.h:27-42 as the reference binary fills it (-Ofast: i * (1/k) in float, one sincosf)
+    std::vector<float> lut(2 * 65536, 0.0f);
+    {
+        const float k_table = 32767.0f / (2.0f * 3.14159274101257324219f);
+        const float rk = 1.0f / k_table;
+        for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
+    }
+    // per data symbol: carrier map, pilot reference, pilot-to-pilot segments
+    const int rows = m.n_data - m.l_fc;          // frame-closing symbol is handled by its own stage
+    h->rows = rows;
+    std::vector<uint8_t> map((size_t)rows * K);
+    std::vector<float> refer((size_t)rows * K);
+    std::vector<std::vector<int4>> segs(rows);
+    int max_seg = 0;
+    for (int r = 0; r < rows; ++r) {
+        std::vector<uint8_t> mp; std::vector<float> rf;
+        t2_symbol_carriers(m, m.n_p2 + r, mp, rf);
+        std::copy(mp.begin(), mp.end(), map.begin() + (size_t)r * K);
+        std::copy(rf.begin(), rf.end(), refer.begin() + (size_t)r * K);
+        int left = 0, d = 0, n = 0;
+        for (int k = 1; k < K; ++k) {
+            const bool pilot = (mp[k] == T2_SCATTERED || mp[k] == T2_CONTINUAL) && k != K / 2;   // centre pilot unused (:224-256)
+            if (mp[k] == T2_DATA) ++n;
+            if (pilot) {
+                segs[r].push_back(make_int4(left, k, d, n));
+                d += n; n = 0; left = k;
+            }
+        }
+        if (d != m.c_data) { set_error("carrier map does not hold c_data data cells"); delete h; return nullptr; }
+        max_seg = std::max(max_seg, (int)segs[r].size());
+    }
+    std::vector<int4> segflat((size_t)rows * max_seg, make_int4(0, 0, 0, 0));
+    std::vector<int32_t> segcount(rows);
+    for (int r = 0; r < rows; ++r) {
+        segcount[r] = (int32_t)segs[r].size();
+        std::copy(segs[r].begin(), segs[r].end(), segflat.begin() + (size_t)r * max_seg);
+    }
+    std::vector<int32_t> he, ho;
+    t2_freq_deint(m, 1, he, ho);
+    bool ok = true;
+    auto up = [&](auto **dst, const void *src, size_t bytes) {
+        ok = ok && hip_ok(hipMalloc((void **)dst, bytes), "hipMalloc") && hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+    };
+    up(&h->d_twiddle, tw.data(), tw.size() * sizeof(float2));
+    up(&h->d_lut, lut.data(), lut.size() * 4);
+    up(&h->d_map, map.data(), map.size());
+    up(&h->d_refer, refer.data(), refer.size() * 4);
+    up(&h->d_segs, segflat.data(), segflat.size() * sizeof(int4));
+    up(&h->d_seg_count, segcount.data(), segcount.size() * 4);
+    up(&h->d_h_even, he.data(), he.size() * 4);
+    up(&h->d_h_odd, ho.data(), ho.size() * 4);
+    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_seg + 1) * sizeof(float4)), "hipMalloc");
+    if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
+    h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, h->d_map, h->d_refer, h->d_segs,
+                     h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut, h->d_lut + 65536};
+    return h;
+}
+
+extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
+{
+    if (!h) return;
+    hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
+    hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
+    hipFree(h->d_sync); hipFree(h->d_index);
+    delete h;
+}
+
+extern "C" int t2gpu_fft_execute_dev(t2gpu_ofdm *h, const float *d_in, float *d_out, int n_symbols, void *stream)
+{
+    if (!h || !d_in || !d_out || n_symbols < 1) { set_error("t2gpu_fft_execute_dev: bad arguments"); return -1; }
+    T2_HIP(launch_fft(h->m.fft_size, reinterpret_cast<const float2 *>(d_in), reinterpret_cast<float2 *>(d_out), h->d_twiddle, n_symbols,
+                      h->num_cu, (hipStream_t)stream));
+    return 0;
+}
+
+static int ensure_staging(t2gpu_ofdm *h)
+{
+    if (h->d_in) return 0;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_symbols * h->m.fft_size * sizeof(float2)));
+    T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_symbols * h->m.fft_size * sizeof(float2)));
+    T2_HIP(hipMalloc(&h->d_sync, (size_t)h->max_symbols * sizeof(float2)));
+    T2_HIP(hipMalloc(&h->d_index, (size_t)h->max_symbols * 4));
+    return 0;
+}
+
+extern "C" int t2gpu_fft_execute(t2gpu_ofdm *h, const float *in, float *out, int n_symbols)
+{
+    if (!h || !in || !out || n_symbols < 1 || n_symbols > h->max_symbols) { set_error("t2gpu_fft_execute: bad arguments"); return -1; }
+    if (ensure_staging(h)) return -1;
+    const size_t bytes = (size_t)n_symbols * h->m.fft_size * sizeof(float2);
+    T2_HIP(hipMemcpy(h->d_in, in, bytes, hipMemcpyHostToDevice));
+    if (t2gpu_fft_execute_dev(h, (const float *)h->d_in, (float *)h->d_out, n_symbols, nullptr)) return -1;
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(out, h->d_out, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32_t *d_symbol_index, int n_symbols,
+                                         float *d_cells, float *d_sync, void *stream)
+{
+    if (!h || !d_symbols || !d_symbol_index || !d_cells || n_symbols < 1 || n_symbols > h->max_symbols) {
+        set_error("t2gpu_eq_data_execute_dev: bad arguments");
+        return -1;
+    }
+    T2_HIP(launch_eq_data(h->eq, reinterpret_cast<const float2 *>(d_symbols), d_symbol_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+    return h->m.c_data;
+}
+
+extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
+                                     float *phase_offset)
+{
+    if (!h || !ofdm_cell || !cells || idx_symbol < h->m.n_p2 || idx_symbol >= h->m.n_p2 + h->rows) {
+        set_error("t2gpu_eq_data_execute: bad arguments");
+        return -1;
+    }
+    if (ensure_staging(h)) return -1;
+    T2_HIP(hipMemcpy(h->d_in, ofdm_cell, (size_t)h->m.fft_size * sizeof(float2), hipMemcpyHostToDevice));
+    T2_HIP(hipMemcpy(h->d_index, &idx_symbol, 4, hipMemcpyHostToDevice));
+    if (t2gpu_eq_data_execute_dev(h, (const float *)h->d_in, h->d_index, 1, (float *)h->d_out, (float *)h->d_sync, nullptr) < 0) return -1;
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(cells, h->d_out, (size_t)h->m.c_data * sizeof(float2), hipMemcpyDeviceToHost));
+    float s[2];
+    T2_HIP(hipMemcpy(s, h->d_sync, 8, hipMemcpyDeviceToHost));
+    if (phase_offset) *phase_offset = s[0];
+    if (sample_rate_offset) *sample_rate_offset = s[1];
+    return h->m.c_data;
+}

@@ -1,0 +1,77 @@
+"""Host-side mirrors of the reference's OFDM-side stage objects for the supported FFT sizes (16K / 32K, SISO).
+
+``fast_fourier_transform`` /root/reference/src/DSP/fast_fourier_transform.h:27-72  (init :54-60, execute :62-70)
+``data_symbol``            /root/reference/src/DVB_T2/data_symbol.h:25-66         (init :30, execute :31-32)
+
+Both share one device context (tables, twiddles): ``t2_ofdm``. The reference's objects take their mode from a
+``dvbt2_parameters`` struct filled while acquiring; here the same fields are constructor arguments."""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check, T2GpuError
+
+FFTSIZE_16K, FFTSIZE_32K = 4, 5          # dvbt2_fft_mode_t (dvbt2_definition.h:116-126)
+
+
+class t2_ofdm(object):
+    INFO = ("fft_size", "k_total", "k_ext", "k_offset", "l_nulls", "c_p2", "c_data", "n_fc", "c_fc", "l_fc", "len_frame",
+            "guard_interval_size")
+
+    def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, max_symbols=64, device=0):
+        self._l = lib()
+        self.args = (fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data)
+        info = (ctypes.c_int * 12)()
+        check(self._l.t2gpu_ofdm_mode_info(*self.args, info), "t2gpu_ofdm_mode_info")
+        for k, v in zip(self.INFO, info):
+            setattr(self, k, v)
+        self.n_p2 = 1
+        self._h = self._l.t2gpu_ofdm_create(*self.args, max_symbols, device)
+        if not self._h:
+            raise T2GpuError("t2gpu_ofdm_create: " + self._l.t2gpu_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.t2gpu_ofdm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- fast_fourier_transform::execute, batched
+    def fft_dev(self, x):
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-2:] == (self.fft_size, 2)
+        y = torch.empty_like(x)
+        check(self._l.t2gpu_fft_execute_dev(self._h, x.data_ptr(), y.data_ptr(), x.numel() // (2 * self.fft_size),
+                                            torch.cuda.current_stream(x.device).cuda_stream), "t2gpu_fft_execute_dev")
+        return y
+
+    def fft(self, x):
+        x = np.ascontiguousarray(x, np.complex64).reshape(-1, self.fft_size)
+        y = np.empty_like(x)
+        check(self._l.t2gpu_fft_execute(self._h, x.ctypes.data, y.ctypes.data, x.shape[0]), "t2gpu_fft_execute")
+        return y
+
+    # ---- data_symbol::execute, batched
+    def eq_data_dev(self, symbols, symbol_index):
+        import torch
+        n = symbols.shape[0]
+        assert symbols.is_cuda and symbols.dtype == torch.float32 and symbols.is_contiguous()
+        assert symbol_index.dtype == torch.int32 and symbol_index.numel() == n
+        cells = torch.empty((n, self.c_data, 2), dtype=torch.float32, device=symbols.device)
+        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device)
+        rc = self._l.t2gpu_eq_data_execute_dev(self._h, symbols.data_ptr(), symbol_index.data_ptr(), n, cells.data_ptr(),
+                                               sync.data_ptr(), torch.cuda.current_stream(symbols.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_eq_data_execute_dev")
+        return cells, sync
+
+    def eq_data(self, idx_symbol, ofdm_cell):
+        """Reference call shape: returns (cells complex64[c_data], sample_rate_offset, phase_offset)."""
+        x = np.ascontiguousarray(ofdm_cell, np.complex64).reshape(self.fft_size)
+        out = np.empty(self.c_data, np.complex64)
+        sro, pho = ctypes.c_float(), ctypes.c_float()
+        rc = self._l.t2gpu_eq_data_execute(self._h, idx_symbol, x.ctypes.data, out.ctypes.data, ctypes.byref(sro), ctypes.byref(pho))
+        if rc < 0:
+            check(rc, "t2gpu_eq_data_execute")
+        return out, sro.value, pho.value

@@ -195,3 +195,46 @@ class OraTi(object):
 
     def __del__(self):
         self._o.ora_ti_destroy(self._h)
+
+
+# ------------------------------------------------------------------------------------------------ OFDM side
+class OraMode(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("fft_mode", "carrier_mode", "pilot_pattern", "guard_interval_mode", "papr_mode", "n_data",
+                                            "is32k", "fft_size", "k_total", "k_ext", "k_offset", "l_nulls", "n_p2", "c_p2", "c_data",
+                                            "n_fc", "c_fc", "l_fc", "len_frame", "dx", "dy")] + \
+               [(n, ctypes.c_float) for n in ("amp_sp", "amp_cp", "amp_p2")]
+
+
+def ora_mode(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data):
+    m = OraMode(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data)
+    rc = oracle().ora_mode_init(ctypes.byref(m))
+    return m if rc == 0 else None
+
+
+def ora_symbol_carriers(m, idx_symbol):
+    mp = np.zeros(m.k_total, np.int32)
+    rf = np.zeros(m.k_total, np.float32)
+    oracle().ora_symbol_carriers(ctypes.byref(m), idx_symbol, mp.ctypes.data_as(_ip), rf.ctypes.data_as(_fp))
+    return mp, rf
+
+
+def ora_freq_deint(m, kind):
+    cells = [m.c_p2, m.c_data, m.n_fc][kind]
+    he, ho = np.zeros(cells, np.int32), np.zeros(cells, np.int32)
+    assert oracle().ora_freq_deint(ctypes.byref(m), kind, he.ctypes.data_as(_ip), ho.ctypes.data_as(_ip)) == cells
+    return he, ho
+
+
+def ora_data_symbol(m, idx_symbol, ofdm_cell):
+    """data_symbol::execute on one fft-shifted symbol (complex64[fft_size]) -> (cells complex64[c_data], phase_offset, sro)."""
+    mp, rf = ora_symbol_carriers(m, idx_symbol)
+    he, ho = ora_freq_deint(m, 1)
+    h = ho if idx_symbol % 2 == 0 else he
+    x = np.ascontiguousarray(ofdm_cell, np.complex64)
+    out = np.zeros(m.c_data, np.complex64)
+    sync = np.zeros(2, np.float32)
+    fn = oracle().ora_data_symbol
+    fn.argtypes = [ctypes.c_void_p] * 7
+    n = fn(ctypes.addressof(m), x.ctypes.data, mp.ctypes.data, rf.ctypes.data, h.ctypes.data, out.ctypes.data, sync.ctypes.data)
+    assert n == m.c_data, (n, m.c_data)
+    return out, float(sync[0]), float(sync[1])

@@ -1,0 +1,108 @@
+"""GPU tier: OFDM-side stages through the C ABI.
+
+FFT: the reference delegates to FFTW3f (binary dependency, not source in the reference tree). Pinned by
+tests/golden/fft_golden.npz, produced with the FFTW library the reference ships; FFTW3f itself deviates from the exact
+DFT by 4.5e-6 .. 6.6e-6 of the output rms (printed by make_fft_golden.py), so the tolerance against it and against a
+float64 DFT is max |error| <= 2e-5 * rms.
+Equaliser: restated float operation by float operation; the equalised cells must equal the oracle's bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "fft_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def golden_input(n):
+    k = np.arange(n, dtype=np.int64)
+    return (((k * 7919) % 251 - 125) / 64.0 + 1j * (((k * 104729) % 241 - 120) / 64.0)).astype(np.complex64)
+
+
+def rel_err(y, ref):
+    return np.abs(y - ref).max() / np.sqrt((np.abs(ref) ** 2).mean())
+
+
+@pytest.mark.parametrize("fft_mode,n", [(5, 32768), (4, 16384)])
+def test_fft_against_reference_fftw_and_dft(torch_cuda, fft_mode, n):
+    import sdr_receiver_dvb_t2_amd as pkg
+    ctx = pkg.t2_ofdm(fft_mode, 1, 6, 4, 0, 59, max_symbols=8)
+    x = golden_input(n)
+    y = ctx.fft(x)[0]                                                        # host-buffer entry point
+    assert rel_err(y, GOLD["fft_%d" % n]) < 2e-5
+    rng = np.random.Generator(np.random.PCG64(n))
+    xb = (rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))).astype(np.complex64)
+    xb[3] = 0; xb[3, 1] = 1.0                                                # impulse at n = 1: a pure phase ramp
+    yb = ctx.fft_dev(torch_cuda.from_numpy(xb.view(np.float32).reshape(5, n, 2)).cuda()).cpu().numpy()
+    yb = yb[..., 0] + 1j * yb[..., 1]
+    ref = np.fft.fftshift(np.fft.fft(xb.astype(np.complex128), axis=1), axes=1)
+    for b in range(5):
+        assert rel_err(yb[b], ref[b]) < 2e-5
+    ctx.close()
+
+
+def test_fft_batch_properties_full_size(torch_cuda):
+    """512 symbols of 32K (the batch size of the bench): Parseval and linearity hold for every symbol."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    torch = torch_cuda
+    n, nb = 32768, 512
+    ctx = pkg.t2_ofdm(5, 1, 6, 4, 0, 59, max_symbols=8)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn((nb, n, 2), device="cuda", generator=g)
+    b = torch.randn((nb, n, 2), device="cuda", generator=g)
+    fa, fb, fab = ctx.fft_dev(a), ctx.fft_dev(b), ctx.fft_dev(a + 2.0 * b)
+    ea = (a.double() ** 2).sum(dim=(1, 2)) * n
+    assert torch.allclose((fa.double() ** 2).sum(dim=(1, 2)), ea, rtol=1e-5)
+    lin = (fab - (fa + 2.0 * fb)).abs().amax() / fab.abs().amax()
+    assert float(lin) < 2e-5
+    ctx.close()
+
+
+def make_symbol(m, idx_symbol, seed, snr_db=25.0):
+    """One received data symbol after the FFT (fft-shifted): pilots per the carrier map, random unit-power data cells, a
+    smooth two-path channel with a common phase, AWGN."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mp, rf = ol.ora_symbol_carriers(m, idx_symbol)
+    k = np.arange(m.k_total)
+    tx = np.where(mp == 1, (rng.standard_normal(m.k_total) + 1j * rng.standard_normal(m.k_total)) / np.sqrt(2), rf.astype(np.complex128))
+    tx[mp == 4] = 0
+    chan = (1.0 + 0.35 * np.exp(-2j * np.pi * k * 37 / m.fft_size)) * np.exp(1j * (0.3 + seed * 0.7)) * (0.8 + 0.05 * seed)
+    sigma = np.sqrt(0.5 * 10 ** (-snr_db / 10))
+    rx = tx * chan + sigma * (rng.standard_normal(m.k_total) + 1j * rng.standard_normal(m.k_total))
+    full = np.zeros(m.fft_size, np.complex64)
+    full[m.l_nulls:m.l_nulls + m.k_total] = rx.astype(np.complex64)
+    return full
+
+
+@pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (5, 0, 3, 0, 0, 20), (5, 1, 1, 2, 2, 12), (4, 1, 6, 4, 0, 30), (4, 0, 0, 3, 0, 17),
+                                  (4, 1, 7, 1, 2, 40)])
+def test_equaliser_matches_oracle(torch_cuda, mode):
+    import sdr_receiver_dvb_t2_amd as pkg
+    torch = torch_cuda
+    m = ol.ora_mode(*mode)
+    ctx = pkg.t2_ofdm(*mode, max_symbols=16)
+    rows = m.n_data - m.l_fc
+    idxs = [1, 2, 3, 4, 5, 1 + (rows - 1), 1 + rows // 2, 2]
+    syms = np.stack([make_symbol(m, i, seed=s) for s, i in enumerate(idxs)])
+    cells, sync = ctx.eq_data_dev(torch.from_numpy(syms.view(np.float32).reshape(len(idxs), m.fft_size, 2)).cuda(),
+                                  torch.tensor(idxs, dtype=torch.int32, device="cuda"))
+    cells = cells.cpu().numpy(); sync = sync.cpu().numpy()
+    for b, i in enumerate(idxs):
+        want, pho, sro = ol.ora_data_symbol(m, i, syms[b])
+        got = cells[b, :, 0] + 1j * cells[b, :, 1]
+        assert np.array_equal(got.astype(np.complex64), want), (i, np.abs(got - want).max())
+        assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
+    # reference-shaped host call
+    got, sro, pho = ctx.eq_data(idxs[0], syms[0])
+    want, wpho, wsro = ol.ora_data_symbol(m, idxs[0], syms[0])
+    assert np.array_equal(got, want) and np.float32(sro) == np.float32(wsro) and np.float32(pho) == np.float32(wpho)
+    ctx.close()
