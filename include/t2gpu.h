@@ -82,6 +82,11 @@ int t2gpu_ldpc_status(t2gpu_ldpc *h);
 typedef struct t2gpu_demap t2gpu_demap;
 t2gpu_demap *t2gpu_demap_create(int mod, int fec_type, int code_rate, int rotation, int max_cells, int device);
 void t2gpu_demap_destroy(t2gpu_demap *h);
+/* saturate = 0 (default): the reference's int8 cast, which does not clamp for 16/64/256-QAM and wraps around once
+ * |LLR| exceeds 127 (llr_demapper.cpp:722-737; for 256-QAM in AWGN this happens on the outer constellation points at any
+ * SNR, because the hard-decision SNR estimate never drops below about 22 dB). saturate = 1 clamps instead -- an extension
+ * beyond the reference, off unless asked for. */
+int t2gpu_demap_configure(t2gpu_demap *h, int saturate);
 int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, int8_t *d_llr,
                             float *d_sums3 /* 3 floats on the device, or NULL */, void *stream);
 int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3 /* or NULL */);
@@ -112,6 +117,20 @@ int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
 int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
 int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
 
+/* ---------------------------------------------------------------- BBFRAME de-framing -> transport stream (host) -----
+ * Replaces  void bb_de_header::execute(int plp_id, l1_postsignalling, int len_in, uint8_t* in)  (src/DVB_T2/bb_de_header.h:59,
+ * bb_de_header.cpp:84-448) and set_out's need_plp (:500-525). in: the k_bch descrambled bits of one BBFRAME, one per byte.
+ * Sequential host code, as in the reference (TS packets and the normal-mode CRC-8 straddle BBFRAMEs); the reference writes
+ * the bytes to UDP 127.0.0.1:7654 or a file, here they are returned: the return value is the number of TS bytes placed in
+ * out (out_cap >= len_in/8 + 376), or -1 BBHEADER CRC-8 error (frame dropped, :108-113), -2 frame skipped (other PLP,
+ * :139-142, or SYNCD = 65535, :160-163), -3 bad arguments. *ts_errors counts packets flagged with TEI (normal mode).
+ * t2gpu_bbdh_mode: 0 normal mode, 1 high-efficiency mode of the last accepted frame. */
+typedef struct t2gpu_bbdh t2gpu_bbdh;
+t2gpu_bbdh *t2gpu_bbdh_create(int need_plp);
+void t2gpu_bbdh_destroy(t2gpu_bbdh *h);
+int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap, int *ts_errors);
+int t2gpu_bbdh_mode(const t2gpu_bbdh *h);
+
 /* ---------------------------------------------------------------- OFDM side: FFT and data-symbol equaliser ----------
  * Mode arguments are the reference's dvbt2_parameters fields (src/DVB_T2/dvbt2_definition.h:215-248): fft_mode
  * (dvbt2_fft_mode_t: FFTSIZE_16K = 4, FFTSIZE_32K = 5, and their _T2GI twins 11 / 7), carrier_mode (0 normal, 1 extended),
@@ -138,6 +157,10 @@ int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32
                               float *d_cells, float *d_sync, void *stream);
 int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
                           float *phase_offset);
+/* Equaliser + frequency de-interleaver part of  complex* p2_symbol::execute(...)  (src/DVB_T2/p2_symbol.h:42-44,
+ * p2_symbol.cpp:89-262) for the P2 symbols of n_symbols frames: [n][fft_size] in, [n][c_p2] cells out (returned count; the
+ * first 1840 + l1_post_size cells of each are L1 signalling, time_deinterleaver.cpp:296-300). L1 parsing is not done here. */
+int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream);
 /* host only: {fft_size, k_total, k_ext, k_offset, l_nulls, c_p2, c_data, n_fc, c_fc, l_fc, len_frame, guard_interval_size}
  * (dvbt2_{p2,bwt_ext,data}_parameters_init, src/DVB_T2/dvbt2_definition.cpp:20-648) */
 int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,

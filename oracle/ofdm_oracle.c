@@ -231,7 +231,7 @@ float ora_atan2_approx(float y, float x)
 
 /* ---- data_symbol::execute (data_symbol.cpp:108-335) ------------------------------------------------------------- */
 /* ofdm_cell: the fft-shifted symbol (fft_size complex, re/im interleaved); map/refer: this symbol's tables; h: h_odd when
- * idx_symbol is even, h_even when odd (caller picks, :148-149). out: c_data cells. sync[0] = phase_offset,
+ * idx_symbol is even, h_even when odd (caller picks, :148-149). out: c_data cells (c_p2 for a P2 symbol's tables). sync[0] = phase_offset,
  * sync[1] = sample_rate_offset. Returns the number of cells written. */
 int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *map, const float *refer, const int *h,
                     float *out, float *sync)
@@ -242,8 +242,8 @@ int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *m
     const float amp_sp = m->amp_sp, amp_cp = m->amp_cp;
     float angle = 0, delta_angle, angle_est, amp = 0, delta_amp, amp_est, dif_angle;
     float sum_angle_1 = 0, sum_angle_2 = 0, sp1r = 0, sp1i = 0, sp2r = 0, sp2i = 0;
-    float amp_pilot = amp_sp;
-    float *buf = (float *)malloc(sizeof(float) * 2 * (size_t)m->c_data + 16);
+    float amp_pilot = map[0] == P2CARRIER ? m->amp_p2 : amp_sp;
+    float *buf = (float *)malloc(sizeof(float) * 2 * (size_t)m->k_total + 16);
     int idx_data = 0, d = 0;
     {   /* first pilot */
         float cr = oc[0], ci = oc[1], pr = refer[0];
@@ -260,8 +260,11 @@ int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *m
             case DATA_CARRIER:
                 buf[2 * idx_data] = cr; buf[2 * idx_data + 1] = ci; ++idx_data;
                 break;
+            case P2CARRIER:                 /* p2_symbol.cpp:89-262: same estimator, every pilot has amplitude amp_p2 */
+                amp_pilot = m->amp_p2;
+                /* fallthrough */
             case CONTINUAL_CARRIER:
-                amp_pilot = amp_cp;
+                if (map[i] == CONTINUAL_CARRIER) amp_pilot = amp_cp;
                 /* fallthrough */
             case SCATTERED_CARRIER: {
                 float er = cr * pr, ei = ci * pr;

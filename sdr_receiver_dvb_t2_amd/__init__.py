@@ -10,5 +10,6 @@ from .ldpc import ldpc_decoder, FECFRAME_SHORT, FEC_FRAME_NORMAL, C1_2, C3_5, C2
 
 from .fec import llr_demapper, time_deinterleaver, bch_decoder  # noqa: F401
 from .ofdm import t2_ofdm  # noqa: F401
+from .chain import t2_chain  # noqa: F401
 
-__all__ = ["lib", "T2GpuError", "library_path", "ldpc_decoder", "llr_demapper", "time_deinterleaver", "bch_decoder", "t2_ofdm"]
+__all__ = ["lib", "T2GpuError", "library_path", "ldpc_decoder", "llr_demapper", "time_deinterleaver", "bch_decoder", "t2_ofdm", "t2_chain"]

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),
     "t2gpu_demap_destroy": (None, [_vp]),
+    "t2gpu_demap_configure": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demap_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp]),
     "t2gpu_demap_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ti_create": (_vp, [ctypes.c_int] * 4),
@@ -44,11 +45,16 @@ PROTOTYPES = {
     "t2gpu_ti_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_bch_descramble_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "t2gpu_bbdh_create": (_vp, [ctypes.c_int]),
+    "t2gpu_bbdh_destroy": (None, [_vp]),
+    "t2gpu_bbdh_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_bbdh_mode": (ctypes.c_int, [_vp]),
     "t2gpu_ofdm_create": (_vp, [ctypes.c_int] * 8),
     "t2gpu_ofdm_destroy": (None, [_vp]),
     "t2gpu_fft_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_fft_execute": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     "t2gpu_eq_data_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_data_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ofdm_mode_info": (ctypes.c_int, [ctypes.c_int] * 6 + [_vp]),
     "t2gpu_table_symbol_carriers": (ctypes.c_int, [ctypes.c_int] * 7 + [_vp, _vp]),

@@ -1,0 +1,113 @@
+"""demod -> TS chain over the C ABI: guard-removed OFDM symbols of whole T2 frames in, transport-stream bytes out.
+
+Mirrors the call sequence of the reference's pipeline objects for one PLP (TI type 0, one TI block per frame):
+``dvbt2_demodulator::symbol_acquisition`` (/root/reference/src/DVB_T2/dvbt2_demodulator.cpp:332-375: fft->execute, then
+p2_demodulator / data_demodulator ->execute) -> ``time_deinterleaver::execute`` -> ``llr_demapper::execute`` ->
+``ldpc_decoder::execute`` -> ``bch_decoder::execute`` -> ``bb_de_header::execute``. All stages but the last run on the GPU
+on one stream with device-resident buffers (torch tensors are the allocator, nothing is computed by torch); BBFRAME
+de-framing is host code in libt2gpu.so as it is host code in the reference. The mode (what L1-pre / L1-post signal) is
+given by the caller; P1 / L1 acquisition are not part of this class."""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check
+from .fec import bch_decoder, llr_demapper, time_deinterleaver
+from .ldpc import ldpc_decoder
+from .ofdm import t2_ofdm
+
+L1_PRE_CELL = 1840      # dvbt2_definition.h:58
+
+
+class t2_chain(object):
+    def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size,
+                 plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames=4, device=0, ldpc_group=32,
+                 ldpc_trials=25, saturate_llr=False):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.max_frames = max_frames
+        self.ofdm = t2_ofdm(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data,
+                            max_symbols=max_frames * (n_data + 1), device=device)
+        o = self.ofdm
+        self.n_sym = o.n_p2 + n_data - o.l_fc                   # symbols handled here (frame-closing symbol: not yet)
+        self.p2_skip = L1_PRE_CELL + l1_post_size               # time_deinterleaver.cpp:46,296-300
+        self.frame_cells = (o.c_p2 - self.p2_skip) + (self.n_sym - 1) * o.c_data
+        self.fec_size = 64800 if plp_fec_type == 1 else 16200
+        self.cells_per_fec = self.fec_size // (2 * (plp_mod + 1))
+        self.num_blocks = plp_num_blocks
+        assert plp_num_blocks * self.cells_per_fec <= self.frame_cells
+        self.ti = [time_deinterleaver(plp_mod, plp_fec_type, plp_num_blocks, device) for _ in range(max_frames)]
+        self.demap = llr_demapper(plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks * self.cells_per_fec, device,
+                                  saturate=saturate_llr)
+        self.ldpc = ldpc_decoder(plp_fec_type, plp_cod, max_frames=max_frames * plp_num_blocks + 64, device=device,
+                                 group=ldpc_group, trials=ldpc_trials)
+        self.bch = bch_decoder(plp_fec_type, plp_cod)
+        self.group = ldpc_group
+        self._l = lib()
+        self._bbdh = self._l.t2gpu_bbdh_create(0)
+        f32 = torch.float32
+        self.cells = torch.zeros((max_frames, self.frame_cells, 2), dtype=f32, device=self.dev)
+        self.p2_cells = torch.empty((max_frames, o.c_p2, 2), dtype=f32, device=self.dev)
+        self.ti_out = torch.zeros((max_frames, plp_num_blocks * self.cells_per_fec, 2), dtype=f32, device=self.dev)
+        self.llr = torch.empty((max_frames * plp_num_blocks + 64, self.fec_size), dtype=torch.int8, device=self.dev)
+        self.carry = 0                                           # FEC frames waiting for a full SIMD batch
+        idx = np.tile(np.arange(1, self.n_sym, dtype=np.int32), max_frames)
+        self.sym_index = torch.from_numpy(idx).to(self.dev)
+
+    def close(self):
+        if getattr(self, "_bbdh", None):
+            self._l.t2gpu_bbdh_destroy(self._bbdh)
+            self._bbdh = None
+
+    def demod_dev(self, symbols, flush=False):
+        """symbols: CUDA float32 [F][n_sym][fft_size][2], F <= max_frames. Returns (bits uint8 [frames][k_bch] on the
+        device, trials-left int32 per SIMD batch) for the FEC frames whose batch of `group` completed (all of them with
+        flush=True: the tail batch is then decoded short, which the reference never does)."""
+        torch = self.torch
+        o = self.ofdm
+        F = symbols.shape[0]
+        assert F <= self.max_frames and symbols.shape[1] == self.n_sym
+        spec = o.fft_dev(symbols.reshape(F * self.n_sym, o.fft_size, 2)).reshape(F, self.n_sym, o.fft_size, 2)
+        # P2: equalise, drop the L1 cells, PLP cells go to the head of the frame's cell stream
+        p2, _ = o.eq_p2_dev(spec[:, 0].contiguous())
+        self.cells[:F, :o.c_p2 - self.p2_skip] = p2[:, self.p2_skip:]
+        # data symbols: equalised cells land directly behind, symbol after symbol
+        data = spec[:, 1:].contiguous().reshape(F * (self.n_sym - 1), o.fft_size, 2)
+        cells, _ = o.eq_data_dev(data, self.sym_index[:F * (self.n_sym - 1)])
+        self.cells[:F, o.c_p2 - self.p2_skip:] = cells.reshape(F, (self.n_sym - 1) * o.c_data, 2)
+        n_ti = self.num_blocks * self.cells_per_fec
+        for f in range(F):
+            self.ti[f].l1_dyn(self.num_blocks)
+            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
+            assert done
+            llr, _ = self.demap.execute_dev(self.ti_out[f])
+            a = self.carry + f * self.num_blocks
+            self.llr[a:a + self.num_blocks] = llr
+        total = self.carry + F * self.num_blocks
+        ready = total if flush else (total // self.group) * self.group
+        if ready == 0:
+            self.carry = total
+            return None, None
+        bits, trials = self.ldpc.execute_dev(self.llr[:ready])
+        out = self.bch.execute_dev(bits)
+        rest = total - ready
+        if rest:
+            self.llr[:rest] = self.llr[ready:total].clone()
+        self.carry = rest
+        return out, trials
+
+    def ts_from_bits(self, bits_host, trials_host):
+        """BBFRAME bits of decoded FEC frames -> TS bytes; SIMD batches the LDPC gave up on (-1) are dropped as the
+        reference drops them (ldpc_decoder.cpp:264-268)."""
+        out = []
+        buf = np.zeros(bits_host.shape[1] // 8 + 400, np.uint8)
+        err = ctypes.c_int(0)
+        for i in range(bits_host.shape[0]):
+            if trials_host[i // self.group] < 0:
+                continue
+            n = self._l.t2gpu_bbdh_execute(self._bbdh, 0, bits_host.shape[1], bits_host[i].ctypes.data, buf.ctypes.data,
+                                           buf.size, ctypes.byref(err))
+            if n > 0:
+                out.append(buf[:n].copy())
+        return np.concatenate(out) if out else np.zeros(0, np.uint8)

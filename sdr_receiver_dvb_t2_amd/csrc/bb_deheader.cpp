@@ -1,0 +1,192 @@
+// bb_deheader.cpp -- host-side BBFRAME de-framing into transport-stream bytes (C-ABI t2gpu_bbdh_*).
+//
+// Replaces bb_de_header::execute (/root/reference/src/DVB_T2/bb_de_header.cpp:84-448; check_crc8_mode :70-82,
+// init_crc8_table :56-68). This stage is sequential by nature (a TS packet may straddle two BBFRAMEs, the running CRC-8 of
+// normal mode crosses the boundary too) and costs a few kilobytes per frame: it stays on the host exactly as in the
+// reference, consuming the descrambled bits the GPU stages deliver. The reference sends the bytes to a UDP socket or a
+// file (:433-443); here they are returned to the caller.
+#include "../../include/t2gpu.h"
+#include "t2gpu_common.h"
+#include <cstring>
+
+using namespace t2gpu;
+
+namespace {
+const int TS_LEN = 188, BIT_PACKET = 188 * 8, BBH_BITS = 80;
+const uint8_t CRC_POLY = 0xAB, TEI = 0x80;
+}
+
+struct t2gpu_bbdh {
+    int need_plp = 0;
+    uint8_t crc_table[256];
+    uint8_t crc = 0;
+    int idx_packet = 0, idx_buffer = 0;
+    bool split = false;
+    uint8_t buffer[188];
+    int last_mode = -1;
+};
+
+static inline uint8_t take_byte(const uint8_t *&in)
+{
+    uint8_t t = 0;
+    for (int n = 7; n >= 0; --n) t |= (uint8_t)((*in++ & 1) << n);
+    return t;
+}
+
+extern "C" t2gpu_bbdh *t2gpu_bbdh_create(int need_plp)
+{
+    t2gpu_bbdh *h = new t2gpu_bbdh();
+    h->need_plp = need_plp;
+    for (int i = 0; i < 256; ++i) {                    // CRC-8, generator 0xD5, MSB first (bb_de_header.cpp:56-68)
+        int r = i, crc = 0;
+        for (int j = 7; j >= 0; --j) {
+            if (((r >> j) & 1) ^ ((crc & 0x80) ? 1 : 0)) crc = (crc << 1) ^ 0xD5;
+            else crc <<= 1;
+        }
+        h->crc_table[i] = (uint8_t)crc;
+    }
+    return h;
+}
+extern "C" void t2gpu_bbdh_destroy(t2gpu_bbdh *h) { delete h; }
+extern "C" int t2gpu_bbdh_mode(const t2gpu_bbdh *h) { return h ? h->last_mode : -1; }
+
+extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap,
+                                  int *ts_errors)
+{
+    if (!h || !bits || !out || len_in < BBH_BITS || out_cap < len_in / 8 + 2 * TS_LEN) { set_error("t2gpu_bbdh_execute: bad arguments"); return -3; }
+    const uint8_t *in = bits;
+    int errors = 0, len_out = 0;
+    uint8_t *o = out, *tei = nullptr;
+    // BBHEADER CRC over its 80 bits: remainder 0 = normal mode, 0xAB = high-efficiency mode (CRC-8 xor MODE), :70-82,101-113
+    uint8_t c = 0;
+    for (int i = 0; i < BBH_BITS; ++i) {
+        uint8_t b = (uint8_t)((in[i] & 1) ^ (c & 0x01));
+        c >>= 1;
+        if (b) c ^= CRC_POLY;
+    }
+    int hem;
+    if (c == 0) hem = 0;
+    else if (c == CRC_POLY) hem = 1;
+    else return -1;                                    // "Baseband header CRC8 error.": frame dropped
+    h->last_mode = hem;
+    in += 2 + 1 + 1 + 1 + 1 + 2;                       // TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT
+    in += 8;                                           // ISI
+    if (h->need_plp != plp_id) return -2;              // :139-142
+    int upl = 0, dfl = 0, sync = 0, syncd = 0;
+    for (int i = 15; i >= 0; --i) upl |= (*in++ & 1) << i;
+    for (int i = 15; i >= 0; --i) dfl |= (*in++ & 1) << i;
+    for (int i = 7; i >= 0; --i) sync |= (*in++ & 1) << i;
+    for (int i = 15; i >= 0; --i) syncd |= (*in++ & 1) << i;
+    (void)upl; (void)sync;
+    if (syncd == 65535) return -2;                     // no user packet starts in this frame (:160-163)
+    in += 8;                                           // CRC-8 field
+    if (dfl > len_in - BBH_BITS) { set_error("t2gpu_bbdh_execute: DFL exceeds the frame"); return -3; }
+
+    if (!hem) {                                        // ---- normal mode (:166-335): CRC-8 of the previous packet replaces the sync byte
+        if (h->split) {
+            h->split = false;
+            if (h->idx_buffer > 0) { *o++ = h->buffer[0]; ++len_out; tei = o; }
+            for (int i = 1; i < h->idx_buffer; ++i) { *o++ = h->buffer[i]; ++len_out; }
+            const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
+            if (len_split <= syncd_byte) {
+                const int take = (len_split == syncd_byte) ? len_split : syncd_byte;
+                for (int i = 0; i < take; ++i) {
+                    uint8_t t = take_byte(in);
+                    h->crc = h->crc_table[t ^ h->crc];
+                    *o++ = t; ++len_out; ++h->idx_packet;
+                }
+                uint8_t t = take_byte(in);
+                if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                h->crc = 0;
+            } else {
+                for (int i = 0; i < syncd_byte; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
+                for (int i = 0; i < len_split - syncd_byte; ++i) { *o++ = 0xF0; ++len_out; ++h->idx_packet; }
+                ++errors;
+                if (tei) *tei |= TEI;
+            }
+        } else {
+            in += syncd + 8;
+        }
+        dfl -= syncd + 8;
+        while (dfl > 0) {
+            if (dfl < BIT_PACKET) {
+                h->split = true;
+                const int len_split = dfl / 8;
+                h->idx_buffer = 0;
+                for (int i = 0; i < len_split; ++i) {
+                    if (h->idx_packet == TS_LEN) {
+                        h->idx_packet = 0;
+                        uint8_t t = take_byte(in);
+                        if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                        h->crc = 0;
+                        h->buffer[h->idx_buffer++] = 0x47;
+                        ++h->idx_packet;
+                    }
+                    uint8_t t = take_byte(in);
+                    h->crc = h->crc_table[t ^ h->crc];
+                    h->buffer[h->idx_buffer++] = t;
+                    ++h->idx_packet;
+                }
+                dfl = 0;
+            } else {
+                if (h->idx_packet == TS_LEN) {
+                    h->idx_packet = 0;
+                    uint8_t t = take_byte(in);
+                    if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                    h->crc = 0;
+                }
+                if (h->idx_packet == 0) {
+                    *o++ = 0x47; ++len_out; ++h->idx_packet;
+                    tei = o;
+                }
+                uint8_t t = take_byte(in);
+                h->crc = h->crc_table[t ^ h->crc];
+                *o++ = t; ++len_out; ++h->idx_packet;
+                dfl -= 8;
+            }
+        }
+    } else {                                           // ---- high-efficiency mode (:336-432): 187-byte packets, sync re-inserted
+        if (h->split) {
+            h->split = false;
+            for (int i = 0; i < h->idx_buffer; ++i) { *o++ = h->buffer[i]; ++len_out; }
+            const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
+            if (len_split <= syncd_byte) {
+                for (int i = 0; i < len_split; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
+                if (len_split < syncd_byte) in += syncd - len_split * 8;
+            } else {
+                for (int i = 0; i < syncd_byte; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
+                for (int i = 0; i < len_split - syncd_byte; ++i) { *o++ = 0xF0; ++len_out; ++h->idx_packet; }
+            }
+        } else {
+            in += syncd;
+        }
+        dfl -= syncd;
+        while (dfl > 0) {
+            if (dfl < BIT_PACKET) {
+                h->split = true;
+                const int len_split = dfl / 8;
+                h->idx_buffer = 0;
+                for (int i = 0; i < len_split; ++i) {
+                    if (h->idx_packet == TS_LEN) {
+                        h->idx_packet = 0;
+                        h->buffer[h->idx_buffer++] = 0x47;
+                        ++h->idx_packet;
+                    }
+                    h->buffer[h->idx_buffer++] = take_byte(in);
+                    ++h->idx_packet;
+                }
+                dfl = 0;
+            } else {
+                if (h->idx_packet == TS_LEN || h->idx_packet == 0) {
+                    h->idx_packet = 0;
+                    *o++ = 0x47; ++len_out; ++h->idx_packet;
+                } else {
+                    *o++ = take_byte(in); ++len_out; ++h->idx_packet;
+                    dfl -= 8;
+                }
+            }
+        }
+    }
+    if (ts_errors) *ts_errors = errors;
+    return len_out;
+}

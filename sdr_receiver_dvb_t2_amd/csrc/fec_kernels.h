@@ -16,6 +16,7 @@ struct DemapParams {
     float rot_c, rot_s;      // cos(-ROT), sin(-ROT) as floats
     float d;                 // normalisation factor
     const uint16_t *address; // [fec_size] bit de-interleaver (null for QPSK)
+    int saturate;            // 0 = the reference's truncating int8 cast (wraps), 1 = clamp to [-128, 127] (extension)
 };
 // K-snr-reduce: sums[0] = sum |s|^2, sums[1] = sum |e|^2 over the hard decisions of n_snr cells (device doubles),
 // partial[] = scratch of 2*blocks doubles. Second stage folds them and writes float sums[0..2] (s, e, precision).

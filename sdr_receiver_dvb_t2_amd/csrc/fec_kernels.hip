@@ -147,8 +147,10 @@ __global__ __launch_bounds__(256) void demap_llr_kernel(DemapParams p, const flo
         const uint16_t *a = p.address + c * p.bits_per_cell;
         float thr = p.d * (float)(1 << p.mod);
         for (int l = 0; l < levels; ++l) {
-            stage[a[2 * l]] = cast_i8_trunc(rintf(mul_r(v.x, precision)));
-            stage[a[2 * l + 1]] = cast_i8_trunc(rintf(mul_r(v.y, precision)));
+            float lx = rintf(mul_r(v.x, precision)), ly = rintf(mul_r(v.y, precision));
+            if (p.saturate) { lx = fminf(fmaxf(lx, -128.0f), 127.0f); ly = fminf(fmaxf(ly, -128.0f), 127.0f); }
+            stage[a[2 * l]] = cast_i8_trunc(lx);
+            stage[a[2 * l + 1]] = cast_i8_trunc(ly);
             v.x = sub_r(fabsf(v.x), thr);
             v.y = sub_r(fabsf(v.y), thr);
             thr *= 0.5f;

@@ -11,8 +11,8 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
                       hipStream_t s);
 
 struct EqParams {
-    int fft_size, l_nulls, k_total, c_data, n_p2, max_seg;
-    float amp_sp, amp_cp;
+    int fft_size, l_nulls, k_total, c_data, n_p2, max_seg;   // c_data: cells out per symbol; n_p2: frame index of table row 0
+    float amp_sp, amp_cp, amp_p2;
     const uint8_t *map;        // [rows][k_total] carrier types of every data symbol of the frame
     const float *refer;        // [rows][k_total] signed pilot reference
     const int4 *segs;          // [rows][max_seg] (left pilot, right pilot, first de-interleaver index, data cells)

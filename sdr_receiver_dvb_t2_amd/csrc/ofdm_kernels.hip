@@ -169,7 +169,8 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
 }
 
 // ====================================================================================================== equaliser
-// Replaces data_symbol::execute (/root/reference/src/DVB_T2/data_symbol.cpp:108-335). Between two consecutive pilots the
+// Replaces data_symbol::execute (/root/reference/src/DVB_T2/data_symbol.cpp:108-335) and the equaliser part of
+// p2_symbol::execute (/root/reference/src/DVB_T2/p2_symbol.cpp:89-262), which differ only in the pilot amplitudes. Between two consecutive pilots the
 // reference interpolates phase and amplitude linearly by repeated float addition and de-rotates every data cell with a
 // LUT cos/sin divided by the amplitude; segments between pilots are independent, so one lane walks one segment with
 // exactly the reference's sequence of float operations. The frequency de-interleaver (out[h[d]]) is fused in.
@@ -220,9 +221,11 @@ __global__ __launch_bounds__(128) void eq_data_kernel(EqParams p, const float2 *
     const int4 sg = p.segs[(size_t)row * p.max_seg + seg];                      // left pilot, right pilot, d start, data count
     const int pl = sg.x, pr = sg.y, n = sg.w;
     int d = sg.z;
-    // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED)
-    const PilotEst L = pilot_estimate(cell[pl], refer[pl], map[pl] == T2_CONTINUAL ? p.amp_cp : p.amp_sp);
-    const PilotEst R = pilot_estimate(cell[pr], refer[pr], map[pr] == T2_CONTINUAL ? p.amp_cp : p.amp_sp);
+    // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
+    // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
+    const uint8_t tl = map[pl], tr = map[pr];
+    const PilotEst L = pilot_estimate(cell[pl], refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
+    const PilotEst R = pilot_estimate(cell[pr], refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
     float dif_angle = R.angle - L.angle;
     if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                      // as written in the reference (:189-191)
     else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;

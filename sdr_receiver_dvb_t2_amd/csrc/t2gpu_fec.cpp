@@ -95,6 +95,13 @@ extern "C" t2gpu_demap *t2gpu_demap_create(int mod, int fec_type, int code_rate,
     return h;
 }
 
+extern "C" int t2gpu_demap_configure(t2gpu_demap *h, int saturate)
+{
+    if (!h) return -1;
+    h->p.saturate = saturate ? 1 : 0;
+    return 0;
+}
+
 extern "C" void t2gpu_demap_destroy(t2gpu_demap *h)
 {
     if (!h) return;

@@ -66,15 +66,34 @@ extern "C" int t2gpu_table_freq_deint(int fft_mode, int carrier_mode, int pilot_
     return (int)he.size();
 }
 
+// pilot-to-pilot segments of one symbol: (left pilot, right pilot, first de-interleaver index, data cells between).
+// The centre carrier is never a segment boundary (data_symbol.cpp:224-256, p2_symbol.cpp:195-204).
+static int build_segments(const std::vector<uint8_t> &mp, int K, std::vector<int4> &segs)
+{
+    int left = 0, d = 0, n = 0;
+    for (int k = 1; k < K; ++k) {
+        const bool pilot = (mp[k] == T2_SCATTERED || mp[k] == T2_CONTINUAL || mp[k] == T2_P2PILOT) && k != K / 2;
+        if (mp[k] == T2_DATA) ++n;            // a data cell on the centre carrier is buffered like any other (data_symbol.cpp:226-229)
+        if (pilot) {
+            segs.push_back(make_int4(left, k, d, n));
+            d += n; n = 0; left = k;
+        }
+    }
+    return d;
+}
+
 struct t2gpu_ofdm {
     T2Mode m;
     int device = 0, max_symbols = 0, rows = 0, num_cu = 256;
-    EqParams eq{};
+    EqParams eq{}, eq_p2{};
     float2 *d_twiddle = nullptr;
     uint8_t *d_map = nullptr;
     float *d_refer = nullptr, *d_lut = nullptr;
-    int4 *d_segs = nullptr;
+    int4 *d_segs = nullptr, *d_segs_p2 = nullptr;
     int32_t *d_seg_count = nullptr, *d_h_even = nullptr, *d_h_odd = nullptr;
+    uint8_t *d_map_p2 = nullptr;
+    float *d_refer_p2 = nullptr;
+    int32_t *d_seg_count_p2 = nullptr, *d_h_even_p2 = nullptr, *d_h_odd_p2 = nullptr;
     float4 *d_pilot_scratch = nullptr;
     // host-call staging
     float2 *d_in = nullptr, *d_out = nullptr, *d_sync = nullptr;
@@ -124,15 +143,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         t2_symbol_carriers(m, m.n_p2 + r, mp, rf);
         std::copy(mp.begin(), mp.end(), map.begin() + (size_t)r * K);
         std::copy(rf.begin(), rf.end(), refer.begin() + (size_t)r * K);
-        int left = 0, d = 0, n = 0;
-        for (int k = 1; k < K; ++k) {
-            const bool pilot = (mp[k] == T2_SCATTERED || mp[k] == T2_CONTINUAL) && k != K / 2;   // centre pilot unused (:224-256)
-            if (mp[k] == T2_DATA) ++n;
-            if (pilot) {
-                segs[r].push_back(make_int4(left, k, d, n));
-                d += n; n = 0; left = k;
-            }
-        }
+        int d = build_segments(mp, K, segs[r]);
         if (d != m.c_data) { set_error("carrier map does not hold c_data data cells"); delete h; return nullptr; }
         max_seg = std::max(max_seg, (int)segs[r].size());
     }
@@ -156,10 +167,26 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     up(&h->d_seg_count, segcount.data(), segcount.size() * 4);
     up(&h->d_h_even, he.data(), he.size() * 4);
     up(&h->d_h_odd, ho.data(), ho.size() * 4);
-    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_seg + 1) * sizeof(float4)), "hipMalloc");
+    // the P2 symbol: one table row of its own (pilots every 3rd / 6th carrier, c_p2 cells, P2 frequency de-interleaver)
+    std::vector<uint8_t> mp2; std::vector<float> rf2; std::vector<int4> seg2;
+    t2_symbol_carriers(m, 0, mp2, rf2);
+    if (build_segments(mp2, K, seg2) != m.c_p2) { set_error("P2 carrier map does not hold c_p2 data cells"); t2gpu_ofdm_destroy(h); return nullptr; }
+    const int32_t nseg2 = (int32_t)seg2.size();
+    std::vector<int32_t> he2, ho2;
+    t2_freq_deint(m, 0, he2, ho2);
+    up(&h->d_map_p2, mp2.data(), mp2.size());
+    up(&h->d_refer_p2, rf2.data(), rf2.size() * 4);
+    up(&h->d_segs_p2, seg2.data(), seg2.size() * sizeof(int4));
+    up(&h->d_seg_count_p2, &nseg2, 4);
+    up(&h->d_h_even_p2, he2.data(), he2.size() * 4);
+    up(&h->d_h_odd_p2, ho2.data(), ho2.size() * 4);
+    const int max_all = std::max(max_seg, (int)nseg2);
+    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_all + 1) * sizeof(float4)), "hipMalloc");
     if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
-    h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, h->d_map, h->d_refer, h->d_segs,
+    h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map, h->d_refer, h->d_segs,
                      h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut, h->d_lut + 65536};
+    h->eq_p2 = EqParams{N, m.l_nulls, K, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
+                        h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut, h->d_lut + 65536};
     return h;
 }
 
@@ -168,7 +195,8 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
     if (!h) return;
     hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
-    hipFree(h->d_sync); hipFree(h->d_index);
+    hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
+    hipFree(h->d_seg_count_p2); hipFree(h->d_h_even_p2); hipFree(h->d_h_odd_p2);
     delete h;
 }
 
@@ -213,6 +241,18 @@ extern "C" int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, 
     T2_HIP(launch_eq_data(h->eq, reinterpret_cast<const float2 *>(d_symbols), d_symbol_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
                           h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.c_data;
+}
+
+// P2 symbols of a batch of frames (idx_symbol = 0 for all of them: n_p2 = 1 for 16K / 32K)
+extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream)
+{
+    if (!h || !d_symbols || !d_cells || n_symbols < 1 || n_symbols > h->max_symbols) { set_error("t2gpu_eq_p2_execute_dev: bad arguments"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (ensure_staging(h)) return -1;
+    T2_HIP(hipMemsetAsync(h->d_index, 0, (size_t)n_symbols * 4, s));           // every symbol is frame symbol 0
+    T2_HIP(launch_eq_data(h->eq_p2, reinterpret_cast<const float2 *>(d_symbols), h->d_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), s));
+    return h->m.c_p2;
 }
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,

@@ -18,11 +18,13 @@ MOD_QPSK, MOD_16QAM, MOD_64QAM, MOD_256QAM = range(4)   # dvbt2_constellation_t 
 
 
 class llr_demapper(object):
-    def __init__(self, plp_mod, plp_fec_type, plp_cod, plp_rotation, max_cells, device=0):
+    def __init__(self, plp_mod, plp_fec_type, plp_cod, plp_rotation, max_cells, device=0, saturate=False):
         self._l = lib()
         self._h = self._l.t2gpu_demap_create(plp_mod, plp_fec_type, plp_cod, plp_rotation, max_cells, device)
         if not self._h:
             raise T2GpuError("t2gpu_demap_create: " + self._l.t2gpu_last_error().decode())
+        if saturate:        # extension: clamp instead of the reference's wrapping int8 cast
+            check(self._l.t2gpu_demap_configure(self._h, 1), "t2gpu_demap_configure")
         self.fec_size = 64800 if plp_fec_type == 1 else 16200
         self.bits_per_cell = 2 * (plp_mod + 1)
         self.cells_per_fec = self.fec_size // self.bits_per_cell

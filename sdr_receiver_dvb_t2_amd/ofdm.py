@@ -66,6 +66,19 @@ class t2_ofdm(object):
             check(rc, "t2gpu_eq_data_execute_dev")
         return cells, sync
 
+    # ---- equaliser part of p2_symbol::execute, batched over frames
+    def eq_p2_dev(self, symbols):
+        import torch
+        n = symbols.shape[0]
+        assert symbols.is_cuda and symbols.dtype == torch.float32 and symbols.is_contiguous()
+        cells = torch.empty((n, self.c_p2, 2), dtype=torch.float32, device=symbols.device)
+        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device)
+        rc = self._l.t2gpu_eq_p2_execute_dev(self._h, symbols.data_ptr(), n, cells.data_ptr(), sync.data_ptr(),
+                                             torch.cuda.current_stream(symbols.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_eq_p2_execute_dev")
+        return cells, sync
+
     def eq_data(self, idx_symbol, ofdm_cell):
         """Reference call shape: returns (cells complex64[c_data], sample_rate_offset, phase_offset)."""
         x = np.ascontiguousarray(ofdm_cell, np.complex64).reshape(self.fft_size)

@@ -228,13 +228,15 @@ def ora_freq_deint(m, kind):
 def ora_data_symbol(m, idx_symbol, ofdm_cell):
     """data_symbol::execute on one fft-shifted symbol (complex64[fft_size]) -> (cells complex64[c_data], phase_offset, sro)."""
     mp, rf = ora_symbol_carriers(m, idx_symbol)
-    he, ho = ora_freq_deint(m, 1)
+    kind = 0 if idx_symbol < m.n_p2 else 1
+    he, ho = ora_freq_deint(m, kind)
     h = ho if idx_symbol % 2 == 0 else he
     x = np.ascontiguousarray(ofdm_cell, np.complex64)
-    out = np.zeros(m.c_data, np.complex64)
+    ncell = m.c_p2 if kind == 0 else m.c_data
+    out = np.zeros(ncell, np.complex64)
     sync = np.zeros(2, np.float32)
     fn = oracle().ora_data_symbol
     fn.argtypes = [ctypes.c_void_p] * 7
     n = fn(ctypes.addressof(m), x.ctypes.data, mp.ctypes.data, rf.ctypes.data, h.ctypes.data, out.ctypes.data, sync.ctypes.data)
-    assert n == m.c_data, (n, m.c_data)
+    assert n == ncell, (n, ncell)
     return out, float(sync[0]), float(sync[1])

@@ -1,0 +1,164 @@
+"""Transmitter-side model of the DVB-T2 chain (test infrastructure): ETSI EN 302 755 forward operations written
+independently of the receiver restatements -- mode adaptation (BBFRAMEs in HEM), BB scrambling, (BCH parity left zero:
+the reference ignores it, bch_decoder.cpp:136), LDPC encoding, bit interleaving + demultiplexing, QAM mapping, constellation
+rotation with cyclic Q delay, cell and time interleaving. It uses only the permutation TABLES of the receiver (inverted),
+never its processing code, so that "what the receiver recovers == what was sent" is a genuine end-to-end check."""
+import numpy as np
+
+import oracle_lib as ol
+
+K_BCH = [7032, 9552, 10632, 11712, 12432, 13152, 32208, 38688, 43040, 48408, 51648, 53840]
+ROT = [0.506145483, 0.293215314, 0.150098316, 0.062418810]
+NORM = [0.707106781, 0.316227766, 0.15430335, 0.076696499]
+
+
+def crc8_d5(bits):
+    """CRC-8 with generator x^8+x^7+x^6+x^4+x^2+1 (EN 302 755 annex F), MSB first over a bit array."""
+    crc = 0
+    for b in bits:
+        fb = ((crc >> 7) & 1) ^ int(b)
+        crc = (crc << 1) & 0xff
+        if fb:
+            crc ^= 0xD5
+    return crc
+
+
+def bits_of(value, n):
+    return [(value >> i) & 1 for i in range(n - 1, -1, -1)]
+
+
+def bbframes_hem(ts, k_bch, n_frames):
+    """Pack 188-byte TS packets (sync 0x47) into n_frames HEM BBFRAMEs: sync bytes removed, packets flow across frames.
+    Returns uint8 bits [n_frames][k_bch] and the number of whole packets consumed."""
+    ts = np.asarray(ts, np.uint8).reshape(-1, 188)
+    assert (ts[:, 0] == 0x47).all()
+    payload = np.unpackbits(ts[:, 1:].reshape(-1))                # 187-byte user packets, MSB first
+    dfl = ((k_bch - 80) // 8) * 8
+    frames = np.zeros((n_frames, k_bch), np.uint8)
+    pos = 0
+    for f in range(n_frames):
+        up_bits = 187 * 8
+        syncd = (-pos) % up_bits                                  # bits until the next packet start
+        hdr = [1, 1, 1, 1, 0, 0, 0, 0] + [0] * 8                  # MATYPE: TS, SIS, CCM, no ISSY, no NPD, EXT 00 | ISI 0
+        hdr += bits_of(0, 16) + bits_of(dfl, 16) + bits_of(0, 8) + bits_of(syncd, 16)
+        hdr += bits_of(crc8_d5(hdr) ^ 1, 8)                       # CRC-8 xor MODE (1 = high efficiency mode)
+        frames[f, :80] = hdr
+        frames[f, 80:80 + dfl] = payload[pos:pos + dfl]
+        pos += dfl
+    return frames, pos // (187 * 8)
+
+
+def scramble(frames):
+    prbs = ol.ora_bb_prbs(frames.shape[1])
+    return frames ^ prbs[None, :]
+
+
+def fec_encode(cid, bbframes):
+    """BBFRAME bits [f][k_bch] -> LDPC codewords [f][n] in transmitted order; the BCH parity field stays zero."""
+    n, k, _, _ = ol.ldpc_params(cid)
+    info = np.zeros((bbframes.shape[0], k), np.uint8)
+    info[:, :bbframes.shape[1]] = bbframes
+    return ol.ldpc_encode(cid, info)
+
+
+def map_axis(bits, d):
+    """bits [..., m] (bit 0 first) -> PAM amplitude: nested sign recursion, the inverse of the demapper's per-axis LLRs."""
+    m = bits.shape[-1]
+    x = np.full(bits.shape[:-1], d, dtype=np.float64)
+    for i in range(m - 1, -1, -1):
+        s = 1.0 - 2.0 * bits[..., i]
+        x = s * x if i == m - 1 else s * (d * (1 << (m - 1 - i)) + x)
+    return x
+
+
+def cells_from_codewords(cw, mod, fec_type, code_rate, rotation=True):
+    """[f][n] code bits -> [f][cells_per_fec] complex cells (bit interleaver + demux via the inverse of the receiver's
+    address table, mapping, rotation, cyclic Q delay)."""
+    bpc = 2 * (mod + 1)
+    f, n = cw.shape
+    if mod == 0:
+        bits = cw.reshape(f, n // 2, 2)
+        c = map_axis(bits[..., 0:1], NORM[0]) + 1j * map_axis(bits[..., 1:2], NORM[0])
+    else:
+        addr = ol.ora_bitdeint_address(mod, fec_type, code_rate)
+        bits = cw[:, addr].reshape(f, n // bpc, bpc)              # LLR k of a frame reports code bit addr[k]
+        c = map_axis(bits[..., 0::2], NORM[mod]) + 1j * map_axis(bits[..., 1::2], NORM[mod])
+    if rotation:
+        c = c * np.exp(1j * ROT[mod])
+        c = c.real + 1j * np.roll(c.imag, 1, axis=1)              # Q of cell q-1 travels with I of cell q (cyclic per block)
+    return c
+
+
+def interleave_ti_block(cells):
+    """[f][ncells] cells of one TI block -> the stream of f*ncells cells in transmission order (cell + time interleaver)."""
+    f, ncells = cells.shape
+    perm = ol.ora_cell_perm(f, ncells)
+    mem = cells.reshape(-1)[perm]                                 # interleaver memory position d holds cell perm[d]
+    rows, cols = ncells // 5, 5 * f
+    n = np.arange(f * ncells)
+    return mem[(n % cols) * rows + n // cols]
+
+
+def ts_packets(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ts = rng.integers(0, 256, size=(n, 188), dtype=np.uint8)
+    ts[:, 0] = 0x47
+    ts[:, 1] &= 0x7f                                               # transport_error_indicator clear
+    return ts
+
+
+# ------------------------------------------------------------------------------------------------ OFDM frame builder
+L1_PRE_CELLS = 1840
+
+
+def plp_blocks_per_frame(m, l1_post_size, cells_per_fec):
+    cells = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (m.n_data - m.l_fc) * m.c_data
+    return cells // cells_per_fec
+
+
+def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0):
+    """One T2 frame after guard-interval removal: returns complex64 [len_frame][fft_size] time-domain symbols.
+    plp_stream: the PLP's cells in transmission order (time-interleaver output); it fills the P2 symbol behind the L1 cells
+    and then the data symbols; the remainder of the last symbol is padded with dummy cells."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_sym = m.n_p2 + m.n_data - m.l_fc
+    cap = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (n_sym - 1) * m.c_data
+    stream = np.zeros(cap, np.complex128)
+    stream[:plp_stream.size] = plp_stream
+    out = np.zeros((n_sym, m.fft_size), np.complex64)
+    pos = 0
+    for l in range(n_sym):
+        mp, rf = ol.ora_symbol_carriers(m, l)
+        kind = 0 if l < m.n_p2 else 1
+        he, ho = ol.ora_freq_deint(m, kind)
+        h = ho if l % 2 == 0 else he
+        ncell = m.c_p2 if kind == 0 else m.c_data
+        if kind == 0:
+            l1 = (1 - 2 * rng.integers(0, 2, L1_PRE_CELLS + l1_post_size)).astype(np.complex128)     # BPSK filler
+            take = ncell - l1.size
+            sym_cells = np.concatenate([l1, stream[pos:pos + take]])
+        else:
+            take = ncell
+            sym_cells = stream[pos:pos + take]
+        pos += take
+        carriers = rf.astype(np.complex128)
+        data_idx = np.nonzero(mp == 1)[0]
+        assert data_idx.size == ncell
+        carriers[data_idx] = sym_cells[h]                   # receiver: cell of the dd-th data carrier lands at h[dd]
+        full = np.zeros(m.fft_size, np.complex128)
+        full[m.l_nulls:m.l_nulls + m.k_total] = carriers * np.exp(1j * phase)
+        x = np.fft.ifft(np.fft.ifftshift(full))
+        if snr_db is not None:
+            p_sig = (np.abs(carriers) ** 2).sum() / m.fft_size ** 2           # mean power per time sample
+            sigma = np.sqrt(p_sig * m.fft_size / m.k_total / 2 * 10 ** (-snr_db / 10))
+            x = x + sigma * (rng.standard_normal(m.fft_size) + 1j * rng.standard_normal(m.fft_size))
+        out[l] = x.astype(np.complex64)
+    return out
+
+
+def build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, n_blocks, rotation=True):
+    """TS packets -> the n_blocks FEC blocks of one TI block -> interleaved cell stream. Returns (stream, bbframes)."""
+    frames, used = bbframes_hem(ts, K_BCH[cid], n_blocks)
+    cw = fec_encode(cid, scramble(frames))
+    cells = cells_from_codewords(cw, mod, fec_type, code_rate, rotation)
+    return interleave_ti_block(cells), frames, used

@@ -106,3 +106,20 @@ def test_equaliser_matches_oracle(torch_cuda, mode):
     want, wpho, wsro = ol.ora_data_symbol(m, idxs[0], syms[0])
     assert np.array_equal(got, want) and np.float32(sro) == np.float32(wsro) and np.float32(pho) == np.float32(wpho)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (4, 1, 6, 4, 0, 30), (5, 0, 1, 2, 0, 12)])
+def test_p2_equaliser_matches_oracle(torch_cuda, mode):
+    import sdr_receiver_dvb_t2_amd as pkg
+    torch = torch_cuda
+    m = ol.ora_mode(*mode)
+    ctx = pkg.t2_ofdm(*mode, max_symbols=8)
+    syms = np.stack([make_symbol(m, 0, seed=s) for s in range(3)])
+    cells, sync = ctx.eq_p2_dev(torch.from_numpy(syms.view(np.float32).reshape(3, m.fft_size, 2)).cuda())
+    cells = cells.cpu().numpy(); sync = sync.cpu().numpy()
+    for b in range(3):
+        want, pho, sro = ol.ora_data_symbol(m, 0, syms[b])
+        got = (cells[b, :, 0] + 1j * cells[b, :, 1]).astype(np.complex64)
+        assert np.array_equal(got, want)
+        assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
+    ctx.close()
