@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the DVB-T2 hot path on MI355X (contract: see the task brief / DESIGN.md "Measurement").
+"""bench.py -- throughput of the DVB-T2 demod -> TS hot path on MI355X (contract: task brief / DESIGN.md "Measurement").
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM. Round-1 workload:
-the dominant stage of the demod->TS chain, LDPC 64800 r=3/4 (reference SIMD-batch semantics, 25 trials), F frames per
-GPU. Rank 0 prints ONE JSON line. `roofline` is computed from HIP-event timing of the LDPC kernel launches inside the
-timed region; `cpu_baseline` times the reference's own LDPC (oracle/_ref, kind "reference") or, if that library cannot
-be loaded on this host, our C restatement (kind "port") on a bounded sample of the same workload, rank 0 / N=1 only.
+Workload (BASELINE.json config 3, "CFG-A"): F complete T2 frames per GPU per step -- 8 MHz, 32K extended, GI 1/128, PP7,
+1 P2 + 59 data symbols, one PLP, rotated 256-QAM, LDPC 64800 r=3/4, 202 FEC blocks per frame -- synthetic, built by the
+transmitter model in tests/t2_tx.py, resident in HBM as guard-removed complex samples before the clock starts. One step
+= FFT -> P2/data equaliser + frequency de-interleave -> time/cell de-interleave -> demap -> LDPC (reference SIMD-batch
+rule, 25 trials) -> BB descramble for all F frames. Rank 0 prints ONE JSON line: `value` = input IQ samples (whole
+frames incl. P1 and guard intervals, at 64/7 Msps) per second; `roofline` is for the dominant kernel (LDPC) from HIP
+events around its launches inside the timed region; `cpu_baseline` times the same chain on one host core (oracle
+restatement + the reference's own LDPC where oracle/_ref is loadable) on one frame.
 """
 import argparse
 import json
@@ -20,45 +23,70 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600   # LLR in + 1-bit-per-byte hard decisions out
-# Memory-side traffic of one launch, from the committed PMC passes (profiles/r01_ldpc_v3_pmc.txt, 4096 frames, ~10.4
-# sweeps per frame): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes per
-# frame. It is dominated by the 8-byte check-node records streamed once per sweep (L2 / Infinity Cache), not by LLR I/O.
-LDPC_MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 2.625e6 + 5.955e6) * 1024 / 4096
-SAMPLES_PER_FRAME = 33024.0 / (27404.0 / 8100.0)   # CFG-A: input IQ samples per FEC frame
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600    # LLR in + one-bit-per-byte hard decisions out
+# memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/r01_ldpc_v3_pmc.txt: 4096 frames,
+# 10.4 sweeps): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes
+LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 2.625e6 + 5.955e6) * 1024 / 4096 / 10.4
+MODE = (5, 1, 6, 4, 0, 59)                  # FFTSIZE_32K, extended, PP7, GI 1/128, no PAPR, 59 data symbols
+L1_POST_SIZE = 350
+PLP = (3, 1, 3, 1)                          # 256-QAM, normal FEC frame, r = 3/4, rotated
+FRAME_SAMPLES = 2048 + 60 * (32768 + 256)   # P1 + 60 symbols with GI 1/128 = 1 983 488
 
 
-def make_workload(frames, sigma, seed):
-    """int8 LLRs of random N3/4 codewords over BPSK/AWGN (positive = bit 0): 256 distinct frames, tiled and shuffled."""
+def make_frames(n_unique, snr_db, seed):
+    """n_unique synthetic CFG-A frames (guard removed): complex64 [n][60][32768], the sent TS packets, blocks per frame."""
     import numpy as np
-    import oracle_lib as ol     # encoder only: test-vector generation, not the measured path
-    cid = ol.code_id(1, 3)
-    uniq = min(frames, 256)
-    info, llr = ol.make_llr(cid, uniq, sigma, seed)
-    reps = (frames + uniq - 1) // uniq
-    rng = np.random.Generator(np.random.PCG64(seed + 1))
-    perm = rng.permutation(uniq * reps)[:frames]
-    return np.tile(info, (reps, 1))[perm], np.ascontiguousarray(np.tile(llr, (reps, 1))[perm])
-
-
-def cpu_baseline(llr, budget_s=12.0):
-    """Reference LDPC on one host core over 32-frame batches of the same workload, ~budget_s of CPU time."""
     import oracle_lib as ol
-    cid = ol.code_id(1, 3)
-    kind, dec = ("reference", ol.ref_decode) if ol.ref() is not None else ("port", ol.ora_decode)
-    done, t0 = 0, time.perf_counter()
-    nb = llr.shape[0] // 32
-    b = 0
-    while True:
-        dec(cid, llr[(b % nb) * 32:(b % nb) * 32 + 32])
-        done += 32
-        b += 1
+    import t2_tx
+    m = ol.ora_mode(*MODE)
+    cid = ol.code_id(PLP[1], PLP[2])
+    nb = t2_tx.plp_blocks_per_frame(m, L1_POST_SIZE, 8100)
+    per = nb * (t2_tx.K_BCH[cid] // 1496 + 1)
+    frames, sent = [], []
+    for f in range(n_unique):
+        ts = t2_tx.ts_packets(per, seed + f)
+        stream, _, _ = t2_tx.build_plp_frame_cells(cid, PLP[0], PLP[1], PLP[2], ts, nb)
+        frames.append(t2_tx.build_frame(m, stream, L1_POST_SIZE, seed + 100 + f, snr_db=snr_db, phase=0.3 * (f + 1)))
+        sent.append(ts)
+    return np.stack(frames), sent, nb
+
+
+def cpu_chain_baseline(frame):
+    """One CFG-A frame through the CPU chain on one core: numpy FFT, oracle equaliser / de-interleavers / demapper (C
+    restatement), the reference's own LDPC build when loadable (else the C restatement), oracle descrambler."""
+    import numpy as np
+    import oracle_lib as ol
+    m = ol.ora_mode(*MODE)
+    cid = ol.code_id(PLP[1], PLP[2])
+    nb = (m.c_p2 - 1840 - L1_POST_SIZE + 59 * m.c_data) // 8100
+    ldpc, kind = (ol.ref_decode, "reference LDPC + port") if ol.ref() is not None else (ol.ora_decode, "port")
+    ti = ol.OraTi(8100, nb)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:                                   # the same frame over and over: ~12 s of single-core work
+        cells = []
+        for l in range(frame.shape[0]):
+            spec = np.fft.fftshift(np.fft.fft(frame[l])).astype(np.complex64)
+            out, _, _ = ol.ora_data_symbol(m, l, spec)
+            cells.append(out[1840 + L1_POST_SIZE:] if l == 0 else out)
+        cells = np.concatenate(cells)[:nb * 8100]
+        ti.begin(nb)
+        tib = np.zeros(nb * 8100, np.complex64)
+        ti.push(cells, tib)
+        llr, _, _ = ol.ora_demap(PLP[0], PLP[1], PLP[2], PLP[3], tib)
+        for b0 in range(0, (nb // 32) * 32, 32):
+            t, bits, _ = ldpc(cid, llr[b0:b0 + 32])
+            if t >= 0:
+                ol.ora_bch_descramble(cid, bits)
+        reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or (kind == "port" and el >= budget_s / 2 and done >= 64):
+        if el >= 12.0:
             break
-    return {"value": round(done / el, 2), "unit": "codewords/s", "cores": 1, "kind": kind,
-            "sample": "%d frames (%d SIMD batches of 32) of the bench workload, %.1f s, 25 trials max" % (done, done // 32, el)}
+    return {"value": round(reps * FRAME_SAMPLES / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d passes over one CFG-A frame (60 symbols, %d of %d FEC blocks in whole SIMD batches of 32 through the LDPC, "
+                      "25 trials each: the wrapped 256-QAM LLRs never converge), %.1f s; stages: numpy FFT + oracle C restatement, "
+                      "LDPC = %s" % (reps, (nb // 32) * 32, nb, el, kind)}
 
 
 def main():
@@ -66,9 +94,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=4096, help="FEC frames per GPU per step")
-    ap.add_argument("--sigma", type=float, default=0.60)
-    ap.add_argument("--group", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=16, help="T2 frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=22.0)
     ap.add_argument("--trials", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -90,69 +117,89 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # weak scaling: every GPU gets args.frames frames of the same statistics (different seed per rank)
-    total = args.frames * world
-    lo, hi = shard_frames(total, world, rank, align=args.group)
-    info, llr_h = make_workload(hi - lo, args.sigma, seed=20250614 + rank)
-    llr = torch.from_numpy(llr_h).to(dev)
-    dec = pkg.ldpc_decoder(1, 3, max_frames=hi - lo, device=local_rank, group=args.group, trials=args.trials)
+    # weak scaling: every GPU demodulates args.frames whole T2 frames per step (frames are independent: no collective)
+    lo, hi = shard_frames(args.frames * world, world, rank, align=1)
+    F = hi - lo
+    uniq, sent, nb = make_frames(2, args.snr, seed=20250614 + 10 * rank)
+    host = np.concatenate([uniq] * ((F + 1) // 2))[:F]
+    x = torch.from_numpy(host.view(np.float32).reshape(F, 60, 32768, 2)).to(dev)
 
-    def step():
-        return dec.execute_dev(llr)
+    def make_chain(saturate):
+        return pkg.t2_chain(*MODE, L1_POST_SIZE, *PLP, nb, max_frames=F, device=local_rank, ldpc_trials=args.trials,
+                            saturate_llr=saturate)
 
+    chain = make_chain(False)                 # reference semantics: truncating int8 cast in the demapper
     for _ in range(args.warmup):
-        bits, trials = step()
+        bits, trials = chain.demod_dev(x, flush=True)
     torch.cuda.synchronize(dev)
-    assert dec.status() == 0
-    # correctness gate on the warm-up output: every batch converged to the sent bits
-    if args.warmup:
-        assert bool((trials >= 0).all()), "a batch did not converge"
-        assert np.array_equal(bits.cpu().numpy(), info), "decoded bits differ from the sent bits"
-        avg_updates = float((args.trials - trials.float()).mean().item())
-    else:
-        avg_updates = float("nan")
+    ref_trials = trials.cpu().numpy() if args.warmup else None
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    chain.time_ldpc = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        step()
-        ev[k][1].record()
+    for _ in range(args.steps):
+        chain.demod_dev(x, flush=True)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    assert dec.status() == 0
-    local_s = t1 - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]           # per launch (memset nodes + kernel), on the launch stream
-    max_s, units = aggregate_timing(local_s, (hi - lo) * args.steps, dist if world > 1 else None, dev)
+    assert chain.ldpc.status() == 0
+    ldpc_ms = [a.elapsed_time(b) for a, b, _ in chain.ldpc_events]
+    ldpc_frames = chain.ldpc_events[0][2]
+    max_s, units = aggregate_timing(t1 - t0, F * args.steps, dist if world > 1 else None, dev)
+
+    # informative second leg (rank 0, N = 1): clamped LLRs (extension) -> the same frames decode; checks the TS bytes
+    extra = {}
+    if rank == 0:
+        c2 = make_chain(True)
+        bits2, trials2 = c2.demod_dev(x[:2], flush=True)
+        torch.cuda.synchronize(dev)
+        t2h = trials2.cpu().numpy()
+        got = c2.ts_from_bits(bits2.cpu().numpy(), t2h)
+        want = sent[0].reshape(-1)
+        npk = (nb * ((48408 - 80) // 8)) // 187 - 1
+        ok = bool((t2h >= 0).all()) and bool(np.array_equal(got[:npk * 188], want[:npk * 188]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c3 = make_chain(True)
+        c3.demod_dev(x, flush=True)
+        e0.record(); c3.demod_dev(x, flush=True); e1.record()
+        torch.cuda.synchronize(dev)
+        extra = {"clamped_llr_variant": {"msamples_per_s": round(F * FRAME_SAMPLES / (e0.elapsed_time(e1) / 1e3) / 1e6, 1),
+                                          "ts_matches_sent": ok, "avg_ldpc_updates": round(float((args.trials - t2h).mean()), 2),
+                                          "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}}
 
     if rank == 0:
-        cw_per_s = units / max_s
-        avg_launch_s = (sum(kern_ms) / len(kern_ms)) / 1e3
-        achieved = LDPC_HBM_BYTES_PER_FRAME * (hi - lo) / avg_launch_s / 1e9
+        msps = units * FRAME_SAMPLES / max_s / 1e6
+        avg_ldpc_s = (sum(ldpc_ms) / len(ldpc_ms)) / 1e3
+        achieved = LDPC_HBM_BYTES_PER_FRAME * ldpc_frames / avg_ldpc_s / 1e9
+        dropped = int((ref_trials < 0).sum()) if ref_trials is not None else -1
         out = {
-            "metric": "LDPC codewords/s (DVB-T2 64800 r=3/4, layered offset-min-sum int8, reference SIMD-batch stop rule)",
-            "value": round(cw_per_s, 1), "unit": "codewords/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(max_s / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "LDPC-only leg of config 3: %d FEC frames/GPU/step, N=64800 r=3/4, BPSK-AWGN LLRs sigma=%.2f "
-                                   "(%.1f updates/batch avg), group=%d, max_trials=%d; full demod->TS chain not yet on GPU"
-                                   % (hi - lo, args.sigma, avg_updates, args.group, args.trials),
-                       "equivalent_iq_msamples_per_s": round(cw_per_s * SAMPLES_PER_FRAME / 1e6, 2),
+            "metric": "IQ Msamples/s demod->TS (32K, 256-QAM, LDPC 64800 r=3/4)",
+            "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(max_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (OFDM, demap) + int8 (LDPC)", "data": "synthetic",
+            "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames; stages on GPU: FFT, "
+                                   "P2+data equaliser/freq-deint, TI/cell-deint, demap, LDPC (group 32, max %d trials), BB descramble; "
+                                   "reference arithmetic incl. the wrapping int8 LLR cast, so %d of %d SIMD batches run all trials and "
+                                   "are dropped as the reference would; P1/L1 acquisition, guard removal, resampler and TS "
+                                   "de-framing are not inside the timed region (samples counted per whole frame, %d each)"
+                                   % (F, F * 60, F * nb, args.trials, dropped, len(ref_trials) if ref_trials is not None else 0,
+                                      FRAME_SAMPLES),
+                       "ldpc_codewords_per_s": round(ldpc_frames / avg_ldpc_s, 1),
                        "parallelism": "frame-shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": round(LDPC_MEASURED_TRAFFIC_BYTES_PER_FRAME * (hi - lo)),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_ldpc_v3_pmc.txt (bytes per launch, scaled by frames)",
-                         "kernel": "ldpc_decode_kernel", "avg_launch_ms": round(avg_launch_s * 1e3, 3),
-                         "note": "LDPC is LDS/VALU-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once"},
+                         "traffic": round(LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP * ldpc_frames * args.trials),
+                         "kernel": "ldpc_decode_kernel<12,12>", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
+                         "share_of_step": round(avg_ldpc_s / (max_s / args.steps), 3),
+                         "note": "the LDPC is VALU/LDS-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once; "
+                                 "traffic = PMC-measured bytes per frame-sweep (profiles/r01_ldpc_v3_pmc.txt) x frames x sweeps"},
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(llr_h)
+            out["cpu_baseline"] = cpu_chain_baseline(host[0])
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

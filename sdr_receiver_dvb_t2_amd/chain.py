@@ -52,6 +52,7 @@ class t2_chain(object):
         self.ti_out = torch.zeros((max_frames, plp_num_blocks * self.cells_per_fec, 2), dtype=f32, device=self.dev)
         self.llr = torch.empty((max_frames * plp_num_blocks + 64, self.fec_size), dtype=torch.int8, device=self.dev)
         self.carry = 0                                           # FEC frames waiting for a full SIMD batch
+        self.time_ldpc, self.ldpc_events = False, []             # bench: HIP events around the LDPC launch
         idx = np.tile(np.arange(1, self.n_sym, dtype=np.int32), max_frames)
         self.sym_index = torch.from_numpy(idx).to(self.dev)
 
@@ -89,7 +90,13 @@ class t2_chain(object):
         if ready == 0:
             self.carry = total
             return None, None
+        if self.time_ldpc:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         bits, trials = self.ldpc.execute_dev(self.llr[:ready])
+        if self.time_ldpc:
+            e1.record()
+            self.ldpc_events.append((e0, e1, ready))
         out = self.bch.execute_dev(bits)
         rest = total - ready
         if rest:
