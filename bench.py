@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--snr", type=float, default=22.0)
     ap.add_argument("--trials", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clamped-variant", action="store_true", help="skip the informative second leg (profiling runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -152,7 +153,7 @@ def main():
 
     # informative second leg (rank 0, N = 1): clamped LLRs (extension) -> the same frames decode; checks the TS bytes
     extra = {}
-    if rank == 0:
+    if rank == 0 and not args.no_clamped_variant:
         c2 = make_chain(True)
         bits2, trials2 = c2.demod_dev(x[:2], flush=True)
         torch.cuda.synchronize(dev)

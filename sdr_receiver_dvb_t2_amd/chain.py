@@ -71,11 +71,11 @@ class t2_chain(object):
         assert F <= self.max_frames and symbols.shape[1] == self.n_sym
         spec = o.fft_dev(symbols.reshape(F * self.n_sym, o.fft_size, 2)).reshape(F, self.n_sym, o.fft_size, 2)
         # P2: equalise, drop the L1 cells, PLP cells go to the head of the frame's cell stream
-        p2, _ = o.eq_p2_dev(spec[:, 0].contiguous())
+        p2, _ = o.eq_p2_dev(spec[:, 0].contiguous(), want_sync=False)    # open loop: the feedback values are not consumed
         self.cells[:F, :o.c_p2 - self.p2_skip] = p2[:, self.p2_skip:]
         # data symbols: equalised cells land directly behind, symbol after symbol
         data = spec[:, 1:].contiguous().reshape(F * (self.n_sym - 1), o.fft_size, 2)
-        cells, _ = o.eq_data_dev(data, self.sym_index[:F * (self.n_sym - 1)])
+        cells, _ = o.eq_data_dev(data, self.sym_index[:F * (self.n_sym - 1)], want_sync=False)
         self.cells[:F, o.c_p2 - self.p2_skip:] = cells.reshape(F, (self.n_sym - 1) * o.c_data, 2)
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):

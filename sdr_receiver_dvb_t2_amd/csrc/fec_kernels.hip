@@ -102,12 +102,14 @@ __global__ __launch_bounds__(256) void demap_stats_kernel(DemapParams p, const f
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
 }
 
-__global__ void demap_stats_final_kernel(const double *__restrict__ partial, int blocks, float d, float precision_override,
-                                         float *__restrict__ sums)
+__global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__restrict__ partial, int blocks, float d,
+                                                               float precision_override, float *__restrict__ sums)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wavefront folds the per-block partial sums; lane-strided accumulation then a fixed butterfly: deterministic
     double ss = 0.0, se = 0.0;
-    for (int b = 0; b < blocks; ++b) { ss += partial[2 * b]; se += partial[2 * b + 1]; }      // fixed order: deterministic
+    for (int b = threadIdx.x; b < blocks; b += 64) { ss += partial[2 * b]; se += partial[2 * b + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_down(ss, o, 64); se += __shfl_down(se, o, 64); }
+    if (threadIdx.x != 0) return;
     const float fs = (float)ss, fe = (float)se;
     float precision = div_r(mul_r(mul_r(8.0f, d), fs), fe);        // 8.0f * NORM * sum_s / sum_e
     if (precision_override > 0.0f) precision = precision_override;

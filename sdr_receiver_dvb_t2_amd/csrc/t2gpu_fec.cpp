@@ -80,7 +80,7 @@ extern "C" t2gpu_demap *t2gpu_demap_create(int mod, int fec_type, int code_rate,
     h->p.rot_c = (float)std::cos(-(double)ROT[mod]);
     h->p.rot_s = (float)std::sin(-(double)ROT[mod]);
     h->p.d = NORM[mod];
-    h->stats_blocks = 1024;
+    h->stats_blocks = 512;
     bool ok = true;
     if (mod > 0) {
         std::vector<uint16_t> addr;

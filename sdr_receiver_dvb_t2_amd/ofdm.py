@@ -53,27 +53,29 @@ class t2_ofdm(object):
         return y
 
     # ---- data_symbol::execute, batched
-    def eq_data_dev(self, symbols, symbol_index):
+    def eq_data_dev(self, symbols, symbol_index, want_sync=True, out=None):
         import torch
         n = symbols.shape[0]
         assert symbols.is_cuda and symbols.dtype == torch.float32 and symbols.is_contiguous()
         assert symbol_index.dtype == torch.int32 and symbol_index.numel() == n
-        cells = torch.empty((n, self.c_data, 2), dtype=torch.float32, device=symbols.device)
-        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device)
+        cells = out if out is not None else torch.empty((n, self.c_data, 2), dtype=torch.float32, device=symbols.device)
+        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device) if want_sync else None
         rc = self._l.t2gpu_eq_data_execute_dev(self._h, symbols.data_ptr(), symbol_index.data_ptr(), n, cells.data_ptr(),
-                                               sync.data_ptr(), torch.cuda.current_stream(symbols.device).cuda_stream)
+                                               sync.data_ptr() if want_sync else None,
+                                               torch.cuda.current_stream(symbols.device).cuda_stream)
         if rc < 0:
             check(rc, "t2gpu_eq_data_execute_dev")
         return cells, sync
 
     # ---- equaliser part of p2_symbol::execute, batched over frames
-    def eq_p2_dev(self, symbols):
+    def eq_p2_dev(self, symbols, want_sync=True):
         import torch
         n = symbols.shape[0]
         assert symbols.is_cuda and symbols.dtype == torch.float32 and symbols.is_contiguous()
         cells = torch.empty((n, self.c_p2, 2), dtype=torch.float32, device=symbols.device)
-        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device)
-        rc = self._l.t2gpu_eq_p2_execute_dev(self._h, symbols.data_ptr(), n, cells.data_ptr(), sync.data_ptr(),
+        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device) if want_sync else None
+        rc = self._l.t2gpu_eq_p2_execute_dev(self._h, symbols.data_ptr(), n, cells.data_ptr(),
+                                             sync.data_ptr() if want_sync else None,
                                              torch.cuda.current_stream(symbols.device).cuda_stream)
         if rc < 0:
             check(rc, "t2gpu_eq_p2_execute_dev")
