@@ -161,6 +161,10 @@ int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell,
  * p2_symbol.cpp:89-262) for the P2 symbols of n_symbols frames: [n][fft_size] in, [n][c_p2] cells out (returned count; the
  * first 1840 + l1_post_size cells of each are L1 signalling, time_deinterleaver.cpp:296-300). L1 parsing is not done here. */
 int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream);
+/* Replaces  complex* fc_symbol::execute(complex* ofdm_cell, float& sample_rate_offset, float& phase_offset)
+ * (src/DVB_T2/fc_symbol.h:31, fc_symbol.cpp:82-271) for the frame-closing symbols of n_symbols frames: [n][fft_size] in,
+ * [n][n_fc] cells out (returned count). Fails when the mode has no frame-closing symbol (l_fc = 0). */
+int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream);
 /* host only: {fft_size, k_total, k_ext, k_offset, l_nulls, c_p2, c_data, n_fc, c_fc, l_fc, len_frame, guard_interval_size}
  * (dvbt2_{p2,bwt_ext,data}_parameters_init, src/DVB_T2/dvbt2_definition.cpp:20-648) */
 int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,

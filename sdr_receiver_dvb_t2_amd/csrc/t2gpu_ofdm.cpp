@@ -85,7 +85,7 @@ static int build_segments(const std::vector<uint8_t> &mp, int K, std::vector<int
 struct t2gpu_ofdm {
     T2Mode m;
     int device = 0, max_symbols = 0, rows = 0, num_cu = 256;
-    EqParams eq{}, eq_p2{};
+    EqParams eq{}, eq_p2{}, eq_fc{};
     float2 *d_twiddle = nullptr;
     uint8_t *d_map = nullptr;
     float *d_refer = nullptr, *d_lut = nullptr;
@@ -94,6 +94,10 @@ struct t2gpu_ofdm {
     uint8_t *d_map_p2 = nullptr;
     float *d_refer_p2 = nullptr;
     int32_t *d_seg_count_p2 = nullptr, *d_h_even_p2 = nullptr, *d_h_odd_p2 = nullptr;
+    uint8_t *d_map_fc = nullptr;
+    float *d_refer_fc = nullptr;
+    int4 *d_segs_fc = nullptr;
+    int32_t *d_seg_count_fc = nullptr, *d_h_even_fc = nullptr, *d_h_odd_fc = nullptr, *d_index_fc = nullptr;
     float4 *d_pilot_scratch = nullptr;
     // host-call staging
     float2 *d_in = nullptr, *d_out = nullptr, *d_sync = nullptr;
@@ -180,11 +184,33 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     up(&h->d_seg_count_p2, &nseg2, 4);
     up(&h->d_h_even_p2, he2.data(), he2.size() * 4);
     up(&h->d_h_odd_p2, ho2.data(), ho2.size() * 4);
-    const int max_all = std::max(max_seg, (int)nseg2);
+    // the frame-closing symbol (when the mode has one): pilots every dx carriers, n_fc cells, its own de-interleaver
+    int nseg3 = 0;
+    if (m.l_fc) {
+        std::vector<uint8_t> mp3; std::vector<float> rf3; std::vector<int4> seg3;
+        t2_symbol_carriers(m, m.len_frame - 1, mp3, rf3);
+        if (build_segments(mp3, K, seg3) != m.n_fc) { set_error("frame-closing carrier map does not hold n_fc data cells"); t2gpu_ofdm_destroy(h); return nullptr; }
+        nseg3 = (int)seg3.size();
+        const int32_t n3 = nseg3, fcidx = m.len_frame - 1;
+        std::vector<int32_t> he3, ho3;
+        t2_freq_deint(m, 2, he3, ho3);
+        std::vector<int32_t> idxfill(max_symbols, fcidx);
+        up(&h->d_map_fc, mp3.data(), mp3.size());
+        up(&h->d_refer_fc, rf3.data(), rf3.size() * 4);
+        up(&h->d_segs_fc, seg3.data(), seg3.size() * sizeof(int4));
+        up(&h->d_seg_count_fc, &n3, 4);
+        up(&h->d_h_even_fc, he3.data(), he3.size() * 4);
+        up(&h->d_h_odd_fc, ho3.data(), ho3.size() * 4);
+        up(&h->d_index_fc, idxfill.data(), idxfill.size() * 4);
+    }
+    const int max_all = std::max(std::max(max_seg, (int)nseg2), nseg3);
     ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_all + 1) * sizeof(float4)), "hipMalloc");
     if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
     h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map, h->d_refer, h->d_segs,
                      h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut, h->d_lut + 65536};
+    if (m.l_fc)
+        h->eq_fc = EqParams{N, m.l_nulls, K, m.n_fc, m.len_frame - 1, nseg3, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_fc, h->d_refer_fc,
+                            h->d_segs_fc, h->d_seg_count_fc, h->d_h_even_fc, h->d_h_odd_fc, h->d_lut, h->d_lut + 65536};
     h->eq_p2 = EqParams{N, m.l_nulls, K, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
                         h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut, h->d_lut + 65536};
     return h;
@@ -197,6 +223,8 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
     hipFree(h->d_seg_count_p2); hipFree(h->d_h_even_p2); hipFree(h->d_h_odd_p2);
+    hipFree(h->d_map_fc); hipFree(h->d_refer_fc); hipFree(h->d_segs_fc); hipFree(h->d_seg_count_fc); hipFree(h->d_h_even_fc);
+    hipFree(h->d_h_odd_fc); hipFree(h->d_index_fc);
     delete h;
 }
 
@@ -253,6 +281,16 @@ extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     T2_HIP(launch_eq_data(h->eq_p2, reinterpret_cast<const float2 *>(d_symbols), h->d_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
                           h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), s));
     return h->m.c_p2;
+}
+
+// frame-closing symbols of a batch of frames (idx_symbol = len_frame - 1 for all of them)
+extern "C" int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream)
+{
+    if (!h || !d_symbols || !d_cells || n_symbols < 1 || n_symbols > h->max_symbols) { set_error("t2gpu_eq_fc_execute_dev: bad arguments"); return -1; }
+    if (!h->m.l_fc) { set_error("t2gpu_eq_fc_execute_dev: this mode has no frame-closing symbol"); return -1; }
+    T2_HIP(launch_eq_data(h->eq_fc, reinterpret_cast<const float2 *>(d_symbols), h->d_index_fc, n_symbols, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+    return h->m.n_fc;
 }
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,

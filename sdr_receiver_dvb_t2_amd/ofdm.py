@@ -81,6 +81,20 @@ class t2_ofdm(object):
             check(rc, "t2gpu_eq_p2_execute_dev")
         return cells, sync
 
+    # ---- fc_symbol::execute, batched over frames
+    def eq_fc_dev(self, symbols, want_sync=True):
+        import torch
+        n = symbols.shape[0]
+        assert symbols.is_cuda and symbols.dtype == torch.float32 and symbols.is_contiguous()
+        cells = torch.empty((n, self.n_fc, 2), dtype=torch.float32, device=symbols.device)
+        sync = torch.empty((n, 2), dtype=torch.float32, device=symbols.device) if want_sync else None
+        rc = self._l.t2gpu_eq_fc_execute_dev(self._h, symbols.data_ptr(), n, cells.data_ptr(),
+                                             sync.data_ptr() if want_sync else None,
+                                             torch.cuda.current_stream(symbols.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_eq_fc_execute_dev")
+        return cells, sync
+
     def eq_data(self, idx_symbol, ofdm_cell):
         """Reference call shape: returns (cells complex64[c_data], sample_rate_offset, phase_offset)."""
         x = np.ascontiguousarray(ofdm_cell, np.complex64).reshape(self.fft_size)

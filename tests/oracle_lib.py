@@ -228,11 +228,11 @@ def ora_freq_deint(m, kind):
 def ora_data_symbol(m, idx_symbol, ofdm_cell):
     """data_symbol::execute on one fft-shifted symbol (complex64[fft_size]) -> (cells complex64[c_data], phase_offset, sro)."""
     mp, rf = ora_symbol_carriers(m, idx_symbol)
-    kind = 0 if idx_symbol < m.n_p2 else 1
+    kind = 0 if idx_symbol < m.n_p2 else (2 if (m.l_fc and idx_symbol == m.len_frame - 1) else 1)
     he, ho = ora_freq_deint(m, kind)
     h = ho if idx_symbol % 2 == 0 else he
     x = np.ascontiguousarray(ofdm_cell, np.complex64)
-    ncell = m.c_p2 if kind == 0 else m.c_data
+    ncell = [m.c_p2, m.c_data, m.n_fc][kind]
     out = np.zeros(ncell, np.complex64)
     sync = np.zeros(2, np.float32)
     fn = oracle().ora_data_symbol

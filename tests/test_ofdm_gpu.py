@@ -123,3 +123,22 @@ def test_p2_equaliser_matches_oracle(torch_cuda, mode):
         assert np.array_equal(got, want)
         assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [(5, 1, 3, 2, 0, 20), (4, 1, 1, 3, 0, 9), (4, 0, 4, 1, 2, 45)])
+def test_frame_closing_equaliser_matches_oracle(torch_cuda, mode):
+    import sdr_receiver_dvb_t2_amd as pkg
+    torch = torch_cuda
+    m = ol.ora_mode(*mode)
+    assert m.l_fc == 1
+    ctx = pkg.t2_ofdm(*mode, max_symbols=8)
+    idx = m.len_frame - 1
+    syms = np.stack([make_symbol(m, idx, seed=s) for s in range(3)])
+    cells, sync = ctx.eq_fc_dev(torch.from_numpy(syms.view(np.float32).reshape(3, m.fft_size, 2)).cuda())
+    cells = cells.cpu().numpy(); sync = sync.cpu().numpy()
+    for b in range(3):
+        want, pho, sro = ol.ora_data_symbol(m, idx, syms[b])
+        got = (cells[b, :, 0] + 1j * cells[b, :, 1]).astype(np.complex64)
+        assert np.array_equal(got, want)
+        assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
+    ctx.close()
