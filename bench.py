@@ -123,7 +123,7 @@ def main():
     F = hi - lo
     uniq, sent, nb = make_frames(2, args.snr, seed=20250614 + 10 * rank)
     host = np.concatenate([uniq] * ((F + 1) // 2))[:F]
-    x = torch.from_numpy(host.view(np.float32).reshape(F, 60, 32768, 2)).to(dev)
+    x = torch.from_numpy(host.view(np.float32).reshape(F, 60, 32768, 2)).to(dev)     # CFG-A has no frame-closing symbol
 
     def make_chain(saturate):
         return pkg.t2_chain(*MODE, L1_POST_SIZE, *PLP, nb, max_frames=F, device=local_rank, ldpc_trials=args.trials,

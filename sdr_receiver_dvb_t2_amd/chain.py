@@ -30,9 +30,10 @@ class t2_chain(object):
         self.ofdm = t2_ofdm(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data,
                             max_symbols=max_frames * (n_data + 1), device=device)
         o = self.ofdm
-        self.n_sym = o.n_p2 + n_data - o.l_fc                   # symbols handled here (frame-closing symbol: not yet)
+        self.n_sym = o.n_p2 + n_data                            # P2, data symbols, frame-closing symbol when the mode has one
+        self.n_dat = n_data - o.l_fc
         self.p2_skip = L1_PRE_CELL + l1_post_size               # time_deinterleaver.cpp:46,296-300
-        self.frame_cells = (o.c_p2 - self.p2_skip) + (self.n_sym - 1) * o.c_data
+        self.frame_cells = (o.c_p2 - self.p2_skip) + self.n_dat * o.c_data + o.l_fc * o.n_fc
         self.fec_size = 64800 if plp_fec_type == 1 else 16200
         self.cells_per_fec = self.fec_size // (2 * (plp_mod + 1))
         self.num_blocks = plp_num_blocks
@@ -53,7 +54,7 @@ class t2_chain(object):
         self.llr = torch.empty((max_frames * plp_num_blocks + 64, self.fec_size), dtype=torch.int8, device=self.dev)
         self.carry = 0                                           # FEC frames waiting for a full SIMD batch
         self.time_ldpc, self.ldpc_events = False, []             # bench: HIP events around the LDPC launch
-        idx = np.tile(np.arange(1, self.n_sym, dtype=np.int32), max_frames)
+        idx = np.tile(np.arange(1, 1 + self.n_dat, dtype=np.int32), max_frames)
         self.sym_index = torch.from_numpy(idx).to(self.dev)
 
     def close(self):
@@ -74,9 +75,14 @@ class t2_chain(object):
         p2, _ = o.eq_p2_dev(spec[:, 0].contiguous(), want_sync=False)    # open loop: the feedback values are not consumed
         self.cells[:F, :o.c_p2 - self.p2_skip] = p2[:, self.p2_skip:]
         # data symbols: equalised cells land directly behind, symbol after symbol
-        data = spec[:, 1:].contiguous().reshape(F * (self.n_sym - 1), o.fft_size, 2)
-        cells, _ = o.eq_data_dev(data, self.sym_index[:F * (self.n_sym - 1)], want_sync=False)
-        self.cells[:F, o.c_p2 - self.p2_skip:] = cells.reshape(F, (self.n_sym - 1) * o.c_data, 2)
+        nd = self.n_dat
+        data = spec[:, 1:1 + nd].contiguous().reshape(F * nd, o.fft_size, 2)
+        cells, _ = o.eq_data_dev(data, self.sym_index[:F * nd], want_sync=False)
+        a = o.c_p2 - self.p2_skip
+        self.cells[:F, a:a + nd * o.c_data] = cells.reshape(F, nd * o.c_data, 2)
+        if o.l_fc:                                               # frame-closing symbol: its n_fc cells end the frame's stream
+            fc, _ = o.eq_fc_dev(spec[:, 1 + nd].contiguous(), want_sync=False)
+            self.cells[:F, a + nd * o.c_data:] = fc
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
             self.ti[f].l1_dyn(self.num_blocks)

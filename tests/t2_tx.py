@@ -112,7 +112,7 @@ L1_PRE_CELLS = 1840
 
 
 def plp_blocks_per_frame(m, l1_post_size, cells_per_fec):
-    cells = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (m.n_data - m.l_fc) * m.c_data
+    cells = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (m.n_data - m.l_fc) * m.c_data + m.l_fc * m.n_fc
     return cells // cells_per_fec
 
 
@@ -121,18 +121,18 @@ def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0):
     plp_stream: the PLP's cells in transmission order (time-interleaver output); it fills the P2 symbol behind the L1 cells
     and then the data symbols; the remainder of the last symbol is padded with dummy cells."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    n_sym = m.n_p2 + m.n_data - m.l_fc
-    cap = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (n_sym - 1) * m.c_data
+    n_sym = m.n_p2 + m.n_data
+    cap = (m.c_p2 - L1_PRE_CELLS - l1_post_size) + (m.n_data - m.l_fc) * m.c_data + m.l_fc * m.n_fc
     stream = np.zeros(cap, np.complex128)
     stream[:plp_stream.size] = plp_stream
     out = np.zeros((n_sym, m.fft_size), np.complex64)
     pos = 0
     for l in range(n_sym):
         mp, rf = ol.ora_symbol_carriers(m, l)
-        kind = 0 if l < m.n_p2 else 1
+        kind = 0 if l < m.n_p2 else (2 if (m.l_fc and l == m.len_frame - 1) else 1)
         he, ho = ol.ora_freq_deint(m, kind)
         h = ho if l % 2 == 0 else he
-        ncell = m.c_p2 if kind == 0 else m.c_data
+        ncell = [m.c_p2, m.c_data, m.n_fc][kind]
         if kind == 0:
             l1 = (1 - 2 * rng.integers(0, 2, L1_PRE_CELLS + l1_post_size)).astype(np.complex128)     # BPSK filler
             take = ncell - l1.size

@@ -32,7 +32,7 @@ def run_chain(torch, mode, l1_post_size, mod, fec_type, code_rate, snr_db, n_fra
         syms.append(t2_tx.build_frame(m, stream, l1_post_size, seed + f, snr_db=snr_db, phase=0.4 * (f + 1)))
         pos += nb
     chain = pkg.t2_chain(*mode, l1_post_size, mod, fec_type, code_rate, 1, nb, max_frames=n_frames, saturate_llr=saturate)
-    x = torch.from_numpy(np.stack(syms).view(np.float32).reshape(n_frames, m.len_frame - m.l_fc, m.fft_size, 2)).cuda()
+    x = torch.from_numpy(np.stack(syms).view(np.float32).reshape(n_frames, m.len_frame, m.fft_size, 2)).cuda()
     bits, trials = chain.demod_dev(x, flush=True)
     torch.cuda.synchronize()
     trials = trials.cpu().numpy()
@@ -54,6 +54,7 @@ def ts_slice(ts, frame_pos, nb, k_bch):
 @pytest.mark.parametrize("name,mode,lps,mod,fec_type,code_rate,snr,saturate", [
     ("CFG-B 16K ext PP7 64-QAM 16200 r1/2", (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 14.0, False),
     ("32K normal PP4 64-QAM 64800 r2/3", (5, 0, 3, 0, 0, 20), 400, 2, 1, 2, 18.0, False),
+    ("16K ext PP2 GI1/8 with frame-closing symbol, 16-QAM 16200 r3/5", (4, 1, 1, 2, 0, 24), 150, 1, 0, 1, 12.0, False),
     # 256-QAM: the reference's int8 cast wraps on the outer points at every SNR (see include/t2gpu.h, t2gpu_demap_configure);
     # with the clamping extension the same chain decodes CFG-A
     ("CFG-A 32K ext PP7 256-QAM 64800 r3/4 (clamped LLRs)", (5, 1, 6, 4, 0, 59), 350, 3, 1, 3, 22.0, True),
