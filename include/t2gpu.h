@@ -117,6 +117,36 @@ int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
 int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
 int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
 
+/* ---------------------------------------------------------------- L1 signalling from the P2 cells (host) ------------
+ * Replaces  bool p2_symbol::l1_pre_info(dvbt2_parameters&)  (src/DVB_T2/p2_symbol.cpp:301-532) and
+ * bool p2_symbol::l1_post_info()  with its field parsers (:534-1089). Input: the equalised, frequency-de-interleaved cells
+ * of the P2 symbol (what t2gpu_eq_p2_execute_dev returns): the first 1840 carry L1-pre (200 systematic BPSK bits are read),
+ * the next l1_post_size carry L1-post. As the reference: hard decisions on the systematic bits + CRC-32, no L1 FEC decoding.
+ * Field names are those of the reference's l1_presignalling / l1_postsignalling structs (dvbt2_definition.h:249-344).
+ * Return 1 = CRC-32 ok (structs filled), 0 = CRC-32 error, -1 = bad arguments. */
+typedef struct {
+    int32_t type, bwt_ext, s1, s2_field1, s2_field2, l1_repetition_flag, guard_interval, papr, l1_post_mod, l1_cod, l1_fec_type,
+        l1_post_size, l1_post_info_size, pilot_pattern, tx_id_availability, cell_id, network_id, t2_system_id, num_t2_frames,
+        num_data_symbols, regen_flag, l1_post_extension, num_rf, current_rf_index, t2_version, l1_post_scrambled, t2_base_lite,
+        reserved;
+    uint32_t crc_32;
+} t2gpu_l1_pre;
+typedef struct {
+    int32_t id, plp_type, plp_payload_type, ff_flag, first_rf_idx, first_frame_idx, plp_group_id, plp_cod, plp_mod, plp_rotation,
+        plp_fec_type, plp_num_blocks_max, frame_interval, time_il_length, time_il_type, in_band_a_flag, in_band_b_flag, reserved_1,
+        plp_mode, static_flag, static_padding_flag;
+} t2gpu_l1_plp;
+typedef struct { int32_t id, start, num_blocks, reserved_2; } t2gpu_l1_dyn_plp;
+typedef struct {
+    int32_t sub_slices_per_frame, num_plp, num_aux, aux_config_rfu, rf_idx[8];
+    uint32_t frequency[8];
+    int32_t fef_type, fef_length, fef_interval, fef_length_msb, reserved_2;
+    int32_t frame_idx, sub_slice_interval, type_2_start, l1_change_counter, start_rf_idx, dyn_reserved_1, dyn_reserved_3;
+} t2gpu_l1_post;
+int t2gpu_l1_pre_parse(const float *p2_cells, t2gpu_l1_pre *out);
+int t2gpu_l1_post_parse(const float *l1_post_cells /* = p2_cells + 2*1840 */, const t2gpu_l1_pre *pre, t2gpu_l1_post *post,
+                        t2gpu_l1_plp *plp /* [max_plp] */, t2gpu_l1_dyn_plp *dyn /* [max_plp] */, int max_plp);
+
 /* ---------------------------------------------------------------- BBFRAME de-framing -> transport stream (host) -----
  * Replaces  void bb_de_header::execute(int plp_id, l1_postsignalling, int len_in, uint8_t* in)  (src/DVB_T2/bb_de_header.h:59,
  * bb_de_header.cpp:84-448) and set_out's need_plp (:500-525). in: the k_bch descrambled bits of one BBFRAME, one per byte.

@@ -162,3 +162,91 @@ def build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, n_blocks, rotation=
     cw = fec_encode(cid, scramble(frames))
     cells = cells_from_codewords(cw, mod, fec_type, code_rate, rotation)
     return interleave_ti_block(cells), frames, used
+
+
+# ------------------------------------------------------------------------------------------------ L1 signalling (EN 302 755 7.2)
+L1_PRE_FIELDS = [("type", 8), ("bwt_ext", 1), ("s1", 3), ("s2_field1", 3), ("s2_field2", 1), ("l1_repetition_flag", 1),
+                 ("guard_interval", 3), ("papr", 4), ("l1_post_mod", 4), ("l1_cod", 2), ("l1_fec_type", 2), ("l1_post_size", 18),
+                 ("l1_post_info_size", 18), ("pilot_pattern", 4), ("tx_id_availability", 8), ("cell_id", 16), ("network_id", 16),
+                 ("t2_system_id", 16), ("num_t2_frames", 8), ("num_data_symbols", 12), ("regen_flag", 3), ("l1_post_extension", 1),
+                 ("num_rf", 3), ("current_rf_index", 3), ("t2_version", 4), ("l1_post_scrambled", 1), ("t2_base_lite", 1), ("reserved", 4)]
+L1_PLP_FIELDS = [("id", 8), ("plp_type", 3), ("plp_payload_type", 5), ("ff_flag", 1), ("first_rf_idx", 3), ("first_frame_idx", 8),
+                 ("plp_group_id", 8), ("plp_cod", 3), ("plp_mod", 3), ("plp_rotation", 1), ("plp_fec_type", 2), ("plp_num_blocks_max", 10),
+                 ("frame_interval", 8), ("time_il_length", 8), ("time_il_type", 1), ("in_band_a_flag", 1), ("in_band_b_flag", 1),
+                 ("reserved_1", 11), ("plp_mode", 2), ("static_flag", 1), ("static_padding_flag", 1)]
+
+
+def crc32_t2(bits):
+    crc = 0xffffffff
+    for b in bits:
+        fb = int(b) ^ ((crc >> 31) & 1)
+        crc = (crc << 1) & 0xffffffff
+        if fb:
+            crc ^= 0x04C11DB7
+    return crc
+
+
+def l1_pre_cells(fields, seed=0):
+    """1840 L1-pre cells: the 200 systematic bits (fields + CRC-32) BPSK-mapped, the parity part random (the reference never
+    reads it)."""
+    bits = []
+    for name, n in L1_PRE_FIELDS:
+        bits += bits_of(int(fields.get(name, 0)), n)
+    assert len(bits) == 168
+    bits += bits_of(crc32_t2(bits), 32)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    allbits = np.concatenate([np.array(bits, np.uint8), rng.integers(0, 2, L1_PRE_CELLS - 200, dtype=np.uint8)])
+    return (1.0 - 2.0 * allbits).astype(np.complex128)
+
+
+def l1_post_bits(post, plps, dyn, num_rf=1, fef=False, num_aux=0):
+    b = bits_of(post.get("sub_slices_per_frame", 1), 15) + bits_of(len(plps), 8) + bits_of(num_aux, 4) + bits_of(post.get("aux_config_rfu", 0), 8)
+    for r in range(num_rf):
+        b += bits_of(r, 3) + bits_of(post.get("frequency", 666000000), 32)
+    if fef:
+        b += bits_of(post.get("fef_type", 0), 4) + bits_of(post.get("fef_length", 0), 22) + bits_of(post.get("fef_interval", 0), 8)
+    for p in plps:
+        for name, n in L1_PLP_FIELDS:
+            b += bits_of(int(p.get(name, 0)), n)
+    b += bits_of(0, 2) + bits_of(0, 30)
+    b += [0] * (32 * num_aux)
+    b += bits_of(post.get("frame_idx", 0), 8) + bits_of(post.get("sub_slice_interval", 0), 22) + bits_of(post.get("type_2_start", 0), 22)
+    b += bits_of(post.get("l1_change_counter", 0), 8) + bits_of(0, 3) + bits_of(0, 8)
+    for d in dyn:
+        b += bits_of(d["id"], 8) + bits_of(d["start"], 22) + bits_of(d["num_blocks"], 10) + bits_of(0, 8)
+    b += bits_of(0, 8) + [0] * (48 * num_aux)
+    return b
+
+
+def l1_post_cells(info_bits, l1_post_mod, l1_post_size, seed=0, scrambled=False):
+    """L1-post cells for BPSK / QPSK / 16-QAM / 64-QAM: info bits + CRC-32 + random fill, bit interleaver (16/64-QAM) and
+    demultiplexer inverted from the receiver's tables, per-axis mapping inverse to the hard decisions of p2_symbol.cpp:596-634."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bpc = 1 if l1_post_mod == 0 else 2 * l1_post_mod
+    n_post = l1_post_size * bpc
+    bits = np.array(list(info_bits) + bits_of(crc32_t2(info_bits), 32), np.uint8)
+    bits = np.concatenate([bits, rng.integers(0, 2, n_post - bits.size, dtype=np.uint8)])
+    if scrambled:
+        bits = bits ^ ol.ora_bb_prbs(n_post)
+    cols = {2: 8, 3: 12}.get(l1_post_mod, 0)
+    rows = n_post // cols if cols else 0
+    inter = np.zeros(n_post, np.uint8)
+    step = l = 0
+    for i in range(n_post):                                  # receiver: bits[l + step] = inter[i]
+        inter[i] = bits[l + step]
+        step += rows
+        if step == rows * cols:
+            step = 0
+            l += 1
+    mux = {2: [7, 1, 3, 5, 2, 4, 6, 0], 3: [11, 8, 5, 2, 10, 7, 4, 1, 9, 6, 3, 0]}.get(l1_post_mod, [0])
+    sub = len(mux)
+    cellbits = np.zeros(n_post, np.uint8)
+    for i in range(n_post):                                  # receiver: inter[mux[i % sub] + sub*(i // sub)] = demapped bit i
+        cellbits[i] = inter[mux[i % sub] + sub * (i // sub)]
+    cb = cellbits.reshape(l1_post_size, bpc)
+    if l1_post_mod == 0:
+        return (1.0 - 2.0 * cb[:, 0]).astype(np.complex128)
+    d = [None, NORM[0], NORM[1], NORM[2]][l1_post_mod]
+    re = map_axis(cb[:, 0::2], d)
+    im = map_axis(cb[:, 1::2], d)
+    return re + 1j * im
