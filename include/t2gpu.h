@@ -207,6 +207,68 @@ int t2gpu_table_symbol_carriers(int fft_mode, int carrier_mode, int pilot_patter
 int t2gpu_table_freq_deint(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,
                            int kind, int32_t *h_even, int32_t *h_odd);
 
+/* ---------------------------------------------------------------- sample-rate front end ----------------------------
+ * Replaces the per-sample loop of
+ *     void dvbt2_demodulator::execute(int len_in, int16_t* i_in, int16_t* q_in, signal_estimate* signal)
+ *     (src/DVB_T2/dvbt2_demodulator.h:64, src/DVB_T2/dvbt2_demodulator.cpp:145-254)
+ * up to the hand-over to symbol_acquisition: int16 -> float, dc removal (exponential_averager, DSP/loop_filters.hh:56-73),
+ * IQ-imbalance correction from the previous call's sign statistics (:184-185,228-234,256-265), NCO de-rotation (:187-205),
+ * cubic Farrow resampling (DSP/interpolator_farrow.hh:41-68) and the 64-tap /2 decimator (DSP/filter_decimator.h:72-131).
+ * The handle owns what the reference keeps in dvbt2_demodulator members between calls (averagers, NCO phases, c1/c2, Farrow
+ * delay line and position, decimator history and phase).
+ *
+ * The reference closes its tracking loops once per OFDM symbol: inside one execute() the input is cut into chunks (one
+ * per symbol, :151-163) and each chunk runs with constant loop values. Here one call takes all chunks of an execute() with
+ * the loop values of each: phase_est_filtered (added to phase_nco at the chunk start, :165), frequency_est_filtered
+ * (subtracted from frequency_nco per sample, :187) and arbitrary_resample (:157-158). A closed loop calls it with one chunk
+ * at a time; an open-loop replay (or the benchmark: zeros and the nominal resample) passes a whole buffer.
+ * id_device: 0 = SDRplay (scale 2^-14), 1 = AirSpy (2^-12, I/Q interleaved: stride 2), 2 = PlutoSDR (2^-11)  (:31-50).
+ * out: decimated complex samples (re,im float pairs) of all chunks back to back; chunk_out_len[c] = cells chunk c produced
+ * (what symbol_acquisition receives as len_in). Returns the total number of output cells, < 0 on error. */
+typedef struct t2gpu_front t2gpu_front;
+t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int max_samples, int device);
+void t2gpu_front_destroy(t2gpu_front *h);
+int t2gpu_front_reset(t2gpu_front *h); /* dvbt2_demodulator::reset, :111-127 */
+/* nominal resample = sample_rate / (SAMPLE_RATE * 2) and its limit (+100 ppm), as :54-55 computes them */
+int t2gpu_front_resample(const t2gpu_front *h, double *resample, double *max_resample);
+long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *phase_est_filtered,
+                             const float *frequency_est_filtered, const double *arbitrary_resample, const int16_t *d_i,
+                             const int16_t *d_q, float *d_out, long out_cap_cells, int32_t *chunk_out_len /* host, or NULL */,
+                             void *stream);
+long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *phase_est_filtered,
+                         const float *frequency_est_filtered, const double *arbitrary_resample, const int16_t *i_in,
+                         const int16_t *q_in, float *out, long out_cap_cells, int32_t *chunk_out_len);
+/* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
+int t2gpu_front_state(t2gpu_front *h, float *out8);
+/* intermediate streams of the last call, for tests: which 0 = de-rotated samples (n_in cells), 1 = resampled (before the
+ * decimator). Synchronises. Returns the number of cells copied. */
+long t2gpu_front_debug_stream(t2gpu_front *h, int which, float *out, long cap_cells);
+
+/* Stand-alone stages with the call shape of the reference classes (host buffers; state kept in the handle):
+ *   filter_decimator::execute(len_in, in, len_out, out)          DSP/filter_decimator.h:72
+ *   interpolator_farrow::operator()(len_in, in, resample, len_out, out)   DSP/interpolator_farrow.hh:41 */
+int t2gpu_decim_execute(t2gpu_front *h, int len_in, const float *in, float *out);
+int t2gpu_farrow_execute(t2gpu_front *h, int len_in, const float *in, double arbitrary_resample, float *out, int out_cap_cells);
+
+/* Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327) for a batch of buffered symbols
+ * (guard + fft_size cells each, guard first): d_out[s] = {sum.re, sum.im, frequency_est, 0}. */
+int t2gpu_cp_correlate_dev(const float *d_symbols, int n_symbols, int fft_size, int guard, float *d_out4, void *stream);
+
+/* Tracking loops of symbol_acquisition, host scalar state exactly as the reference keeps it (:328-330,429-439;
+ * proportional_integral_loop_filter, DSP/loop_filters.hh:20-54). */
+typedef struct t2gpu_sync t2gpu_sync;
+t2gpu_sync *t2gpu_sync_create(float sample_rate);
+void t2gpu_sync_destroy(t2gpu_sync *h);
+void t2gpu_sync_frequency(t2gpu_sync *h, float frequency_est, int fft_size);
+void t2gpu_sync_symbol(t2gpu_sync *h, float phase_est, float sample_rate_est);
+/* out4 = {phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered, arbitrary_resample of the next chunk} */
+void t2gpu_sync_get(const t2gpu_sync *h, double *out4);
+
+/* host only (no GPU): the exact run-table expansion of the two float accumulators (csrc/front_plan.h), for tests.
+ * nco: values[i] = frequency_nco used for sample i; farrow: counts[i] = outputs of input i, positions[i] = x1 at input i. */
+int t2gpu_plan_nco(float *frequency_nco /* in/out */, int n, float frequency_est_filtered, float *values, int *n_runs);
+long t2gpu_plan_farrow(float *x1 /* in/out */, int n, double arbitrary_resample, int32_t *counts, float *positions, int *n_runs);
+
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
  * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),

@@ -65,6 +65,24 @@ PROTOTYPES = {
     "t2gpu_table_bitdeint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "t2gpu_table_cell_deint": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "t2gpu_table_bb_prbs": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_front_create": (_vp, [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int]),
+    "t2gpu_front_destroy": (None, [_vp]),
+    "t2gpu_front_reset": (ctypes.c_int, [_vp]),
+    "t2gpu_front_resample": (ctypes.c_int, [_vp, _vp, _vp]),
+    "t2gpu_front_execute_dev": (ctypes.c_long, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp, _vp]),
+    "t2gpu_front_execute": (ctypes.c_long, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
+    "t2gpu_front_state": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_front_debug_stream": (ctypes.c_long, [_vp, ctypes.c_int, _vp, ctypes.c_long]),
+    "t2gpu_decim_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_farrow_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_int]),
+    "t2gpu_cp_correlate_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "t2gpu_sync_create": (_vp, [ctypes.c_float]),
+    "t2gpu_sync_destroy": (None, [_vp]),
+    "t2gpu_sync_frequency": (None, [_vp, ctypes.c_float, ctypes.c_int]),
+    "t2gpu_sync_symbol": (None, [_vp, ctypes.c_float, ctypes.c_float]),
+    "t2gpu_sync_get": (None, [_vp, _vp]),
+    "t2gpu_plan_nco": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
+    "t2gpu_plan_farrow": (ctypes.c_long, [_vp, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,47 @@
+// front_kernels.h -- launchers of the sample-rate front end kernels (front_kernels.hip): dc removal / IQ-imbalance /
+// NCO de-rotation, Farrow resampler, /2 decimation FIR, guard-interval correlation. See front_kernels.hip for the mapping.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "front_plan.h"
+
+constexpr int FRONT_BLOCK = 1024;          // input samples per workgroup in the dc / de-rotation kernels
+constexpr int FRONT_RUN_STRIDE = 256;      // one entry of the run-index arrays per this many input samples
+
+// Device-resident state of one front end (what dvbt2_demodulator keeps in members between execute() calls).
+struct FrontState {
+    double dc_re, dc_im;                   // exponential averagers (dvbt2_demodulator.h:94-96), kept in double on the device
+    double theta[3];                       // sign statistics of the last call (dvbt2_demodulator.cpp:256-265)
+    float c1, c2;                          // IQ-imbalance coefficients used by the NEXT call (:228-234)
+    float level_detect;                    // :235
+    int32_t decim_phase;                   // filter_decimator's d (filter_decimator.h:77)
+};
+
+struct FrontParams {
+    const int16_t *i_in, *q_in;            // device, stride `stride` elements
+    int stride;
+    float short_to_float;
+    int n;                                 // input samples of this call
+    int n_blocks;                          // ceil(n / FRONT_BLOCK)
+    FrontState *state;
+    double *blk;                           // [n_blocks][4] = a, b_re, b_im, -   (block aggregates) then start values
+    double *theta_part;                    // [n_blocks][4]
+    const FrontRun *nco_runs; const int32_t *nco_index; int n_nco_runs;
+    const FrontRun *far_runs; const int32_t *far_index; int n_far_runs;
+    const float *lut_sin, *lut_cos;
+    float2 *derot;                         // [3 + n]: 3 carried samples (delay_data_3,2,1) then this call's
+    float2 *interp;                        // [63 + n_interp]: 63 carried samples then this call's
+    int stages;                            // FRONT_STAGE_* mask: which parts of the chain this call runs
+    long n_interp;
+    float2 *out;                           // decimated stream, n_out cells
+    long n_out;
+    int decim_phase;                       // phase at the start of this call (host copy)
+};
+
+enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4 };
+
+void launch_front(const FrontParams &p, hipStream_t stream);
+
+// Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
+// sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).
+void launch_cp_correlate(const float2 *sym, int n_symbols, int fft_size, int guard, float4 *out, hipStream_t stream);

@@ -1,0 +1,330 @@
+// front_kernels.hip -- sample-rate front end of the reference on gfx950.
+//
+// Replaces the per-sample loop of dvbt2_demodulator::execute (/root/reference/src/DVB_T2/dvbt2_demodulator.cpp:145-254), the cubic
+// Farrow resampler (/root/reference/src/DSP/interpolator_farrow.hh:41-68), the 64-tap /2 decimator
+// (/root/reference/src/DSP/filter_decimator.h:72-131) and the guard-interval correlation of symbol_acquisition
+// (dvbt2_demodulator.cpp:321-327). All of it is streaming HBM work: int16 IQ in, complex float out.
+//
+// What is sequential in the reference and how it is made parallel here:
+//   * dc averager  out += 1e-6 * (in - out)  -- a linear recurrence; composed as (a, b) pairs (x -> a*x + b) in a three-level
+//     scan (thread, workgroup, call). Evaluated in double; the reference's float rounding noise is not reproducible in any
+//     parallel order, parity for this stage is by tolerance (stated in tests/test_front_gpu.py).
+//   * NCO phase and Farrow position accumulators -- exact, through the run tables of front_plan.h.
+//   * decimation phase, delay lines -- carried in the buffers' prefixes (3 de-rotated samples, 63 interpolated samples).
+// Everything else is the reference's float arithmetic in its source order (no FMA contraction: -ffp-contract=off and the
+// *_r helpers), so given the same de-rotated samples the Farrow and decimator outputs are bit-identical to the oracle.
+#include "front_kernels.h"
+#include "tables/dsp_tables_data.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float mul_r(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_r(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_r(float a, float b) { return a - b; }
+
+constexpr double DC_ALPHA = (double)1.0e-6f;                 // dc_ratio, dvbt2_demodulator.h:94
+constexpr float PI_F = 3.14159274101257324219f;
+constexpr float PI_X_2 = PI_F * 2.0f;
+constexpr float K_TABLE = 32767.0f / (2.0f * PI_F);          // fast_math.h:29
+
+struct Lin { double a, re, im; };                            // x -> a*x + (re, im)
+__device__ __forceinline__ Lin compose(const Lin &l, const Lin &r) { return Lin{l.a * r.a, r.a * l.re + r.re, r.a * l.im + r.im}; }
+
+__device__ __forceinline__ void load4(const FrontParams &p, long s0, float xr[4], float xi[4], int &valid)
+{
+    valid = (int)min(4L, max(0L, (long)p.n - s0));
+    if (p.stride == 1 && valid == 4 && ((((uintptr_t)p.i_in | (uintptr_t)p.q_in) & 7) == 0)) {
+        const short4 vi = *reinterpret_cast<const short4 *>(p.i_in + s0);
+        const short4 vq = *reinterpret_cast<const short4 *>(p.q_in + s0);
+        xr[0] = (float)vi.x * p.short_to_float; xr[1] = (float)vi.y * p.short_to_float;
+        xr[2] = (float)vi.z * p.short_to_float; xr[3] = (float)vi.w * p.short_to_float;
+        xi[0] = (float)vq.x * p.short_to_float; xi[1] = (float)vq.y * p.short_to_float;
+        xi[2] = (float)vq.z * p.short_to_float; xi[3] = (float)vq.w * p.short_to_float;
+    } else {
+        for (int k = 0; k < 4; ++k) {
+            const long j = (s0 + k) * p.stride;                                  // dvbt2_demodulator.cpp:176-178
+            xr[k] = k < valid ? (float)p.i_in[j] * p.short_to_float : 0.0f;
+            xi[k] = k < valid ? (float)p.q_in[j] * p.short_to_float : 0.0f;
+        }
+    }
+}
+
+__device__ __forceinline__ Lin thread_lin(const float xr[4], const float xi[4], int valid)
+{
+    Lin l{1.0, 0.0, 0.0};
+    for (int k = 0; k < 4; ++k)
+        if (k < valid) { l.a *= (1.0 - DC_ALPHA); l.re = (1.0 - DC_ALPHA) * l.re + DC_ALPHA * (double)xr[k]; l.im = (1.0 - DC_ALPHA) * l.im + DC_ALPHA * (double)xi[k]; }
+    return l;
+}
+
+// ---- level 1: per-workgroup aggregate of the dc recurrence
+__global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
+{
+    __shared__ Lin sh[256];
+    const int tid = threadIdx.x;
+    float xr[4], xi[4]; int valid;
+    load4(p, (long)blockIdx.x * FRONT_BLOCK + tid * 4, xr, xi, valid);
+    sh[tid] = thread_lin(xr, xi, valid);
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        if ((tid & (2 * s - 1)) == 0) sh[tid] = compose(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) { double *o = p.blk + 4 * (long)blockIdx.x; o[0] = sh[0].a; o[1] = sh[0].re; o[2] = sh[0].im; }
+}
+
+// ---- level 2: scan over the workgroup aggregates (one workgroup); blk[b] becomes the averager value BEFORE block b
+__global__ __launch_bounds__(1024) void front_dc_scan_kernel(FrontParams p)
+{
+    __shared__ Lin sh[2][1024];
+    const int tid = threadIdx.x, nb = p.n_blocks;
+    const int per = (nb + 1023) / 1024, b0 = tid * per, b1 = min(nb, b0 + per);
+    Lin l{1.0, 0.0, 0.0};
+    for (int b = b0; b < b1; ++b) { const double *v = p.blk + 4 * (long)b; l = compose(l, Lin{v[0], v[1], v[2]}); }
+    int cur = 0;
+    sh[0][tid] = l;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {                                          // inclusive Hillis-Steele
+        Lin v = sh[cur][tid];
+        if (tid >= s) v = compose(sh[cur][tid - s], v);
+        sh[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const double s_re = p.state->dc_re, s_im = p.state->dc_im;
+    Lin ex = tid ? sh[cur][tid - 1] : Lin{1.0, 0.0, 0.0};
+    double re = ex.a * s_re + ex.re, im = ex.a * s_im + ex.im;
+    for (int b = b0; b < b1; ++b) {
+        double *v = p.blk + 4 * (long)b;
+        const Lin w{v[0], v[1], v[2]};
+        v[0] = re; v[1] = im;
+        re = w.a * re + w.re; im = w.a * im + w.im;
+    }
+    __syncthreads();
+    if (tid == 1023) { const Lin t = sh[cur][1023]; p.state->dc_re = t.a * s_re + t.re; p.state->dc_im = t.a * s_im + t.im; }
+}
+
+__device__ __forceinline__ float wrap_2pi(float a)
+{
+    while (a > PI_X_2) a -= PI_X_2;
+    while (a < -PI_X_2) a += PI_X_2;
+    return a;
+}
+
+// ---- level 3: dc removal, sign statistics, IQ-imbalance correction, NCO de-rotation (dvbt2_demodulator.cpp:175-205)
+__global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
+{
+    __shared__ Lin sh[2][256];
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * 4;
+    float xr[4], xi[4]; int valid;
+    load4(p, s0, xr, xi, valid);
+    int cur = 0;
+    sh[0][tid] = thread_lin(xr, xi, valid);
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        Lin v = sh[cur][tid];
+        if (tid >= s) v = compose(sh[cur][tid - s], v);
+        sh[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const double *start = p.blk + 4 * (long)blockIdx.x;
+    const Lin ex = tid ? sh[cur][tid - 1] : Lin{1.0, 0.0, 0.0};
+    double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
+    const float c1 = p.state->c1, c2 = p.state->c2;
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    int r = valid ? p.nco_index[s0 / FRONT_RUN_STRIDE] : 0;
+    for (int k = 0; k < valid; ++k) {
+        const long i = s0 + k;
+        dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
+        dim = dim + DC_ALPHA * ((double)xi[k] - dim);
+        float real = sub_r(xr[k], (float)dre), imag = sub_r(xi[k], (float)dim);
+        float sgn = real < 0 ? -1.0f : 1.0f;                                    // est_1_bit_quantization, :256-265
+        t1 -= (double)mul_r(imag, sgn);
+        t2 += (double)mul_r(real, sgn);
+        sgn = imag < 0 ? -1.0f : 1.0f;
+        t3 += (double)mul_r(imag, sgn);
+        real = mul_r(real, c2);                                                 // :184-185
+        imag = add_r(imag, mul_r(c1, real));
+        while (r + 1 < p.n_nco_runs && p.nco_runs[r + 1].i0 <= i) ++r;
+        const FrontRun run = p.nco_runs[r];
+        const float fnco = (float)(run.base + (double)(i - run.i0) * run.step); // frequency_nco for this sample (exact)
+        const float off = wrap_2pi(sub_r(fnco, run.aux));                       // :194-200
+        const int li = (int)(off * K_TABLE + 32767) & 65535;                    // fast_math.h:47-58
+        const float nr = p.lut_cos[li], ni = p.lut_sin[li];
+        p.derot[3 + i] = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
+    }
+    red[0][tid] = t1; red[1][tid] = t2; red[2][tid] = t3;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) { double *o = p.theta_part + 4 * (long)blockIdx.x; o[0] = red[0][0]; o[1] = red[1][0]; o[2] = red[2][0]; }
+}
+
+// ---- Farrow resampler: one lane per input sample (interpolator_farrow.hh:47-66); positions from the run table
+__global__ __launch_bounds__(256) void front_farrow_kernel(FrontParams p)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    int r = p.far_index[i / FRONT_RUN_STRIDE];
+    while (r + 1 < p.n_far_runs && p.far_runs[r + 1].i0 <= i) ++r;
+    const FrontRun run = p.far_runs[r];
+    const long k = i - run.i0;
+    float x1 = (float)(run.base + (double)k * run.step);
+    long o = (long)run.o0 + k * run.cnt;
+    const float delay_x = run.aux;
+    const float2 in = p.derot[3 + i], d1 = p.derot[2 + i], d2 = p.derot[1 + i], d3 = p.derot[i];
+    float a0[2], a1[2], a2[2], a3[2];
+    const float vin[2] = {in.x, in.y}, v1[2] = {d1.x, d1.y}, v2[2] = {d2.x, d2.y}, v3[2] = {d3.x, d3.y};
+    for (int c = 0; c < 2; ++c) {
+        const float even1 = add_r(v3[c], vin[c]), even2 = add_r(v2[c], v1[c]);
+        const float odd1 = sub_r(v3[c], vin[c]), odd2 = sub_r(v2[c], v1[c]);
+        a0[c] = sub_r(mul_r(9.0f / 16.0f, even2), mul_r(1.0f / 16.0f, even1));
+        a1[c] = sub_r(mul_r(1.0f / 8.0f, odd1), mul_r(11.0f / 8.0f, odd2));
+        a2[c] = mul_r(1.0f / 4.0f, sub_r(even1, even2));
+        a3[c] = sub_r(mul_r(3.0f / 2.0f, odd2), mul_r(1.0f / 2.0f, odd1));
+    }
+    float2 *out = p.interp + 63;
+    while (x1 < 0.5f) {
+        const float x2 = mul_r(x1, x1), x3 = mul_r(x2, x1);
+        float v[2];
+        for (int c = 0; c < 2; ++c) v[c] = add_r(add_r(add_r(mul_r(a3[c], x3), mul_r(a2[c], x2)), mul_r(a1[c], x1)), a0[c]);
+        out[o++] = make_float2(v[0], v[1]);
+        x1 = add_r(x1, delay_x);
+    }
+}
+
+// ---- /2 decimator: one lane per output cell; the window and the summation order of filter_decimator.h:83-115
+__constant__ float c_taps[64];
+
+__global__ __launch_bounds__(256) void front_decimate_kernel(FrontParams p)
+{
+    __shared__ float2 w[2 * 256 + 64];
+    const long k0 = (long)blockIdx.x * 256;
+    const long m0 = 2 * k0 + (1 - p.decim_phase);            // buffer index (63-cell prefix included) of the oldest cell of output k0
+    const long avail = 63 + p.n_interp;
+    for (int t = threadIdx.x; t < 2 * 256 + 62; t += 256) w[t] = m0 + t < avail ? p.interp[m0 + t] : make_float2(0.f, 0.f);
+    __syncthreads();
+    const long k = k0 + threadIdx.x;
+    if (k >= p.n_out) return;
+    const float2 *x = w + 2 * threadIdx.x;
+    float lane_r[4], lane_i[4];
+    for (int q = 0; q < 4; ++q) {
+        float ar = 0.0f, ai = 0.0f;
+        for (int blk = 0; blk < 4; ++blk) {
+            const int c = 16 * blk + q;
+            const float2 x0 = x[c], x1 = x[c + 4], x2 = x[c + 8], x3 = x[c + 12];
+            const float h0 = c_taps[c], h1 = c_taps[c + 4], h2 = c_taps[c + 8], h3 = c_taps[c + 12];
+            ar = add_r(ar, add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
+            ai = add_r(ai, add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+        }
+        lane_r[q] = ar; lane_i[q] = ai;
+    }
+    p.out[k] = make_float2(add_r(add_r(add_r(lane_r[0], lane_r[1]), lane_r[2]), lane_r[3]),
+                           add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
+}
+
+// ---- end of execute(): statistics -> c1, c2, level (:228-235); carry the delay lines and the decimation phase
+__global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
+{
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int b = tid; b < ((p.stages & FRONT_STAGE_DEROTATE) ? p.n_blocks : 0); b += 256) { const double *v = p.theta_part + 4 * (long)b; t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; }
+    for (int c = 0; c < 3; ++c) red[c][tid] = t[c];
+    const bool carry_d = (p.stages & FRONT_STAGE_FARROW) && tid < 3;
+    const bool carry_i = (p.stages & FRONT_STAGE_DECIMATE) && tid >= 64 && tid < 64 + 63;
+    float2 keep = make_float2(0.f, 0.f);
+    if (carry_d) keep = p.derot[p.n + tid];
+    else if (carry_i) keep = p.interp[p.n_interp + (tid - 64)];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) for (int c = 0; c < 3; ++c) red[c][tid] += red[c][tid + s];
+        __syncthreads();
+    }
+    if (carry_d) p.derot[tid] = keep;
+    else if (carry_i) p.interp[tid - 64] = keep;
+    if (tid == 0 && (p.stages & FRONT_STAGE_DECIMATE)) p.state->decim_phase = (int)((p.decim_phase + p.n_interp) & 1);
+    if (tid == 0 && (p.stages & FRONT_STAGE_DEROTATE) && p.n > 0) {
+        FrontState &s = *p.state;
+        for (int c = 0; c < 3; ++c) s.theta[c] = red[c][0];
+        const float len = (float)p.n;
+        const float avg1 = (float)red[0][0] / len, avg2 = (float)red[1][0] / len, avg3 = (float)red[2][0] / len;
+        s.c1 = avg1 / avg2;
+        const float c_temp = avg3 / avg2;
+        s.c2 = sqrtf(sub_r(mul_r(c_temp, c_temp), mul_r(s.c1, s.c1)));
+        s.level_detect = mul_r(avg2, avg3);
+    }
+}
+
+__device__ __forceinline__ float atan2_approx_dev(float y, float x)              // DSP/fast_math.h:61-81
+{
+    const float PI_2 = 1.57079637050628662109f;
+    if (x == 0.0f) return y > 0.0f ? PI_2 : -PI_2;
+    if (y == 0.0f) return x > 0.0f ? 0.0f : -PI_F;
+    const float abs_x = fabsf(x), abs_y = fabsf(y);
+    const bool min_x = abs_x < abs_y;
+    const float a = min_x ? abs_x / abs_y : abs_y / abs_x;
+    const float s = a * a;
+    float r = ((-4.6496475e-2f * s + 1.5931422e-1f) * s - 3.2762276e-1f) * s * a + a;
+    if (min_x) r = PI_2 - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, int fft_size, int guard, float4 *out)
+{
+    __shared__ double red[2][256];
+    const float2 *s = sym + (long)blockIdx.x * (fft_size + guard), *cp = s + fft_size;
+    double sr = 0.0, si = 0.0;
+    for (int i = 4 + threadIdx.x; i < guard - 4; i += 256) {
+        const float2 a = cp[i], b = s[i];
+        sr += (double)add_r(mul_r(a.x, b.x), mul_r(a.y, b.y));                  // cp[i] * conj(sym[i])
+        si += (double)sub_r(mul_r(a.y, b.x), mul_r(a.x, b.y));
+    }
+    red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
+    __syncthreads();
+    for (int t = 128; t > 0; t >>= 1) {
+        if (threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float re = (float)red[0][0], im = (float)red[1][0];
+        out[blockIdx.x] = make_float4(re, im, atan2_approx_dev(im, re) / (float)(fft_size << 1), 0.0f);
+    }
+}
+
+bool g_taps_loaded[16] = {};
+
+}  // namespace
+
+void launch_front(const FrontParams &p, hipStream_t stream)
+{
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !g_taps_loaded[dev]) {
+        hipMemcpyToSymbol(HIP_SYMBOL(c_taps), T2_DECIM_TAPS, sizeof(T2_DECIM_TAPS));
+        g_taps_loaded[dev] = true;
+    }
+    if (p.n > 0 && (p.stages & FRONT_STAGE_DEROTATE)) {
+        hipLaunchKernelGGL(front_dc_block_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(front_derotate_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
+    }
+    if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))
+        hipLaunchKernelGGL(front_farrow_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+    if (p.n_out > 0 && (p.stages & FRONT_STAGE_DECIMATE)) hipLaunchKernelGGL(front_decimate_kernel, dim3((unsigned)((p.n_out + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(front_finish_kernel, dim3(1), dim3(256), 0, stream, p);
+}
+
+void launch_cp_correlate(const float2 *sym, int n_symbols, int fft_size, int guard, float4 *out, hipStream_t stream)
+{
+    if (n_symbols > 0) hipLaunchKernelGGL(cp_correlate_kernel, dim3(n_symbols), dim3(256), 0, stream, sym, fft_size, guard, out);
+}

@@ -1,0 +1,450 @@
+// t2gpu_front.cpp -- C ABI of the sample-rate front end (include/t2gpu.h, "sample-rate front end"): host planner for the two
+// float accumulators (front_plan.h), device buffers that carry the reference's per-object state between calls, and the
+// scalar tracking loops of symbol_acquisition.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/t2gpu.h"
+#include "front_kernels.h"
+#include "front_plan.h"
+#include "t2gpu_common.h"
+
+using t2gpu::set_error;
+
+struct t2gpu_front {
+    int device = 0, id_device = 0, stride = 1, max_samples = 0;
+    float short_to_float = 1.0f, sample_rate = 0.0f;
+    double resample = 0.5, max_resample = 0.5;
+    long interp_cap = 0;
+    // the two accumulators that do not depend on the signal live on the host (front_plan.h)
+    float phase_nco = 0.0f, frequency_nco = 0.0f, x1 = -0.5f;
+    int decim_phase = 0;
+    // device state and work buffers
+    FrontState *d_state = nullptr;
+    double *d_blk = nullptr, *d_theta = nullptr;
+    float *d_lut = nullptr;
+    float2 *d_derot = nullptr, *d_interp = nullptr;
+    FrontRun *d_runs = nullptr, *h_runs = nullptr;            // [nco runs | farrow runs], pinned staging + device copy
+    int32_t *d_index = nullptr, *h_index = nullptr;           // [nco index | farrow index]
+    size_t run_cap = 0, index_cap = 0;
+    hipEvent_t staged = nullptr;
+    bool staged_pending = false;
+    hipStream_t last_stream = nullptr;
+    long last_n = 0, last_n_interp = 0;
+    // host-call staging
+    int16_t *d_i = nullptr, *d_q = nullptr;
+    float2 *d_out = nullptr;
+    std::vector<FrontRun> nco_runs, far_runs;
+};
+
+namespace {
+
+bool ensure_runs(t2gpu_front *h, size_t need)
+{
+    if (need <= h->run_cap) return true;
+    size_t cap = std::max<size_t>(need + need / 2, 1 << 16);
+    if (h->staged_pending) { hipEventSynchronize(h->staged); h->staged_pending = false; }
+    hipDeviceSynchronize();
+    if (h->d_runs) hipFree(h->d_runs);
+    if (h->h_runs) hipHostFree(h->h_runs);
+    h->d_runs = nullptr; h->h_runs = nullptr; h->run_cap = 0;
+    if (hipMalloc(&h->d_runs, cap * sizeof(FrontRun)) != hipSuccess || hipHostMalloc(&h->h_runs, cap * sizeof(FrontRun)) != hipSuccess) {
+        set_error("t2gpu_front: cannot allocate the run tables");
+        return false;
+    }
+    h->run_cap = cap;
+    return true;
+}
+
+void build_index(const std::vector<FrontRun> &runs, int n, int32_t *index)
+{
+    const int groups = (n + FRONT_RUN_STRIDE - 1) / FRONT_RUN_STRIDE;
+    size_t r = 0;
+    for (int g = 0; g < groups; ++g) {
+        const int i = g * FRONT_RUN_STRIDE;
+        while (r + 1 < runs.size() && runs[r + 1].i0 <= i) ++r;
+        index[g] = (int32_t)r;
+    }
+}
+
+// plan one execute(): fills h->nco_runs / far_runs, advances the host accumulators, returns the interpolated sample count
+long plan_call(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *pe, const float *fe, const double *rs,
+               bool nco, bool farrow, int32_t *chunk_out_len, long *n_out_total)
+{
+    h->nco_runs.clear(); h->far_runs.clear();
+    long pos = 0, o = 0, outs = 0;
+    int phase = h->decim_phase;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int len = chunk_len[c];
+        if (nco) {
+            h->phase_nco = t2_wrap_2pi(h->phase_nco + (pe ? pe[c] : 0.0f));                      // dvbt2_demodulator.cpp:165-171
+            t2_plan_nco(h->frequency_nco, (int)pos, len, fe ? fe[c] : 0.0f, h->phase_nco, h->nco_runs);
+        }
+        long made = 0;
+        if (farrow) {
+            const float d = (float)(rs ? rs[c] : h->resample);                                   // interpolator_farrow.hh:45
+            const size_t first = h->far_runs.size();
+            made = t2_plan_farrow(h->x1, (int)pos, o, len, d, h->far_runs);
+            if (made < 0) { set_error("t2gpu_front: arbitrary_resample outside (1/256, 4)"); return -1; }
+            for (size_t r = first; r < h->far_runs.size(); ++r) h->far_runs[r].aux = d;
+        }
+        const long before = (phase + o) / 2, after = (phase + o + made) / 2;                     // filter_decimator.h:88-90
+        if (chunk_out_len) chunk_out_len[c] = (int32_t)(after - before);
+        outs += after - before;
+        o += made;
+        pos += len;
+    }
+    *n_out_total = outs;
+    return o;
+}
+
+int stage_tables(t2gpu_front *h, int n, hipStream_t stream, FrontParams &p)
+{
+    const size_t nn = h->nco_runs.size(), nf = h->far_runs.size();
+    const size_t groups = (size_t)(n + FRONT_RUN_STRIDE - 1) / FRONT_RUN_STRIDE;
+    if (!ensure_runs(h, nn + nf + 2)) return -1;
+    if (2 * groups + 2 > h->index_cap) { set_error("t2gpu_front: internal index capacity"); return -1; }
+    if (h->staged_pending) { T2_HIP(hipEventSynchronize(h->staged)); h->staged_pending = false; }
+    if (nn) std::memcpy(h->h_runs, h->nco_runs.data(), nn * sizeof(FrontRun));
+    if (nf) std::memcpy(h->h_runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
+    if (nn) build_index(h->nco_runs, n, h->h_index);
+    if (nf) build_index(h->far_runs, n, h->h_index + groups);
+    if (nn + nf) T2_HIP(hipMemcpyAsync(h->d_runs, h->h_runs, (nn + nf) * sizeof(FrontRun), hipMemcpyHostToDevice, stream));
+    if (groups) T2_HIP(hipMemcpyAsync(h->d_index, h->h_index, 2 * groups * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    T2_HIP(hipEventRecord(h->staged, stream));
+    h->staged_pending = true;
+    p.nco_runs = h->d_runs; p.n_nco_runs = (int)nn; p.nco_index = h->d_index;
+    p.far_runs = h->d_runs + nn; p.n_far_runs = (int)nf; p.far_index = h->d_index + groups;
+    return 0;
+}
+
+FrontParams base_params(t2gpu_front *h)
+{
+    FrontParams p{};
+    p.stride = h->stride; p.short_to_float = h->short_to_float;
+    p.state = h->d_state; p.blk = h->d_blk; p.theta_part = h->d_theta;
+    p.lut_sin = h->d_lut; p.lut_cos = h->d_lut + 65536;
+    p.derot = h->d_derot; p.interp = h->d_interp;
+    p.decim_phase = h->decim_phase;
+    return p;
+}
+
+}  // namespace
+
+extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int max_samples, int device)
+{
+    if (id_device < 0 || id_device > 2 || max_samples < 1 || !(sample_rate > 0.0f)) {
+        set_error("t2gpu_front_create: bad arguments");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+        set_error("t2gpu_front_create: no usable HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    t2gpu_front *h = new t2gpu_front();
+    h->device = device; h->id_device = id_device; h->max_samples = max_samples; h->sample_rate = sample_rate;
+    h->stride = id_device == 1 ? 2 : 1;                                                    // dvbt2_demodulator.cpp:31-50
+    h->short_to_float = 1.0f / (float)(1 << (id_device == 0 ? 14 : id_device == 1 ? 12 : 11));
+    const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);                                      // SAMPLE_RATE
+    h->resample = sample_rate / (fs * 2);                                                  // :54 (float arithmetic)
+    h->max_resample = h->resample + h->resample * 1.0e-4;                                  // :55
+    h->interp_cap = (long)((double)max_samples / std::min(h->resample, 1.0) * 1.001) + 64;
+    const size_t nb = (size_t)(max_samples + FRONT_BLOCK - 1) / FRONT_BLOCK;
+    h->index_cap = 2 * ((size_t)max_samples / FRONT_RUN_STRIDE + 2) + 2;
+    std::vector<float> lut(2 * 65536, 0.0f);
+    {   // DSP/fast_math.h:31-42 as the reference binary evaluates it (see t2gpu_ofdm.cpp)
+        const float k_table = 32767.0f / (2.0f * 3.14159274101257324219f);
+        const float rk = 1.0f / k_table;
+        for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
+    }
+    bool ok = hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, nb * 4 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
+              hipMalloc(&h->d_derot, ((size_t)max_samples + 3) * sizeof(float2)) == hipSuccess &&
+              hipMalloc(&h->d_interp, ((size_t)h->interp_cap + 63) * sizeof(float2)) == hipSuccess &&
+              hipMalloc(&h->d_index, h->index_cap * sizeof(int32_t)) == hipSuccess &&
+              hipHostMalloc(&h->h_index, h->index_cap * sizeof(int32_t)) == hipSuccess &&
+              hipEventCreateWithFlags(&h->staged, hipEventDisableTiming) == hipSuccess &&
+              hipMemcpy(h->d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice) == hipSuccess && ensure_runs(h, 1 << 16);
+    if (!ok || t2gpu_front_reset(h) != 0) {
+        set_error("t2gpu_front_create: device allocation failed");
+        t2gpu_front_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void t2gpu_front_destroy(t2gpu_front *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
+    hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
+    if (h->h_runs) hipHostFree(h->h_runs);
+    if (h->h_index) hipHostFree(h->h_index);
+    if (h->staged) hipEventDestroy(h->staged);
+    delete h;
+}
+
+extern "C" int t2gpu_front_reset(t2gpu_front *h)
+{
+    if (!h) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipDeviceSynchronize());
+    FrontState s{};
+    s.c1 = 0.0f; s.c2 = 1.0f;                                                              // dvbt2_demodulator.h:98-99
+    s.level_detect = 3.402823466e+38f;                                                     // .h:161
+    T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    T2_HIP(hipMemset(h->d_derot, 0, 3 * sizeof(float2)));
+    T2_HIP(hipMemset(h->d_interp, 0, 63 * sizeof(float2)));
+    h->phase_nco = 0.0f; h->frequency_nco = 0.0f; h->x1 = -0.5f; h->decim_phase = 0;
+    h->last_n = 0; h->last_n_interp = 0;
+    return 0;
+}
+
+extern "C" int t2gpu_front_resample(const t2gpu_front *h, double *resample, double *max_resample)
+{
+    if (!h) return -1;
+    if (resample) *resample = h->resample;
+    if (max_resample) *max_resample = h->max_resample;
+    return 0;
+}
+
+extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *pe, const float *fe,
+                                        const double *rs, const int16_t *d_i, const int16_t *d_q, float *d_out, long out_cap_cells,
+                                        int32_t *chunk_out_len, void *stream_)
+{
+    if (!h || n_chunks < 0 || (n_chunks && !chunk_len) || !d_i || !d_q || !d_out) { set_error("t2gpu_front_execute: bad arguments"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    long n = 0;
+    for (int c = 0; c < n_chunks; ++c) { if (chunk_len[c] < 0) { set_error("t2gpu_front_execute: negative chunk"); return -1; } n += chunk_len[c]; }
+    if (n > h->max_samples) { set_error("t2gpu_front_execute: more samples than max_samples"); return -1; }
+    if (n == 0) return 0;
+    T2_HIP(hipSetDevice(h->device));
+    // plan on copies so that a capacity error leaves the state untouched
+    const float s_phase = h->phase_nco, s_freq = h->frequency_nco, s_x1 = h->x1;
+    long n_out = 0;
+    const long n_interp = plan_call(h, n_chunks, chunk_len, pe, fe, rs, true, true, chunk_out_len, &n_out);
+    if (n_interp < 0 || n_interp > h->interp_cap || n_out > out_cap_cells) {
+        if (n_interp >= 0) set_error("t2gpu_front_execute: output does not fit (interp_cap / out_cap_cells)");
+        h->phase_nco = s_phase; h->frequency_nco = s_freq; h->x1 = s_x1;
+        return -1;
+    }
+    FrontParams p = base_params(h);
+    p.i_in = d_i; p.q_in = d_q; p.n = (int)n; p.n_blocks = (int)((n + FRONT_BLOCK - 1) / FRONT_BLOCK);
+    p.n_interp = n_interp; p.out = reinterpret_cast<float2 *>(d_out); p.n_out = n_out;
+    p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;
+    if (stage_tables(h, (int)n, stream, p) != 0) return -1;
+    launch_front(p, stream);
+    T2_HIP(hipGetLastError());
+    h->decim_phase = (int)((h->decim_phase + n_interp) & 1);
+    h->last_stream = stream; h->last_n = n; h->last_n_interp = n_interp;
+    return n_out;
+}
+
+extern "C" long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *pe, const float *fe,
+                                    const double *rs, const int16_t *i_in, const int16_t *q_in, float *out, long out_cap_cells,
+                                    int32_t *chunk_out_len)
+{
+    if (!h || !i_in || !q_in || !out) { set_error("t2gpu_front_execute: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    long n = 0;
+    for (int c = 0; c < n_chunks; ++c) n += chunk_len[c];
+    if (n > h->max_samples || n < 0) { set_error("t2gpu_front_execute: more samples than max_samples"); return -1; }
+    if (!h->d_i) {
+        const size_t el = (size_t)h->max_samples * h->stride;
+        if (hipMalloc(&h->d_i, el * 2) != hipSuccess || hipMalloc(&h->d_q, el * 2) != hipSuccess ||
+            hipMalloc(&h->d_out, ((size_t)h->interp_cap / 2 + 2) * sizeof(float2)) != hipSuccess) { set_error("t2gpu_front_execute: staging allocation failed"); return -1; }
+    }
+    if (n == 0) return 0;
+    T2_HIP(hipMemcpy(h->d_i, i_in, (size_t)n * h->stride * 2, hipMemcpyHostToDevice));
+    T2_HIP(hipMemcpy(h->d_q, q_in, (size_t)n * h->stride * 2, hipMemcpyHostToDevice));
+    const long cap = std::min<long>(out_cap_cells, h->interp_cap / 2 + 2);
+    const long n_out = t2gpu_front_execute_dev(h, n_chunks, chunk_len, pe, fe, rs, h->d_i, h->d_q, reinterpret_cast<float *>(h->d_out), cap,
+                                               chunk_out_len, nullptr);
+    if (n_out < 0) return -1;
+    T2_HIP(hipStreamSynchronize(nullptr));
+    if (n_out) T2_HIP(hipMemcpy(out, h->d_out, (size_t)n_out * sizeof(float2), hipMemcpyDeviceToHost));
+    return n_out;
+}
+
+extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
+{
+    if (!h || !out8) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize(h->last_stream));
+    FrontState s;
+    T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+    out8[0] = (float)s.dc_re; out8[1] = (float)s.dc_im; out8[2] = s.c1; out8[3] = s.c2;
+    out8[4] = h->phase_nco; out8[5] = h->frequency_nco; out8[6] = s.level_detect; out8[7] = h->x1;
+    return 0;
+}
+
+extern "C" long t2gpu_front_debug_stream(t2gpu_front *h, int which, float *out, long cap_cells)
+{
+    if (!h || !out || which < 0 || which > 1) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize(h->last_stream));
+    // after the call the buffers' prefixes already hold the carried tail; the call's own samples start behind them
+    const long n = std::min(cap_cells, which == 0 ? h->last_n : h->last_n_interp);
+    // the first 3 (63) cells of the stream were overwritten by the carry when the call was shorter than the prefix; only
+    // the part behind the prefix is reported intact, which is all of it for n >= 3 (63) -- callers use long calls
+    const float2 *src = which == 0 ? h->d_derot + 3 : h->d_interp + 63;
+    if (n > 0) T2_HIP(hipMemcpy(out, src, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int t2gpu_decim_execute(t2gpu_front *h, int len_in, const float *in, float *out)
+{
+    if (!h || len_in < 0 || !in || !out || len_in > h->interp_cap) { set_error("t2gpu_decim_execute: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (len_in == 0) return 0;
+    if (!h->d_out && hipMalloc(&h->d_out, ((size_t)h->interp_cap / 2 + 2) * sizeof(float2)) != hipSuccess) { set_error("t2gpu_decim_execute: staging allocation failed"); return -1; }
+    T2_HIP(hipMemcpy(h->d_interp + 63, in, (size_t)len_in * sizeof(float2), hipMemcpyHostToDevice));
+    FrontParams p = base_params(h);
+    p.n = 0; p.n_blocks = 0; p.n_interp = len_in; p.out = h->d_out;
+    p.n_out = (h->decim_phase + len_in) / 2;
+    p.stages = FRONT_STAGE_DECIMATE;
+    launch_front(p, nullptr);
+    T2_HIP(hipGetLastError());
+    T2_HIP(hipStreamSynchronize(nullptr));
+    h->decim_phase = (h->decim_phase + len_in) & 1;
+    h->last_n_interp = len_in;
+    if (p.n_out) T2_HIP(hipMemcpy(out, h->d_out, (size_t)p.n_out * sizeof(float2), hipMemcpyDeviceToHost));
+    return (int)p.n_out;
+}
+
+extern "C" int t2gpu_farrow_execute(t2gpu_front *h, int len_in, const float *in, double arbitrary_resample, float *out, int out_cap_cells)
+{
+    if (!h || len_in < 0 || !in || !out || len_in > h->max_samples) { set_error("t2gpu_farrow_execute: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (len_in == 0) return 0;
+    const float s_x1 = h->x1;
+    const int32_t chunk = len_in;
+    long n_out_unused = 0;
+    const long n_interp = plan_call(h, 1, &chunk, nullptr, nullptr, &arbitrary_resample, false, true, nullptr, &n_out_unused);
+    if (n_interp < 0 || n_interp > h->interp_cap || n_interp > out_cap_cells) {
+        if (n_interp >= 0) set_error("t2gpu_farrow_execute: output does not fit");
+        h->x1 = s_x1;
+        return -1;
+    }
+    T2_HIP(hipMemcpy(h->d_derot + 3, in, (size_t)len_in * sizeof(float2), hipMemcpyHostToDevice));
+    FrontParams p = base_params(h);
+    p.n = len_in; p.n_blocks = (len_in + FRONT_BLOCK - 1) / FRONT_BLOCK; p.n_interp = n_interp; p.n_out = 0;
+    p.stages = FRONT_STAGE_FARROW;
+    if (stage_tables(h, len_in, nullptr, p) != 0) return -1;
+    launch_front(p, nullptr);
+    T2_HIP(hipGetLastError());
+    T2_HIP(hipStreamSynchronize(nullptr));
+    h->last_n = len_in; h->last_n_interp = n_interp;
+    if (n_interp) T2_HIP(hipMemcpy(out, h->d_interp + 63, (size_t)n_interp * sizeof(float2), hipMemcpyDeviceToHost));
+    return (int)n_interp;
+}
+
+extern "C" int t2gpu_cp_correlate_dev(const float *d_symbols, int n_symbols, int fft_size, int guard, float *d_out4, void *stream)
+{
+    if (!d_symbols || !d_out4 || n_symbols < 0 || fft_size < 1 || guard < 9) { set_error("t2gpu_cp_correlate_dev: bad arguments"); return -1; }
+    launch_cp_correlate(reinterpret_cast<const float2 *>(d_symbols), n_symbols, fft_size, guard, reinterpret_cast<float4 *>(d_out4), (hipStream_t)stream);
+    T2_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- tracking loops (host scalars) ------------------------------------------------------------------------------------
+namespace {
+struct PiFilter {                                                                          // DSP/loop_filters.hh:20-54
+    float k_p = 0.0f, k_i = 0.0f, old_integral = 0.0f;
+    void init(float damping, int bw_hz, int samplerate_hz)
+    {
+        const double dr = damping;
+        const float theta = (float)(((1.0 * bw_hz) / samplerate_hz) / (dr + 1.0 / (4.0 * dr)));
+        k_p = (float)(4.0 * dr * theta / (1.0 + 2.0 * dr * theta + (double)(theta * theta)));
+        k_i = (float)(4.0 * theta * theta / (1.0 + 2.0 * dr * theta + (double)(theta * theta)));
+    }
+    float step(float err, float max_integral)
+    {
+        float integral = old_integral + k_i * err;
+        const float out = integral + k_p * err;
+        if (integral > max_integral) integral = max_integral;
+        else if (integral < -max_integral) integral = -max_integral;
+        old_integral = integral;
+        return out;
+    }
+};
+}  // namespace
+
+struct t2gpu_sync {
+    PiFilter phase, freq;
+    float phase_est_filtered = 0.0f, frequency_est_filtered = 0.0f, old_sample_rate_est = 0.0f;
+    double sample_rate_est_filtered = 0.0, resample = 0.5, max_resample = 0.5;
+};
+
+extern "C" t2gpu_sync *t2gpu_sync_create(float sample_rate)
+{
+    t2gpu_sync *s = new t2gpu_sync();
+    const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);
+    s->phase.init(0.3f, 1000000, (int)fs);                                                 // dvbt2_demodulator.h:106-110
+    s->freq.init(0.7f, 4000000, (int)fs);                                                  // .h:112-116
+    s->resample = sample_rate / (fs * 2);
+    s->max_resample = s->resample + s->resample * 1.0e-4;
+    return s;
+}
+extern "C" void t2gpu_sync_destroy(t2gpu_sync *h) { delete h; }
+extern "C" void t2gpu_sync_frequency(t2gpu_sync *s, float frequency_est, int fft_size)
+{
+    if (s) s->frequency_est_filtered += s->freq.step(frequency_est, 1.0f / (float)fft_size);   // dvbt2_demodulator.cpp:328-330
+}
+extern "C" void t2gpu_sync_symbol(t2gpu_sync *s, float phase_est, float sample_rate_est)       // :429-439
+{
+    if (!s) return;
+    s->phase_est_filtered = s->phase.step(phase_est * 0.5f, 3.14159274101257324219f * 2);
+    const double step = 8.0e-9;
+    if (s->old_sample_rate_est - sample_rate_est > 0.0f) {
+        s->sample_rate_est_filtered -= step;
+        if (s->resample - s->sample_rate_est_filtered < -s->max_resample) s->sample_rate_est_filtered += step;
+    } else if (s->old_sample_rate_est - sample_rate_est < 0.0f) {
+        s->sample_rate_est_filtered += step;
+        if (s->resample - s->sample_rate_est_filtered > s->max_resample) s->sample_rate_est_filtered -= step;
+    }
+    s->old_sample_rate_est = sample_rate_est;
+}
+extern "C" void t2gpu_sync_get(const t2gpu_sync *s, double *out4)
+{
+    if (!s || !out4) return;
+    double r = s->resample - s->sample_rate_est_filtered;                                  // :157-158
+    if (r > s->max_resample) r = s->max_resample;
+    out4[0] = s->phase_est_filtered; out4[1] = s->frequency_est_filtered; out4[2] = s->sample_rate_est_filtered; out4[3] = r;
+}
+
+// ---- planner expansion for tests (host only) -----------------------------------------------------------------------------
+extern "C" int t2gpu_plan_nco(float *frequency_nco, int n, float fe, float *values, int *n_runs)
+{
+    if (!frequency_nco || n < 0 || !values) return -1;
+    std::vector<FrontRun> runs;
+    t2_plan_nco(*frequency_nco, 0, n, fe, 0.0f, runs);
+    for (size_t r = 0; r < runs.size(); ++r) {
+        const int end = r + 1 < runs.size() ? runs[r + 1].i0 : n;
+        for (int i = runs[r].i0; i < end; ++i) values[i] = (float)(runs[r].base + (double)(i - runs[r].i0) * runs[r].step);
+    }
+    if (n_runs) *n_runs = (int)runs.size();
+    return 0;
+}
+
+extern "C" long t2gpu_plan_farrow(float *x1, int n, double arbitrary_resample, int32_t *counts, float *positions, int *n_runs)
+{
+    if (!x1 || n < 0 || !counts || !positions) return -1;
+    std::vector<FrontRun> runs;
+    const long total = t2_plan_farrow(*x1, 0, 0, n, (float)arbitrary_resample, runs);
+    if (total < 0) return -1;
+    for (size_t r = 0; r < runs.size(); ++r) {
+        const int end = r + 1 < runs.size() ? runs[r + 1].i0 : n;
+        for (int i = runs[r].i0; i < end; ++i) {
+            counts[i] = runs[r].cnt;
+            positions[i] = (float)(runs[r].base + (double)(i - runs[r].i0) * runs[r].step);
+        }
+    }
+    if (n_runs) *n_runs = (int)runs.size();
+    return total;
+}

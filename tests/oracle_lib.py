@@ -240,3 +240,177 @@ def ora_data_symbol(m, idx_symbol, ofdm_cell):
     n = fn(ctypes.addressof(m), x.ctypes.data, mp.ctypes.data, rf.ctypes.data, h.ctypes.data, out.ctypes.data, sync.ctypes.data)
     assert n == ncell, (n, ncell)
     return out, float(sync[0]), float(sync[1])
+
+
+# ---- sample-rate front end (oracle/front_oracle.c) and the reference's Qt-free DSP classes (oracle/_ref/libref_dsp.so) ----
+def ref_dsp(strict=False):
+    """The reference's Qt-free DSP headers compiled unmodified: with the reference's own flags (-Ofast), or strict=True
+    without fast-math so every float operation happens in the order the reference source writes it."""
+    key = "ref_dsp_strict" if strict else "ref_dsp"
+    if key not in _cache:
+        path = os.path.join(ROOT, "oracle", "_ref", "lib%s.so" % key)
+        try:
+            _cache[key] = ctypes.CDLL(path) if os.path.exists(path) else None
+        except OSError:
+            _cache[key] = None
+    return _cache[key]
+
+
+def _c64(x):
+    return np.ascontiguousarray(x, np.complex64)
+
+
+class OraDecim(object):
+    """filter_decimator restated; ref=True drives the reference class itself."""
+
+    def __init__(self, ref=False, strict=False):
+        self.lib = ref_dsp(strict) if ref else oracle()
+        self.new, self.free, self.run = ((self.lib.ref_decim_new, self.lib.ref_decim_free, self.lib.ref_decim_execute) if ref else
+                                         (self.lib.ora_decim_create, self.lib.ora_decim_destroy, self.lib.ora_decim_execute))
+        self.new.restype = ctypes.c_void_p
+        self.free.argtypes = [ctypes.c_void_p]
+        self.run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.h = self.new()
+
+    def __call__(self, x):
+        x = _c64(x)
+        out = np.zeros(len(x) // 2 + 1, np.complex64)
+        n = self.run(self.h, len(x), x.ctypes.data, out.ctypes.data)
+        return out[:n].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.free(self.h)
+            self.h = None
+
+
+class OraFarrow(object):
+    """interpolator_farrow<complex,float> restated; ref=True drives the reference template itself."""
+
+    def __init__(self, ref=False, strict=False):
+        self.ref = ref
+        self.lib = ref_dsp(strict) if ref else oracle()
+        self.new, self.free, self.run = ((self.lib.ref_farrow_new, self.lib.ref_farrow_free, self.lib.ref_farrow_execute) if ref else
+                                         (self.lib.ora_farrow_create, self.lib.ora_farrow_destroy, self.lib.ora_farrow_execute))
+        self.new.restype = ctypes.c_void_p
+        self.free.argtypes = [ctypes.c_void_p]
+        self.run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p] + ([] if ref else [ctypes.c_void_p])
+        self.h = self.new()
+
+    def __call__(self, x, resample, want_phases=False):
+        x = _c64(x)
+        cap = int(len(x) / max(resample, 0.05)) + 8
+        out = np.zeros(cap, np.complex64)
+        if self.ref:
+            n = self.run(self.h, len(x), x.ctypes.data, resample, out.ctypes.data)
+            return out[:n].copy()
+        ph = np.zeros(cap, np.float32)
+        n = self.run(self.h, len(x), x.ctypes.data, resample, out.ctypes.data, ph.ctypes.data)
+        return (out[:n].copy(), ph[:n].copy()) if want_phases else out[:n].copy()
+
+    def phase(self):
+        """x1 after the last call (restated class only)."""
+        fn = self.lib.ora_farrow_phase
+        fn.restype = ctypes.c_float
+        fn.argtypes = [ctypes.c_void_p]
+        return np.float32(fn(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.free(self.h)
+            self.h = None
+
+
+class OraPi(ctypes.Structure):
+    _fields_ = [("k_p", ctypes.c_float), ("k_i", ctypes.c_float), ("old_integral", ctypes.c_float)]
+
+
+class OraFront(object):
+    """dvbt2_demodulator::execute front loop (dc / iq imbalance / NCO), chunk by chunk."""
+
+    def __init__(self, id_device=0):
+        o = oracle()
+        o.ora_front_create.restype = ctypes.c_void_p
+        o.ora_front_destroy.argtypes = [ctypes.c_void_p]
+        o.ora_front_chunk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+        o.ora_front_finish.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        o.ora_front_get_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.o = o
+        self.h = o.ora_front_create(id_device)
+        self.stride = 2 if id_device == 1 else 1
+
+    def execute(self, i_in, q_in, chunk_len, phase_est_filtered, frequency_est_filtered):
+        """One execute() call: chunks in order with their loop values. Returns the derotated stream."""
+        i_in = np.ascontiguousarray(i_in, np.int16)
+        q_in = np.ascontiguousarray(q_in, np.int16)
+        total = int(np.sum(chunk_len))
+        out = np.zeros(total, np.complex64)
+        theta = np.zeros(3, np.float32)
+        pos = 0
+        for n, pe, fe in zip(chunk_len, phase_est_filtered, frequency_est_filtered):
+            self.o.ora_front_chunk(self.h, int(n), i_in.ctypes.data, q_in.ctypes.data, pos, float(pe), float(fe),
+                                   theta.ctypes.data, out[pos:].ctypes.data)
+            pos += int(n)
+        self.o.ora_front_finish(self.h, total, theta.ctypes.data)
+        return out, theta
+
+    def set_iq(self, c1, c2):
+        self.o.ora_front_set_iq.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+        self.o.ora_front_set_iq(self.h, float(c1), float(c2))
+
+    def state(self):
+        v = np.zeros(8, np.float32)
+        self.o.ora_front_get_state(self.h, v.ctypes.data)
+        return dict(dc_re=v[0], dc_im=v[1], c1=v[2], c2=v[3], phase_nco=v[4], frequency_nco=v[5], level_detect=v[6])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.ora_front_destroy(self.h)
+            self.h = None
+
+
+def ora_cp_frequency_est(sym, fft_size, guard):
+    sym = _c64(sym)
+    s2 = np.zeros(2, np.float32)
+    fn = oracle().ora_cp_frequency_est
+    fn.restype = ctypes.c_float
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return float(fn(sym.ctypes.data, fft_size, guard, s2.ctypes.data)), complex(s2[0], s2[1])
+
+
+class OraSync(object):
+    """Tracking updates of symbol_acquisition (PI loop filters + the bang-bang sample-rate tracker)."""
+
+    def __init__(self, sample_rate):
+        o = oracle()
+        o.ora_sync_create.restype = ctypes.c_void_p
+        o.ora_sync_create.argtypes = [ctypes.c_float]
+        o.ora_sync_destroy.argtypes = [ctypes.c_void_p]
+        o.ora_sync_frequency.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int]
+        o.ora_sync_symbol.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+        o.ora_sync_resample.restype = ctypes.c_double
+        o.ora_sync_resample.argtypes = [ctypes.c_void_p]
+        o.ora_sync_get.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.o = o
+        self.h = o.ora_sync_create(sample_rate)
+
+    def frequency(self, frequency_est, fft_size):
+        self.o.ora_sync_frequency(self.h, frequency_est, fft_size)
+
+    def symbol(self, phase_est, sample_rate_est):
+        self.o.ora_sync_symbol(self.h, phase_est, sample_rate_est)
+
+    def resample(self):
+        return self.o.ora_sync_resample(self.h)
+
+    def get(self):
+        v = np.zeros(4, np.float64)
+        self.o.ora_sync_get(self.h, v.ctypes.data)
+        return dict(phase_est_filtered=np.float32(v[0]), frequency_est_filtered=np.float32(v[1]),
+                    sample_rate_est_filtered=v[2], resample=v[3])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.ora_sync_destroy(self.h)
+            self.h = None

@@ -1,0 +1,99 @@
+"""The front-end restatement (oracle/front_oracle.c) against the reference's own Qt-free classes compiled unmodified
+(oracle/_ref/libref_dsp.so: filter_decimator.h, interpolator_farrow.hh, loop_filters.hh, buffers.hh)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+needs_ref = pytest.mark.skipif(ol.ref_dsp() is None or ol.ref_dsp(True) is None, reason="oracle/_ref/libref_dsp.so not built here")
+
+
+def _sig(n, seed, scale=0.2):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * scale).astype(np.complex64)
+
+
+@needs_ref
+def test_decimator_bit_exact_vs_reference_class():
+    x = _sig(20000, 1)
+    a, b, c = ol.OraDecim(), ol.OraDecim(ref=True, strict=True), ol.OraDecim(ref=True)
+    pos = 0
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097, 7001):          # odd chunk lengths move the decimation phase
+        ya, yb, yc = a(x[pos:pos + n]), b(x[pos:pos + n]), c(x[pos:pos + n])
+        assert len(ya) == len(yb) == len(yc)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))      # source order of the AVX2 adds
+        np.testing.assert_allclose(ya, yc, rtol=0, atol=3e-7)              # the -Ofast build re-associates them
+        pos += n
+    del b, c
+    # impulse response = the taps, every second one
+    imp = np.zeros(200, np.complex64)
+    imp[0] = 1
+    h = ol.OraDecim()(imp)
+    assert abs(h.real.sum() + 0) > 0 and np.count_nonzero(h) == 32
+
+
+@needs_ref
+@pytest.mark.parametrize("resample", [0.5, 0.5 - 3 * 8.0e-9, 0.5 + 5 * 8.0e-9, 0.5 * (1 + 1.0e-4), 0.4571, 0.73, 1.0])
+def test_farrow_counts_exact_values_close(resample):
+    x = _sig(30000, 2)
+    a, b, c = ol.OraFarrow(), ol.OraFarrow(ref=True, strict=True), ol.OraFarrow(ref=True)
+    pos = 0
+    for n in (1, 2, 3, 500, 8191, 20000):
+        ya, yb, yc = a(x[pos:pos + n], resample), b(x[pos:pos + n], resample), c(x[pos:pos + n], resample)
+        assert len(ya) == len(yb) == len(yc)                                # output count = phase sequence is exact
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))       # source order
+        np.testing.assert_allclose(ya, yc, rtol=0, atol=2e-6)               # -Ofast association only
+        pos += n
+
+
+@needs_ref
+def test_exponential_averager_and_pi_filters_bit_exact():
+    r, o = ol.ref_dsp(), ol.oracle()
+    x = (_sig(50000, 3).real + 0.01).astype(np.float32)
+    r.ref_avg_new.restype = ctypes.c_void_p
+    r.ref_avg_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    h = r.ref_avg_new()
+    yr = np.zeros_like(x)
+    r.ref_avg_run(h, len(x), x.ctypes.data, yr.ctypes.data)
+    o.ora_exp_avg.restype = ctypes.c_float
+    o.ora_exp_avg.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    st = ctypes.c_float(0.0)
+    yo = np.array([o.ora_exp_avg(ctypes.byref(st), 1.0e-6, float(v)) for v in x[:5000]], np.float32)
+    assert np.array_equal(yo.view(np.uint32), yr[:5000].view(np.uint32))
+
+    r.ref_pi_new.restype = ctypes.c_void_p
+    r.ref_pi_new.argtypes = [ctypes.c_int]
+    r.ref_pi_step.restype = ctypes.c_float
+    r.ref_pi_step.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    o.ora_pi_init.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    o.ora_pi_step.restype = ctypes.c_float
+    o.ora_pi_step.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    fs = int(np.float32(1.0) / (np.float32(1.0e-6) * np.float32(7.0) / np.float32(64.0)))
+    rng = np.random.Generator(np.random.PCG64(4))
+    for which, damping, bw, lim in ((0, 0.3, 1000000, 6.2831855), (1, 0.7, 4000000, 1.0 / 32768)):
+        hp = r.ref_pi_new(which)
+        s = ol.OraPi()
+        o.ora_pi_init(ctypes.byref(s), damping, bw, fs)
+        for e in (rng.standard_normal(2000) * lim * 0.3).astype(np.float32):
+            a = r.ref_pi_step(which, hp, float(e), lim)
+            b = o.ora_pi_step(ctypes.byref(s), float(e), lim)
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+
+
+def test_front_chunk_properties():
+    """Unpinned part: sanity of the restated front loop (dc removal, IQ-imbalance statistics, NCO rotation)."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 40000
+    iq = (rng.standard_normal((2, n)) * 2000).astype(np.int16)
+    f = ol.OraFront(0)
+    out, theta = f.execute(iq[0], iq[1], [15000, 25000], [0.0, 0.0], [0.0, 0.0])
+    x = (iq[0].astype(np.float32) + 1j * iq[1].astype(np.float32)) / 16384
+    assert np.abs(out - x).max() < 1e-3                                       # no rotation, c1 = 0, c2 = 1
+    st = f.state()
+    assert abs(st["c1"]) < 0.05 and abs(st["c2"] - 1) < 0.05
+    out2, _ = f.execute(iq[0], iq[1], [n], [0.0], [1.0e-3])                   # constant CFO correction: |out| unchanged
+    assert np.allclose(np.abs(out2), np.abs(out2 * 0 + out2), atol=0)
+    ph = np.unwrap(np.angle(out2[100:2000] / (x[100:2000] * st["c2"] + 1e-9)))
+    assert abs(np.polyfit(np.arange(len(ph)), ph, 1)[0] + 1.0e-3) < 2e-4       # rotates by -frequency_est_filtered per sample
