@@ -269,6 +269,36 @@ void t2gpu_sync_get(const t2gpu_sync *h, double *out4);
 int t2gpu_plan_nco(float *frequency_nco /* in/out */, int n, float frequency_est_filtered, float *values, int *n_runs);
 long t2gpu_plan_farrow(float *x1 /* in/out */, int n, double arbitrary_resample, int32_t *counts, float *positions, int *n_runs);
 
+/* ---------------------------------------------------------------- P1 preamble ----------------------------------------
+ * Replaces  bool p1_symbol::execute(bool gain_changed, float level_detect, const int len_in, complex* in, int& consume,
+ *                                   complex* buffer_sym, int& idx_buffer_sym, dvbt2_parameters& dvbt2,
+ *                                   double& coarse_freq_offset, bool& p1_decoded, bool& reset)
+ *           (src/DVB_T2/p1_symbol.h:33-37, src/DVB_T2/p1_symbol.cpp:75-178) and p1_symbol::demodulate (:180-298).
+ * in: the decimated complex stream symbol_acquisition hands over; *consume: index of the first sample to look at on entry,
+ * index behind the last consumed sample on return (the reference's by-reference argument). Returns 1 when a P1 symbol ended
+ * inside the samples (the reference's return value), 0 when the input was used up, < 0 on error. The handle keeps the
+ * correlator history, the thresholds and the decoded flag between calls exactly as the object does; like the reference it
+ * starts a fresh correlator after every detection.
+ * On detection, in[consume - idx_buffer_sym .. consume) are the samples the reference has already copied into buffer_sym
+ * (the start of the P2 symbol): a caller that keeps buffer_sym copies them itself.
+ * preamble / fft_mode use the reference enums (dvbt2_definition.h:115-133); -1 when this call did not decode (already decoded
+ * and reset_flag = 0, or no carrier shift in 76..95 gave a consistent S1). */
+typedef struct t2gpu_p1 t2gpu_p1;
+typedef struct {
+    int32_t detected, idx_buffer_sym, p1_decoded, preamble, fft_mode, s1, s2, shift, a_part_clipped;
+    float max_correlation, arg_max[2];
+    double coarse_freq_offset; /* Hz */
+} t2gpu_p1_result;
+t2gpu_p1 *t2gpu_p1_create(int max_samples, int device);
+void t2gpu_p1_destroy(t2gpu_p1 *h);
+int t2gpu_p1_reset(t2gpu_p1 *h);
+int t2gpu_p1_execute_dev(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *d_in, int *consume,
+                         int reset_flag, t2gpu_p1_result *res, void *stream);
+int t2gpu_p1_execute(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *in, int *consume, int reset_flag,
+                     t2gpu_p1_result *res);
+/* for tests: correlation trace of the last pass (returns the number of values) and the fft-shifted 1K spectrum of part A */
+int t2gpu_p1_debug(t2gpu_p1 *h, float *corr, int n_corr, float *p1_fft1024);
+
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
  * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),

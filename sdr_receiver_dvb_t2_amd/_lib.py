@@ -81,6 +81,12 @@ PROTOTYPES = {
     "t2gpu_sync_frequency": (None, [_vp, ctypes.c_float, ctypes.c_int]),
     "t2gpu_sync_symbol": (None, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_sync_get": (None, [_vp, _vp]),
+    "t2gpu_p1_create": (_vp, [ctypes.c_int, ctypes.c_int]),
+    "t2gpu_p1_destroy": (None, [_vp]),
+    "t2gpu_p1_reset": (ctypes.c_int, [_vp]),
+    "t2gpu_p1_execute_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_p1_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_p1_debug": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_plan_nco": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "t2gpu_plan_farrow": (ctypes.c_long, [_vp, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp]),
 }

@@ -1,0 +1,289 @@
+// p1_kernels.hip -- P1 preamble detection on gfx950.
+//
+// Replaces p1_symbol::execute / demodulate (/root/reference/src/DVB_T2/p1_symbol.cpp:75-178,180-298). The reference runs a per-sample
+// recursive correlator (delay lines and running sums of /root/reference/src/DSP/buffers.hh). Written out, its output for sample n is
+//     out[n] = AC[n-964] * AB[n-2],   AC[m] = sum_{k=m-540..m} x[k] conj(s[k-542]),   AB[m] = sum_{k=m-480..m} s[k] conj(x[k-482]),
+//     s[k] = x[k] * fq_shift[k mod 1024]
+// (sum_of_buffer<LEN> holds LEN-1 terms: it subtracts the slot it is about to overwrite, buffers.hh:33-39), with x = 0 before the
+// start of the search because reset_buffer() clears every delay line. So the correlator is a pure function of the last 2047
+// samples and every sample is computed independently here: a workgroup stages the two product sequences of its 256 outputs in
+// LDS and each lane adds its two windows in double. The reference's float running sums drift by rounding (sum - old + new,
+// millions of times); parity of the correlation value is therefore by tolerance (tests/test_p1_gpu.py), the detection logic
+// that consumes it is restated exactly.
+// The threshold / arg-max state machine is sequential over samples but trivial; one workgroup runs it from LDS-staged
+// correlation values, skipping in parallel over stretches below the begin threshold. Part A's 1K FFT and the 20 carrier-shift
+// DBPSK decodes run in the same launch sequence; only the 64-byte result goes back to the host.
+#include "p1_kernels.h"
+#include "tables/dsp_tables_data.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr float PI_F = 3.14159274101257324219f;
+constexpr float PI_X_2 = PI_F * 2.0f;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+
+__device__ __forceinline__ float atan2_approx_dev(float y, float x)              // DSP/fast_math.h:61-81
+{
+    const float PI_2 = 1.57079637050628662109f;
+    if (x == 0.0f) return y > 0.0f ? PI_2 : -PI_2;
+    if (y == 0.0f) return x > 0.0f ? 0.0f : -PI_F;
+    const float abs_x = fabsf(x), abs_y = fabsf(y);
+    const bool min_x = abs_x < abs_y;
+    const float a = min_x ? abs_x / abs_y : abs_y / abs_x;
+    const float s = a * a;
+    float r = ((-4.6496475e-2f * s + 1.5931422e-1f) * s - 3.2762276e-1f) * s * a + a;
+    if (min_x) r = PI_2 - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// ---- correlator: 256 outputs per workgroup
+constexpr int NC = 256 + 540, NB = 256 + 480;
+
+__global__ __launch_bounds__(256) void p1_correlate_kernel(P1Params p)
+{
+    __shared__ float2 pc[NC], pb[NB];
+    const int n0 = blockIdx.x * 256, tid = threadIdx.x;
+    const float2 *x = p.xb + P1_HIST;                       // x[k], k >= -P1_HIST
+    const int f0 = p.state->idx_fq_shift;
+    for (int t = tid; t < NC; t += 256) {                   // pc[k] = x[k] * conj(s[k - 542]), k = n0 - 964 - 540 + t
+        const int k = n0 - 1504 + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < p.n) { const float2 xs = x[k - 542]; v = cmulc(x[k], cmul(xs, p.fq_shift[(f0 + k - 542) & 1023])); }
+        pc[t] = v;
+    }
+    for (int t = tid; t < NB; t += 256) {                   // pb[k] = s[k] * conj(x[k - 482]), k = n0 - 2 - 480 + t
+        const int k = n0 - 482 + t;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < p.n) v = cmulc(cmul(x[k], p.fq_shift[(f0 + k) & 1023]), x[k - 482]);
+        pb[t] = v;
+    }
+    __syncthreads();
+    const int n = n0 + tid;
+    if (n >= p.n) return;
+    double acr = 0.0, aci = 0.0, abr = 0.0, abi = 0.0;
+    for (int j = 0; j < 541; ++j) { const float2 v = pc[tid + j]; acr += (double)v.x; aci += (double)v.y; }
+    for (int j = 0; j < 481; ++j) { const float2 v = pb[tid + j]; abr += (double)v.x; abi += (double)v.y; }
+    const float2 a = make_float2((float)acr, (float)aci), d = make_float2((float)abr, (float)abi);
+    const float2 o = cmul(a, d);                            // :159
+    p.out[n] = o;
+    p.corr[n] = o.x * o.x + o.y * o.y;                      // norm(out), :160
+}
+
+// ---- threshold / arg-max state machine (p1_symbol.cpp:93-109,162-170), one workgroup
+__global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
+{
+    __shared__ float sc[2048];
+    __shared__ int s_first, s_stop;
+    const int tid = threadIdx.x;
+    P1State &st = *p.state;
+    P1Result &res = *p.result;
+    int n = 0;
+    if (tid == 0) {
+        res.status = 0; res.consumed = p.n; res.a_part_clipped = 0; s_stop = 0;
+        if (p.gain_changed) { st.begin_threshold = p.level_detect * 2.0e+5f; st.end_threshold = 0.5f * st.begin_threshold; }   // :88-91
+    }
+    __syncthreads();
+    while (n < p.n) {
+        if (!st.correlation_detect) {
+            // nothing but `correlation` changes while the value stays at or below the begin threshold: skip ahead in parallel
+            if (tid == 0) s_first = p.n;
+            __syncthreads();
+            for (int base = n; base < p.n && s_first == p.n; base += 4096) {
+                int mine = p.n;
+                for (int k = base + tid; k < min(p.n, base + 4096); k += 256)
+                    if (p.corr[k] > st.begin_threshold) { mine = k; break; }
+                if (mine < p.n) atomicMin(&s_first, mine);
+                __syncthreads();
+            }
+            const int first = s_first;
+            __syncthreads();
+            if (first >= p.n) { if (tid == 0 && p.n > n) st.correlation = p.corr[p.n - 1]; n = p.n; break; }
+            if (tid == 0 && first > n) st.correlation = p.corr[first - 1];
+            n = first;
+            __syncthreads();
+        }
+        // sequential stretch of up to 2048 samples from LDS
+        const int cnt = min(2048, p.n - n);
+        for (int k = tid; k < cnt; k += 256) sc[k] = p.corr[n + k];
+        __syncthreads();
+        if (tid == 0) {
+            int k = 0;
+            for (; k < cnt; ++k) {
+                if (st.correlation_detect) {
+                    if (++st.idx_buffer > 2048) {           // :101-104: reset_buffer() clears the correlator
+                        st.correlation_detect = 0; st.max_correlation = 0.0f; st.idx_buffer = 0;
+                        if (!(st.correlation < st.end_threshold)) {     // otherwise the reference falls into :106 with idx_buffer = 0
+                            res.status = 2; res.consumed = n + k; s_stop = 1;   // the caller restarts the search at this sample
+                            break;
+                        }
+                    }
+                    if (st.correlation < st.end_threshold) {   // :106
+                        res.status = 1; res.consumed = n + k + 1; res.idx_buffer_sym = st.idx_buffer; s_stop = 1;
+                        break;
+                    }
+                }
+                const float c = sc[k];
+                st.correlation = c;
+                if (c > st.begin_threshold) {
+                    st.correlation_detect = 1;
+                    if (c > st.max_correlation) {
+                        st.max_correlation = c;
+                        const float2 o = p.out[n + k];
+                        st.arg_max_re = o.x; st.arg_max_im = o.y;
+                        st.idx_buffer = 0;
+                    }
+                } else if (!st.correlation_detect) { ++k; break; }   // back to the parallel skip
+            }
+            s_first = k;
+        }
+        __syncthreads();
+        if (s_stop) break;
+        n += s_first;
+        __syncthreads();
+    }
+    // the correlator consumed every sample except the one that ended the search (:106-147 breaks before the update)
+    if (tid == 0) {
+        const int fed = res.status == 1 ? res.consumed - 1 : res.consumed;
+        st.idx_fq_shift = (st.idx_fq_shift + fed) & 1023;
+        res.max_correlation = st.max_correlation; res.arg_max_re = st.arg_max_re; res.arg_max_im = st.arg_max_im;
+    }
+}
+
+// ---- part A: 1K FFT (fft-shifted) + carrier search + DBPSK / S1 / S2 decode (:111-131,180-298), one workgroup
+__global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
+{
+    __shared__ float2 buf[2][1024];
+    __shared__ int ok[20], r_pre[20], r_fft[20], r_s1[20], r_s2[20];
+    const int tid = threadIdx.x;
+    P1State &st = *p.state;
+    P1Result &res = *p.result;
+    if (res.status != 1) return;
+    // save_buffer::read()[P1_C_PART - idx_buffer + j]: the newest sample (the one that ended the search) is element 2047
+    const int newest = res.consumed - 1, start = newest - 2047 + 542 - res.idx_buffer_sym;
+    const float2 *x = p.xb + P1_HIST;
+    for (int j = tid; j < 1024; j += 256) {
+        const int k = start + j;
+        const bool in = k >= -P1_HIST && k <= newest;
+        buf[0][j] = in ? x[k] : make_float2(0.f, 0.f);
+        if (!in && tid == 0) res.a_part_clipped = 1;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int s = 1, stage = 0; stage < 10; ++stage, s <<= 1) {       // Stockham radix-2, 512 butterflies per stage
+        const int m = 1024 / (2 * s);                                // sub-transform count factor
+        for (int b = tid; b < 512; b += 256) {
+            const int j = b / s, k = b % s;                          // j < m
+            const float2 a = buf[cur][j * s + k], c = buf[cur][(j + m) * s + k];
+            const float2 w = p.twiddle[j * s];                       // exp(-2 pi i j / (2 m))
+            const float2 d = make_float2(a.x - c.x, a.y - c.y);
+            buf[cur ^ 1][2 * j * s + k] = make_float2(a.x + c.x, a.y + c.y);
+            buf[cur ^ 1][(2 * j + 1) * s + k] = cmul(d, w);
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    // fftshift (fast_fourier_transform::execute): out[k + 512] = X[k]
+    for (int j = tid; j < 1024; j += 256) { const float2 v = buf[cur][j]; buf[cur ^ 1][(j + 512) & 1023] = v; }
+    __syncthreads();
+    cur ^= 1;
+    for (int j = tid; j < 1024; j += 256) p.p1_fft[j] = buf[cur][j];
+    if (tid < 20) ok[tid] = 0;
+    __syncthreads();
+    const bool try_decode = !st.p1_decoded || p.reset_flag;          // :116
+    if (try_decode && tid < 20) {
+        const float2 *p1 = buf[cur] + 76 + tid;                      // shift = 76 + tid
+        int randomize_sr = 0x4e46;                                   // init_p1_randomize, :45-55 (generated on the fly)
+        int old_bit = -1, prev_desc = 0, dec_old = 1;
+        uint8_t data[48];
+        int idx_data = 0, next_bit = 0, cur_byte = 0;
+        float2 prev = make_float2(0.f, 0.f);
+        for (int i = 0; i < 384; ++i) {
+            const int b = (randomize_sr ^ (randomize_sr >> 1)) & 1;
+            const int rnd = b == 0 ? 1 : -1;
+            randomize_sr >>= 1;
+            if (b > 0) randomize_sr |= 0x4000;
+            const float2 c = p1[T2_P1_ACTIVE_CARRIERS[i]];
+            const float2 v = make_float2(c.x * 0.1f, c.y * 0.1f);
+            int bit_i;
+            if (i == 0) bit_i = old_bit;
+            else {
+                const float2 dif = cmulc(v, prev);
+                const float angle = atan2_approx_dev(dif.y, dif.x);
+                bit_i = fabsf(angle) > (PI_F / 2.0f) ? -old_bit : old_bit;
+                old_bit = bit_i;
+            }
+            prev = v;
+            prev_desc = bit_i * rnd;                                 // dbpsk_bit[i] *= p1_randomize[i]
+            const int bit = prev_desc == dec_old ? 0 : 1;
+            dec_old = prev_desc;
+            if (next_bit == 8) { data[idx_data++] = (uint8_t)cur_byte; cur_byte = 0; next_bit = 0; }
+            cur_byte = ((cur_byte << 1) + bit) & 0xFF;
+            ++next_bit;
+        }
+        data[idx_data] = (uint8_t)cur_byte;
+        bool good = true;
+        int s1 = 0, s2 = 0;
+        for (int i = 0; i < 8; ++i) {
+            if (data[i] != data[i + 40]) { good = false; break; }
+            if (data[0] == T2_P1_S1_PATTERNS[i][0]) s1 = i;
+        }
+        if (good) {
+            for (int i = 0; i < 16; ++i)
+                if (data[8] == T2_P1_S2_PATTERNS[i][0] && data[9] == T2_P1_S2_PATTERNS[i][1]) s2 = i;
+            if (s1 > 4) good = false;                                // :233-252
+        }
+        ok[tid] = good; r_pre[tid] = s1; r_fft[tid] = s2 >> 1; r_s1[tid] = s1; r_s2[tid] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);
+        const float hz_per_rad = (fs / PI_X_2) / (float)(2048 << 1);                      // P1_HERTZ_PER_RADIAN
+        double cfo = (double)atan2_approx_dev(st.arg_max_im, st.arg_max_re) * (double)hz_per_rad;   // :115
+        res.shift = -1; res.preamble = -1; res.fft_mode = -1; res.s1 = -1; res.s2 = -1;
+        if (try_decode) {
+            for (int t = 0; t < 20; ++t) {
+                if (ok[t]) {                                         // first shift that decodes (:117-126)
+                    st.p1_decoded = 1;
+                    res.shift = 76 + t; res.preamble = r_pre[t]; res.fft_mode = r_fft[t]; res.s1 = r_s1[t]; res.s2 = r_s2[t];
+                    if (res.shift != 86) cfo += (double)(res.shift - 86) * (double)(fs / 1024.0f);
+                    break;
+                }
+            }
+        }
+        res.p1_decoded = st.p1_decoded;
+        res.coarse_freq_offset = cfo;
+        // reset_buffer() (:133,300-311); the correlator history is cleared by the carry kernel
+        st.correlation_detect = 0; st.max_correlation = 0.0f; st.idx_buffer = 0;
+    }
+}
+
+// ---- carry the history: the last 2048 samples, or zeros after a detection / overflow reset (delay lines cleared)
+__global__ __launch_bounds__(256) void p1_carry_kernel(P1Params p)
+{
+    __shared__ float2 keep[P1_HIST];
+    const int status = p.result->status, consumed = p.result->consumed;
+    for (int j = threadIdx.x; j < P1_HIST; j += 256) {
+        // not finished: history = samples [n - 2048, n). finished at `consumed`: zeros (the caller restarts behind it)
+        keep[j] = status == 0 ? p.xb[p.n + j] : make_float2(0.f, 0.f);
+    }
+    (void)consumed;
+    __syncthreads();
+    for (int j = threadIdx.x; j < P1_HIST; j += 256) p.xb[j] = keep[j];
+}
+
+}  // namespace
+
+void launch_p1(const P1Params &p, hipStream_t stream)
+{
+    if (p.n <= 0) return;
+    hipLaunchKernelGGL(p1_correlate_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_detect_kernel, dim3(1), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_decode_kernel, dim3(1), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_carry_kernel, dim3(1), dim3(256), 0, stream, p);
+}

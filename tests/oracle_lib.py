@@ -414,3 +414,37 @@ class OraSync(object):
         if getattr(self, "h", None):
             self.o.ora_sync_destroy(self.h)
             self.h = None
+
+
+class OraP1(object):
+    """p1_symbol restated (oracle/p1_oracle.c)."""
+
+    def __init__(self):
+        o = oracle()
+        o.ora_p1_create.restype = ctypes.c_void_p
+        o.ora_p1_destroy.argtypes = [ctypes.c_void_p]
+        o.ora_p1_execute.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.o = o
+        self.h = o.ora_p1_create()
+        self.buffer_sym = np.zeros(4096, np.complex64)
+
+    def execute(self, x, consume=0, gain_changed=False, level_detect=0.0, reset=False, want_trace=False):
+        x = _c64(x)
+        c = ctypes.c_int(consume)
+        res = (ctypes.c_int * 9)()
+        coarse = ctypes.c_double()
+        tr = np.full(len(x), np.nan, np.float32)
+        fft = np.zeros(1024, np.complex64)
+        d = self.o.ora_p1_execute(self.h, int(gain_changed), float(level_detect), len(x), x.ctypes.data, ctypes.byref(c),
+                                  self.buffer_sym.ctypes.data, res, ctypes.byref(coarse), int(reset), tr.ctypes.data, fft.ctypes.data)
+        out = dict(detected=bool(d), consume=c.value, idx_buffer_sym=res[0], p1_decoded=res[1], preamble=res[2], fft_mode=res[3],
+                   s1=res[4], s2=res[5], shift=res[6], coarse_freq_offset=coarse.value)
+        if want_trace:
+            out["trace"], out["p1_fft"] = tr, fft
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.ora_p1_destroy(self.h)
+            self.h = None

@@ -3,6 +3,8 @@ independently of the receiver restatements -- mode adaptation (BBFRAMEs in HEM),
 the reference ignores it, bch_decoder.cpp:136), LDPC encoding, bit interleaving + demultiplexing, QAM mapping, constellation
 rotation with cyclic Q delay, cell and time interleaving. It uses only the permutation TABLES of the receiver (inverted),
 never its processing code, so that "what the receiver recovers == what was sent" is a genuine end-to-end check."""
+import os
+
 import numpy as np
 
 import oracle_lib as ol
@@ -250,3 +252,38 @@ def l1_post_cells(info_bits, l1_post_mod, l1_post_size, seed=0, scrambled=False)
     re = map_axis(cb[:, 0::2], d)
     im = map_axis(cb[:, 1::2], d)
     return re + 1j * im
+
+
+# ------------------------------------------------------------------------------------------------ P1 preamble (EN 302 755 9.8)
+def p1_symbol(s1, s2):
+    """The 2048-sample P1 symbol (C-A-B structure) signalling S1 (3 bit) and S2 (4 bit), unit mean power in part A.
+    Modulation signalling sequence = S1 pattern | S2 pattern | S1 pattern (384 bit), DBPSK, scrambled with the PRBS
+    x^15 + x^14 + 1 (initial state 100111001000110), on the 384 active carriers of a 1K symbol."""
+    import ctypes
+    o = ol.oracle()
+    carriers = np.array([int(x) for x in _dsp_table("T2_P1_ACTIVE_CARRIERS")])
+    s1p = np.array(_dsp_table("T2_P1_S1_PATTERNS"), np.uint8).reshape(8, 8)
+    s2p = np.array(_dsp_table("T2_P1_S2_PATTERNS"), np.uint8).reshape(16, 32)
+    mss = np.concatenate([np.unpackbits(s1p[s1]), np.unpackbits(s2p[s2]), np.unpackbits(s1p[s1])]).astype(np.int64)
+    diff = np.cumprod(1 - 2 * mss)                                   # DBPSK: starts from +1, a one flips the sign
+    sr, prbs = 0x4e46, np.zeros(384, np.int64)
+    for i in range(384):                                             # same generator as the receiver's descrambler
+        b = (sr ^ (sr >> 1)) & 1
+        prbs[i] = 1 if b == 0 else -1
+        sr >>= 1
+        if b:
+            sr |= 0x4000
+    spectrum = np.zeros(1024, np.complex128)                         # fft-shifted: bin 512 is DC, first of the 853 carriers at 86
+    spectrum[86 + carriers] = diff * prbs
+    a = np.fft.ifft(np.fft.ifftshift(spectrum)) * 1024 / np.sqrt(384)
+    t = np.arange(2048)
+    shift = np.exp(2j * np.pi * t / 1024.0)
+    return np.concatenate([a[:542] * shift[:542], a, a[542:] * shift[1566:]])
+
+
+def _dsp_table(name):
+    import re
+    path = os.path.join(ol.ROOT, "sdr_receiver_dvb_t2_amd", "csrc", "tables", "dsp_tables_data.h")
+    src = open(path).read()
+    m = re.search(name + r"[^=]*=\s*\{(.*?)\};", src, re.S)
+    return [int(x, 0) for x in re.findall(r"0x[0-9A-Fa-f]+|\d+", m.group(1))]

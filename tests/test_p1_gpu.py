@@ -1,0 +1,114 @@
+"""GPU tier: P1 preamble detector through the C ABI against the oracle (oracle/p1_oracle.c).
+
+Parity bars: the decisions -- detected, samples consumed, idx_buffer_sym, decoded flag, S1/S2, preamble, FFT size, carrier shift --
+are compared EXACTLY; the correlation trace to 1e-4 of its peak and coarse_freq_offset to 0.5 Hz (the reference's recursive
+float running sums drift by rounding, the device adds each window afresh in double); the 1K spectrum of part A to 1e-5 of its
+largest bin against a float64 FFT of the same samples (FFTW3f in the reference)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import t2_tx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda(built):
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def noise(rng, n, s):
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * s).astype(np.complex64)
+
+
+def stream(seed, frames, snr_noise=0.02, cfo_carriers=0.0, gap=(3000, 2500)):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts, p1_ends = [], []
+    pos = 0
+    for s1, s2 in frames:
+        p1 = t2_tx.p1_symbol(s1, s2) * 0.3
+        seg = np.concatenate([noise(rng, gap[0], 0.05), p1.astype(np.complex64) + noise(rng, 2048, snr_noise), noise(rng, gap[1], 0.05)])
+        parts.append(seg)
+        p1_ends.append(pos + gap[0] + 2048)
+        pos += len(seg)
+    x = np.concatenate(parts)
+    x = (x * np.exp(2j * np.pi * cfo_carriers * np.arange(len(x)) / 1024.0)).astype(np.complex64)
+    return x, p1_ends
+
+
+def same_decisions(r, res, consume):
+    assert r["consume"] == consume
+    assert r["idx_buffer_sym"] == res.idx_buffer_sym and r["p1_decoded"] == res.p1_decoded
+    assert (r["shift"], r["s1"], r["s2"], r["preamble"], r["fft_mode"]) == (res.shift, res.s1, res.s2, res.preamble, res.fft_mode) or \
+        (r["shift"] == -1 and res.shift == -1)
+    assert abs(r["coarse_freq_offset"] - res.coarse_freq_offset) < 0.5
+
+
+@pytest.mark.parametrize("frames,cfo", [([(0, 10)], 0.0), ([(0, 8)], 2.03), ([(1, 11)], -6.98), ([(0, 10), (0, 10), (0, 10)], 0.3)])
+def test_p1_matches_oracle(torch_cuda, frames, cfo):
+    from sdr_receiver_dvb_t2_amd import p1 as p1mod
+    x, ends = stream(7 + len(frames), frames, cfo_carriers=cfo)
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag)))
+    g, o = p1mod.p1_symbol(max_samples=len(x)), ol.OraP1()
+    consume_g = consume_o = 0
+    for k in range(len(frames)):
+        r = o.execute(x, consume_o, k == 0, level, want_trace=True)
+        det, consume_g2, res = g.execute(x, consume_g, k == 0, level)
+        assert det == r["detected"] == True
+        same_decisions(r, res, consume_g2)
+        assert abs(consume_g2 - res.idx_buffer_sym - ends[k]) <= 2
+        corr, fft = g.debug(consume_g2 - consume_g - 1)
+        tr = r["trace"][consume_g:consume_g2 - 1]
+        assert not np.isnan(tr).any()
+        assert np.abs(corr - tr).max() <= 1e-4 * tr.max()
+        a0 = consume_g2 - 1 - 2047 + 542 - res.idx_buffer_sym
+        want = np.fft.fftshift(np.fft.fft(x[a0:a0 + 1024].astype(np.complex128)))
+        assert np.abs(fft - want).max() <= 1e-5 * np.abs(want).max()
+        assert np.abs(fft - r["p1_fft"]).max() <= 1e-5 * np.abs(want).max()
+        consume_g, consume_o = consume_g2, r["consume"]
+    # nothing left: both run out of input without a detection
+    r = o.execute(x, consume_o, False, 0.0)
+    det, consume_g2, res = g.execute(x, consume_g, False, 0.0)
+    assert not det and not r["detected"] and consume_g2 == r["consume"] == len(x)
+
+
+def test_p1_split_calls_and_dev_entry(torch_cuda):
+    """The search continues across calls (history and thresholds live in the handle), at any cut position."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd import p1 as p1mod
+    x, ends = stream(21, [(0, 10), (0, 10)], cfo_carriers=1.0)
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag)))
+    for cuts in ([1000, 3100, 4000, 5047, 5048, 5049, 5300, 9000, 12000], [len(x)], [2047, 2048, 2049, 6000, 6001]):
+        g, o = p1mod.p1_symbol(max_samples=len(x)), ol.OraP1()
+        bounds = [0] + [c for c in cuts if c < len(x)] + [len(x)]
+        found_g, found_o = [], []
+        first = True
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            seg = x[lo:hi]
+            cg = co = 0
+            while cg < len(seg) or co < len(seg):
+                r = o.execute(seg, co, first, level)
+                det, cg2, res = g.execute_dev(torch.from_numpy(seg).cuda(), cg, first, level)
+                first = False
+                assert det == r["detected"]
+                same_decisions(r, res, cg2)
+                if det:
+                    found_g.append(lo + cg2 - res.idx_buffer_sym)
+                    found_o.append(lo + r["consume"] - r["idx_buffer_sym"])
+                cg, co = cg2, r["consume"]
+        assert found_g == found_o and len(found_g) == 2
+        assert all(abs(a - b) <= 2 for a, b in zip(found_g, ends))
+
+
+def test_p1_no_false_alarm_and_weak_signal(torch_cuda):
+    from sdr_receiver_dvb_t2_amd import p1 as p1mod
+    rng = np.random.Generator(np.random.PCG64(99))
+    x = noise(rng, 200000, 0.1)
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag)))
+    g, o = p1mod.p1_symbol(max_samples=len(x)), ol.OraP1()
+    det, c, res = g.execute(x, 0, True, level)
+    r = o.execute(x, 0, True, level)
+    assert not det and not r["detected"] and c == r["consume"] == len(x)
