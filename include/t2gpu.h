@@ -183,6 +183,12 @@ t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pilot_pattern,
 void t2gpu_ofdm_destroy(t2gpu_ofdm *h);
 int t2gpu_fft_execute_dev(t2gpu_ofdm *h, const float *d_in, float *d_out, int n_symbols, void *stream);
 int t2gpu_fft_execute(t2gpu_ofdm *h, const float *in, float *out, int n_symbols);
+/* The same transform reading its symbols straight out of the decimated sample stream: symbol i of the batch starts at cell
+ * first + (i / per_frame) * frame_stride + (i % per_frame) * sym_stride. With first = position of the first useful sample,
+ * sym_stride = guard_interval_size + fft_size this is symbol_acquisition's guard removal + fft->execute()
+ * (src/DVB_T2/dvbt2_demodulator.cpp:332-334) for whole frames, without the intermediate copy. */
+int t2gpu_fft_execute_strided_dev(t2gpu_ofdm *h, const float *d_stream, long first, long frame_stride, int per_frame, int sym_stride,
+                                  float *d_out, int n_symbols, void *stream);
 int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32_t *d_symbol_index, int n_symbols,
                               float *d_cells, float *d_sync, void *stream);
 int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
@@ -253,6 +259,10 @@ int t2gpu_farrow_execute(t2gpu_front *h, int len_in, const float *in, double arb
 /* Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327) for a batch of buffered symbols
  * (guard + fft_size cells each, guard first): d_out[s] = {sum.re, sum.im, frequency_est, 0}. */
 int t2gpu_cp_correlate_dev(const float *d_symbols, int n_symbols, int fft_size, int guard, float *d_out4, void *stream);
+/* the same on symbols lying in the sample stream: symbol i starts (guard first) at first + (i / per_frame) * frame_stride +
+ * (i % per_frame) * (guard + fft_size) */
+int t2gpu_cp_correlate_stream_dev(const float *d_stream, long first, long frame_stride, int per_frame, int n_symbols, int fft_size,
+                                  int guard, float *d_out4, void *stream);
 
 /* Tracking loops of symbol_acquisition, host scalar state exactly as the reference keeps it (:328-330,429-439;
  * proportional_integral_loop_filter, DSP/loop_filters.hh:20-54). */
@@ -296,6 +306,16 @@ int t2gpu_p1_execute_dev(t2gpu_p1 *h, int gain_changed, float level_detect, int 
                          int reset_flag, t2gpu_p1_result *res, void *stream);
 int t2gpu_p1_execute(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *in, int *consume, int reset_flag,
                      t2gpu_p1_result *res);
+/* Batch form for whole buffers of frames whose P1 positions are known to a few hundred samples (steady state: one frame length
+ * after the previous P1): window w = d_stream[win_start[w] .. + win_len[w]) is searched by a FRESH correlator -- what the reference
+ * has at that point too, since it clears its correlator after every detected P1 (reset_buffer, p1_symbol.cpp:133,300-311) -- with
+ * the handle's thresholds and decoded flag. All windows run in one launch sequence. res[w] / consumed[w] per window (consumed
+ * relative to the window start); returns the number of windows with a detection. Differences to n_windows stream calls: the
+ * frequency-shift table index restarts at 0 in every window (a constant phase that cancels in the correlator output), and when
+ * nothing was decoded before the call every window attempts the S1/S2 decode. */
+int t2gpu_p1_execute_batch_dev(t2gpu_p1 *h, int gain_changed, float level_detect, const float *d_stream, int n_windows,
+                               const long *win_start, const int *win_len, int reset_flag, t2gpu_p1_result *res, int *consumed,
+                               void *stream);
 /* for tests: correlation trace of the last pass (returns the number of values) and the fft-shifted 1K spectrum of part A */
 int t2gpu_p1_debug(t2gpu_p1 *h, float *corr, int n_corr, float *p1_fft1024);
 

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "t2gpu_ofdm_destroy": (None, [_vp]),
     "t2gpu_fft_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_fft_execute": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    "t2gpu_fft_execute_strided_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "t2gpu_eq_data_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_fc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     "t2gpu_decim_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_farrow_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_int]),
     "t2gpu_cp_correlate_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "t2gpu_cp_correlate_stream_dev": (ctypes.c_int, [_vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "t2gpu_sync_create": (_vp, [ctypes.c_float]),
     "t2gpu_sync_destroy": (None, [_vp]),
     "t2gpu_sync_frequency": (None, [_vp, ctypes.c_float, ctypes.c_int]),
@@ -86,6 +88,7 @@ PROTOTYPES = {
     "t2gpu_p1_reset": (ctypes.c_int, [_vp]),
     "t2gpu_p1_execute_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_p1_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_p1_execute_batch_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_p1_debug": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_plan_nco": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "t2gpu_plan_farrow": (ctypes.c_long, [_vp, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp]),

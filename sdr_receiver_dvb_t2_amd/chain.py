@@ -66,11 +66,27 @@ class t2_chain(object):
         """symbols: CUDA float32 [F][n_sym][fft_size][2], F <= max_frames. Returns (bits uint8 [frames][k_bch] on the
         device, trials-left int32 per SIMD batch) for the FEC frames whose batch of `group` completed (all of them with
         flush=True: the tail batch is then decoded short, which the reference never does)."""
-        torch = self.torch
         o = self.ofdm
         F = symbols.shape[0]
         assert F <= self.max_frames and symbols.shape[1] == self.n_sym
         spec = o.fft_dev(symbols.reshape(F * self.n_sym, o.fft_size, 2)).reshape(F, self.n_sym, o.fft_size, 2)
+        return self.demod_spectrum_dev(spec, flush)
+
+    def demod_stream_dev(self, stream, first, frame_stride, n_frames, flush=False):
+        """The same from the decimated sample stream (complex64 device tensor): frame f's first useful P2 sample is at
+        first + f * frame_stride, symbols follow every guard + fft_size samples; the guard interval is skipped by addressing
+        (symbol_acquisition's memcpy from buffer_sym + guard_interval_size, dvbt2_demodulator.cpp:332-333)."""
+        o = self.ofdm
+        F = n_frames
+        assert F <= self.max_frames
+        spec = o.fft_stream_dev(stream, first, frame_stride, self.n_sym, o.fft_size + o.guard_interval_size, F * self.n_sym)
+        return self.demod_spectrum_dev(spec.reshape(F, self.n_sym, o.fft_size, 2), flush)
+
+    def demod_spectrum_dev(self, spec, flush=False):
+        """spec: CUDA float32 [F][n_sym][fft_size][2], the fft-shifted spectra of whole frames."""
+        torch = self.torch
+        o = self.ofdm
+        F = spec.shape[0]
         # P2: equalise, drop the L1 cells, PLP cells go to the head of the frame's cell stream
         p2, _ = o.eq_p2_dev(spec[:, 0].contiguous(), want_sync=False)    # open loop: the feedback values are not consumed
         self.cells[:F, :o.c_p2 - self.p2_skip] = p2[:, self.p2_skip:]

@@ -44,4 +44,6 @@ void launch_front(const FrontParams &p, hipStream_t stream);
 
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
 // sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).
-void launch_cp_correlate(const float2 *sym, int n_symbols, int fft_size, int guard, float4 *out, hipStream_t stream);
+// Symbol i starts at first + (i / per_frame) * frame_stride + (i % per_frame) * (guard + fft_size).
+void launch_cp_correlate(const float2 *sym, long first, long frame_stride, int per_frame, int n_symbols, int fft_size, int guard,
+                         float4 *out, hipStream_t stream);

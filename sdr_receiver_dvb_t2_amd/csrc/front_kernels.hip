@@ -279,10 +279,12 @@ __device__ __forceinline__ float atan2_approx_dev(float y, float x)             
     return r;
 }
 
-__global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, int fft_size, int guard, float4 *out)
+__global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, long first, long frame_stride, int per_frame, int fft_size,
+                                                           int guard, float4 *out)
 {
     __shared__ double red[2][256];
-    const float2 *s = sym + (long)blockIdx.x * (fft_size + guard), *cp = s + fft_size;
+    const int i = blockIdx.x;
+    const float2 *s = sym + first + (long)(i / per_frame) * frame_stride + (long)(i % per_frame) * (fft_size + guard), *cp = s + fft_size;
     double sr = 0.0, si = 0.0;
     for (int i = 4 + threadIdx.x; i < guard - 4; i += 256) {
         const float2 a = cp[i], b = s[i];
@@ -324,7 +326,9 @@ void launch_front(const FrontParams &p, hipStream_t stream)
     hipLaunchKernelGGL(front_finish_kernel, dim3(1), dim3(256), 0, stream, p);
 }
 
-void launch_cp_correlate(const float2 *sym, int n_symbols, int fft_size, int guard, float4 *out, hipStream_t stream)
+void launch_cp_correlate(const float2 *sym, long first, long frame_stride, int per_frame, int n_symbols, int fft_size, int guard,
+                         float4 *out, hipStream_t stream)
 {
-    if (n_symbols > 0) hipLaunchKernelGGL(cp_correlate_kernel, dim3(n_symbols), dim3(256), 0, stream, sym, fft_size, guard, out);
+    if (n_symbols > 0)
+        hipLaunchKernelGGL(cp_correlate_kernel, dim3(n_symbols), dim3(256), 0, stream, sym, first, frame_stride, per_frame, fft_size, guard, out);
 }

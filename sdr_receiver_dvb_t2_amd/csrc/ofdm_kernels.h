@@ -6,9 +6,14 @@
 
 namespace t2gpu {
 
-// twiddle[m] = exp(-j*2*pi*m/N), m in [0, N)
+// Where the symbols of a batch start inside the input stream (cells): symbol i is at
+// first + (i / per_frame) * frame_stride + (i % per_frame) * sym_stride. The FFT reads fft_size cells from there, which is how the
+// guard interval is dropped (symbol_acquisition copies buffer_sym + guard_interval_size, dvbt2_demodulator.cpp:332-333).
+struct FftLayout { long first, frame_stride; int per_frame, sym_stride; };
+
+// twiddle[m] = exp(-j*2*pi*m/N), m in [0, N); layout = nullptr: contiguous symbols
 hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
-                      hipStream_t s);
+                      hipStream_t s, const FftLayout *layout = nullptr);
 
 struct EqParams {
     int fft_size, l_nulls, k_total, c_data, n_p2, max_seg;   // c_data: cells out per symbol; n_p2: frame index of table row 0

@@ -56,13 +56,14 @@ template <int R> __device__ __forceinline__ constexpr int bitrev(int i)
 // T2 = 32: N = 32768, 1024 threads. T2 = 16: N = 16384, 512 threads.
 template <int T2>
 __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                               const float2 *__restrict__ twiddle, int n_symbols)
+                                                               const float2 *__restrict__ twiddle, int n_symbols, FftLayout lay)
 {
     constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     for (int sym = blockIdx.x; sym < n_symbols; sym += gridDim.x) {
-        const float2 *x = in + (size_t)sym * N;
+        // symbol `sym` of the batch starts at first + (sym / per_frame) * frame_stride + (sym % per_frame) * sym_stride cells
+        const float2 *x = in + lay.first + (long)(sym / lay.per_frame) * lay.frame_stride + (long)(sym % lay.per_frame) * lay.sym_stride;
         float2 *y = out + (size_t)sym * N;
         cf v[32];
         // ---- stage A: thread t holds x[t + T*j]; 32-point DFT over j -> index k1 (bit-reversed in registers)
@@ -139,8 +140,9 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
 }
 
 hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
-                      hipStream_t s)
+                      hipStream_t s, const FftLayout *layout)
 {
+    const FftLayout lay = layout ? *layout : FftLayout{0, 0, n_symbols > 0 ? n_symbols : 1, fft_size};
     const int blocks = n_symbols < max_blocks ? n_symbols : max_blocks;
     if (fft_size == 32768) {
         const int lds_bytes = 32 * 1024 * 4 > 32 * 32 * 33 * 4 ? 32 * 1024 * 4 : 32 * 32 * 33 * 4;
@@ -151,7 +153,7 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
             if (e != hipSuccess) return e;
             set = true;
         }
-        hipLaunchKernelGGL(fft_fwd_shift_kernel<32>, dim3(blocks), dim3(1024), lds_bytes, s, in, out, twiddle, n_symbols);
+        hipLaunchKernelGGL(fft_fwd_shift_kernel<32>, dim3(blocks), dim3(1024), lds_bytes, s, in, out, twiddle, n_symbols, lay);
     } else if (fft_size == 16384) {
         const int lds_bytes = 32 * 32 * 33 * 4;      // >= 32*512*4
         static bool set = false;
@@ -161,7 +163,7 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
             if (e != hipSuccess) return e;
             set = true;
         }
-        hipLaunchKernelGGL(fft_fwd_shift_kernel<16>, dim3(blocks), dim3(512), lds_bytes, s, in, out, twiddle, n_symbols);
+        hipLaunchKernelGGL(fft_fwd_shift_kernel<16>, dim3(blocks), dim3(512), lds_bytes, s, in, out, twiddle, n_symbols, lay);
     } else {
         return hipErrorInvalidValue;
     }

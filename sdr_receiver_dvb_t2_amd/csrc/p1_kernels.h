@@ -30,16 +30,25 @@ struct P1Result {
     double coarse_freq_offset;
 };
 
+// One window of samples to search. Stream mode (one window): base = xb + P1_HIST with P1_HIST valid samples in front.
+// Batch mode: windows lie in the caller's stream, each starts a fresh correlator (zeros in front of it), as the reference does
+// after every detected P1 (reset_buffer, p1_symbol.cpp:133).
+struct P1Window { long start; int len; int buf_off; };   // buf_off: offset of this window in corr[] / out[]
+
 struct P1Params {
-    float2 *xb;                            // [P1_HIST + n]: history then this call's samples
-    int n;
+    float2 *xb;                            // stream mode: [P1_HIST + n] history then this call's samples (carry target)
+    const float2 *base;                    // sample k of window w is base[win[w].start + k]
+    const P1Window *win;                   // [n_windows] (device)
+    int n_windows;
+    int hist;                              // valid samples in front of a window's first sample (P1_HIST or 0)
+    int n;                                 // longest window
     const float2 *fq_shift;                // 1024 entries (sin, cos) as p1_symbol.cpp:26-32 fills them
     const float2 *twiddle;                 // 1024-point FFT twiddles
-    float *corr;                           // [n]
-    float2 *out;                           // [n] correlator output a*d
-    P1State *state;
-    P1Result *result;
-    float2 *p1_fft;                        // [1024] fft-shifted spectrum of part A (kept for inspection)
+    float *corr;                           // [sum of window lengths]
+    float2 *out;                           // correlator output a*d, same layout
+    P1State *state;                        // [n_windows]
+    P1Result *result;                      // [n_windows]
+    float2 *p1_fft;                        // [n_windows][1024] fft-shifted spectrum of part A (kept for inspection)
     int reset_flag;
     int gain_changed;                      // :88-91: thresholds follow the level estimate once the gain is settled
     float level_detect;

@@ -49,30 +49,34 @@ __global__ __launch_bounds__(256) void p1_correlate_kernel(P1Params p)
 {
     __shared__ float2 pc[NC], pb[NB];
     const int n0 = blockIdx.x * 256, tid = threadIdx.x;
-    const float2 *x = p.xb + P1_HIST;                       // x[k], k >= -P1_HIST
-    const int f0 = p.state->idx_fq_shift;
+    const P1Window w = p.win[blockIdx.y];
+    if (n0 >= w.len) return;
+    const float2 *xw = p.base + w.start;
+    const int lo = -p.hist, len = w.len;
+    auto x = [&](int k) { return k >= lo ? xw[k] : make_float2(0.f, 0.f); };       // zeros in front of the search
+    const int f0 = p.state[blockIdx.y].idx_fq_shift;
     for (int t = tid; t < NC; t += 256) {                   // pc[k] = x[k] * conj(s[k - 542]), k = n0 - 964 - 540 + t
         const int k = n0 - 1504 + t;
         float2 v = make_float2(0.f, 0.f);
-        if (k < p.n) { const float2 xs = x[k - 542]; v = cmulc(x[k], cmul(xs, p.fq_shift[(f0 + k - 542) & 1023])); }
+        if (k < len && k >= lo) v = cmulc(x(k), cmul(x(k - 542), p.fq_shift[(f0 + k - 542) & 1023]));
         pc[t] = v;
     }
     for (int t = tid; t < NB; t += 256) {                   // pb[k] = s[k] * conj(x[k - 482]), k = n0 - 2 - 480 + t
         const int k = n0 - 482 + t;
         float2 v = make_float2(0.f, 0.f);
-        if (k < p.n) v = cmulc(cmul(x[k], p.fq_shift[(f0 + k) & 1023]), x[k - 482]);
+        if (k < len && k >= lo) v = cmulc(cmul(x(k), p.fq_shift[(f0 + k) & 1023]), x(k - 482));
         pb[t] = v;
     }
     __syncthreads();
     const int n = n0 + tid;
-    if (n >= p.n) return;
+    if (n >= len) return;
     double acr = 0.0, aci = 0.0, abr = 0.0, abi = 0.0;
     for (int j = 0; j < 541; ++j) { const float2 v = pc[tid + j]; acr += (double)v.x; aci += (double)v.y; }
     for (int j = 0; j < 481; ++j) { const float2 v = pb[tid + j]; abr += (double)v.x; abi += (double)v.y; }
     const float2 a = make_float2((float)acr, (float)aci), d = make_float2((float)abr, (float)abi);
     const float2 o = cmul(a, d);                            // :159
-    p.out[n] = o;
-    p.corr[n] = o.x * o.x + o.y * o.y;                      // norm(out), :160
+    p.out[w.buf_off + n] = o;
+    p.corr[w.buf_off + n] = o.x * o.x + o.y * o.y;          // norm(out), :160
 }
 
 // ---- threshold / arg-max state machine (p1_symbol.cpp:93-109,162-170), one workgroup
@@ -81,36 +85,40 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
     __shared__ float sc[2048];
     __shared__ int s_first, s_stop;
     const int tid = threadIdx.x;
-    P1State &st = *p.state;
-    P1Result &res = *p.result;
+    P1State &st = p.state[blockIdx.x];
+    P1Result &res = p.result[blockIdx.x];
+    const P1Window w = p.win[blockIdx.x];
+    const float *corr = p.corr + w.buf_off;
+    const float2 *outv = p.out + w.buf_off;
+    const int N = w.len;
     int n = 0;
     if (tid == 0) {
-        res.status = 0; res.consumed = p.n; res.a_part_clipped = 0; s_stop = 0;
+        res.status = 0; res.consumed = N; res.a_part_clipped = 0; s_stop = 0;
         if (p.gain_changed) { st.begin_threshold = p.level_detect * 2.0e+5f; st.end_threshold = 0.5f * st.begin_threshold; }   // :88-91
     }
     __syncthreads();
-    while (n < p.n) {
+    while (n < N) {
         if (!st.correlation_detect) {
             // nothing but `correlation` changes while the value stays at or below the begin threshold: skip ahead in parallel
-            if (tid == 0) s_first = p.n;
+            if (tid == 0) s_first = N;
             __syncthreads();
-            for (int base = n; base < p.n && s_first == p.n; base += 4096) {
-                int mine = p.n;
-                for (int k = base + tid; k < min(p.n, base + 4096); k += 256)
-                    if (p.corr[k] > st.begin_threshold) { mine = k; break; }
-                if (mine < p.n) atomicMin(&s_first, mine);
+            for (int base = n; base < N && s_first == N; base += 4096) {
+                int mine = N;
+                for (int k = base + tid; k < min(N, base + 4096); k += 256)
+                    if (corr[k] > st.begin_threshold) { mine = k; break; }
+                if (mine < N) atomicMin(&s_first, mine);
                 __syncthreads();
             }
             const int first = s_first;
             __syncthreads();
-            if (first >= p.n) { if (tid == 0 && p.n > n) st.correlation = p.corr[p.n - 1]; n = p.n; break; }
-            if (tid == 0 && first > n) st.correlation = p.corr[first - 1];
+            if (first >= N) { if (tid == 0 && N > n) st.correlation = corr[N - 1]; n = N; break; }
+            if (tid == 0 && first > n) st.correlation = corr[first - 1];
             n = first;
             __syncthreads();
         }
         // sequential stretch of up to 2048 samples from LDS
-        const int cnt = min(2048, p.n - n);
-        for (int k = tid; k < cnt; k += 256) sc[k] = p.corr[n + k];
+        const int cnt = min(2048, N - n);
+        for (int k = tid; k < cnt; k += 256) sc[k] = corr[n + k];
         __syncthreads();
         if (tid == 0) {
             int k = 0;
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
                     st.correlation_detect = 1;
                     if (c > st.max_correlation) {
                         st.max_correlation = c;
-                        const float2 o = p.out[n + k];
+                        const float2 o = outv[n + k];
                         st.arg_max_re = o.x; st.arg_max_im = o.y;
                         st.idx_buffer = 0;
                     }
@@ -161,15 +169,15 @@ __global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
     __shared__ float2 buf[2][1024];
     __shared__ int ok[20], r_pre[20], r_fft[20], r_s1[20], r_s2[20];
     const int tid = threadIdx.x;
-    P1State &st = *p.state;
-    P1Result &res = *p.result;
+    P1State &st = p.state[blockIdx.x];
+    P1Result &res = p.result[blockIdx.x];
     if (res.status != 1) return;
     // save_buffer::read()[P1_C_PART - idx_buffer + j]: the newest sample (the one that ended the search) is element 2047
     const int newest = res.consumed - 1, start = newest - 2047 + 542 - res.idx_buffer_sym;
-    const float2 *x = p.xb + P1_HIST;
+    const float2 *x = p.base + p.win[blockIdx.x].start;
     for (int j = tid; j < 1024; j += 256) {
         const int k = start + j;
-        const bool in = k >= -P1_HIST && k <= newest;
+        const bool in = k >= -p.hist && k <= newest;
         buf[0][j] = in ? x[k] : make_float2(0.f, 0.f);
         if (!in && tid == 0) res.a_part_clipped = 1;
     }
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
     for (int j = tid; j < 1024; j += 256) { const float2 v = buf[cur][j]; buf[cur ^ 1][(j + 512) & 1023] = v; }
     __syncthreads();
     cur ^= 1;
-    for (int j = tid; j < 1024; j += 256) p.p1_fft[j] = buf[cur][j];
+    for (int j = tid; j < 1024; j += 256) p.p1_fft[1024 * blockIdx.x + j] = buf[cur][j];
     if (tid < 20) ok[tid] = 0;
     __syncthreads();
     const bool try_decode = !st.p1_decoded || p.reset_flag;          // :116
@@ -267,12 +275,11 @@ __global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
 __global__ __launch_bounds__(256) void p1_carry_kernel(P1Params p)
 {
     __shared__ float2 keep[P1_HIST];
-    const int status = p.result->status, consumed = p.result->consumed;
+    const int status = p.result->status;
     for (int j = threadIdx.x; j < P1_HIST; j += 256) {
-        // not finished: history = samples [n - 2048, n). finished at `consumed`: zeros (the caller restarts behind it)
+        // not finished: history = samples [n - 2048, n). finished: zeros (the caller restarts behind `consumed`)
         keep[j] = status == 0 ? p.xb[p.n + j] : make_float2(0.f, 0.f);
     }
-    (void)consumed;
     __syncthreads();
     for (int j = threadIdx.x; j < P1_HIST; j += 256) p.xb[j] = keep[j];
 }
@@ -281,9 +288,9 @@ __global__ __launch_bounds__(256) void p1_carry_kernel(P1Params p)
 
 void launch_p1(const P1Params &p, hipStream_t stream)
 {
-    if (p.n <= 0) return;
-    hipLaunchKernelGGL(p1_correlate_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(p1_detect_kernel, dim3(1), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(p1_decode_kernel, dim3(1), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(p1_carry_kernel, dim3(1), dim3(256), 0, stream, p);
+    if (p.n <= 0 || p.n_windows <= 0) return;
+    hipLaunchKernelGGL(p1_correlate_kernel, dim3((p.n + 255) / 256, p.n_windows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_detect_kernel, dim3(p.n_windows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_decode_kernel, dim3(p.n_windows), dim3(256), 0, stream, p);
+    if (p.xb) hipLaunchKernelGGL(p1_carry_kernel, dim3(1), dim3(256), 0, stream, p);
 }

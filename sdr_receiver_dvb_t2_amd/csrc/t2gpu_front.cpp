@@ -347,7 +347,21 @@ extern "C" int t2gpu_farrow_execute(t2gpu_front *h, int len_in, const float *in,
 extern "C" int t2gpu_cp_correlate_dev(const float *d_symbols, int n_symbols, int fft_size, int guard, float *d_out4, void *stream)
 {
     if (!d_symbols || !d_out4 || n_symbols < 0 || fft_size < 1 || guard < 9) { set_error("t2gpu_cp_correlate_dev: bad arguments"); return -1; }
-    launch_cp_correlate(reinterpret_cast<const float2 *>(d_symbols), n_symbols, fft_size, guard, reinterpret_cast<float4 *>(d_out4), (hipStream_t)stream);
+    launch_cp_correlate(reinterpret_cast<const float2 *>(d_symbols), 0, 0, n_symbols > 0 ? n_symbols : 1, n_symbols, fft_size, guard,
+                        reinterpret_cast<float4 *>(d_out4), (hipStream_t)stream);
+    T2_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int t2gpu_cp_correlate_stream_dev(const float *d_stream, long first, long frame_stride, int per_frame, int n_symbols, int fft_size,
+                                             int guard, float *d_out4, void *stream)
+{
+    if (!d_stream || !d_out4 || n_symbols < 0 || fft_size < 1 || guard < 9 || per_frame < 1 || first < 0 || frame_stride < 0) {
+        set_error("t2gpu_cp_correlate_stream_dev: bad arguments");
+        return -1;
+    }
+    launch_cp_correlate(reinterpret_cast<const float2 *>(d_stream), first, frame_stride, per_frame, n_symbols, fft_size, guard,
+                        reinterpret_cast<float4 *>(d_out4), (hipStream_t)stream);
     T2_HIP(hipGetLastError());
     return 0;
 }

@@ -236,6 +236,19 @@ extern "C" int t2gpu_fft_execute_dev(t2gpu_ofdm *h, const float *d_in, float *d_
     return 0;
 }
 
+extern "C" int t2gpu_fft_execute_strided_dev(t2gpu_ofdm *h, const float *d_stream, long first, long frame_stride, int per_frame,
+                                             int sym_stride, float *d_out, int n_symbols, void *stream)
+{
+    if (!h || !d_stream || !d_out || n_symbols < 1 || per_frame < 1 || first < 0 || sym_stride < 0 || frame_stride < 0) {
+        set_error("t2gpu_fft_execute_strided_dev: bad arguments");
+        return -1;
+    }
+    const FftLayout lay{first, frame_stride, per_frame, sym_stride};
+    T2_HIP(launch_fft(h->m.fft_size, reinterpret_cast<const float2 *>(d_stream), reinterpret_cast<float2 *>(d_out), h->d_twiddle, n_symbols,
+                      h->num_cu, (hipStream_t)stream, &lay));
+    return 0;
+}
+
 static int ensure_staging(t2gpu_ofdm *h)
 {
     if (h->d_in) return 0;

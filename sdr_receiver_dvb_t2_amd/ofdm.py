@@ -46,6 +46,18 @@ class t2_ofdm(object):
                                             torch.cuda.current_stream(x.device).cuda_stream), "t2gpu_fft_execute_dev")
         return y
 
+    def fft_stream_dev(self, stream_cells, first, frame_stride, per_frame, sym_stride, n_symbols, out=None):
+        """FFT of n_symbols symbols read in place from a complex64 device stream (guard removal by addressing)."""
+        import torch
+        assert stream_cells.is_cuda and stream_cells.dtype == torch.complex64 and stream_cells.is_contiguous()
+        last = first + ((n_symbols - 1) // per_frame) * frame_stride + ((n_symbols - 1) % per_frame) * sym_stride + self.fft_size
+        assert last <= stream_cells.numel()
+        y = out if out is not None else torch.empty((n_symbols, self.fft_size, 2), dtype=torch.float32, device=stream_cells.device)
+        check(self._l.t2gpu_fft_execute_strided_dev(self._h, stream_cells.data_ptr(), first, frame_stride, per_frame, sym_stride,
+                                                    y.data_ptr(), n_symbols, torch.cuda.current_stream(y.device).cuda_stream),
+              "t2gpu_fft_execute_strided_dev")
+        return y
+
     def fft(self, x):
         x = np.ascontiguousarray(x, np.complex64).reshape(-1, self.fft_size)
         y = np.empty_like(x)

@@ -53,6 +53,22 @@ class p1_symbol(object):
             raise T2GpuError("t2gpu_p1_execute_dev: " + self._l.t2gpu_last_error().decode())
         return bool(rc), c.value, res
 
+    def execute_batch_dev(self, x, win_start, win_len, gain_changed=False, level_detect=0.0, reset=False, stream=None):
+        """x: complex64 torch device tensor (the sample stream); windows searched independently in one launch sequence.
+        Returns (list of p1_result, consumed per window)."""
+        import torch
+        ws = np.ascontiguousarray(win_start, np.int64)
+        wl = np.ascontiguousarray(win_len, np.int32)
+        assert len(ws) == len(wl) and int((ws + wl).max()) <= x.numel()
+        res = (p1_result * len(ws))()
+        cons = np.zeros(len(ws), np.int32)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = self._l.t2gpu_p1_execute_batch_dev(self.h, int(gain_changed), float(level_detect), x.data_ptr(), len(ws), ws.ctypes.data,
+                                                wl.ctypes.data, int(reset), ctypes.byref(res), cons.ctypes.data, s)
+        if rc < 0:
+            raise T2GpuError("t2gpu_p1_execute_batch_dev: " + self._l.t2gpu_last_error().decode())
+        return list(res), cons
+
     def debug(self, n):
         corr = np.zeros(n, np.float32)
         fft = np.zeros(1024, np.complex64)

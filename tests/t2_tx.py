@@ -287,3 +287,25 @@ def _dsp_table(name):
     src = open(path).read()
     m = re.search(name + r"[^=]*=\s*\{(.*?)\};", src, re.S)
     return [int(x, 0) for x in re.findall(r"0x[0-9A-Fa-f]+|\d+", m.group(1))]
+
+
+def iq_stream(frames, guard, s2, snr_db, seed, rms=0.22, scale_bits=14, s1=0):
+    """Whole T2 frames as the tuner delivers them: P1 + (cyclic prefix + symbol) for every symbol of every frame, AWGN, scaled to
+    int16 (SDRplay convention: value / 2^14, dvbt2_demodulator.cpp:35). frames: list of [n_sym][fft_size] complex arrays from
+    build_frame(snr_db=None). Returns (I int16, Q int16, samples per frame)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parts = []
+    for fr in frames:
+        fr = np.asarray(fr, np.complex128)
+        p = np.sqrt(np.mean(np.abs(fr) ** 2))
+        fr = fr / p                                                   # unit power, like part A of the P1 symbol
+        body = np.concatenate([fr[:, -guard:], fr], axis=1).reshape(-1)
+        parts.append(np.concatenate([p1_symbol(s1, s2), body]))
+    x = np.concatenate(parts) * rms * np.sqrt(2)                      # re/im rms = rms
+    if snr_db is not None:
+        sigma = rms * 10 ** (-snr_db / 20)
+        x = x + sigma * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))
+    q = float(1 << scale_bits)
+    i16 = np.clip(np.rint(x.real * q), -32768, 32767).astype(np.int16)
+    q16 = np.clip(np.rint(x.imag * q), -32768, 32767).astype(np.int16)
+    return i16, q16, len(parts[0])

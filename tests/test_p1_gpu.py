@@ -112,3 +112,28 @@ def test_p1_no_false_alarm_and_weak_signal(torch_cuda):
     det, c, res = g.execute(x, 0, True, level)
     r = o.execute(x, 0, True, level)
     assert not det and not r["detected"] and c == r["consume"] == len(x)
+
+
+def test_p1_batch_windows(torch_cuda):
+    """Batch form: one fresh correlator per window, all windows in one launch sequence; same decisions as the stream form."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd import p1 as p1mod
+    frames = [(0, 10)] * 5
+    x, ends = stream(33, frames, cfo_carriers=-2.0, gap=(0, 4000))                  # every frame starts with its P1
+    flen = 2048 + 4000
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag)))
+    g = p1mod.p1_symbol(max_samples=len(x))
+    starts = np.arange(5) * flen
+    res, cons = g.execute_batch_dev(torch.from_numpy(x).cuda(), starts, np.full(5, 3072), True, level)
+    for w in range(5):
+        o = ol.OraP1()                                                              # fresh object = fresh correlator
+        r = o.execute(x[starts[w]:starts[w] + 3072], 0, True, level)
+        assert res[w].detected and r["detected"] and cons[w] == r["consume"] and res[w].idx_buffer_sym == r["idx_buffer_sym"]
+        assert (res[w].shift, res[w].s1, res[w].s2) == (r["shift"], r["s1"], r["s2"]) == (84, 0, 10)
+        assert abs(res[w].coarse_freq_offset - r["coarse_freq_offset"]) < 0.5
+        assert abs(starts[w] + cons[w] - res[w].idx_buffer_sym - ends[w]) <= 2
+    # already decoded: the next batch does not decode again (shift -1) unless reset is set
+    res2, _ = g.execute_batch_dev(torch.from_numpy(x).cuda(), starts[:2], np.full(2, 3072))
+    assert all(r.detected and r.shift == -1 and r.p1_decoded == 1 for r in res2)
+    res3, _ = g.execute_batch_dev(torch.from_numpy(x).cuda(), starts[:2], np.full(2, 3072), reset=True)
+    assert all(r.shift == 84 for r in res3)
