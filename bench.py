@@ -6,12 +6,14 @@
 
 Workload (BASELINE.json config 3, "CFG-A"): F complete T2 frames per GPU per step -- 8 MHz, 32K extended, GI 1/128, PP7,
 1 P2 + 59 data symbols, one PLP, rotated 256-QAM, LDPC 64800 r=3/4, 202 FEC blocks per frame -- synthetic, built by the
-transmitter model in tests/t2_tx.py, resident in HBM as guard-removed complex samples before the clock starts. One step
-= FFT -> P2/data equaliser + frequency de-interleave -> time/cell de-interleave -> demap -> LDPC (reference SIMD-batch
-rule, 25 trials) -> BB descramble for all F frames. Rank 0 prints ONE JSON line: `value` = input IQ samples (whole
-frames incl. P1 and guard intervals, at 64/7 Msps) per second; `roofline` is for the dominant kernel (LDPC) from HIP
-events around its launches inside the timed region; `cpu_baseline` times the same chain on one host core (oracle
-restatement + the reference's own LDPC where oracle/_ref is loadable) on one frame.
+transmitter model in tests/t2_tx.py (P1 + cyclic prefixes + AWGN), resident in HBM as the int16 I/Q samples a tuner
+delivers at 64/7 Msps (the dvbt2_demodulator::execute boundary) before the clock starts. One step = front end (dc / IQ
+imbalance / NCO / Farrow x2 / 64-tap decimator) -> P1 detection at every frame start -> guard-interval correlation of
+every symbol -> FFT with the guard dropped -> P2/data equaliser + frequency de-interleave -> time/cell de-interleave ->
+demap -> LDPC (reference SIMD-batch rule, 25 trials) -> BB descramble for all F frames, tracking loops open (zeros and
+the nominal resample). Rank 0 prints ONE JSON line: `value` = input IQ samples per second; `roofline` is for the dominant
+kernel (LDPC) from HIP events around its launches inside the timed region; `cpu_baseline` times the same chain on one
+host core (oracle restatement + the reference's own LDPC where oracle/_ref is loadable) on one frame.
 """
 import argparse
 import json
@@ -35,7 +37,8 @@ FRAME_SAMPLES = 2048 + 60 * (32768 + 256)   # P1 + 60 symbols with GI 1/128 = 1 
 
 
 def make_frames(n_unique, snr_db, seed):
-    """n_unique synthetic CFG-A frames (guard removed): complex64 [n][60][32768], the sent TS packets, blocks per frame."""
+    """n_unique synthetic CFG-A frames as int16 I/Q at the tuner interface: (I [n][FRAME_SAMPLES], Q, sent TS packets, blocks
+    per frame)."""
     import numpy as np
     import oracle_lib as ol
     import t2_tx
@@ -47,14 +50,17 @@ def make_frames(n_unique, snr_db, seed):
     for f in range(n_unique):
         ts = t2_tx.ts_packets(per, seed + f)
         stream, _, _ = t2_tx.build_plp_frame_cells(cid, PLP[0], PLP[1], PLP[2], ts, nb)
-        frames.append(t2_tx.build_frame(m, stream, L1_POST_SIZE, seed + 100 + f, snr_db=snr_db, phase=0.3 * (f + 1)))
+        frames.append(t2_tx.build_frame(m, stream, L1_POST_SIZE, seed + 100 + f, snr_db=None, phase=0.0))
         sent.append(ts)
-    return np.stack(frames), sent, nb
+    i16, q16, flen = t2_tx.iq_stream(frames, 256, 10, snr_db, seed)                  # S2 = 1010: 32K, not mixed
+    assert flen == FRAME_SAMPLES
+    return i16.reshape(n_unique, flen), q16.reshape(n_unique, flen), sent, nb
 
 
-def cpu_chain_baseline(frame):
-    """One CFG-A frame through the CPU chain on one core: numpy FFT, oracle equaliser / de-interleavers / demapper (C
-    restatement), the reference's own LDPC build when loadable (else the C restatement), oracle descrambler."""
+def cpu_chain_baseline(i16, q16):
+    """One CFG-A frame (int16 I/Q) through the CPU chain on one core: oracle front end (dc / IQ / NCO, Farrow, decimator), P1
+    detector, guard correlation, numpy FFT, oracle equaliser / de-interleavers / demapper (C restatement), the reference's own
+    LDPC build when loadable (else the C restatement), oracle descrambler."""
     import numpy as np
     import oracle_lib as ol
     m = ol.ora_mode(*MODE)
@@ -62,12 +68,22 @@ def cpu_chain_baseline(frame):
     nb = (m.c_p2 - 1840 - L1_POST_SIZE + 59 * m.c_data) // 8100
     ldpc, kind = (ol.ref_decode, "reference LDPC + port") if ol.ref() is not None else (ol.ora_decode, "port")
     ti = ol.OraTi(8100, nb)
+    sym = 32768 + 256
     t0 = time.perf_counter()
     reps = 0
-    while True:                                   # the same frame over and over: ~12 s of single-core work
+    while True:                                   # the same frame over and over until ~12 s of single-core work are done
+        fo, fa, de, p1 = ol.OraFront(0), ol.OraFarrow(), ol.OraDecim(), ol.OraP1()
+        x = np.concatenate((i16, i16[:4096])), np.concatenate((q16, q16[:4096]))     # a little of the next frame: filter delay
+        derot, theta = fo.execute(x[0], x[1], [len(x[0])], [0.0], [0.0])
+        stream = de(fa(derot, 0.5))
+        level = float(np.mean(np.abs(stream.real)) * np.mean(np.abs(stream.imag)))
+        r = p1.execute(stream[:3072], 0, True, level)
+        first = r["consume"] - r["idx_buffer_sym"] if r["detected"] else 2048 + 17
         cells = []
-        for l in range(frame.shape[0]):
-            spec = np.fft.fftshift(np.fft.fft(frame[l])).astype(np.complex64)
+        for l in range(60):
+            s0 = first + l * sym
+            ol.ora_cp_frequency_est(stream[s0:s0 + sym], 32768, 256)
+            spec = np.fft.fftshift(np.fft.fft(stream[s0 + 256:s0 + sym])).astype(np.complex64)
             out, _, _ = ol.ora_data_symbol(m, l, spec)
             cells.append(out[1840 + L1_POST_SIZE:] if l == 0 else out)
         cells = np.concatenate(cells)[:nb * 8100]
@@ -84,9 +100,9 @@ def cpu_chain_baseline(frame):
         if el >= 12.0:
             break
     return {"value": round(reps * FRAME_SAMPLES / el / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d passes over one CFG-A frame (60 symbols, %d of %d FEC blocks in whole SIMD batches of 32 through the LDPC, "
-                      "25 trials each: the wrapped 256-QAM LLRs never converge), %.1f s; stages: numpy FFT + oracle C restatement, "
-                      "LDPC = %s" % (reps, (nb // 32) * 32, nb, el, kind)}
+            "sample": "%d passes over one CFG-A frame from int16 I/Q (front end, P1, 60 symbols, %d of %d FEC blocks in whole SIMD "
+                      "batches of 32 through the LDPC, 25 trials each: the wrapped 256-QAM LLRs never converge), %.1f s; stages: "
+                      "oracle C restatement + numpy FFT, LDPC = %s" % (reps, (nb // 32) * 32, nb, el, kind)}
 
 
 def main():
@@ -121,19 +137,23 @@ def main():
     # weak scaling: every GPU demodulates args.frames whole T2 frames per step (frames are independent: no collective)
     lo, hi = shard_frames(args.frames * world, world, rank, align=1)
     F = hi - lo
-    uniq, sent, nb = make_frames(2, args.snr, seed=20250614 + 10 * rank)
-    host = np.concatenate([uniq] * ((F + 1) // 2))[:F]
-    x = torch.from_numpy(host.view(np.float32).reshape(F, 60, 32768, 2)).to(dev)     # CFG-A has no frame-closing symbol
+    from sdr_receiver_dvb_t2_amd.receiver import t2_receiver
+    ui, uq, sent, nb = make_frames(2, args.snr, seed=20250614 + 10 * rank)
+    d_i = torch.from_numpy(np.concatenate([ui] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)     # int16 [F * FRAME_SAMPLES]
+    d_q = torch.from_numpy(np.concatenate([uq] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)
 
-    def make_chain(saturate):
-        return pkg.t2_chain(*MODE, L1_POST_SIZE, *PLP, nb, max_frames=F, device=local_rank, ldpc_trials=args.trials,
-                            saturate_llr=saturate)
+    def make_rx(saturate, frames):
+        return t2_receiver((*MODE, L1_POST_SIZE, *PLP, nb), dict(ldpc_trials=args.trials, saturate_llr=saturate), max_frames=frames,
+                           device=local_rank)
 
-    chain = make_chain(False)                 # reference semantics: truncating int8 cast in the demapper
+    rx = make_rx(False, F)                    # reference semantics: truncating int8 cast in the demapper
+    chain = rx.chain
+    r0 = rx.demod_iq_dev(d_i, d_q, F, first_call=True, flush=True)                    # thresholds from the level estimate
+    level = float(rx.front.state()["level_detect"])
     for _ in range(args.warmup):
-        bits, trials = chain.demod_dev(x, flush=True)
+        r0 = rx.demod_iq_dev(d_i, d_q, F, level_detect=level, first_call=False, flush=True)
     torch.cuda.synchronize(dev)
-    ref_trials = trials.cpu().numpy() if args.warmup else None
+    ref_trials = r0["trials"].cpu().numpy()
 
     chain.time_ldpc = True
     if world > 1:
@@ -141,7 +161,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        chain.demod_dev(x, flush=True)
+        rx.demod_iq_dev(d_i, d_q, F, level_detect=level, first_call=False, flush=True)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -154,19 +174,21 @@ def main():
     # informative second leg (rank 0, N = 1): clamped LLRs (extension) -> the same frames decode; checks the TS bytes
     extra = {}
     if rank == 0 and not args.no_clamped_variant:
-        c2 = make_chain(True)
-        bits2, trials2 = c2.demod_dev(x[:2], flush=True)
+        c2 = make_rx(True, 2)
+        r2 = c2.demod_iq_dev(d_i[:2 * FRAME_SAMPLES], d_q[:2 * FRAME_SAMPLES], 2, flush=True)
         torch.cuda.synchronize(dev)
-        t2h = trials2.cpu().numpy()
-        got = c2.ts_from_bits(bits2.cpu().numpy(), t2h)
+        t2h = r2["trials"].cpu().numpy()
+        got = c2.chain.ts_from_bits(r2["bits"].cpu().numpy(), t2h)
+        c2.close()
         want = sent[0].reshape(-1)
         npk = (nb * ((48408 - 80) // 8)) // 187 - 1
         ok = bool((t2h >= 0).all()) and bool(np.array_equal(got[:npk * 188], want[:npk * 188]))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c3 = make_chain(True)
-        c3.demod_dev(x, flush=True)
-        e0.record(); c3.demod_dev(x, flush=True); e1.record()
+        c3 = make_rx(True, F)
+        c3.demod_iq_dev(d_i, d_q, F, flush=True)
+        e0.record(); c3.demod_iq_dev(d_i, d_q, F, level_detect=level, first_call=False, flush=True); e1.record()
         torch.cuda.synchronize(dev)
+        c3.close()
         extra = {"clamped_llr_variant": {"msamples_per_s": round(F * FRAME_SAMPLES / (e0.elapsed_time(e1) / 1e3) / 1e6, 1),
                                           "ts_matches_sent": ok, "avg_ldpc_updates": round(float((args.trials - t2h).mean()), 2),
                                           "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}}
@@ -180,12 +202,14 @@ def main():
             "metric": "IQ Msamples/s demod->TS (32K, 256-QAM, LDPC 64800 r=3/4)",
             "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (OFDM, demap) + int8 (LDPC)", "data": "synthetic",
-            "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames; stages on GPU: FFT, "
-                                   "P2+data equaliser/freq-deint, TI/cell-deint, demap, LDPC (group 32, max %d trials), BB descramble; "
+            "vs_baseline": None, "dtype": "int16 in, f32 (front end, OFDM, demap) + int8 (LDPC)", "data": "synthetic",
+            "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames, from int16 I/Q at the "
+                                   "dvbt2_demodulator::execute boundary; stages on GPU: front end (dc, IQ imbalance, NCO, Farrow x2, "
+                                   "64-tap decimator), P1 detect, guard correlation, FFT, P2+data equaliser/freq-deint, TI/cell-deint, "
+                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; "
                                    "reference arithmetic incl. the wrapping int8 LLR cast, so %d of %d SIMD batches run all trials and "
-                                   "are dropped as the reference would; P1/L1 acquisition, guard removal, resampler and TS "
-                                   "de-framing are not inside the timed region (samples counted per whole frame, %d each)"
+                                   "are dropped as the reference would; L1 parsing and TS de-framing (host code) are not inside the "
+                                   "timed region (%d samples per frame)"
                                    % (F, F * 60, F * nb, args.trials, dropped, len(ref_trials) if ref_trials is not None else 0,
                                       FRAME_SAMPLES),
                        "ldpc_codewords_per_s": round(ldpc_frames / avg_ldpc_s, 1),
@@ -200,7 +224,7 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_chain_baseline(host[0])
+            out["cpu_baseline"] = cpu_chain_baseline(ui[0], uq[0])
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -51,7 +51,10 @@ void t2_plan_nco(float &acc, int i_begin, int n, float fe, float phase_nco, std:
         const float v0 = nco_next(prev, fe, &w);
         long len = 1;
         double step = 0.0;
-        if (n - i >= 3 && v0 != 0.0f) {
+        bool w0;
+        if (nco_next(v0, fe, &w0) == v0 && !w0) {
+            len = n - i;                                                      // the accumulator no longer moves (fe = 0 or below half an ulp)
+        } else if (n - i >= 3 && v0 != 0.0f) {
             bool w1, w2;
             const float v1 = nco_next(v0, fe, &w1), v2 = nco_next(v1, fe, &w2);
             const double s1 = (double)v1 - (double)v0, s2 = (double)v2 - (double)v1;

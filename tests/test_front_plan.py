@@ -38,6 +38,13 @@ def test_nco_runs_exact(built, fe):
         acc = acc_w
 
 
+def test_nco_stationary_is_one_run(built):
+    from sdr_receiver_dvb_t2_amd import front
+    for acc, fe in ((0.0, 0.0), (0.3, 0.0), (5.0, 1.0e-9), (-6.0, -1.0e-8)):      # fe = 0 or below half an ulp of the accumulator
+        got, acc_g, runs = front.plan_nco(acc, 100000, fe)
+        assert runs == 1 and np.all(got == np.float32(acc)) and np.float32(acc_g) == np.float32(acc)
+
+
 def test_nco_many_random(built):
     from sdr_receiver_dvb_t2_amd import front
     rng = np.random.Generator(np.random.PCG64(77))
