@@ -75,7 +75,8 @@ T2_HD int t2_f(int a)
 }
 
 // Per-thread registers of one check node (link slots 0..CNT-1 information bits in entry order, slot CNT own parity
-// bit pty[360*i+j], slot CNT+1 previous parity bit -- absent for node (0,0), address < 0).
+// bit pty[360*i+j], slot CNT+1 previous parity bit -- absent for node (0,0), address < 0). Addresses are what the memory
+// object L takes in ld()/st(): LLR index + L.off(); callers pass a_p0 / a_p1 (and LayerDesc::dummy) in that form.
 template <int CNT>
 struct CnRegs {
     static constexpr int DEG = CNT + 2;
@@ -140,7 +141,9 @@ T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, in
     r.n0 = 0; r.n1 = 0;
 #pragma unroll
     for (int c = 0; c < CNT + 2; ++c) {
-        r.addr[c] = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0], j) : (c == CNT ? a_p0 : a_p1);
+        // L.off(): where the LLR array starts in the memory L addresses (the LDS offset on the GPU; folded into the table entry's
+        // base by scalar arithmetic, so the per-lane address needs no further add at the load or the store)
+        r.addr[c] = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0] + (uint32_t)L.off(), j) : (c == CNT ? a_p0 : a_p1);
         t2_read_slot<CNT>(L, r, c);
     }
 }
@@ -211,16 +214,28 @@ T2_HD uint32_t t2_pair_record(const CnRegs<CNT> &r)
 
 // One step down a chain. X = LLR of the shared bit after the predecessor; returns it after this node:
 //   X' = sat(in0 + s * min(f(E), f(|sat(X - msg1)|))),  s = sign parity of the others * sign(X - msg1).
-// f(|sat(u)|) = med3(|u| - 1, 0, 126) also without the saturation (|u| <= 160), so the chain is sub, max, med3, sign, add, sat.
-T2_HD int t2_pair_step(uint32_t rec, int X)
+// f(|sat(u)|) = med3(|u| - 1, 0, 126) also without the saturation (|u| <= 160). Written so that only six operations depend
+// on X in sequence -- |u| - 1 = max(X + c1, c2 - X) with c1 = -msg1 - 1, c2 = msg1 - 1; med3; xor with the sign; one add of
+// (in0 - sign); the final saturation -- because this recurrence IS the critical path of a PAIR layer.
+struct PairRec { int msg1, c1, c2, cap, in0, psm; };
+T2_HD PairRec t2_pair_unpack(uint32_t rec)
 {
-    const int msg1 = (int)(int8_t)(rec & 0xff), cap = (int)((rec >> 8) & 0xff), in0 = (int)(int8_t)((rec >> 16) & 0xff);
-    const int psm = -(int)((rec >> 24) & 1u);           // 0 / -1
-    const int u = X - msg1;
-    const int a1 = (u > -u ? u : -u) - 1;
-    const int t = t2_clamp(a1, 0, cap);
-    const int sm = (u >> 31) ^ psm;
-    return t2_clamp(in0 + ((t ^ sm) - sm), -128, 127);
+    PairRec r;
+    r.msg1 = (int)(int8_t)(rec & 0xff);
+    r.cap = (int)((rec >> 8) & 0xff);
+    r.in0 = (int)(int8_t)((rec >> 16) & 0xff);
+    r.psm = -(int)((rec >> 24) & 1u);                    // 0 / -1
+    r.c1 = -r.msg1 - 1;
+    r.c2 = r.msg1 - 1;
+    return r;
+}
+T2_HD int t2_pair_step(const PairRec &r, int X)
+{
+    const int a = X + r.c1, b = r.c2 - X;
+    const int a1 = a > b ? a : b;                        // |X - msg1| - 1
+    const int t = t2_clamp(a1, 0, r.cap);
+    const int sm = ((X - r.msg1) >> 31) ^ r.psm;
+    return t2_clamp((t ^ sm) + (r.in0 - sm), -128, 127);
 }
 
 // Parity check of node j on the current LLRs (LDPCDecoder::bad, layered_decoder.hh:65-82): the node is bad when
@@ -232,7 +247,7 @@ T2_HD bool t2_cn_bad(const LMEM &L, const uint32_t *__restrict__ ent, int j, int
     bool zero = false;
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-        int v = (int)L.ld(t2_link_addr(ent[c], j));
+        int v = (int)L.ld(t2_link_addr(ent[c] + (uint32_t)L.off(), j));
         sx ^= v;
         zero |= (v == 0);
     }
@@ -248,6 +263,7 @@ T2_HD bool t2_cn_bad(const LMEM &L, const uint32_t *__restrict__ ent, int j, int
 struct LayerDesc {
     const uint32_t *ent;
     int cnt, lmax, nc, kind, step;
+    int dummy;      // address of a scratch byte in the LLR memory: target of the stores a chain walker predicates away
 };
 
 // phase A: every node loads; PLAIN nodes and chain-start / level-free nodes finish at once
@@ -264,11 +280,10 @@ T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_
         t2_cn_pack<CNT>(r, st);
     } else if (d.kind == T2_LAYER_PAIR) {
         t2_cn_partial<CNT>(r, 2);
-        if (j < d.step) {                       // chain start: nothing earlier touches its bits
-            t2_cn_merge<CNT>(r, 2);
-#pragma unroll
-            for (int c = 0; c < CNT + 2; ++c) t2_write_slot<CNT>(L, r, c, true);
-            t2_cn_pack<CNT>(r, st);
+        if (j < d.step) {                       // chain start: nothing earlier touches its bits. Its two group bits must be final
+            t2_cn_merge<CNT>(r, 2);             // early -- slot 0 is handed down the chain, slot 1 is the slot-0 bit of the chain END
+            t2_write_slot<CNT>(L, r, 0, true);  // j + 360 - step, which re-reads it in phase C; the private slots wait for phase C
+            t2_write_slot<CNT>(L, r, 1, true);  // so that every wavefront has the same amount of work in both phases
         } else {
             pair_rec[j] = t2_pair_record<CNT>(r);
         }
@@ -277,37 +292,69 @@ T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_
     }
 }
 
-// PAIR phase B: lane `lane` < step walks chain lane, lane+step, ... (all nodes that have a successor). Records are
-// fetched four steps ahead so that only the scalar recurrence (X in a register) is on the critical path.
+// PAIR phase B: lane `lane` < step walks chain lane, lane+step, ... (all nodes that have a successor). Records are fetched
+// and unpacked a batch ahead so that only the scalar recurrence (X in a register) is on the critical path. A walking
+// wavefront is issue-bound (one lane's worth of work per instruction), so the body is kept short and branch-free: all chains
+// of a layer have n or n + 1 such nodes (n = (360 - step) / step - 1, the same for every lane), the first n steps run
+// unconditionally in batches of four, at most four predicated steps finish (record index clamped, X kept, store redirected
+// to the scratch byte d.dummy for a lane that is already done).
 template <class LMEM>
 T2_HD void t2_pair_walk(LMEM &L, const LayerDesc &d, int lane, const uint32_t *pair_rec)
 {
+    constexpr int B = 4;
     const uint32_t e0 = d.ent[0];
-    const int base = (int)(e0 & 0xffffu), s0 = (int)(e0 >> 16), step = d.step;
+    const int base = (int)(e0 & 0xffffu) + L.off(), s0 = (int)(e0 >> 16), step = d.step;
     int m = lane - s0;                                   // position of the shared bit inside its 360-bit group
     m += (m < 0) ? 360 : 0;
     int X = (int)L.ld(base + m);
-    for (int jj = lane + step; jj + step < 360; jj += 4 * step) {
-        uint32_t rec[4];
+    const int n_common = (360 - step) / step - 1;        // nodes with a successor that every chain of this layer has
+    int jj = lane + step;
+    int k = 0;
+    if (n_common >= B) {
+        uint32_t nxt[B];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rec[u] = (jj + (u + 1) * step < 360) ? pair_rec[jj + u * step] : 0u;
+        for (int u = 0; u < B; ++u) nxt[u] = pair_rec[jj + u * step];
+        for (; k + B <= n_common; k += B) {
+            PairRec cur[B];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (jj + (u + 1) * step < 360) {
-                m += step;
-                m -= (m >= 360) ? 360 : 0;
-                X = t2_pair_step(rec[u], X);
+            for (int u = 0; u < B; ++u) cur[u] = t2_pair_unpack(nxt[u]);
+            jj += B * step;
+#pragma unroll
+            for (int u = 0; u < B; ++u) { const int q = jj + u * step; nxt[u] = pair_rec[q < 359 ? q : 359]; }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const unsigned t = (unsigned)(m + step);
+                m = (int)(t < t - 360u ? t : t - 360u);  // (m + step) mod 360
+                X = t2_pair_step(cur[u], X);
                 L.st(base + m, (int8_t)X);
             }
         }
     }
+    // the remaining nodes of this lane's chain (fewer than B + 1)
+#pragma unroll
+    for (int u = 0; u < B + 1; ++u) {
+        const int q = jj + u * step;
+        const bool live = q + step < 360;
+        const PairRec r = t2_pair_unpack(pair_rec[q < 359 ? q : 359]);
+        const unsigned t = (unsigned)(m + step);
+        m = (int)(t < t - 360u ? t : t - 360u);
+        const int Xn = t2_pair_step(r, X);
+        X = live ? Xn : X;
+        L.st(live ? base + m : d.dummy, (int8_t)X);
+    }
 }
 
-// PAIR phase C: every node that is not a chain start finishes (slot 1 always re-read, slot 0 when it is a chain end)
+// PAIR phase C: every node finishes. Chain starts wrote slots 0 and 1 in phase A; the others re-read slot 1 (always) and slot 0
+// (when they are a chain end) first.
 template <int CNT, class LMEM>
 T2_HD void t2_pair_finish(LMEM &L, const LayerDesc &d, int j, CnState &st, CnRegs<CNT> &r)
 {
-    if (j < d.step) return;
+    if (j < d.step) {
+#pragma unroll
+        for (int c = 2; c < CNT + 2; ++c) t2_write_slot<CNT>(L, r, c, true);
+        t2_cn_pack<CNT>(r, st);
+        return;
+    }
     const bool has_succ = j + d.step < 360;
     t2_read_slot<CNT>(L, r, 1);
     if (!has_succ) t2_read_slot<CNT>(L, r, 0);

@@ -74,8 +74,18 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
                         if (j2 < j) { lv = std::max(lv, lev[j2] + 1); dep |= 1u << x; }
                     }
                 lev[j] = (uint8_t)lv;
-                g.cninfo[(size_t)i * GROUP + j] = (uint32_t)lv | (dep << 8);
+                g.cninfo[(size_t)i * GROUP + j] = (uint32_t)lv | (dep << 8) | ((uint32_t)j << 20);
                 lmax = std::max(lmax, lv);
+            }
+            if (L.kind == T2_LAYER_GENERIC) {
+                // thread t of the workgroup takes node order[t]: nodes sorted by level, so that a level step keeps one or two
+                // wavefronts busy instead of a few lanes in every wavefront
+                std::vector<int> order(GROUP);
+                for (int j = 0; j < GROUP; ++j) order[j] = j;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lev[a] < lev[b]; });
+                std::vector<uint32_t> byt(GROUP);
+                for (int t = 0; t < GROUP; ++t) byt[t] = g.cninfo[(size_t)i * GROUP + order[t]];
+                for (int t = 0; t < GROUP; ++t) g.cninfo[(size_t)i * GROUP + t] = byt[t];
             }
         }
         L.lmax = lmax;

@@ -34,7 +34,8 @@ struct LdpcGraph {
     std::vector<LdpcLayer> layers;     // [q]
     std::vector<uint32_t> entries;     // packed: base (bits 0..15) | shift (bits 16..24)
     std::vector<uint8_t> levels;       // [q*360], values 1..lmax
-    std::vector<uint32_t> cninfo;      // [q*360]: level (bits 0..7) | dependent-conflict-slot mask << 8 (GENERIC layers)
+    std::vector<uint32_t> cninfo;      // [q*360]: level (bits 0..7) | dependent-conflict-slot mask << 8 | node j << 20. In GENERIC
+                                       // layers entry t describes the node THREAD t takes (nodes sorted by level), else node t
     int serial_steps = 0;              // sum over layers of sequential steps a sweep needs (chain walks + level steps)
 };
 

@@ -22,10 +22,14 @@
 
 namespace t2gpu {
 
+// LLR bytes in LDS, addressed by their 32-bit LDS address: the array's LDS offset is folded into the scalar part of every
+// address computation (ldpc_cn.h, L.off()), so a load or store is one ds instruction without a per-lane add.
+typedef __attribute__((address_space(3))) int8_t lds_i8;
 struct LdsMem {
-    int8_t *p;
-    __device__ __forceinline__ int8_t ld(int a) const { return p[a]; }
-    __device__ __forceinline__ void st(int a, int8_t v) { p[a] = v; }
+    uint32_t base;
+    __device__ __forceinline__ int off() const { return (int)base; }
+    __device__ __forceinline__ int8_t ld(int a) const { return *reinterpret_cast<const lds_i8 *>((uint32_t)a); }
+    __device__ __forceinline__ void st(int a, int8_t v) { *reinterpret_cast<lds_i8 *>((uint32_t)a) = v; }
 };
 
 static constexpr int kThreads = T2GPU_LDPC_THREADS;   // 6 wavefronts; 360 of 384 lanes own a check node
@@ -114,31 +118,50 @@ __device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, 
     return bad != 0;
 }
 
+#ifndef T2_PROF_DETAIL
+#define T2_PROF_DETAIL 0      // diagnostics builds: 1 splits the PAIR layers, 2 the GENERIC layers into slots 3 / 4 / 5
+#endif
+#define T2_DTL(kind_, slot_)                                                                                        \
+    do {                                                                                                            \
+        if (T2_PROF_DETAIL == (kind_) && prof && threadIdx.x == 0) {                                                \
+            const long long now_ = (long long)__builtin_readcyclecounter();                                        \
+            prof[blockIdx.x * 8 + (slot_)] += now_ - tdt;                                                           \
+            tdt = now_;                                                                                             \
+        }                                                                                                           \
+    } while (0)
+
 template <int CNT>
 __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int j, bool active, int a0, int a1,
-                                             CnState &st, uint32_t info, uint32_t *pair_rec)
+                                             CnState &st, uint32_t info, uint32_t *pair_rec, long long *prof)
 {
     CnRegs<CNT> r;
+    long long tdt = (T2_PROF_DETAIL && prof) ? (long long)__builtin_readcyclecounter() : 0;
     if (active) t2_layer_phase_a<CNT>(L, d, j, a0, a1, st, r, pair_rec);
     // The sequential parts (chain walks, level steps) keep only a few lanes busy and sit on the workgroup's critical
     // path while the co-resident workgroup is usually in a throughput phase: give them issue priority.
     if (d.kind == T2_LAYER_PAIR) {
         lds_barrier();
+        T2_DTL(1, 3);
         __builtin_amdgcn_s_setprio(3);
         if (j < d.step) t2_pair_walk(L, d, j, pair_rec);
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();
+        T2_DTL(1, 4);
         if (active) t2_pair_finish<CNT>(L, d, j, st, r);
     } else if (d.kind == T2_LAYER_GENERIC) {
+        T2_DTL(2, 3);
         __builtin_amdgcn_s_setprio(3);
         for (int lv = 1; lv <= d.lmax; ++lv) {
             if (active) t2_generic_level<CNT>(L, d, lv, info, r);
             lds_barrier();
         }
         __builtin_amdgcn_s_setprio(0);
+        T2_DTL(2, 4);
         if (active) t2_generic_finish<CNT>(L, d, st, r);
     }
     lds_barrier();
+    if (d.kind == T2_LAYER_PAIR) T2_DTL(1, 5);
+    if (d.kind == T2_LAYER_GENERIC) T2_DTL(2, 5);
 }
 
 #define T2_PROF_T(var) long long var = p.prof ? (long long)__builtin_readcyclecounter() : 0
@@ -156,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
     int *s_ctl = reinterpret_cast<int *>(lds + p.lds_ctl_offset);
     uint32_t *pair_rec = reinterpret_cast<uint32_t *>(lds + p.lds_rec_offset);
     uint32_t *S2 = reinterpret_cast<uint32_t *>(lds + p.lds_sign_offset);
-    LdsMem L{Lm};
+    LdsMem L{(uint32_t)(uintptr_t)(lds_i8 *)Lm};     // generic -> LDS address space cast: the 32-bit LDS offset of the array
 
     const int tid = threadIdx.x;
     const int j = tid;
@@ -225,17 +248,25 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
 
             // ---- one layered update sweep (LDPCDecoder::update)
             if (have) {
+                // records belong to (layer, thread); in GENERIC layers thread j takes node cninfo >> 20 (nodes sorted by dependency
+                // level, ldpc_graph.cpp), elsewhere node j
                 uint2 nxt = active ? state[j] : make_uint2(0u, 0u);
+                uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
                 for (int i = 0; i < p.q; ++i) {
                     const LdpcLayerDev ly = layers[i];
-                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step};
-                    const int a0 = p.k + 360 * i + j, a1 = parity_prev_addr(p.k, p.q, i, j);
+                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32};
+                    const uint32_t info = info_nxt;
+                    const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
+                    const int a0 = L.off() + p.k + 360 * i + jn, a1r = parity_prev_addr(p.k, p.q, i, jn);
+                    const int a1 = a1r >= 0 ? a1r + L.off() : -1;
                     CnState st{nxt.x, nxt.y};
-                    if (active && i + 1 < p.q) nxt = state[(i + 1) * 360 + j];      // prefetch the next layer's record
-                    const uint32_t info = (active && ly.kind == T2_LAYER_GENERIC) ? cninfo[i * 360 + j] : 0u;
+                    if (active && i + 1 < p.q) {                                     // prefetch the next layer's record (and node)
+                        nxt = state[(i + 1) * 360 + j];
+                        info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
+                    }
                     T2_PROF_T(tp2);
-                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, layer_update<CNT>(L, d, j, active, a0, a1, st, info, pair_rec));
-                    T2_PROF_ADD(2 + ly.kind, tp2);
+                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, layer_update<CNT>(L, d, jn, active, a0, a1, st, info, pair_rec, p.prof));
+                    if (!(T2_PROF_DETAIL && ly.kind == T2_PROF_DETAIL)) T2_PROF_ADD(2 + ly.kind, tp2);
                     if (active) state[i * 360 + j] = make_uint2(st.w0, st.w1);
                 }
             }

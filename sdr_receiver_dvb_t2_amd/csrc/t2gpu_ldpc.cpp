@@ -4,6 +4,7 @@
 #include "ldpc_graph.h"
 #include "ldpc_kernel.h"
 #include "t2gpu_common.h"
+#include <cstdlib>
 #include <vector>
 
 using namespace t2gpu;
@@ -72,6 +73,10 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     h->lds_bytes = h->lds_sign_offset + (h->g.n / 360) * 13 * 4;
     if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu)) != hipSuccess) return fail("kernel attributes", e);
     if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
+    if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {          // experiments: fewer resident workgroups per CU
+        const int v = std::atoi(lim);
+        if (v >= 1 && v < h->blocks_per_cu) h->blocks_per_cu = v;
+    }
 
     std::vector<LdpcLayerDev> ld(h->g.q);
     for (int i = 0; i < h->g.q; ++i)

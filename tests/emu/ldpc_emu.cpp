@@ -20,6 +20,7 @@ using namespace t2gpu;
 namespace {
 struct Mem {
     int8_t *p;
+    int off() const { return 0; }
     int8_t ld(int a) const { return p[a]; }
     void st(int a, int8_t v) { p[a] = v; }
 };
@@ -41,18 +42,21 @@ template <int CNT>
 void emu_layer(Mem &L, const LdpcGraph &g, int i, CnState *st, Order &ord)
 {
     const LdpcLayer &ly = g.layers[i];
-    LayerDesc d{&g.entries[ly.first_entry], ly.cnt, ly.lmax, ly.n_conflict, ly.kind, ly.step};
+    LayerDesc d{&g.entries[ly.first_entry], ly.cnt, ly.lmax, ly.n_conflict, ly.kind, ly.step, g.n};   // scratch byte behind the LLRs
     std::vector<CnRegs<CNT>> regs(360);
     std::vector<uint32_t> rec(360, 0xdeadbeefu);
     auto a0 = [&](int j) { return g.k + 360 * i + j; };
     auto a1 = [&](int j) { return prev_addr(g.k, g.q, i, j); };
     if (d.kind == T2_LAYER_GENERIC) {
+        // cninfo entry t describes the node thread t takes (bits 20..28); index it by node here
+        std::vector<uint32_t> info(360, 0);
+        for (int t = 0; t < 360; ++t) { const uint32_t v = g.cninfo[(size_t)i * 360 + t]; info[v >> 20] = v; }
         for (int j : ord.make()) {       // epoch 1: phase A immediately followed by level step 1 (no barrier between)
             t2_layer_phase_a<CNT>(L, d, j, a0(j), a1(j), st[j], regs[j], rec.data());
-            t2_generic_level<CNT>(L, d, 1, g.cninfo[(size_t)i * 360 + j], regs[j]);
+            t2_generic_level<CNT>(L, d, 1, info[j], regs[j]);
         }
         for (int lv = 2; lv <= d.lmax; ++lv)
-            for (int j : ord.make()) t2_generic_level<CNT>(L, d, lv, g.cninfo[(size_t)i * 360 + j], regs[j]);
+            for (int j : ord.make()) t2_generic_level<CNT>(L, d, lv, info[j], regs[j]);
         for (int j : ord.make()) t2_generic_finish<CNT>(L, d, st[j], regs[j]);
         return;
     }
@@ -71,7 +75,7 @@ extern "C" int emu_ldpc_decode(int code_id, const int8_t *llr_in, int blocks, in
 {
     LdpcGraph g;
     if (!ldpc_build_graph(code_id, g)) return -2;
-    std::vector<std::vector<int8_t>> Lv(blocks, std::vector<int8_t>(g.n));
+    std::vector<std::vector<int8_t>> Lv(blocks, std::vector<int8_t>(g.n + 1));
     std::vector<std::vector<CnState>> S(blocks, std::vector<CnState>((size_t)g.q * 360, CnState{0, 0}));
     for (int b = 0; b < blocks; ++b) memcpy(Lv[b].data(), llr_in + (size_t)b * g.n, g.n);
     Order ord{order_mode, std::mt19937(1234u + order_mode)};

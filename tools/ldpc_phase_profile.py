@@ -19,8 +19,8 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); bits, trials = dec.execute_dev(x); e1.record(); torch.cuda.synchronize()
 out = (ctypes.c_longlong * 8)()
 pkg.lib().t2gpu_ldpc_profile(dec._h, out)
-names = ["parity check", "rendezvous", "PLAIN layers", "PAIR layers", "GENERIC layers"]
-tot = sum(out[:5])
+names = ["parity check", "rendezvous", "PLAIN layers", "PAIR layers / slot3", "GENERIC / slot4", "slot5"]
+tot = sum(out[:6])
 print("launch %.3f ms, frames %d, avg updates %.2f" % (e0.elapsed_time(e1), frames, float((25 - trials.float()).mean())))
 for n, v in zip(names, out):
     print("%-16s %14d cycles  %5.1f %%" % (n, v, 100.0 * v / max(tot, 1)))
