@@ -1,0 +1,292 @@
+// t2gpu_stages.hpp -- host side above the C ABI, in the reference's own language: Qt-free C++ classes with the NAMES, slot
+// signatures and drop behaviour of the reference's pipeline objects for the accelerated path, so that code written against
+// src/DVB_T2/*.h reads the same here. A Qt `signal` becomes a std::function member of the same name (connect = assign); a
+// slot's body is one call into libt2gpu.so (include/t2gpu.h). Nothing here computes: without the library / a GPU every
+// constructor throws. Header-only; link with -lt2gpu.
+//
+//   reference object (file)                               here
+//   ldpc_decoder       src/DVB_T2/ldpc_decoder.h:66-93    t2::ldpc_decoder
+//   bch_decoder        src/DVB_T2/bch_decoder.h:26-58     t2::bch_decoder
+//   bb_de_header       src/DVB_T2/bb_de_header.h:37-110   t2::bb_de_header
+//   llr_demapper       src/DVB_T2/llr_demapper.h:29-48    t2::llr_demapper
+//   time_deinterleaver src/DVB_T2/time_deinterleaver.h    t2::time_deinterleaver  (one PLP, TI type 0: what the library covers)
+//   filter_decimator   src/DSP/filter_decimator.h:14-131  t2::filter_decimator
+//   interpolator_farrow src/DSP/interpolator_farrow.hh    t2::interpolator_farrow
+//   p1_symbol          src/DVB_T2/p1_symbol.h:26-48       t2::p1_symbol
+//   fast_fourier_transform + data_symbol / p2_symbol / fc_symbol (src/DSP/fast_fourier_transform.h, src/DVB_T2/data_symbol.h)
+//                                                         t2::ofdm_demodulator (one handle owns the mode tables of all three)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "t2gpu.h"
+
+namespace t2 {
+
+typedef std::complex<float> complex;                       // dvbt2_definition.h:23
+constexpr int SIZEOF_SIMD = T2GPU_SIMD_BATCH;              // ldpc_decoder.h:28-32 (AVX2 build)
+
+// l1_postsignalling as the stages receive it by value (dvbt2_definition.h): configurable part, PLP loop, dynamic part
+struct l1_postsignalling {
+    t2gpu_l1_post post{};
+    std::vector<t2gpu_l1_plp> plp;
+    std::vector<t2gpu_l1_dyn_plp> dyn_plp;
+};
+
+inline void fail(const char *what) { throw std::runtime_error(std::string(what) + ": " + t2gpu_last_error()); }
+
+// ---------------------------------------------------------------------------------------------------------------- LDPC
+class ldpc_decoder {
+public:
+    explicit ldpc_decoder(int device = 0) : device_(device) {}
+    ~ldpc_decoder() { for (auto &row : gpu_) for (auto *h : row) if (h) t2gpu_ldpc_destroy(h); }
+    // signals (ldpc_decoder.h:83-87)
+    std::function<void(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_out, uint8_t *out)> bit_bch;
+    // slot (ldpc_decoder.h:90, ldpc_decoder.cpp:157-301): 32 frames of int8 LLRs in, information bits (one per byte) out through
+    // bit_bch; a batch the decoder cannot recover is reported on stderr and DROPPED, exactly as the reference does (:264-268)
+    void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, int8_t *in)
+    {
+        const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
+        t2gpu_ldpc *&h = gpu_[p.plp_fec_type & 1][p.plp_cod % 6];
+        if (!h && !(h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
+        int k_ldpc = 0;
+        t2gpu_ldpc_info(h, nullptr, &k_ldpc, nullptr, nullptr);
+        std::vector<uint8_t> &out = swap_buffer ? buffer_a : buffer_b;
+        out.resize((size_t)k_ldpc * SIZEOF_SIMD);
+        int trials_left = -1;
+        if (t2gpu_ldpc_execute(h, in, len_in, out.data(), &trials_left) != 0) fail("t2gpu_ldpc_execute");
+        if (trials_left < 0) {
+            std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials_left);
+            return;
+        }
+        swap_buffer = !swap_buffer;
+        if (bit_bch) bit_bch(idx_plp_simd, l1_post, k_ldpc * SIZEOF_SIMD, out.data());
+    }
+private:
+    int device_;
+    t2gpu_ldpc *gpu_[2][6] = {};
+    std::vector<uint8_t> buffer_a, buffer_b;
+    bool swap_buffer = true;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- BCH stub
+class bch_decoder {
+public:
+    std::function<void(int plp_id, const l1_postsignalling &l1_post, int len_out, uint8_t *out)> bit_descramble;   // bch_decoder.h:35
+    // slot (bch_decoder.h:41, bch_decoder.cpp:63-164): strips the BCH parity (the reference corrects nothing) and descrambles;
+    // one bit_descramble per FEC frame
+    void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, uint8_t *in)
+    {
+        const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
+        const int k_ldpc = ldpc_k(p.plp_fec_type, p.plp_cod), frames = len_in / k_ldpc;
+        out_.resize((size_t)len_in);
+        const int k_bch = t2gpu_bch_descramble(p.plp_fec_type, p.plp_cod, in, frames, out_.data());
+        if (k_bch < 0) fail("t2gpu_bch_descramble");
+        for (int n = 0; n < frames; ++n)
+            if (bit_descramble) bit_descramble(idx_plp_simd[n], l1_post, k_bch, out_.data() + (size_t)n * k_bch);
+    }
+private:
+    static int ldpc_k(int fec_type, int cod)
+    {
+        static const int kn[6] = {32400, 38880, 43200, 48600, 51840, 54000}, ks[6] = {7200, 9720, 10800, 11880, 12600, 13320};
+        return fec_type ? kn[cod % 6] : ks[cod % 6];                  // k_ldpc, ldpc_decoder.cpp:177-246
+    }
+    std::vector<uint8_t> out_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- BB de-header
+class bb_de_header {
+public:
+    explicit bb_de_header(int need_plp = 0) : h_(t2gpu_bbdh_create(need_plp)) { if (!h_) fail("t2gpu_bbdh_create"); }
+    ~bb_de_header() { t2gpu_bbdh_destroy(h_); }
+    std::function<void(const std::string &info)> ts_stage;                       // bb_de_header.h:56
+    std::function<void(const uint8_t *ts, int len)> write_out;                   // the UDP datagram / file write of :433-443
+    // slot (bb_de_header.h:59, bb_de_header.cpp:84-448)
+    void execute(int plp_id, const l1_postsignalling &, int len_in, uint8_t *in)
+    {
+        buf_.resize((size_t)len_in / 8 + 400);
+        int errors = 0;
+        const int n = t2gpu_bbdh_execute(h_, plp_id, len_in, in, buf_.data(), (int)buf_.size(), &errors);
+        if (n > 0 && write_out) write_out(buf_.data(), n);
+        else if (n == -1 && ts_stage) ts_stage("Baseband header CRC8 error.");
+    }
+private:
+    t2gpu_bbdh *h_;
+    std::vector<uint8_t> buf_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- LLR demapper
+class llr_demapper {
+public:
+    explicit llr_demapper(int device = 0) : device_(device) {}
+    ~llr_demapper() { if (h_) t2gpu_demap_destroy(h_); }
+    std::function<void(float snr)> signal_noise_ratio;                                                             // llr_demapper.h:38
+    std::function<void(int *idx_plp_simd, const l1_postsignalling &, int len_out, int8_t *out)> soft_multiplexer_de_twist;   // :39
+    // slot (llr_demapper.h:44-45, llr_demapper.cpp:132-158): one TI block of cells in; LLR frames are collected into batches of
+    // SIZEOF_SIMD and handed on whenever one is full (:742-764), the remainder waits for the next TI block
+    void execute(int ti_block_size, complex *time_deint_cell, int plp_id, const l1_postsignalling &l1_post)
+    {
+        const t2gpu_l1_plp &p = l1_post.plp.at((size_t)plp_id);
+        const int fec_size = p.plp_fec_type ? 64800 : 16200;
+        if (!h_ || key_ != key(p)) {
+            if (h_) t2gpu_demap_destroy(h_);
+            const int cells_max = (p.plp_num_blocks_max > 0 ? p.plp_num_blocks_max : 1) * fec_size / (2 * (p.plp_mod + 1));
+            if (!(h_ = t2gpu_demap_create(p.plp_mod, p.plp_fec_type, p.plp_cod, p.plp_rotation, std::max(cells_max, ti_block_size), device_)))
+                fail("t2gpu_demap_create");
+            key_ = key(p);
+        }
+        frames_.resize((size_t)(ti_block_size / (fec_size / (2 * (p.plp_mod + 1))) + 1) * fec_size);
+        float sums[3] = {0, 0, 0};
+        const int frames = t2gpu_demap_execute(h_, reinterpret_cast<const float *>(time_deint_cell), ti_block_size, frames_.data(), sums);
+        if (frames < 0) fail("t2gpu_demap_execute");
+        if (signal_noise_ratio) signal_noise_ratio(20.0f * std::log10(sums[0] / sums[1]));                       // :659
+        for (int f = 0; f < frames; ++f) {
+            std::vector<int8_t> &out = swap_buffer ? buffer_a : buffer_b;
+            out.resize((size_t)fec_size * SIZEOF_SIMD);
+            std::copy(frames_.begin() + (size_t)f * fec_size, frames_.begin() + (size_t)(f + 1) * fec_size, out.begin() + (size_t)blocks * fec_size);
+            idx_plp_simd[blocks] = plp_id;
+            if (++blocks == SIZEOF_SIMD) {
+                blocks = 0;
+                swap_buffer = !swap_buffer;
+                if (soft_multiplexer_de_twist) soft_multiplexer_de_twist(idx_plp_simd, l1_post, fec_size * SIZEOF_SIMD, out.data());
+            }
+        }
+    }
+private:
+    static int key(const t2gpu_l1_plp &p) { return p.plp_mod | (p.plp_fec_type << 4) | (p.plp_cod << 8) | (p.plp_rotation << 12) | (p.plp_num_blocks_max << 13); }
+    int device_, key_ = -1, blocks = 0;
+    t2gpu_demap *h_ = nullptr;
+    int idx_plp_simd[SIZEOF_SIMD] = {};
+    std::vector<int8_t> frames_, buffer_a, buffer_b;
+    bool swap_buffer = true;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- time de-interleaver
+class time_deinterleaver {
+public:
+    explicit time_deinterleaver(int device = 0) : device_(device) {}
+    ~time_deinterleaver() { if (h_) t2gpu_ti_destroy(h_); }
+    std::function<void(int ti_block_size, complex *time_deint_cell, int plp_id, const l1_postsignalling &)> ti_block;   // :38
+    // time_deinterleaver.h:33 (PLP 0; the L1 cells at the head of P2 are skipped as :46,296-300 does)
+    void start(const t2gpu_l1_pre &l1_pre, const l1_postsignalling &l1_post)
+    {
+        const t2gpu_l1_plp &p = l1_post.plp.at(0);
+        if (h_) t2gpu_ti_destroy(h_);
+        if (!(h_ = t2gpu_ti_create(p.plp_mod, p.plp_fec_type, p.plp_num_blocks_max, device_))) fail("t2gpu_ti_create");
+        p2_start_idx_cell = 1840 + l1_pre.l1_post_size;
+        out_.resize((size_t)p.plp_num_blocks_max * t2gpu_ti_cells_per_fec(h_));
+    }
+    void l1_dyn_execute(const l1_postsignalling &l1_post, int len_in, complex *ofdm_cell)      // :43, cpp:268-288
+    {
+        l1_post_ = l1_post;
+        if (t2gpu_ti_begin(h_, l1_post.dyn_plp.at(0).num_blocks) != 0) fail("t2gpu_ti_begin");
+        push(len_in - p2_start_idx_cell, ofdm_cell + p2_start_idx_cell);
+    }
+    void execute(int len_in, complex *ofdm_cell) { push(len_in, ofdm_cell); }                  // :45, cpp:290-376
+private:
+    void push(int n, complex *cells)
+    {
+        const int done = t2gpu_ti_push(h_, reinterpret_cast<const float *>(cells), n, reinterpret_cast<float *>(out_.data()));
+        if (done < 0) fail("t2gpu_ti_push");
+        if (done == 1 && ti_block)
+            ti_block(l1_post_.dyn_plp.at(0).num_blocks * t2gpu_ti_cells_per_fec(h_), out_.data(), 0, l1_post_);
+    }
+    int device_, p2_start_idx_cell = 0;
+    t2gpu_ti *h_ = nullptr;
+    l1_postsignalling l1_post_;
+    std::vector<complex> out_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- DSP front end
+// filter_decimator / interpolator_farrow keep their state in a front-end handle each (they are members of dvbt2_demodulator in
+// the reference, dvbt2_demodulator.h:129-130)
+class filter_decimator {
+public:
+    explicit filter_decimator(int max_len = 1 << 20, int device = 0) : h_(t2gpu_front_create(0, 64.0e6f / 7.0f, max_len, device)) { if (!h_) fail("t2gpu_front_create"); }
+    ~filter_decimator() { t2gpu_front_destroy(h_); }
+    void execute(int len_in, complex *in, int &len_out, complex *out)                      // filter_decimator.h:72
+    {
+        len_out = t2gpu_decim_execute(h_, len_in, reinterpret_cast<const float *>(in), reinterpret_cast<float *>(out));
+        if (len_out < 0) fail("t2gpu_decim_execute");
+    }
+private:
+    t2gpu_front *h_;
+};
+
+class interpolator_farrow {
+public:
+    explicit interpolator_farrow(int max_len = 1 << 20, int device = 0) : cap_(max_len), h_(t2gpu_front_create(0, 64.0e6f / 7.0f, max_len, device)) { if (!h_) fail("t2gpu_front_create"); }
+    ~interpolator_farrow() { t2gpu_front_destroy(h_); }
+    void operator()(int len_in, complex *in, double &arbitrary_resample, int &len_out, complex *out)   // interpolator_farrow.hh:41
+    {
+        len_out = t2gpu_farrow_execute(h_, len_in, reinterpret_cast<const float *>(in), arbitrary_resample, reinterpret_cast<float *>(out), 4 * cap_ + 64);
+        if (len_out < 0) fail("t2gpu_farrow_execute");
+    }
+private:
+    int cap_;
+    t2gpu_front *h_;
+};
+
+// p1_symbol (p1_symbol.h:33-37): the by-reference outputs of the reference signature, dvbt2_parameters reduced to the two
+// fields P1 sets
+class p1_symbol {
+public:
+    explicit p1_symbol(int max_len = 1 << 20, int device = 0) : h_(t2gpu_p1_create(max_len, device)) { if (!h_) fail("t2gpu_p1_create"); }
+    ~p1_symbol() { t2gpu_p1_destroy(h_); }
+    bool execute(bool gain_changed, float level_detect, const int len_in, complex *in, int &consume, complex *buffer_sym,
+                 int &idx_buffer_sym, int &preamble, int &fft_mode, double &coarse_freq_offset, bool &p1_decoded, bool &reset)
+    {
+        t2gpu_p1_result r;
+        const int rc = t2gpu_p1_execute(h_, gain_changed, level_detect, len_in, reinterpret_cast<const float *>(in), &consume, reset, &r);
+        if (rc < 0) fail("t2gpu_p1_execute");
+        if (rc == 0) return false;
+        idx_buffer_sym = r.idx_buffer_sym;
+        for (int i = 0; i < r.idx_buffer_sym; ++i) buffer_sym[i] = in[consume - r.idx_buffer_sym + i];   // p1_symbol.cpp:97
+        if (r.shift >= 0) { preamble = r.preamble; fft_mode = r.fft_mode; }
+        coarse_freq_offset = r.coarse_freq_offset;
+        p1_decoded = r.p1_decoded != 0;
+        return true;
+    }
+private:
+    t2gpu_p1 *h_;
+};
+
+// fast_fourier_transform::execute + data_symbol::execute for one symbol at a time (the reference call shape; whole frames go
+// through the *_dev entry points instead)
+class ofdm_demodulator {
+public:
+    ofdm_demodulator(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data, int device = 0)
+        : h_(t2gpu_ofdm_create(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, 1, device))
+    {
+        if (!h_) fail("t2gpu_ofdm_create");
+        int info[12];
+        t2gpu_ofdm_mode_info(fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, info);
+        fft_size = info[0]; c_data = info[6];
+        spectrum_.resize((size_t)fft_size); cells_.resize((size_t)fft_size);
+    }
+    ~ofdm_demodulator() { t2gpu_ofdm_destroy(h_); }
+    complex *fft_execute(complex *in)                                                          // fast_fourier_transform.h:62-70
+    {
+        if (t2gpu_fft_execute(h_, reinterpret_cast<const float *>(in), reinterpret_cast<float *>(spectrum_.data()), 1) != 0) fail("t2gpu_fft_execute");
+        return spectrum_.data();
+    }
+    complex *data_execute(int idx_symbol, complex *ofdm_cell, float &sample_rate_offset, float &phase_offset)   // data_symbol.h:33
+    {
+        if (t2gpu_eq_data_execute(h_, idx_symbol, reinterpret_cast<const float *>(ofdm_cell), reinterpret_cast<float *>(cells_.data()),
+                                  &sample_rate_offset, &phase_offset) < 0) fail("t2gpu_eq_data_execute");
+        return cells_.data();
+    }
+    int fft_size = 0, c_data = 0;
+private:
+    t2gpu_ofdm *h_;
+    std::vector<complex> spectrum_, cells_;
+};
+
+}  // namespace t2

@@ -1,0 +1,92 @@
+"""GPU tier: the C++ host side above the C ABI (include/t2gpu_stages.hpp -- the reference's object / slot / signal shapes in the
+reference's own language). tests/cpp/stage_mirror_test.cpp wires the classes the way the reference wires its objects with
+connect() and is fed vectors from here; what it emits is compared with the oracle. Also proves the library is usable from a
+plain C++ program with no Python / torch in the process."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import t2_tx
+
+pytestmark = pytest.mark.gpu
+ROOT = ol.ROOT
+
+
+@pytest.fixture(scope="module")
+def driver(built, tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "stage_mirror_test")
+    pkg = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "stage_mirror_test.cpp"), "-L" + pkg, "-lt2gpu",
+                           "-Wl,-rpath," + pkg, "-o", out])
+    return out
+
+
+def run(driver, *args):
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([driver] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr
+    return p.stderr
+
+
+def sig(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.2).astype(np.complex64)
+
+
+def test_decimator_and_farrow_classes(driver, tmp_path):
+    x = sig(50001, 1)
+    x.tofile(tmp_path / "in.c64")
+    run(driver, "decim", tmp_path / "in.c64", tmp_path / "dec.c64", 4097)
+    got = np.fromfile(tmp_path / "dec.c64", np.complex64)
+    o = ol.OraDecim()
+    want = np.concatenate([o(x[p:p + 4097]) for p in range(0, len(x), 4097)])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for resample in (0.5, 0.5 - 24e-9):
+        run(driver, "farrow", tmp_path / "in.c64", tmp_path / "far.c64", 10007, repr(resample))
+        got = np.fromfile(tmp_path / "far.c64", np.complex64)
+        f = ol.OraFarrow()
+        want = np.concatenate([f(x[p:p + 10007], resample) for p in range(0, len(x), 10007)])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("fec_type,cod", [(0, 0), (1, 3)])
+def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod):
+    """ldpc_decoder.bit_bch -> bch_decoder.execute -> bit_descramble, three SIMD batches, the middle one undecodable: the
+    reference prints its message and drops that batch; the other two come out descrambled, frame by frame."""
+    cid = ol.code_id(fec_type, cod)
+    n, k, _, _ = ol.ldpc_params(cid)
+    info, llr = ol.make_llr(cid, 96, 0.55 if fec_type else 0.7, 5)
+    rng = np.random.Generator(np.random.PCG64(6))
+    llr[32:64] = rng.integers(-20, 21, size=(32, n), dtype=np.int8)              # noise only: never converges
+    llr.tofile(tmp_path / "llr.i8")
+    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod)
+    assert err.count("LDPC decoder could not recover the codeword!") == 1
+    k_bch = t2_tx.K_BCH[cid]
+    got = np.fromfile(tmp_path / "out.u8", np.uint8).reshape(-1, 1 + k_bch)
+    assert got.shape[0] == 64 and (got[:, 0] == 0).all()                          # plp id of every emitted frame
+    want = []
+    for b in (0, 64):
+        t, bits, _ = ol.ora_decode(cid, llr[b:b + 32])
+        assert t >= 0
+        want.append(ol.ora_bch_descramble(cid, bits))
+    assert np.array_equal(got[:, 1:], np.concatenate(want))
+
+
+def test_p1_class(driver, tmp_path):
+    rng = np.random.Generator(np.random.PCG64(8))
+    noise = lambda n, s: ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * s).astype(np.complex64)
+    x = np.concatenate([noise(2700, 0.05), (t2_tx.p1_symbol(0, 8) * 0.3).astype(np.complex64) + noise(2048, 0.02), noise(3000, 0.05)])
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag)))
+    x.tofile(tmp_path / "p1.c64")
+    run(driver, "p1", tmp_path / "p1.c64", tmp_path / "p1.txt", repr(level))
+    hit, consume, idx_sym, preamble, fft_mode, decoded, cfo = open(tmp_path / "p1.txt").read().split()
+    r = ol.OraP1().execute(x, 0, True, level)
+    assert int(hit) == 1 and r["detected"]
+    assert (int(consume), int(idx_sym), int(preamble), int(fft_mode), int(decoded)) == \
+        (r["consume"], r["idx_buffer_sym"], r["preamble"], r["fft_mode"], r["p1_decoded"]) and int(fft_mode) == 4
+    assert abs(float(cfo) - r["coarse_freq_offset"]) < 0.5
