@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
 {
     __shared__ float sc[2048];
     __shared__ int s_first, s_stop;
+    __shared__ P1State st;                  // the detector state lives in LDS / registers during the pass, global memory only at both ends
     const int tid = threadIdx.x;
-    P1State &st = p.state[blockIdx.x];
     P1Result &res = p.result[blockIdx.x];
     const P1Window w = p.win[blockIdx.x];
     const float *corr = p.corr + w.buf_off;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
     const int N = w.len;
     int n = 0;
     if (tid == 0) {
+        st = p.state[blockIdx.x];
         res.status = 0; res.consumed = N; res.a_part_clipped = 0; s_stop = 0;
         if (p.gain_changed) { st.begin_threshold = p.level_detect * 2.0e+5f; st.end_threshold = 0.5f * st.begin_threshold; }   // :88-91
     }
@@ -121,33 +122,35 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
         for (int k = tid; k < cnt; k += 256) sc[k] = corr[n + k];
         __syncthreads();
         if (tid == 0) {
+            P1State l = st;                 // registers for the sequential stretch
             int k = 0;
             for (; k < cnt; ++k) {
-                if (st.correlation_detect) {
-                    if (++st.idx_buffer > 2048) {           // :101-104: reset_buffer() clears the correlator
-                        st.correlation_detect = 0; st.max_correlation = 0.0f; st.idx_buffer = 0;
-                        if (!(st.correlation < st.end_threshold)) {     // otherwise the reference falls into :106 with idx_buffer = 0
+                if (l.correlation_detect) {
+                    if (++l.idx_buffer > 2048) {           // :101-104: reset_buffer() clears the correlator
+                        l.correlation_detect = 0; l.max_correlation = 0.0f; l.idx_buffer = 0;
+                        if (!(l.correlation < l.end_threshold)) {     // otherwise the reference falls into :106 with idx_buffer = 0
                             res.status = 2; res.consumed = n + k; s_stop = 1;   // the caller restarts the search at this sample
                             break;
                         }
                     }
-                    if (st.correlation < st.end_threshold) {   // :106
-                        res.status = 1; res.consumed = n + k + 1; res.idx_buffer_sym = st.idx_buffer; s_stop = 1;
+                    if (l.correlation < l.end_threshold) {   // :106
+                        res.status = 1; res.consumed = n + k + 1; res.idx_buffer_sym = l.idx_buffer; s_stop = 1;
                         break;
                     }
                 }
                 const float c = sc[k];
-                st.correlation = c;
-                if (c > st.begin_threshold) {
-                    st.correlation_detect = 1;
-                    if (c > st.max_correlation) {
-                        st.max_correlation = c;
+                l.correlation = c;
+                if (c > l.begin_threshold) {
+                    l.correlation_detect = 1;
+                    if (c > l.max_correlation) {
+                        l.max_correlation = c;
                         const float2 o = outv[n + k];
-                        st.arg_max_re = o.x; st.arg_max_im = o.y;
-                        st.idx_buffer = 0;
+                        l.arg_max_re = o.x; l.arg_max_im = o.y;
+                        l.idx_buffer = 0;
                     }
-                } else if (!st.correlation_detect) { ++k; break; }   // back to the parallel skip
+                } else if (!l.correlation_detect) { ++k; break; }   // back to the parallel skip
             }
+            st = l;
             s_first = k;
         }
         __syncthreads();
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
         const int fed = res.status == 1 ? res.consumed - 1 : res.consumed;
         st.idx_fq_shift = (st.idx_fq_shift + fed) & 1023;
         res.max_correlation = st.max_correlation; res.arg_max_re = st.arg_max_re; res.arg_max_im = st.arg_max_im;
+        p.state[blockIdx.x] = st;
     }
 }
 
