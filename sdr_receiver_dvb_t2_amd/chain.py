@@ -99,6 +99,12 @@ class t2_chain(object):
         if o.l_fc:                                               # frame-closing symbol: its n_fc cells end the frame's stream
             fc, _ = o.eq_fc_dev(spec[:, 1 + nd].contiguous(), want_sync=False)
             self.cells[:F, a + nd * o.c_data:] = fc
+        return self.demod_cells_dev(F, flush)
+
+    def demod_cells_dev(self, F, flush=False):
+        """From the equalised, frequency-de-interleaved cells of F frames already in self.cells[:F] (PLP cells of P2, then of every
+        data symbol, then of the frame-closing symbol) to descrambled BBFRAME bits."""
+        torch = self.torch
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
             self.ti[f].l1_dyn(self.num_blocks)

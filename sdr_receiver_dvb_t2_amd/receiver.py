@@ -28,7 +28,7 @@ class t2_receiver(object):
         self.max_frames = max_frames
         n_max = max_frames * self.frame_len + 4096
         self.front = front_end(id_device=id_device, sample_rate=sample_rate, max_samples=n_max, device=device)
-        self.p1 = p1_symbol(max_samples=max_frames * 4096, device=device)
+        self.p1 = p1_symbol(max_samples=max(max_frames * 4096, 2 * self.sym_size + 8192), device=device)
         self.stream = torch.zeros(n_max + 64, dtype=torch.complex64, device=self.chain.dev)
         self.search = P1_LEN + 1024                                                    # samples searched from each frame start
 
@@ -64,3 +64,121 @@ class t2_receiver(object):
                                                   torch.cuda.current_stream().cuda_stream), "t2gpu_cp_correlate_stream_dev")
         bits, trials = self.chain.demod_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, n_frames, flush)
         return dict(bits=bits, trials=trials, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
+
+
+class t2_closed_loop(object):
+    """The reference's own operating mode: ``dvbt2_demodulator::execute`` + ``symbol_acquisition`` symbol by symbol, every
+    tracking loop closed (src/DVB_T2/dvbt2_demodulator.cpp:145-254,267-448) -- chunk sizing from est_chunk (:151-163), P1 search
+    with carried correlator state, guard-interval frequency loop once L1-pre has passed its CRC (:321-330), phase PI loop and
+    the bang-bang sample-rate tracker from the equalisers' pilot sums (:429-439), Farrow ratio and NCO values fed back into the
+    next chunk. Compute is the same C-ABI stages as the batch receiver, one symbol per call; the state machine is host code as in
+    the reference. The tuner the reference re-tunes when P1 reports >= 10 Hz (:291-305) is emulated by an extra NCO term."""
+
+    def __init__(self, rx):
+        self.rx = rx
+        self.torch = rx.torch
+        from .front import sync_loops
+        self.sync = sync_loops()
+        c, o = rx.chain, rx.chain.ofdm
+        self.sym_size = rx.sym_size
+        dev = c.dev
+        self.buffer_sym = self.torch.zeros(self.sym_size + 8, dtype=self.torch.complex64, device=dev)
+        self.out = self.torch.zeros(2 * (self.sym_size + 4096), dtype=self.torch.complex64, device=dev)
+        self.spec = self.torch.zeros((1, o.fft_size, 2), dtype=self.torch.float32, device=dev)
+        self.next_symbol_type = "P1"
+        self.est_chunk = 0
+        self.idx_buffer_sym = 0
+        self.idx_symbol = 0
+        self.crc32_l1_pre = False
+        self.tuner = 0.0                      # rad/sample, the emulated re-tune
+        self.cell_pos = 0
+        self.log = []                         # (symbol type, frequency_est_filtered, phase_est_filtered, resample) per symbol
+        self.p1_seen = 0
+        self.l1 = None
+        self.level_detect = None              # set by the caller when the AGC has settled (signal_->gain_changed, :283); else the
+                                              # front end's own estimate of the previous buffer is used
+        rx.front.reset()
+        rx.p1.reset()
+
+    def execute(self, d_i, d_q, level_gain_changed=True):
+        """d_i, d_q: int16 device tensors (one execute() buffer). Returns the list of (bits, trials) of the frames completed."""
+        torch = self.torch
+        rx, c, o = self.rx, self.rx.chain, self.rx.chain.ofdm
+        from .l1 import l1_pre_info, l1_post_info
+        len_in = d_i.numel() // rx.front.stride
+        idx_in, done = 0, []
+        level = self.level_detect if self.level_detect is not None else float(rx.front.state()["level_detect"])
+        while idx_in < len_in:
+            if self.est_chunk == 0:                                                      # :151-155
+                self.est_chunk = (2048 if self.next_symbol_type == "P1" else 0) + self.sym_size
+            g = self.sync.get()
+            resample = g["arbitrary_resample"]
+            chunk = min(int(np.rint(self.est_chunk * resample * 2)), len_in - idx_in)    # :160-162
+            s = rx.front.stride
+            n_out, _ = rx.front.execute_dev(d_i[idx_in * s:], d_q[idx_in * s:], [chunk], self.out, [g["phase_est_filtered"]],
+                                            [np.float32(g["frequency_est_filtered"] + np.float32(self.tuner))], [resample])
+            idx_in += chunk
+            # ---- symbol_acquisition (:267-448)
+            consume = 0
+            while consume < n_out:
+                if self.next_symbol_type == "P1":
+                    det, consume, r = rx.p1.execute_dev(self.out[:n_out], consume, level_gain_changed, level)
+                    if det:
+                        self.p1_seen += 1
+                        k = r.idx_buffer_sym
+                        self.buffer_sym[:k] = self.out[consume - k:consume]              # p1_symbol.cpp:97
+                        self.idx_buffer_sym = k
+                        if abs(r.coarse_freq_offset) >= 10.0 and not self.crc32_l1_pre:  # :291-305: ask the tuner, wait for the next P1
+                            self.tuner += 2.0 * np.pi * r.coarse_freq_offset / (64.0e6 / 7.0)
+                            self.idx_buffer_sym = 0
+                        else:
+                            self.next_symbol_type = "P2"
+                    continue
+                n = min(n_out - consume, self.sym_size - self.idx_buffer_sym)
+                self.buffer_sym[self.idx_buffer_sym:self.idx_buffer_sym + n] = self.out[consume:consume + n]
+                consume += n
+                self.idx_buffer_sym += n
+                if self.idx_buffer_sym < self.sym_size:
+                    self.est_chunk = self.sym_size - self.idx_buffer_sym                 # :339
+                    continue
+                self.idx_buffer_sym = 0
+                if self.crc32_l1_pre:                                                    # :321-330
+                    cp = cp_correlate_dev(self.buffer_sym[:self.sym_size].reshape(1, -1), o.fft_size, o.guard_interval_size)
+                    self.sync.frequency(float(cp[0, 2]), o.fft_size)
+                o.fft_stream_dev(self.buffer_sym, o.guard_interval_size, 0, 1, self.sym_size, 1, out=self.spec)   # :332-334
+                self.est_chunk = 0
+                kind = self.next_symbol_type
+                if kind == "P2":
+                    self.idx_symbol = 0
+                    cells, sync = o.eq_p2_dev(self.spec)
+                    host = cells[0].cpu().numpy().view(np.complex64).reshape(-1)
+                    ok, pre = l1_pre_info(host)
+                    self.crc32_l1_pre = bool(ok)
+                    if ok:
+                        okp, post, plp, dyn = l1_post_info(host, pre)
+                        self.l1 = (pre, post, plp, dyn) if okp else None
+                    c.cells[0, :o.c_p2 - c.p2_skip] = cells[0, c.p2_skip:]
+                    self.cell_pos = o.c_p2 - c.p2_skip
+                    self.idx_symbol = 1
+                    self.next_symbol_type = "DATA"
+                elif kind == "DATA":
+                    cells, sync = o.eq_data_dev(self.spec, torch.tensor([self.idx_symbol], dtype=torch.int32, device=c.dev))
+                    c.cells[0, self.cell_pos:self.cell_pos + o.c_data] = cells[0]
+                    self.cell_pos += o.c_data
+                    self.idx_symbol += 1
+                    if self.idx_symbol == o.n_p2 + c.n_dat:
+                        self.next_symbol_type = "FC" if o.l_fc else "P1"
+                else:
+                    cells, sync = o.eq_fc_dev(self.spec)
+                    c.cells[0, self.cell_pos:self.cell_pos + o.n_fc] = cells[0]
+                    self.cell_pos += o.n_fc
+                    self.next_symbol_type = "P1"
+                sv = sync[0].cpu().numpy()
+                self.sync.symbol(float(sv[0]), float(sv[1]))                              # :429-439
+                g2 = self.sync.get()
+                self.log.append((kind, float(g2["frequency_est_filtered"]), float(g2["phase_est_filtered"]), g2["arbitrary_resample"]))
+                if self.next_symbol_type == "P1" and kind != "P1":                       # frame complete: hand the cells on (emit data)
+                    if self.crc32_l1_pre:
+                        bits, trials = c.demod_cells_dev(1, flush=True)
+                        done.append((bits.clone(), trials.clone()))                      # the chain reuses its output buffers
+        return done

@@ -118,7 +118,7 @@ def plp_blocks_per_frame(m, l1_post_size, cells_per_fec):
     return cells // cells_per_fec
 
 
-def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0):
+def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0, l1_cells=None):
     """One T2 frame after guard-interval removal: returns complex64 [len_frame][fft_size] time-domain symbols.
     plp_stream: the PLP's cells in transmission order (time-interleaver output); it fills the P2 symbol behind the L1 cells
     and then the data symbols; the remainder of the last symbol is padded with dummy cells."""
@@ -136,7 +136,11 @@ def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0):
         h = ho if l % 2 == 0 else he
         ncell = [m.c_p2, m.c_data, m.n_fc][kind]
         if kind == 0:
-            l1 = (1 - 2 * rng.integers(0, 2, L1_PRE_CELLS + l1_post_size)).astype(np.complex128)     # BPSK filler
+            if l1_cells is not None:                                     # real L1-pre + L1-post cells (l1_pre_cells / l1_post_cells)
+                l1 = np.asarray(l1_cells, np.complex128)
+                assert l1.size == L1_PRE_CELLS + l1_post_size
+            else:
+                l1 = (1 - 2 * rng.integers(0, 2, L1_PRE_CELLS + l1_post_size)).astype(np.complex128)     # BPSK filler
             take = ncell - l1.size
             sym_cells = np.concatenate([l1, stream[pos:pos + take]])
         else:

@@ -67,3 +67,70 @@ def test_iq_to_ts(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, sa
     matched = sum(bytes(p) in sp for p in got[:n].reshape(-1, 188))
     assert matched >= n_frames * per_frame - 1 and n // 188 - matched <= 2, (matched, n // 188, per_frame)
     rx.close()
+
+
+def test_closed_loop_tracks_cfo_and_decodes(torch_cuda):
+    """Symbol-by-symbol operation with every tracking loop closed, on a 16K frame structure with a frame-closing symbol: a
+    100 Hz carrier offset (0.18 carrier spacings) and a static phase. P1 reports the offset frame after frame -- the reference's
+    estimate is (deliberately or not) a fraction of the true value, :21,115, so the emulated tuner converges geometrically, as
+    the real one does -- until it is below 10 Hz; then L1-pre/L1-post pass their CRCs, the guard-interval loop removes the
+    residue, the phase loop and the sample-rate tracker run, and the transport stream of the frames after acquisition comes back."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_receiver, t2_closed_loop
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 1, 2, 0, 24), 400, 1, 0, 1, 12.0, 8
+    n_frames, seed, cfo_hz = 7, 91, 100.0        # L1-post in BPSK: the reference takes hard decisions of the systematic bits (no L1 FEC)
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
+    pre = dict(type=0, bwt_ext=mode[1], s1=0, s2_field1=4, guard_interval=mode[3], papr=0, l1_post_mod=0, l1_cod=0, l1_fec_type=0,
+               l1_post_size=lps, pilot_pattern=mode[2], num_t2_frames=2, num_data_symbols=mode[5], num_rf=1, t2_version=2)
+    plp = [dict(id=0, plp_type=1, plp_cod=code_rate, plp_mod=mod, plp_rotation=1, plp_fec_type=fec_type, plp_num_blocks_max=nb,
+                frame_interval=1, time_il_length=1, time_il_type=0, plp_mode=1)]
+    info = t2_tx.l1_post_bits(dict(), plp, [dict(id=0, start=0, num_blocks=nb)])
+    pre["l1_post_info_size"] = len(info)
+    l1c = np.concatenate([t2_tx.l1_pre_cells(pre, 3), t2_tx.l1_post_cells(info, 0, lps, 4)])
+    frames, bbframes = [], []
+    for f in range(n_frames):
+        cells, bb, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, f * nb, nb, k_bch), nb)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c))
+        bbframes.append(np.asarray(bb).reshape(nb, -1))
+    rx = t2_receiver((*mode, lps, mod, fec_type, code_rate, 1, nb), dict(), max_frames=1)
+    i16, q16, flen = t2_tx.iq_stream(frames, rx.chain.ofdm.guard_interval_size, s2, snr, seed)
+    x = (i16.astype(np.float64) + 1j * q16.astype(np.float64)) * np.exp(1j * (2 * np.pi * cfo_hz / (64e6 / 7) * np.arange(len(i16)) + 0.7))
+    i16, q16 = np.rint(x.real).astype(np.int16), np.rint(x.imag).astype(np.int16)
+    tail = np.zeros(8192, np.int16)
+    d_i, d_q = torch.from_numpy(np.concatenate([i16, tail])).cuda(), torch.from_numpy(np.concatenate([q16, tail])).cuda()
+    cl = t2_closed_loop(rx)
+    rx.front.execute_dev(d_i[:65536], d_q[:65536], [65536], torch.zeros(65600, dtype=torch.complex64, device="cuda"))   # a buffer to
+    # settle level_detect (the AGC window of dvbt2_demodulator.cpp:235-251), as at start-up
+    cl.level_detect = float(rx.front.state()["level_detect"])
+    assert 0.01 < cl.level_detect < 0.08
+    rx.front.reset()
+    done = []
+    step = 1 << 18                                                         # execute() buffers of 262144 samples
+    for a in range(0, d_i.numel(), step):
+        done += cl.execute(d_i[a:a + step], d_q[a:a + step], level_gain_changed=(a == 0))
+    assert cl.p1_seen == n_frames
+    hz = (64e6 / 7) / (2 * np.pi)
+    assert abs(cl.tuner * hz - cfo_hz) < 30.0                                # the tuner stops once P1 REPORTS < 10 Hz (~0.4 x true)
+    assert cl.l1 is not None and cl.l1[0].guard_interval == mode[3] and cl.l1[0].pilot_pattern == mode[2]
+    assert cl.l1[2][0].plp_mod == mod and cl.l1[2][0].plp_cod == code_rate and cl.l1[3][0].num_blocks == nb
+    assert abs((cl.tuner + cl.log[-1][1]) * hz - cfo_hz) < 1.0               # tuner + guard-interval loop settle on the offset
+    assert {k for k, *_ in cl.log} == {"P2", "DATA", "FC"}
+    assert 2 <= len(done) <= n_frames - 2                                    # the first frames went into acquisition (P1 -> tuner)
+    first = n_frames - len(done)
+    dfl_bytes = (k_bch - 80) // 8
+    per_frame = (nb * dfl_bytes) // 187 - 1
+    for f, (bits, trials) in enumerate(done, start=first):
+        t = trials.cpu().numpy()
+        assert (t >= 0).all(), (f, t)
+        b = bits.cpu().numpy()
+        assert np.array_equal(b[:, :k_bch], bbframes[f][:, :k_bch]), f          # every BBFRAME of the frame, bit for bit
+        if f == first:                                                           # and as transport stream (the transmitter model
+            got = rx.chain.ts_from_bits(b, t)                                    # restarts on a packet boundary every frame, so only
+            sent = ts_slice(ts, f * nb, nb, k_bch).reshape(-1)                   # the first frame lines up with a fresh de-framer)
+            assert np.array_equal(got[:per_frame * 188], sent[:per_frame * 188])
+    rx.close()
