@@ -84,7 +84,11 @@ class t2_chain(object):
 
     def demod_spectrum_dev(self, spec, flush=False):
         """spec: CUDA float32 [F][n_sym][fft_size][2], the fft-shifted spectra of whole frames."""
-        torch = self.torch
+        F = self.spectrum_to_cells(spec)
+        return self.demod_cells_dev(F, flush)
+
+    def spectrum_to_cells(self, spec):
+        """Equalisers + frequency de-interleavers: fills self.cells[:F] with the PLP cells of every frame; returns F."""
         o = self.ofdm
         F = spec.shape[0]
         # P2: equalise, drop the L1 cells, PLP cells go to the head of the frame's cell stream
@@ -99,7 +103,7 @@ class t2_chain(object):
         if o.l_fc:                                               # frame-closing symbol: its n_fc cells end the frame's stream
             fc, _ = o.eq_fc_dev(spec[:, 1 + nd].contiguous(), want_sync=False)
             self.cells[:F, a + nd * o.c_data:] = fc
-        return self.demod_cells_dev(F, flush)
+        return F
 
     def demod_cells_dev(self, F, flush=False):
         """From the equalised, frequency-de-interleaved cells of F frames already in self.cells[:F] (PLP cells of P2, then of every
@@ -110,9 +114,8 @@ class t2_chain(object):
             self.ti[f].l1_dyn(self.num_blocks)
             done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
             assert done
-            llr, _ = self.demap.execute_dev(self.ti_out[f])
             a = self.carry + f * self.num_blocks
-            self.llr[a:a + self.num_blocks] = llr
+            self.demap.execute_dev(self.ti_out[f], out=self.llr[a:a + self.num_blocks])
         total = self.carry + F * self.num_blocks
         ready = total if flush else (total // self.group) * self.group
         if ready == 0:
@@ -131,6 +134,32 @@ class t2_chain(object):
             self.llr[:rest] = self.llr[ready:total].clone()
         self.carry = rest
         return out, trials
+
+    # ---- the same in two halves for a two-stream software pipeline (whole frames, every FEC frame decoded: flush semantics):
+    # stage_llr = time de-interleaver + demapper into LLR buffer `slot`; stage_fec = LDPC + descrambler from that buffer
+    def stage_llr(self, F, slot):
+        torch = self.torch
+        if not hasattr(self, "llr2"):
+            self.llr2 = [self.llr, torch.empty_like(self.llr)]
+        assert self.carry == 0
+        n_ti = self.num_blocks * self.cells_per_fec
+        for f in range(F):
+            self.ti[f].l1_dyn(self.num_blocks)
+            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
+            assert done
+            self.demap.execute_dev(self.ti_out[f], out=self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
+        return F * self.num_blocks
+
+    def stage_fec(self, count, slot):
+        torch = self.torch
+        if self.time_ldpc:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        bits, trials = self.ldpc.execute_dev(self.llr2[slot][:count])
+        if self.time_ldpc:
+            e1.record()
+            self.ldpc_events.append((e0, e1, count))
+        return self.bch.execute_dev(bits), trials
 
     def ts_from_bits(self, bits_host, trials_host):
         """BBFRAME bits of decoded FEC frames -> TS bytes; SIMD batches the LDPC gave up on (-1) are dropped as the

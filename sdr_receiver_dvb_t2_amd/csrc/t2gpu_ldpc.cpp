@@ -135,6 +135,10 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     const int nbatches = (n_frames + group - 1) / group;
     int maxslots = resident_blocks(h) / group;
     if (maxslots < 1) { set_error("device cannot keep one batch resident"); return -1; }
+    if (const char *lim = std::getenv("T2GPU_LDPC_MAX_SLOTS")) {              // experiments: leave part of the device to other streams
+        const int v = std::atoi(lim);
+        if (v >= 1 && v < maxslots) maxslots = v;
+    }
     int nslots = nbatches < maxslots ? nbatches : maxslots;
     int grid = nslots * group;
     if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }

@@ -36,13 +36,16 @@ class llr_demapper(object):
 
     __del__ = close
 
-    def execute_dev(self, cells, precision_override=0.0):
-        """cells: CUDA float32 [n_cells, 2] (re, im). Returns (llr int8 [n_frames, fec_size], sums float32[3])."""
+    def execute_dev(self, cells, precision_override=0.0, out=None):
+        """cells: CUDA float32 [n_cells, 2] (re, im). Returns (llr int8 [n_frames, fec_size], sums float32[3]); `out`: write the
+        LLR frames there instead of a fresh tensor."""
         import torch
         assert cells.is_cuda and cells.dtype == torch.float32 and cells.is_contiguous()
         n_cells = cells.numel() // 2
         n_frames = n_cells // self.cells_per_fec
-        llr = torch.empty((n_frames, self.fec_size), dtype=torch.int8, device=cells.device)
+        if out is not None:
+            assert out.is_contiguous() and out.dtype == torch.int8 and out.numel() == n_frames * self.fec_size
+        llr = out if out is not None else torch.empty((n_frames, self.fec_size), dtype=torch.int8, device=cells.device)
         sums = torch.empty((3,), dtype=torch.float32, device=cells.device)
         stream = torch.cuda.current_stream(cells.device).cuda_stream
         rc = self._l.t2gpu_demap_execute_dev(self._h, cells.data_ptr(), n_cells, float(precision_override), llr.data_ptr(),

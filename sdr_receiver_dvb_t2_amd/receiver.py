@@ -37,7 +37,7 @@ class t2_receiver(object):
         self.front.close()
         self.p1.close()
 
-    def demod_iq_dev(self, d_i, d_q, n_frames, level_detect=None, first_call=True, flush=False, loops=None):
+    def demod_iq_dev(self, d_i, d_q, n_frames, level_detect=None, first_call=True, flush=False, loops=None, pipeline_slot=None):
         """d_i, d_q: int16 device tensors holding n_frames whole frames starting at a P1 symbol (stride 2 for AirSpy).
         Returns dict(bits, trials, p1 results, P2 start per frame, guard-correlation estimates [frames][symbols][4])."""
         torch = self.torch
@@ -62,8 +62,44 @@ class t2_receiver(object):
         check(lib().t2gpu_cp_correlate_stream_dev(self.stream.data_ptr(), first, self.frame_len, self.chain.n_sym, n_frames * self.chain.n_sym,
                                                   o.fft_size, o.guard_interval_size, cp.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream), "t2gpu_cp_correlate_stream_dev")
-        bits, trials = self.chain.demod_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, n_frames, flush)
-        return dict(bits=bits, trials=trials, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
+        if pipeline_slot is None:
+            bits, trials = self.chain.demod_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, n_frames, flush)
+            return dict(bits=bits, trials=trials, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
+        c = self.chain
+        spec = o.fft_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, c.n_sym, o.fft_size + o.guard_interval_size,
+                                n_frames * c.n_sym)
+        c.spectrum_to_cells(spec.reshape(n_frames, c.n_sym, o.fft_size, 2))
+        count = c.stage_llr(n_frames, pipeline_slot)
+        return dict(count=count, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, c.n_sym, 4))
+
+    # ---- two-stream software pipeline: everything up to the LLRs of buffer k+1 (HBM-bound streaming kernels) runs on one
+    # stream while the LDPC of buffer k (VALU/LDS-bound, persistent workgroups) runs on another; LLR buffers alternate.
+    def pipeline_step(self, d_i, d_q, n_frames, level_detect, first_call=False):
+        torch = self.torch
+        if not hasattr(self, "_pipe"):
+            self._pipe = dict(sa=torch.cuda.Stream(device=self.chain.dev), sb=torch.cuda.Stream(device=self.chain.dev), k=0,
+                              llr_ready=[torch.cuda.Event(), torch.cuda.Event()], fec_done=[None, None])
+        pp = self._pipe
+        slot = pp["k"] % 2
+        pp["k"] += 1
+        with torch.cuda.stream(pp["sa"]):
+            if pp["fec_done"][slot] is not None:
+                pp["sa"].wait_event(pp["fec_done"][slot])                       # the LDPC that read this LLR buffer two steps ago
+            a = self.demod_iq_dev(d_i, d_q, n_frames, level_detect=level_detect, first_call=first_call, pipeline_slot=slot)
+            pp["llr_ready"][slot].record(pp["sa"])
+        with torch.cuda.stream(pp["sb"]):
+            pp["sb"].wait_event(pp["llr_ready"][slot])
+            bits, trials = self.chain.stage_fec(a["count"], slot)
+            ev = torch.cuda.Event()
+            ev.record(pp["sb"])
+            pp["fec_done"][slot] = ev
+        a.update(bits=bits, trials=trials)
+        return a
+
+    def pipeline_sync(self):
+        if hasattr(self, "_pipe"):
+            self._pipe["sa"].synchronize()
+            self._pipe["sb"].synchronize()
 
 
 class t2_closed_loop(object):
