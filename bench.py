@@ -151,10 +151,11 @@ def main():
     chain = rx.chain
     r0 = rx.demod_iq_dev(d_i, d_q, F, first_call=True, flush=True)                    # thresholds from the level estimate
     level = float(rx.front.state()["level_detect"])
-    # Steps are software-pipelined over two HIP streams (receiver.pipeline_step): the streaming stages of step k+1 (front end ..
-    # demapper, HBM-bound) overlap the LDPC of step k (VALU/LDS-bound, persistent workgroups); every step enqueues both halves
-    # of its own buffer, so K timed steps contain exactly K x the whole chain.
-    for _ in range(max(args.warmup, 1)):
+    # Steps are software-pipelined over four HIP streams (receiver.pipeline_step): while the LDPC of buffer k-1 runs (VALU/LDS-
+    # bound, persistent workgroups holding the CUs' LDS) the LDS-free streaming stages of buffers k and k+1 run beside it, the
+    # 32K FFT and the demapper's LLR pass take the gap between two decodes. Every call enqueues the front half of a new buffer
+    # and the back half of the previous one, so K timed calls contain exactly K x the whole chain.
+    for _ in range(max(args.warmup, 1) + 1):
         r0 = rx.pipeline_step(d_i, d_q, F, level)
     rx.pipeline_sync()
     torch.cuda.synchronize(dev)
@@ -191,7 +192,7 @@ def main():
         ok = bool((t2h >= 0).all()) and bool(np.array_equal(got[:npk * 188], want[:npk * 188]))
         c3 = make_rx(True, F)
         c3.demod_iq_dev(d_i, d_q, F, flush=True)
-        for _ in range(2):
+        for _ in range(3):
             c3.pipeline_step(d_i, d_q, F, level)
         c3.pipeline_sync()
         tc0 = time.perf_counter()
@@ -217,8 +218,8 @@ def main():
             "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames, from int16 I/Q at the "
                                    "dvbt2_demodulator::execute boundary; stages on GPU: front end (dc, IQ imbalance, NCO, Farrow x2, "
                                    "64-tap decimator), P1 detect, guard correlation, FFT, P2+data equaliser/freq-deint, TI/cell-deint, "
-                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; steps software-pipelined over two HIP "
-                                   "streams (streaming stages of step k+1 overlap the LDPC of step k); "
+                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; steps software-pipelined over four HIP "
+                                   "streams (LDS-free streaming stages beside the LDPC of the previous buffer, FFT and LLR pass between decodes); "
                                    "reference arithmetic incl. the wrapping int8 LLR cast, so %d of %d SIMD batches run all trials and "
                                    "are dropped as the reference would; L1 parsing and TS de-framing (host code) are not inside the "
                                    "timed region (%d samples per frame)"

@@ -90,6 +90,10 @@ int t2gpu_demap_configure(t2gpu_demap *h, int saturate);
 int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, int8_t *d_llr,
                             float *d_sums3 /* 3 floats on the device, or NULL */, void *stream);
 int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3 /* or NULL */);
+/* t2gpu_demap_execute_dev as two enqueues -- the statistics pass (sum_s, sum_e, LLR scale -> d_sums3) and the LLR pass that reads
+ * them -- so that a multi-stream scheduler can place them separately; calling one after the other equals execute_dev. */
+int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, float *d_sums3, void *stream);
+int t2gpu_demap_llr_dev(t2gpu_demap *h, const float *d_cells, int n_cells, const float *d_sums3, int8_t *d_llr, void *stream);
 
 /* ---------------------------------------------------------------- time / cell de-interleaver ----------------------
  * Replaces  void time_deinterleaver::execute(int len, complex* cells) / l1_dyn_execute(l1_post, len, cells)

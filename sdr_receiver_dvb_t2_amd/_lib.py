@@ -37,6 +37,8 @@ PROTOTYPES = {
     "t2gpu_demap_configure": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demap_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp]),
     "t2gpu_demap_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_demap_stats_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
+    "t2gpu_demap_llr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_ti_create": (_vp, [ctypes.c_int] * 4),
     "t2gpu_ti_destroy": (None, [_vp]),
     "t2gpu_ti_cells_per_fec": (ctypes.c_int, [_vp]),

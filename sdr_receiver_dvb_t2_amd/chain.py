@@ -150,6 +150,25 @@ class t2_chain(object):
             self.demap.execute_dev(self.ti_out[f], out=self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
         return F * self.num_blocks
 
+    # finer stages for the four-stream schedule of receiver.pipeline_step (single LLR buffer: slot 0)
+    def stage_ti_stats(self, F):
+        torch = self.torch
+        if not hasattr(self, "llr2"):
+            self.llr2 = [self.llr, torch.empty_like(self.llr)]
+        if not hasattr(self, "sums"):
+            self.sums = torch.zeros((self.max_frames, 4), dtype=torch.float32, device=self.dev)
+        n_ti = self.num_blocks * self.cells_per_fec
+        for f in range(F):
+            self.ti[f].l1_dyn(self.num_blocks)
+            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
+            assert done
+            self.demap.stats_dev(self.ti_out[f], self.sums[f])
+
+    def stage_llr_only(self, F, slot=0):
+        for f in range(F):
+            self.demap.llr_dev(self.ti_out[f], self.sums[f], self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
+        return F * self.num_blocks
+
     def stage_fec(self, count, slot):
         torch = self.torch
         if self.time_ldpc:

@@ -124,6 +124,27 @@ extern "C" int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int
     return n_frames;
 }
 
+// The two passes of the demapper as separate enqueues (same kernels, same results): a scheduler can then put the statistics pass
+// (no LDS to speak of) beside another stream's work and the LLR pass (one FEC frame staged in LDS) where a CU is free.
+extern "C" int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, float *d_sums3,
+                                     void *stream)
+{
+    if (!h || !d_cells || !d_sums3 || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_stats_dev: bad arguments"); return -1; }
+    const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;
+    const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
+    T2_HIP(launch_demap_stats(h->p, reinterpret_cast<const float2 *>(d_cells), n_snr, h->d_partial, blocks, d_sums3, precision_override,
+                              (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int t2gpu_demap_llr_dev(t2gpu_demap *h, const float *d_cells, int n_cells, const float *d_sums3, int8_t *d_llr, void *stream)
+{
+    if (!h || !d_cells || !d_sums3 || !d_llr || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_llr_dev: bad arguments"); return -1; }
+    const int n_frames = n_cells / h->p.cells_per_fec;
+    if (n_frames > 0) T2_HIP(launch_demap_llr(h->p, reinterpret_cast<const float2 *>(d_cells), n_frames, d_sums3, d_llr, (hipStream_t)stream));
+    return n_frames;
+}
+
 extern "C" int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3)
 {
     if (!h || !cells || !llr || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_execute: bad arguments"); return -1; }

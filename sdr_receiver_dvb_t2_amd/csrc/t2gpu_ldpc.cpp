@@ -4,6 +4,7 @@
 #include "ldpc_graph.h"
 #include "ldpc_kernel.h"
 #include "t2gpu_common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -157,7 +158,28 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.lds_sign_offset = h->lds_sign_offset;
     p.prof = h->d_prof;
     if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long), s));
-    T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
+    // One persistent launch walks all batches (best when batches take different numbers of sweeps). T2GPU_LDPC_ROUNDS_PER_LAUNCH=r
+    // cuts it into launches of r rounds of `nslots` batches: workgroups of other streams that need a whole CU's LDS (the 32K FFT)
+    // then get in at the launch boundaries instead of waiting for the whole decode.
+    int rounds = 0;
+    if (const char *r = std::getenv("T2GPU_LDPC_ROUNDS_PER_LAUNCH")) rounds = std::atoi(r);
+    if (rounds < 1 || (long)rounds * nslots >= nbatches) {
+        T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
+        return 0;
+    }
+    for (int b0 = 0; b0 < nbatches; b0 += rounds * nslots) {
+        const int nb = std::min(rounds * nslots, nbatches - b0);
+        const int f0 = b0 * group, nf = std::min(nb * group, n_frames - f0);
+        LdpcKernelParams q = p;
+        q.llr = d_llr + (size_t)f0 * h->g.n;
+        q.n_frames = nf;
+        q.bits = d_bits ? d_bits + (size_t)f0 * h->g.k : nullptr;
+        q.llr_out = d_llr_out ? d_llr_out + (size_t)f0 * h->g.n : nullptr;
+        q.trials_left = d_trials_left + b0;
+        q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
+        const int slots = std::min(nslots, nb);
+        T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
+    }
     return 0;
 }
 

@@ -54,6 +54,22 @@ class llr_demapper(object):
             check(rc, "t2gpu_demap_execute_dev")
         return llr, sums
 
+    def stats_dev(self, cells, sums, precision_override=0.0):
+        """First pass only: sum_s, sum_e and the LLR scale of this TI block into the float32[3] device tensor `sums`."""
+        import torch
+        rc = self._l.t2gpu_demap_stats_dev(self._h, cells.data_ptr(), cells.numel() // 2, float(precision_override), sums.data_ptr(),
+                                           torch.cuda.current_stream(cells.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_demap_stats_dev")
+
+    def llr_dev(self, cells, sums, out):
+        """Second pass only: LLR frames into `out` with the statistics `sums` of stats_dev."""
+        import torch
+        rc = self._l.t2gpu_demap_llr_dev(self._h, cells.data_ptr(), cells.numel() // 2, sums.data_ptr(), out.data_ptr(),
+                                         torch.cuda.current_stream(cells.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_demap_llr_dev")
+
     def execute(self, ti_block_size, time_deint_cell):
         """Reference call shape on host buffers; returns (llr [n_frames][fec_size], (sum_s, sum_e, precision))."""
         cells = np.ascontiguousarray(time_deint_cell, dtype=np.complex64).reshape(-1)[:ti_block_size]

@@ -31,13 +31,16 @@ class t2_receiver(object):
         self.p1 = p1_symbol(max_samples=max(max_frames * 4096, 2 * self.sym_size + 8192), device=device)
         self.stream = torch.zeros(n_max + 64, dtype=torch.complex64, device=self.chain.dev)
         self.search = P1_LEN + 1024                                                    # samples searched from each frame start
+        # the batch form places every frame's FFT windows from the first frame's P1 position; the P1 arg-max jitters by a few
+        # samples with noise, which the guard interval absorbs
+        self.timing_slack = min(16, max(2, o.guard_interval_size // 8))
 
     def close(self):
         self.chain.close()
         self.front.close()
         self.p1.close()
 
-    def demod_iq_dev(self, d_i, d_q, n_frames, level_detect=None, first_call=True, flush=False, loops=None, pipeline_slot=None):
+    def demod_iq_dev(self, d_i, d_q, n_frames, level_detect=None, first_call=True, flush=False, loops=None):
         """d_i, d_q: int16 device tensors holding n_frames whole frames starting at a P1 symbol (stride 2 for AirSpy).
         Returns dict(bits, trials, p1 results, P2 start per frame, guard-correlation estimates [frames][symbols][4])."""
         torch = self.torch
@@ -54,7 +57,7 @@ class t2_receiver(object):
         if (p2_start < 0).any():
             raise RuntimeError("P1 not found in %d of %d frames" % (int((p2_start < 0).sum()), n_frames))
         first = int(p2_start[0])
-        if np.abs(p2_start - (first + starts)).max() > 2:
+        if np.abs(p2_start - (first + starts)).max() > self.timing_slack:
             raise RuntimeError("frames are not equally spaced: P2 starts %s" % p2_start)
         o = self.chain.ofdm
         cp = torch.empty((n_frames * self.chain.n_sym, 4), dtype=torch.float32, device=self.chain.dev)
@@ -62,44 +65,102 @@ class t2_receiver(object):
         check(lib().t2gpu_cp_correlate_stream_dev(self.stream.data_ptr(), first, self.frame_len, self.chain.n_sym, n_frames * self.chain.n_sym,
                                                   o.fft_size, o.guard_interval_size, cp.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream), "t2gpu_cp_correlate_stream_dev")
-        if pipeline_slot is None:
-            bits, trials = self.chain.demod_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, n_frames, flush)
-            return dict(bits=bits, trials=trials, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
-        c = self.chain
-        spec = o.fft_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, c.n_sym, o.fft_size + o.guard_interval_size,
-                                n_frames * c.n_sym)
-        c.spectrum_to_cells(spec.reshape(n_frames, c.n_sym, o.fft_size, 2))
-        count = c.stage_llr(n_frames, pipeline_slot)
-        return dict(count=count, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, c.n_sym, 4))
+        bits, trials = self.chain.demod_stream_dev(self.stream, first + o.guard_interval_size, self.frame_len, n_frames, flush)
+        return dict(bits=bits, trials=trials, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
 
-    # ---- two-stream software pipeline: everything up to the LLRs of buffer k+1 (HBM-bound streaming kernels) runs on one
-    # stream while the LDPC of buffer k (VALU/LDS-bound, persistent workgroups) runs on another; LLR buffers alternate.
+    # ---- software pipeline over four HIP streams. The LDPC's persistent workgroups hold almost all LDS of every CU for the
+    # whole decode, so of the other kernels only those with (nearly) no LDS can run beside it: the front end, P1, guard correlation,
+    # equalisers, time de-interleaver and the demapper's statistics pass. The 32K FFT (128 KB of LDS per workgroup) and the
+    # demapper's LLR pass (one FEC frame in LDS) get their own streams and fall into the gap between two decodes. Call k enqueues
+    #   sa: front end, P1, guard correlation of buffer k;  equalisers, TI, demapper statistics of buffer k-1
+    #   sf: FFT of buffer k          sd: LLR pass of buffer k-1          sb: LDPC + descrambler of buffer k-1
+    # with events for the true dependencies; the result returned by call k belongs to buffer k-1 (None for the first call).
     def pipeline_step(self, d_i, d_q, n_frames, level_detect, first_call=False):
         torch = self.torch
+        c, o = self.chain, self.chain.ofdm
         if not hasattr(self, "_pipe"):
-            self._pipe = dict(sa=torch.cuda.Stream(device=self.chain.dev), sb=torch.cuda.Stream(device=self.chain.dev), k=0,
-                              llr_ready=[torch.cuda.Event(), torch.cuda.Event()], fec_done=[None, None])
+            import os
+            hi = int(os.environ.get("T2GPU_PIPE_LDPC_PRIORITY", "0"))           # lower number = higher priority; equal measured best
+            mk = lambda prio=0: torch.cuda.Stream(device=c.dev, priority=prio)
+            self._pipe = dict(sa=mk(), sf=mk(), sd=mk(), sb=mk(hi), k=0, serial=bool(int(os.environ.get("T2GPU_PIPE_SERIAL", "0"))), prev=None, fft_done=None, eq_done=None, llr_done=None,
+                              ldpc_done=None,
+                              spec=torch.empty((self.max_frames * c.n_sym, o.fft_size, 2), dtype=torch.float32, device=c.dev))
         pp = self._pipe
-        slot = pp["k"] % 2
-        pp["k"] += 1
-        with torch.cuda.stream(pp["sa"]):
-            if pp["fec_done"][slot] is not None:
-                pp["sa"].wait_event(pp["fec_done"][slot])                       # the LDPC that read this LLR buffer two steps ago
-            a = self.demod_iq_dev(d_i, d_q, n_frames, level_detect=level_detect, first_call=first_call, pipeline_slot=slot)
-            pp["llr_ready"][slot].record(pp["sa"])
-        with torch.cuda.stream(pp["sb"]):
-            pp["sb"].wait_event(pp["llr_ready"][slot])
-            bits, trials = self.chain.stage_fec(a["count"], slot)
-            ev = torch.cuda.Event()
-            ev.record(pp["sb"])
-            pp["fec_done"][slot] = ev
-        a.update(bits=bits, trials=trials)
-        return a
+        sa, sf, sd, sb = pp["sa"], pp["sf"], pp["sd"], pp["sb"]
+        ev = lambda st: (lambda e: (e.record(st), e)[1])(torch.cuda.Event())
+        out = None
+        cur = None
+        with torch.cuda.stream(sa):
+            if d_i is not None:
+                if pp["fft_done"] is not None:
+                    sa.wait_event(pp["fft_done"])                                # the FFT that still reads the sample stream
+                cur = self._front_p1_cp(d_i, d_q, n_frames, level_detect, first_call)
+                front_done = ev(sa)
+            prev = pp["prev"]
+            if prev is not None:
+                if pp["llr_done"] is not None:
+                    sa.wait_event(pp["llr_done"])                                # the LLR pass that still reads ti_out / sums
+                sa.wait_event(pp["fft_done"])
+                c.spectrum_to_cells(pp["spec"][:prev["n"] * c.n_sym].reshape(prev["n"], c.n_sym, o.fft_size, 2))
+                pp["eq_done"] = ev(sa)
+                c.stage_ti_stats(prev["n"])
+                stats_done = ev(sa)
+        if cur is not None:
+            with torch.cuda.stream(sf):
+                sf.wait_event(front_done)
+                if pp["eq_done"] is not None:
+                    sf.wait_event(pp["eq_done"])                                 # the equaliser that still reads the spectrum buffer
+                o.fft_stream_dev(self.stream, cur["first"] + o.guard_interval_size, self.frame_len, c.n_sym,
+                                 o.fft_size + o.guard_interval_size, n_frames * c.n_sym, out=pp["spec"][:n_frames * c.n_sym])
+                pp["fft_done"] = ev(sf)
+        if prev is not None:
+            with torch.cuda.stream(sd):
+                sd.wait_event(stats_done)
+                if pp["ldpc_done"] is not None:
+                    sd.wait_event(pp["ldpc_done"])                               # the decode that still reads the LLR buffer
+                count = c.stage_llr_only(prev["n"], 0)
+                pp["llr_done"] = ev(sd)
+            with torch.cuda.stream(sb):
+                sb.wait_event(pp["llr_done"])
+                bits, trials = c.stage_fec(count, 0)
+                pp["ldpc_done"] = ev(sb)
+            out = dict(prev["info"], bits=bits, trials=trials)
+        pp["prev"] = None if cur is None else dict(n=n_frames, info=dict(p1=cur["p1"], p2_start=cur["p2_start"], cp=cur["cp"]))
+        if pp["serial"]:
+            self.pipeline_sync()                                                 # A/B baseline: same kernels, no overlap
+        return out
+
+    def pipeline_flush(self):
+        """Decode the buffer still in flight (the last call's); returns its result."""
+        return self.pipeline_step(None, None, 0, 0.0)
+
+    def _front_p1_cp(self, d_i, d_q, n_frames, level_detect, first_call):
+        """Front end, P1 windows, guard correlation of one buffer on the current stream (first part of demod_iq_dev)."""
+        torch = self.torch
+        n_in = n_frames * self.frame_len
+        cells, _ = self.front.execute_dev(d_i, d_q, [n_in], self.stream)
+        assert cells == n_in, (cells, n_in)
+        starts = np.arange(n_frames, dtype=np.int64) * self.frame_len
+        lens = np.minimum(self.search, n_in - starts).astype(np.int32)
+        res, cons = self.p1.execute_batch_dev(self.stream, starts, lens, first_call, level_detect)
+        p2_start = np.array([s + c - r.idx_buffer_sym if r.detected else -1 for s, c, r in zip(starts, cons, res)], np.int64)
+        if (p2_start < 0).any():
+            raise RuntimeError("P1 not found in %d of %d frames" % (int((p2_start < 0).sum()), n_frames))
+        first = int(p2_start[0])
+        if np.abs(p2_start - (first + starts)).max() > self.timing_slack:
+            raise RuntimeError("frames are not equally spaced: P2 starts %s" % p2_start)
+        o = self.chain.ofdm
+        cp = torch.empty((n_frames * self.chain.n_sym, 4), dtype=torch.float32, device=self.chain.dev)
+        from ._lib import lib, check
+        check(lib().t2gpu_cp_correlate_stream_dev(self.stream.data_ptr(), first, self.frame_len, self.chain.n_sym, n_frames * self.chain.n_sym,
+                                                  o.fft_size, o.guard_interval_size, cp.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "t2gpu_cp_correlate_stream_dev")
+        return dict(first=first, p1=res, p2_start=p2_start, cp=cp.reshape(n_frames, self.chain.n_sym, 4))
 
     def pipeline_sync(self):
         if hasattr(self, "_pipe"):
-            self._pipe["sa"].synchronize()
-            self._pipe["sb"].synchronize()
+            for k in ("sa", "sf", "sd", "sb"):
+                self._pipe[k].synchronize()
 
 
 class t2_closed_loop(object):

@@ -69,6 +69,54 @@ def test_iq_to_ts(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, sa
     rx.close()
 
 
+def test_pipelined_schedule_equals_plain_calls(torch_cuda):
+    """receiver.pipeline_step (four streams, stages of neighbouring buffers overlapped) returns, one call late, exactly what the
+    plain call sequence returns for the same buffers."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_receiver
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 16.0, 8
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    nb = t2_tx.plp_blocks_per_frame(m, lps, 16200 // (2 * (mod + 1)))
+    k_bch = t2_tx.K_BCH[cid]
+    bufs = []
+    for b in range(3):
+        ts = t2_tx.ts_packets(2 * nb * (k_bch // 1496 + 1) + 8, 40 + b)
+        frames = []
+        for f in range(2):
+            cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, f * nb, nb, k_bch), nb)
+            frames.append(t2_tx.build_frame(m, cells, lps, 50 + 2 * b + f, snr_db=None, phase=0.0))
+        bufs.append(frames)
+    a = t2_receiver((*mode, lps, mod, fec_type, code_rate, 1, nb), dict(), max_frames=2)
+    b_ = t2_receiver((*mode, lps, mod, fec_type, code_rate, 1, nb), dict(), max_frames=2)
+    guard = a.chain.ofdm.guard_interval_size
+    iq = [t2_tx.iq_stream(fr, guard, s2, snr, 60 + i)[:2] for i, fr in enumerate(bufs)]
+    dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(q).cuda()) for i, q in iq]
+    plain = []
+    level = None
+    for k, (di, dq) in enumerate(dev):
+        r = a.demod_iq_dev(di, dq, 2, level_detect=level, first_call=(k == 0), flush=True)
+        if level is None:
+            level = float(a.front.state()["level_detect"])
+        plain.append((r["bits"].cpu().numpy(), r["trials"].cpu().numpy(), r["p2_start"].copy()))
+    # the pipelined receiver needs the same thresholds: take the level estimate the plain one saw after its first buffer
+    lv0 = float(np.mean(np.abs(iq[0][0] / 16384.0)) * np.mean(np.abs(iq[0][1] / 16384.0)))
+    outs = []
+    for k, (di, dq) in enumerate(dev):
+        r = b_.pipeline_step(di, dq, 2, lv0 if k == 0 else level, first_call=True)
+        if r is not None:
+            outs.append(r)
+    outs.append(b_.pipeline_flush())
+    b_.pipeline_sync()
+    assert len(outs) == 3
+    for (bits, trials, p2), r in zip(plain, outs):
+        assert np.array_equal(r["p2_start"], p2)
+        assert np.array_equal(r["trials"].cpu().numpy(), trials) and (trials >= 0).all()
+        assert np.array_equal(r["bits"].cpu().numpy(), bits)
+    a.close()
+    b_.close()
+
+
 def test_closed_loop_tracks_cfo_and_decodes(torch_cuda):
     """Symbol-by-symbol operation with every tracking loop closed, on a 16K frame structure with a frame-closing symbol: a
     100 Hz carrier offset (0.18 carrier spacings) and a static phase. P1 reports the offset frame after frame -- the reference's
