@@ -94,6 +94,10 @@ int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t 
  * them -- so that a multi-stream scheduler can place them separately; calling one after the other equals execute_dev. */
 int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, float *d_sums3, void *stream);
 int t2gpu_demap_llr_dev(t2gpu_demap *h, const float *d_cells, int n_cells, const float *d_sums3, int8_t *d_llr, void *stream);
+/* the LLR pass for n_blocks TI blocks in one launch: block t = cells_per_block cells at d_cells + 2 * t * cells_per_block floats,
+ * its statistics at d_sums + t * sums_stride; LLR frames back to back in d_llr. Returns the number of FEC frames. */
+int t2gpu_demap_llr_batch_dev(t2gpu_demap *h, const float *d_cells, int n_blocks, int cells_per_block, const float *d_sums,
+                              int sums_stride, int8_t *d_llr, void *stream);
 
 /* ---------------------------------------------------------------- time / cell de-interleaver ----------------------
  * Replaces  void time_deinterleaver::execute(int len, complex* cells) / l1_dyn_execute(l1_post, len, cells)
@@ -195,6 +199,13 @@ int t2gpu_fft_execute_strided_dev(t2gpu_ofdm *h, const float *d_stream, long fir
                                   float *d_out, int n_symbols, void *stream);
 int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32_t *d_symbol_index, int n_symbols,
                               float *d_cells, float *d_sync, void *stream);
+/* The same for the data symbols of whole frames, read in place from the frames' spectra (n_frames x syms_per_frame x fft_size
+ * cells, what t2gpu_fft_execute_strided_dev wrote) and written in place into the frames' cell streams: data symbol first_symbol + l
+ * of frame f is read at d_spectrum + 2 * (f * syms_per_frame + first_symbol + l) * fft_size floats and its c_data cells go to
+ * d_cells + 2 * (f * cells_frame_stride + cells_offset + l * c_data) floats. d_sync (optional): n_frames * n_data_symbols pairs. */
+int t2gpu_eq_data_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, int first_symbol,
+                             int n_data_symbols, float *d_cells, long cells_frame_stride, long cells_offset, float *d_sync,
+                             void *stream);
 int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
                           float *phase_offset);
 /* Equaliser + frequency de-interleaver part of  complex* p2_symbol::execute(...)  (src/DVB_T2/p2_symbol.h:42-44,

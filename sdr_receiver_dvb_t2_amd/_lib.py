@@ -39,6 +39,7 @@ PROTOTYPES = {
     "t2gpu_demap_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_demap_stats_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "t2gpu_demap_llr_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_demap_llr_batch_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ti_create": (_vp, [ctypes.c_int] * 4),
     "t2gpu_ti_destroy": (None, [_vp]),
     "t2gpu_ti_cells_per_fec": (ctypes.c_int, [_vp]),
@@ -59,6 +60,8 @@ PROTOTYPES = {
     "t2gpu_fft_execute": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     "t2gpu_fft_execute_strided_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "t2gpu_eq_data_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_eq_data_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long,
+                                                ctypes.c_long, _vp, _vp]),
     "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_fc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_data_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),

@@ -96,10 +96,13 @@ class t2_chain(object):
         self.cells[:F, :o.c_p2 - self.p2_skip] = p2[:, self.p2_skip:]
         # data symbols: equalised cells land directly behind, symbol after symbol
         nd = self.n_dat
-        data = spec[:, 1:1 + nd].contiguous().reshape(F * nd, o.fft_size, 2)
-        cells, _ = o.eq_data_dev(data, self.sym_index[:F * nd], want_sync=False)
         a = o.c_p2 - self.p2_skip
-        self.cells[:F, a:a + nd * o.c_data] = cells.reshape(F, nd * o.c_data, 2)
+        if spec.is_contiguous():            # straight from the frames' spectra into the frames' cell streams
+            o.eq_data_frames_dev(spec, F, self.n_sym, 1, nd, self.cells, a)
+        else:
+            data = spec[:, 1:1 + nd].contiguous().reshape(F * nd, o.fft_size, 2)
+            cells, _ = o.eq_data_dev(data, self.sym_index[:F * nd], want_sync=False)
+            self.cells[:F, a:a + nd * o.c_data] = cells.reshape(F, nd * o.c_data, 2)
         if o.l_fc:                                               # frame-closing symbol: its n_fc cells end the frame's stream
             fc, _ = o.eq_fc_dev(spec[:, 1 + nd].contiguous(), want_sync=False)
             self.cells[:F, a + nd * o.c_data:] = fc
@@ -165,6 +168,9 @@ class t2_chain(object):
             self.demap.stats_dev(self.ti_out[f], self.sums[f])
 
     def stage_llr_only(self, F, slot=0):
+        n_ti = self.num_blocks * self.cells_per_fec
+        if self.ti_out.shape[1] == n_ti:                 # TI blocks back to back: one launch for the whole buffer
+            return self.demap.llr_batch_dev(self.ti_out, F, n_ti, self.sums, self.llr2[slot])
         for f in range(F):
             self.demap.llr_dev(self.ti_out[f], self.sums[f], self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
         return F * self.num_blocks

@@ -23,7 +23,9 @@ struct DemapParams {
 hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
                               float precision_override, hipStream_t s);
 // K-demap-bdi: one workgroup per FEC frame; LLRs staged in LDS in LDPC order, written out coalesced.
-hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s);
+// frames_per_sums / sums_stride: several TI blocks in one launch, each with its own statistics triple (0 = one triple for all)
+hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s,
+                            int frames_per_sums = 0, int sums_stride = 0);
 
 // K-ti-cdi-qdelay: scatter cells n0 .. n0+n-1 of a TI block (time + cell de-interleave + cyclic Q delay removal)
 struct TiParams {

@@ -129,12 +129,14 @@ __device__ __forceinline__ int8_t cast_i8_trunc(float v)
     return (int8_t)(uint8_t)((int)v & 0xff);      // cvttss2si + low byte, no saturation (16/64/256-QAM paths)
 }
 
+// frames_per_sums: FEC frames that share one statistics triple (one TI block); sums of TI block t at sums + t * sums_stride
 __global__ __launch_bounds__(256) void demap_llr_kernel(DemapParams p, const float2 *__restrict__ cells,
-                                                       const float *__restrict__ sums, int8_t *__restrict__ out)
+                                                       const float *__restrict__ sums, int8_t *__restrict__ out, int frames_per_sums,
+                                                       int sums_stride)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t stage[];        // one FEC frame in LDPC input order
     const int f = blockIdx.x;
-    const float precision = sums[2];
+    const float precision = sums[(size_t)(f / frames_per_sums) * sums_stride + 2];
     const float2 *src = cells + (size_t)f * p.cells_per_fec;
     const int levels = p.mod + 1;
     for (int c = threadIdx.x; c < p.cells_per_fec; c += blockDim.x) {
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(256) void demap_llr_kernel(DemapParams p, const flo
     for (int i = threadIdx.x; i < p.fec_size / 8; i += blockDim.x) dst[i] = s2[i];
 }
 
-hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s)
+hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s,
+                            int frames_per_sums, int sums_stride)
 {
+    if (frames_per_sums < 1) frames_per_sums = n_frames > 0 ? n_frames : 1;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demap_llr_kernel),
@@ -173,7 +177,7 @@ hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_fra
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(256), p.fec_size, s, p, cells, sums, out);
+    hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(256), p.fec_size, s, p, cells, sums, out, frames_per_sums, sums_stride);
     return hipGetLastError();
 }
 

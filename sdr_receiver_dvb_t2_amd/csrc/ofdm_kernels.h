@@ -24,6 +24,12 @@ struct EqParams {
     const int32_t *seg_count;  // [rows]
     const int32_t *h_even, *h_odd;
     const float *lut_sin, *lut_cos;   // 65536-entry tables of DSP/fast_math.h
+    // Frame layout (per_frame > 0): symbol b of the batch is data symbol `first + b % per_frame` of frame b / per_frame; its
+    // spectrum is at symbols + (frame * in_syms_per_frame + first + b % per_frame) * fft_size, its cells go to
+    // out + frame * out_frame_stride + out_offset + (b % per_frame) * c_data. per_frame == 0: symbols and cells back to back,
+    // positions from symbol_index[].
+    int per_frame = 0, first = 0, in_syms_per_frame = 0;
+    long out_frame_stride = 0, out_offset = 0;
 };
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);

@@ -210,16 +210,17 @@ __global__ __launch_bounds__(128) void eq_data_kernel(EqParams p, const float2 *
     const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
     const float PI = 3.14159274101257324219f;
     const int b = blockIdx.y;                                                   // symbol of the batch
-    const int idx_symbol = symbol_index[b];                                     // position in the T2 frame (P2 = 0)
+    const int fr = p.per_frame ? b / p.per_frame : 0, lo = p.per_frame ? b - fr * p.per_frame : 0;
+    const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];        // position in the T2 frame (P2 = 0)
     const int row = idx_symbol - p.n_p2;                                        // data-symbol table row
     const int nseg = p.seg_count[row];
     const int seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= nseg) return;
-    const float2 *cell = symbols + (size_t)b * p.fft_size + p.l_nulls;
+    const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
     const uint8_t *map = p.map + (size_t)row * p.k_total;
     const float *refer = p.refer + (size_t)row * p.k_total;
     const int32_t *h = (idx_symbol & 1) ? p.h_even : p.h_odd;                   // data_symbol.cpp:148-149
-    float2 *o = out + (size_t)b * p.c_data;
+    float2 *o = p.per_frame ? out + (size_t)fr * p.out_frame_stride + p.out_offset + (size_t)lo * p.c_data : out + (size_t)b * p.c_data;
     const int4 sg = p.segs[(size_t)row * p.max_seg + seg];                      // left pilot, right pilot, d start, data count
     const int pl = sg.x, pr = sg.y, n = sg.w;
     int d = sg.z;
@@ -256,7 +257,7 @@ __global__ void eq_sync_kernel(EqParams p, const int32_t *__restrict__ symbol_in
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_symbols) return;
-    const int nseg = p.seg_count[symbol_index[b] - p.n_p2];
+    const int nseg = p.seg_count[(p.per_frame ? p.first + b % p.per_frame : symbol_index[b]) - p.n_p2];
     const float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
     float s1r = 0, s1i = 0, s2r = 0, s2i = 0, a1 = 0, a2 = 0;
     s1r += ps[0].x; s1i += ps[0].y;

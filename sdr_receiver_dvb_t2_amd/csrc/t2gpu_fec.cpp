@@ -145,6 +145,20 @@ extern "C" int t2gpu_demap_llr_dev(t2gpu_demap *h, const float *d_cells, int n_c
     return n_frames;
 }
 
+// n_blocks TI blocks of cells_per_block cells each, back to back in d_cells, statistics of block t at d_sums + t * sums_stride
+extern "C" int t2gpu_demap_llr_batch_dev(t2gpu_demap *h, const float *d_cells, int n_blocks, int cells_per_block, const float *d_sums,
+                                         int sums_stride, int8_t *d_llr, void *stream)
+{
+    if (!h || !d_cells || !d_sums || !d_llr || n_blocks < 1 || cells_per_block < 1 || cells_per_block > h->max_cells ||
+        cells_per_block % h->p.cells_per_fec || sums_stride < 3) {
+        set_error("t2gpu_demap_llr_batch_dev: bad arguments");
+        return -1;
+    }
+    const int per = cells_per_block / h->p.cells_per_fec;
+    T2_HIP(launch_demap_llr(h->p, reinterpret_cast<const float2 *>(d_cells), n_blocks * per, d_sums, d_llr, (hipStream_t)stream, per, sums_stride));
+    return n_blocks * per;
+}
+
 extern "C" int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t *llr, float *sums3)
 {
     if (!h || !cells || !llr || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_execute: bad arguments"); return -1; }

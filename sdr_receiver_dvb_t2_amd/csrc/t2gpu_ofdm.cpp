@@ -284,6 +284,25 @@ extern "C" int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, 
     return h->m.c_data;
 }
 
+// Data symbols of whole frames straight from the frames' spectra into the frames' cell streams (no gather / scatter copies)
+extern "C" int t2gpu_eq_data_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, int first_symbol,
+                                        int n_data_symbols, float *d_cells, long cells_frame_stride, long cells_offset, float *d_sync,
+                                        void *stream)
+{
+    const long n = (long)n_frames * n_data_symbols;
+    if (!h || !d_spectrum || !d_cells || n_frames < 1 || n_data_symbols < 1 || n > h->max_symbols || first_symbol < h->m.n_p2 ||
+        first_symbol + n_data_symbols > syms_per_frame || cells_frame_stride < (long)n_data_symbols * h->m.c_data || cells_offset < 0) {
+        set_error("t2gpu_eq_data_frames_dev: bad arguments");
+        return -1;
+    }
+    EqParams p = h->eq;
+    p.per_frame = n_data_symbols; p.first = first_symbol; p.in_syms_per_frame = syms_per_frame;
+    p.out_frame_stride = cells_frame_stride; p.out_offset = cells_offset;
+    T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, (int)n, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+    return h->m.c_data;
+}
+
 // P2 symbols of a batch of frames (idx_symbol = 0 for all of them: n_p2 = 1 for 16K / 32K)
 extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream)
 {

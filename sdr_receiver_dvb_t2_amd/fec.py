@@ -70,6 +70,15 @@ class llr_demapper(object):
         if rc < 0:
             check(rc, "t2gpu_demap_llr_dev")
 
+    def llr_batch_dev(self, cells, n_blocks, cells_per_block, sums, out):
+        """LLR pass of n_blocks TI blocks (contiguous in `cells`, statistics rows in `sums` [n_blocks][>=3]) in one launch."""
+        import torch
+        rc = self._l.t2gpu_demap_llr_batch_dev(self._h, cells.data_ptr(), n_blocks, cells_per_block, sums.data_ptr(), sums.stride(0),
+                                               out.data_ptr(), torch.cuda.current_stream(cells.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_demap_llr_batch_dev")
+        return rc
+
     def execute(self, ti_block_size, time_deint_cell):
         """Reference call shape on host buffers; returns (llr [n_frames][fec_size], (sum_s, sum_e, precision))."""
         cells = np.ascontiguousarray(time_deint_cell, dtype=np.complex64).reshape(-1)[:ti_block_size]

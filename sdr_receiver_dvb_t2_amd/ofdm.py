@@ -79,6 +79,19 @@ class t2_ofdm(object):
             check(rc, "t2gpu_eq_data_execute_dev")
         return cells, sync
 
+    def eq_data_frames_dev(self, spec, n_frames, syms_per_frame, first_symbol, n_data_symbols, cells, cells_offset, want_sync=False):
+        """Data symbols of whole frames in place: spec float32 [n_frames * syms_per_frame][fft_size][2] -> cells float32
+        [n_frames][cells per frame][2] at cell offset cells_offset of every frame."""
+        import torch
+        assert spec.is_contiguous() and cells.is_contiguous() and cells.dim() == 3
+        sync = torch.empty((n_frames * n_data_symbols, 2), dtype=torch.float32, device=spec.device) if want_sync else None
+        rc = self._l.t2gpu_eq_data_frames_dev(self._h, spec.data_ptr(), n_frames, syms_per_frame, first_symbol, n_data_symbols,
+                                              cells.data_ptr(), cells.shape[1], cells_offset, sync.data_ptr() if want_sync else None,
+                                              torch.cuda.current_stream(spec.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_eq_data_frames_dev")
+        return sync
+
     # ---- equaliser part of p2_symbol::execute, batched over frames
     def eq_p2_dev(self, symbols, want_sync=True):
         import torch
