@@ -151,10 +151,10 @@ def main():
     chain = rx.chain
     r0 = rx.demod_iq_dev(d_i, d_q, F, first_call=True, flush=True)                    # thresholds from the level estimate
     level = float(rx.front.state()["level_detect"])
-    # Steps are software-pipelined over four HIP streams (receiver.pipeline_step): while the LDPC of buffer k-1 runs (VALU/LDS-
-    # bound, persistent workgroups holding the CUs' LDS) the LDS-free streaming stages of buffers k and k+1 run beside it, the
-    # 32K FFT and the demapper's LLR pass take the gap between two decodes. Every call enqueues the front half of a new buffer
-    # and the back half of the previous one, so K timed calls contain exactly K x the whole chain.
+    # Steps go through receiver.pipeline_step: every call enqueues the front half (front end, P1, guard correlation, FFT) of a new
+    # buffer and the back half (equalisers .. descrambler) of the previous one, so K timed calls contain exactly K x the whole
+    # chain. The stages sit on four HIP streams with event dependencies; by default each call is drained before the next
+    # (T2GPU_PIPE_SERIAL=1) because overlapping other kernels with the decoder measured slower and unstable (see receiver.py).
     for _ in range(max(args.warmup, 1) + 1):
         r0 = rx.pipeline_step(d_i, d_q, F, level)
     rx.pipeline_sync()
@@ -218,8 +218,8 @@ def main():
             "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames, from int16 I/Q at the "
                                    "dvbt2_demodulator::execute boundary; stages on GPU: front end (dc, IQ imbalance, NCO, Farrow x2, "
                                    "64-tap decimator), P1 detect, guard correlation, FFT, P2+data equaliser/freq-deint, TI/cell-deint, "
-                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; steps software-pipelined over four HIP "
-                                   "streams (LDS-free streaming stages beside the LDPC of the previous buffer, FFT and LLR pass between decodes); "
+                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; one call = front half of a new buffer + back "
+                                   "half of the previous one, drained per call (overlapping other kernels with the decoder measured slower); "
                                    "reference arithmetic incl. the wrapping int8 LLR cast, so %d of %d SIMD batches run all trials and "
                                    "are dropped as the reference would; L1 parsing and TS de-framing (host code) are not inside the "
                                    "timed region (%d samples per frame)"

@@ -57,6 +57,11 @@ int t2gpu_ldpc_graph_stats(int fec_type, int code_rate, int *links_total, int *l
 int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uint8_t *d_bits,
                            int8_t *d_llr_out /* optional [n_frames][fec_size] final LLRs, or NULL */,
                            int *d_trials_left /* [ceil(n_frames/group)] */, void *stream);
+/* For callers that run other streams beside the decoder: enqueue on `stream` a wait (no host blocking) until every workgroup of
+ * every decode enqueued so far on this handle has started. The decoder's workgroups are persistent and the frames of a SIMD
+ * batch meet at every sweep, so kernels of another stream that grab the CUs first stall whole batches; with this wait they
+ * start once the decoder is placed and use what it leaves. */
+int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream);
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
+    "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),
     "t2gpu_demap_destroy": (None, [_vp]),

@@ -32,6 +32,32 @@ constexpr float K_TABLE = 32767.0f / (2.0f * PI_F);          // fast_math.h:29
 struct Lin { double a, re, im; };                            // x -> a*x + (re, im)
 __device__ __forceinline__ Lin compose(const Lin &l, const Lin &r) { return Lin{l.a * r.a, r.a * l.re + r.re, r.a * l.im + r.im}; }
 
+__device__ __forceinline__ Lin shfl_up_lin(const Lin &v, int d)
+{
+    return Lin{__shfl_up(v.a, d, 64), __shfl_up(v.re, d, 64), __shfl_up(v.im, d, 64)};
+}
+// Inclusive scan of `v` (composition in thread order) over the 256 threads of a workgroup: wavefront scan by shuffles, the four
+// wavefront totals through 96 bytes of LDS. Returns the EXCLUSIVE prefix of this thread; *total receives the workgroup's
+// composition. These kernels run beside the LDPC decoder of another stream, whose persistent workgroups leave only ~12 KB of
+// LDS per CU: keeping LDS use tiny is what lets them overlap (receiver.pipeline_step).
+__device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[4] */, Lin *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Lin o = shfl_up_lin(v, d);
+        if (lane >= d) v = compose(o, v);
+    }
+    if (lane == 63) wave_tot[wave] = v;
+    __syncthreads();
+    Lin ex = shfl_up_lin(v, 1);
+    if (lane == 0) ex = Lin{1.0, 0.0, 0.0};
+    Lin pre{1.0, 0.0, 0.0};
+    for (int w = 0; w < wave; ++w) pre = compose(pre, wave_tot[w]);
+    if (total) { Lin t{1.0, 0.0, 0.0}; for (int w = 0; w < 4; ++w) t = compose(t, wave_tot[w]); *total = t; }
+    return compose(pre, ex);
+}
+
 __device__ __forceinline__ void load4(const FrontParams &p, long s0, float xr[4], float xi[4], int &valid)
 {
     valid = (int)min(4L, max(0L, (long)p.n - s0));
@@ -76,25 +102,16 @@ __global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
 }
 
 // ---- level 2: scan over the workgroup aggregates (one workgroup); blk[b] becomes the averager value BEFORE block b
-__global__ __launch_bounds__(1024) void front_dc_scan_kernel(FrontParams p)
+__global__ __launch_bounds__(256) void front_dc_scan_kernel(FrontParams p)
 {
-    __shared__ Lin sh[2][1024];
+    __shared__ Lin wave_tot[4];
     const int tid = threadIdx.x, nb = p.n_blocks;
-    const int per = (nb + 1023) / 1024, b0 = tid * per, b1 = min(nb, b0 + per);
+    const int per = (nb + 255) / 256, b0 = tid * per, b1 = min(nb, b0 + per);
     Lin l{1.0, 0.0, 0.0};
     for (int b = b0; b < b1; ++b) { const double *v = p.blk + 4 * (long)b; l = compose(l, Lin{v[0], v[1], v[2]}); }
-    int cur = 0;
-    sh[0][tid] = l;
-    __syncthreads();
-    for (int s = 1; s < 1024; s <<= 1) {                                          // inclusive Hillis-Steele
-        Lin v = sh[cur][tid];
-        if (tid >= s) v = compose(sh[cur][tid - s], v);
-        sh[cur ^ 1][tid] = v;
-        cur ^= 1;
-        __syncthreads();
-    }
+    Lin total;
+    const Lin ex = block_scan_exclusive(l, wave_tot, &total);
     const double s_re = p.state->dc_re, s_im = p.state->dc_im;
-    Lin ex = tid ? sh[cur][tid - 1] : Lin{1.0, 0.0, 0.0};
     double re = ex.a * s_re + ex.re, im = ex.a * s_im + ex.im;
     for (int b = b0; b < b1; ++b) {
         double *v = p.blk + 4 * (long)b;
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(1024) void front_dc_scan_kernel(FrontParams p)
         re = w.a * re + w.re; im = w.a * im + w.im;
     }
     __syncthreads();
-    if (tid == 1023) { const Lin t = sh[cur][1023]; p.state->dc_re = t.a * s_re + t.re; p.state->dc_im = t.a * s_im + t.im; }
+    if (tid == 0) { p.state->dc_re = total.a * s_re + total.re; p.state->dc_im = total.a * s_im + total.im; }
 }
 
 __device__ __forceinline__ float wrap_2pi(float a)
@@ -116,24 +133,14 @@ __device__ __forceinline__ float wrap_2pi(float a)
 // ---- level 3: dc removal, sign statistics, IQ-imbalance correction, NCO de-rotation (dvbt2_demodulator.cpp:175-205)
 __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
 {
-    __shared__ Lin sh[2][256];
-    __shared__ double red[3][256];
+    __shared__ Lin wave_tot[4];
+    __shared__ double red[3][4];
     const int tid = threadIdx.x;
     const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * 4;
     float xr[4], xi[4]; int valid;
     load4(p, s0, xr, xi, valid);
-    int cur = 0;
-    sh[0][tid] = thread_lin(xr, xi, valid);
-    __syncthreads();
-    for (int s = 1; s < 256; s <<= 1) {
-        Lin v = sh[cur][tid];
-        if (tid >= s) v = compose(sh[cur][tid - s], v);
-        sh[cur ^ 1][tid] = v;
-        cur ^= 1;
-        __syncthreads();
-    }
     const double *start = p.blk + 4 * (long)blockIdx.x;
-    const Lin ex = tid ? sh[cur][tid - 1] : Lin{1.0, 0.0, 0.0};
+    const Lin ex = block_scan_exclusive(thread_lin(xr, xi, valid), wave_tot, nullptr);
     double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
     const float c1 = p.state->c1, c2 = p.state->c2;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
@@ -158,13 +165,14 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
         const float nr = p.lut_cos[li], ni = p.lut_sin[li];
         p.derot[3 + i] = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
     }
-    red[0][tid] = t1; red[1][tid] = t2; red[2][tid] = t3;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { t1 += __shfl_down(t1, d, 64); t2 += __shfl_down(t2, d, 64); t3 += __shfl_down(t3, d, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = t1; red[1][tid >> 6] = t2; red[2][tid >> 6] = t3; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
-        __syncthreads();
+    if (tid == 0) {
+        double *o = p.theta_part + 4 * (long)blockIdx.x;
+        for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
     }
-    if (tid == 0) { double *o = p.theta_part + 4 * (long)blockIdx.x; o[0] = red[0][0]; o[1] = red[1][0]; o[2] = red[2][0]; }
 }
 
 // ---- Farrow resampler: one lane per input sample (interpolator_farrow.hh:47-66); positions from the run table
@@ -317,7 +325,7 @@ void launch_front(const FrontParams &p, hipStream_t stream)
     }
     if (p.n > 0 && (p.stages & FRONT_STAGE_DEROTATE)) {
         hipLaunchKernelGGL(front_dc_block_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(front_derotate_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
     }
     if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))

@@ -34,6 +34,7 @@ struct LdpcKernelParams {
     int lds_rec_offset;           // byte offset of the 360 chain-walk records (PAIR layers)
     int lds_sign_offset;          // byte offset of the packed sign words (13 dwords per 360-bit group)
     long long *prof;              // optional [grid][8] cycle counters (diagnostics; null in production)
+    unsigned *resident;           // counts workgroups that have started, cumulatively over launches (t2gpu_ldpc_wait_resident)
 };
 
 hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu);

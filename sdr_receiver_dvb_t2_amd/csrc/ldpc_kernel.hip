@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
     uint2 *state = p.state + (size_t)blockIdx.x * p.q * 360;
 
     if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 6] = wall_clock64();
+    if (tid == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // "this workgroup is placed"
     for (int batch = slot; batch < nbatches; batch += nslots) {
         const int frame = batch * group + member;
         const bool have = frame < p.n_frames;

@@ -43,25 +43,26 @@ __device__ __forceinline__ float atan2_approx_dev(float y, float x)             
 }
 
 // ---- correlator: 256 outputs per workgroup
-constexpr int NC = 256 + 540, NB = 256 + 480;
+constexpr int P1_TILE = 128;                 // outputs per workgroup: (128+540 + 128+480) * 8 B = 10.2 KB of LDS, small enough to
+constexpr int NC = P1_TILE + 540, NB = P1_TILE + 480;   // run beside another stream's LDS-heavy kernel
 
-__global__ __launch_bounds__(256) void p1_correlate_kernel(P1Params p)
+__global__ __launch_bounds__(P1_TILE) void p1_correlate_kernel(P1Params p)
 {
     __shared__ float2 pc[NC], pb[NB];
-    const int n0 = blockIdx.x * 256, tid = threadIdx.x;
+    const int n0 = blockIdx.x * P1_TILE, tid = threadIdx.x;
     const P1Window w = p.win[blockIdx.y];
     if (n0 >= w.len) return;
     const float2 *xw = p.base + w.start;
     const int lo = -p.hist, len = w.len;
     auto x = [&](int k) { return k >= lo ? xw[k] : make_float2(0.f, 0.f); };       // zeros in front of the search
     const int f0 = p.state[blockIdx.y].idx_fq_shift;
-    for (int t = tid; t < NC; t += 256) {                   // pc[k] = x[k] * conj(s[k - 542]), k = n0 - 964 - 540 + t
+    for (int t = tid; t < NC; t += P1_TILE) {               // pc[k] = x[k] * conj(s[k - 542]), k = n0 - 964 - 540 + t
         const int k = n0 - 1504 + t;
         float2 v = make_float2(0.f, 0.f);
         if (k < len && k >= lo) v = cmulc(x(k), cmul(x(k - 542), p.fq_shift[(f0 + k - 542) & 1023]));
         pc[t] = v;
     }
-    for (int t = tid; t < NB; t += 256) {                   // pb[k] = s[k] * conj(x[k - 482]), k = n0 - 2 - 480 + t
+    for (int t = tid; t < NB; t += P1_TILE) {               // pb[k] = s[k] * conj(x[k - 482]), k = n0 - 2 - 480 + t
         const int k = n0 - 482 + t;
         float2 v = make_float2(0.f, 0.f);
         if (k < len && k >= lo) v = cmulc(cmul(x(k), p.fq_shift[(f0 + k) & 1023]), x(k - 482));
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
 // ---- part A: 1K FFT (fft-shifted) + carrier search + DBPSK / S1 / S2 decode (:111-131,180-298), one workgroup
 __global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
 {
-    __shared__ float2 buf[2][1024];
+    __shared__ float2 buf[1024];              // 8 KB: in-place transform (runs beside other streams' LDS-heavy kernels)
     __shared__ int ok[20], r_pre[20], r_fft[20], r_s1[20], r_s2[20];
     const int tid = threadIdx.x;
     P1State &st = p.state[blockIdx.x];
@@ -182,34 +183,37 @@ __global__ __launch_bounds__(256) void p1_decode_kernel(P1Params p)
     for (int j = tid; j < 1024; j += 256) {
         const int k = start + j;
         const bool in = k >= -p.hist && k <= newest;
-        buf[0][j] = in ? x[k] : make_float2(0.f, 0.f);
+        buf[j] = in ? x[k] : make_float2(0.f, 0.f);
         if (!in && tid == 0) res.a_part_clipped = 1;
     }
     __syncthreads();
-    int cur = 0;
-    for (int s = 1, stage = 0; stage < 10; ++stage, s <<= 1) {       // Stockham radix-2, 512 butterflies per stage
-        const int m = 1024 / (2 * s);                                // sub-transform count factor
+    // radix-2 decimation in frequency, in place: after the 10 stages bin k sits at the bit-reversed index of k
+    for (int half = 512; half >= 1; half >>= 1) {
         for (int b = tid; b < 512; b += 256) {
-            const int j = b / s, k = b % s;                          // j < m
-            const float2 a = buf[cur][j * s + k], c = buf[cur][(j + m) * s + k];
-            const float2 w = p.twiddle[j * s];                       // exp(-2 pi i j / (2 m))
-            const float2 d = make_float2(a.x - c.x, a.y - c.y);
-            buf[cur ^ 1][2 * j * s + k] = make_float2(a.x + c.x, a.y + c.y);
-            buf[cur ^ 1][(2 * j + 1) * s + k] = cmul(d, w);
+            const int grp = b / half, k = b - grp * half, i = grp * 2 * half + k;
+            const float2 a = buf[i], c = buf[i + half];
+            const float2 w = p.twiddle[k * (512 / half)];               // exp(-2 pi i k / (2 half))
+            buf[i] = make_float2(a.x + c.x, a.y + c.y);
+            buf[i + half] = cmul(make_float2(a.x - c.x, a.y - c.y), w);
         }
-        cur ^= 1;
         __syncthreads();
     }
-    // fftshift (fast_fourier_transform::execute): out[k + 512] = X[k]
-    for (int j = tid; j < 1024; j += 256) { const float2 v = buf[cur][j]; buf[cur ^ 1][(j + 512) & 1023] = v; }
+    // fftshift (fast_fourier_transform::execute): out[(k + 512) mod 1024] = X[k]; X[k] = buf[bitrev10(k)]
+    float2 mine[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = tid + 256 * u;                                     // shifted position
+        const int k = (j + 512) & 1023;
+        mine[u] = buf[__brev((unsigned)k) >> 22];
+    }
     __syncthreads();
-    cur ^= 1;
-    for (int j = tid; j < 1024; j += 256) p.p1_fft[1024 * blockIdx.x + j] = buf[cur][j];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { buf[tid + 256 * u] = mine[u]; p.p1_fft[1024 * blockIdx.x + tid + 256 * u] = mine[u]; }
     if (tid < 20) ok[tid] = 0;
     __syncthreads();
     const bool try_decode = !st.p1_decoded || p.reset_flag;          // :116
     if (try_decode && tid < 20) {
-        const float2 *p1 = buf[cur] + 76 + tid;                      // shift = 76 + tid
+        const float2 *p1 = buf + 76 + tid;                           // shift = 76 + tid
         int randomize_sr = 0x4e46;                                   // init_p1_randomize, :45-55 (generated on the fly)
         int old_bit = -1, prev_desc = 0, dec_old = 1;
         uint8_t data[48];
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void p1_carry_kernel(P1Params p)
 void launch_p1(const P1Params &p, hipStream_t stream)
 {
     if (p.n <= 0 || p.n_windows <= 0) return;
-    hipLaunchKernelGGL(p1_correlate_kernel, dim3((p.n + 255) / 256, p.n_windows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(p1_correlate_kernel, dim3((p.n + P1_TILE - 1) / P1_TILE, p.n_windows), dim3(P1_TILE), 0, stream, p);
     hipLaunchKernelGGL(p1_detect_kernel, dim3(p.n_windows), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(p1_decode_kernel, dim3(p.n_windows), dim3(256), 0, stream, p);
     if (p.xb) hipLaunchKernelGGL(p1_carry_kernel, dim3(1), dim3(256), 0, stream, p);

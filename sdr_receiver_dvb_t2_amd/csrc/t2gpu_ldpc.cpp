@@ -22,6 +22,8 @@ struct t2gpu_ldpc {
     unsigned *d_sync = nullptr;
     size_t sync_words = 0;
     int *d_error = nullptr;
+    unsigned *d_resident = nullptr;     // signal memory: workgroups started, cumulative
+    unsigned resident_total = 0;        // value d_resident reaches once every workgroup of every launch so far has started
     long long *d_prof = nullptr;   // diagnostics, allocated by t2gpu_ldpc_profile()
     // host-call staging
     int8_t *d_in = nullptr;
@@ -95,6 +97,8 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     h->sync_words = (size_t)(max_frames + 1) * 64;   // enough for group >= 1 and max_trials <= 63
     if ((e = hipMalloc(&h->d_sync, h->sync_words * 4)) != hipSuccess) return fail("hipMalloc sync", e);
     if ((e = hipMalloc(&h->d_error, 4)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipExtMallocWithFlags(reinterpret_cast<void **>(&h->d_resident), 8, hipMallocSignalMemory)) != hipSuccess) return fail("hipExtMallocWithFlags", e);
+    if ((e = hipMemset(h->d_resident, 0, 8)) != hipSuccess) return fail("hipMemset", e);
     return h;
 }
 
@@ -102,6 +106,7 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
     hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_cninfo); hipFree(h->d_state);
+    hipFree(h->d_resident);
     hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     delete h;
 }
@@ -157,6 +162,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.lds_rec_offset = h->lds_rec_offset;
     p.lds_sign_offset = h->lds_sign_offset;
     p.prof = h->d_prof;
+    p.resident = h->d_resident;
     if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long), s));
     // One persistent launch walks all batches (best when batches take different numbers of sweeps). T2GPU_LDPC_ROUNDS_PER_LAUNCH=r
     // cuts it into launches of r rounds of `nslots` batches: workgroups of other streams that need a whole CU's LDS (the 32K FFT)
@@ -164,6 +170,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     int rounds = 0;
     if (const char *r = std::getenv("T2GPU_LDPC_ROUNDS_PER_LAUNCH")) rounds = std::atoi(r);
     if (rounds < 1 || (long)rounds * nslots >= nbatches) {
+        h->resident_total += (unsigned)grid;
         T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
         return 0;
     }
@@ -178,8 +185,19 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         q.trials_left = d_trials_left + b0;
         q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
         const int slots = std::min(nslots, nb);
+        h->resident_total += (unsigned)(slots * group);
         T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
     }
+    return 0;
+}
+
+// The decoder's workgroups are persistent and the 32 of a SIMD batch meet at every sweep: a workgroup that finds no room on
+// the device because another stream's kernels got there first stalls its whole batch. A stream that wants to run beside the
+// decoder enqueues this wait first: it holds the stream until every workgroup of every decode enqueued so far has started.
+extern "C" int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream)
+{
+    if (!h) return -1;
+    T2_HIP(hipStreamWaitValue32((hipStream_t)stream, h->d_resident, h->resident_total, hipStreamWaitValueGte, 0xffffffffu));
     return 0;
 }
 

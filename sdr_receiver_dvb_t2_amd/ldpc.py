@@ -59,6 +59,12 @@ class ldpc_decoder(object):
               "t2gpu_ldpc_execute_dev")
         return (bits, trials, llr_out) if want_llr else (bits, trials)
 
+    def wait_resident(self, stream=None):
+        """Hold `stream` (default: torch's current one) until all workgroups of the decodes enqueued so far have started."""
+        import torch
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        check(self._l.t2gpu_ldpc_wait_resident(self._h, s), "t2gpu_ldpc_wait_resident")
+
     def status(self):
         return self._l.t2gpu_ldpc_status(self._h)
 

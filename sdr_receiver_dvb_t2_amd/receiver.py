@@ -75,6 +75,10 @@ class t2_receiver(object):
     #   sa: front end, P1, guard correlation of buffer k;  equalisers, TI, demapper statistics of buffer k-1
     #   sf: FFT of buffer k          sd: LLR pass of buffer k-1          sb: LDPC + descrambler of buffer k-1
     # with events for the true dependencies; the result returned by call k belongs to buffer k-1 (None for the first call).
+    # MEASURED (round 1, MI355X, CFG-A): running anything beside the decoder costs more than it hides. The 32 workgroups of a SIMD
+    # batch meet at every sweep, so one workgroup slowed by a neighbour on its CU slows its whole batch: the decode goes from
+    # 31.3 ms to 35-42 ms (10-step runs) while only ~3 ms of other work is hidden. The default is therefore T2GPU_PIPE_SERIAL=1:
+    # same stages and streams, each call drained before the next; T2GPU_PIPE_SERIAL=0 enables the overlapped schedule.
     def pipeline_step(self, d_i, d_q, n_frames, level_detect, first_call=False):
         torch = self.torch
         c, o = self.chain, self.chain.ofdm
@@ -82,7 +86,7 @@ class t2_receiver(object):
             import os
             hi = int(os.environ.get("T2GPU_PIPE_LDPC_PRIORITY", "0"))           # lower number = higher priority; equal measured best
             mk = lambda prio=0: torch.cuda.Stream(device=c.dev, priority=prio)
-            self._pipe = dict(sa=mk(), sf=mk(), sd=mk(), sb=mk(hi), k=0, serial=bool(int(os.environ.get("T2GPU_PIPE_SERIAL", "0"))), prev=None, fft_done=None, eq_done=None, llr_done=None,
+            self._pipe = dict(sa=mk(), sf=mk(), sd=mk(), sb=mk(hi), k=0, serial=bool(int(os.environ.get("T2GPU_PIPE_SERIAL", "1"))), prev=None, fft_done=None, eq_done=None, llr_done=None,
                               ldpc_done=None,
                               spec=torch.empty((self.max_frames * c.n_sym, o.fft_size, 2), dtype=torch.float32, device=c.dev))
         pp = self._pipe
@@ -91,6 +95,8 @@ class t2_receiver(object):
         out = None
         cur = None
         with torch.cuda.stream(sa):
+            if pp["ldpc_done"] is not None and not pp["serial"]:
+                c.ldpc.wait_resident()                                           # beside the decoder, not ahead of it (see t2gpu.h)
             if d_i is not None:
                 if pp["fft_done"] is not None:
                     sa.wait_event(pp["fft_done"])                                # the FFT that still reads the sample stream
