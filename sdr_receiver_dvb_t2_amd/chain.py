@@ -22,7 +22,7 @@ L1_PRE_CELL = 1840      # dvbt2_definition.h:58
 class t2_chain(object):
     def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size,
                  plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames=4, device=0, ldpc_group=32,
-                 ldpc_trials=25, saturate_llr=False):
+                 ldpc_trials=25, saturate_llr=False, time_il_length=1):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
@@ -38,6 +38,12 @@ class t2_chain(object):
         self.cells_per_fec = self.fec_size // (2 * (plp_mod + 1))
         self.num_blocks = plp_num_blocks
         assert plp_num_blocks * self.cells_per_fec <= self.frame_cells
+        # TI blocks of one interleaving frame (time_il_type 0: time_il_length blocks per T2 frame), FEC blocks in each as
+        # time_deinterleaver::l1_dyn_execute splits them (time_deinterleaver.cpp:275-285): the later blocks take the remainder
+        n_ti = max(1, time_il_length)
+        base = plp_num_blocks // n_ti
+        self.ti_blocks = [base + (1 if j >= n_ti - plp_num_blocks % n_ti else 0) for j in range(n_ti)]
+        assert sum(self.ti_blocks) == plp_num_blocks and min(self.ti_blocks) >= 1
         self.ti = [time_deinterleaver(plp_mod, plp_fec_type, plp_num_blocks, device) for _ in range(max_frames)]
         self.demap = llr_demapper(plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks * self.cells_per_fec, device,
                                   saturate=saturate_llr)
@@ -112,13 +118,15 @@ class t2_chain(object):
         """From the equalised, frequency-de-interleaved cells of F frames already in self.cells[:F] (PLP cells of P2, then of every
         data symbol, then of the frame-closing symbol) to descrambled BBFRAME bits."""
         torch = self.torch
-        n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
-            self.ti[f].l1_dyn(self.num_blocks)
-            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
-            assert done
-            a = self.carry + f * self.num_blocks
-            self.demap.execute_dev(self.ti_out[f], out=self.llr[a:a + self.num_blocks])
+            a, c0 = self.carry + f * self.num_blocks, 0
+            for nbk in self.ti_blocks:                           # one TI block after the other, each with its own SNR estimate
+                n = nbk * self.cells_per_fec
+                self.ti[f].l1_dyn(nbk)
+                done = self.ti[f].execute_dev(self.cells[f, c0:c0 + n], self.ti_out[f, c0:c0 + n])
+                assert done
+                self.demap.execute_dev(self.ti_out[f, c0:c0 + n], out=self.llr[a:a + nbk])
+                a, c0 = a + nbk, c0 + n
         total = self.carry + F * self.num_blocks
         ready = total if flush else (total // self.group) * self.group
         if ready == 0:
@@ -144,7 +152,7 @@ class t2_chain(object):
         torch = self.torch
         if not hasattr(self, "llr2"):
             self.llr2 = [self.llr, torch.empty_like(self.llr)]
-        assert self.carry == 0
+        assert self.carry == 0 and len(self.ti_blocks) == 1
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
             self.ti[f].l1_dyn(self.num_blocks)
@@ -160,6 +168,7 @@ class t2_chain(object):
             self.llr2 = [self.llr, torch.empty_like(self.llr)]
         if not hasattr(self, "sums"):
             self.sums = torch.zeros((self.max_frames, 4), dtype=torch.float32, device=self.dev)
+        assert len(self.ti_blocks) == 1, "the staged schedule covers one TI block per frame"
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
             self.ti[f].l1_dyn(self.num_blocks)

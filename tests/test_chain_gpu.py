@@ -75,3 +75,39 @@ def test_cfg_a_reference_semantics_drops_every_batch(torch_cuda):
     nothing -- the chain reports exactly that instead of inventing output."""
     got, ts, nb = run_chain(torch_cuda, (5, 1, 6, 4, 0, 59), 350, 3, 1, 3, 22.0, n_frames=1, seed=11, saturate=False, expect_ok=False)
     assert got.size == 0
+
+
+def test_three_ti_blocks_per_frame(torch_cuda):
+    """time_il_type 0 with time_il_length 3: the frame's FEC blocks are split into three TI blocks (sizes as
+    time_deinterleaver::l1_dyn_execute computes them, the later blocks take the remainder), each interleaved on its own and
+    each with its own SNR estimate in the demapper."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    mode, lps, mod, fec_type, code_rate, snr = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 14.0
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    assert nb % 3 != 0                                                       # uneven split: exercises the remainder rule
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(nb * (k_bch // 1496 + 1) + 8, 5)
+    frames, used = t2_tx.bbframes_hem(ts, k_bch, nb)
+    cells = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(frames)), mod, fec_type, code_rate, True)
+    base = nb // 3
+    sizes = [base + (1 if j >= 3 - nb % 3 else 0) for j in range(3)]
+    stream, pos = [], 0
+    for n in sizes:
+        stream.append(t2_tx.interleave_ti_block(cells[pos:pos + n]))
+        pos += n
+    sym = t2_tx.build_frame(m, np.concatenate(stream), lps, 9, snr_db=snr, phase=0.5)
+    chain = pkg.t2_chain(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1, time_il_length=3)
+    assert chain.ti_blocks == sizes
+    x = torch.from_numpy(sym[None].view(np.float32).reshape(1, m.len_frame, m.fft_size, 2)).cuda()
+    bits, trials = chain.demod_dev(x, flush=True)
+    torch.cuda.synchronize()
+    t = trials.cpu().numpy()
+    assert (t >= 0).all(), t
+    got = chain.ts_from_bits(bits.cpu().numpy(), t)
+    n_pkts = (nb * ((k_bch - 80) // 8)) // 187 - 1
+    assert np.array_equal(got[:n_pkts * 188], ts.reshape(-1)[:n_pkts * 188])
+    chain.close()
