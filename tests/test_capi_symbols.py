@@ -67,3 +67,15 @@ def test_create_without_gpu_fails_loudly(built):
     import sdr_receiver_dvb_t2_amd as pkg
     with pytest.raises(pkg.T2GpuError):
         pkg.ldpc_decoder(1, 3)
+
+
+def test_cpp_host_header_compiles(built, tmp_path):
+    """include/t2gpu_stages.hpp (the reference's stage classes over the C ABI) and its test driver build with a plain g++."""
+    import subprocess
+    import sdr_receiver_dvb_t2_amd as pkg
+    out = str(tmp_path / "stage_mirror_test")
+    pkgdir = os.path.dirname(pkg.library_path())
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "stage_mirror_test.cpp"), "-L" + pkgdir, "-lt2gpu",
+                           "-Wl,-rpath," + pkgdir, "-o", out])
+    assert os.path.getsize(out) > 10000

@@ -183,3 +183,22 @@ def test_cp_correlation_matches_oracle(torch_cuda):
             fe, sm = ol.ora_cp_frequency_est(syms[s], fft_size, guard)
             assert abs(out[s, 0] - sm.real) <= 2e-5 * abs(sm) and abs(out[s, 1] - sm.imag) <= 2e-5 * abs(sm)
             assert abs(out[s, 2] - fe) <= 1e-9 + 1e-4 * abs(fe)
+
+
+def test_decimator_and_farrow_against_reference_vectors(torch_cuda):
+    """Straight against what the reference's own filter_decimator / interpolator_farrow classes produced (tests/golden/
+    dsp_golden.npz, compiled from the reference sources without fast-math): bit for bit."""
+    import os
+    from sdr_receiver_dvb_t2_amd import front
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dsp_golden.npz"))
+    x = g["x"]
+    f = front.front_end(max_samples=1 << 14)
+    pos, parts = 0, []
+    for n in g["decim_lens"]:
+        parts.append(f.decimate(x[pos:pos + int(n)]))
+        pos += int(n)
+    assert np.array_equal(bits(np.concatenate(parts)), bits(g["decim_strict"]))
+    for k, r in enumerate(g["farrow_ratios"]):
+        f = front.front_end(sample_rate=front.SAMPLE_RATE * 2 * min(float(r), 0.5), max_samples=1 << 14)
+        y = np.concatenate([f.farrow(x[:3000], float(r)), f.farrow(x[3000:], float(r))])
+        assert np.array_equal(bits(y), bits(g["farrow%d_strict" % k]))

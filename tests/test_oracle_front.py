@@ -97,3 +97,44 @@ def test_front_chunk_properties():
     assert np.allclose(np.abs(out2), np.abs(out2 * 0 + out2), atol=0)
     ph = np.unwrap(np.angle(out2[100:2000] / (x[100:2000] * st["c2"] + 1e-9)))
     assert abs(np.polyfit(np.arange(len(ph)), ph, 1)[0] + 1.0e-3) < 2e-4       # rotates by -frequency_est_filtered per sample
+
+
+def test_restatement_against_committed_reference_vectors():
+    """The same pinning without oracle/_ref: tests/golden/dsp_golden.npz holds what the reference's own classes produced
+    (tests/golden/make_dsp_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dsp_golden.npz"))
+    x = g["x"]
+    d, pos, parts = ol.OraDecim(), 0, []
+    for n in g["decim_lens"]:
+        parts.append(d(x[pos:pos + int(n)]))
+        pos += int(n)
+    got = np.concatenate(parts)
+    assert np.array_equal(got.view(np.uint32), g["decim_strict"].view(np.uint32))
+    np.testing.assert_allclose(got, g["decim_fast"], rtol=0, atol=3e-7)
+    for k, r in enumerate(g["farrow_ratios"]):
+        f = ol.OraFarrow()
+        y = np.concatenate([f(x[:3000], float(r)), f(x[3000:], float(r))])
+        assert len(y) == len(g["farrow%d_strict" % k]) == len(g["farrow%d_fast" % k])
+        assert np.array_equal(y.view(np.uint32), g["farrow%d_strict" % k].view(np.uint32))
+        np.testing.assert_allclose(y, g["farrow%d_fast" % k], rtol=0, atol=2e-6)
+    o = ol.oracle()
+    o.ora_exp_avg.restype = ctypes.c_float
+    o.ora_exp_avg.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    st = ctypes.c_float(0.0)
+    avg = np.array([o.ora_exp_avg(ctypes.byref(st), 1.0e-6, float(v)) for v in g["avg_in"][:3000]], np.float32)
+    assert np.array_equal(avg.view(np.uint32), g["avg_out"][:3000].view(np.uint32))
+    o.ora_pi_init.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    o.ora_pi_step.restype = ctypes.c_float
+    o.ora_pi_step.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+    fs = int(np.float32(1.0) / (np.float32(1.0e-6) * np.float32(7.0) / np.float32(64.0)))
+    for which, damping, bw in ((0, 0.3, 1000000), (1, 0.7, 4000000)):
+        s = ol.OraPi()
+        o.ora_pi_init(ctypes.byref(s), damping, bw, fs)
+        lim = float(g["pi%d_lim" % which])
+        got = np.array([o.ora_pi_step(ctypes.byref(s), float(e), lim) for e in g["pi%d_in" % which]], np.float32)
+        assert np.array_equal(got.view(np.uint32), g["pi%d_out" % which].view(np.uint32))
+    for ln in (482, 542):
+        b = np.zeros_like(x)
+        o.ora_sum_run(ln, len(x), x.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(b.view(np.uint32), g["sum%d" % ln].view(np.uint32))
