@@ -30,7 +30,11 @@ struct EqParams {
     // positions from symbol_index[].
     int per_frame = 0, first = 0, in_syms_per_frame = 0;
     long out_frame_stride = 0, out_offset = 0;
+    // LDS staging of the equaliser (EQ_GROUP consecutive segments per workgroup): the widest carrier span / data-cell span any
+    // group of this table covers (host-computed, sizes the dynamic LDS)
+    int lds_span = 0, lds_dspan = 0;
 };
+constexpr int EQ_GROUP = 64;
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);
 

@@ -203,10 +203,18 @@ __device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, flo
     return p;
 }
 
-__global__ __launch_bounds__(128) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
-                                                     const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
-                                                     float4 *__restrict__ pilot_scratch)
+// One workgroup = EQ_GROUP consecutive segments of one symbol, one lane per segment. The group's carriers (one contiguous run),
+// their carrier types and the de-interleaver indices of its data cells are first copied into LDS with coalesced loads -- in
+// global memory neighbouring lanes are a whole pilot spacing (up to 96 carriers = 768 B) apart, which made the kernel fetch five
+// times its algorithmic bytes. The LDS index is skewed by one word per 32 so that the per-lane stride becomes odd (bank-conflict
+// free); real and imaginary parts in separate planes.
+__device__ __forceinline__ int eq_skew(int i) { return i + (i >> 5); }
+
+__global__ __launch_bounds__(EQ_GROUP) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
+                                                          const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
+                                                          float4 *__restrict__ pilot_scratch)
 {
+    extern __shared__ __attribute__((aligned(16))) float eq_lds[];
     const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
     const float PI = 3.14159274101257324219f;
     const int b = blockIdx.y;                                                   // symbol of the batch
@@ -214,36 +222,69 @@ __global__ __launch_bounds__(128) void eq_data_kernel(EqParams p, const float2 *
     const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];        // position in the T2 frame (P2 = 0)
     const int row = idx_symbol - p.n_p2;                                        // data-symbol table row
     const int nseg = p.seg_count[row];
-    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= nseg) return;
+    const int seg0 = blockIdx.x * EQ_GROUP;
+    if (seg0 >= nseg) return;
+    const int seg1 = min(nseg, seg0 + EQ_GROUP) - 1;
+    const int seg = seg0 + threadIdx.x;
     const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
     const uint8_t *map = p.map + (size_t)row * p.k_total;
     const float *refer = p.refer + (size_t)row * p.k_total;
     const int32_t *h = (idx_symbol & 1) ? p.h_even : p.h_odd;                   // data_symbol.cpp:148-149
     float2 *o = p.per_frame ? out + (size_t)fr * p.out_frame_stride + p.out_offset + (size_t)lo * p.c_data : out + (size_t)b * p.c_data;
-    const int4 sg = p.segs[(size_t)row * p.max_seg + seg];                      // left pilot, right pilot, d start, data count
+    const int4 *segs = p.segs + (size_t)row * p.max_seg;
+    const int4 sgf = segs[seg0], sgl = segs[seg1];
+    const int c0 = sgf.x, span = sgl.y - sgf.x + 1, d0 = sgf.z, dspan = sgl.z + sgl.w - sgf.z;
+    float *l_re = eq_lds, *l_im = l_re + eq_skew(p.lds_span) + 1;
+    uint16_t *l_h = reinterpret_cast<uint16_t *>(l_im + eq_skew(p.lds_span) + 1);
+    uint8_t *l_map = reinterpret_cast<uint8_t *>(l_h + ((p.lds_dspan + 1) & ~1));
+    for (int i = threadIdx.x; i < span; i += EQ_GROUP) {
+        const float2 v = cell[c0 + i];
+        l_re[eq_skew(i)] = v.x; l_im[eq_skew(i)] = v.y;
+        l_map[i] = map[c0 + i];
+    }
+    for (int i = threadIdx.x; i < dspan; i += EQ_GROUP) l_h[i] = (uint16_t)h[d0 + i];
+    __syncthreads();
+    if (seg > seg1) return;
+    const int4 sg = segs[seg];                                                  // left pilot, right pilot, d start, data count
     const int pl = sg.x, pr = sg.y, n = sg.w;
-    int d = sg.z;
+    int d = sg.z - d0;
+    auto ld = [&](int c) { const int k = eq_skew(c - c0); return make_float2(l_re[k], l_im[k]); };
     // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
     // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
-    const uint8_t tl = map[pl], tr = map[pr];
-    const PilotEst L = pilot_estimate(cell[pl], refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
-    const PilotEst R = pilot_estimate(cell[pr], refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
+    const uint8_t tl = l_map[pl - c0], tr = l_map[pr - c0];
+    const PilotEst L = pilot_estimate(ld(pl), refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
+    const PilotEst R = pilot_estimate(ld(pr), refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
     float dif_angle = R.angle - L.angle;
     if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                      // as written in the reference (:189-191)
     else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
     const float delta_angle = dif_angle / (float)(n + 1);
     const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
     float angle_est = L.angle, amp_est = L.amp;
-    for (int i = pl + 1; i < pr; ++i) {
-        if (map[i] != T2_DATA) continue;                                        // reserved tones / the unused centre pilot
-        angle_est += delta_angle;
-        amp_est += delta_amp;
-        const int li = (int)(angle_est * K_TABLE + 32767) & 65535;
-        const float dr = p.lut_cos[li] / amp_est, di = p.lut_sin[li] / amp_est;
-        const float2 c = cell[i];
-        o[h[d]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);        // buffer_cell[j] * conj(derotate)
-        ++d;
+    const float *__restrict__ lut_c = p.lut_cos, *__restrict__ lut_s = p.lut_sin;
+    // Same float operations in the same order as the reference's loop; only the two table reads of eight cells are issued
+    // together ahead of their use (the angle / amplitude recurrences do not depend on them), which hides the L2 latency that a
+    // lone wavefront per workgroup cannot hide by itself.
+    constexpr int U = 8;
+    for (int i0 = pl + 1; i0 < pr; i0 += U) {
+        float amp[U], cr[U], sr[U];
+        bool isd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            isd[u] = i < pr && l_map[i - c0] == T2_DATA;                        // reserved tones / the unused centre pilot are skipped
+            if (isd[u]) { angle_est += delta_angle; amp_est += delta_amp; }
+            amp[u] = amp_est;
+            const int li = (int)(angle_est * K_TABLE + 32767) & 65535;
+            cr[u] = lut_c[li]; sr[u] = lut_s[li];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!isd[u]) continue;
+            const float dr = cr[u] / amp[u], di = sr[u] / amp[u];
+            const float2 c = ld(i0 + u);
+            o[l_h[d]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);  // buffer_cell[j] * conj(derotate)
+            ++d;
+        }
     }
     // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
     float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
@@ -272,8 +313,16 @@ __global__ void eq_sync_kernel(EqParams p, const int32_t *__restrict__ symbol_in
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s)
 {
-    dim3 grid((p.max_seg + 127) / 128, n_symbols);
-    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(128), 0, s, p, symbols, symbol_index, out, pilot_scratch);
+    const int words = 2 * (p.lds_span + (p.lds_span >> 5) + 1);                           // two skewed float planes
+    const int lds_bytes = words * 4 + ((p.lds_dspan + 1) & ~1) * 2 + ((p.lds_span + 15) & ~15);
+    static int attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_data_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_bytes = lds_bytes;
+    }
+    dim3 grid((p.max_seg + EQ_GROUP - 1) / EQ_GROUP, n_symbols);
+    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(EQ_GROUP), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch);
     if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3((n_symbols + 63) / 64), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
     return hipGetLastError();
 }

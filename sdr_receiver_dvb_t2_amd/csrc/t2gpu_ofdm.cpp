@@ -186,11 +186,13 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     up(&h->d_h_odd_p2, ho2.data(), ho2.size() * 4);
     // the frame-closing symbol (when the mode has one): pilots every dx carriers, n_fc cells, its own de-interleaver
     int nseg3 = 0;
+    std::vector<int4> seg3_keep;
     if (m.l_fc) {
         std::vector<uint8_t> mp3; std::vector<float> rf3; std::vector<int4> seg3;
         t2_symbol_carriers(m, m.len_frame - 1, mp3, rf3);
         if (build_segments(mp3, K, seg3) != m.n_fc) { set_error("frame-closing carrier map does not hold n_fc data cells"); t2gpu_ofdm_destroy(h); return nullptr; }
         nseg3 = (int)seg3.size();
+        seg3_keep = seg3;
         const int32_t n3 = nseg3, fcidx = m.len_frame - 1;
         std::vector<int32_t> he3, ho3;
         t2_freq_deint(m, 2, he3, ho3);
@@ -213,6 +215,17 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
                             h->d_segs_fc, h->d_seg_count_fc, h->d_h_even_fc, h->d_h_odd_fc, h->d_lut, h->d_lut + 65536};
     h->eq_p2 = EqParams{N, m.l_nulls, K, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
                         h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut, h->d_lut + 65536};
+    // widest carrier / data-cell span of any EQ_GROUP consecutive segments, per table (sizes the equaliser's LDS staging)
+    auto spans = [](const std::vector<int4> &sg, int &span, int &dspan) {
+        for (size_t g0 = 0; g0 < sg.size(); g0 += EQ_GROUP) {
+            const size_t g1 = std::min(sg.size(), g0 + EQ_GROUP) - 1;
+            span = std::max(span, sg[g1].y - sg[g0].x + 1);
+            dspan = std::max(dspan, sg[g1].z + sg[g1].w - sg[g0].z);
+        }
+    };
+    for (int r = 0; r < rows; ++r) spans(segs[r], h->eq.lds_span, h->eq.lds_dspan);
+    spans(seg2, h->eq_p2.lds_span, h->eq_p2.lds_dspan);
+    if (m.l_fc) spans(seg3_keep, h->eq_fc.lds_span, h->eq_fc.lds_dspan);
     return h;
 }
 
