@@ -209,8 +209,12 @@ __device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, flo
 // times its algorithmic bytes. The LDS index is skewed by one word per 32 so that the per-lane stride becomes odd (bank-conflict
 // free); real and imaginary parts in separate planes.
 __device__ __forceinline__ int eq_skew(int i) { return i + (i >> 5); }
+// EQ_SPLIT lanes share one segment: every lane runs the (cheap) angle / amplitude recurrences over all cells, so all see the
+// reference's exact sequence of values, and does the table reads, divisions and the store for every EQ_SPLIT-th data cell.
+// Four times the wavefronts for the same LDS footprint, which is what hides the latency of this kernel.
+constexpr int EQ_SPLIT = 4;
 
-__global__ __launch_bounds__(EQ_GROUP) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
+__global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
                                                           const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
                                                           float4 *__restrict__ pilot_scratch)
 {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(EQ_GROUP) void eq_data_kernel(EqParams p, const flo
     const int seg0 = blockIdx.x * EQ_GROUP;
     if (seg0 >= nseg) return;
     const int seg1 = min(nseg, seg0 + EQ_GROUP) - 1;
-    const int seg = seg0 + threadIdx.x;
+    const int seg = seg0 + threadIdx.x / EQ_SPLIT, sub = threadIdx.x % EQ_SPLIT;
     const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
     const uint8_t *map = p.map + (size_t)row * p.k_total;
     const float *refer = p.refer + (size_t)row * p.k_total;
@@ -237,12 +241,12 @@ __global__ __launch_bounds__(EQ_GROUP) void eq_data_kernel(EqParams p, const flo
     float *l_re = eq_lds, *l_im = l_re + eq_skew(p.lds_span) + 1;
     uint16_t *l_h = reinterpret_cast<uint16_t *>(l_im + eq_skew(p.lds_span) + 1);
     uint8_t *l_map = reinterpret_cast<uint8_t *>(l_h + ((p.lds_dspan + 1) & ~1));
-    for (int i = threadIdx.x; i < span; i += EQ_GROUP) {
+    for (int i = threadIdx.x; i < span; i += EQ_GROUP * EQ_SPLIT) {
         const float2 v = cell[c0 + i];
         l_re[eq_skew(i)] = v.x; l_im[eq_skew(i)] = v.y;
         l_map[i] = map[c0 + i];
     }
-    for (int i = threadIdx.x; i < dspan; i += EQ_GROUP) l_h[i] = (uint16_t)h[d0 + i];
+    for (int i = threadIdx.x; i < dspan; i += EQ_GROUP * EQ_SPLIT) l_h[i] = (uint16_t)h[d0 + i];
     __syncthreads();
     if (seg > seg1) return;
     const int4 sg = segs[seg];                                                  // left pilot, right pilot, d start, data count
@@ -267,29 +271,34 @@ __global__ __launch_bounds__(EQ_GROUP) void eq_data_kernel(EqParams p, const flo
     constexpr int U = 8;
     for (int i0 = pl + 1; i0 < pr; i0 += U) {
         float amp[U], cr[U], sr[U];
-        bool isd[U];
+        int dd[U];
+        bool mine[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u;
-            isd[u] = i < pr && l_map[i - c0] == T2_DATA;                        // reserved tones / the unused centre pilot are skipped
-            if (isd[u]) { angle_est += delta_angle; amp_est += delta_amp; }
+            const bool data = i < pr && l_map[i - c0] == T2_DATA;               // reserved tones / the unused centre pilot are skipped
+            if (data) { angle_est += delta_angle; amp_est += delta_amp; }
+            mine[u] = data && (d & (EQ_SPLIT - 1)) == sub;                      // this lane's share: every EQ_SPLIT-th data cell
+            dd[u] = d;
+            d += data ? 1 : 0;
             amp[u] = amp_est;
-            const int li = (int)(angle_est * K_TABLE + 32767) & 65535;
+            const int li = mine[u] ? ((int)(angle_est * K_TABLE + 32767) & 65535) : 0;
             cr[u] = lut_c[li]; sr[u] = lut_s[li];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!isd[u]) continue;
+            if (!mine[u]) continue;
             const float dr = cr[u] / amp[u], di = sr[u] / amp[u];
             const float2 c = ld(i0 + u);
-            o[l_h[d]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);  // buffer_cell[j] * conj(derotate)
-            ++d;
+            o[l_h[dd[u]]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);   // buffer_cell[j] * conj(derotate)
         }
     }
     // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
     float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
-    if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);                  // first pilot: no angle term (:153-162)
-    ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
+    if (sub == 0) {
+        if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);              // first pilot: no angle term (:153-162)
+        ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
+    }
 }
 
 // phase_offset = atan2(sum_pilot_2) + atan2(sum_pilot_1), sample_rate_offset = sum_angle_2 - sum_angle_1 (:319-324)
@@ -322,7 +331,7 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         attr_bytes = lds_bytes;
     }
     dim3 grid((p.max_seg + EQ_GROUP - 1) / EQ_GROUP, n_symbols);
-    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(EQ_GROUP), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch);
+    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(EQ_GROUP * EQ_SPLIT), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch);
     if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3((n_symbols + 63) / 64), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
     return hipGetLastError();
 }
