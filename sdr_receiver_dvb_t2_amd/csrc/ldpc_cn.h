@@ -264,6 +264,7 @@ struct LayerDesc {
     const uint32_t *ent;
     int cnt, lmax, nc, kind, step;
     int dummy;      // address of a scratch byte in the LLR memory: target of the stores a chain walker predicates away
+    uint32_t e0;    // ent[0], fetched when the descriptor is made (the chain walker needs it right behind a barrier)
 };
 
 // phase A: every node loads; PLAIN nodes and chain-start / level-free nodes finish at once
@@ -302,7 +303,7 @@ template <class LMEM>
 T2_HD void t2_pair_walk(LMEM &L, const LayerDesc &d, int lane, const uint32_t *pair_rec)
 {
     constexpr int B = 4;
-    const uint32_t e0 = d.ent[0];
+    const uint32_t e0 = d.e0;
     const int base = (int)(e0 & 0xffffu) + L.off(), s0 = (int)(e0 >> 16), step = d.step;
     int m = lane - s0;                                   // position of the shared bit inside its 360-bit group
     m += (m < 0) ? 360 : 0;
@@ -330,12 +331,19 @@ T2_HD void t2_pair_walk(LMEM &L, const LayerDesc &d, int lane, const uint32_t *p
             }
         }
     }
-    // the remaining nodes of this lane's chain (fewer than B + 1)
-#pragma unroll
-    for (int u = 0; u < B + 1; ++u) {
-        const int q = jj + u * step;
-        const bool live = q + step < 360;
-        const PairRec r = t2_pair_unpack(pair_rec[q < 359 ? q : 359]);
+    // the rest of the common part (fewer than B nodes, same count for every lane) ...
+    for (; k < n_common; ++k) {
+        const PairRec r = t2_pair_unpack(pair_rec[jj]);
+        const unsigned t = (unsigned)(m + step);
+        m = (int)(t < t - 360u ? t : t - 360u);
+        X = t2_pair_step(r, X);
+        L.st(base + m, (int8_t)X);
+        jj += step;
+    }
+    // ... and the one node more that the chains of the low lanes have
+    {
+        const bool live = jj + step < 360;
+        const PairRec r = t2_pair_unpack(pair_rec[jj < 359 ? jj : 359]);
         const unsigned t = (unsigned)(m + step);
         m = (int)(t < t - 360u ? t : t - 360u);
         const int Xn = t2_pair_step(r, X);

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
                 uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
                 for (int i = 0; i < p.q; ++i) {
                     const LdpcLayerDev ly = layers[i];
-                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32};
+                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry]};
                     const uint32_t info = info_nxt;
                     const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
                     const int a0 = L.off() + p.k + 360 * i + jn, a1r = parity_prev_addr(p.k, p.q, i, jn);

@@ -42,7 +42,7 @@ template <int CNT>
 void emu_layer(Mem &L, const LdpcGraph &g, int i, CnState *st, Order &ord)
 {
     const LdpcLayer &ly = g.layers[i];
-    LayerDesc d{&g.entries[ly.first_entry], ly.cnt, ly.lmax, ly.n_conflict, ly.kind, ly.step, g.n};   // scratch byte behind the LLRs
+    LayerDesc d{&g.entries[ly.first_entry], ly.cnt, ly.lmax, ly.n_conflict, ly.kind, ly.step, g.n, g.entries[ly.first_entry]};   // scratch byte behind the LLRs
     std::vector<CnRegs<CNT>> regs(360);
     std::vector<uint32_t> rec(360, 0xdeadbeefu);
     auto a0 = [&](int j) { return g.k + 360 * i + j; };
