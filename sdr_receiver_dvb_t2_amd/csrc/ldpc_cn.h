@@ -139,13 +139,17 @@ T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, in
                 ((uint32_t)((-B) & 0xff) << 24);
     }
     r.n0 = 0; r.n1 = 0;
+    // three passes -- addresses, loads, arithmetic -- so that the CNT + 2 LDS reads are in flight together
 #pragma unroll
     for (int c = 0; c < CNT + 2; ++c) {
         // L.off(): where the LLR array starts in the memory L addresses (the LDS offset on the GPU; folded into the table entry's
         // base by scalar arithmetic, so the per-lane address needs no further add at the load or the store)
         r.addr[c] = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0] + (uint32_t)L.off(), j) : (c == CNT ? a_p0 : a_p1);
-        t2_read_slot<CNT>(L, r, c);
     }
+#pragma unroll
+    for (int c = 0; c < CNT + 2; ++c) r.in[c] = t2_present(r, c) ? (int)L.ld(r.addr[c]) : 0;
+#pragma unroll
+    for (int c = 0; c < CNT + 2; ++c) r.in[c] = t2_present(r, c) ? t2_clamp(r.in[c] - t2_old_msg(r, c), -128, 127) : 0;
 }
 
 // second smallest of {m0 <= m1, a} is the median; smallest is the min
@@ -373,20 +377,35 @@ T2_HD void t2_pair_finish(LMEM &L, const LayerDesc &d, int j, CnState &st, CnReg
 }
 
 // GENERIC level step lv (1-based): nodes of that level settle their conflict slots. All conflict slots are re-read
-// (batched, branch-free): a slot nobody touched earlier still holds the value read in phase A.
-template <int CNT, class LMEM>
-T2_HD void t2_generic_level(LMEM &L, const LayerDesc &d, int lv, uint32_t info, CnRegs<CNT> &r)
+// (batched, branch-free): a slot nobody touched earlier still holds the value read in phase A. NC (the layer's number of
+// conflict slots) is a template argument so that the loads of a step are issued back to back and waited for once -- with a
+// run-time bound every slot became its own load / wait / branch and a level step paid one LDS round trip per slot.
+template <int CNT, int NC, class LMEM>
+T2_HD void t2_generic_level_nc(LMEM &L, int lv, uint32_t info, CnRegs<CNT> &r)
 {
     if ((int)(info & 0xff) != lv) return;
     if (lv > 1) {
 #pragma unroll
-        for (int c = 0; c < T2_LDPC_NC_MAX; ++c)
-            if (c < CNT && c < d.nc) t2_read_slot<CNT>(L, r, c);
+        for (int c = 0; c < NC; ++c) t2_read_slot<CNT>(L, r, c);
     }
-    t2_cn_merge<CNT>(r, d.nc);
+    int m0 = r.p0, m1 = r.p1, sx = r.psx;
 #pragma unroll
-    for (int c = 0; c < T2_LDPC_NC_MAX; ++c)
-        if (c < CNT && c < d.nc) t2_write_slot<CNT>(L, r, c, true);
+    for (int c = 0; c < NC; ++c) { t2_min2(t2_rawmag<CNT>(r, c), m0, m1); sx ^= r.in[c]; }
+    r.m0 = m0; r.m0f = t2_f(m0); r.m1f = t2_f(m1); r.sx = sx;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t2_write_slot<CNT>(L, r, c, true);
+}
+
+// NCMAX: the largest conflict-slot count the code family of the calling kernel has (bounds the instances carried)
+template <int CNT, int NCMAX = T2_LDPC_NC_MAX, class LMEM>
+T2_HD void t2_generic_level(LMEM &L, const LayerDesc &d, int lv, uint32_t info, CnRegs<CNT> &r)
+{
+    switch (d.nc) {
+#define T2_NC_(n) case n: if constexpr (n <= CNT && n <= NCMAX) t2_generic_level_nc<CNT, n>(L, lv, info, r); break;
+        T2_NC_(2) T2_NC_(3) T2_NC_(4) T2_NC_(5) T2_NC_(6) T2_NC_(7) T2_NC_(8) T2_NC_(9) T2_NC_(10)
+#undef T2_NC_
+    default: break;
+    }
 }
 
 // GENERIC last phase: the private slots

@@ -130,7 +130,7 @@ __device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, 
         }                                                                                                           \
     } while (0)
 
-template <int CNT>
+template <int CNT, int NCMAX>
 __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int j, bool active, int a0, int a1,
                                              CnState &st, uint32_t info, uint32_t *pair_rec, long long *prof)
 {
@@ -152,7 +152,7 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
         T2_DTL(2, 3);
         __builtin_amdgcn_s_setprio(3);
         for (int lv = 1; lv <= d.lmax; ++lv) {
-            if (active) t2_generic_level<CNT>(L, d, lv, info, r);
+            if (active) t2_generic_level<CNT, NCMAX>(L, d, lv, info, r);
             lds_barrier();
         }
         __builtin_amdgcn_s_setprio(0);
@@ -170,7 +170,7 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
         if (p.prof && threadIdx.x == 0) p.prof[blockIdx.x * 8 + (slot)] += (long long)__builtin_readcyclecounter() - (t0); \
     } while (0)
 
-template <int LO, int HI>
+template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
 __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
                                                                   const uint32_t *__restrict__ cninfo, LdpcKernelParams p)
 {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
                         info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
                     }
                     T2_PROF_T(tp2);
-                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, layer_update<CNT>(L, d, jn, active, a0, a1, st, info, pair_rec, p.prof));
+                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_update<CNT, NCMAX>(L, d, jn, active, a0, a1, st, info, pair_rec, p.prof)));
                     if (!(T2_PROF_DETAIL && ly.kind == T2_PROF_DETAIL)) T2_PROF_ADD(2 + ly.kind, tp2);
                     if (active) state[i * 360 + j] = make_uint2(st.w0, st.w1);
                 }
@@ -298,14 +298,14 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
 typedef void (*ldpc_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, LdpcKernelParams);
 static ldpc_kernel_fn pick_kernel(int min_cnt, int max_cnt)
 {
-    if (min_cnt == max_cnt) {      // the six normal-frame codes have one link count each
-        switch (max_cnt) {
-        case 5: return ldpc_decode_kernel<5, 5>;
-        case 8: return ldpc_decode_kernel<8, 8>;
-        case 9: return ldpc_decode_kernel<9, 9>;
-        case 12: return ldpc_decode_kernel<12, 12>;
-        case 16: return ldpc_decode_kernel<16, 16>;
-        case 20: return ldpc_decode_kernel<20, 20>;
+    if (min_cnt == max_cnt) {      // the six normal-frame codes have one link count each; third argument = the most conflict
+        switch (max_cnt) {         // slots any of that code's layers has (ldpc_graph.cpp; checked by tests/test_capi_symbols.py)
+        case 5: return ldpc_decode_kernel<5, 5, 2>;      // N 1/2: no GENERIC layer
+        case 8: return ldpc_decode_kernel<8, 8, 4>;      // N 2/3
+        case 9: return ldpc_decode_kernel<9, 9, 4>;      // N 3/5
+        case 12: return ldpc_decode_kernel<12, 12, 4>;   // N 3/4
+        case 16: return ldpc_decode_kernel<16, 16, 7>;   // N 4/5
+        case 20: return ldpc_decode_kernel<20, 20, 6>;   // N 5/6
         default: break;
         }
     }

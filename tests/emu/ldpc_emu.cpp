@@ -120,3 +120,13 @@ extern "C" int emu_ldpc_graph_summary(int code_id, int *n_plain, int *n_pair, in
     *n_plain = c[0]; *n_pair = c[1]; *n_generic = c[2]; *serial_steps = g.serial_steps;
     return 0;
 }
+
+// largest number of conflict slots of any GENERIC layer of the code (0 when it has none)
+extern "C" int emu_ldpc_max_conflict(int code_id)
+{
+    LdpcGraph g;
+    if (!ldpc_build_graph(code_id, g)) return -1;
+    int m = 0;
+    for (const LdpcLayer &l : g.layers) if (l.kind == T2_LAYER_GENERIC) m = std::max(m, l.n_conflict);
+    return m;
+}

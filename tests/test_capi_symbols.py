@@ -79,3 +79,16 @@ def test_cpp_host_header_compiles(built, tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "stage_mirror_test.cpp"), "-L" + pkgdir, "-lt2gpu",
                            "-Wl,-rpath," + pkgdir, "-o", out])
     assert os.path.getsize(out) > 10000
+
+
+def test_conflict_slot_bounds_of_the_normal_codes(built):
+    """ldpc_kernel.hip instantiates the six normal-frame kernels with the largest conflict-slot count of their code; keep that
+    table honest against the graph builder (the emulator library exposes the graph)."""
+    import ctypes
+    import oracle_lib as ol
+    e = ol.emu()
+    if not hasattr(e, "emu_ldpc_max_conflict"):
+        pytest.skip("emulator without emu_ldpc_max_conflict")
+    want = {6: 2, 8: 4, 7: 4, 9: 4, 10: 7, 11: 6}
+    for cid, bound in want.items():
+        assert 0 <= e.emu_ldpc_max_conflict(cid) <= bound, cid
