@@ -30,7 +30,7 @@ LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600    # LLR in + one-bit-p
 # memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/r01_rx_pmc.txt, tools/pmc_passes.sh: this
 # bench's launch of 3232 frames x 25 sweeps): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE,
 # KiB -> bytes
-LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 4.746e6 + 1.0515e7) * 1024 / 3232 / 25
+LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 4.695e6 + 1.0491e7) * 1024 / 3232 / 25
 MODE = (5, 1, 6, 4, 0, 59)                  # FFTSIZE_32K, extended, PP7, GI 1/128, no PAPR, 59 data symbols
 L1_POST_SIZE = 350
 PLP = (3, 1, 3, 1)                          # 256-QAM, normal FEC frame, r = 3/4, rotated
@@ -230,7 +230,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": round(LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP * ldpc_frames * args.trials),
-                         "kernel": "ldpc_decode_kernel<12,12>", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
+                         "kernel": "ldpc_decode_kernel<12,12,4>", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
                          "share_of_step": round(avg_ldpc_s / (max_s / args.steps), 3),
                          "note": "the LDPC is VALU/LDS-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once; "
                                  "traffic = PMC-measured bytes per frame-sweep (profiles/r01_rx_pmc.txt) x frames x sweeps"},
