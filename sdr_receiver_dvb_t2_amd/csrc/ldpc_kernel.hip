@@ -225,7 +225,10 @@ __global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLaye
                     unsigned v;
                     long long t0 = wall_clock64();
                     int verdict = -1;
-                    for (;;) {
+                    // A frame that still fails its parity check knows the verdict without waiting: the batch goes on. Only
+                    // parity-clean frames have to learn whether all the others are clean too.
+                    if (!all_ok) verdict = 0;
+                    else for (;;) {
                         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((int)(v >> 16) >= members) { verdict = ((int)(v & 0xffffu) == members); break; }
                         if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
