@@ -106,8 +106,8 @@ int t2gpu_demap_llr_batch_dev(t2gpu_demap *h, const float *d_cells, int n_blocks
 
 /* ---------------------------------------------------------------- time / cell de-interleaver ----------------------
  * Replaces  void time_deinterleaver::execute(int len, complex* cells) / l1_dyn_execute(l1_post, len, cells)
- *           (src/DVB_T2/time_deinterleaver.h:33,44-45; time_deinterleaver.cpp:268-376) for one PLP with one TI block
- *           per T2 frame (TIME_IL_TYPE 0, TIME_IL_LENGTH 1 -- the reference's tested configuration):
+ *           (src/DVB_T2/time_deinterleaver.h:33,44-45; time_deinterleaver.cpp:268-376) for one TI block of one PLP
+ *           (TIME_IL_TYPE 0; which TI blocks a frame holds, for any number of PLPs: t2gpu_ti_frame_plan below):
  * time de-interleaving (N_split = 5), cell de-interleaving and removal of the cyclic Q delay in one scatter.
  * t2gpu_ti_begin(num_blocks) is the geometry step of l1_dyn_execute (PLP_NUM_BLOCKS of this frame); cells are then
  * pushed in arrival order, any number per call (the reference pushes one OFDM symbol at a time; the P2 symbol's
@@ -159,6 +159,25 @@ typedef struct {
 int t2gpu_l1_pre_parse(const float *p2_cells, t2gpu_l1_pre *out);
 int t2gpu_l1_post_parse(const float *l1_post_cells /* = p2_cells + 2*1840 */, const t2gpu_l1_pre *pre, t2gpu_l1_post *post,
                         t2gpu_l1_plp *plp /* [max_plp] */, t2gpu_l1_dyn_plp *dyn /* [max_plp] */, int max_plp);
+
+/* ---------------------------------------------------------------- frame de-multiplexer of the time de-interleaver (host) --
+ * The PLP / TI-block bookkeeping of  time_deinterleaver::start, l1_dyn_execute, execute  (src/DVB_T2/time_deinterleaver.cpp
+ * :38-145, :268-286, :296-312, :337-371) for any number of PLPs: which TI blocks the cell stream of one T2 frame holds, in the
+ * order the reference emits ti_block for them. The cell stream is what follows the L1 cells of P2 (frame_cells = its length:
+ * PLP cells of P2, of every data symbol and of the frame-closing symbol). Block k covers cells [offset, offset + size) and
+ * belongs to PLP index `plp` (index into plp[] / dyn[], which the reference also uses PLP_ID as, :360); it is de-interleaved by
+ * t2gpu_ti_begin(handle of that PLP, num_blocks) + t2gpu_ti_push[_dev]. Reproduced as the reference behaves:
+ *  - the frame starts with the PLP whose PLP_START is 0 (else the PLP the previous frame ended in: *plp_state, in/out);
+ *  - TIME_IL_TYPE 0 only: TIME_IL_LENGTH TI blocks per T2 frame, the later blocks take the remainder of PLP_NUM_BLOCKS;
+ *  - a PLP is followed by the PLP whose PLP_START is the next cell, provided the PLP ends where the reference computes its end
+ *    -- with the cell count per FEC block of PLP index 1 (:273-274), i.e. PLPs of one modulation and FEC type;
+ *  - otherwise the same PLP's geometry is applied to the following cells again (what comes out is noise for the LDPC to drop);
+ *  - a TI block that does not complete inside the frame is discarded at the next frame start.
+ * Returns the number of blocks written to out (<= max_out), -1 bad arguments, -2 TIME_IL_TYPE 1 (the reference writes past its
+ * per-PLP arrays for it and never collects cells over several frames), -3 out too small. */
+typedef struct { int32_t plp, offset, num_blocks, size; } t2gpu_ti_block;
+int t2gpu_ti_frame_plan(int num_plp, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn, int frame_cells, int *plp_state,
+                        t2gpu_ti_block *out, int max_out);
 
 /* ---------------------------------------------------------------- BBFRAME de-framing -> transport stream (host) -----
  * Replaces  void bb_de_header::execute(int plp_id, l1_postsignalling, int len_in, uint8_t* in)  (src/DVB_T2/bb_de_header.h:59,

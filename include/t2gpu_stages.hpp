@@ -9,7 +9,7 @@
 //   bch_decoder        src/DVB_T2/bch_decoder.h:26-58     t2::bch_decoder
 //   bb_de_header       src/DVB_T2/bb_de_header.h:37-110   t2::bb_de_header
 //   llr_demapper       src/DVB_T2/llr_demapper.h:29-48    t2::llr_demapper
-//   time_deinterleaver src/DVB_T2/time_deinterleaver.h    t2::time_deinterleaver  (one PLP, TI type 0: what the library covers)
+//   time_deinterleaver src/DVB_T2/time_deinterleaver.h    t2::time_deinterleaver  (any number of PLPs, TI type 0)
 //   filter_decimator   src/DSP/filter_decimator.h:14-131  t2::filter_decimator
 //   interpolator_farrow src/DSP/interpolator_farrow.hh    t2::interpolator_farrow
 //   p1_symbol          src/DVB_T2/p1_symbol.h:26-48       t2::p1_symbol
@@ -172,34 +172,59 @@ private:
 class time_deinterleaver {
 public:
     explicit time_deinterleaver(int device = 0) : device_(device) {}
-    ~time_deinterleaver() { if (h_) t2gpu_ti_destroy(h_); }
+    ~time_deinterleaver() { release(); }
     std::function<void(int ti_block_size, complex *time_deint_cell, int plp_id, const l1_postsignalling &)> ti_block;   // :38
-    // time_deinterleaver.h:33 (PLP 0; the L1 cells at the head of P2 are skipped as :46,296-300 does)
+    // time_deinterleaver.h:33, cpp:38-145: one de-interleaver per PLP (the reference keeps one permutation per PLP)
     void start(const t2gpu_l1_pre &l1_pre, const l1_postsignalling &l1_post)
     {
-        const t2gpu_l1_plp &p = l1_post.plp.at(0);
-        if (h_) t2gpu_ti_destroy(h_);
-        if (!(h_ = t2gpu_ti_create(p.plp_mod, p.plp_fec_type, p.plp_num_blocks_max, device_))) fail("t2gpu_ti_create");
+        release();
+        size_t len_max = 0;
+        for (const t2gpu_l1_plp &p : l1_post.plp) {
+            t2gpu_ti *h = t2gpu_ti_create(p.plp_mod, p.plp_fec_type, p.plp_num_blocks_max, device_);
+            if (!h) fail("t2gpu_ti_create");
+            h_.push_back(h);
+            len_max = std::max(len_max, (size_t)p.plp_num_blocks_max * t2gpu_ti_cells_per_fec(h));
+        }
         p2_start_idx_cell = 1840 + l1_pre.l1_post_size;
-        out_.resize((size_t)p.plp_num_blocks_max * t2gpu_ti_cells_per_fec(h_));
+        out_.assign(len_max, complex());
+        plp_state_ = 0;
     }
-    void l1_dyn_execute(const l1_postsignalling &l1_post, int len_in, complex *ofdm_cell)      // :43, cpp:268-288
+    // :43, cpp:268-288. The PLP / TI-block sequence of the frame follows from the dynamic signalling alone
+    // (t2gpu_ti_frame_plan); cells are then routed to the PLP's de-interleaver as they arrive.
+    void l1_dyn_execute(const l1_postsignalling &l1_post, int len_in, complex *ofdm_cell)
     {
         l1_post_ = l1_post;
-        if (t2gpu_ti_begin(h_, l1_post.dyn_plp.at(0).num_blocks) != 0) fail("t2gpu_ti_begin");
+        plan_.resize(4096);
+        const int n = t2gpu_ti_frame_plan((int)l1_post.plp.size(), l1_post.plp.data(), l1_post.dyn_plp.data(), 1 << 22, &plp_state_,
+                                          plan_.data(), (int)plan_.size());
+        if (n < 0) fail("t2gpu_ti_frame_plan");
+        plan_.resize(n);
+        k_ = 0; pos_ = 0;
         push(len_in - p2_start_idx_cell, ofdm_cell + p2_start_idx_cell);
     }
     void execute(int len_in, complex *ofdm_cell) { push(len_in, ofdm_cell); }                  // :45, cpp:290-376
 private:
     void push(int n, complex *cells)
     {
-        const int done = t2gpu_ti_push(h_, reinterpret_cast<const float *>(cells), n, reinterpret_cast<float *>(out_.data()));
-        if (done < 0) fail("t2gpu_ti_push");
-        if (done == 1 && ti_block)
-            ti_block(l1_post_.dyn_plp.at(0).num_blocks * t2gpu_ti_cells_per_fec(h_), out_.data(), 0, l1_post_);
+        while (n > 0 && k_ < plan_.size()) {
+            const t2gpu_ti_block &b = plan_[k_];
+            t2gpu_ti *h = h_.at(b.plp);
+            if (pos_ == b.offset && t2gpu_ti_begin(h, b.num_blocks) != 0) fail("t2gpu_ti_begin");
+            const int take = std::min(n, b.offset + b.size - pos_);
+            const int done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(out_.data()));
+            if (done < 0) fail("t2gpu_ti_push");
+            cells += take; n -= take; pos_ += take;
+            if (done == 1) {
+                if (ti_block) ti_block(b.size, out_.data(), b.plp, l1_post_);
+                ++k_;
+            }
+        }
     }
-    int device_, p2_start_idx_cell = 0;
-    t2gpu_ti *h_ = nullptr;
+    void release() { for (t2gpu_ti *h : h_) t2gpu_ti_destroy(h); h_.clear(); }
+    int device_, p2_start_idx_cell = 0, plp_state_ = 0, pos_ = 0;
+    size_t k_ = 0;
+    std::vector<t2gpu_ti *> h_;
+    std::vector<t2gpu_ti_block> plan_;
     l1_postsignalling l1_post_;
     std::vector<complex> out_;
 };

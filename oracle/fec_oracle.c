@@ -308,3 +308,86 @@ int ora_ti_push(ora_ti *t, const float *cells, int n, float *out)
     }
     return done;
 }
+
+/* ---------------------------------------------------------------- frame de-multiplexer of the time de-interleaver (any number of PLPs)
+ * The bookkeeping of time_deinterleaver::start (time_deinterleaver.cpp:38-145), l1_dyn_execute (:268-286) and execute
+ * (:288-376) walked cell by cell exactly as the reference does, without moving any cell: reports for which PLP, from which
+ * cell and with which size ti_block is emitted (:349). num_cells = cells of the frame behind the L1 cells (:298-300).
+ * out4: rows of (plp_id, first cell, FEC blocks, cells). *plp_id_io is the member plp_id, which survives from frame to frame.
+ * TIME_IL_TYPE 1 is refused (-2): the reference indexes fec_blocks_per_time_interleving[i][j] for j < time_il_length with
+ * arrays of n_ti = 1 entries there (:122-129, :277-284). With one PLP the reference reads cells_per_fec_block[1] past the
+ * array (:273); nothing can follow a single PLP, so PLP 0's value is used. PARITY UNPINNED (time_deinterleaver.cpp is a
+ * QObject); cross-checked against the transmitter-side construction in tests/. */
+typedef struct { int mod, fec_type, time_il_length, time_il_type; } ora_plp_cfg;
+typedef struct { int id, start, num_blocks; } ora_plp_dyn;
+
+int ora_ti_frame_walk(int num_plp, const ora_plp_cfg *plp, const ora_plp_dyn *dyn, int num_cells, int *plp_id_io, int *out4,
+                      int max_out)
+{
+    enum { MAXP = 256, MAXTI = 256 };
+    static int cells_per_fec_block[MAXP], num_rows[MAXP], n_ti[MAXP], p_i[MAXP], slice_end[MAXP];
+    static int num_cols[MAXP][MAXTI];
+    if (num_plp < 1 || num_plp > MAXP) return -1;
+    for (int i = 0; i < num_plp; ++i) {                                            /* start(), :57-129 */
+        int fec_len_bits = plp[i].fec_type == 0 ? 16200 : 64800;
+        int bits_per_cell = 2 * (plp[i].mod + 1);
+        cells_per_fec_block[i] = fec_len_bits / bits_per_cell;
+        num_rows[i] = cells_per_fec_block[i] / 5;
+        if (plp[i].time_il_type == 0) { n_ti[i] = plp[i].time_il_length; p_i[i] = 1; }
+        else return -2;
+        if (n_ti[i] < 1 || n_ti[i] > MAXTI) return -1;
+    }
+    for (int i = 0; i < num_plp; ++i) {                                            /* l1_dyn_execute(), :271-285 */
+        slice_end[i] = dyn[i].start + dyn[i].num_blocks * cells_per_fec_block[num_plp > 1 ? 1 : 0] / p_i[i] - 1;
+        int fec_blocks_per_ti_block = (int)floorf((float)dyn[i].num_blocks / (float)n_ti[i] * (float)p_i[i]);
+        for (int j = 0; j < plp[i].time_il_length; ++j) {
+            int f = fec_blocks_per_ti_block;
+            if (j >= (n_ti[i] - dyn[i].num_blocks % n_ti[i])) f += 1;
+            num_cols[i][j] = f * 5;
+        }
+    }
+    /* execute(), first call of the frame, :296-312 */
+    int plp_id = *plp_id_io;
+    int idx_cell = 0;
+    for (int i = 0; i < num_plp; ++i) if (dyn[i].start == 0) plp_id = i;
+    if (plp_id < 0 || plp_id >= num_plp) return -1;
+    int num_rows_plp = num_rows[plp_id];
+    int cells_per_fec_block_plp = cells_per_fec_block[plp_id];
+    int idx_time_il = 0;
+    int ti_block_size = num_cols[plp_id][idx_time_il] * num_rows_plp;
+    int idx_step_ti = 0, idx_row_ti = 0;
+    int n_out = 0, block_first = 0;
+    for (int c = 0; c < num_cells; ++c) {                                          /* :316-374 without the cell moves */
+        idx_step_ti += num_rows_plp;
+        if (idx_step_ti == ti_block_size) {
+            idx_step_ti = 0;
+            if (++idx_row_ti == num_rows_plp) {
+                idx_row_ti = 0;
+                if (n_out >= max_out) return -3;
+                out4[4 * n_out + 0] = plp_id; out4[4 * n_out + 1] = block_first;
+                out4[4 * n_out + 2] = ti_block_size / cells_per_fec_block_plp; out4[4 * n_out + 3] = ti_block_size;
+                ++n_out;
+                block_first = idx_cell + 1;
+                if (++idx_time_il == plp[plp_id].time_il_length) {
+                    idx_time_il = 0;
+                    if (idx_cell == slice_end[plp_id]) {
+                        for (int i = 0; i < num_plp; ++i) {
+                            if (idx_cell == dyn[i].start - 1) {
+                                plp_id = dyn[i].id;
+                                if (plp_id < 0 || plp_id >= num_plp) return -1;
+                                num_rows_plp = num_rows[plp_id];
+                                ti_block_size = num_cols[plp_id][idx_time_il] * num_rows_plp;
+                                cells_per_fec_block_plp = cells_per_fec_block[plp_id];
+                            }
+                        }
+                    }
+                } else {
+                    ti_block_size = num_cols[plp_id][idx_time_il] * num_rows_plp;
+                }
+            }
+        }
+        ++idx_cell;
+    }
+    *plp_id_io = plp_id;
+    return n_out;
+}

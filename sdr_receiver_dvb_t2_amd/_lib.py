@@ -51,6 +51,7 @@ PROTOTYPES = {
     "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "t2gpu_l1_pre_parse": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_l1_post_parse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    "t2gpu_ti_frame_plan": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "t2gpu_bbdh_create": (_vp, [ctypes.c_int]),
     "t2gpu_bbdh_destroy": (None, [_vp]),
     "t2gpu_bbdh_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),

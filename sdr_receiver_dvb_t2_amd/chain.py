@@ -1,6 +1,6 @@
 """demod -> TS chain over the C ABI: guard-removed OFDM symbols of whole T2 frames in, transport-stream bytes out.
 
-Mirrors the call sequence of the reference's pipeline objects for one PLP (TI type 0, one TI block per frame):
+Mirrors the call sequence of the reference's pipeline objects (TI type 0; one PLP, or several PLPs of one modulation / code):
 ``dvbt2_demodulator::symbol_acquisition`` (/root/reference/src/DVB_T2/dvbt2_demodulator.cpp:332-375: fft->execute, then
 p2_demodulator / data_demodulator ->execute) -> ``time_deinterleaver::execute`` -> ``llr_demapper::execute`` ->
 ``ldpc_decoder::execute`` -> ``bch_decoder::execute`` -> ``bb_de_header::execute``. All stages but the last run on the GPU
@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from ._lib import lib, check
-from .fec import bch_decoder, llr_demapper, time_deinterleaver
+from .fec import bch_decoder, llr_demapper, time_deinterleaver, ti_frame_plan
 from .ldpc import ldpc_decoder
 from .ofdm import t2_ofdm
 
@@ -22,7 +22,14 @@ L1_PRE_CELL = 1840      # dvbt2_definition.h:58
 class t2_chain(object):
     def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size,
                  plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames=4, device=0, ldpc_group=32,
-                 ldpc_trials=25, saturate_llr=False, time_il_length=1):
+                 ldpc_trials=25, saturate_llr=False, time_il_length=1, plps=None, need_plp=0):
+        """plps (optional): several PLPs in the frame, a list of dicts with num_blocks and start (L1-post dynamic: PLP_NUM_BLOCKS,
+        PLP_START) and optionally plp_rotation, time_il_length, plp_num_blocks_max, id; list position = PLP index. All PLPs
+        share plp_mod / plp_fec_type / plp_cod: the reference decodes a SIMD batch with the code of its first frame whichever
+        PLPs the other 31 belong to (ldpc_decoder.cpp:173-174), fills one batch per modulation (llr_demapper.cpp:172,242,378,549)
+        and finds a PLP's end with one cell count (time_deinterleaver.cpp:273-274). need_plp: the PLP whose BBFRAMEs become the
+        transport stream (bb_de_header::set_out, bb_de_header.cpp:500-525). Without plps: one PLP starting at cell 0 with
+        plp_num_blocks FEC blocks per frame."""
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
@@ -36,29 +43,41 @@ class t2_chain(object):
         self.frame_cells = (o.c_p2 - self.p2_skip) + self.n_dat * o.c_data + o.l_fc * o.n_fc
         self.fec_size = 64800 if plp_fec_type == 1 else 16200
         self.cells_per_fec = self.fec_size // (2 * (plp_mod + 1))
-        self.num_blocks = plp_num_blocks
-        assert plp_num_blocks * self.cells_per_fec <= self.frame_cells
-        # TI blocks of one interleaving frame (time_il_type 0: time_il_length blocks per T2 frame), FEC blocks in each as
-        # time_deinterleaver::l1_dyn_execute splits them (time_deinterleaver.cpp:275-285): the later blocks take the remainder
-        n_ti = max(1, time_il_length)
-        base = plp_num_blocks // n_ti
-        self.ti_blocks = [base + (1 if j >= n_ti - plp_num_blocks % n_ti else 0) for j in range(n_ti)]
-        assert sum(self.ti_blocks) == plp_num_blocks and min(self.ti_blocks) >= 1
-        self.ti = [time_deinterleaver(plp_mod, plp_fec_type, plp_num_blocks, device) for _ in range(max_frames)]
-        self.demap = llr_demapper(plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks * self.cells_per_fec, device,
-                                  saturate=saturate_llr)
+        # TI blocks of one T2 frame in the order the reference emits them (time_il_type 0: time_il_length blocks per PLP and
+        # frame, the later blocks take the remainder, time_deinterleaver.cpp:275-285; PLP after PLP, :357-368)
+        if plps is None:
+            plps = [dict(num_blocks=plp_num_blocks, start=0, plp_rotation=plp_rotation, time_il_length=max(1, time_il_length))]
+        P = [dict(plp_mod=plp_mod, plp_fec_type=plp_fec_type, plp_cod=plp_cod, plp_rotation=q.get("plp_rotation", plp_rotation),
+                  time_il_length=q.get("time_il_length", 1), time_il_type=0,
+                  plp_num_blocks_max=q.get("plp_num_blocks_max", q["num_blocks"])) for q in plps]
+        D = [dict(id=q.get("id", i), start=q["start"], num_blocks=q["num_blocks"]) for i, q in enumerate(plps)]
+        self.plan, _ = ti_frame_plan(P, D, self.frame_cells)
+        assert self.plan, "no TI block fits the frame"
+        self.ti_blocks = [b[2] for b in self.plan]
+        self.frame_tags = [b[0] for b in self.plan for _ in range(b[2])]     # PLP of every FEC frame of a T2 frame
+        plp_num_blocks = self.num_blocks = len(self.frame_tags)              # FEC frames per T2 frame, all PLPs
+        self.need_plp = need_plp
+        self.ti = [[time_deinterleaver(plp_mod, plp_fec_type, q["plp_num_blocks_max"], device) for q in P] for _ in range(max_frames)]
+        by_rotation = {}
+        for q in P:
+            if q["plp_rotation"] not in by_rotation:
+                by_rotation[q["plp_rotation"]] = llr_demapper(plp_mod, plp_fec_type, plp_cod, q["plp_rotation"],
+                                                             max(b[3] for b in self.plan), device, saturate=saturate_llr)
+        self.demaps = [by_rotation[q["plp_rotation"]] for q in P]
+        self.demap = self.demaps[self.plan[0][0]]
         self.ldpc = ldpc_decoder(plp_fec_type, plp_cod, max_frames=max_frames * plp_num_blocks + 64, device=device,
                                  group=ldpc_group, trials=ldpc_trials)
         self.bch = bch_decoder(plp_fec_type, plp_cod)
         self.group = ldpc_group
         self._l = lib()
-        self._bbdh = self._l.t2gpu_bbdh_create(0)
+        self._bbdh = self._l.t2gpu_bbdh_create(need_plp)
         f32 = torch.float32
         self.cells = torch.zeros((max_frames, self.frame_cells, 2), dtype=f32, device=self.dev)
         self.p2_cells = torch.empty((max_frames, o.c_p2, 2), dtype=f32, device=self.dev)
         self.ti_out = torch.zeros((max_frames, plp_num_blocks * self.cells_per_fec, 2), dtype=f32, device=self.dev)
         self.llr = torch.empty((max_frames * plp_num_blocks + 64, self.fec_size), dtype=torch.int8, device=self.dev)
         self.carry = 0                                           # FEC frames waiting for a full SIMD batch
+        self.tags, self.last_tags = [], []                       # PLP of the waiting frames / of the frames last handed out
         self.time_ldpc, self.ldpc_events = False, []             # bench: HIP events around the LDPC launch
         idx = np.tile(np.arange(1, 1 + self.n_dat, dtype=np.int32), max_frames)
         self.sym_index = torch.from_numpy(idx).to(self.dev)
@@ -120,13 +139,13 @@ class t2_chain(object):
         torch = self.torch
         for f in range(F):
             a, c0 = self.carry + f * self.num_blocks, 0
-            for nbk in self.ti_blocks:                           # one TI block after the other, each with its own SNR estimate
-                n = nbk * self.cells_per_fec
-                self.ti[f].l1_dyn(nbk)
-                done = self.ti[f].execute_dev(self.cells[f, c0:c0 + n], self.ti_out[f, c0:c0 + n])
+            for plp, off, nbk, n in self.plan:                   # one TI block after the other, each with its own SNR estimate
+                self.ti[f][plp].l1_dyn(nbk)
+                done = self.ti[f][plp].execute_dev(self.cells[f, off:off + n], self.ti_out[f, c0:c0 + n])
                 assert done
-                self.demap.execute_dev(self.ti_out[f, c0:c0 + n], out=self.llr[a:a + nbk])
+                self.demaps[plp].execute_dev(self.ti_out[f, c0:c0 + n], out=self.llr[a:a + nbk])
                 a, c0 = a + nbk, c0 + n
+            self.tags += self.frame_tags
         total = self.carry + F * self.num_blocks
         ready = total if flush else (total // self.group) * self.group
         if ready == 0:
@@ -144,6 +163,7 @@ class t2_chain(object):
         if rest:
             self.llr[:rest] = self.llr[ready:total].clone()
         self.carry = rest
+        self.last_tags, self.tags = self.tags[:ready], self.tags[ready:]
         return out, trials
 
     # ---- the same in two halves for a two-stream software pipeline (whole frames, every FEC frame decoded: flush semantics):
@@ -155,8 +175,8 @@ class t2_chain(object):
         assert self.carry == 0 and len(self.ti_blocks) == 1
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
-            self.ti[f].l1_dyn(self.num_blocks)
-            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
+            self.ti[f][0].l1_dyn(self.num_blocks)
+            done = self.ti[f][0].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
             assert done
             self.demap.execute_dev(self.ti_out[f], out=self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
         return F * self.num_blocks
@@ -171,8 +191,8 @@ class t2_chain(object):
         assert len(self.ti_blocks) == 1, "the staged schedule covers one TI block per frame"
         n_ti = self.num_blocks * self.cells_per_fec
         for f in range(F):
-            self.ti[f].l1_dyn(self.num_blocks)
-            done = self.ti[f].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
+            self.ti[f][0].l1_dyn(self.num_blocks)
+            done = self.ti[f][0].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
             assert done
             self.demap.stats_dev(self.ti_out[f], self.sums[f])
 
@@ -195,16 +215,19 @@ class t2_chain(object):
             self.ldpc_events.append((e0, e1, count))
         return self.bch.execute_dev(bits), trials
 
-    def ts_from_bits(self, bits_host, trials_host):
+    def ts_from_bits(self, bits_host, trials_host, tags=None):
         """BBFRAME bits of decoded FEC frames -> TS bytes; SIMD batches the LDPC gave up on (-1) are dropped as the
-        reference drops them (ldpc_decoder.cpp:264-268)."""
+        reference drops them (ldpc_decoder.cpp:264-268); frames of PLPs other than need_plp are skipped by the de-framer
+        (bb_de_header.cpp:139-142). tags: PLP of every frame (default: those of the frames demod_cells_dev last returned)."""
         out = []
         buf = np.zeros(bits_host.shape[1] // 8 + 400, np.uint8)
         err = ctypes.c_int(0)
+        if tags is None:
+            tags = self.last_tags if len(self.last_tags) == bits_host.shape[0] else [self.need_plp] * bits_host.shape[0]
         for i in range(bits_host.shape[0]):
             if trials_host[i // self.group] < 0:
                 continue
-            n = self._l.t2gpu_bbdh_execute(self._bbdh, 0, bits_host.shape[1], bits_host[i].ctypes.data, buf.ctypes.data,
+            n = self._l.t2gpu_bbdh_execute(self._bbdh, tags[i], bits_host.shape[1], bits_host[i].ctypes.data, buf.ctypes.data,
                                            buf.size, ctypes.byref(err))
             if n > 0:
                 out.append(buf[:n].copy())

@@ -131,6 +131,34 @@ class time_deinterleaver(object):
         return rc == 1
 
 
+class ti_block(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("plp", "offset", "num_blocks", "size")]
+
+
+def ti_frame_plan(plps, dyns, frame_cells, plp_state=0, max_blocks=1024):
+    """TI blocks of one T2 frame's cell stream, in the order time_deinterleaver::execute emits ti_block for them
+    (time_deinterleaver.cpp:296-312,337-371). plps / dyns: sequences of dicts with the L1-post fields the stage reads
+    (plp_mod, plp_fec_type, plp_num_blocks_max, time_il_length, time_il_type / id, start, num_blocks) or the ctypes arrays
+    of l1.l1_post_info. Returns ([(plp index, first cell, FEC blocks, cells)], PLP the frame ended in)."""
+    from .l1 import dynamic_plp, l1_postsignalling_plp
+    n = len(plps)
+    P, D = (l1_postsignalling_plp * n)(), (dynamic_plp * n)()
+    for i in range(n):
+        for arr, src in ((P, plps[i]), (D, dyns[i])):
+            if isinstance(src, dict):
+                for k, v in src.items():
+                    if hasattr(arr[i], k):
+                        setattr(arr[i], k, int(v))
+            else:
+                ctypes.pointer(arr[i])[0] = src
+    out = (ti_block * max_blocks)()
+    st = ctypes.c_int(plp_state)
+    rc = lib().t2gpu_ti_frame_plan(n, P, D, frame_cells, ctypes.byref(st), out, max_blocks)
+    if rc < 0:
+        check(rc, "t2gpu_ti_frame_plan")
+    return [(out[k].plp, out[k].offset, out[k].num_blocks, out[k].size) for k in range(rc)], st.value
+
+
 class bch_decoder(object):
     """The reference's BCH stage is a parity strip + BB descrambler (bch_decoder.cpp:136-142)."""
 

@@ -4,6 +4,9 @@
 //   stage_mirror_test farrow in.c64 out.c64 chunk resample
 //   stage_mirror_test fec    llr.i8 out.u8 fec_type code_rate       (LLR batches of 32 frames -> descrambled BBFRAME bits)
 //   stage_mirror_test p1     in.c64 out.txt level
+//   stage_mirror_test cells  cells.c64 out.u8 need_plp ts.u8 l1_post_size cod n_sym sizes... num_plp {mod fec rot nb_max til start nb}...
+//                            (equalised cells of one T2 frame, symbol by symbol as data_symbol hands them over -> the whole
+//                            FEC side: time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder -> bb_de_header)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +81,54 @@ int main(int argc, char **argv)
             std::FILE *f = std::fopen(argv[3], "w");
             std::fprintf(f, "%d %d %d %d %d %d %.3f\n", hit ? 1 : 0, consume, idx_buffer_sym, preamble, fft_mode, decoded ? 1 : 0, cfo);
             std::fclose(f);
+        } else if (mode == "cells") {
+            std::vector<t2::complex> cells = slurp<t2::complex>(argv[2]);
+            int a = 4;
+            const int need_plp = std::atoi(argv[a++]);
+            const char *ts_path = argv[a++];
+            t2gpu_l1_pre pre{};
+            pre.l1_post_size = std::atoi(argv[a++]);
+            const int cod = std::atoi(argv[a++]);
+            std::vector<int> sizes((size_t)std::atoi(argv[a++]));
+            for (int &v : sizes) v = std::atoi(argv[a++]);
+            t2::l1_postsignalling l1;
+            l1.post.num_plp = std::atoi(argv[a++]);
+            l1.plp.resize((size_t)l1.post.num_plp);
+            l1.dyn_plp.resize(l1.plp.size());
+            for (size_t i = 0; i < l1.plp.size(); ++i) {
+                t2gpu_l1_plp &p = l1.plp[i];
+                p.id = (int)i; p.plp_cod = cod;
+                p.plp_mod = std::atoi(argv[a++]); p.plp_fec_type = std::atoi(argv[a++]); p.plp_rotation = std::atoi(argv[a++]);
+                p.plp_num_blocks_max = std::atoi(argv[a++]); p.time_il_length = std::atoi(argv[a++]);
+                l1.dyn_plp[i].id = (int)i;
+                l1.dyn_plp[i].start = std::atoi(argv[a++]); l1.dyn_plp[i].num_blocks = std::atoi(argv[a++]);
+            }
+            // the reference's connect() chain from the time de-interleaver down (time_deinterleaver.cpp:30, llr_demapper.cpp:83,
+            // ldpc_decoder.cpp:149, bch_decoder.cpp:43)
+            t2::time_deinterleaver ti;
+            t2::llr_demapper qam;
+            t2::ldpc_decoder ldpc;
+            t2::bch_decoder bch;
+            t2::bb_de_header deheader(need_plp);
+            std::vector<uint8_t> out, ts;
+            ti.ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
+            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+            ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
+            bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) {
+                out.push_back((uint8_t)plp_id);
+                out.insert(out.end(), bits, bits + len);
+                deheader.execute(plp_id, p, len, bits);
+            };
+            deheader.write_out = [&](const uint8_t *b, int n) { ts.insert(ts.end(), b, b + n); };
+            ti.start(pre, l1);
+            size_t pos = 0;
+            for (size_t l = 0; l < sizes.size(); ++l) {                      // dvbt2_demodulator.cpp:348-375: P2 first, then every symbol
+                if (l == 0) ti.l1_dyn_execute(l1, sizes[l], cells.data() + pos);
+                else ti.execute(sizes[l], cells.data() + pos);
+                pos += (size_t)sizes[l];
+            }
+            dump(argv[3], out);
+            dump(ts_path, ts);
         } else return 2;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "stage_mirror_test: %s\n", e.what());

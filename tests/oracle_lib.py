@@ -177,6 +177,21 @@ def ora_cell_perm(num_blocks, cells_per_fec):
     return p
 
 
+def ora_ti_frame_walk(plps, dyns, num_cells, plp_state=0, max_out=4096):
+    """plps: [(mod, fec_type, time_il_length, time_il_type)], dyns: [(id, start, num_blocks)] -> ([(plp, first, blocks, size)], state)"""
+    o = oracle()
+    P = np.ascontiguousarray(np.array(plps, np.int32).reshape(len(plps), 4))
+    D = np.ascontiguousarray(np.array(dyns, np.int32).reshape(len(plps), 3))
+    out = np.zeros((max_out, 4), np.int32)
+    st = ctypes.c_int(plp_state)
+    o.ora_ti_frame_walk.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int]
+    rc = o.ora_ti_frame_walk(len(plps), P.ctypes.data, D.ctypes.data, num_cells, ctypes.byref(st), out.ctypes.data, max_out)
+    if rc < 0:
+        return rc, st.value
+    return [tuple(int(v) for v in out[k]) for k in range(rc)], st.value
+
+
 class OraTi(object):
     def __init__(self, cells_per_fec, num_blocks_max):
         o = oracle()

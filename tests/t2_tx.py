@@ -73,7 +73,7 @@ def map_axis(bits, d):
     return x
 
 
-def cells_from_codewords(cw, mod, fec_type, code_rate, rotation=True):
+def cells_from_codewords(cw, mod, fec_type, code_rate, rotation=True, q_delay=None):
     """[f][n] code bits -> [f][cells_per_fec] complex cells (bit interleaver + demux via the inverse of the receiver's
     address table, mapping, rotation, cyclic Q delay)."""
     bpc = 2 * (mod + 1)
@@ -87,6 +87,7 @@ def cells_from_codewords(cw, mod, fec_type, code_rate, rotation=True):
         c = map_axis(bits[..., 0::2], NORM[mod]) + 1j * map_axis(bits[..., 1::2], NORM[mod])
     if rotation:
         c = c * np.exp(1j * ROT[mod])
+    if rotation if q_delay is None else q_delay:                 # EN 302 755 6.3: the cyclic Q delay belongs to the rotation
         c = c.real + 1j * np.roll(c.imag, 1, axis=1)              # Q of cell q-1 travels with I of cell q (cyclic per block)
     return c
 

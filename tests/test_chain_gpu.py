@@ -111,3 +111,80 @@ def test_three_ti_blocks_per_frame(torch_cuda):
     n_pkts = (nb * ((k_bch - 80) // 8)) // 187 - 1
     assert np.array_equal(got[:n_pkts * 188], ts.reshape(-1)[:n_pkts * 188])
     chain.close()
+
+
+def test_two_plps_in_one_frame(torch_cuda):
+    """Two PLPs of one modulation and code share the frame (PLP 0: one TI block; PLP 1: two TI blocks). The frame de-multiplexer follows time_deinterleaver::execute (time_deinterleaver.cpp:296-312,357-368), the
+    FEC frames of both PLPs fill the SIMD batches in arrival order (llr_demapper.cpp:742-760) and only need_plp's BBFRAMEs
+    become transport stream (bb_de_header.cpp:139-142)."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    mode, lps, mod, fec_type, code_rate, snr = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 14.0
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    n0 = nb // 3
+    n1 = nb - n0
+    assert n1 % 2 == 1                                                       # uneven TI blocks in PLP 1
+    k_bch = t2_tx.K_BCH[cid]
+    ts0 = t2_tx.ts_packets(n0 * (k_bch // 1496 + 1) + 8, 21)
+    ts1 = t2_tx.ts_packets(n1 * (k_bch // 1496 + 1) + 8, 22)
+    fr0, _ = t2_tx.bbframes_hem(ts0, k_bch, n0)
+    fr1, _ = t2_tx.bbframes_hem(ts1, k_bch, n1)
+    c0 = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(fr0)), mod, fec_type, code_rate, True)
+    c1 = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(fr1)), mod, fec_type, code_rate, True)
+    a = n1 // 2
+    stream = np.concatenate([t2_tx.interleave_ti_block(c0), t2_tx.interleave_ti_block(c1[:a]), t2_tx.interleave_ti_block(c1[a:])])
+    sym = t2_tx.build_frame(m, stream, lps, 9, snr_db=snr, phase=-0.3)
+    plps = [dict(num_blocks=n0, start=0, plp_rotation=1, time_il_length=1),
+            dict(num_blocks=n1, start=n0 * cpf, plp_rotation=1, time_il_length=2)]
+    x = torch.from_numpy(sym[None].view(np.float32).reshape(1, m.len_frame, m.fft_size, 2)).cuda()
+    for need in (1, 0):
+        chain = pkg.t2_chain(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1, plps=plps, need_plp=need)
+        assert chain.plan == [(0, 0, n0, n0 * cpf), (1, n0 * cpf, a, a * cpf), (1, (n0 + a) * cpf, n1 - a, (n1 - a) * cpf)]
+        bits, trials = chain.demod_dev(x, flush=True)
+        torch.cuda.synchronize()
+        t = trials.cpu().numpy()
+        assert (t >= 0).all(), t
+        b = bits.cpu().numpy()
+        assert chain.last_tags == [0] * n0 + [1] * n1
+        assert np.array_equal(b[:n0], fr0) and np.array_equal(b[n0:], fr1)  # every BBFRAME of both PLPs, bit for bit
+        got = chain.ts_from_bits(b, t)
+        ts, n = (ts1, n1) if need == 1 else (ts0, n0)
+        n_pkts = (n * ((k_bch - 80) // 8)) // 187 - 1
+        assert np.array_equal(got[:n_pkts * 188], ts.reshape(-1)[:n_pkts * 188])
+        assert got.size <= (n_pkts + 2) * 188                               # nothing of the other PLP leaked in
+        chain.close()
+
+
+@pytest.mark.parametrize("q_delay,decodes", [(False, False), (True, True)])
+def test_plain_constellation_plp_loses_its_q_alignment(torch_cuda, q_delay, decodes):
+    """PLP_ROTATION = 0. The reference's time de-interleaver moves every Q one cell back whatever the PLP signals (no test of
+    plp_rotation in time_deinterleaver.cpp:316-336; only the demapper looks at it, llr_demapper.cpp:167,237,373,544), so a
+    standard non-rotated PLP -- which carries no cyclic Q delay -- comes out with I and Q of neighbouring cells paired and
+    every SIMD batch is dropped. The chain reproduces that; a transmitter that delays Q without rotating decodes, which pins
+    the cause."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    mode, lps, mod, fec_type, code_rate, snr = (4, 1, 6, 4, 0, 40), 200, 1, 0, 0, 14.0
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = 64
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(nb * (k_bch // 1496 + 1) + 8, 31)
+    fr, _ = t2_tx.bbframes_hem(ts, k_bch, nb)
+    cells = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(fr)), mod, fec_type, code_rate, False, q_delay=q_delay)
+    sym = t2_tx.build_frame(m, t2_tx.interleave_ti_block(cells), lps, 3, snr_db=snr, phase=0.2)
+    chain = pkg.t2_chain(*mode, lps, mod, fec_type, code_rate, 0, nb, max_frames=1)
+    x = torch.from_numpy(sym[None].view(np.float32).reshape(1, m.len_frame, m.fft_size, 2)).cuda()
+    bits, trials = chain.demod_dev(x, flush=True)
+    torch.cuda.synchronize()
+    t = trials.cpu().numpy()[:2]                                            # the 64 frames of the PLP = two whole batches
+    if decodes:
+        assert (t >= 0).all(), t
+        assert np.array_equal(bits.cpu().numpy()[:nb], fr)
+    else:
+        assert (t < 0).all(), t
+    chain.close()

@@ -90,3 +90,48 @@ def test_p1_class(driver, tmp_path):
     assert (int(consume), int(idx_sym), int(preamble), int(fft_mode), int(decoded)) == \
         (r["consume"], r["idx_buffer_sym"], r["preamble"], r["fft_mode"], r["p1_decoded"]) and int(fft_mode) == 4
     assert abs(float(cfo) - r["coarse_freq_offset"]) < 0.5
+
+
+def test_fec_side_from_cells_two_plps(driver, tmp_path):
+    """The whole FEC side in C++ as the reference wires it -- time_deinterleaver (two PLPs, the second with two TI blocks) ->
+    llr_demapper -> ldpc_decoder -> bch_decoder -> bb_de_header(need_plp) -- fed symbol by symbol with the equalised cells of one
+    T2 frame. Whole SIMD batches come out (the reference never flushes the tail); BBFRAMEs are bit-exact and tagged with their
+    PLP, the transport stream holds only need_plp's packets."""
+    mode, lps, mod, fec_type, code_rate = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    n0 = 40
+    n1 = 63                                                                  # 103 frames: three SIMD batches and a tail of 7
+    k_bch = t2_tx.K_BCH[cid]
+    ts0 = t2_tx.ts_packets(n0 * (k_bch // 1496 + 1) + 8, 41)
+    ts1 = t2_tx.ts_packets(n1 * (k_bch // 1496 + 1) + 8, 42)
+    fr0, _ = t2_tx.bbframes_hem(ts0, k_bch, n0)
+    fr1, _ = t2_tx.bbframes_hem(ts1, k_bch, n1)
+    c0 = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(fr0)), mod, fec_type, code_rate, True)
+    c1 = t2_tx.cells_from_codewords(t2_tx.fec_encode(cid, t2_tx.scramble(fr1)), mod, fec_type, code_rate, True)
+    a = n1 // 2
+    stream = np.concatenate([t2_tx.interleave_ti_block(c0), t2_tx.interleave_ti_block(c1[:a]), t2_tx.interleave_ti_block(c1[a:])])
+    rng = np.random.Generator(np.random.PCG64(43))
+    cap = (m.c_p2 - 1840 - lps) + m.n_data * m.c_data
+    cells = np.zeros(1840 + lps + cap, np.complex64)                         # L1 cells (skipped by the stage), PLP cells, dummy cells
+    cells[1840 + lps:1840 + lps + stream.size] = stream
+    cells += (0.05 * (rng.standard_normal(cells.size) + 1j * rng.standard_normal(cells.size))).astype(np.complex64)
+    cells.tofile(tmp_path / "cells.c64")
+    sizes = [m.c_p2] + [m.c_data] * m.n_data
+    assert sum(sizes) == cells.size
+    # The two PLPs leave more than a TI block of dummy cells in the frame. No PLP starts behind PLP 1, so the reference stays in
+    # PLP 1 and de-interleaves the dummy cells with its geometry (time_deinterleaver.cpp:357-371): the frames that come out of
+    # them are noise, their SIMD batches are dropped by the LDPC stage -- together with the 7 good frames of the tail.
+    assert cap - (n0 + n1) * cpf > (n1 - a) * cpf
+    plps = [mod, fec_type, 1, n0, 1, 0, n0, mod, fec_type, 1, n1, 2, n0 * cpf, n1]
+    run(driver, "cells", tmp_path / "cells.c64", tmp_path / "out.u8", 1, tmp_path / "ts.u8", lps, code_rate, len(sizes), *sizes, 2, *plps)
+    got = np.fromfile(tmp_path / "out.u8", np.uint8).reshape(-1, 1 + k_bch)
+    assert got.shape[0] == 96
+    want = np.concatenate([fr0, fr1])[:96]
+    assert np.array_equal(got[:, 0], np.array([0] * n0 + [1] * (96 - n0), np.uint8))
+    assert np.array_equal(got[:, 1:], want)
+    ts = np.fromfile(tmp_path / "ts.u8", np.uint8)
+    n_pkts = ((96 - n0) * ((k_bch - 80) // 8)) // 187 - 1
+    assert np.array_equal(ts[:n_pkts * 188], ts1.reshape(-1)[:n_pkts * 188])
