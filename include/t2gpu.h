@@ -274,6 +274,16 @@ typedef struct t2gpu_front t2gpu_front;
 t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int max_samples, int device);
 void t2gpu_front_destroy(t2gpu_front *h);
 int t2gpu_front_reset(t2gpu_front *h); /* dvbt2_demodulator::reset, :111-127 */
+/* dvbt2_demodulator::reset (:111-127) as far as it concerns this handle: dc averagers and both NCO accumulators to zero;
+ * c1 / c2 / level_detect and the filter delay lines live on (t2gpu_front_reset is the constructor state). */
+int t2gpu_front_reset_loops(t2gpu_front *h);
+/* frequency_nco = value (set_guard_interval_by_brute_force zeroes it, :486-487) */
+int t2gpu_front_set_frequency_nco(t2gpu_front *h, float frequency_nco);
+/* One execute() of the reference = several calls here when the loops are closed (one per chunk). hold = 1: the calls only add
+ * to the sign statistics; t2gpu_front_commit_iq at the end of the execute() derives c1 / c2 / level_detect from all of them
+ * (:227-235) for the NEXT execute(), as the reference does. hold = 0 (default): every call is an execute() of its own. */
+int t2gpu_front_hold_iq(t2gpu_front *h, int hold);
+int t2gpu_front_commit_iq(t2gpu_front *h, void *stream);
 /* nominal resample = sample_rate / (SAMPLE_RATE * 2) and its limit (+100 ppm), as :54-55 computes them */
 int t2gpu_front_resample(const t2gpu_front *h, double *resample, double *max_resample);
 long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *phase_est_filtered,
@@ -312,6 +322,11 @@ void t2gpu_sync_frequency(t2gpu_sync *h, float frequency_est, int fft_size);
 void t2gpu_sync_symbol(t2gpu_sync *h, float phase_est, float sample_rate_est);
 /* out4 = {phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered, arbitrary_resample of the next chunk} */
 void t2gpu_sync_get(const t2gpu_sync *h, double *out4);
+/* dvbt2_demodulator::reset (:111-127); frequency_est_filtered = 0 (brute-force guard search, :486); resample -= correct_resample *
+ * resample after a re-tune (:291) */
+void t2gpu_sync_reset(t2gpu_sync *h, float sample_rate);
+void t2gpu_sync_clear_frequency(t2gpu_sync *h);
+void t2gpu_sync_correct_resample(t2gpu_sync *h, double correct_resample);
 
 /* host only (no GPU): the exact run-table expansion of the two float accumulators (csrc/front_plan.h), for tests.
  * nco: values[i] = frequency_nco used for sample i; farrow: counts[i] = outputs of input i, positions[i] = x1 at input i. */
@@ -357,6 +372,61 @@ int t2gpu_p1_execute_batch_dev(t2gpu_p1 *h, int gain_changed, float level_detect
                                void *stream);
 /* for tests: correlation trace of the last pass (returns the number of values) and the fft-shifted 1K spectrum of part A */
 int t2gpu_p1_debug(t2gpu_p1 *h, float *corr, int n_corr, float *p1_fft1024);
+
+/* ---------------------------------------------------------------- the demodulator object ------------------------------
+ * Replaces the class behind the boundary slot
+ *     void dvbt2_demodulator::execute(int len_in, int16_t* i_in, int16_t* q_in, signal_estimate* signal_)
+ *     (src/DVB_T2/dvbt2_demodulator.h:56-78, src/DVB_T2/dvbt2_demodulator.cpp:145-254)
+ * with everything it drives up to the time de-interleaver: symbol_acquisition (:267-448: P1 search, symbol buffering, guard
+ * correlation, FFT, P2 / data / frame-closing equalisers, L1-pre / L1-post, tracking loops), init_dvbt2 (:129-143), reset
+ * (:111-127), set_guard_interval (:450-480) and set_guard_interval_by_brute_force (:482-548). Acquisition is the reference's:
+ * the mode comes from P1 (FFT size, SISO) and L1-pre (carrier mode, guard interval, pilot pattern, PAPR, NUM_DATA_SYMBOLS);
+ * like the reference the first P2 is demodulated with extended carriers and a guessed guard interval, and the P2 tables are
+ * never rebuilt (a normal-carrier signal therefore never passes L1-pre, there as here).
+ * i_in / q_in: host buffers as the SDR thread hands them over (AirSpy: interleaved, stride 2, dvbt2_demodulator.cpp:36-42).
+ * signal_: the struct shared with the SDR thread (dvbt2_demodulator.h:42-52), same fields and meaning, bool as int32_t.
+ * Signals of the class (dvbt2_demodulator.h:70-75) are C callbacks; cell pointers are host memory valid during the call:
+ *   start            time_deinterleaver::start(dvbt2, l1_pre, l1_post) -- the direct call at :386
+ *   l1_dyn_execute   emit l1_dyn_execute(l1_post, c_p2, cells)          :391
+ *   data             emit data(c_data | n_fc, cells)                    :346,361
+ *   amount_plp       emit amount_plp(num_plp)                           :388
+ *   replace_null_indicator(sample_rate_offset_hz, frequency_offset_hz)  :444
+ * t2gpu_demod_execute returns 0, or -1 when a stage failed (t2gpu_last_error; e.g. P1 announces an FFT size outside 16K / 32K).
+ * t2gpu_demod_set_tuner: there is no tuner behind a recorded buffer. The reference asks the SDR thread to move the local
+ * oscillator by signal_->coarse_freq_offset (change_frequency, :301; rx_sdrplay.cpp:158-176); a caller replaying samples moves
+ * it here instead: offset_hz is the sum of the requested moves, applied as one more NCO term. Extension, inert when never called. */
+typedef struct {
+    int32_t change_frequency;
+    double coarse_freq_offset;
+    int32_t frequency_changed; /* initial value 1 */
+    int32_t change_gain, gain_offset;
+    int32_t gain_changed;      /* initial value 1 */
+    double correct_resample;
+    int32_t reset, p1_reset;
+} t2gpu_signal_estimate;
+typedef struct {
+    void *user;
+    void (*start)(void *user, const t2gpu_l1_pre *l1_pre, const t2gpu_l1_post *l1_post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn);
+    void (*l1_dyn_execute)(void *user, const t2gpu_l1_post *l1_post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn, int len_in,
+                           const float *cells);
+    void (*data)(void *user, int len_in, const float *cells);
+    void (*amount_plp)(void *user, int num_plp);
+    void (*replace_null_indicator)(void *user, float sample_rate_offset_hz, float frequency_offset_hz);
+} t2gpu_demod_signals;
+typedef struct {
+    int32_t next_symbol_type /* 0 P1, 1 P2, 2 DATA, 3 FC */, p2_init, demodulator_init, deint_start, crc32_l1_pre, fft_mode, fft_size,
+        guard_interval_size, symbol_size, carrier_mode, pilot_pattern, n_data, idx_symbol;
+    int64_t symbols, frames, resets; /* OFDM symbols demodulated, T2 frames completed, reset() calls */
+    float level_detect;
+    double phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered, arbitrary_resample;
+} t2gpu_demod_info;
+typedef struct t2gpu_demod t2gpu_demod;
+t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int device);
+void t2gpu_demod_destroy(t2gpu_demod *h);
+int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *signals);
+int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const int16_t *q_in, t2gpu_signal_estimate *signal_);
+int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
+int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
 
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):

@@ -15,6 +15,7 @@
 //   p1_symbol          src/DVB_T2/p1_symbol.h:26-48       t2::p1_symbol
 //   fast_fourier_transform + data_symbol / p2_symbol / fc_symbol (src/DSP/fast_fourier_transform.h, src/DVB_T2/data_symbol.h)
 //                                                         t2::ofdm_demodulator (one handle owns the mode tables of all three)
+//   dvbt2_demodulator  src/DVB_T2/dvbt2_demodulator.h:56  t2::dvbt2_demodulator   (the boundary slot execute(len, i, q, signal))
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -312,6 +313,91 @@ public:
 private:
     t2gpu_ofdm *h_;
     std::vector<complex> spectrum_, cells_;
+};
+
+// ---------------------------------------------------------------------------------------------------------------- demodulator
+enum id_device_t { id_sdrplay = 0, id_airspy, id_plutosdr };                                  // dvbt2_demodulator.h:36-40
+struct signal_estimate {                                                                      // dvbt2_demodulator.h:42-52
+    bool change_frequency = false;
+    double coarse_freq_offset = 0.0;
+    bool frequency_changed = true;
+    bool change_gain = false;
+    int gain_offset = 0;
+    bool gain_changed = true;
+    double correct_resample = 0.0;
+    bool reset = false;
+    bool p1_reset = false;
+};
+
+// dvbt2_demodulator (dvbt2_demodulator.h:56-176): owns the time de-interleaver and is wired to it as the reference's constructor
+// wires it (dvbt2_demodulator.cpp:84-95: data -> execute, l1_dyn_execute -> l1_dyn_execute; start() is called directly, :386).
+// The signals stay re-assignable std::function members.
+class dvbt2_demodulator {
+public:
+    dvbt2_demodulator(id_device_t id_device, float sample_rate, int device = 0)
+        : deinterleaver(new time_deinterleaver(device)), h_(t2gpu_demod_create((int)id_device, sample_rate, device))
+    {
+        if (!h_) { delete deinterleaver; fail("t2gpu_demod_create"); }
+        l1_dyn_execute = [this](const l1_postsignalling &p, int len, complex *c) { deinterleaver->l1_dyn_execute(p, len, c); };
+        data = [this](int len, complex *c) { deinterleaver->execute(len, c); };
+        t2gpu_demod_signals s{};
+        s.user = this;
+        s.start = [](void *u, const t2gpu_l1_pre *pre, const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn) {
+            static_cast<dvbt2_demodulator *>(u)->deinterleaver->start(*pre, pack(post, plp, dyn));
+        };
+        s.l1_dyn_execute = [](void *u, const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn, int len, const float *cells) {
+            auto *d = static_cast<dvbt2_demodulator *>(u);
+            if (d->l1_dyn_execute) d->l1_dyn_execute(pack(post, plp, dyn), len, reinterpret_cast<complex *>(const_cast<float *>(cells)));
+        };
+        s.data = [](void *u, int len, const float *cells) {
+            auto *d = static_cast<dvbt2_demodulator *>(u);
+            if (d->data) d->data(len, reinterpret_cast<complex *>(const_cast<float *>(cells)));
+        };
+        s.amount_plp = [](void *u, int n) { auto *d = static_cast<dvbt2_demodulator *>(u); if (d->amount_plp) d->amount_plp(n); };
+        s.replace_null_indicator = [](void *u, float b1, float b2) {
+            auto *d = static_cast<dvbt2_demodulator *>(u);
+            if (d->replace_null_indicator) d->replace_null_indicator(b1, b2);
+        };
+        t2gpu_demod_connect(h_, &s);
+    }
+    ~dvbt2_demodulator() { t2gpu_demod_destroy(h_); delete deinterleaver; }
+    dvbt2_demodulator(const dvbt2_demodulator &) = delete;
+    dvbt2_demodulator &operator=(const dvbt2_demodulator &) = delete;
+
+    time_deinterleaver *deinterleaver;                                                        // .h:68
+    // signals (.h:70-75)
+    std::function<void(float b1, float b2)> replace_null_indicator;
+    std::function<void(const l1_postsignalling &l1_post, int len_in, complex *in)> l1_dyn_execute;
+    std::function<void(int num_plp)> amount_plp;
+    std::function<void(int len_in, complex *in)> data;
+    // slot (.h:78)
+    void execute(int len_in, int16_t *i_in, int16_t *q_in, signal_estimate *signal_)
+    {
+        t2gpu_signal_estimate s{};
+        s.change_frequency = signal_->change_frequency; s.coarse_freq_offset = signal_->coarse_freq_offset;
+        s.frequency_changed = signal_->frequency_changed; s.change_gain = signal_->change_gain; s.gain_offset = signal_->gain_offset;
+        s.gain_changed = signal_->gain_changed; s.correct_resample = signal_->correct_resample; s.reset = signal_->reset;
+        s.p1_reset = signal_->p1_reset;
+        const int rc = t2gpu_demod_execute(h_, len_in, i_in, q_in, &s);
+        signal_->change_frequency = s.change_frequency != 0; signal_->coarse_freq_offset = s.coarse_freq_offset;
+        signal_->frequency_changed = s.frequency_changed != 0; signal_->change_gain = s.change_gain != 0; signal_->gain_offset = s.gain_offset;
+        signal_->gain_changed = s.gain_changed != 0; signal_->correct_resample = s.correct_resample; signal_->reset = s.reset != 0;
+        signal_->p1_reset = s.p1_reset != 0;
+        if (rc != 0) fail("t2gpu_demod_execute");
+    }
+    // a recorded buffer has no tuner to move: see t2gpu_demod_set_tuner
+    void set_tuner(double offset_hz) { if (t2gpu_demod_set_tuner(h_, offset_hz) != 0) fail("t2gpu_demod_set_tuner"); }
+    t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
+private:
+    static l1_postsignalling pack(const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn)
+    {
+        l1_postsignalling p;
+        p.post = *post;
+        p.plp.assign(plp, plp + post->num_plp);
+        p.dyn_plp.assign(dyn, dyn + post->num_plp);
+        return p;
+    }
+    t2gpu_demod *h_;
 };
 
 }  // namespace t2

@@ -51,6 +51,19 @@ PROTOTYPES = {
     "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "t2gpu_l1_pre_parse": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_l1_post_parse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    "t2gpu_front_reset_loops": (ctypes.c_int, [_vp]),
+    "t2gpu_front_set_frequency_nco": (ctypes.c_int, [_vp, ctypes.c_float]),
+    "t2gpu_front_hold_iq": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_front_commit_iq": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_sync_reset": (None, [_vp, ctypes.c_float]),
+    "t2gpu_sync_clear_frequency": (None, [_vp]),
+    "t2gpu_sync_correct_resample": (None, [_vp, ctypes.c_double]),
+    "t2gpu_demod_create": (_vp, [ctypes.c_int, ctypes.c_float, ctypes.c_int]),
+    "t2gpu_demod_destroy": (None, [_vp]),
+    "t2gpu_demod_connect": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ti_frame_plan": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "t2gpu_bbdh_create": (_vp, [ctypes.c_int]),
     "t2gpu_bbdh_destroy": (None, [_vp]),

@@ -15,6 +15,8 @@ struct FrontState {
     float c1, c2;                          // IQ-imbalance coefficients used by the NEXT call (:228-234)
     float level_detect;                    // :235
     int32_t decim_phase;                   // filter_decimator's d (filter_decimator.h:77)
+    int32_t pad_;
+    double theta_acc[3], n_acc;            // sign statistics / samples of the chunks of one execute() still open (FRONT_STAGE_HOLD_IQ)
 };
 
 struct FrontParams {
@@ -38,7 +40,10 @@ struct FrontParams {
     int decim_phase;                       // phase at the start of this call (host copy)
 };
 
-enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4 };
+// FRONT_STAGE_HOLD_IQ: this call is one chunk of an execute() that goes on -- its sign statistics are added to the open sums and
+// c1 / c2 / level_detect stay as they are until launch_front_commit_iq (the reference derives them once per execute(), :227-235)
+enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4, FRONT_STAGE_HOLD_IQ = 8 };
+void launch_front_commit_iq(FrontState *state, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 

@@ -238,6 +238,16 @@ __global__ __launch_bounds__(256) void front_decimate_kernel(FrontParams p)
                            add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
 }
 
+// c1, c2, level_detect from the sign statistics of `len` samples (dvbt2_demodulator.cpp:227-235)
+__device__ __forceinline__ void front_iq_estimate(FrontState &s, double t1, double t2, double t3, float len)
+{
+    const float avg1 = (float)t1 / len, avg2 = (float)t2 / len, avg3 = (float)t3 / len;
+    s.c1 = avg1 / avg2;
+    const float c_temp = avg3 / avg2;
+    s.c2 = sqrtf(sub_r(mul_r(c_temp, c_temp), mul_r(s.c1, s.c1)));
+    s.level_detect = mul_r(avg2, avg3);
+}
+
 // ---- end of execute(): statistics -> c1, c2, level (:228-235); carry the delay lines and the decimation phase
 __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
 {
@@ -262,14 +272,24 @@ __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
     if (tid == 0 && (p.stages & FRONT_STAGE_DEROTATE) && p.n > 0) {
         FrontState &s = *p.state;
         for (int c = 0; c < 3; ++c) s.theta[c] = red[c][0];
-        const float len = (float)p.n;
-        const float avg1 = (float)red[0][0] / len, avg2 = (float)red[1][0] / len, avg3 = (float)red[2][0] / len;
-        s.c1 = avg1 / avg2;
-        const float c_temp = avg3 / avg2;
-        s.c2 = sqrtf(sub_r(mul_r(c_temp, c_temp), mul_r(s.c1, s.c1)));
-        s.level_detect = mul_r(avg2, avg3);
+        if (p.stages & FRONT_STAGE_HOLD_IQ) {
+            for (int c = 0; c < 3; ++c) s.theta_acc[c] += red[c][0];
+            s.n_acc += (double)p.n;
+        } else {
+            front_iq_estimate(s, red[0][0], red[1][0], red[2][0], (float)p.n);
+        }
     }
 }
+
+// end of an execute() whose chunks ran with FRONT_STAGE_HOLD_IQ (:227-235)
+__global__ void front_commit_iq_kernel(FrontState *state)
+{
+    FrontState &s = *state;
+    if (s.n_acc > 0.0) front_iq_estimate(s, s.theta_acc[0], s.theta_acc[1], s.theta_acc[2], (float)s.n_acc);
+    s.theta_acc[0] = s.theta_acc[1] = s.theta_acc[2] = 0.0;
+    s.n_acc = 0.0;
+}
+
 
 __device__ __forceinline__ float atan2_approx_dev(float y, float x)              // DSP/fast_math.h:61-81
 {
@@ -314,6 +334,11 @@ __global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, lo
 bool g_taps_loaded[16] = {};
 
 }  // namespace
+
+void launch_front_commit_iq(FrontState *state, hipStream_t stream)
+{
+    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state);
+}
 
 void launch_front(const FrontParams &p, hipStream_t stream)
 {

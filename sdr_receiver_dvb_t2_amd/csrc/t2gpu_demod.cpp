@@ -1,0 +1,445 @@
+// t2gpu_demod.cpp -- the reference's top-level slot as one C-ABI object:
+//     void dvbt2_demodulator::execute(int len_in, int16_t* i_in, int16_t* q_in, signal_estimate* signal_)
+//     (/root/reference/src/DVB_T2/dvbt2_demodulator.h:78, dvbt2_demodulator.cpp:145-254) with symbol_acquisition (:267-448),
+//     init_dvbt2 (:129-143), reset (:111-127), set_guard_interval (:450-480) and set_guard_interval_by_brute_force (:482-548).
+// Everything that touches samples runs on the GPU through the stage entry points of this library (front end, P1, guard
+// correlation, FFT, equalisers); what remains here is the reference's own host logic: chunk sizing, the symbol state machine,
+// acquisition from P1 / L1-pre / L1-post, the tracking-loop scalars. Buffers stay in HBM between the stages; what crosses to
+// the host per symbol is what the reference's signals carry (the equalised cells of a symbol for `data` / `l1_dyn_execute`),
+// two feedback floats and, for P2, the L1 cells.
+#include "../../include/t2gpu.h"
+#include "t2gpu_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace t2gpu;
+
+namespace {
+enum { SYMBOL_TYPE_P1 = 0, SYMBOL_TYPE_P2, SYMBOL_TYPE_DATA, SYMBOL_TYPE_FC };   // dvbt2_demodulator.h:146-151
+constexpr int P1_LEN = 2048;                                                        // dvbt2_definition.h:52
+constexpr int MAX_PLP = 32;
+constexpr float SAMPLE_RATE_HZ = 1.0f / (1.0e-6f * 7.0f / 64.0f);                  // SAMPLE_RATE, dvbt2_definition.h:36-38
+}
+
+struct t2gpu_demod {
+    int device = 0, id_device = 0, stride = 1;
+    float sample_rate = 0.0f, level_min = 0.02f, level_max = 0.04f;                 // :31-50
+    t2gpu_front *front = nullptr;
+    t2gpu_p1 *p1 = nullptr;
+    t2gpu_sync *sync = nullptr;
+    t2gpu_ofdm *p2_ofdm = nullptr, *data_ofdm = nullptr;
+    t2gpu_demod_signals sig{};
+    // members of dvbt2_demodulator (.h:84-176)
+    int next_symbol_type = SYMBOL_TYPE_P1;
+    bool p2_init = false, demodulator_init = false, deint_start = false, crc32_l1_pre = false, frame_closing_symbol = false;
+    int est_chunk = 0, symbol_size = P1_LEN, idx_buffer_sym = 0, idx_symbol = 0, end_data_symbol = 0;
+    float level_detect = 3.402823466e+38f;
+    // dvbt2_parameters as far as this path reads them
+    int preamble = -1, fft_mode = -1, fft_size = 0, guard_interval_mode = 0, guard_interval_size = 0, carrier_mode = 1,
+        pilot_pattern = 0, papr_mode = 0, n_data = 0, c_p2 = 0, c_data = 0, n_fc = 0, l_fc = 0, len_frame = 0;
+    int bf_idx = 0, bf_c = 0;                                                       // the statics of the brute-force search (:484-485)
+    t2gpu_l1_pre l1_pre{};
+    t2gpu_l1_post l1_post{};
+    t2gpu_l1_plp plp[MAX_PLP]{};
+    t2gpu_l1_dyn_plp dyn[MAX_PLP]{};
+    double tuner = 0.0;                                                             // rad / sample: the emulated local oscillator
+    long symbols = 0, frames = 0, resets = 0;
+    // device buffers
+    int16_t *d_i = nullptr, *d_q = nullptr;
+    size_t in_cap = 0;
+    float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec = nullptr, *d_cells = nullptr, *d_sync = nullptr, *d_cp = nullptr;
+    int32_t *d_symidx = nullptr;
+    long out_cap = 0;
+    std::vector<float> h_cells;
+};
+
+namespace {
+
+constexpr int MAX_SYMBOL = 32768 + 32768 / 4 + P1_LEN;                              // max_len_symbol, :52
+constexpr int CHUNK_MAX = 2 * (MAX_SYMBOL + P1_LEN) + 4096;                         // input samples of one chunk, resample <= ~1
+
+void free_all(t2gpu_demod *h)
+{
+    if (h->front) t2gpu_front_destroy(h->front);
+    if (h->p1) t2gpu_p1_destroy(h->p1);
+    if (h->sync) t2gpu_sync_destroy(h->sync);
+    if (h->p2_ofdm) t2gpu_ofdm_destroy(h->p2_ofdm);
+    if (h->data_ofdm) t2gpu_ofdm_destroy(h->data_ofdm);
+    hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out); hipFree(h->d_buffer_sym); hipFree(h->d_spec); hipFree(h->d_cells);
+    hipFree(h->d_sync); hipFree(h->d_cp); hipFree(h->d_symidx);
+}
+
+// dvbt2_demodulator::reset (:111-127)
+int reset(t2gpu_demod *h)
+{
+    if (t2gpu_front_reset_loops(h->front) != 0) return -1;
+    t2gpu_sync_reset(h->sync, h->sample_rate);
+    h->p2_init = false;
+    h->demodulator_init = false;
+    h->next_symbol_type = SYMBOL_TYPE_P1;
+    ++h->resets;
+    return 0;
+}
+
+// init_dvbt2 (:129-143): mode from P1 alone -- extended carriers assumed (dvbt2_definition.cpp:89), guard interval 1/4 "for start"
+int init_dvbt2(t2gpu_demod *h)
+{
+    if (h->preamble != 0 && h->preamble != 3) {     // T2_SISO / T2_LITE_SISO (dvbt2_definition.h:115-121)
+        set_error("t2gpu_demod: MISO preamble -- outside the supported set (README.md:17-23)");
+        return -1;
+    }
+    int info[12];
+    // P2 tables do not depend on pilot pattern, guard interval, PAPR or NUM_DATA_SYMBOLS: any valid combination serves
+    const int n_any = (h->fft_mode == 5 || h->fft_mode == 7) ? 59 : 40;
+    if (t2gpu_ofdm_mode_info(h->fft_mode, 1, 6, 4, 0, n_any, info) != 0) {
+        set_error("t2gpu_demod: FFT size signalled by P1 is outside the supported set (16K / 32K)");
+        return -1;
+    }
+    if (h->p2_ofdm) t2gpu_ofdm_destroy(h->p2_ofdm);
+    if (!(h->p2_ofdm = t2gpu_ofdm_create(h->fft_mode, 1, 6, 4, 0, n_any, 1, h->device))) return -1;
+    h->carrier_mode = 1;
+    h->fft_size = info[0];
+    h->c_p2 = info[5];
+    h->guard_interval_size = h->fft_size / 4;
+    h->symbol_size = h->fft_size + h->guard_interval_size;
+    h->est_chunk = h->symbol_size;
+    h->p2_init = true;
+    return 0;
+}
+
+void set_guard_interval(t2gpu_demod *h)                                             // :450-480
+{
+    const int f = h->fft_size;
+    switch (h->guard_interval_mode) {                                               // dvbt2_guardinterval_t
+    case 0: h->guard_interval_size = f / 32; break;
+    case 1: h->guard_interval_size = f / 16; break;
+    case 2: h->guard_interval_size = f / 8; break;
+    case 3: h->guard_interval_size = f / 4; break;
+    case 4: h->guard_interval_size = f / 128; break;
+    case 5: h->guard_interval_size = (f / 128) * 19; break;
+    case 6: h->guard_interval_size = (f / 256) * 19; break;
+    default: break;
+    }
+    h->symbol_size = f + h->guard_interval_size;
+    h->est_chunk = h->symbol_size;
+}
+
+void set_guard_interval_by_brute_force(t2gpu_demod *h)                              // :482-548
+{
+    const int num = 5, f = h->fft_size;
+    if (h->bf_c == 0) {
+        t2gpu_sync_clear_frequency(h->sync);
+        t2gpu_front_set_frequency_nco(h->front, 0.0f);
+    }
+    static const int div_mul[7][2] = {{32, 1}, {16, 1}, {8, 1}, {4, 1}, {128, 1}, {128, 19}, {256, 19}};
+    h->guard_interval_size = (f / div_mul[h->bf_idx][0]) * div_mul[h->bf_idx][1];
+    if (h->bf_c++ > num) {
+        h->bf_idx = h->bf_idx == 6 ? 0 : h->bf_idx + 1;
+        h->bf_c = 0;
+    }
+    h->symbol_size = f + h->guard_interval_size;
+    h->est_chunk = h->symbol_size;
+}
+
+// the data / frame-closing demodulators of the mode L1-pre signals (data_demodulator->init, fc_demod->init, :396-404)
+int init_data(t2gpu_demod *h)
+{
+    int info[12];
+    if (t2gpu_ofdm_mode_info(h->fft_mode, h->carrier_mode, h->pilot_pattern, h->guard_interval_mode, h->papr_mode, h->n_data, info) != 0) {
+        set_error("t2gpu_demod: the mode L1-pre signals is outside the supported set");
+        return -1;
+    }
+    if (h->data_ofdm) t2gpu_ofdm_destroy(h->data_ofdm);
+    if (!(h->data_ofdm = t2gpu_ofdm_create(h->fft_mode, h->carrier_mode, h->pilot_pattern, h->guard_interval_mode, h->papr_mode,
+                                           h->n_data, 1, h->device))) return -1;
+    h->c_data = info[6]; h->n_fc = info[7]; h->l_fc = info[9]; h->len_frame = info[10];
+    h->end_data_symbol = h->len_frame - h->l_fc;
+    h->frame_closing_symbol = h->l_fc != 0;
+    return 0;
+}
+
+// cells of the symbol just equalised -> host, for the signal that carries them
+const float *cells_to_host(t2gpu_demod *h, int n)
+{
+    if ((int)h->h_cells.size() < 2 * n) h->h_cells.resize((size_t)2 * n);
+    if (hipMemcpy(h->h_cells.data(), h->d_cells, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    return h->h_cells.data();
+}
+
+// symbol_acquisition (:267-448). Returns 0, or -1 on an error of a stage.
+int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal_)
+{
+    int consume = 0;
+    while (consume < len_in) {
+        if (h->next_symbol_type == SYMBOL_TYPE_P1) {
+            t2gpu_p1_result r;
+            const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, h->d_out, &consume,
+                                                 signal_->p1_reset, &r, nullptr);
+            if (det < 0) return -1;
+            if (det == 1) {
+                const int k = r.idx_buffer_sym;                                     // p1_symbol.cpp:97: already in buffer_sym
+                if (k > 0) T2_HIP(hipMemcpyAsync(h->d_buffer_sym, h->d_out + 2 * (size_t)(consume - k), (size_t)k * 8, hipMemcpyDeviceToDevice, nullptr));
+                h->idx_buffer_sym = k;
+                if (r.fft_mode >= 0) { h->fft_mode = r.fft_mode; h->preamble = r.preamble; }
+                signal_->coarse_freq_offset = r.coarse_freq_offset;
+                if (h->p2_init) {
+                    h->next_symbol_type = SYMBOL_TYPE_P2;
+                } else if (signal_->frequency_changed) {
+                    t2gpu_sync_correct_resample(h->sync, signal_->correct_resample);
+                    if (std::fabs((float)signal_->coarse_freq_offset) < 10.0f) {
+                        if (r.p1_decoded) {
+                            if (!signal_->p1_reset) {
+                                if (init_dvbt2(h) != 0) return -1;
+                            } else {
+                                h->p2_init = true;
+                                h->demodulator_init = true;
+                                signal_->p1_reset = 0;
+                            }
+                        }
+                    } else {
+                        signal_->change_frequency = 1;
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- buffer one symbol, guard correlation, FFT (:312-341)
+        const int len_in_sym = len_in - consume, len_out_sym = h->symbol_size - h->idx_buffer_sym;
+        const int len_cpy_sym = len_out_sym > len_in_sym ? len_in_sym : len_out_sym;
+        T2_HIP(hipMemcpyAsync(h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym, h->d_out + 2 * (size_t)consume, (size_t)len_cpy_sym * 8,
+                              hipMemcpyDeviceToDevice, nullptr));
+        consume += len_cpy_sym;
+        h->idx_buffer_sym += len_cpy_sym;
+        if (h->idx_buffer_sym != h->symbol_size) {
+            h->est_chunk = h->symbol_size - h->idx_buffer_sym;
+            continue;
+        }
+        h->idx_buffer_sym = 0;
+        if (h->crc32_l1_pre) {
+            float cp[4];
+            if (t2gpu_cp_correlate_dev(h->d_buffer_sym, 1, h->fft_size, h->guard_interval_size, h->d_cp, nullptr) != 0) return -1;
+            T2_HIP(hipMemcpy(cp, h->d_cp, sizeof cp, hipMemcpyDeviceToHost));
+            t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
+        }
+        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec, 1, nullptr) != 0)
+            return -1;
+        h->est_chunk = 0;
+        ++h->symbols;
+        float sv[2] = {0.0f, 0.0f};                                                 // phase_est, sample_rate_est of this symbol
+        // ---- the symbol demodulators (:343-427)
+        if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
+            if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec, h->d_symidx + h->idx_symbol, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
+            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
+            if (h->deint_start && h->sig.data) {
+                const float *c = cells_to_host(h, h->c_data);
+                if (!c) return -1;
+                h->sig.data(h->sig.user, h->c_data, c);
+            }
+            ++h->idx_symbol;
+            if (h->idx_symbol == h->end_data_symbol) {
+                h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
+                if (!h->frame_closing_symbol) ++h->frames;
+            }
+        } else if (h->next_symbol_type == SYMBOL_TYPE_FC) {
+            if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
+            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
+            if (h->deint_start && h->sig.data) {
+                const float *c = cells_to_host(h, h->n_fc);
+                if (!c) return -1;
+                h->sig.data(h->sig.user, h->n_fc, c);
+            }
+            h->next_symbol_type = SYMBOL_TYPE_P1;
+            ++h->frames;
+        } else {                                                                    // SYMBOL_TYPE_P2
+            h->idx_symbol = 0;
+            if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
+            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
+            const float *c = cells_to_host(h, h->c_p2);
+            if (!c) return -1;
+            // p2_symbol::execute's tail (p2_symbol.cpp:281-296): L1-pre, then L1-post
+            bool crc32_l1_post = false;
+            t2gpu_l1_pre pre;
+            h->crc32_l1_pre = t2gpu_l1_pre_parse(c, &pre) == 1;
+            if (h->crc32_l1_pre) {
+                h->l1_pre = pre;
+                h->carrier_mode = pre.bwt_ext;                                      // p2_symbol.cpp:493-500
+                h->guard_interval_mode = pre.guard_interval;
+                h->papr_mode = pre.papr;
+                h->pilot_pattern = pre.pilot_pattern;
+                h->n_data = pre.num_data_symbols;
+                if (1840 + pre.l1_post_size <= h->c_p2)
+                    crc32_l1_post = t2gpu_l1_post_parse(c + 2 * 1840, &pre, &h->l1_post, h->plp, h->dyn, MAX_PLP) == 1;
+            }
+            if (h->crc32_l1_pre) {
+                if (h->demodulator_init) {
+                    if (crc32_l1_post) {
+                        if (!h->deint_start) {
+                            if (h->sig.start) h->sig.start(h->sig.user, &h->l1_pre, &h->l1_post, h->plp, h->dyn);
+                            h->deint_start = true;
+                            if (h->sig.amount_plp) h->sig.amount_plp(h->sig.user, h->l1_post.num_plp);
+                        }
+                        if (h->sig.l1_dyn_execute) h->sig.l1_dyn_execute(h->sig.user, &h->l1_post, h->plp, h->dyn, h->c_p2, c);
+                    }
+                    ++h->idx_symbol;
+                    h->next_symbol_type = SYMBOL_TYPE_DATA;
+                } else {
+                    set_guard_interval(h);
+                    if (init_data(h) != 0) return -1;
+                    h->demodulator_init = true;
+                    h->next_symbol_type = SYMBOL_TYPE_P1;
+                    continue;
+                }
+            } else {
+                if (!h->demodulator_init) {
+                    set_guard_interval_by_brute_force(h);
+                    h->next_symbol_type = SYMBOL_TYPE_P1;
+                    continue;
+                } else {
+                    signal_->reset = 1;
+                    signal_->p1_reset = 1;
+                    return reset(h);
+                }
+            }
+        }
+        // ---- tracking loops (:429-439) and the readout the GUI gets (:441-444)
+        t2gpu_sync_symbol(h->sync, sv[0], sv[1]);
+        if (h->sig.replace_null_indicator) {
+            double g[4];
+            t2gpu_sync_get(h->sync, g);
+            const float PI_X_2 = 3.14159274101257324219f * 2.0f;
+            h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int device)
+{
+    if (id_device < 0 || id_device > 2 || !(sample_rate > 0.0f)) { set_error("t2gpu_demod_create: bad arguments"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+        set_error("t2gpu_demod_create: no usable HIP device (this library has no CPU path)");
+        return nullptr;
+    }
+    t2gpu_demod *h = new t2gpu_demod();
+    h->device = device; h->id_device = id_device; h->sample_rate = sample_rate;
+    h->stride = id_device == 1 ? 2 : 1;                                             // convert_input, :31-50
+    h->front = t2gpu_front_create(id_device, sample_rate, CHUNK_MAX, device);
+    h->out_cap = CHUNK_MAX + 4096;
+    h->p1 = t2gpu_p1_create((int)h->out_cap, device);
+    h->sync = t2gpu_sync_create(sample_rate);
+    bool ok = h->front && h->p1 && h->sync;
+    ok = ok && hipMalloc(&h->d_out, (size_t)h->out_cap * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)(MAX_SYMBOL + 8) * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_spec, (size_t)32768 * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
+    if (ok) {
+        std::vector<int32_t> idx(4096);
+        for (int i = 0; i < 4096; ++i) idx[i] = i;
+        ok = hipMemcpy(h->d_symidx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemset(h->d_buffer_sym, 0, (size_t)(MAX_SYMBOL + 8) * 8) == hipSuccess;
+    }
+    if (!ok) {
+        if (h->front && h->p1 && h->sync) set_error("t2gpu_demod_create: device allocation failed");
+        free_all(h);
+        delete h;
+        return nullptr;
+    }
+    t2gpu_front_hold_iq(h->front, 1);                                               // c1 / c2 / level once per execute(), :227-235
+    return h;
+}
+
+extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+}
+
+extern "C" int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *signals)
+{
+    if (!h) { set_error("t2gpu_demod_connect: bad arguments"); return -1; }
+    h->sig = signals ? *signals : t2gpu_demod_signals{};
+    return 0;
+}
+
+extern "C" int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz)
+{
+    if (!h) { set_error("t2gpu_demod_set_tuner: bad arguments"); return -1; }
+    h->tuner = 2.0 * 3.14159265358979323846 * offset_hz / (double)SAMPLE_RATE_HZ;
+    return 0;
+}
+
+extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const int16_t *q_in, t2gpu_signal_estimate *signal_)
+{
+    if (!h || len_in < 0 || !i_in || !q_in || !signal_) { set_error("t2gpu_demod_execute: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (len_in == 0) return 0;
+    const size_t el = (size_t)len_in * h->stride;
+    if (el > h->in_cap) {
+        T2_HIP(hipDeviceSynchronize());
+        hipFree(h->d_i); hipFree(h->d_q);
+        h->d_i = h->d_q = nullptr; h->in_cap = 0;
+        T2_HIP(hipMalloc(&h->d_i, el * 2));
+        T2_HIP(hipMalloc(&h->d_q, el * 2));
+        h->in_cap = el;
+    }
+    T2_HIP(hipMemcpy(h->d_i, i_in, el * 2, hipMemcpyHostToDevice));
+    T2_HIP(hipMemcpy(h->d_q, q_in, el * 2, hipMemcpyHostToDevice));
+    int idx_in = 0;
+    while (idx_in < len_in) {
+        if (h->est_chunk == 0) {                                                    // :151-155
+            if (h->next_symbol_type == SYMBOL_TYPE_P1) h->est_chunk += P1_LEN;
+            h->est_chunk += h->symbol_size;
+        }
+        double g[4];
+        t2gpu_sync_get(h->sync, g);
+        const double arbitrary_resample = g[3];                                     // :157-158
+        int32_t chunk = (int32_t)std::nearbyint(h->est_chunk * arbitrary_resample * 2.0);   // :160
+        if (chunk > len_in - idx_in) chunk = len_in - idx_in;
+        if (chunk > CHUNK_MAX) { set_error("t2gpu_demod_execute: chunk larger than the work buffers"); return -1; }
+        const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+        const long n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
+                                                   h->d_q + (size_t)idx_in * h->stride, h->d_out, h->out_cap, nullptr, nullptr);
+        if (n_out < 0) return -1;
+        idx_in += chunk;
+        if (symbol_acquisition(h, (int)n_out, signal_) != 0) return -1;
+    }
+    // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
+    if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;
+    float st[8];
+    if (t2gpu_front_state(h->front, st) != 0) return -1;
+    h->level_detect = st[6];
+    if (signal_->gain_changed) {
+        if (h->level_detect < h->level_min) { signal_->gain_offset = 1; signal_->change_gain = 1; }
+        else if (h->level_detect > h->level_max) { signal_->gain_offset = -1; signal_->change_gain = 1; }
+        else { signal_->gain_offset = 0; signal_->change_gain = 0; }
+    }
+    return 0;
+}
+
+extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
+{
+    if (!h || !out) { set_error("t2gpu_demod_status: bad arguments"); return -1; }
+    double g[4];
+    t2gpu_sync_get(h->sync, g);
+    out->next_symbol_type = h->next_symbol_type;
+    out->p2_init = h->p2_init; out->demodulator_init = h->demodulator_init; out->deint_start = h->deint_start;
+    out->crc32_l1_pre = h->crc32_l1_pre;
+    out->fft_mode = h->fft_mode; out->fft_size = h->fft_size; out->guard_interval_size = h->guard_interval_size;
+    out->symbol_size = h->symbol_size; out->carrier_mode = h->carrier_mode; out->pilot_pattern = h->pilot_pattern;
+    out->n_data = h->n_data; out->idx_symbol = h->idx_symbol;
+    out->symbols = h->symbols; out->frames = h->frames; out->resets = h->resets;
+    out->level_detect = h->level_detect;
+    out->phase_est_filtered = g[0]; out->frequency_est_filtered = g[1]; out->sample_rate_est_filtered = g[2];
+    out->arbitrary_resample = g[3];
+    return 0;
+}

@@ -21,6 +21,7 @@ struct t2gpu_front {
     // the two accumulators that do not depend on the signal live on the host (front_plan.h)
     float phase_nco = 0.0f, frequency_nco = 0.0f, x1 = -0.5f;
     int decim_phase = 0;
+    bool hold_iq = false;
     // device state and work buffers
     FrontState *d_state = nullptr;
     double *d_blk = nullptr, *d_theta = nullptr;
@@ -205,6 +206,45 @@ extern "C" int t2gpu_front_reset(t2gpu_front *h)
     return 0;
 }
 
+// dvbt2_demodulator::reset (:111-127) touches the dc averagers and the two NCOs only: c1 / c2 / level_detect and the filter
+// delay lines live on
+extern "C" int t2gpu_front_reset_loops(t2gpu_front *h)
+{
+    if (!h) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize(h->last_stream));
+    FrontState s;
+    T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+    s.dc_re = 0.0; s.dc_im = 0.0;
+    T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    h->phase_nco = 0.0f; h->frequency_nco = 0.0f;
+    return 0;
+}
+
+extern "C" int t2gpu_front_set_frequency_nco(t2gpu_front *h, float frequency_nco)
+{
+    if (!h) return -1;
+    h->frequency_nco = frequency_nco;
+    return 0;
+}
+
+extern "C" int t2gpu_front_hold_iq(t2gpu_front *h, int hold)
+{
+    if (!h) return -1;
+    h->hold_iq = hold != 0;
+    return 0;
+}
+
+extern "C" int t2gpu_front_commit_iq(t2gpu_front *h, void *stream)
+{
+    if (!h) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    launch_front_commit_iq(h->d_state, (hipStream_t)stream);
+    T2_HIP(hipGetLastError());
+    h->last_stream = (hipStream_t)stream;
+    return 0;
+}
+
 extern "C" int t2gpu_front_resample(const t2gpu_front *h, double *resample, double *max_resample)
 {
     if (!h) return -1;
@@ -236,7 +276,7 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     FrontParams p = base_params(h);
     p.i_in = d_i; p.q_in = d_q; p.n = (int)n; p.n_blocks = (int)((n + FRONT_BLOCK - 1) / FRONT_BLOCK);
     p.n_interp = n_interp; p.out = reinterpret_cast<float2 *>(d_out); p.n_out = n_out;
-    p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;
+    p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
     if (stage_tables(h, (int)n, stream, p) != 0) return -1;
     launch_front(p, stream);
     T2_HIP(hipGetLastError());
@@ -386,6 +426,7 @@ struct PiFilter {                                                               
         old_integral = integral;
         return out;
     }
+    void reset() { old_integral = 0.0f; }
 };
 }  // namespace
 
@@ -424,6 +465,21 @@ extern "C" void t2gpu_sync_symbol(t2gpu_sync *s, float phase_est, float sample_r
     }
     s->old_sample_rate_est = sample_rate_est;
 }
+// dvbt2_demodulator::reset (:111-127): loop filters, both estimates, the sample-rate tracker and the nominal resample
+extern "C" void t2gpu_sync_reset(t2gpu_sync *s, float sample_rate)
+{
+    if (!s) return;
+    s->phase.reset(); s->freq.reset();
+    s->frequency_est_filtered = 0.0f; s->old_sample_rate_est = 0.0f;            // phase_est_filtered is not touched there
+    s->sample_rate_est_filtered = 0.0;
+    const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);
+    s->resample = sample_rate / (fs * 2);
+}
+// set_guard_interval_by_brute_force, first attempt of a guard length (:484-487): the frequency estimate starts from zero
+extern "C" void t2gpu_sync_clear_frequency(t2gpu_sync *s) { if (s) s->frequency_est_filtered = 0.0f; }
+// symbol_acquisition after a re-tune (:291): resample -= correct_resample * resample
+extern "C" void t2gpu_sync_correct_resample(t2gpu_sync *s, double correct_resample) { if (s) s->resample -= correct_resample * s->resample; }
+
 extern "C" void t2gpu_sync_get(const t2gpu_sync *s, double *out4)
 {
     if (!s || !out4) return;

@@ -7,6 +7,9 @@
 //   stage_mirror_test cells  cells.c64 out.u8 need_plp ts.u8 l1_post_size cod n_sym sizes... num_plp {mod fec rot nb_max til start nb}...
 //                            (equalised cells of one T2 frame, symbol by symbol as data_symbol hands them over -> the whole
 //                            FEC side: time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder -> bb_de_header)
+//   stage_mirror_test rx     i.s16 q.s16 out.ts buf_len need_plp log.txt
+//                            (int16 I/Q as the SDR thread delivers it -> dvbt2_demodulator::execute buffer by buffer -> ... -> TS;
+//                            the loop around it is rx_sdrplay::start with the tuner emulated, no AGC)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -128,6 +131,75 @@ int main(int argc, char **argv)
                 pos += (size_t)sizes[l];
             }
             dump(argv[3], out);
+            dump(ts_path, ts);
+        } else if (mode == "rx") {
+            std::vector<int16_t> vi = slurp<int16_t>(argv[2]), vq = slurp<int16_t>(argv[3]);
+            const char *ts_path = argv[4];
+            const int buf_len = std::atoi(argv[5]), need_plp = std::atoi(argv[6]);
+            std::FILE *log = std::fopen(argv[7], "w");
+            t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f);
+            t2::llr_demapper qam;
+            t2::ldpc_decoder ldpc;
+            t2::bch_decoder bch;
+            t2::bb_de_header deheader(need_plp);
+            std::vector<uint8_t> ts;
+            long bbframes = 0;
+            demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
+            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+            ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
+            bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; deheader.execute(plp_id, p, len, bits); };
+            deheader.write_out = [&](const uint8_t *b, int n) { ts.insert(ts.end(), b, b + n); };
+            demodulator.amount_plp = [&](int n) { std::fprintf(log, "amount_plp %d\n", n); };
+            // ---- the SDR thread (rx_sdrplay.cpp:135-261) over a recording
+            t2::signal_estimate signal;
+            double rf_frequency = 0, ch_frequency = 626.0e6, tuner_hz = 0;
+            bool frequency_changed = true, gain_changed = true;
+            auto set_rf_frequency = [&]() {                                  // :158-176
+                if (!signal.frequency_changed) signal.frequency_changed = frequency_changed;
+                if (signal.change_frequency) {
+                    signal.change_frequency = false;
+                    frequency_changed = false;
+                    signal.frequency_changed = false;
+                    signal.correct_resample = signal.coarse_freq_offset / rf_frequency;
+                    rf_frequency += signal.coarse_freq_offset;
+                    tuner_hz += signal.coarse_freq_offset;                   // mir_sdr_SetRf: the recording cannot be re-tuned, the demodulator's
+                    demodulator.set_tuner(tuner_hz);                         // extra NCO term stands in for the local oscillator
+                    std::fprintf(log, "set_rf %.3f\n", tuner_hz);
+                }
+            };
+            auto set_gain = [&]() {                                          // :178-197 with agc = false
+                if (!signal.gain_changed) signal.gain_changed = gain_changed;
+            };
+            auto reset = [&]() {                                             // :135-156
+                signal.reset = false;
+                rf_frequency = ch_frequency;
+                tuner_hz = 0;
+                demodulator.set_tuner(0.0);
+                signal.coarse_freq_offset = 0.0;
+                signal.change_frequency = true;
+                signal.correct_resample = 0.0;
+                signal.gain_offset = 0;
+                signal.change_gain = true;
+                set_rf_frequency();
+                set_gain();
+                std::fprintf(log, "reset\n");
+            };
+            reset();
+            for (size_t pos = 0; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len) {
+                frequency_changed = true;                                    // rf_changed / gr_changed arrive with the next packets (:216-223)
+                gain_changed = true;
+                if (signal.reset) { reset(); continue; }                     // :229-235 (the buffer is dropped)
+                set_rf_frequency();
+                set_gain();
+                demodulator.execute(buf_len, vi.data() + pos, vq.data() + pos, &signal);
+                const t2gpu_demod_info st = demodulator.status();
+                std::fprintf(log, "buf %zu next %d p2_init %d init %d deint %d crc %d gi %d sym %ld frames %ld resets %ld level %.5f cfo %.2f fe %.3e res %.9f\n",
+                             pos / (size_t)buf_len, st.next_symbol_type, st.p2_init, st.demodulator_init, st.deint_start, st.crc32_l1_pre,
+                             st.guard_interval_size, (long)st.symbols, (long)st.frames, (long)st.resets, st.level_detect, signal.coarse_freq_offset,
+                             st.frequency_est_filtered, st.arbitrary_resample);
+            }
+            std::fprintf(log, "bbframes %ld ts %zu\n", bbframes, ts.size());
+            std::fclose(log);
             dump(ts_path, ts);
         } else return 2;
     } catch (const std::exception &e) {

@@ -135,3 +135,57 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
     ts = np.fromfile(tmp_path / "ts.u8", np.uint8)
     n_pkts = ((96 - n0) * ((k_bch - 80) // 8)) // 187 - 1
     assert np.array_equal(ts[:n_pkts * 188], ts1.reshape(-1)[:n_pkts * 188])
+
+
+def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
+    """t2::dvbt2_demodulator::execute(len, i, q, signal) -- the boundary slot -- fed buffer by buffer with int16 I/Q by a loop that is
+    rx_sdrplay::start over a recording. Nothing about the signal is configured: FFT size and SISO come from P1, the guard
+    interval from the reference's own search (first guess 1/4 fails, the brute-force list starts at 1/32 -- the signal's value; any
+    other value costs seven frames per list entry there as here, because the equaliser's phase unwrapping, data_symbol.cpp:189-191,
+    only follows one sign of slope and so needs the exact guard length), carrier mode, pilot pattern, frame length from L1-pre,
+    the PLP from L1-post; a 60 Hz carrier offset makes P1 ask for re-tunes until it reports less than 10 Hz. Everything from
+    the time de-interleaver down is the reference's connect() chain in C++. The transport stream of every frame after
+    acquisition comes back byte for byte."""
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 0, 0, 24), 400, 1, 0, 1, 12.0, 8
+    n_frames, seed, cfo_hz = 12, 191, 60.0
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    k_bch = t2_tx.K_BCH[cid]
+    per = nb * (k_bch // 1496 + 1)
+    ts = t2_tx.ts_packets(n_frames * per + 8, seed)
+    pre = dict(type=0, bwt_ext=mode[1], s1=0, s2_field1=4, guard_interval=mode[3], papr=0, l1_post_mod=0, l1_cod=0, l1_fec_type=0,
+               l1_post_size=lps, pilot_pattern=mode[2], num_t2_frames=2, num_data_symbols=mode[5], num_rf=1, t2_version=2)
+    plp = [dict(id=0, plp_type=1, plp_cod=code_rate, plp_mod=mod, plp_rotation=1, plp_fec_type=fec_type, plp_num_blocks_max=nb,
+                frame_interval=1, time_il_length=1, time_il_type=0, plp_mode=1)]
+    info = t2_tx.l1_post_bits(dict(), plp, [dict(id=0, start=0, num_blocks=nb)])
+    pre["l1_post_info_size"] = len(info)
+    l1c = np.concatenate([t2_tx.l1_pre_cells(pre, 3), t2_tx.l1_post_cells(info, 0, lps, 4)])
+    frames = []
+    for f in range(n_frames):
+        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts[f * per:(f + 1) * per], nb)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c))
+    i16, q16, flen = t2_tx.iq_stream(frames, m.fft_size // 32, s2, snr, seed)
+    x = (i16.astype(np.float64) + 1j * q16.astype(np.float64)) * np.exp(1j * (2 * np.pi * cfo_hz / (64e6 / 7) * np.arange(len(i16)) + 0.7))
+    buf = 1 << 18
+    pad = (-len(x)) % buf
+    x = np.concatenate([x, np.zeros(pad)])
+    np.rint(x.real).astype(np.int16).tofile(tmp_path / "i.s16")
+    np.rint(x.imag).astype(np.int16).tofile(tmp_path / "q.s16")
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out.ts", buf, 0, tmp_path / "log.txt")
+    log = open(tmp_path / "log.txt").read()
+    lines = [ln for ln in log.splitlines() if ln.startswith("buf ")]
+    last = dict(zip(lines[-1].split()[2::2], lines[-1].split()[3::2]))
+    assert "amount_plp 1" in log, log
+    assert log.count("set_rf") >= 2, log                                    # the initial tune of reset() and at least one re-tune
+    assert last["init"] == "1" and last["deint"] == "1" and last["crc"] == "1" and last["resets"] == "0", log
+    assert int(last["gi"]) == m.fft_size // 32, log                         # GUARD_INTERVAL of L1-pre confirmed the search
+    got = np.fromfile(tmp_path / "out.ts", np.uint8).tobytes()
+    dfl_bytes = (k_bch - 80) // 8
+    per_frame = (nb * dfl_bytes) // 187 - 1
+    found = [f for f in range(n_frames) if got.find(ts[f * per:f * per + per_frame - 1].tobytes()) >= 0]
+    # acquisition takes P1 (tune) .. P1 (init) .. P2 (guard search) .. P2 (L1-pre) .. P2 (L1-post): the frames after that are all
+    # there; the last frames' FEC blocks wait in an unfinished SIMD batch
+    assert len(found) >= 3 and found == list(range(found[0], found[0] + len(found))) and found[0] <= 8, (found, log)
+    assert found[-1] >= n_frames - 2, (found, log)
