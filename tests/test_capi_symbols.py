@@ -69,6 +69,39 @@ def test_create_without_gpu_fails_loudly(built):
         pkg.ldpc_decoder(1, 3)
 
 
+def test_every_handle_type_refuses_to_exist_without_a_gpu(built):
+    """no CPU path anywhere: each *_create of the ABI returns NULL and says why"""
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sdr_receiver_dvb_t2_amd._lib import lib
+    l = lib()
+    rate = ctypes.c_float(64.0e6 / 7.0)
+    for name, args in [("t2gpu_ldpc_create", (1, 3, 32, 0)), ("t2gpu_demap_create", (3, 1, 3, 1, 8100, 0)), ("t2gpu_ti_create", (3, 1, 10, 0)),
+                       ("t2gpu_ofdm_create", (5, 1, 6, 4, 0, 59, 1, 0)), ("t2gpu_front_create", (0, rate, 4096, 0)),
+                       ("t2gpu_p1_create", (4096, 0)), ("t2gpu_demod_create", (0, rate, 0))]:
+        assert not getattr(l, name)(*args), name
+        msg = l.t2gpu_last_error().decode()
+        assert "device" in msg.lower() or "gpu" in msg.lower(), (name, msg)
+
+
+def test_bad_arguments_are_errors_not_crashes(built):
+    import ctypes
+    from sdr_receiver_dvb_t2_amd._lib import lib
+    l = lib()
+    assert not l.t2gpu_demod_create(7, ctypes.c_float(1.0e6), 0)                       # unknown id_device
+    assert not l.t2gpu_demod_create(0, ctypes.c_float(0.0), 0)
+    assert l.t2gpu_demod_execute(None, 16, None, None, None) == -1
+    assert l.t2gpu_demod_status(None, None) == -1
+    assert l.t2gpu_demod_set_tuner(None, 1.0) == -1
+    assert l.t2gpu_ti_frame_plan(0, None, None, 100, None, None, 0) == -1
+    assert l.t2gpu_front_hold_iq(None, 1) == -1 and l.t2gpu_front_commit_iq(None, None) == -1
+    l.t2gpu_sync_reset(None, ctypes.c_float(1.0))                                        # void functions tolerate NULL
+    l.t2gpu_sync_clear_frequency(None)
+    l.t2gpu_sync_correct_resample(None, 0.0)
+
+
 def test_cpp_host_header_compiles(built, tmp_path):
     """include/t2gpu_stages.hpp (the reference's stage classes over the C ABI) and its test driver build with a plain g++."""
     import subprocess
