@@ -171,7 +171,10 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
     } while (0)
 
 template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
-__global__ __launch_bounds__(kThreads, 4) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
+#ifndef T2_LDPC_MIN_WAVES
+#define T2_LDPC_MIN_WAVES 4        // waves per SIMD the register allocation leaves room for: 4 -> 128 VGPRs (two workgroups per CU)
+#endif
+__global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
                                                                   const uint32_t *__restrict__ cninfo, LdpcKernelParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
