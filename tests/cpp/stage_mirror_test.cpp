@@ -10,6 +10,7 @@
 //   stage_mirror_test rx     i.s16 q.s16 out.ts buf_len need_plp log.txt
 //                            (int16 I/Q as the SDR thread delivers it -> dvbt2_demodulator::execute buffer by buffer -> ... -> TS;
 //                            the loop around it is rx_sdrplay::start with the tuner emulated, no AGC)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -185,6 +186,7 @@ int main(int argc, char **argv)
                 std::fprintf(log, "reset\n");
             };
             reset();
+            const auto t_begin = std::chrono::steady_clock::now();
             for (size_t pos = 0; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len) {
                 frequency_changed = true;                                    // rf_changed / gr_changed arrive with the next packets (:216-223)
                 gain_changed = true;
@@ -198,7 +200,9 @@ int main(int argc, char **argv)
                              st.guard_interval_size, (long)st.symbols, (long)st.frames, (long)st.resets, st.level_detect, signal.coarse_freq_offset,
                              st.frequency_est_filtered, st.arbitrary_resample);
             }
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             std::fprintf(log, "bbframes %ld ts %zu\n", bbframes, ts.size());
+            std::fprintf(log, "wall %.3f s for %zu samples = %.2f Msamples/s (real time: 9.14)\n", secs, vi.size(), vi.size() / secs / 1e6);
             std::fclose(log);
             dump(ts_path, ts);
         } else return 2;

@@ -175,6 +175,7 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     np.rint(x.imag).astype(np.int16).tofile(tmp_path / "q.s16")
     run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out.ts", buf, 0, tmp_path / "log.txt")
     log = open(tmp_path / "log.txt").read()
+    print(log.splitlines()[-1])                                                # throughput of the symbol-by-symbol form (pytest -s)
     lines = [ln for ln in log.splitlines() if ln.startswith("buf ")]
     last = dict(zip(lines[-1].split()[2::2], lines[-1].split()[3::2]))
     assert "amount_plp 1" in log, log
