@@ -121,6 +121,11 @@ int t2gpu_ti_cells_per_fec(const t2gpu_ti *h);
 int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks);
 int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream);
 int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
+/* n_blocks complete TI blocks of the geometry set by t2gpu_ti_begin in one launch (e.g. the same TI block of every T2 frame of a
+ * buffer): block f reads ti_block_size cells at d_cells + 2 * f * in_stride_cells floats and writes d_out + 2 * f *
+ * out_stride_cells. Same result as t2gpu_ti_begin + one whole-block t2gpu_ti_push_dev per block. Returns n_blocks. */
+int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_stride_cells, float *d_out, long out_stride_cells,
+                                int n_blocks, void *stream);
 
 /* ---------------------------------------------------------------- BB descrambler (the reference's BCH stage) ------
  * Replaces  void bch_decoder::execute(int* idx_plp_simd, l1_postsignalling, int len_in, uint8_t* in)

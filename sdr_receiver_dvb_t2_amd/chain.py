@@ -57,7 +57,7 @@ class t2_chain(object):
         self.frame_tags = [b[0] for b in self.plan for _ in range(b[2])]     # PLP of every FEC frame of a T2 frame
         plp_num_blocks = self.num_blocks = len(self.frame_tags)              # FEC frames per T2 frame, all PLPs
         self.need_plp = need_plp
-        self.ti = [[time_deinterleaver(plp_mod, plp_fec_type, q["plp_num_blocks_max"], device) for q in P] for _ in range(max_frames)]
+        self.ti = [time_deinterleaver(plp_mod, plp_fec_type, q["plp_num_blocks_max"], device) for q in P]   # one per PLP
         by_rotation = {}
         for q in P:
             if q["plp_rotation"] not in by_rotation:
@@ -137,12 +137,14 @@ class t2_chain(object):
         """From the equalised, frequency-de-interleaved cells of F frames already in self.cells[:F] (PLP cells of P2, then of every
         data symbol, then of the frame-closing symbol) to descrambled BBFRAME bits."""
         torch = self.torch
+        c0 = 0
+        for plp, off, nbk, n in self.plan:                       # TI block k of every frame in one launch
+            self.ti[plp].l1_dyn(nbk)
+            self.ti[plp].execute_blocks_dev(self.cells[:F, off:off + n], self.ti_out[:F, c0:c0 + n])
+            c0 += n
         for f in range(F):
             a, c0 = self.carry + f * self.num_blocks, 0
             for plp, off, nbk, n in self.plan:                   # one TI block after the other, each with its own SNR estimate
-                self.ti[f][plp].l1_dyn(nbk)
-                done = self.ti[f][plp].execute_dev(self.cells[f, off:off + n], self.ti_out[f, c0:c0 + n])
-                assert done
                 self.demaps[plp].execute_dev(self.ti_out[f, c0:c0 + n], out=self.llr[a:a + nbk])
                 a, c0 = a + nbk, c0 + n
             self.tags += self.frame_tags
@@ -174,10 +176,9 @@ class t2_chain(object):
             self.llr2 = [self.llr, torch.empty_like(self.llr)]
         assert self.carry == 0 and len(self.ti_blocks) == 1
         n_ti = self.num_blocks * self.cells_per_fec
+        self.ti[0].l1_dyn(self.num_blocks)
+        self.ti[0].execute_blocks_dev(self.cells[:F, :n_ti], self.ti_out[:F])
         for f in range(F):
-            self.ti[f][0].l1_dyn(self.num_blocks)
-            done = self.ti[f][0].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
-            assert done
             self.demap.execute_dev(self.ti_out[f], out=self.llr2[slot][f * self.num_blocks:(f + 1) * self.num_blocks])
         return F * self.num_blocks
 
@@ -190,10 +191,9 @@ class t2_chain(object):
             self.sums = torch.zeros((self.max_frames, 4), dtype=torch.float32, device=self.dev)
         assert len(self.ti_blocks) == 1, "the staged schedule covers one TI block per frame"
         n_ti = self.num_blocks * self.cells_per_fec
+        self.ti[0].l1_dyn(self.num_blocks)
+        self.ti[0].execute_blocks_dev(self.cells[:F, :n_ti], self.ti_out[:F])
         for f in range(F):
-            self.ti[f][0].l1_dyn(self.num_blocks)
-            done = self.ti[f][0].execute_dev(self.cells[f, :n_ti], self.ti_out[f])
-            assert done
             self.demap.stats_dev(self.ti_out[f], self.sums[f])
 
     def stage_llr_only(self, F, slot=0):

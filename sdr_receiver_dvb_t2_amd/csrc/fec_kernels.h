@@ -37,4 +37,12 @@ hipError_t launch_ti_scatter(const TiParams &p, const float2 *cells, int n0, int
 hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_t *lost, int num_blocks, const float *first_q,
                            float2 *out, hipStream_t s);
 
+// Whole TI blocks, one workgroup per FEC block with the block's cells staged in LDS (cells_per_fec * 8 bytes): reads the five
+// interleaver columns of the block row by row (40-byte runs), permutes inside LDS, writes the block contiguously. frames TI
+// blocks of the same geometry in one launch: block f reads cells + f * in_stride, writes out + f * out_stride (in cells).
+// lost_by_block[b] = 1: the reference never stores the parked Q of FEC block b (see t2gpu_ti_begin), the last cell keeps its Q.
+// Returns hipErrorInvalidValue when the FEC block does not fit LDS (QPSK with 64800-bit frames): use the scatter kernels.
+hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
+                            float2 *out, long out_stride, int frames, hipStream_t s);
+
 }  // namespace t2gpu

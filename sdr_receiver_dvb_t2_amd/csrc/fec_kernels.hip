@@ -228,4 +228,48 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
     return hipGetLastError();
 }
 
+// ---- the same for complete TI blocks, staged through LDS -------------------------------------------------------------------
+// Cell n = row * cols + col of the TI block sits at interleaver address d = col * rows + row; FEC block b owns columns
+// 5b .. 5b+4 and perm maps its d range onto its own output range (time_deinterleaver.cpp:174-266: the cell permutation is
+// block-local), so a workgroup needs nothing but its block's cells.
+__global__ __launch_bounds__(512) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
+                                                      const float2 *__restrict__ cells, long in_stride, float2 *__restrict__ out,
+                                                      long out_stride)
+{
+    extern __shared__ float ti_lds[];                    // [cells_per_fec][2]
+    const int b = blockIdx.x % num_blocks, f = blockIdx.x / num_blocks;
+    const int C = p.cells_per_fec, rows = p.rows;
+    const float2 *in = cells + (long)f * in_stride;
+    float2 *o = out + (long)f * out_stride + (long)b * C;
+    const int32_t *perm = p.perm + (long)b * C;
+    const int base = b * C;
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        const int row = t / 5, c5 = t - row * 5;
+        const float2 v = in[(long)row * p.cols + 5 * b + c5];
+        const int ia = perm[c5 * rows + row] - base;     // position inside the FEC block
+        ti_lds[2 * ia] = v.x;
+        ti_lds[2 * (ia == 0 ? C - 1 : ia - 1) + 1] = v.y; // Q travels one cell behind its I, cyclically (:321-336)
+    }
+    __syncthreads();
+    const bool lost = lost_by_block[b] != 0;
+    for (int t = threadIdx.x; t < C; t += blockDim.x) {
+        if (t == C - 1 && lost) reinterpret_cast<float *>(o)[2 * t] = ti_lds[2 * t];
+        else o[t] = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
+    }
+}
+
+hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
+                            float2 *out, long out_stride, int frames, hipStream_t s)
+{
+    const size_t lds = (size_t)p.cells_per_fec * 8;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(num_blocks * frames)), dim3(512), lds, s, p, lost_by_block, num_blocks, cells, in_stride,
+                       out, out_stride);
+    return hipGetLastError();
+}
+
 }  // namespace t2gpu

@@ -182,7 +182,7 @@ struct t2gpu_ti {
     TiParams p{};
     std::vector<int32_t> perm;         // host copy, for the per-geometry event order
     int32_t *d_perm = nullptr, *d_order = nullptr;
-    uint8_t *d_lost = nullptr;
+    uint8_t *d_lost = nullptr, *d_lost_blk = nullptr;
     float *d_first_q = nullptr;
     float *d_in = nullptr, *d_out = nullptr;   // host-call staging
     std::map<int, std::pair<std::vector<int32_t>, std::vector<uint8_t>>> geom;   // num_blocks -> (order, lost)
@@ -203,6 +203,7 @@ extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, 
     ok = ok && hip_ok(hipMemcpy(h->d_perm, h->perm.data(), h->perm.size() * 4, hipMemcpyHostToDevice), "hipMemcpy");
     ok = ok && hip_ok(hipMalloc(&h->d_order, num_blocks_max * 4), "hipMalloc");
     ok = ok && hip_ok(hipMalloc(&h->d_lost, num_blocks_max), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc(&h->d_lost_blk, num_blocks_max), "hipMalloc");
     ok = ok && hip_ok(hipMalloc(&h->d_first_q, num_blocks_max * 4), "hipMalloc");
     if (!ok) { t2gpu_ti_destroy(h); return nullptr; }
     h->p.cells_per_fec = h->cells_per_fec;
@@ -214,7 +215,7 @@ extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, 
 extern "C" void t2gpu_ti_destroy(t2gpu_ti *h)
 {
     if (!h) return;
-    hipFree(h->d_perm); hipFree(h->d_order); hipFree(h->d_lost); hipFree(h->d_first_q); hipFree(h->d_in); hipFree(h->d_out);
+    hipFree(h->d_perm); hipFree(h->d_order); hipFree(h->d_lost); hipFree(h->d_lost_blk); hipFree(h->d_first_q); hipFree(h->d_in); hipFree(h->d_out);
     delete h;
 }
 
@@ -225,9 +226,11 @@ extern "C" int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks)
 {
     if (!h || num_blocks < 1 || num_blocks > h->num_blocks_max) { set_error("t2gpu_ti_begin: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
+    const bool loaded = h->num_blocks == num_blocks;       // the device tables of this geometry are already in place
     h->num_blocks = num_blocks; h->pos = 0;
     h->p.cols = 5 * num_blocks;
     h->p.ti_block_size = h->p.cols * h->p.rows;
+    if (loaded) return 0;
     auto it = h->geom.find(num_blocks);
     if (it == h->geom.end()) {
         // Order in which the first cells of the FEC blocks arrive, and which of their parked Q values the reference
@@ -253,7 +256,34 @@ extern "C" int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks)
     }
     T2_HIP(hipMemcpy(h->d_order, it->second.first.data(), num_blocks * 4, hipMemcpyHostToDevice));
     T2_HIP(hipMemcpy(h->d_lost, it->second.second.data(), num_blocks, hipMemcpyHostToDevice));
+    std::vector<uint8_t> lost_by_block(num_blocks, 0);
+    for (int k = 0; k < num_blocks; ++k) lost_by_block[it->second.first[k]] = it->second.second[k];
+    T2_HIP(hipMemcpy(h->d_lost_blk, lost_by_block.data(), num_blocks, hipMemcpyHostToDevice));
     return 0;
+}
+
+// Complete TI blocks of the current geometry (t2gpu_ti_begin), n_blocks of them in one launch -- e.g. the same TI block of every
+// T2 frame of a buffer. Equivalent to t2gpu_ti_begin + one t2gpu_ti_push_dev of ti_block_size cells per block.
+extern "C" int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_stride_cells, float *d_out, long out_stride_cells,
+                                           int n_blocks, void *stream)
+{
+    if (!h || !d_cells || !d_out || n_blocks < 0 || !h->num_blocks || h->pos != 0) {
+        set_error("t2gpu_ti_execute_blocks_dev: bad arguments (t2gpu_ti_begin first; no TI block may be half pushed)");
+        return -1;
+    }
+    if (n_blocks == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = launch_ti_blocks(h->p, h->d_lost_blk, h->num_blocks, reinterpret_cast<const float2 *>(d_cells), in_stride_cells,
+                                    reinterpret_cast<float2 *>(d_out), out_stride_cells, n_blocks, s);
+    if (e == hipErrorInvalidValue) {            // FEC block larger than LDS: block by block through the scatter kernels
+        for (int f = 0; f < n_blocks; ++f) {
+            const int rc = t2gpu_ti_push_dev(h, d_cells + 2 * f * in_stride_cells, h->p.ti_block_size, d_out + 2 * f * out_stride_cells, stream);
+            if (rc != 1) return -1;
+        }
+        return n_blocks;
+    }
+    T2_HIP(e);
+    return n_blocks;
 }
 
 extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream)

@@ -122,6 +122,21 @@ class time_deinterleaver(object):
             check(rc, "t2gpu_ti_push_dev")
         return rc == 1
 
+    def execute_blocks_dev(self, cells, out):
+        """cells, out: CUDA float32 [n][>= ti_block_size][2] views (row stride free): the same TI block of n frames in one launch."""
+        import torch
+        assert cells.is_cuda and out.is_cuda and cells.dtype == torch.float32 and out.dtype == torch.float32
+        assert cells.dim() == 3 and out.dim() == 3 and cells.shape[0] == out.shape[0]
+        assert cells.stride(2) == 1 and cells.stride(1) == 2 and out.stride(2) == 1 and out.stride(1) == 2
+        assert cells.stride(0) % 2 == 0 and out.stride(0) % 2 == 0
+        assert cells.shape[1] >= self.num_blocks * self.cells_per_fec and out.shape[1] >= self.num_blocks * self.cells_per_fec
+        stream = torch.cuda.current_stream(cells.device).cuda_stream
+        rc = self._l.t2gpu_ti_execute_blocks_dev(self._h, cells.data_ptr(), cells.stride(0) // 2, out.data_ptr(), out.stride(0) // 2,
+                                                 cells.shape[0], stream)
+        if rc < 0:
+            check(rc, "t2gpu_ti_execute_blocks_dev")
+        return rc
+
     def execute(self, cells, out):
         cells = np.ascontiguousarray(cells, dtype=np.complex64).reshape(-1)
         assert out.dtype == np.complex64 and out.flags.c_contiguous

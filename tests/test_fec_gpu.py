@@ -126,3 +126,28 @@ def test_time_cell_deinterleaver(torch_cuda, mod, fec_type, blocks):
     assert ti.execute(cells, host_out)
     assert np.array_equal(host_out, out_o)
     ti.close()
+
+
+@pytest.mark.parametrize("mod,fec_type,blocks", [(3, 1, 202), (3, 0, 9), (2, 1, 5), (1, 1, 4), (0, 1, 2), (1, 0, 1)])
+def test_time_deinterleaver_whole_blocks_in_one_launch(torch_cuda, mod, fec_type, blocks):
+    """t2gpu_ti_execute_blocks_dev (FEC blocks staged through LDS, the same TI block of several frames per launch) against the
+    streaming entry point it is defined by -- including the parked-Q cells the reference never stores (they keep the buffer's
+    previous content) and the geometry whose FEC block is larger than LDS (QPSK, 64800: scatter path inside)."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    frames = 3
+    a, b = pkg.time_deinterleaver(mod, fec_type, blocks), pkg.time_deinterleaver(mod, fec_type, blocks)
+    n = blocks * a.cells_per_fec
+    rng = np.random.Generator(np.random.PCG64(1000 + mod * 10 + blocks))
+    pad = 37                                                                     # frames do not lie back to back
+    cells = torch.from_numpy(rng.standard_normal((frames, n + pad, 2)).astype(np.float32)).cuda()
+    hist = torch.from_numpy(rng.standard_normal((frames, n + pad, 2)).astype(np.float32)).cuda()
+    out_a, out_b = hist.clone(), hist.clone()
+    for f in range(frames):
+        a.l1_dyn(blocks)
+        assert a.execute_dev(cells[f, :n], out_a[f, :n])
+    b.l1_dyn(blocks)
+    assert b.execute_blocks_dev(cells[:, :n], out_b[:, :n]) == frames
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    a.close(); b.close()
