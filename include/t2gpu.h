@@ -99,6 +99,10 @@ int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cells, int8_t 
  * them -- so that a multi-stream scheduler can place them separately; calling one after the other equals execute_dev. */
 int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override, float *d_sums3, void *stream);
 int t2gpu_demap_llr_dev(t2gpu_demap *h, const float *d_cells, int n_cells, const float *d_sums3, int8_t *d_llr, void *stream);
+/* the statistics pass for n_blocks TI blocks of cells_per_block cells in one launch: block t at d_cells + 2 * t * cells_stride
+ * floats, its triple at d_sums + t * sums_stride (same sums as n_blocks calls of t2gpu_demap_stats_dev, bit for bit) */
+int t2gpu_demap_stats_batch_dev(t2gpu_demap *h, const float *d_cells, long cells_stride, int n_blocks, int cells_per_block,
+                                float precision_override, float *d_sums, int sums_stride, void *stream);
 /* the LLR pass for n_blocks TI blocks in one launch: block t = cells_per_block cells at d_cells + 2 * t * cells_per_block floats,
  * its statistics at d_sums + t * sums_stride; LLR frames back to back in d_llr. Returns the number of FEC frames. */
 int t2gpu_demap_llr_batch_dev(t2gpu_demap *h, const float *d_cells, int n_blocks, int cells_per_block, const float *d_sums,

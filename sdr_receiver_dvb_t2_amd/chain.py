@@ -193,8 +193,7 @@ class t2_chain(object):
         n_ti = self.num_blocks * self.cells_per_fec
         self.ti[0].l1_dyn(self.num_blocks)
         self.ti[0].execute_blocks_dev(self.cells[:F, :n_ti], self.ti_out[:F])
-        for f in range(F):
-            self.demap.stats_dev(self.ti_out[f], self.sums[f])
+        self.demap.stats_batch_dev(self.ti_out[:F, :n_ti], self.sums)
 
     def stage_llr_only(self, F, slot=0):
         n_ti = self.num_blocks * self.cells_per_fec

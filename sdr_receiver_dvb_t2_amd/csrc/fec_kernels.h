@@ -22,6 +22,8 @@ struct DemapParams {
 // partial[] = scratch of 2*blocks doubles. Second stage folds them and writes float sums[0..2] (s, e, precision).
 hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
                               float precision_override, hipStream_t s);
+hipError_t launch_demap_stats_batch(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, double *partial,
+                                    int blocks, float *sums, int sums_stride, float precision_override, hipStream_t s);
 // K-demap-bdi: one workgroup per FEC frame; LLRs staged in LDS in LDPC order, written out coalesced.
 // frames_per_sums / sums_stride: several TI blocks in one launch, each with its own statistics triple (0 = one triple for all)
 hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s,

@@ -80,9 +80,12 @@ __device__ __forceinline__ float slice_axis(int mod, float x, float d)
     return (x < -x2) ? -(d * 3.0f) : -d;
 }
 
+// blockIdx.y = TI block of a batch: its cells at cells + y * cells_stride, its partial sums at partial + y * 2 * gridDim.x
 __global__ __launch_bounds__(256) void demap_stats_kernel(DemapParams p, const float2 *__restrict__ cells, int n_snr,
-                                                         double *__restrict__ partial)
+                                                         double *__restrict__ partial, long cells_stride)
 {
+    cells += (long)blockIdx.y * cells_stride;
+    partial += (long)blockIdx.y * 2 * gridDim.x;
     double ss = 0.0, se = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_snr; i += gridDim.x * blockDim.x) {
         float2 v = cells[i];
@@ -103,8 +106,10 @@ __global__ __launch_bounds__(256) void demap_stats_kernel(DemapParams p, const f
 }
 
 __global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__restrict__ partial, int blocks, float d,
-                                                               float precision_override, float *__restrict__ sums)
+                                                               float precision_override, float *__restrict__ sums, int sums_stride)
 {
+    partial += (long)blockIdx.x * 2 * blocks;
+    sums += (long)blockIdx.x * sums_stride;
     // one wavefront folds the per-block partial sums; lane-strided accumulation then a fixed butterfly: deterministic
     double ss = 0.0, se = 0.0;
     for (int b = threadIdx.x; b < blocks; b += 64) { ss += partial[2 * b]; se += partial[2 * b + 1]; }
@@ -119,8 +124,18 @@ __global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__r
 hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
                               float precision_override, hipStream_t s)
 {
-    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n_snr, partial);
-    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums);
+    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n_snr, partial, 0L);
+    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, 0);
+    return hipGetLastError();
+}
+
+// n_batch TI blocks in one launch pair; partial holds n_batch * blocks pairs. Per block the additions happen in the order of
+// launch_demap_stats, so the sums are the same bit for bit.
+hipError_t launch_demap_stats_batch(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, double *partial,
+                                    int blocks, float *sums, int sums_stride, float precision_override, hipStream_t s)
+{
+    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks, n_batch), dim3(256), 0, s, p, cells, n_snr, partial, cells_stride);
+    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(n_batch), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, sums_stride);
     return hipGetLastError();
 }
 

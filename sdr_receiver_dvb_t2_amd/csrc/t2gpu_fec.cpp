@@ -53,7 +53,7 @@ extern "C" int t2gpu_table_bb_prbs(uint8_t *out, int n)
 // ------------------------------------------------------------------------------------------------ demapper
 struct t2gpu_demap {
     DemapParams p{};
-    int device = 0, max_cells = 0, stats_blocks = 0;
+    int device = 0, max_cells = 0, stats_blocks = 0, partial_batches = 1;
     uint16_t *d_address = nullptr;
     double *d_partial = nullptr;
     float *d_sums = nullptr;
@@ -134,6 +134,31 @@ extern "C" int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n
     const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
     T2_HIP(launch_demap_stats(h->p, reinterpret_cast<const float2 *>(d_cells), n_snr, h->d_partial, blocks, d_sums3, precision_override,
                               (hipStream_t)stream));
+    return 0;
+}
+
+// the statistics pass for n_blocks TI blocks of cells_per_block cells in one launch: block t at d_cells + 2 * t * cells_stride
+// floats, its triple at d_sums + t * sums_stride
+extern "C" int t2gpu_demap_stats_batch_dev(t2gpu_demap *h, const float *d_cells, long cells_stride, int n_blocks, int cells_per_block,
+                                           float precision_override, float *d_sums, int sums_stride, void *stream)
+{
+    if (!h || !d_cells || !d_sums || n_blocks < 1 || cells_per_block < 1 || cells_per_block > h->max_cells || sums_stride < 3) {
+        set_error("t2gpu_demap_stats_batch_dev: bad arguments");
+        return -1;
+    }
+    T2_HIP(hipSetDevice(h->device));
+    if (n_blocks > h->partial_batches) {
+        T2_HIP(hipStreamSynchronize((hipStream_t)stream));
+        double *p = nullptr;
+        T2_HIP(hipMalloc(&p, sizeof(double) * 2 * h->stats_blocks * (size_t)n_blocks));
+        T2_HIP(hipDeviceSynchronize());
+        hipFree(h->d_partial);
+        h->d_partial = p; h->partial_batches = n_blocks;
+    }
+    const int n_snr = h->p.mod == 0 ? std::min(cells_per_block, 2048) : cells_per_block;
+    const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
+    T2_HIP(launch_demap_stats_batch(h->p, reinterpret_cast<const float2 *>(d_cells), cells_stride, n_snr, n_blocks, h->d_partial, blocks,
+                                    d_sums, sums_stride, precision_override, (hipStream_t)stream));
     return 0;
 }
 

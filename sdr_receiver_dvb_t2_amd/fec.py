@@ -62,6 +62,17 @@ class llr_demapper(object):
         if rc < 0:
             check(rc, "t2gpu_demap_stats_dev")
 
+    def stats_batch_dev(self, cells, sums, precision_override=0.0):
+        """First pass for n TI blocks in one launch: cells float32 [n][block cells][2] (row stride free), sums float32 [n][>= 3]."""
+        import torch
+        assert cells.dim() == 3 and cells.stride(2) == 1 and cells.stride(1) == 2 and cells.stride(0) % 2 == 0
+        assert sums.dim() == 2 and sums.shape[0] >= cells.shape[0] and sums.stride(1) == 1
+        rc = self._l.t2gpu_demap_stats_batch_dev(self._h, cells.data_ptr(), cells.stride(0) // 2, cells.shape[0], cells.shape[1],
+                                                 float(precision_override), sums.data_ptr(), sums.stride(0),
+                                                 torch.cuda.current_stream(cells.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_demap_stats_batch_dev")
+
     def llr_dev(self, cells, sums, out):
         """Second pass only: LLR frames into `out` with the statistics `sums` of stats_dev."""
         import torch

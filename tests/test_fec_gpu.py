@@ -151,3 +151,22 @@ def test_time_deinterleaver_whole_blocks_in_one_launch(torch_cuda, mod, fec_type
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("mod,blocks", [(3, 5), (0, 2), (2, 3)])
+def test_demapper_statistics_of_several_ti_blocks_in_one_launch(torch_cuda, mod, blocks):
+    """t2gpu_demap_stats_batch_dev against t2gpu_demap_stats_dev block by block: the same three floats, bit for bit"""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    fec_type, n_ti = 0, 4
+    dm = pkg.llr_demapper(mod, fec_type, 1, 1, max_cells=blocks * (16200 // (2 * (mod + 1))))
+    n = blocks * (16200 // (2 * (mod + 1)))
+    rng = np.random.Generator(np.random.PCG64(60 + mod))
+    cells = torch.from_numpy((rng.standard_normal((n_ti, n + 11, 2)) * np.linspace(0.5, 1.5, n_ti)[:, None, None]).astype(np.float32)).cuda()
+    one = torch.zeros((n_ti, 4), dtype=torch.float32, device="cuda")
+    many = torch.zeros((n_ti, 4), dtype=torch.float32, device="cuda")
+    for t in range(n_ti):
+        dm.stats_dev(cells[t, :n], one[t])
+    dm.stats_batch_dev(cells[:, :n], many)
+    torch.cuda.synchronize()
+    assert torch.equal(one, many) and float(one[:, 2].min()) > 0
