@@ -130,7 +130,7 @@ T2_HD int t2_rawmag(const CnRegs<CNT> &r, int c)
 
 template <int CNT, class LMEM>
 T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, int a_p0, int a_p1, const CnState &st,
-                      CnRegs<CNT> &r)
+                      CnRegs<CNT> &r, const uint32_t *__restrict__ ent2 = nullptr)
 {
     r.c0 = st.w0; r.c1 = st.w1;
     {
@@ -144,7 +144,18 @@ T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, in
     for (int c = 0; c < CNT + 2; ++c) {
         // L.off(): where the LLR array starts in the memory L addresses (the LDS offset on the GPU; folded into the table entry's
         // base by scalar arithmetic, so the per-lane address needs no further add at the load or the store)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (c < CNT) {
+            int m = j - (int)ent2[2 * c + 1];
+            m += (m < 0) ? 360 : 0;
+            r.addr[c] = (int)ent2[2 * c] + m;
+        } else {
+            r.addr[c] = (c == CNT ? a_p0 : a_p1);
+        }
+#else
+        (void)ent2;
         r.addr[c] = (c < CNT) ? t2_link_addr(ent[c < CNT ? c : 0] + (uint32_t)L.off(), j) : (c == CNT ? a_p0 : a_p1);
+#endif
     }
 #pragma unroll
     for (int c = 0; c < CNT + 2; ++c) r.in[c] = t2_present(r, c) ? (int)L.ld(r.addr[c]) : 0;
@@ -269,6 +280,8 @@ struct LayerDesc {
     int cnt, lmax, nc, kind, step;
     int dummy;      // address of a scratch byte in the LLR memory: target of the stores a chain walker predicates away
     uint32_t e0;    // ent[0], fetched when the descriptor is made (the chain walker needs it right behind a barrier)
+    const uint32_t *ent2 = nullptr;   // GPU only: the same entries as (base + L.off(), shift) dword pairs -- saves the scalar
+                                      // add / shift / mask per link that unpacking costs every wavefront in every layer
 };
 
 // phase A: every node loads; PLAIN nodes and chain-start / level-free nodes finish at once
@@ -276,7 +289,7 @@ template <int CNT, class LMEM>
 T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_p1, CnState &st, CnRegs<CNT> &r,
                             uint32_t *pair_rec)
 {
-    t2_cn_load<CNT>(L, d.ent, j, a_p0, a_p1, st, r);
+    t2_cn_load<CNT>(L, d.ent, j, a_p0, a_p1, st, r, d.ent2);
     if (d.kind == T2_LAYER_PLAIN) {
         t2_cn_partial<CNT>(r, 0);
         r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;

@@ -16,6 +16,8 @@ struct LdpcKernelParams {
     int n, k, q;
     const LdpcLayerDev *layers;   // [q]
     const uint32_t *entries;      // packed base | shift<<16
+    const uint32_t *entries2;     // the same as pairs (base + lds_base, shift): what the check-node load reads
+    int lds_base;                 // LDS address of the LLR array the pairs were made for (= the kernel's static LDS size)
     const uint32_t *cninfo;       // [q*360] level | dependent-slot mask << 8 (GENERIC layers)
     // job
     const int8_t *llr;            // [n_frames][n] received LLRs, transmitted order
@@ -37,7 +39,7 @@ struct LdpcKernelParams {
     unsigned *resident;           // counts workgroups that have started, cumulatively over launches (t2gpu_ldpc_wait_resident)
 };
 
-hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu);
+hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes);
 hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);
 
 }  // namespace t2gpu

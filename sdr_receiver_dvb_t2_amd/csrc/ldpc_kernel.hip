@@ -175,7 +175,8 @@ template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
 #define T2_LDPC_MIN_WAVES 4        // waves per SIMD the register allocation leaves room for: 4 -> 128 VGPRs (two workgroups per CU)
 #endif
 __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
-                                                                  const uint32_t *__restrict__ cninfo, LdpcKernelParams p)
+                                                                  const uint32_t *__restrict__ cninfo, const uint32_t *__restrict__ entries2,
+                                                                  LdpcKernelParams p)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
     int8_t *Lm = lds;
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
     const int tid = threadIdx.x;
     const int j = tid;
     const bool active = j < 360;
+    if (L.off() != p.lds_base) {                     // the split table was built for another LDS layout: refuse, loudly
+        if (tid == 0) *p.error = 2;
+        return;
+    }
     const int group = p.group;
     const int slot = blockIdx.x / group, member = blockIdx.x % group;
     const int nslots = gridDim.x / group;
@@ -261,7 +266,8 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
                 uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
                 for (int i = 0; i < p.q; ++i) {
                     const LdpcLayerDev ly = layers[i];
-                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry]};
+                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
+                                entries2 + 2 * ly.first_entry};
                     const uint32_t info = info_nxt;
                     const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
                     const int a0 = L.off() + p.k + 360 * i + jn, a1r = parity_prev_addr(p.k, p.q, i, jn);
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
 }
 
 // Kernel variants by range of information-bit links per check node: the twelve T2 codes fall into four families.
-typedef void (*ldpc_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, LdpcKernelParams);
+typedef void (*ldpc_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, const uint32_t *, LdpcKernelParams);
 static ldpc_kernel_fn pick_kernel(int min_cnt, int max_cnt)
 {
     if (min_cnt == max_cnt) {      // the six normal-frame codes have one link count each; third argument = the most conflict
@@ -322,18 +328,21 @@ static ldpc_kernel_fn pick_kernel(int min_cnt, int max_cnt)
     return ldpc_decode_kernel<1, 20>;
 }
 
-hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu)
+hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes)
 {
     ldpc_kernel_fn fn = pick_kernel(min_cnt, max_cnt);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
+    hipFuncAttributes attr;
+    if ((e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(fn))) != hipSuccess) return e;
+    *static_lds_bytes = (int)attr.sharedSizeBytes;        // the dynamic array (the LLRs) starts behind the static LDS
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads, lds_bytes);
 }
 
 hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
 {
     ldpc_kernel_fn fn = pick_kernel(min_cnt, max_cnt);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes, stream, p.layers, p.entries, p.cninfo, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes, stream, p.layers, p.entries, p.cninfo, p.entries2, p);
     return hipGetLastError();
 }
 

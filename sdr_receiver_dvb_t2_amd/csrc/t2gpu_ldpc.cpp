@@ -15,7 +15,8 @@ struct t2gpu_ldpc {
     int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
     int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0;
     LdpcLayerDev *d_layers = nullptr;
-    uint32_t *d_entries = nullptr;
+    uint32_t *d_entries = nullptr, *d_entries2 = nullptr;
+    int lds_base = 0;
     uint32_t *d_cninfo = nullptr;
     uint2 *d_state = nullptr;
     size_t state_blocks = 0;
@@ -74,7 +75,7 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     h->lds_rec_offset = h->lds_ctl_offset + 64;
     h->lds_sign_offset = h->lds_rec_offset + 360 * 4;
     h->lds_bytes = h->lds_sign_offset + (h->g.n / 360) * 13 * 4;
-    if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu)) != hipSuccess) return fail("kernel attributes", e);
+    if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu, &h->lds_base)) != hipSuccess) return fail("kernel attributes", e);
     if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
     if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {          // experiments: fewer resident workgroups per CU
         const int v = std::atoi(lim);
@@ -90,6 +91,15 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemcpy(h->d_layers, ld.data(), ld.size() * sizeof(LdpcLayerDev), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
     if ((e = hipMemcpy(h->d_entries, h->g.entries.data(), h->g.entries.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    {   // the entries once more, unpacked and with the LDS address of the LLR array folded in (ldpc_cn.h, LayerDesc::ent2)
+        std::vector<uint32_t> e2(2 * h->g.entries.size());
+        for (size_t i = 0; i < h->g.entries.size(); ++i) {
+            e2[2 * i] = (h->g.entries[i] & 0xffffu) + (uint32_t)h->lds_base;
+            e2[2 * i + 1] = h->g.entries[i] >> 16;
+        }
+        if ((e = hipMalloc(&h->d_entries2, e2.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
+        if ((e = hipMemcpy(h->d_entries2, e2.data(), e2.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    }
     if ((e = hipMemcpy(h->d_cninfo, h->g.cninfo.data(), h->g.cninfo.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
 
     h->state_blocks = (size_t)resident_blocks(h);
@@ -105,7 +115,7 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
-    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_cninfo); hipFree(h->d_state);
+    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
     hipFree(h->d_resident);
     hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     delete h;
@@ -153,7 +163,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
-    p.layers = h->d_layers; p.entries = h->d_entries; p.cninfo = h->d_cninfo;
+    p.layers = h->d_layers; p.entries = h->d_entries; p.entries2 = h->d_entries2; p.lds_base = h->lds_base; p.cninfo = h->d_cninfo;
     p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
     p.state = h->d_state; p.sync = h->d_sync; p.error = h->d_error;
