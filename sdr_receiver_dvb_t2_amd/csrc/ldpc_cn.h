@@ -33,6 +33,10 @@
 #define T2_HD inline
 #endif
 
+#ifndef T2_CN_HOOK_AFTER_LOAD
+#define T2_CN_HOOK_AFTER_LOAD ((void)0)      // diagnostics builds of the kernel time-stamp this point (ldpc_kernel.hip, T2_PROF_DETAIL 3)
+#endif
+
 namespace t2gpu {
 
 enum { T2_LAYER_PLAIN = 0, T2_LAYER_PAIR = 1, T2_LAYER_GENERIC = 2 };
@@ -290,6 +294,7 @@ T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_
                             uint32_t *pair_rec)
 {
     t2_cn_load<CNT>(L, d.ent, j, a_p0, a_p1, st, r, d.ent2);
+    T2_CN_HOOK_AFTER_LOAD;
     if (d.kind == T2_LAYER_PLAIN) {
         t2_cn_partial<CNT>(r, 0);
         r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;

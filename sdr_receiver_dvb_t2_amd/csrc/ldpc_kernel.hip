@@ -17,6 +17,14 @@
 //     atomic word per (batch, trial).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef T2_PROF_DETAIL
+#define T2_PROF_DETAIL 0      // diagnostics builds: 1 splits the PAIR layers, 2 the GENERIC layers, 3 the PLAIN layers into slots 3 / 4 / 5
+#endif
+#if T2_PROF_DETAIL == 3
+// PLAIN layers: slot 3 = table entries + addresses + LDS loads + input arithmetic, slot 4 = minima, outputs, stores, slot 5 = barrier
+namespace t2gpu { __device__ __forceinline__ void hook_after_load(); }
+#define T2_CN_HOOK_AFTER_LOAD t2gpu::hook_after_load()
+#endif
 #include "ldpc_cn.h"
 #include "ldpc_kernel.h"
 
@@ -118,8 +126,14 @@ __device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, 
     return bad != 0;
 }
 
-#ifndef T2_PROF_DETAIL
-#define T2_PROF_DETAIL 0      // diagnostics builds: 1 splits the PAIR layers, 2 the GENERIC layers into slots 3 / 4 / 5
+#if T2_PROF_DETAIL == 3
+__shared__ long long s_after_load;
+__device__ __forceinline__ void hook_after_load()
+{
+    // wait for the loads and their arithmetic to be done before reading the clock: the stamp is only as good as the fence
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) s_after_load = (long long)__builtin_readcyclecounter();
+}
 #endif
 #define T2_DTL(kind_, slot_)                                                                                        \
     do {                                                                                                            \
@@ -137,6 +151,14 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
     CnRegs<CNT> r;
     long long tdt = (T2_PROF_DETAIL && prof) ? (long long)__builtin_readcyclecounter() : 0;
     if (active) t2_layer_phase_a<CNT>(L, d, j, a0, a1, st, r, pair_rec);
+#if T2_PROF_DETAIL == 3
+    if (d.kind == T2_LAYER_PLAIN && prof && threadIdx.x == 0) {
+        const long long now_ = (long long)__builtin_readcyclecounter();
+        prof[blockIdx.x * 8 + 3] += s_after_load - tdt;
+        prof[blockIdx.x * 8 + 4] += now_ - s_after_load;
+        tdt = now_;
+    }
+#endif
     // The sequential parts (chain walks, level steps) keep only a few lanes busy and sit on the workgroup's critical
     // path while the co-resident workgroup is usually in a throughput phase: give them issue priority.
     if (d.kind == T2_LAYER_PAIR) {
@@ -160,6 +182,9 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
         if (active) t2_generic_finish<CNT>(L, d, st, r);
     }
     lds_barrier();
+#if T2_PROF_DETAIL == 3
+    if (d.kind == T2_LAYER_PLAIN && prof && threadIdx.x == 0) prof[blockIdx.x * 8 + 5] += (long long)__builtin_readcyclecounter() - tdt;
+#endif
     if (d.kind == T2_LAYER_PAIR) T2_DTL(1, 5);
     if (d.kind == T2_LAYER_GENERIC) T2_DTL(2, 5);
 }
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
                     }
                     T2_PROF_T(tp2);
                     T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_update<CNT, NCMAX>(L, d, jn, active, a0, a1, st, info, pair_rec, p.prof)));
-                    if (!(T2_PROF_DETAIL && ly.kind == T2_PROF_DETAIL)) T2_PROF_ADD(2 + ly.kind, tp2);
+                    if (!(T2_PROF_DETAIL && (ly.kind == T2_PROF_DETAIL || T2_PROF_DETAIL == 3))) T2_PROF_ADD(2 + ly.kind, tp2);   // mode 3: slots 3-5 are the PLAIN split only
                     if (active) state[i * 360 + j] = make_uint2(st.w0, st.w1);
                 }
             }
