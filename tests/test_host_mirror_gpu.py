@@ -137,17 +137,11 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
     assert np.array_equal(ts[:n_pkts * 188], ts1.reshape(-1)[:n_pkts * 188])
 
 
-def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
-    """t2::dvbt2_demodulator::execute(len, i, q, signal) -- the boundary slot -- fed buffer by buffer with int16 I/Q by a loop that is
-    rx_sdrplay::start over a recording. Nothing about the signal is configured: FFT size and SISO come from P1, the guard
-    interval from the reference's own search (first guess 1/4 fails, the brute-force list starts at 1/32 -- the signal's value; any
-    other value costs seven frames per list entry there as here, because the equaliser's phase unwrapping, data_symbol.cpp:189-191,
-    only follows one sign of slope and so needs the exact guard length), carrier mode, pilot pattern, frame length from L1-pre,
-    the PLP from L1-post; a 60 Hz carrier offset makes P1 ask for re-tunes until it reports less than 10 Hz. Everything from
-    the time de-interleaver down is the reference's connect() chain in C++. The transport stream of every frame after
-    acquisition comes back byte for byte."""
+def _unconfigured_stream(tmp_path, n_frames, seed, cfo_hz, spoil_frame=None):
+    """int16 I/Q of n_frames T2 frames (16K extended PP7 GI 1/32, 24 data symbols + frame-closing symbol, 16-QAM 16200 r=3/5, real L1
+    signalling) with a carrier offset, written to tmp_path as i.s16 / q.s16 in 2^18-sample buffers. spoil_frame: the P2 symbol of
+    that frame is blanked (L1-pre cannot pass its CRC there)."""
     mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 0, 0, 24), 400, 1, 0, 1, 12.0, 8
-    n_frames, seed, cfo_hz = 12, 191, 60.0
     m = ol.ora_mode(*mode)
     cid = ol.code_id(fec_type, code_rate)
     cpf = 16200 // (2 * (mod + 1))
@@ -165,14 +159,33 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     frames = []
     for f in range(n_frames):
         cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts[f * per:(f + 1) * per], nb)
-        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c))
+        fr = t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c)
+        if f == spoil_frame:
+            fr[0] = 0
+        frames.append(fr)
     i16, q16, flen = t2_tx.iq_stream(frames, m.fft_size // 32, s2, snr, seed)
     x = (i16.astype(np.float64) + 1j * q16.astype(np.float64)) * np.exp(1j * (2 * np.pi * cfo_hz / (64e6 / 7) * np.arange(len(i16)) + 0.7))
     buf = 1 << 18
-    pad = (-len(x)) % buf
-    x = np.concatenate([x, np.zeros(pad)])
+    x = np.concatenate([x, np.zeros((-len(x)) % buf)])
     np.rint(x.real).astype(np.int16).tofile(tmp_path / "i.s16")
     np.rint(x.imag).astype(np.int16).tofile(tmp_path / "q.s16")
+    dfl_bytes = (k_bch - 80) // 8
+    per_frame = (nb * dfl_bytes) // 187 - 1
+    marks = [ts[f * per:f * per + per_frame - 1].tobytes() for f in range(n_frames)]
+    return m, buf, marks
+
+
+def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
+    """t2::dvbt2_demodulator::execute(len, i, q, signal) -- the boundary slot -- fed buffer by buffer with int16 I/Q by a loop that is
+    rx_sdrplay::start over a recording. Nothing about the signal is configured: FFT size and SISO come from P1, the guard
+    interval from the reference's own search (first guess 1/4 fails, the brute-force list starts at 1/32 -- the signal's value; any
+    other value costs seven frames per list entry there as here, because the equaliser's phase unwrapping, data_symbol.cpp:189-191,
+    only follows one sign of slope and so needs the exact guard length), carrier mode, pilot pattern, frame length from L1-pre,
+    the PLP from L1-post; a 60 Hz carrier offset makes P1 ask for re-tunes until it reports less than 10 Hz. Everything from
+    the time de-interleaver down is the reference's connect() chain in C++. The transport stream of every frame after
+    acquisition comes back byte for byte."""
+    n_frames = 12
+    m, buf, marks = _unconfigured_stream(tmp_path, n_frames, 191, 60.0)
     run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out.ts", buf, 0, tmp_path / "log.txt")
     log = open(tmp_path / "log.txt").read()
     print(log.splitlines()[-1])                                                # throughput of the symbol-by-symbol form (pytest -s)
@@ -183,10 +196,27 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     assert last["init"] == "1" and last["deint"] == "1" and last["crc"] == "1" and last["resets"] == "0", log
     assert int(last["gi"]) == m.fft_size // 32, log                         # GUARD_INTERVAL of L1-pre confirmed the search
     got = np.fromfile(tmp_path / "out.ts", np.uint8).tobytes()
-    dfl_bytes = (k_bch - 80) // 8
-    per_frame = (nb * dfl_bytes) // 187 - 1
-    found = [f for f in range(n_frames) if got.find(ts[f * per:f * per + per_frame - 1].tobytes()) >= 0]
+    found = [f for f in range(n_frames) if got.find(marks[f]) >= 0]
     # acquisition takes P1 (tune) .. P1 (init) .. P2 (guard search) .. P2 (L1-pre) .. P2 (L1-post): the frames after that are all
     # there; the last frames' FEC blocks wait in an unfinished SIMD batch
     assert len(found) >= 3 and found == list(range(found[0], found[0] + len(found))) and found[0] <= 8, (found, log)
     assert found[-1] >= n_frames - 2, (found, log)
+
+
+def test_demodulator_class_resets_and_recovers(driver, tmp_path):
+    """A P2 symbol that cannot pass the L1-pre CRC after the demodulator has initialised: the reference calls reset(), raises
+    signal->reset and signal->p1_reset (dvbt2_demodulator.cpp:418-424), the SDR thread re-tunes from scratch (rx_sdrplay.cpp:135-156,
+    229-235) and the next decoded P1 restores p2_init / demodulator_init without a new guard search (:293-297). The stream keeps
+    coming out afterwards."""
+    n_frames, spoil = 16, 9
+    m, buf, marks = _unconfigured_stream(tmp_path, n_frames, 291, 0.0, spoil_frame=spoil)
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out.ts", buf, 0, tmp_path / "log.txt")
+    log = open(tmp_path / "log.txt").read()
+    lines = [ln for ln in log.splitlines() if ln.startswith("buf ")]
+    last = dict(zip(lines[-1].split()[2::2], lines[-1].split()[3::2]))
+    assert last["resets"] == "1" and log.count("\nreset") >= 1, log            # reset() in the demodulator, reset() in the SDR loop
+    assert last["init"] == "1" and last["crc"] == "1" and int(last["gi"]) == m.fft_size // 32, log
+    got = np.fromfile(tmp_path / "out.ts", np.uint8).tobytes()
+    found = [f for f in range(n_frames) if got.find(marks[f]) >= 0]
+    assert any(f < spoil for f in found) and any(f > spoil + 1 for f in found), (found, log)
+    assert spoil not in found, found
