@@ -138,67 +138,67 @@ def main():
     # weak scaling: every GPU demodulates args.frames whole T2 frames per step (frames are independent: no collective)
     lo, hi = shard_frames(args.frames * world, world, rank, align=1)
     F = hi - lo
-    from sdr_receiver_dvb_t2_amd.receiver import t2_receiver
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    from sdr_receiver_dvb_t2_amd.chain import ts_from_bits
     ui, uq, sent, nb = make_frames(2, args.snr, seed=20250614 + 10 * rank)
     d_i = torch.from_numpy(np.concatenate([ui] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)     # int16 [F * FRAME_SAMPLES]
     d_q = torch.from_numpy(np.concatenate([uq] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)
 
+    # The receiver is the library's batch object (t2gpu_rx_*, csrc/t2gpu_rx.cpp): buffers, stage sequencing and launches are C++
+    # behind the C ABI; this script hands over two device pointers per step and reads results back. torch is the allocator of the
+    # input buffers and the process-group plumbing, nothing else.
     def make_rx(saturate, frames):
-        return t2_receiver((*MODE, L1_POST_SIZE, *PLP, nb), dict(ldpc_trials=args.trials, saturate_llr=saturate), max_frames=frames,
-                           device=local_rank)
+        return t2_rx(*MODE, L1_POST_SIZE, *PLP, nb, max_frames=frames, ldpc_trials=args.trials, saturate_llr=saturate, device=local_rank)
 
     rx = make_rx(False, F)                    # reference semantics: truncating int8 cast in the demapper
-    chain = rx.chain
-    r0 = rx.demod_iq_dev(d_i, d_q, F, first_call=True, flush=True)                    # thresholds from the level estimate
-    level = float(rx.front.state()["level_detect"])
-    # Steps go through receiver.pipeline_step: every call enqueues the front half (front end, P1, guard correlation, FFT) of a new
-    # buffer and the back half (equalisers .. descrambler) of the previous one, so K timed calls contain exactly K x the whole
-    # chain. The stages sit on four HIP streams with event dependencies; by default each call is drained before the next
-    # (T2GPU_PIPE_SERIAL=1) because overlapping other kernels with the decoder measured slower and unstable (see receiver.py).
-    for _ in range(max(args.warmup, 1) + 1):
-        r0 = rx.pipeline_step(d_i, d_q, F, level)
-    rx.pipeline_sync()
+    assert rx.frame_len == FRAME_SAMPLES
+    count = rx.execute_dev(d_i, d_q, F, first_call=True)                               # thresholds from the level estimate
+    level = rx.results(F)["level_detect"]
+    # One step = one call = the whole chain over one buffer of F frames (front end .. descrambler), drained by the host once per
+    # call because the P1 decisions are host data. Running stages of neighbouring buffers beside the decoder on other streams
+    # measured slower, so there is no overlap to lose.
+    for _ in range(max(args.warmup, 1)):
+        count = rx.execute_dev(d_i, d_q, F, level)
+    ref_trials = rx.fetch(count)[1]
     torch.cuda.synchronize(dev)
-    ref_trials = r0["trials"].cpu().numpy()
 
-    chain.time_ldpc = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    ldpc_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rx.pipeline_step(d_i, d_q, F, level)
-    rx.pipeline_sync()
+        rx.execute_dev(d_i, d_q, F, level)
+        ldpc_ms.append(rx.last_ldpc_ms())          # HIP events around the decoder's launch, on its stream; also drains the step
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    assert chain.ldpc.status() == 0
-    ldpc_ms = [a.elapsed_time(b) for a, b, _ in chain.ldpc_events]
-    ldpc_frames = chain.ldpc_events[0][2]
+    ldpc_frames = count
     max_s, units = aggregate_timing(t1 - t0, F * args.steps, dist if world > 1 else None, dev)
+    rx.close()
 
     # informative second leg (rank 0, N = 1): clamped LLRs (extension) -> the same frames decode; checks the TS bytes
     extra = {}
     if rank == 0 and not args.no_clamped_variant:
         c2 = make_rx(True, 2)
-        r2 = c2.demod_iq_dev(d_i[:2 * FRAME_SAMPLES], d_q[:2 * FRAME_SAMPLES], 2, flush=True)
-        torch.cuda.synchronize(dev)
-        t2h = r2["trials"].cpu().numpy()
-        got = c2.chain.ts_from_bits(r2["bits"].cpu().numpy(), t2h)
+        n2 = c2.execute_dev(d_i[:2 * FRAME_SAMPLES], d_q[:2 * FRAME_SAMPLES], 2, first_call=True)
+        b2, t2h = c2.fetch(n2)
+        got = ts_from_bits(b2, t2h)
         c2.close()
         want = sent[0].reshape(-1)
         npk = (nb * ((48408 - 80) // 8)) // 187 - 1
         ok = bool((t2h >= 0).all()) and bool(np.array_equal(got[:npk * 188], want[:npk * 188]))
         c3 = make_rx(True, F)
-        c3.demod_iq_dev(d_i, d_q, F, flush=True)
+        c3.execute_dev(d_i, d_q, F, first_call=True)
         for _ in range(3):
-            c3.pipeline_step(d_i, d_q, F, level)
-        c3.pipeline_sync()
+            c3.execute_dev(d_i, d_q, F, level)
+        c3.last_ldpc_ms()
         tc0 = time.perf_counter()
         for _ in range(4):
-            c3.pipeline_step(d_i, d_q, F, level)
-        c3.pipeline_sync()
+            c3.execute_dev(d_i, d_q, F, level)
+        c3.last_ldpc_ms()
+        torch.cuda.synchronize(dev)
         tc1 = time.perf_counter()
         c3.close()
         extra = {"clamped_llr_variant": {"msamples_per_s": round(4 * F * FRAME_SAMPLES / (tc1 - tc0) / 1e6, 1),
@@ -218,8 +218,8 @@ def main():
             "config": {"workload": "config 3 (CFG-A): %d T2 frames/GPU/step = %d symbols of 32K, %d FEC frames, from int16 I/Q at the "
                                    "dvbt2_demodulator::execute boundary; stages on GPU: front end (dc, IQ imbalance, NCO, Farrow x2, "
                                    "64-tap decimator), P1 detect, guard correlation, FFT, P2+data equaliser/freq-deint, TI/cell-deint, "
-                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; one call = front half of a new buffer + back "
-                                   "half of the previous one, drained per call (overlapping other kernels with the decoder measured slower); "
+                                   "demap, LDPC (group 32, max %d trials), BB descramble; tracking loops open; one call of the library's batch receiver "
+                                   "(t2gpu_rx_execute_dev) per step, drained per call (overlapping other kernels with the decoder measured slower); "
                                    "reference arithmetic incl. the wrapping int8 LLR cast, so %d of %d SIMD batches run all trials and "
                                    "are dropped as the reference would; L1 parsing and TS de-framing (host code) are not inside the "
                                    "timed region (%d samples per frame)"

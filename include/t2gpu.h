@@ -437,6 +437,44 @@ int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const i
 int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
 int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
 
+/* ---------------------------------------------------------------- batch receiver: buffers of whole T2 frames --------------
+ * The receive path of dvbt2_demodulator::execute (src/DVB_T2/dvbt2_demodulator.cpp:145-448) and of the stages behind it, for
+ * buffers that hold n_frames whole T2 frames starting at a P1 symbol, in one object: int16 I/Q in device memory ->
+ * descrambled BBFRAME bits in device memory. Front end (nominal resample, loops open) -> P1 search at every frame start ->
+ * guard-interval correlation of every symbol -> FFT (guard dropped by addressing) -> P2 / data / frame-closing equalisers ->
+ * time de-interleaver -> demapper -> LDPC (all FEC frames of the buffer, SIMD batches of ldpc_group, the tail batch short) ->
+ * BB descrambler. Every frame is independent given the mode, so all frames of the buffer share each launch.
+ * The mode is the caller's (what L1-pre / L1-post signal: fields as in dvbt2_parameters / l1_postsignalling_plp); one PLP
+ * starting at cell 0 with one TI block per frame -- the reference's tested configuration; other layouts go through the
+ * stage entry points (t2gpu_ti_frame_plan).
+ * t2gpu_rx_front_dev / t2gpu_rx_back_dev are the two halves of t2gpu_rx_execute_dev for callers that software-pipeline buffers
+ * (front half of buffer k, back half of buffer k-1); the back half works on the spectra the last front half left.
+ * Returns: front 0 / back and execute the number of FEC frames decoded; -1 stage error, -2 P1 missing or frames not equally spaced.
+ * d_bits_out: [fec frames][k_bch] one bit per byte; d_trials_out: per SIMD batch, trials left or -1 = dropped by the reference
+ * (ldpc_decoder.cpp:264-268). Both point into the handle and stay valid until the next back half.
+ * t2gpu_rx_results (synchronises): P1 decisions, first P2 sample of every frame, guard correlations [frames * n_sym][4], the
+ * level estimate of the last buffer (dvbt2_demodulator.cpp:235), duration of the last LDPC launch in ms. Any pointer may be NULL.
+ * t2gpu_rx_fetch (synchronises): the bits / trials of the last back half into host memory. */
+typedef struct {
+    int32_t id_device;                /* id_device_t: 0 SDRplay, 1 AirSpy, 2 PlutoSDR (scale and stride of the int16 input) */
+    float sample_rate;                /* 0 = 64e6 / 7 */
+    int32_t fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size;
+    int32_t plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks;
+    int32_t max_frames, ldpc_group /* 0 = 32 */, ldpc_trials /* 0 = 25 */, saturate_llr /* t2gpu_demap_configure */;
+} t2gpu_rx_config;
+typedef struct { int32_t frame_len, n_sym, fft_size, guard_interval_size, frame_cells, fec_frames_per_t2_frame, k_bch, k_ldpc; } t2gpu_rx_geometry;
+typedef struct t2gpu_rx t2gpu_rx;
+t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *cfg, int device);
+void t2gpu_rx_destroy(t2gpu_rx *h);
+int t2gpu_rx_info(const t2gpu_rx *h, t2gpu_rx_geometry *out);
+int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect /* <= 0: the handle's own */,
+                       int first_call, void *stream);
+int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
+int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call,
+                         uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
+int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect, float *ldpc_ms);
+int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials);
+
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
  * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),

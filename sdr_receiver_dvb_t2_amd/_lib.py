@@ -66,6 +66,14 @@ PROTOTYPES = {
     "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_create": (_vp, [_vp, ctypes.c_int]),
+    "t2gpu_rx_destroy": (None, [_vp]),
+    "t2gpu_rx_info": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_front_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
+    "t2gpu_rx_back_dev": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_rx_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_rx_results": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "t2gpu_rx_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ti_frame_plan": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "t2gpu_bbdh_create": (_vp, [ctypes.c_int]),
     "t2gpu_bbdh_destroy": (None, [_vp]),

@@ -19,6 +19,27 @@ from .ofdm import t2_ofdm
 L1_PRE_CELL = 1840      # dvbt2_definition.h:58
 
 
+def ts_from_bits(bits_host, trials_host, group=32, need_plp=0, tags=None, bbdh=None):
+    """Descrambled BBFRAME bits [frames][k_bch] -> TS bytes through the library's de-framer (t2gpu_bbdh_*); SIMD batches the LDPC
+    gave up on (trials -1) are dropped as the reference drops them (ldpc_decoder.cpp:264-268)."""
+    l = lib()
+    own = bbdh is None
+    h = l.t2gpu_bbdh_create(need_plp) if own else bbdh
+    out = []
+    buf = np.zeros(bits_host.shape[1] // 8 + 400, np.uint8)
+    err = ctypes.c_int(0)
+    for i in range(bits_host.shape[0]):
+        if trials_host[i // group] < 0:
+            continue
+        n = l.t2gpu_bbdh_execute(h, need_plp if tags is None else tags[i], bits_host.shape[1], bits_host[i].ctypes.data, buf.ctypes.data,
+                                 buf.size, ctypes.byref(err))
+        if n > 0:
+            out.append(buf[:n].copy())
+    if own:
+        l.t2gpu_bbdh_destroy(h)
+    return np.concatenate(out) if out else np.zeros(0, np.uint8)
+
+
 class t2_chain(object):
     def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size,
                  plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames=4, device=0, ldpc_group=32,

@@ -6,6 +6,8 @@ the guard dropped (:332-334) -> P2 / data / frame-closing equalisers -> time de-
 BBFRAME de-framing. The tracking loops run OPEN here: the loop values are inputs (zeros and the nominal resample for a
 synchronous source), the estimates the stages produce (P1 position and CFO, guard correlation, equaliser sync sums) are
 returned to the caller instead of being fed back symbol by symbol -- the batch form of SURVEY.md section 8(e)."""
+import ctypes
+
 import numpy as np
 
 from .chain import t2_chain
@@ -167,6 +169,91 @@ class t2_receiver(object):
         if hasattr(self, "_pipe"):
             for k in ("sa", "sf", "sd", "sb"):
                 self._pipe[k].synchronize()
+
+
+class rx_config(ctypes.Structure):
+    _fields_ = [("id_device", ctypes.c_int32), ("sample_rate", ctypes.c_float)] + \
+               [(n, ctypes.c_int32) for n in ("fft_mode carrier_mode pilot_pattern guard_interval_mode papr_mode n_data l1_post_size plp_mod "
+                                              "plp_fec_type plp_cod plp_rotation plp_num_blocks max_frames ldpc_group ldpc_trials "
+                                              "saturate_llr").split()]
+
+
+class rx_geometry(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in "frame_len n_sym fft_size guard_interval_size frame_cells fec_frames_per_t2_frame k_bch k_ldpc".split()]
+
+
+class t2_rx(object):
+    """The same batch receiver as ``t2_receiver`` with nothing but the C ABI underneath (``t2gpu_rx_*``, csrc/t2gpu_rx.cpp): buffers,
+    stage sequencing and launches live in the library; Python hands over two device pointers per buffer. This is what bench.py times."""
+
+    def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size, plp_mod, plp_fec_type,
+                 plp_cod, plp_rotation, plp_num_blocks, max_frames=4, ldpc_group=32, ldpc_trials=25, saturate_llr=False, id_device=0,
+                 sample_rate=0.0, device=0):
+        from ._lib import lib, T2GpuError
+        self._l = lib()
+        self.cfg = rx_config(id_device, sample_rate, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data,
+                             l1_post_size, plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames, ldpc_group,
+                             ldpc_trials, int(bool(saturate_llr)))
+        self._h = self._l.t2gpu_rx_create(ctypes.byref(self.cfg), device)
+        if not self._h:
+            raise T2GpuError("t2gpu_rx_create: " + self._l.t2gpu_last_error().decode())
+        self.geometry = rx_geometry()
+        self._l.t2gpu_rx_info(self._h, ctypes.byref(self.geometry))
+        self.frame_len, self.k_bch = self.geometry.frame_len, self.geometry.k_bch
+        self.group = ldpc_group
+        self.max_frames = max_frames
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.t2gpu_rx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _stream(self, stream):
+        import torch
+        return torch.cuda.current_stream().cuda_stream if stream is None else stream
+
+    def _check(self, rc, what):
+        if rc < 0:
+            from ._lib import T2GpuError
+            raise T2GpuError(what + ": " + self._l.t2gpu_last_error().decode())
+        return rc
+
+    def front_dev(self, d_i, d_q, n_frames, level_detect=0.0, first_call=False, stream=None):
+        return self._check(self._l.t2gpu_rx_front_dev(self._h, d_i.data_ptr(), d_q.data_ptr(), n_frames, float(level_detect), int(first_call),
+                                                      self._stream(stream)), "t2gpu_rx_front_dev")
+
+    def back_dev(self, n_frames, stream=None):
+        return self._check(self._l.t2gpu_rx_back_dev(self._h, n_frames, None, None, self._stream(stream)), "t2gpu_rx_back_dev")
+
+    def execute_dev(self, d_i, d_q, n_frames, level_detect=0.0, first_call=False, stream=None):
+        """d_i, d_q: int16 device tensors with n_frames whole frames from a P1 symbol on. Enqueues the whole path; returns the
+        number of FEC frames decoded (results: fetch / results)."""
+        return self._check(self._l.t2gpu_rx_execute_dev(self._h, d_i.data_ptr(), d_q.data_ptr(), n_frames, float(level_detect),
+                                                        int(first_call), None, None, self._stream(stream)), "t2gpu_rx_execute_dev")
+
+    def fetch(self, count):
+        bits = np.empty((count, self.k_bch), np.uint8)
+        trials = np.empty(((count + self.group - 1) // self.group,), np.int32)
+        self._check(self._l.t2gpu_rx_fetch(self._h, count, bits.ctypes.data, trials.ctypes.data), "t2gpu_rx_fetch")
+        return bits, trials
+
+    def last_ldpc_ms(self):
+        """Duration of the last LDPC launch (HIP events on the stream it ran on); waits for it."""
+        ms = ctypes.c_float(0)
+        self._check(self._l.t2gpu_rx_results(self._h, 0, None, None, None, None, ctypes.byref(ms)), "t2gpu_rx_results")
+        return ms.value
+
+    def results(self, n_frames):
+        from .p1 import p1_result
+        p1 = (p1_result * n_frames)()
+        p2 = np.zeros(n_frames, np.int64)
+        cp = np.zeros((n_frames, self.geometry.n_sym, 4), np.float32)
+        level, ms = ctypes.c_float(0), ctypes.c_float(0)
+        self._check(self._l.t2gpu_rx_results(self._h, n_frames, p1, p2.ctypes.data, cp.ctypes.data, ctypes.byref(level), ctypes.byref(ms)),
+                    "t2gpu_rx_results")
+        return dict(p1=list(p1), p2_start=p2, cp=cp, level_detect=level.value, ldpc_ms=ms.value)
 
 
 class t2_closed_loop(object):

@@ -66,6 +66,19 @@ def test_iq_to_ts(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, sa
     sp = {bytes(p) for p in sent.reshape(-1, 188)}
     matched = sum(bytes(p) in sp for p in got[:n].reshape(-1, 188))
     assert matched >= n_frames * per_frame - 1 and n // 188 - matched <= 2, (matched, n // 188, per_frame)
+    # the library's own batch receiver (t2gpu_rx_*: stage sequencing in C++, nothing above the ABI) gives the same buffer the same answer
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    nat = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames, saturate_llr=saturate)
+    assert nat.frame_len == frame_len
+    count = nat.execute_dev(torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda(), n_frames, first_call=True)
+    assert count == n_frames * nb
+    nbits, ntrials = nat.fetch(count)
+    info = nat.results(n_frames)
+    assert np.array_equal(ntrials, trials) and np.array_equal(nbits, out["bits"].cpu().numpy())
+    assert np.array_equal(info["p2_start"], out["p2_start"]) and np.array_equal(info["cp"], out["cp"].cpu().numpy())
+    assert [(r.detected, r.s1, r.s2, r.shift) for r in info["p1"]] == [(r.detected, r.s1, r.s2, r.shift) for r in out["p1"]]
+    assert info["ldpc_ms"] > 0
+    nat.close()
     rx.close()
 
 
