@@ -84,6 +84,10 @@ def test_every_handle_type_refuses_to_exist_without_a_gpu(built):
         assert not getattr(l, name)(*args), name
         msg = l.t2gpu_last_error().decode()
         assert "device" in msg.lower() or "gpu" in msg.lower(), (name, msg)
+    from sdr_receiver_dvb_t2_amd.receiver import rx_config
+    cfg = rx_config(0, 0.0, 5, 1, 6, 4, 0, 59, 350, 3, 1, 3, 1, 202, 2, 32, 25, 0)
+    assert not l.t2gpu_rx_create(ctypes.byref(cfg), 0)
+    assert "device" in l.t2gpu_last_error().decode().lower()
 
 
 def test_bad_arguments_are_errors_not_crashes(built):
@@ -96,6 +100,9 @@ def test_bad_arguments_are_errors_not_crashes(built):
     assert l.t2gpu_demod_status(None, None) == -1
     assert l.t2gpu_demod_set_tuner(None, 1.0) == -1
     assert l.t2gpu_ti_frame_plan(0, None, None, 100, None, None, 0) == -1
+    assert not l.t2gpu_rx_create(None, 0)
+    assert l.t2gpu_rx_execute_dev(None, None, None, 1, ctypes.c_float(0.0), 0, None, None, None) == -1
+    assert l.t2gpu_rx_fetch(None, 0, None, None) == -1 and l.t2gpu_rx_info(None, None) == -1
     assert l.t2gpu_front_hold_iq(None, 1) == -1 and l.t2gpu_front_commit_iq(None, None) == -1
     l.t2gpu_sync_reset(None, ctypes.c_float(1.0))                                        # void functions tolerate NULL
     l.t2gpu_sync_clear_frequency(None)
