@@ -286,6 +286,7 @@ struct LayerDesc {
     uint32_t e0;    // ent[0], fetched when the descriptor is made (the chain walker needs it right behind a barrier)
     const uint32_t *ent2 = nullptr;   // GPU only: the same entries as (base + L.off(), shift) dword pairs -- saves the scalar
                                       // add / shift / mask per link that unpacking costs every wavefront in every layer
+    int ent_lds = 0;                  // pair-lane kernel: LDS address of a copy of those pairs (ldpc_cn2.h)
 };
 
 // phase A: every node loads; PLAIN nodes and chain-start / level-free nodes finish at once
@@ -324,7 +325,11 @@ T2_HD void t2_layer_phase_a(LMEM &L, const LayerDesc &d, int j, int a_p0, int a_
 template <class LMEM>
 T2_HD void t2_pair_walk(LMEM &L, const LayerDesc &d, int lane, const uint32_t *pair_rec)
 {
+#ifdef T2_PAIR_WALK_BATCH
+    constexpr int B = T2_PAIR_WALK_BATCH;
+#else
     constexpr int B = 4;
+#endif
     const uint32_t e0 = d.e0;
     const int base = (int)(e0 & 0xffffu) + L.off(), s0 = (int)(e0 >> 16), step = d.step;
     int m = lane - s0;                                   // position of the shared bit inside its 360-bit group

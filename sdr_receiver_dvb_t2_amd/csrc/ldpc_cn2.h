@@ -1,0 +1,266 @@
+// ldpc_cn2.h -- the check-node update of ldpc_cn.h with one check node spread over TWO adjacent lanes (GPU only).
+//
+// Lane pair (2j, 2j+1) owns node j: lane half h = 0 takes the even link slots c = 0, 2, 4, ..., h = 1 the odd ones, slot numbering,
+// record format, layer kinds and phase structure exactly as in ldpc_cn.h (which stays the reference form: the schedule emulator in
+// tests/emu runs it, and every function below names the one it splits). What a node needs as a whole -- the two smallest
+// magnitudes, the sign parity, the code bits of its record -- meets through one DPP move between the two lanes
+// (quad_perm [1,0,3,2]); nothing else changes hands, and the two lanes never touch the same LLR.
+//
+// Why: 360 nodes are 6 wavefronts on 4 SIMDs, two SIMDs carry two of them and the layer waits for those (a third of a PLAIN
+// layer was barrier wait). 720 half-nodes are 12 wavefronts, three per SIMD, each with half the
+// instruction stream.
+#pragma once
+#include "ldpc_cn.h"
+
+namespace t2gpu {
+
+// value of v in the partner lane (lane ^ 1)
+__device__ __forceinline__ int pl_x(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t pl_xu(uint32_t v) { return (uint32_t)pl_x((int)v); }
+
+// the two smallest of the union of two sorted pairs
+__device__ __forceinline__ void pl_merge2(int a0, int a1, int b0, int b1, int &m0, int &m1)
+{
+    const int lo = a0 < b0 ? a0 : b0, hi = a0 < b0 ? b0 : a0;
+    const int s = a1 < b1 ? a1 : b1;
+    m0 = lo;
+    m1 = hi < s ? hi : s;
+}
+
+template <int CNT>
+struct PlRegs {
+    static constexpr int DEG = CNT + 2, H = (DEG + 1) / 2;     // link slots of the node / of one lane (slot c = 2v + h)
+    int addr[H], in[H];         // absent slots: addr < 0, in = 0
+    uint32_t lut;               // as CnRegs::lut
+    uint32_t c0s, c1s;          // old code words shifted right by 2h: slot v's code sits at bits 4v (word 0: c < 16, word 1: the rest)
+    int p0, p1, psx;            // node-wide: two smallest raw magnitudes / sign xor over the non-conflict slots
+    int m0, m0f, m1f, sx;       // node-wide over all slots
+    uint32_t n0, n1;            // new codes of this lane's slots at bits 4v (as if h were 0); shifted and joined in pl_pack
+    int h;
+};
+
+// compile-time classification of slot c of a node with CNT information links
+template <int CNT> __device__ __forceinline__ constexpr bool pl_is_info(int c) { return c < CNT; }
+
+template <int CNT>
+__device__ __forceinline__ bool pl_present(const PlRegs<CNT> &r, int v)
+{
+    return (2 * v + 1 <= CNT) || r.addr[v] >= 0;      // both candidates are information or own-parity slots: always there
+}
+
+template <int CNT>
+__device__ __forceinline__ int pl_old_msg(const PlRegs<CNT> &r, int v)
+{
+    const uint32_t w = v < 8 ? r.c0s : r.c1s;
+    return t2_lut_byte(r.lut, (w >> (4 * (v & 7))) & 3u);
+}
+
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_read_slot(const LMEM &L, PlRegs<CNT> &r, int v)
+{
+    const bool present = pl_present(r, v);
+    const int lc = present ? (int)L.ld(r.addr[v]) : 0;
+    r.in[v] = present ? t2_clamp(lc - pl_old_msg(r, v), -128, 127) : 0;
+}
+
+template <int CNT>
+__device__ __forceinline__ int pl_rawmag(const PlRegs<CNT> &r, int v)
+{
+    const int x = r.in[v], nx = -x;
+    const int a = x > nx ? x : nx;
+    return pl_present(r, v) ? a : 255;
+}
+
+// t2_cn_load for one lane. ent_lds: LDS address of the layer's entries as (base + L.off(), shift) pairs.
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h, int a_p0, int a_p1, const CnState &st, PlRegs<CNT> &r)
+{
+    constexpr int H = PlRegs<CNT>::H;
+    r.h = h;
+    {
+        const int A = (int)((st.w1 >> 16) & 0xffu), B = (int)(st.w1 >> 24);
+        r.lut = (uint32_t)(A > 31 ? 31 : A) | ((uint32_t)((-A) & 0xff) << 8) | ((uint32_t)(B > 31 ? 31 : B) << 16) |
+                ((uint32_t)((-B) & 0xff) << 24);
+    }
+    r.c0s = st.w0 >> (2 * h);
+    r.c1s = (st.w1 & 0xfffu) >> (2 * h);
+    r.n0 = 0; r.n1 = 0;
+    uint2 e[H];
+    const int mine = ent_lds + 8 * h;                              // the odd lane reads the odd entries
+#pragma unroll
+    for (int v = 0; v < H; ++v) {                                  // the lane's table entries from the LDS copy, issued together
+        const int c0 = 2 * v, c1 = 2 * v + 1;
+        if (c1 < CNT) e[v] = L.ld_pair(mine + 8 * c0);
+        else if (c0 < CNT) e[v] = L.ld_pair(ent_lds + 8 * c0);
+        else e[v] = make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        const int c0 = 2 * v, c1 = 2 * v + 1;
+        int m = j - (int)e[v].y;
+        m += (m < 0) ? 360 : 0;
+        const int link = (int)e[v].x + m;
+        if (c1 < CNT) r.addr[v] = link;                             // information slots on both lanes
+        else if (c0 < CNT) r.addr[v] = h ? a_p0 : link;             // c1 == CNT: own parity bit on the odd lane
+        else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
+        else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
+    }
+#pragma unroll
+    for (int v = 0; v < H; ++v) r.in[v] = pl_present(r, v) ? (int)L.ld(r.addr[v]) : 0;
+#pragma unroll
+    for (int v = 0; v < H; ++v) r.in[v] = pl_present(r, v) ? t2_clamp(r.in[v] - pl_old_msg(r, v), -128, 127) : 0;
+}
+
+// t2_cn_partial: over the node's slots c >= nc (both lanes), result node-wide in p0 / p1 / psx
+template <int CNT>
+__device__ __forceinline__ void pl_partial(PlRegs<CNT> &r, int nc)
+{
+    constexpr int H = PlRegs<CNT>::H;
+    int m0 = 255, m1 = 255, sx = 0;
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        if (2 * v + 1 >= nc) {                                      // uniform: at least the odd lane's slot counts
+            const bool mine = (2 * v >= nc) || r.h;
+            t2_min2(mine ? pl_rawmag(r, v) : 255, m0, m1);
+            sx ^= mine ? r.in[v] : 0;
+        }
+    }
+    pl_merge2(m0, m1, pl_x(m0), pl_x(m1), r.p0, r.p1);
+    r.psx = sx ^ pl_x(sx);
+}
+
+// t2_cn_merge: fold the conflict slots c < nc into the partial result, apply f. NV = the most slots v a lane can have below nc.
+template <int CNT, int NV>
+__device__ __forceinline__ void pl_merge(PlRegs<CNT> &r, int nc)
+{
+    int m0 = 255, m1 = 255, sx = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < PlRegs<CNT>::H && 2 * v < nc) {                     // uniform: at least the even lane's slot is a conflict slot
+            const bool mine = (2 * v + 1 < nc) || !r.h;
+            t2_min2(mine ? pl_rawmag(r, v) : 255, m0, m1);
+            sx ^= mine ? r.in[v] : 0;
+        }
+    }
+    int c0, c1;
+    pl_merge2(m0, m1, pl_x(m0), pl_x(m1), c0, c1);
+    sx ^= pl_x(sx);
+    int a0, a1;
+    pl_merge2(c0, c1, r.p0, r.p1, a0, a1);
+    r.m0 = a0; r.m0f = t2_f(a0); r.m1f = t2_f(a1); r.sx = sx ^ r.psx;
+}
+
+// t2_write_slot for lane slot v
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_write_slot(LMEM &L, PlRegs<CNT> &r, int v, bool store)
+{
+    const bool present = pl_present(r, v);
+    const bool eq = present && (r.in[v] == r.m0 || r.in[v] == -r.m0);
+    const int other = eq ? r.m1f : r.m0f;
+    const int sm = (r.sx ^ r.in[v]) >> 31;
+    const int out = (other ^ sm) - sm;
+    const int ln = t2_clamp(r.in[v] + out, -128, 127);
+    if (present && store) L.st(r.addr[v], (int8_t)ln);
+    const uint32_t bits = ((uint32_t)sm & (1u << (4 * (v & 7)))) | (eq ? (2u << (4 * (v & 7))) : 0u);
+    if (v < 8) r.n0 |= bits; else r.n1 |= bits;
+}
+
+// t2_cn_pack: both lanes end up with the node's whole record
+template <int CNT>
+__device__ __forceinline__ void pl_pack(const PlRegs<CNT> &r, CnState &st)
+{
+    const uint32_t x0 = r.n0 << (2 * r.h), x1 = r.n1 << (2 * r.h);
+    st.w0 = x0 | pl_xu(x0);
+    st.w1 = ((x1 | pl_xu(x1)) & 0xfffu) | ((uint32_t)(r.m0f > 32 ? 32 : r.m0f) << 16) | ((uint32_t)(r.m1f > 32 ? 32 : r.m1f) << 24);
+}
+
+// t2_layer_phase_a
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_phase_a(LMEM &L, const LayerDesc &d, int j, int h, int a_p0, int a_p1, CnState &st, PlRegs<CNT> &r,
+                                           uint32_t *pair_rec)
+{
+    constexpr int H = PlRegs<CNT>::H;
+    pl_load<CNT>(L, d.ent_lds, j, h, a_p0, a_p1, st, r);
+    if (d.kind == T2_LAYER_PLAIN) {
+        pl_partial<CNT>(r, 0);
+        r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;
+#pragma unroll
+        for (int v = 0; v < H; ++v) pl_write_slot<CNT>(L, r, v, true);
+        pl_pack<CNT>(r, st);
+    } else if (d.kind == T2_LAYER_PAIR) {
+        pl_partial<CNT>(r, 2);
+        if (j < d.step) {                       // chain start: its two group bits (slot 0 on the even lane, slot 1 on the odd one) now
+            pl_merge<CNT, 1>(r, 2);
+            pl_write_slot<CNT>(L, r, 0, true);
+        } else if (h == 0) {                    // t2_pair_record: msg1 = old message of slot 1, from the record's code bits 2..3
+            const int msg1 = t2_lut_byte(r.lut, (st.w0 >> 2) & 3u);
+            const int cap = t2_f(r.p0);
+            pair_rec[j] = (uint32_t)(msg1 & 0xff) | ((uint32_t)cap << 8) | ((uint32_t)(r.in[0] & 0xff) << 16) | ((r.psx < 0) ? (1u << 24) : 0u);
+        }
+    } else {
+        pl_partial<CNT>(r, d.nc);
+    }
+}
+
+// t2_pair_finish
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_pair_finish(LMEM &L, const LayerDesc &d, int j, CnState &st, PlRegs<CNT> &r)
+{
+    constexpr int H = PlRegs<CNT>::H;
+    if (j < d.step) {
+#pragma unroll
+        for (int v = 1; v < H; ++v) pl_write_slot<CNT>(L, r, v, true);
+        pl_pack<CNT>(r, st);
+        return;
+    }
+    const bool has_succ = j + d.step < 360;
+    if (r.h || !has_succ) pl_read_slot<CNT>(L, r, 0);     // slot 1 always, slot 0 when the node ends its chain
+    pl_merge<CNT, 1>(r, 2);
+#pragma unroll
+    for (int v = 0; v < H; ++v) pl_write_slot<CNT>(L, r, v, !(v == 0 && !r.h && has_succ));
+    pl_pack<CNT>(r, st);
+}
+
+// t2_generic_level_nc
+template <int CNT, int NC, class LMEM>
+__device__ __forceinline__ void pl_generic_level_nc(LMEM &L, int lv, uint32_t info, PlRegs<CNT> &r)
+{
+    if ((int)(info & 0xff) != lv) return;
+    constexpr int NV = (NC + 1) / 2;
+    if (lv > 1) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if ((2 * v + 1 < NC) || !r.h) pl_read_slot<CNT>(L, r, v);
+    }
+    pl_merge<CNT, NV>(r, NC);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if ((2 * v + 1 < NC) || !r.h) pl_write_slot<CNT>(L, r, v, true);
+}
+
+template <int CNT, int NCMAX = T2_LDPC_NC_MAX, class LMEM>
+__device__ __forceinline__ void pl_generic_level(LMEM &L, const LayerDesc &d, int lv, uint32_t info, PlRegs<CNT> &r)
+{
+    switch (d.nc) {
+#define T2_NC_(n) case n: if constexpr (n <= CNT && n <= NCMAX) pl_generic_level_nc<CNT, n>(L, lv, info, r); break;
+        T2_NC_(2) T2_NC_(3) T2_NC_(4) T2_NC_(5) T2_NC_(6) T2_NC_(7) T2_NC_(8) T2_NC_(9) T2_NC_(10)
+#undef T2_NC_
+    default: break;
+    }
+}
+
+// t2_generic_finish
+template <int CNT, class LMEM>
+__device__ __forceinline__ void pl_generic_finish(LMEM &L, const LayerDesc &d, CnState &st, PlRegs<CNT> &r)
+{
+    constexpr int H = PlRegs<CNT>::H;
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        if (2 * v + 1 >= d.nc) {
+            if ((2 * v >= d.nc) || r.h) pl_write_slot<CNT>(L, r, v, true);
+        }
+    }
+    pl_pack<CNT>(r, st);
+}
+
+}  // namespace t2gpu

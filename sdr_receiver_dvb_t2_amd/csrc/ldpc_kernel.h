@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define T2GPU_LDPC_THREADS 384
+#ifndef T2_LDPC_PAIRLANE
+#define T2_LDPC_PAIRLANE 1         // 1: one check node on two adjacent lanes (ldpc_cn2.h), 12 wavefronts; 0: one lane per node, 6 wavefronts
+#endif
+#define T2GPU_LDPC_THREADS (T2_LDPC_PAIRLANE ? 768 : 384)
 
 namespace t2gpu {
 
@@ -35,6 +38,7 @@ struct LdpcKernelParams {
     int lds_ctl_offset;           // byte offset of the control words behind the LLR array
     int lds_rec_offset;           // byte offset of the 360 chain-walk records (PAIR layers)
     int lds_sign_offset;          // byte offset of the packed sign words (13 dwords per 360-bit group)
+    int lds_ent_offset, n_entries; // pair-lane kernel: byte offset of the LDS copy of entries2, number of entries
     long long *prof;              // optional [grid][8] cycle counters (diagnostics; null in production)
     unsigned *resident;           // counts workgroups that have started, cumulatively over launches (t2gpu_ldpc_wait_resident)
 };

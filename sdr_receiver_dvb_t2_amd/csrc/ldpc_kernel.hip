@@ -25,8 +25,11 @@
 namespace t2gpu { __device__ __forceinline__ void hook_after_load(); }
 #define T2_CN_HOOK_AFTER_LOAD t2gpu::hook_after_load()
 #endif
-#include "ldpc_cn.h"
 #include "ldpc_kernel.h"
+#include "ldpc_cn.h"
+#if T2_LDPC_PAIRLANE
+#include "ldpc_cn2.h"
+#endif
 
 namespace t2gpu {
 
@@ -38,9 +41,14 @@ struct LdsMem {
     __device__ __forceinline__ int off() const { return (int)base; }
     __device__ __forceinline__ int8_t ld(int a) const { return *reinterpret_cast<const lds_i8 *>((uint32_t)a); }
     __device__ __forceinline__ void st(int a, int8_t v) { *reinterpret_cast<lds_i8 *>((uint32_t)a) = v; }
+    __device__ __forceinline__ uint2 ld_pair(int a) const
+    {
+        const __attribute__((address_space(3))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a);
+        return make_uint2(q[0], q[1]);
+    }
 };
 
-static constexpr int kThreads = T2GPU_LDPC_THREADS;   // 6 wavefronts; 360 of 384 lanes own a check node
+static constexpr int kThreads = T2GPU_LDPC_THREADS;   // 6 wavefronts, 360 of 384 lanes own a check node -- or 12 and two lanes per node
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() would also drain the vector-memory queue
 // (s_waitcnt vmcnt(0)) and so expose the L2 round trip of the record loads/stores at every layer; those records are
@@ -144,6 +152,32 @@ __device__ __forceinline__ void hook_after_load()
         }                                                                                                           \
     } while (0)
 
+#if T2_LDPC_PAIRLANE
+template <int CNT, int NCMAX>
+__device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1,
+                                             CnState &st, uint32_t info, uint32_t *pair_rec, long long *prof)
+{
+    PlRegs<CNT> r;
+    if (active) pl_phase_a<CNT>(L, d, j, h, a0, a1, st, r, pair_rec);
+    if (d.kind == T2_LAYER_PAIR) {
+        lds_barrier();
+        __builtin_amdgcn_s_setprio(3);
+        if ((int)threadIdx.x < d.step) t2_pair_walk(L, d, (int)threadIdx.x, pair_rec);   // any lane can walk any chain: the first `step` threads do
+        __builtin_amdgcn_s_setprio(0);
+        lds_barrier();
+        if (active) pl_pair_finish<CNT>(L, d, j, st, r);
+    } else if (d.kind == T2_LAYER_GENERIC) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int lv = 1; lv <= d.lmax; ++lv) {
+            if (active) pl_generic_level<CNT, NCMAX>(L, d, lv, info, r);
+            lds_barrier();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (active) pl_generic_finish<CNT>(L, d, st, r);
+    }
+    lds_barrier();
+}
+#else
 template <int CNT, int NCMAX>
 __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int j, bool active, int a0, int a1,
                                              CnState &st, uint32_t info, uint32_t *pair_rec, long long *prof)
@@ -188,6 +222,7 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
     if (d.kind == T2_LAYER_PAIR) T2_DTL(1, 5);
     if (d.kind == T2_LAYER_GENERIC) T2_DTL(2, 5);
 }
+#endif
 
 #define T2_PROF_T(var) long long var = p.prof ? (long long)__builtin_readcyclecounter() : 0
 #define T2_PROF_ADD(slot, t0)                                                                                   \
@@ -197,7 +232,7 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
 
 template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
 #ifndef T2_LDPC_MIN_WAVES
-#define T2_LDPC_MIN_WAVES 4        // waves per SIMD the register allocation leaves room for: 4 -> 128 VGPRs (two workgroups per CU)
+#define T2_LDPC_MIN_WAVES (T2_LDPC_PAIRLANE ? 6 : 4)   // waves per SIMD the register allocation leaves room for (two workgroups per CU): 4 -> 128 VGPRs, 6 -> 80
 #endif
 __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
                                                                   const uint32_t *__restrict__ cninfo, const uint32_t *__restrict__ entries2,
@@ -208,10 +243,18 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
     int *s_ctl = reinterpret_cast<int *>(lds + p.lds_ctl_offset);
     uint32_t *pair_rec = reinterpret_cast<uint32_t *>(lds + p.lds_rec_offset);
     uint32_t *S2 = reinterpret_cast<uint32_t *>(lds + p.lds_sign_offset);
+#if T2_LDPC_PAIRLANE
+    uint32_t *lds_ent = reinterpret_cast<uint32_t *>(lds + p.lds_ent_offset);
+    for (int x = threadIdx.x; x < 2 * p.n_entries; x += kThreads) lds_ent[x] = entries2[x];      // made visible by the first barrier below
+#endif
     LdsMem L{(uint32_t)(uintptr_t)(lds_i8 *)Lm};     // generic -> LDS address space cast: the 32-bit LDS offset of the array
 
     const int tid = threadIdx.x;
+#if T2_LDPC_PAIRLANE
+    const int j = tid >> 1, h = tid & 1;             // node, and which half of its link slots this lane takes
+#else
     const int j = tid;
+#endif
     const bool active = j < 360;
     if (L.off() != p.lds_base) {                     // the split table was built for another LDS layout: refuse, loudly
         if (tid == 0) *p.error = 2;
@@ -235,8 +278,7 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
             const uint2 *src = reinterpret_cast<const uint2 *>(p.llr + (size_t)frame * p.n);
             uint2 *dst = reinterpret_cast<uint2 *>(Lm);
             for (int x = tid; x < p.n / 8; x += kThreads) dst[x] = src[x];
-            if (active)
-                for (int i = 0; i < p.q; ++i) state[i * 360 + j] = make_uint2(0u, 0u);
+            for (int x = tid; x < p.q * 360; x += kThreads) state[x] = make_uint2(0u, 0u);
         }
         __syncthreads();
 
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
                 for (int i = 0; i < p.q; ++i) {
                     const LdpcLayerDev ly = layers[i];
                     LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
-                                entries2 + 2 * ly.first_entry};
+                                entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
                     const uint32_t info = info_nxt;
                     const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
                     const int a0 = L.off() + p.k + 360 * i + jn, a1r = parity_prev_addr(p.k, p.q, i, jn);
@@ -303,9 +345,17 @@ __global__ __launch_bounds__(kThreads, T2_LDPC_MIN_WAVES) void ldpc_decode_kerne
                         info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
                     }
                     T2_PROF_T(tp2);
+#if T2_LDPC_PAIRLANE
+                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_update<CNT, NCMAX>(L, d, jn, h, active, a0, a1, st, info, pair_rec, p.prof)));
+#else
                     T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_update<CNT, NCMAX>(L, d, jn, active, a0, a1, st, info, pair_rec, p.prof)));
+#endif
                     if (!(T2_PROF_DETAIL && (ly.kind == T2_PROF_DETAIL || T2_PROF_DETAIL == 3))) T2_PROF_ADD(2 + ly.kind, tp2);   // mode 3: slots 3-5 are the PLAIN split only
+#if T2_LDPC_PAIRLANE
+                    if (active && h == 0) state[i * 360 + j] = make_uint2(st.w0, st.w1);
+#else
                     if (active) state[i * 360 + j] = make_uint2(st.w0, st.w1);
+#endif
                 }
             }
             __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep

@@ -13,7 +13,7 @@ using namespace t2gpu;
 struct t2gpu_ldpc {
     LdpcGraph g;
     int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
-    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0;
+    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0, lds_ent_offset = 0;
     LdpcLayerDev *d_layers = nullptr;
     uint32_t *d_entries = nullptr, *d_entries2 = nullptr;
     int lds_base = 0;
@@ -75,6 +75,10 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     h->lds_rec_offset = h->lds_ctl_offset + 64;
     h->lds_sign_offset = h->lds_rec_offset + 360 * 4;
     h->lds_bytes = h->lds_sign_offset + (h->g.n / 360) * 13 * 4;
+#if T2_LDPC_PAIRLANE
+    h->lds_ent_offset = (h->lds_bytes + 7) & ~7;                  // the table entries as (base, shift) pairs: the two lanes of a node
+    h->lds_bytes = h->lds_ent_offset + (int)h->g.entries.size() * 8;   // read different entries, so the table cannot come through scalar loads
+#endif
     if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu, &h->lds_base)) != hipSuccess) return fail("kernel attributes", e);
     if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
     if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {          // experiments: fewer resident workgroups per CU
@@ -171,6 +175,8 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.lds_ctl_offset = h->lds_ctl_offset;
     p.lds_rec_offset = h->lds_rec_offset;
     p.lds_sign_offset = h->lds_sign_offset;
+    p.lds_ent_offset = h->lds_ent_offset;
+    p.n_entries = (int)h->g.entries.size();
     p.prof = h->d_prof;
     p.resident = h->d_resident;
     if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long), s));
