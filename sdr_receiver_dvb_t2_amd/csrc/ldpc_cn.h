@@ -220,41 +220,48 @@ T2_HD void t2_cn_pack(const CnRegs<CNT> &r, CnState &st)
 }
 
 // ---- PAIR layers -------------------------------------------------------------------------------------------------
-// Record a chain walker needs from a node that has both a predecessor and a successor:
-//   byte0 msg1 (old message of slot 1), byte1 cap = min(126, f(E)) with E the smallest raw magnitude of the slots other
-//   than 0 and 1, byte2 in0 (input of slot 0), bit 24 = sign parity of those other slots.
+// Record a chain walker needs from a node that has both a predecessor and a successor, in the form the walk consumes:
+//   bits 0-7   k1 = -s * msg1 - 1 (signed), msg1 = old message of slot 1, s = +1 / -1 the sign parity of the slots other than 0, 1
+//   bits 8-14  cap = min(126, f(E)), E the smallest raw magnitude of those other slots
+//   bits 16-23 in0 (input of slot 0, signed)          bits 24-25 s as a 2-bit signed field
+T2_HD uint32_t t2_pair_pack(int msg1, int cap, int in0, bool neg)
+{
+    const int k1 = (neg ? msg1 : -msg1) - 1;
+    return (uint32_t)(k1 & 0xff) | ((uint32_t)cap << 8) | ((uint32_t)(in0 & 0xff) << 16) | (neg ? (3u << 24) : (1u << 24));
+}
 template <int CNT>
 T2_HD uint32_t t2_pair_record(const CnRegs<CNT> &r)
 {
-    int cap = t2_f(r.p0);
-    return (uint32_t)(t2_old_msg(r, 1) & 0xff) | ((uint32_t)cap << 8) | ((uint32_t)(r.in[0] & 0xff) << 16) |
-           ((r.psx < 0) ? (1u << 24) : 0u);
+    return t2_pair_pack(t2_old_msg(r, 1), t2_f(r.p0), r.in[0], r.psx < 0);
 }
 
 // One step down a chain. X = LLR of the shared bit after the predecessor; returns it after this node:
-//   X' = sat(in0 + s * min(f(E), f(|sat(X - msg1)|))),  s = sign parity of the others * sign(X - msg1).
-// f(|sat(u)|) = med3(|u| - 1, 0, 126) also without the saturation (|u| <= 160). Written so that only six operations depend
-// on X in sequence -- |u| - 1 = max(X + c1, c2 - X) with c1 = -msg1 - 1, c2 = msg1 - 1; med3; xor with the sign; one add of
-// (in0 - sign); the final saturation -- because this recurrence IS the critical path of a PAIR layer.
-struct PairRec { int msg1, c1, c2, cap, in0, psm; };
+//   X' = sat(in0 + s * sign(u) * min(f(E), f(|sat(u)|))),  u = X - msg1.
+// f(|sat(u)|) = med3(|u| - 1, 0, 126) also without the saturation (|u| <= 160), so the middle term is the odd function
+//   g(w) = sign(w) * med3(|w| - 1, 0, cap) = med3(w - 1, 0, cap) + med3(w + 1, -cap, 0)   of   w = s * u = s * X + (k1 + 1),
+// which needs no absolute value and no sign bookkeeping: one multiply-add, one add, two med3, one three-operand add, the final
+// saturation -- four operations deep, because this recurrence IS the critical path of a PAIR layer.
+struct PairRec { int k1, cap, ncap, in0, sg; };
 T2_HD PairRec t2_pair_unpack(uint32_t rec)
 {
     PairRec r;
-    r.msg1 = (int)(int8_t)(rec & 0xff);
-    r.cap = (int)((rec >> 8) & 0xff);
+    r.k1 = (int)(int8_t)(rec & 0xff);
+    r.cap = (int)((rec >> 8) & 0x7f);
+    r.ncap = -r.cap;
     r.in0 = (int)(int8_t)((rec >> 16) & 0xff);
-    r.psm = -(int)((rec >> 24) & 1u);                    // 0 / -1
-    r.c1 = -r.msg1 - 1;
-    r.c2 = r.msg1 - 1;
+    r.sg = ((int)(rec << 6)) >> 30;                      // bits 24-25, sign-extended: +1 / -1
     return r;
 }
 T2_HD int t2_pair_step(const PairRec &r, int X)
 {
-    const int a = X + r.c1, b = r.c2 - X;
-    const int a1 = a > b ? a : b;                        // |X - msg1| - 1
-    const int t = t2_clamp(a1, 0, r.cap);
-    const int sm = ((X - r.msg1) >> 31) ^ r.psm;
-    return t2_clamp((t ^ sm) + (r.in0 - sm), -128, 127);
+#if defined(__HIP_DEVICE_COMPILE__)
+    int t1;                                              // w - 1
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t1) : "v"(X), "v"(r.sg), "v"(r.k1));
+#else
+    const int t1 = X * r.sg + r.k1;
+#endif
+    const int t2 = t1 + 2;                               // w + 1
+    return t2_clamp(t2_clamp(t1, 0, r.cap) + t2_clamp(t2, r.ncap, 0) + r.in0, -128, 127);
 }
 
 // Parity check of node j on the current LLRs (LDPCDecoder::bad, layered_decoder.hh:65-82): the node is bad when

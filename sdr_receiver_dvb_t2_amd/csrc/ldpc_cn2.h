@@ -181,6 +181,7 @@ __device__ __forceinline__ void pl_phase_a(LMEM &L, const LayerDesc &d, int j, i
 {
     constexpr int H = PlRegs<CNT>::H;
     pl_load<CNT>(L, d.ent_lds, j, h, a_p0, a_p1, st, r);
+    T2_CN_HOOK_AFTER_LOAD;
     if (d.kind == T2_LAYER_PLAIN) {
         pl_partial<CNT>(r, 0);
         r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;
@@ -193,9 +194,7 @@ __device__ __forceinline__ void pl_phase_a(LMEM &L, const LayerDesc &d, int j, i
             pl_merge<CNT, 1>(r, 2);
             pl_write_slot<CNT>(L, r, 0, true);
         } else if (h == 0) {                    // t2_pair_record: msg1 = old message of slot 1, from the record's code bits 2..3
-            const int msg1 = t2_lut_byte(r.lut, (st.w0 >> 2) & 3u);
-            const int cap = t2_f(r.p0);
-            pair_rec[j] = (uint32_t)(msg1 & 0xff) | ((uint32_t)cap << 8) | ((uint32_t)(r.in[0] & 0xff) << 16) | ((r.psx < 0) ? (1u << 24) : 0u);
+            pair_rec[j] = t2_pair_pack(t2_lut_byte(r.lut, (st.w0 >> 2) & 3u), t2_f(r.p0), r.in[0], r.psx < 0);
         }
     } else {
         pl_partial<CNT>(r, d.nc);

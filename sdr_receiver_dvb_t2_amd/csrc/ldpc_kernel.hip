@@ -158,24 +158,42 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
                                              CnState &st, uint32_t info, uint32_t *pair_rec, long long *prof)
 {
     PlRegs<CNT> r;
+    long long tdt = (T2_PROF_DETAIL && prof) ? (long long)__builtin_readcyclecounter() : 0;
     if (active) pl_phase_a<CNT>(L, d, j, h, a0, a1, st, r, pair_rec);
+#if T2_PROF_DETAIL == 3
+    if (d.kind == T2_LAYER_PLAIN && prof && threadIdx.x == 0) {
+        const long long now_ = (long long)__builtin_readcyclecounter();
+        prof[blockIdx.x * 8 + 3] += s_after_load - tdt;
+        prof[blockIdx.x * 8 + 4] += now_ - s_after_load;
+        tdt = now_;
+    }
+#endif
     if (d.kind == T2_LAYER_PAIR) {
         lds_barrier();
+        T2_DTL(1, 3);
         __builtin_amdgcn_s_setprio(3);
         if ((int)threadIdx.x < d.step) t2_pair_walk(L, d, (int)threadIdx.x, pair_rec);   // any lane can walk any chain: the first `step` threads do
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();
+        T2_DTL(1, 4);
         if (active) pl_pair_finish<CNT>(L, d, j, st, r);
     } else if (d.kind == T2_LAYER_GENERIC) {
+        T2_DTL(2, 3);
         __builtin_amdgcn_s_setprio(3);
         for (int lv = 1; lv <= d.lmax; ++lv) {
             if (active) pl_generic_level<CNT, NCMAX>(L, d, lv, info, r);
             lds_barrier();
         }
         __builtin_amdgcn_s_setprio(0);
+        T2_DTL(2, 4);
         if (active) pl_generic_finish<CNT>(L, d, st, r);
     }
     lds_barrier();
+#if T2_PROF_DETAIL == 3
+    if (d.kind == T2_LAYER_PLAIN && prof && threadIdx.x == 0) prof[blockIdx.x * 8 + 5] += (long long)__builtin_readcyclecounter() - tdt;
+#endif
+    if (d.kind == T2_LAYER_PAIR) T2_DTL(1, 5);
+    if (d.kind == T2_LAYER_GENERIC) T2_DTL(2, 5);
 }
 #else
 template <int CNT, int NCMAX>
