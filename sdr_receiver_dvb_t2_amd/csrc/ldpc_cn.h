@@ -150,9 +150,7 @@ T2_HD void t2_cn_load(const LMEM &L, const uint32_t *__restrict__ ent, int j, in
         // base by scalar arithmetic, so the per-lane address needs no further add at the load or the store)
 #if defined(__HIP_DEVICE_COMPILE__)
         if (c < CNT) {
-            int m = j - (int)ent2[2 * c + 1];
-            m += (m < 0) ? 360 : 0;
-            r.addr[c] = (int)ent2[2 * c] + m;
+            r.addr[c] = (int)ent2[2 * c] + (j >= (int)ent2[2 * c + 1] ? j : j + 360);
         } else {
             r.addr[c] = (c == CNT ? a_p0 : a_p1);
         }
@@ -291,7 +289,7 @@ struct LayerDesc {
     int cnt, lmax, nc, kind, step;
     int dummy;      // address of a scratch byte in the LLR memory: target of the stores a chain walker predicates away
     uint32_t e0;    // ent[0], fetched when the descriptor is made (the chain walker needs it right behind a barrier)
-    const uint32_t *ent2 = nullptr;   // GPU only: the same entries as (base + L.off(), shift) dword pairs -- saves the scalar
+    const uint32_t *ent2 = nullptr;   // GPU only: the same entries as (base + L.off() - shift, shift) dword pairs -- saves the scalar
                                       // add / shift / mask per link that unpacking costs every wavefront in every layer
     int ent_lds = 0;                  // pair-lane kernel: LDS address of a copy of those pairs (ldpc_cn2.h)
 };

@@ -71,7 +71,7 @@ __device__ __forceinline__ int pl_rawmag(const PlRegs<CNT> &r, int v)
     return pl_present(r, v) ? a : 255;
 }
 
-// t2_cn_load for one lane. ent_lds: LDS address of the layer's entries as (base + L.off(), shift) pairs.
+// t2_cn_load for one lane. ent_lds: LDS address of the layer's entries as (base + L.off() - shift, shift) pairs.
 template <int CNT, class LMEM>
 __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h, int a_p0, int a_p1, const CnState &st, PlRegs<CNT> &r)
 {
@@ -86,6 +86,7 @@ __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h
     r.c1s = (st.w1 & 0xfffu) >> (2 * h);
     r.n0 = 0; r.n1 = 0;
     uint2 e[H];
+    const int jw = j + 360;
     const int mine = ent_lds + 8 * h;                              // the odd lane reads the odd entries
 #pragma unroll
     for (int v = 0; v < H; ++v) {                                  // the lane's table entries from the LDS copy, issued together
@@ -97,9 +98,7 @@ __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         const int c0 = 2 * v, c1 = 2 * v + 1;
-        int m = j - (int)e[v].y;
-        m += (m < 0) ? 360 : 0;
-        const int link = (int)e[v].x + m;
+        const int link = (int)e[v].x + (j >= (int)e[v].y ? j : jw);  // (base - shift) + j, + 360 where the shift wraps
         if (c1 < CNT) r.addr[v] = link;                             // information slots on both lanes
         else if (c0 < CNT) r.addr[v] = h ? a_p0 : link;             // c1 == CNT: own parity bit on the odd lane
         else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity

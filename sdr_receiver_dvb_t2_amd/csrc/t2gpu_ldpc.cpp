@@ -98,8 +98,8 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     {   // the entries once more, unpacked and with the LDS address of the LLR array folded in (ldpc_cn.h, LayerDesc::ent2)
         std::vector<uint32_t> e2(2 * h->g.entries.size());
         for (size_t i = 0; i < h->g.entries.size(); ++i) {
-            e2[2 * i] = (h->g.entries[i] & 0xffffu) + (uint32_t)h->lds_base;
-            e2[2 * i + 1] = h->g.entries[i] >> 16;
+            e2[2 * i] = (h->g.entries[i] & 0xffffu) + (uint32_t)h->lds_base - (h->g.entries[i] >> 16);   // base - shift: the address is
+            e2[2 * i + 1] = h->g.entries[i] >> 16;                                                       // this + (j >= shift ? j : j + 360)
         }
         if ((e = hipMalloc(&h->d_entries2, e2.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
         if ((e = hipMemcpy(h->d_entries2, e2.data(), e2.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
