@@ -31,6 +31,7 @@ template <int CNT>
 struct PlRegs {
     static constexpr int DEG = CNT + 2, H = (DEG + 1) / 2;     // link slots of the node / of one lane (slot c = 2v + h)
     int addr[H], in[H];         // absent slots: addr < 0, in = 0
+    int mag[H];                 // raw magnitude |in| (255 for an absent slot), kept for the "held the minimum" test of the write phase
     uint32_t lut;               // as CnRegs::lut
     uint32_t c0s, c1s;          // old code words shifted right by 2h: slot v's code sits at bits 4v (word 0: c < 16, word 1: the rest)
     int p0, p1, psx;            // node-wide: two smallest raw magnitudes / sign xor over the non-conflict slots
@@ -55,21 +56,25 @@ __device__ __forceinline__ int pl_old_msg(const PlRegs<CNT> &r, int v)
     return t2_lut_byte(r.lut, (w >> (4 * (v & 7))) & 3u);
 }
 
+template <int CNT> __device__ __forceinline__ int pl_rawmag_of(const PlRegs<CNT> &r, int v);
 template <int CNT, class LMEM>
 __device__ __forceinline__ void pl_read_slot(const LMEM &L, PlRegs<CNT> &r, int v)
 {
     const bool present = pl_present(r, v);
     const int lc = present ? (int)L.ld(r.addr[v]) : 0;
     r.in[v] = present ? t2_clamp(lc - pl_old_msg(r, v), -128, 127) : 0;
+    r.mag[v] = pl_rawmag_of(r, v);
 }
 
 template <int CNT>
-__device__ __forceinline__ int pl_rawmag(const PlRegs<CNT> &r, int v)
+__device__ __forceinline__ int pl_rawmag_of(const PlRegs<CNT> &r, int v)
 {
     const int x = r.in[v], nx = -x;
     const int a = x > nx ? x : nx;
     return pl_present(r, v) ? a : 255;
 }
+template <int CNT>
+__device__ __forceinline__ int pl_rawmag(const PlRegs<CNT> &r, int v) { return r.mag[v]; }
 
 // t2_cn_load for one lane. ent_lds: LDS address of the layer's entries as (base + L.off() - shift, shift) pairs.
 template <int CNT, class LMEM>
@@ -107,7 +112,10 @@ __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h
 #pragma unroll
     for (int v = 0; v < H; ++v) r.in[v] = pl_present(r, v) ? (int)L.ld(r.addr[v]) : 0;
 #pragma unroll
-    for (int v = 0; v < H; ++v) r.in[v] = pl_present(r, v) ? t2_clamp(r.in[v] - pl_old_msg(r, v), -128, 127) : 0;
+    for (int v = 0; v < H; ++v) {
+        r.in[v] = pl_present(r, v) ? t2_clamp(r.in[v] - pl_old_msg(r, v), -128, 127) : 0;
+        r.mag[v] = pl_rawmag_of(r, v);
+    }
 }
 
 // t2_cn_partial: over the node's slots c >= nc (both lanes), result node-wide in p0 / p1 / psx
@@ -154,7 +162,7 @@ template <int CNT, class LMEM>
 __device__ __forceinline__ void pl_write_slot(LMEM &L, PlRegs<CNT> &r, int v, bool store)
 {
     const bool present = pl_present(r, v);
-    const bool eq = present && (r.in[v] == r.m0 || r.in[v] == -r.m0);
+    const bool eq = r.mag[v] == r.m0;                    // an absent slot carries 255 and the node's minimum is at most 128
     const int other = eq ? r.m1f : r.m0f;
     const int sm = (r.sx ^ r.in[v]) >> 31;
     const int out = (other ^ sm) - sm;
