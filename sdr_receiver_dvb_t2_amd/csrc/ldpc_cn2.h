@@ -164,9 +164,10 @@ __device__ __forceinline__ void pl_write_slot(LMEM &L, PlRegs<CNT> &r, int v, bo
     const bool present = pl_present(r, v);
     const bool eq = r.mag[v] == r.m0;                    // an absent slot carries 255 and the node's minimum is at most 128
     const int other = eq ? r.m1f : r.m0f;
-    const int sm = (r.sx ^ r.in[v]) >> 31;
-    const int out = (other ^ sm) - sm;
-    const int ln = t2_clamp(r.in[v] + out, -128, 127);
+    const int sm = (r.sx ^ r.in[v]) >> 31;               // 0 / -1: sign of the product of the other inputs
+    int upd;                                             // in + sign * other in one multiply-add (sign = sm | 1 = +1 / -1)
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(upd) : "v"(other), "v"(sm | 1), "v"(r.in[v]));
+    const int ln = t2_clamp(upd, -128, 127);
     if (present && store) L.st(r.addr[v], (int8_t)ln);
     const uint32_t bits = ((uint32_t)sm & (1u << (4 * (v & 7)))) | (eq ? (2u << (4 * (v & 7))) : 0u);
     if (v < 8) r.n0 |= bits; else r.n1 |= bits;
