@@ -249,6 +249,14 @@ int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols
  * (src/DVB_T2/fc_symbol.h:31, fc_symbol.cpp:82-271) for the frame-closing symbols of n_symbols frames: [n][fft_size] in,
  * [n][n_fc] cells out (returned count). Fails when the mode has no frame-closing symbol (l_fc = 0). */
 int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream);
+/* The same two for whole frames, in place like t2gpu_eq_data_frames_dev: the P2 (frame-closing) symbol of frame f is read at
+ * d_spectrum + 2 * f * syms_per_frame * fft_size floats (+ the symbol's position in the frame); P2: the cells behind the first
+ * skip_cells (the L1 cells, time_deinterleaver.cpp:296-300) go to d_cells + 2 * f * cells_frame_stride floats; frame closing: the
+ * n_fc cells go to d_cells + 2 * (f * cells_frame_stride + cells_offset). Return the cells stored per frame. */
+int t2gpu_eq_p2_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                           long cells_frame_stride, int skip_cells, float *d_sync, void *stream);
+int t2gpu_eq_fc_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                           long cells_frame_stride, long cells_offset, float *d_sync, void *stream);
 /* host only: {fft_size, k_total, k_ext, k_offset, l_nulls, c_p2, c_data, n_fc, c_fc, l_fc, len_frame, guard_interval_size}
  * (dvbt2_{p2,bwt_ext,data}_parameters_init, src/DVB_T2/dvbt2_definition.cpp:20-648) */
 int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_eq_p2_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp]),
+    "t2gpu_eq_fc_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp]),
     "t2gpu_rx_create": (_vp, [_vp, ctypes.c_int]),
     "t2gpu_rx_destroy": (None, [_vp]),
     "t2gpu_rx_info": (ctypes.c_int, [_vp, _vp]),

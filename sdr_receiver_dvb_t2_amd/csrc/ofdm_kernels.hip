@@ -290,7 +290,8 @@ __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p
             if (!mine[u]) continue;
             const float dr = cr[u] / amp[u], di = sr[u] / amp[u];
             const float2 c = ld(i0 + u);
-            o[l_h[dd[u]]] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);   // buffer_cell[j] * conj(derotate)
+            const int at = (int)l_h[dd[u]] - p.out_skip;
+            if (at >= 0) o[at] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);   // buffer_cell[j] * conj(derotate)
         }
     }
     // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel

@@ -328,6 +328,41 @@ extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     return h->m.c_p2;
 }
 
+// The P2 / frame-closing symbol of every frame read in place from the frames' spectra and written in place into the frames' cell
+// streams (as t2gpu_eq_data_frames_dev does for the data symbols): no gather of the symbols, no copy of the cells.
+extern "C" int t2gpu_eq_p2_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                                      long cells_frame_stride, int skip_cells, float *d_sync, void *stream)
+{
+    if (!h || !d_spectrum || !d_cells || n_frames < 1 || n_frames > h->max_symbols || syms_per_frame < 1 || skip_cells < 0 ||
+        skip_cells > h->m.c_p2 || cells_frame_stride < h->m.c_p2 - skip_cells) {
+        set_error("t2gpu_eq_p2_frames_dev: bad arguments");
+        return -1;
+    }
+    EqParams p = h->eq_p2;
+    p.per_frame = 1; p.first = 0; p.in_syms_per_frame = syms_per_frame;
+    p.out_frame_stride = cells_frame_stride; p.out_offset = 0; p.out_skip = skip_cells;
+    T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, n_frames, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+    return h->m.c_p2 - skip_cells;
+}
+
+extern "C" int t2gpu_eq_fc_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                                      long cells_frame_stride, long cells_offset, float *d_sync, void *stream)
+{
+    if (!h || !d_spectrum || !d_cells || n_frames < 1 || n_frames > h->max_symbols || syms_per_frame < h->m.len_frame || cells_offset < 0 ||
+        cells_frame_stride < cells_offset + h->m.n_fc) {
+        set_error("t2gpu_eq_fc_frames_dev: bad arguments");
+        return -1;
+    }
+    if (!h->m.l_fc) { set_error("t2gpu_eq_fc_frames_dev: this mode has no frame-closing symbol"); return -1; }
+    EqParams p = h->eq_fc;
+    p.per_frame = 1; p.first = h->m.len_frame - 1; p.in_syms_per_frame = syms_per_frame;
+    p.out_frame_stride = cells_frame_stride; p.out_offset = cells_offset;
+    T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, n_frames, reinterpret_cast<float2 *>(d_cells),
+                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+    return h->m.n_fc;
+}
+
 // frame-closing symbols of a batch of frames (idx_symbol = len_frame - 1 for all of them)
 extern "C" int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream)
 {

@@ -190,21 +190,13 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out
     T2_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
-    const size_t fft_b = (size_t)h->fft_size * 8, frame_spec_b = (size_t)h->n_sym * fft_b, frame_cells_b = (size_t)h->frame_cells * 8;
-    // P2: the frames' first spectra, equalised; the PLP cells behind the L1 cells head the frame's cell stream
-    T2_HIP(hipMemcpy2DAsync(h->d_p2_in, fft_b, h->d_spec, frame_spec_b, fft_b, F, hipMemcpyDeviceToDevice, s));
-    if (t2gpu_eq_p2_execute_dev(h->ofdm, h->d_p2_in, F, h->d_p2_cells, nullptr, s) < 0) return -1;
+    // P2, data symbols, frame-closing symbol: read in place from the spectra, written in place into the cell streams (P2 without
+    // its L1 cells, time_deinterleaver.cpp:296-300)
     const int a = h->c_p2 - h->p2_skip;
-    if (a > 0) T2_HIP(hipMemcpy2DAsync(h->d_cells, frame_cells_b, h->d_p2_cells + 2 * (size_t)h->p2_skip, (size_t)h->c_p2 * 8, (size_t)a * 8, F,
-                                       hipMemcpyDeviceToDevice, s));
-    // data symbols: read in place from the spectra, written in place into the cell streams
+    if (t2gpu_eq_p2_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, nullptr, s) < 0) return -1;
     if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, nullptr, s) < 0) return -1;
-    if (h->l_fc) {                                          // frame-closing symbol: its n_fc cells end the stream
-        T2_HIP(hipMemcpy2DAsync(h->d_p2_in, fft_b, h->d_spec + 2 * (size_t)(1 + h->n_dat) * h->fft_size, frame_spec_b, fft_b, F, hipMemcpyDeviceToDevice, s));
-        if (t2gpu_eq_fc_execute_dev(h->ofdm, h->d_p2_in, F, h->d_fc_cells, nullptr, s) < 0) return -1;
-        T2_HIP(hipMemcpy2DAsync(h->d_cells + 2 * (size_t)(a + h->n_dat * h->c_data), frame_cells_b, h->d_fc_cells, (size_t)h->n_fc * 8,
-                                (size_t)h->n_fc * 8, F, hipMemcpyDeviceToDevice, s));
-    }
+    if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data, nullptr, s) < 0)
+        return -1;
     // TI block of every frame in one launch, statistics in one launch, LLRs in one launch
     if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
     if (t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0) return -1;
