@@ -131,6 +131,18 @@ __device__ __forceinline__ float wrap_2pi(float a)
 }
 
 // ---- level 3: dc removal, sign statistics, IQ-imbalance correction, NCO de-rotation (dvbt2_demodulator.cpp:175-205)
+// last run whose first sample is <= i (runs are sorted by i0, the first starts at the call's first sample). The planner emits
+// one run for whole buffers when the loops stand still and never more than one per sample; a search costs log2(runs) cached loads.
+__device__ __forceinline__ int find_run(const FrontRun *__restrict__ runs, int n, long i)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (runs[mid].i0 <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
 {
     __shared__ Lin wave_tot[4];
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
     double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
     const float c1 = p.state->c1, c2 = p.state->c2;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    int r = valid ? p.nco_index[s0 / FRONT_RUN_STRIDE] : 0;
+    int r = valid ? find_run(p.nco_runs, p.n_nco_runs, s0) : 0;
     for (int k = 0; k < valid; ++k) {
         const long i = s0 + k;
         dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
@@ -180,9 +192,7 @@ __global__ __launch_bounds__(256) void front_farrow_kernel(FrontParams p)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
-    int r = p.far_index[i / FRONT_RUN_STRIDE];
-    while (r + 1 < p.n_far_runs && p.far_runs[r + 1].i0 <= i) ++r;
-    const FrontRun run = p.far_runs[r];
+    const FrontRun run = p.far_runs[find_run(p.far_runs, p.n_far_runs, i)];
     const long k = i - run.i0;
     float x1 = (float)(run.base + (double)k * run.step);
     long o = (long)run.o0 + k * run.cnt;

@@ -59,17 +59,6 @@ bool ensure_runs(t2gpu_front *h, size_t need)
     return true;
 }
 
-void build_index(const std::vector<FrontRun> &runs, int n, int32_t *index)
-{
-    const int groups = (n + FRONT_RUN_STRIDE - 1) / FRONT_RUN_STRIDE;
-    size_t r = 0;
-    for (int g = 0; g < groups; ++g) {
-        const int i = g * FRONT_RUN_STRIDE;
-        while (r + 1 < runs.size() && runs[r + 1].i0 <= i) ++r;
-        index[g] = (int32_t)r;
-    }
-}
-
 // plan one execute(): fills h->nco_runs / far_runs, advances the host accumulators, returns the interpolated sample count
 long plan_call(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *pe, const float *fe, const double *rs,
                bool nco, bool farrow, int32_t *chunk_out_len, long *n_out_total)
@@ -110,14 +99,13 @@ int stage_tables(t2gpu_front *h, int n, hipStream_t stream, FrontParams &p)
     if (h->staged_pending) { T2_HIP(hipEventSynchronize(h->staged)); h->staged_pending = false; }
     if (nn) std::memcpy(h->h_runs, h->nco_runs.data(), nn * sizeof(FrontRun));
     if (nf) std::memcpy(h->h_runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
-    if (nn) build_index(h->nco_runs, n, h->h_index);
-    if (nf) build_index(h->far_runs, n, h->h_index + groups);
-    if (nn + nf) T2_HIP(hipMemcpyAsync(h->d_runs, h->h_runs, (nn + nf) * sizeof(FrontRun), hipMemcpyHostToDevice, stream));
-    if (groups) T2_HIP(hipMemcpyAsync(h->d_index, h->h_index, 2 * groups * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    if (nn + nf) T2_HIP(hipMemcpyAsync(h->d_runs, h->h_runs, (nn + nf) * sizeof(FrontRun), hipMemcpyHostToDevice, stream));   // the kernels
+    // find a sample's run by binary search: no per-block index to build and ship
     T2_HIP(hipEventRecord(h->staged, stream));
     h->staged_pending = true;
-    p.nco_runs = h->d_runs; p.n_nco_runs = (int)nn; p.nco_index = h->d_index;
-    p.far_runs = h->d_runs + nn; p.n_far_runs = (int)nf; p.far_index = h->d_index + groups;
+    p.nco_runs = h->d_runs; p.n_nco_runs = (int)nn; p.nco_index = nullptr;
+    p.far_runs = h->d_runs + nn; p.n_far_runs = (int)nf; p.far_index = nullptr;
+    (void)groups;
     return 0;
 }
 
