@@ -216,17 +216,23 @@ constexpr int EQ_SPLIT = 4;
 
 __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
                                                           const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
-                                                          float4 *__restrict__ pilot_scratch)
+                                                          float4 *__restrict__ pilot_scratch, int n_symbols, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) float eq_lds[];
     const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
     const float PI = 3.14159274101257324219f;
-    const int b = blockIdx.y;                                                   // symbol of the batch
+    // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own, and the de-interleaved cells of a symbol are
+    // 8-byte stores scattered over the symbol's whole output: they only merge into full lines if all groups of the symbol write
+    // through the SAME L2. Linear id w -> XCD w % 8; symbol = 8 * (w / 8 / groups) + w % 8, group = (w / 8) % groups.
+    const int wg = (int)blockIdx.x;
+    const int b = 8 * ((wg >> 3) / groups) + (wg & 7);                          // symbol of the batch
+    const int grp = (wg >> 3) % groups;
+    if (b >= n_symbols) return;
     const int fr = p.per_frame ? b / p.per_frame : 0, lo = p.per_frame ? b - fr * p.per_frame : 0;
     const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];        // position in the T2 frame (P2 = 0)
     const int row = idx_symbol - p.n_p2;                                        // data-symbol table row
     const int nseg = p.seg_count[row];
-    const int seg0 = blockIdx.x * EQ_GROUP;
+    const int seg0 = grp * EQ_GROUP;
     if (seg0 >= nseg) return;
     const int seg1 = min(nseg, seg0 + EQ_GROUP) - 1;
     const int seg = seg0 + threadIdx.x / EQ_SPLIT, sub = threadIdx.x % EQ_SPLIT;
@@ -331,8 +337,10 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         if (e != hipSuccess) return e;
         attr_bytes = lds_bytes;
     }
-    dim3 grid((p.max_seg + EQ_GROUP - 1) / EQ_GROUP, n_symbols);
-    hipLaunchKernelGGL(eq_data_kernel, grid, dim3(EQ_GROUP * EQ_SPLIT), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch);
+    const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
+    const unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                   // linear id, see the kernel
+    hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_GROUP * EQ_SPLIT), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
+                       groups);
     if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3((n_symbols + 63) / 64), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
     return hipGetLastError();
 }
