@@ -14,6 +14,24 @@
 
 namespace t2gpu {
 
+// f of ldpc_cn.h for a raw magnitude 0..255 in two instructions
+__device__ __forceinline__ int pl_f(int a) { return t2_clamp(a - 1, 0, 126); }
+
+// The record of a node with at most 16 link slots keeps all its codes in w0, so w1 can carry the message table of the NEXT sweep
+// ready-made (bytes min(A,31), -A, min(B,31), -B with A = min(f(min0), 32), B = min(f(min1), 32)) instead of A and B:
+// six instructions at the pack (two packed 16-bit ones) replace five there plus eight at every load.
+typedef short pl_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pl_lut_word(int m0f, int m1f)
+{
+    const int A = m0f > 32 ? 32 : m0f, B = m1f > 32 ? 32 : m1f;
+    const uint32_t ab = (uint32_t)A | ((uint32_t)B << 16);
+    pl_short2 x = __builtin_bit_cast(pl_short2, ab);
+    const pl_short2 neg = -x;
+    const pl_short2 lim = {31, 31};
+    const pl_short2 cap = __builtin_elementwise_min(x, lim);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, neg), __builtin_bit_cast(uint32_t, cap), 0x06020400u);
+}
+
 // value of v in the partner lane (lane ^ 1)
 __device__ __forceinline__ int pl_x(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t pl_xu(uint32_t v) { return (uint32_t)pl_x((int)v); }
@@ -82,13 +100,16 @@ __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h
 {
     constexpr int H = PlRegs<CNT>::H;
     r.h = h;
-    {
+    if constexpr (PlRegs<CNT>::DEG <= 16) {
+        r.lut = st.w1;                                             // see pl_lut_word
+        r.c1s = 0;
+    } else {
         const int A = (int)((st.w1 >> 16) & 0xffu), B = (int)(st.w1 >> 24);
         r.lut = (uint32_t)(A > 31 ? 31 : A) | ((uint32_t)((-A) & 0xff) << 8) | ((uint32_t)(B > 31 ? 31 : B) << 16) |
                 ((uint32_t)((-B) & 0xff) << 24);
+        r.c1s = (st.w1 & 0xfffu) >> (2 * h);
     }
     r.c0s = st.w0 >> (2 * h);
-    r.c1s = (st.w1 & 0xfffu) >> (2 * h);
     r.n0 = 0; r.n1 = 0;
     uint2 e[H];
     const int jw = j + 360;
@@ -154,7 +175,7 @@ __device__ __forceinline__ void pl_merge(PlRegs<CNT> &r, int nc)
     sx ^= pl_x(sx);
     int a0, a1;
     pl_merge2(c0, c1, r.p0, r.p1, a0, a1);
-    r.m0 = a0; r.m0f = t2_f(a0); r.m1f = t2_f(a1); r.sx = sx ^ r.psx;
+    r.m0 = a0; r.m0f = pl_f(a0); r.m1f = pl_f(a1); r.sx = sx ^ r.psx;
 }
 
 // t2_write_slot for lane slot v
@@ -177,9 +198,14 @@ __device__ __forceinline__ void pl_write_slot(LMEM &L, PlRegs<CNT> &r, int v, bo
 template <int CNT>
 __device__ __forceinline__ void pl_pack(const PlRegs<CNT> &r, CnState &st)
 {
-    const uint32_t x0 = r.n0 << (2 * r.h), x1 = r.n1 << (2 * r.h);
+    const uint32_t x0 = r.n0 << (2 * r.h);
     st.w0 = x0 | pl_xu(x0);
-    st.w1 = ((x1 | pl_xu(x1)) & 0xfffu) | ((uint32_t)(r.m0f > 32 ? 32 : r.m0f) << 16) | ((uint32_t)(r.m1f > 32 ? 32 : r.m1f) << 24);
+    if constexpr (PlRegs<CNT>::DEG <= 16) {
+        st.w1 = pl_lut_word(r.m0f, r.m1f);
+    } else {
+        const uint32_t x1 = r.n1 << (2 * r.h);
+        st.w1 = ((x1 | pl_xu(x1)) & 0xfffu) | ((uint32_t)(r.m0f > 32 ? 32 : r.m0f) << 16) | ((uint32_t)(r.m1f > 32 ? 32 : r.m1f) << 24);
+    }
 }
 
 // t2_layer_phase_a
@@ -192,7 +218,7 @@ __device__ __forceinline__ void pl_phase_a(LMEM &L, const LayerDesc &d, int j, i
     T2_CN_HOOK_AFTER_LOAD;
     if (d.kind == T2_LAYER_PLAIN) {
         pl_partial<CNT>(r, 0);
-        r.m0 = r.p0; r.m0f = t2_f(r.p0); r.m1f = t2_f(r.p1); r.sx = r.psx;
+        r.m0 = r.p0; r.m0f = pl_f(r.p0); r.m1f = pl_f(r.p1); r.sx = r.psx;
 #pragma unroll
         for (int v = 0; v < H; ++v) pl_write_slot<CNT>(L, r, v, true);
         pl_pack<CNT>(r, st);
