@@ -74,13 +74,25 @@ __device__ __forceinline__ int pl_old_msg(const PlRegs<CNT> &r, int v)
     return t2_lut_byte(r.lut, (w >> (4 * (v & 7))) & 3u);
 }
 
+// sat-free part of alg.sub for slot v: (LLR byte, sign-extended) - (old message). The message is byte `code` of lut; a selector
+// with zero upper bytes leaves lut's byte 0 in the upper bytes of the permute result, which the byte-selecting subtract never
+// reads -- so the code needs no "| 0x0c0c0c00": bit-field extract, permute, byte-selecting subtract (three instructions, four before).
+template <int CNT>
+__device__ __forceinline__ int pl_llr_minus_msg(const PlRegs<CNT> &r, int v, uint8_t raw)
+{
+    const uint32_t w = v < 8 ? r.c0s : r.c1s;
+    const uint32_t code = __builtin_amdgcn_ubfe(w, 4u * (uint32_t)(v & 7), 2u);
+    const uint32_t m = __builtin_amdgcn_perm(0u, r.lut, code);
+    return (int)(int8_t)raw - (int)(int8_t)(m & 0xffu);   // both sign extensions ride on the subtract (SDWA byte selects)
+}
+
 template <int CNT> __device__ __forceinline__ int pl_rawmag_of(const PlRegs<CNT> &r, int v);
 template <int CNT, class LMEM>
 __device__ __forceinline__ void pl_read_slot(const LMEM &L, PlRegs<CNT> &r, int v)
 {
     const bool present = pl_present(r, v);
-    const int lc = present ? (int)L.ld(r.addr[v]) : 0;
-    r.in[v] = present ? t2_clamp(lc - pl_old_msg(r, v), -128, 127) : 0;
+    const uint8_t raw = present ? L.ld_raw(r.addr[v]) : (uint8_t)0;
+    r.in[v] = present ? t2_clamp(pl_llr_minus_msg(r, v, raw), -128, 127) : 0;
     r.mag[v] = pl_rawmag_of(r, v);
 }
 
@@ -130,11 +142,12 @@ __device__ __forceinline__ void pl_load(const LMEM &L, int ent_lds, int j, int h
         else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
         else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
     }
+    uint8_t raw[H];
 #pragma unroll
-    for (int v = 0; v < H; ++v) r.in[v] = pl_present(r, v) ? (int)L.ld(r.addr[v]) : 0;
+    for (int v = 0; v < H; ++v) raw[v] = pl_present(r, v) ? L.ld_raw(r.addr[v]) : (uint8_t)0;
 #pragma unroll
     for (int v = 0; v < H; ++v) {
-        r.in[v] = pl_present(r, v) ? t2_clamp(r.in[v] - pl_old_msg(r, v), -128, 127) : 0;
+        r.in[v] = pl_present(r, v) ? t2_clamp(pl_llr_minus_msg(r, v, raw[v]), -128, 127) : 0;
         r.mag[v] = pl_rawmag_of(r, v);
     }
 }

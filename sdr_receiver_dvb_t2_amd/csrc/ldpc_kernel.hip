@@ -41,6 +41,10 @@ struct LdsMem {
     __device__ __forceinline__ int off() const { return (int)base; }
     __device__ __forceinline__ int8_t ld(int a) const { return *reinterpret_cast<const lds_i8 *>((uint32_t)a); }
     __device__ __forceinline__ void st(int a, int8_t v) { *reinterpret_cast<lds_i8 *>((uint32_t)a) = v; }
+    __device__ __forceinline__ uint8_t ld_raw(int a) const       // the LLR byte as ds_read_u8 delivers it; the upper bits are nobody's business
+    {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uint32_t)a);
+    }
     __device__ __forceinline__ uint2 ld_pair(int a) const
     {
         const __attribute__((address_space(3))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a);
