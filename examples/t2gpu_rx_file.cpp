@@ -1,0 +1,133 @@
+// t2gpu_rx_file -- a Qt-free stand-in for the reference's source and sink around the accelerated path: int16 I/Q from files in,
+// transport stream out to a UDP port or a file.
+//
+//   source  rx_sdrplay::start / set_rf_frequency / set_gain / reset   (/root/reference/src/rx_sdrplay.cpp:135-261): the loop that
+//           hands buffers to dvbt2_demodulator::execute and serves its requests (re-tune, reset). A recording has no tuner: the
+//           requested moves of the local oscillator go to t2::dvbt2_demodulator::set_tuner, there is no AGC.
+//   sink    bb_de_header's output (/root/reference/src/DVB_T2/bb_de_header.cpp:433-443, set_out :500-525): one UDP datagram per
+//           BBFRAME to 127.0.0.1:<port> (the reference's `vlc udp://@:7654`), or the raw bytes appended to a file.
+//   between t2::dvbt2_demodulator -> time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder -> bb_de_header, wired as the
+//           reference's constructors wire them (include/t2gpu_stages.hpp), every stage a call into libt2gpu.so.
+//
+// build:  g++ -O2 -std=c++17 -I../include t2gpu_rx_file.cpp -L../sdr_receiver_dvb_t2_amd -lt2gpu -Wl,-rpath,$PWD/../sdr_receiver_dvb_t2_amd -o t2gpu_rx_file
+// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 262144] [--device 0]
+#include <arpa/inet.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include "t2gpu_stages.hpp"
+
+static std::vector<int16_t> slurp(const char *path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+    std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<int16_t> v(raw.size() / 2);
+    std::memcpy(v.data(), raw.data(), v.size() * 2);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s i.s16 q.s16 (--out file | --udp port) [--plp n] [--buf samples] [--device n]\n", argv[0]);
+        return 2;
+    }
+    const char *out_path = nullptr;
+    int udp_port = 0, need_plp = 0, buf_len = 1 << 18, device = 0;
+    for (int a = 3; a + 1 < argc; a += 2) {
+        if (!std::strcmp(argv[a], "--out")) out_path = argv[a + 1];
+        else if (!std::strcmp(argv[a], "--udp")) udp_port = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--plp")) need_plp = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--buf")) buf_len = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--device")) device = std::atoi(argv[a + 1]);
+    }
+    if ((!out_path && !udp_port) || buf_len < 4096) return 2;
+    const std::vector<int16_t> vi = slurp(argv[1]), vq = slurp(argv[2]);
+
+    std::FILE *file = out_path ? std::fopen(out_path, "wb") : nullptr;
+    int sock = -1;
+    sockaddr_in to{};
+    if (udp_port) {
+        sock = socket(AF_INET, SOCK_DGRAM, 0);
+        to.sin_family = AF_INET; to.sin_port = htons((uint16_t)udp_port); to.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    }
+    try {
+        t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f, device);
+        t2::llr_demapper qam(device);
+        t2::ldpc_decoder ldpc(device);
+        t2::bch_decoder bch;
+        t2::bb_de_header deheader(need_plp);
+        long bbframes = 0, ts_bytes = 0;
+        demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
+        qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+        ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
+        bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; deheader.execute(plp_id, p, len, bits); };
+        deheader.write_out = [&](const uint8_t *b, int n) {
+            ts_bytes += n;
+            if (file) std::fwrite(b, 1, (size_t)n, file);
+            if (sock >= 0) sendto(sock, b, (size_t)n, 0, reinterpret_cast<const sockaddr *>(&to), sizeof to);
+        };
+        demodulator.amount_plp = [&](int n) { std::fprintf(stderr, "PLPs: %d\n", n); };
+
+        t2::signal_estimate signal;
+        double rf_frequency = 0, tuner_hz = 0;
+        const double ch_frequency = 626.0e6;
+        bool frequency_changed = true, gain_changed = true;
+        auto set_rf_frequency = [&]() {                                   // rx_sdrplay.cpp:158-176
+            if (!signal.frequency_changed) signal.frequency_changed = frequency_changed;
+            if (signal.change_frequency) {
+                signal.change_frequency = false;
+                frequency_changed = false;
+                signal.frequency_changed = false;
+                signal.correct_resample = signal.coarse_freq_offset / rf_frequency;
+                rf_frequency += signal.coarse_freq_offset;
+                tuner_hz += signal.coarse_freq_offset;
+                demodulator.set_tuner(tuner_hz);
+                std::fprintf(stderr, "re-tune: %+.1f Hz (total %+.1f)\n", signal.coarse_freq_offset, tuner_hz);
+            }
+        };
+        auto set_gain = [&]() { if (!signal.gain_changed) signal.gain_changed = gain_changed; };     // :178-197, agc off
+        auto reset = [&]() {                                              // :135-156
+            signal.reset = false;
+            rf_frequency = ch_frequency;
+            tuner_hz = 0;
+            demodulator.set_tuner(0.0);
+            signal.coarse_freq_offset = 0.0;
+            signal.change_frequency = true;
+            signal.correct_resample = 0.0;
+            signal.gain_offset = 0;
+            signal.change_gain = true;
+            set_rf_frequency();
+            set_gain();
+        };
+        reset();
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t pos = 0;
+        for (; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len) {
+            frequency_changed = true;                                     // what rf_changed / gr_changed report with the next packets (:216-223)
+            gain_changed = true;
+            if (signal.reset) { reset(); continue; }                      // :229-235
+            set_rf_frequency();
+            set_gain();
+            demodulator.execute(buf_len, const_cast<int16_t *>(vi.data()) + pos, const_cast<int16_t *>(vq.data()) + pos, &signal);
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const t2gpu_demod_info st = demodulator.status();
+        std::fprintf(stderr, "%zu samples in %.3f s (%.1f Msamples/s, real time 9.14), %ld symbols, %ld T2 frames, %ld BBFRAMEs, %ld TS bytes\n",
+                     pos, secs, pos / secs / 1e6, (long)st.symbols, (long)st.frames, bbframes, ts_bytes);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "t2gpu_rx_file: %s\n", e.what());
+        return 1;
+    }
+    if (file) std::fclose(file);
+    if (sock >= 0) close(sock);
+    return 0;
+}

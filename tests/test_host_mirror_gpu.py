@@ -220,3 +220,53 @@ def test_demodulator_class_resets_and_recovers(driver, tmp_path):
     found = [f for f in range(n_frames) if got.find(marks[f]) >= 0]
     assert any(f < spoil for f in found) and any(f > spoil + 1 for f in found), (found, log)
     assert spoil not in found, found
+
+
+def test_example_rx_file_program(driver, tmp_path):
+    """examples/t2gpu_rx_file.cpp -- the Qt-free source + sink around the accelerated path -- writes the same
+    transport stream to a file as the test driver collects, and the same bytes as UDP datagrams (one per BBFRAME, as the
+    reference's bb_de_header sends them) to a local port."""
+    import socket
+    import threading
+    exe = str(tmp_path / "t2gpu_rx_file")
+    pkg = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "t2gpu_rx_file.cpp"), "-L" + pkg, "-lt2gpu", "-Wl,-rpath," + pkg, "-o", exe])
+    m, buf, marks = _unconfigured_stream(tmp_path, 10, 391, 0.0)
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "ref.ts", buf, 0, tmp_path / "log.txt")
+    want = np.fromfile(tmp_path / "ref.ts", np.uint8).tobytes()
+    assert len(want) > 100000
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    subprocess.run([exe, str(tmp_path / "i.s16"), str(tmp_path / "q.s16"), "--out", str(tmp_path / "out.ts"), "--buf", str(buf)],
+                   check=True, env=env, timeout=300, stderr=subprocess.PIPE)
+    assert np.fromfile(tmp_path / "out.ts", np.uint8).tobytes() == want
+    # UDP sink: collect the datagrams on a local port
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 24)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(2.0)
+    port = rx.getsockname()[1]
+    got = []
+
+    def collect():
+        try:
+            while True:
+                got.append(rx.recv(65536))
+        except socket.timeout:
+            pass
+
+    t = threading.Thread(target=collect)
+    t.start()
+    subprocess.run([exe, str(tmp_path / "i.s16"), str(tmp_path / "q.s16"), "--udp", str(port), "--buf", str(buf)],
+                   check=True, env=env, timeout=300, stderr=subprocess.PIPE)
+    t.join()
+    rx.close()
+    joined = b"".join(got)
+    # localhost UDP can drop under load: what arrived must be whole BBFRAME payloads of the stream, in order
+    assert len(got) > 10 and len(joined) > len(want) // 2
+    pos = 0
+    for d in got:
+        at = want.find(d, pos)
+        assert at >= 0
+        pos = at + len(d)
