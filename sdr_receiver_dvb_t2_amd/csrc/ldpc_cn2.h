@@ -248,6 +248,47 @@ __device__ __forceinline__ void pl_phase_a(LMEM &L, const LayerDesc &d, int j, i
     }
 }
 
+// PAIR phase B for long chains: the walk cut into segments. A node whose other slots leave no room (cap = f(E) = 0: its smallest
+// other magnitude is 0 or 1) hands down sat(in0) whatever it receives -- the recurrence forgets its past there. Every such node
+// and every chain start walks its own segment up to the next such node; the results are those of the single walk, the length
+// is that of the longest segment instead of the chain (N 3/4 has a layer with two chains of 180 nodes: two thirds of all chain
+// steps of a sweep, walked by two lanes). Data dependent: with confident LLRs there are no such nodes and nothing changes.
+// `node` = 0..359, one lane each; nodes without a successor (>= 360 - step) are not walked, as in t2_pair_walk.
+template <class LMEM>
+__device__ __forceinline__ void pl_pair_walk_segments(LMEM &L, const LayerDesc &d, int node, const uint32_t *pair_rec)
+{
+    const uint32_t e0 = d.e0;
+    const int base = (int)(e0 & 0xffffu) + L.off(), s0 = (int)(e0 >> 16), step = d.step;
+    const int last = 360 - step;                          // nodes below `last` have a successor
+    int m = node - s0;                                    // position of the node's slot-0 bit inside its 360-bit group
+    m += (m < 0) ? 360 : 0;
+    bool go = false;
+    int X = 0;
+    if (node < step) {                                    // chain start: its bit was finished in phase A
+        go = true;
+        X = (int)L.ld(base + m);
+    } else if (node < last) {
+        const PairRec r = t2_pair_unpack(pair_rec[node]);
+        if (r.cap == 0) {                                 // segment head: output independent of the input
+            go = true;
+            X = r.in0;
+            L.st(base + m, (int8_t)X);
+        }
+    }
+    int jj = node + step;
+    uint32_t nxt = (go && jj < last) ? pair_rec[jj] : 0u;
+    while (go && jj < last) {
+        const PairRec r = t2_pair_unpack(nxt);
+        if (r.cap == 0) break;                            // the next node heads a segment of its own
+        jj += step;
+        nxt = pair_rec[jj < 359 ? jj : 359];
+        const unsigned t = (unsigned)(m + step);
+        m = (int)(t < t - 360u ? t : t - 360u);           // (m + step) mod 360
+        X = t2_pair_step(r, X);
+        L.st(base + m, (int8_t)X);
+    }
+}
+
 // t2_pair_finish
 template <int CNT, class LMEM>
 __device__ __forceinline__ void pl_pair_finish(LMEM &L, const LayerDesc &d, int j, CnState &st, PlRegs<CNT> &r)

@@ -176,7 +176,14 @@ __device__ __forceinline__ void layer_update(LdsMem &L, const LayerDesc &d, int 
         lds_barrier();
         T2_DTL(1, 3);
         __builtin_amdgcn_s_setprio(3);
-        if ((int)threadIdx.x < d.step) t2_pair_walk(L, d, (int)threadIdx.x, pair_rec);   // any lane can walk any chain: the first `step` threads do
+#ifndef T2_SEG_WALK_MIN
+#define T2_SEG_WALK_MIN 12         // chains at least this long are walked in segments (ldpc_cn2.h)
+#endif
+        if (d.lmax >= T2_SEG_WALK_MIN) {
+            if ((int)threadIdx.x < 360) pl_pair_walk_segments(L, d, (int)threadIdx.x, pair_rec);
+        } else if ((int)threadIdx.x < d.step) {
+            t2_pair_walk(L, d, (int)threadIdx.x, pair_rec);   // any lane can walk any chain: the first `step` threads do
+        }
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();
         T2_DTL(1, 4);
