@@ -38,6 +38,9 @@ struct t2gpu_front {
     int16_t *d_i = nullptr, *d_q = nullptr;
     float2 *d_out = nullptr;
     std::vector<FrontRun> nco_runs, far_runs;
+    std::vector<FrontRun> dev_runs;            // what d_runs holds (nco runs, then Farrow runs)
+    size_t dev_nn = 0;
+    bool dev_runs_valid = false;
 };
 
 namespace {
@@ -50,7 +53,7 @@ bool ensure_runs(t2gpu_front *h, size_t need)
     hipDeviceSynchronize();
     if (h->d_runs) hipFree(h->d_runs);
     if (h->h_runs) hipHostFree(h->h_runs);
-    h->d_runs = nullptr; h->h_runs = nullptr; h->run_cap = 0;
+    h->d_runs = nullptr; h->h_runs = nullptr; h->run_cap = 0; h->dev_runs_valid = false;
     if (hipMalloc(&h->d_runs, cap * sizeof(FrontRun)) != hipSuccess || hipHostMalloc(&h->h_runs, cap * sizeof(FrontRun)) != hipSuccess) {
         set_error("t2gpu_front: cannot allocate the run tables");
         return false;
@@ -96,13 +99,21 @@ int stage_tables(t2gpu_front *h, int n, hipStream_t stream, FrontParams &p)
     const size_t groups = (size_t)(n + FRONT_RUN_STRIDE - 1) / FRONT_RUN_STRIDE;
     if (!ensure_runs(h, nn + nf + 2)) return -1;
     if (2 * groups + 2 > h->index_cap) { set_error("t2gpu_front: internal index capacity"); return -1; }
-    if (h->staged_pending) { T2_HIP(hipEventSynchronize(h->staged)); h->staged_pending = false; }
-    if (nn) std::memcpy(h->h_runs, h->nco_runs.data(), nn * sizeof(FrontRun));
-    if (nf) std::memcpy(h->h_runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
-    if (nn + nf) T2_HIP(hipMemcpyAsync(h->d_runs, h->h_runs, (nn + nf) * sizeof(FrontRun), hipMemcpyHostToDevice, stream));   // the kernels
-    // find a sample's run by binary search: no per-block index to build and ship
-    T2_HIP(hipEventRecord(h->staged, stream));
-    h->staged_pending = true;
+    // A source that stands still (loops open, nominal resample) plans the same runs call after call: the table on the device is
+    // then already the right one and nothing is shipped. (The kernels find a sample's run by binary search: no per-block index.)
+    const bool same = h->dev_runs_valid && h->dev_nn == nn && h->dev_runs.size() == nn + nf &&
+                      (!nn || !std::memcmp(h->dev_runs.data(), h->nco_runs.data(), nn * sizeof(FrontRun))) &&
+                      (!nf || !std::memcmp(h->dev_runs.data() + nn, h->far_runs.data(), nf * sizeof(FrontRun)));
+    if (!same) {
+        if (h->staged_pending) { T2_HIP(hipEventSynchronize(h->staged)); h->staged_pending = false; }
+        if (nn) std::memcpy(h->h_runs, h->nco_runs.data(), nn * sizeof(FrontRun));
+        if (nf) std::memcpy(h->h_runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
+        if (nn + nf) T2_HIP(hipMemcpyAsync(h->d_runs, h->h_runs, (nn + nf) * sizeof(FrontRun), hipMemcpyHostToDevice, stream));
+        T2_HIP(hipEventRecord(h->staged, stream));
+        h->staged_pending = true;
+        h->dev_runs.assign(h->h_runs, h->h_runs + nn + nf);
+        h->dev_nn = nn; h->dev_runs_valid = true;
+    }
     p.nco_runs = h->d_runs; p.n_nco_runs = (int)nn; p.nco_index = nullptr;
     p.far_runs = h->d_runs + nn; p.n_far_runs = (int)nf; p.far_index = nullptr;
     (void)groups;
