@@ -89,25 +89,75 @@ __device__ __forceinline__ uint32_t sign_window(const uint32_t *S2, int g, int m
     return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)(m & 31));
 }
 
+// one 32-bit sign word (bits 32*kk .. 32*kk+31 of group g) from the LLR bytes; *zero collects "some LLR is exactly 0"
+__device__ __forceinline__ uint32_t sign_word(const int8_t *Lm, int g, int kk, uint32_t *zero)
+{
+    const uint2 *src = reinterpret_cast<const uint2 *>(Lm + g * 360 + 32 * kk);
+    const int nb = (kk == 11) ? 1 : 4;          // dword 11 holds only bits 352..359
+    uint32_t word = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+        if (x < nb) {
+            uint2 v = src[x];
+            *zero |= has_zero_byte(v.x) | has_zero_byte(v.y);
+            word |= (sign_nibble(v.x) | (sign_nibble(v.y) << 4)) << (8 * x);
+        }
+    return word;
+}
+
+// 32 checks of layer i (nodes 32*tj ..) as one XOR of sign windows; nonzero bits = failing checks
+__device__ __forceinline__ uint32_t layer_syndrome(const uint32_t *S2, const LdpcLayerDev &ly, const uint32_t *__restrict__ ent, int gp0, int q,
+                                                   int i, int tj)
+{
+    const int j0 = 32 * tj;
+    uint32_t syn = S2[(gp0 + i) * 13 + tj];                                   // own parity bits pty[360*i + j]
+    if (i > 0) syn ^= S2[(gp0 + i - 1) * 13 + tj];                            // pty[360*(i-1) + j]
+    else syn ^= (tj == 0) ? (S2[(gp0 + q - 1) * 13] << 1)                     // pty[360*(q-1) + j - 1], none for j = 0
+                          : sign_window(S2, gp0 + q - 1, j0 - 1);
+    for (int c = 0; c < ly.cnt; ++c) {
+        const uint32_t e = ent[c];
+        const int g = (int)__umulhi(e & 0xffffu, 11930465u);                 // base / 360 (base is a multiple of 360)
+        int m = j0 - (int)(e >> 16);
+        m += (m < 0) ? 360 : 0;
+        syn ^= sign_window(S2, g, m);
+    }
+    return syn & ((tj == 11) ? 0xffu : 0xffffffffu);
+}
+
 // returns nonzero (per thread) if this thread saw a zero LLR or a failing check
 __device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, const LdpcLayerDev *__restrict__ layers,
                                                 const uint32_t *__restrict__ entries, int n, int k, int q, int tid)
 {
     const int ngroups = n / 360;
+    const int gp0 = k / 360;
     uint32_t zero = 0;
+    // Probe: a frame that has not converged almost always fails already among the 360 checks of one layer, and those need the sign
+    // words of ~14 of the 180 groups only. Layer 1 is taken (its two parity groups are ordinary ones). If it fails the frame is
+    // bad -- the answer the full check would give; only when it passes is the full check run.
+    if (q > 1) {
+        const LdpcLayerDev ly = layers[1];
+        const uint32_t *ent = entries + ly.first_entry;
+        const int ng = ly.cnt + 2;
+        if (tid < ng * 12) {
+            const int gi = tid / 12, kk = tid - gi * 12;
+            const int g = gi < ly.cnt ? (int)__umulhi(ent[gi] & 0xffffu, 11930465u) : gp0 + (gi - ly.cnt);
+            S2[g * 13 + kk] = sign_word(Lm, g, kk, &zero);
+        }
+        lds_barrier();
+        if (tid < ng) {
+            const int g = tid < ly.cnt ? (int)__umulhi(ent[tid] & 0xffffu, 11930465u) : gp0 + (tid - ly.cnt);
+            const uint32_t d0 = S2[g * 13], d1 = S2[g * 13 + 1];
+            S2[g * 13 + 11] = (S2[g * 13 + 11] & 0xffu) | (d0 << 8);         // two entries may name the same group: idempotent
+            S2[g * 13 + 12] = (d0 >> 24) | (d1 << 8);
+        }
+        lds_barrier();
+        uint32_t bad = zero;
+        if (tid < 12) bad |= layer_syndrome(S2, ly, ent, gp0, q, 1, tid);
+        if (__syncthreads_or(bad != 0)) return 1;
+    }
     for (int task = tid; task < ngroups * 12; task += kThreads) {
         const int g = task / 12, kk = task - g * 12;
-        const uint2 *src = reinterpret_cast<const uint2 *>(Lm + g * 360 + 32 * kk);
-        const int nb = (kk == 11) ? 1 : 4;          // dword 11 holds only bits 352..359
-        uint32_t word = 0;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (x < nb) {
-                uint2 v = src[x];
-                zero |= has_zero_byte(v.x) | has_zero_byte(v.y);
-                word |= (sign_nibble(v.x) | (sign_nibble(v.y) << 4)) << (8 * x);
-            }
-        S2[g * 13 + kk] = word;
+        S2[g * 13 + kk] = sign_word(Lm, g, kk, &zero);
     }
     lds_barrier();
     for (int g = tid; g < ngroups; g += kThreads) {
@@ -117,23 +167,10 @@ __device__ __forceinline__ int frame_parity_bad(const int8_t *Lm, uint32_t *S2, 
     }
     lds_barrier();
     uint32_t bad = zero;
-    const int gp0 = k / 360;
     for (int task = tid; task < q * 12; task += kThreads) {
-        const int i = task / 12, tj = task - i * 12, j0 = 32 * tj;
+        const int i = task / 12, tj = task - i * 12;
         const LdpcLayerDev ly = layers[i];
-        const uint32_t *ent = entries + ly.first_entry;
-        uint32_t syn = S2[(gp0 + i) * 13 + tj];                                   // own parity bits pty[360*i + j]
-        if (i > 0) syn ^= S2[(gp0 + i - 1) * 13 + tj];                            // pty[360*(i-1) + j]
-        else syn ^= (tj == 0) ? (S2[(gp0 + q - 1) * 13] << 1)                     // pty[360*(q-1) + j - 1], none for j = 0
-                              : sign_window(S2, gp0 + q - 1, j0 - 1);
-        for (int c = 0; c < ly.cnt; ++c) {
-            const uint32_t e = ent[c];
-            const int g = (int)__umulhi(e & 0xffffu, 11930465u);                 // base / 360 (base is a multiple of 360)
-            int m = j0 - (int)(e >> 16);
-            m += (m < 0) ? 360 : 0;
-            syn ^= sign_window(S2, g, m);
-        }
-        bad |= syn & ((tj == 11) ? 0xffu : 0xffffffffu);
+        bad |= layer_syndrome(S2, ly, entries + ly.first_entry, gp0, q, i, tj);
     }
     return bad != 0;
 }
