@@ -30,7 +30,7 @@ LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600    # LLR in + one-bit-p
 # memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/r01_rx_pmc.txt, tools/pmc_passes.sh: this
 # bench's launch of 3232 frames x 25 sweeps): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE,
 # KiB -> bytes
-LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 6.049e6 + 1.0811e7) * 1024 / 3232 / 25
+LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 6.078e6 + 1.0823e7) * 1024 / 3232 / 25
 MODE = (5, 1, 6, 4, 0, 59)                  # FFTSIZE_32K, extended, PP7, GI 1/128, no PAPR, 59 data symbols
 L1_POST_SIZE = 350
 PLP = (3, 1, 3, 1)                          # 256-QAM, normal FEC frame, r = 3/4, rotated
