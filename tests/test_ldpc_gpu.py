@@ -154,3 +154,26 @@ def test_parity_check_sees_every_single_bit_error(torch_cuda):
     _, trials, lo = _run(torch_cuda, cid, llr, group=1, trials=0)
     assert trials[-1] == 0 and (trials[:-1] == -1).all()
     assert np.array_equal(lo, llr)
+
+
+def test_noisy_full_grid_is_exact_and_repeatable(torch_cuda):
+    """Noise-like LLRs (nothing converges: every sweep runs, chains are walked in segments, the parity check stops at its probe) on
+    a grid larger than the resident one: the same launch twice gives the same LLRs bit for bit, and a sample of the SIMD batches
+    equals the oracle's LLRs after all 25 sweeps."""
+    cid = 9
+    n, k, _, _ = ol.ldpc_params(cid)
+    rng = np.random.Generator(np.random.PCG64(77))
+    base = rng.integers(-127, 128, size=(96, n), dtype=np.int8)
+    base[rng.random(base.shape) < 0.35] >>= 3                              # a third of the LLRs small: many nodes with min 0 / 1
+    frames = 32 * 40                                                       # 1280 frames > 512 resident workgroups
+    llr = np.ascontiguousarray(np.tile(base, (frames // 96 + 1, 1))[:frames])
+    for f in range(frames):                                                # make every frame different
+        llr[f, (f * 131) % n] ^= 0x15
+    bits1, trials1, lo1 = _run(torch_cuda, cid, llr, group=32)
+    bits2, trials2, lo2 = _run(torch_cuda, cid, llr, group=32)
+    assert (trials1 < 0).all()
+    assert np.array_equal(trials1, trials2) and np.array_equal(lo1, lo2) and np.array_equal(bits1, bits2)
+    for b in (0, 17, 39):
+        t, wb, wl = ol.ora_decode(cid, llr[32 * b:32 * b + 32])
+        assert t < 0
+        assert np.array_equal(lo1[32 * b:32 * b + 32], wl)
