@@ -139,6 +139,19 @@ int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_strid
 int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
 int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
 
+/* Outer code applied for real (NOT what the reference does: bch_decoder.cpp:136 is "// TODO BCH decode", so a
+ * drop-in caller goes straight to t2gpu_bch_descramble). The code of EN 302 755 clause 6.1.1 for the (k_bch, n_bch) pairs of
+ * bch_decoder.cpp:79-134: t = 12 over GF(2^16) (t = 10 for r = 2/3 and 5/6) on 64 800-bit frames, t = 12 over GF(2^14) on 16 200-bit ones.
+ * bits: [n_frames][n_bch = k_ldpc] one bit per byte as the LDPC stage leaves them (8-byte aligned), corrected IN PLACE;
+ * status[f] = number of bits corrected (0 = the frame was a codeword), -1 = more than t errors, frame left untouched.
+ * Return n_frames. t2gpu_bch_info: field degree m, t, k_bch, n_bch of a code (any pointer may be NULL). */
+int t2gpu_bch_info(int fec_type, int code_rate, int *m, int *t, int *k_bch, int *n_bch);
+/* host only: the minimal polynomials of alpha, alpha^3, ..., alpha^(2t-1) over GF(2^m) whose product is the generator (bit k =
+ * coefficient of x^k; EN 302 755 tables 6a / 6b list the same polynomials). Returns t. */
+int t2gpu_table_bch_minpoly(int m, int t, uint32_t *out);
+int t2gpu_bch_decode_dev(int fec_type, int code_rate, uint8_t *d_bits, int n_frames, int32_t *d_status, void *stream);
+int t2gpu_bch_decode(int fec_type, int code_rate, uint8_t *bits, int n_frames, int32_t *status);
+
 /* ---------------------------------------------------------------- L1 signalling from the P2 cells (host) ------------
  * Replaces  bool p2_symbol::l1_pre_info(dvbt2_parameters&)  (src/DVB_T2/p2_symbol.cpp:301-532) and
  * bool p2_symbol::l1_post_info()  with its field parsers (:534-1089). Input: the equalised, frequency-de-interleaved cells
@@ -482,6 +495,11 @@ int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, in
                          uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
 int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect, float *ldpc_ms);
 int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials);
+/* opt-in (off by default = the reference's behaviour, bch_decoder.cpp:136): run t2gpu_bch_decode_dev on the LDPC output of every
+ * back half before the descrambler; t2gpu_rx_outer_code_status (synchronises) copies the per-FEC-frame status of the last back
+ * half (bits corrected, -1 = more than t errors; frames of batches the LDPC stage dropped carry whatever the decoder left). */
+int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable);
+int t2gpu_rx_outer_code_status(t2gpu_rx *h, int n_fec_frames, int32_t *status);
 
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):

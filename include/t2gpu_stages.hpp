@@ -83,11 +83,19 @@ public:
     std::function<void(int plp_id, const l1_postsignalling &l1_post, int len_out, uint8_t *out)> bit_descramble;   // bch_decoder.h:35
     // slot (bch_decoder.h:41, bch_decoder.cpp:63-164): strips the BCH parity (the reference corrects nothing) and descrambles;
     // one bit_descramble per FEC frame
+    // not in the reference (its decoder is a TODO, bch_decoder.cpp:136): when set, execute applies the outer code to `in` first and
+    // outer_code_status holds, per FEC frame of the last call, the bits corrected or -1 (more than t errors, frame untouched)
+    bool outer_code = false;
+    std::vector<int32_t> outer_code_status;
     void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, uint8_t *in)
     {
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
         const int k_ldpc = ldpc_k(p.plp_fec_type, p.plp_cod), frames = len_in / k_ldpc;
         out_.resize((size_t)len_in);
+        if (outer_code) {
+            outer_code_status.assign((size_t)frames, 0);
+            if (t2gpu_bch_decode(p.plp_fec_type, p.plp_cod, in, frames, outer_code_status.data()) != frames) fail("t2gpu_bch_decode");
+        }
         const int k_bch = t2gpu_bch_descramble(p.plp_fec_type, p.plp_cod, in, frames, out_.data());
         if (k_bch < 0) fail("t2gpu_bch_descramble");
         for (int n = 0; n < frames; ++n)

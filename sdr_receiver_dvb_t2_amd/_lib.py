@@ -51,6 +51,10 @@ PROTOTYPES = {
     "t2gpu_ti_execute_blocks_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_long, _vp, ctypes.c_long, ctypes.c_int, _vp]),
     "t2gpu_bch_descramble_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_bch_descramble": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "t2gpu_bch_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "t2gpu_table_bch_minpoly": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
+    "t2gpu_bch_decode_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_bch_decode": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "t2gpu_l1_pre_parse": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_l1_post_parse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "t2gpu_front_reset_loops": (ctypes.c_int, [_vp]),
@@ -76,6 +80,8 @@ PROTOTYPES = {
     "t2gpu_rx_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_rx_results": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "t2gpu_rx_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_rx_set_outer_code": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_rx_outer_code_status": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "t2gpu_ti_frame_plan": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     "t2gpu_bbdh_create": (_vp, [ctypes.c_int]),
     "t2gpu_bbdh_destroy": (None, [_vp]),

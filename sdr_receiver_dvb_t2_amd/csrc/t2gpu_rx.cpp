@@ -38,7 +38,8 @@ struct t2gpu_rx {
           *d_ti_out = nullptr, *d_sums = nullptr, *d_cp = nullptr;
     int8_t *d_llr = nullptr;
     uint8_t *d_bits = nullptr, *d_out = nullptr;
-    int32_t *d_trials = nullptr;
+    int32_t *d_trials = nullptr, *d_outer = nullptr;
+    bool outer_code = false;
     hipEvent_t ev_ldpc0 = nullptr, ev_ldpc1 = nullptr;
     bool timed = false;
     std::vector<t2gpu_p1_result> p1_res;
@@ -56,7 +57,7 @@ void free_all(t2gpu_rx *h)
     if (h->demap) t2gpu_demap_destroy(h->demap);
     if (h->ldpc) t2gpu_ldpc_destroy(h->ldpc);
     hipFree(h->d_stream); hipFree(h->d_spec); hipFree(h->d_p2_in); hipFree(h->d_p2_cells); hipFree(h->d_fc_cells); hipFree(h->d_cells);
-    hipFree(h->d_ti_out); hipFree(h->d_sums); hipFree(h->d_cp); hipFree(h->d_llr); hipFree(h->d_bits); hipFree(h->d_out); hipFree(h->d_trials);
+    hipFree(h->d_ti_out); hipFree(h->d_sums); hipFree(h->d_cp); hipFree(h->d_llr); hipFree(h->d_bits); hipFree(h->d_out); hipFree(h->d_trials); hipFree(h->d_outer);
     if (h->ev_ldpc0) hipEventDestroy(h->ev_ldpc0);
     if (h->ev_ldpc1) hipEventDestroy(h->ev_ldpc1);
 }
@@ -206,6 +207,7 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out
     if (t2gpu_ldpc_execute_dev(h->ldpc, h->d_llr, count, h->d_bits, nullptr, h->d_trials, s) != 0) return -1;
     T2_HIP(hipEventRecord(h->ev_ldpc1, s));
     h->timed = true;
+    if (h->outer_code && t2gpu_bch_decode_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_outer, s) < 0) return -1;
     if (t2gpu_bch_descramble_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_out, s) < 0) return -1;
     if (d_bits_out) *d_bits_out = h->d_out;
     if (d_trials_out) *d_trials_out = h->d_trials;
@@ -244,6 +246,27 @@ extern "C" int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, 
     }
     if (n_frames == 0) return 0;                           // a pure timing query: no read-back of the decoder's status word
     return t2gpu_ldpc_status(h->ldpc) == 0 ? 0 : -1;
+}
+
+extern "C" int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable)
+{
+    if (!h) { set_error("t2gpu_rx_set_outer_code: null handle"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (enable && !h->d_outer) T2_HIP(hipMalloc(&h->d_outer, ((size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + 64) * sizeof(int32_t)));
+    h->outer_code = enable != 0;
+    return 0;
+}
+
+extern "C" int t2gpu_rx_outer_code_status(t2gpu_rx *h, int n_fec_frames, int32_t *status)
+{
+    if (!h || !status || n_fec_frames < 0 || n_fec_frames > h->cfg.max_frames * h->cfg.plp_num_blocks || !h->outer_code) {
+        set_error("t2gpu_rx_outer_code_status: bad arguments, or the outer code is not enabled on this handle");
+        return -1;
+    }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipDeviceSynchronize());
+    if (n_fec_frames) T2_HIP(hipMemcpy(status, h->d_outer, (size_t)n_fec_frames * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return n_fec_frames;
 }
 
 extern "C" int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials)

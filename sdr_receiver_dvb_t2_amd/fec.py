@@ -204,6 +204,27 @@ class bch_decoder(object):
             check(rc, "t2gpu_bch_descramble_dev")
         return out
 
+    def correct_dev(self, bits):
+        """Apply the outer code in place on [n_frames][k_ldpc] device bits (opt-in: the reference does not, bch_decoder.cpp:136).
+        Returns an int32 device tensor: bits corrected per frame, -1 = more than t errors (frame untouched)."""
+        import torch
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.dim() == 2
+        status = torch.empty(bits.shape[0], dtype=torch.int32, device=bits.device)
+        stream = torch.cuda.current_stream(bits.device).cuda_stream
+        rc = self._l.t2gpu_bch_decode_dev(self.fec_type, self.cod, bits.data_ptr(), bits.shape[0], status.data_ptr(), stream)
+        if rc < 0:
+            check(rc, "t2gpu_bch_decode_dev")
+        return status
+
+    def correct(self, words):
+        """Host form of correct_dev: returns (corrected copy of [n_frames][k_ldpc] bits, status)."""
+        out = np.ascontiguousarray(words, dtype=np.uint8).copy()
+        status = np.empty(out.shape[0], dtype=np.int32)
+        rc = self._l.t2gpu_bch_decode(self.fec_type, self.cod, out.ctypes.data, out.shape[0], status.ctypes.data)
+        if rc < 0:
+            check(rc, "t2gpu_bch_decode")
+        return out, status
+
     def execute(self, len_in, _in):
         bits = np.ascontiguousarray(_in, dtype=np.uint8).reshape(-1)[:len_in]
         k_ldpc = {0: (7200, 9720, 10800, 11880, 12600, 13320), 1: (32400, 38880, 43200, 48600, 51840, 54000)}[self.fec_type][self.cod]

@@ -239,6 +239,15 @@ class t2_rx(object):
         self._check(self._l.t2gpu_rx_fetch(self._h, count, bits.ctypes.data, trials.ctypes.data), "t2gpu_rx_fetch")
         return bits, trials
 
+    def set_outer_code(self, enable=True):
+        """Opt-in BCH check / correction of the LDPC output before the descrambler (the reference does none, bch_decoder.cpp:136)."""
+        self._check(self._l.t2gpu_rx_set_outer_code(self._h, int(enable)), "t2gpu_rx_set_outer_code")
+
+    def outer_code_status(self, count):
+        st = np.empty((count,), np.int32)
+        self._check(self._l.t2gpu_rx_outer_code_status(self._h, count, st.ctypes.data), "t2gpu_rx_outer_code_status")
+        return st
+
     def last_ldpc_ms(self):
         """Duration of the last LDPC launch (HIP events on the stream it ran on); waits for it."""
         ms = ctypes.c_float(0)

@@ -62,9 +62,13 @@ int main(int argc, char **argv)
             l1.plp[0].plp_fec_type = fec_type; l1.plp[0].plp_cod = cod;
             t2::ldpc_decoder ldpc;
             t2::bch_decoder bch;
+            bch.outer_code = argc > 6 && std::string(argv[6]) == "outer";       // the library's opt-in BCH correction in front
             std::vector<uint8_t> out;
             // the reference's connect() chain: ldpc.bit_bch -> bch.execute, bch.bit_descramble -> (here) collect
-            ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
+            ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) {
+                bch.execute(idx, p, len, bits);
+                for (int32_t st : bch.outer_code_status) std::fprintf(stderr, "outer %d\n", st);
+            };
             bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &, int len, uint8_t *bits) {
                 out.push_back((uint8_t)plp_id);
                 out.insert(out.end(), bits, bits + len);

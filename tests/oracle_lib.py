@@ -71,12 +71,13 @@ def ldpc_encode(cid, info):
     return cw
 
 
-def make_llr(cid, frames, sigma, seed, scale=8.0):
-    """Random codewords through a BPSK/AWGN channel, quantised to the int8 LLR format the demapper produces
-    (positive = bit 0). Returns (info bits, int8 LLRs)."""
+def make_llr(cid, frames, sigma, seed, scale=8.0, info=None):
+    """Random codewords (or the codewords of the given information bits) through a BPSK/AWGN channel, quantised to the int8 LLR
+    format the demapper produces (positive = bit 0). Returns (info bits, int8 LLRs)."""
     n, k, _, _ = ldpc_params(cid)
     rng = np.random.Generator(np.random.PCG64(seed))
-    info = rng.integers(0, 2, size=(frames, k), dtype=np.uint8)
+    rnd = rng.integers(0, 2, size=(frames, k), dtype=np.uint8)
+    info = rnd if info is None else np.ascontiguousarray(info, dtype=np.uint8)
     cw = ldpc_encode(cid, info)
     y = (1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.shape)
     llr = np.clip(np.rint(y * scale), -127, 127).astype(np.int8)
@@ -147,6 +148,46 @@ def ora_bch_descramble(cid, bits):
     out = np.zeros((bits.shape[0], kb), np.uint8)
     assert oracle().ora_bch_descramble(cid, bits.ctypes.data_as(_u8p), bits.shape[0], out.ctypes.data_as(_u8p)) == kb
     return out
+
+
+def bch_params(cid):
+    """(m, t, k_bch, n_bch) of LDPC code cid: parity bits = n_bch - k_bch = m * t (bch_decoder.cpp:79-134 holds the pairs)."""
+    _, k, _, _ = ldpc_params(cid)
+    kb = [7032, 9552, 10632, 11712, 12432, 13152, 32208, 38688, 43040, 48408, 51648, 53840][cid]
+    m = 14 if cid < 6 else 16
+    return m, (k - kb) // m, kb, k
+
+
+def ora_bch_minpoly(m, j):
+    o = oracle()
+    o.ora_bch_minpoly.restype = ctypes.c_uint32
+    return int(o.ora_bch_minpoly(m, j))
+
+
+def ora_bch_generator(m, t):
+    g = np.zeros(m * t + 1, np.uint8)
+    deg = oracle().ora_bch_generator(m, t, g.ctypes.data_as(_u8p))
+    return g[:deg + 1]
+
+
+def ora_bch_encode(cid, msg):
+    """[f][k_bch] -> [f][n_bch] systematic codewords (bitwise LFSR)."""
+    m, t, kb, nb = bch_params(cid)
+    out = np.zeros((msg.shape[0], nb), np.uint8)
+    out[:, :kb] = msg
+    for row in out:
+        assert oracle().ora_bch_encode(m, t, row.ctypes.data_as(_u8p), kb, nb) == 0
+    return out
+
+
+def ora_bch_decode(cid, words):
+    """[f][n_bch] received words -> (corrected copy, status per frame: corrected bits, or -1 = more than t errors)."""
+    m, t, _, nb = bch_params(cid)
+    out = np.ascontiguousarray(words, dtype=np.uint8).copy()
+    st = np.zeros(out.shape[0], np.int32)
+    for i, row in enumerate(out):
+        st[i] = oracle().ora_bch_decode(m, t, row.ctypes.data_as(_u8p), nb)
+    return out, st
 
 
 def ora_bitdeint_address(mod, fec_type, code_rate):

@@ -55,11 +55,91 @@ def scramble(frames):
     return frames ^ prbs[None, :]
 
 
-def fec_encode(cid, bbframes):
-    """BBFRAME bits [f][k_bch] -> LDPC codewords [f][n] in transmitted order; the BCH parity field stays zero."""
+# ---- outer code (EN 302 755 clause 6.1.1), polynomials over GF(2) held in Python integers (bit k = coefficient of x^k) ----
+def _pmod(a, p):
+    dp = p.bit_length() - 1
+    while a.bit_length() - 1 >= dp:
+        a ^= p << (a.bit_length() - 1 - dp)
+    return a
+
+
+def _pmulmod(a, b, p):
+    r = 0
+    while b:
+        if b & 1:
+            r ^= a
+        b >>= 1
+        a = _pmod(a << 1, p)
+    return r
+
+
+def bch_generator(cid):
+    """g(x) of LDPC code cid (0-5 short, 6-11 normal): the product of the minimal polynomials of alpha, alpha^3, ... with alpha
+    a root of 1+x+x^3+x^5+x^14 (short) / 1+x^2+x^3+x^5+x^16 (normal), as many as the parity field has room for."""
+    m, prim = (14, 0x402B) if cid < 6 else (16, 0x1002D)
+    _, k, _, _ = ol.ldpc_params(cid)
+    t = (k - K_BCH[cid]) // m
+    g = 1
+    for j in range(1, 2 * t, 2):
+        beta = 1
+        for _ in range(j):
+            beta = _pmulmod(beta, 2, prim)
+        conj, x = [], beta                                   # (X + beta)(X + beta^2)(X + beta^4)...
+        while not conj or x != beta:
+            conj.append(x)
+            x = _pmulmod(x, x, prim)
+        coef = [1]
+        for c in conj:
+            nxt = [0] * (len(coef) + 1)
+            for i, a in enumerate(coef):
+                nxt[i + 1] ^= a
+                nxt[i] ^= _pmulmod(a, c, prim)
+            coef = nxt
+        assert all(c in (0, 1) for c in coef)
+        mp = sum(c << i for i, c in enumerate(coef))
+        ng = 0                                               # g *= mp over GF(2)
+        for i in range(mp.bit_length()):
+            if mp >> i & 1:
+                ng ^= g << i
+        g = ng
+    assert g.bit_length() - 1 == k - K_BCH[cid]
+    return g, m, t
+
+
+def bch_parity(cid, bbframes):
+    """[f][k_bch] message bits (first bit = highest power of x) -> [f][n_bch - k_bch] parity bits of the systematic code."""
+    g, _, _ = bch_generator(cid)
+    r = g.bit_length() - 1
+    out = np.zeros((bbframes.shape[0], r), np.uint8)
+    for f, row in enumerate(bbframes):
+        msg = int.from_bytes(np.packbits(row).tobytes(), "big") >> ((-len(row)) % 8)
+        rem = _pmod_fast(msg << r, g)
+        out[f] = [(rem >> (r - 1 - i)) & 1 for i in range(r)]
+    return out
+
+
+def _pmod_fast(a, g):
+    """a mod g, a byte of a at a time (table of (v * x^r) mod g for the 256 top bytes)."""
+    r = g.bit_length() - 1
+    tab = [_pmod(v << r, g) for v in range(256)]
+    nbytes = (a.bit_length() + 7) // 8
+    mask = (1 << r) - 1
+    reg = 0
+    data = a.to_bytes(nbytes, "big")
+    for byte in data[:max(nbytes - r // 8, 0)]:              # r is a multiple of 8 for every T2 code; the last r bits of a are zero
+        top = (reg >> (r - 8)) ^ byte
+        reg = ((reg << 8) & mask) ^ tab[top]
+    return reg
+
+
+def fec_encode(cid, bbframes, bch=False):
+    """BBFRAME bits [f][k_bch] -> LDPC codewords [f][n] in transmitted order. The BCH parity field stays zero unless bch is set
+    (the reference ignores it, bch_decoder.cpp:136; the opt-in BCH stage of the library needs the real parity)."""
     n, k, _, _ = ol.ldpc_params(cid)
     info = np.zeros((bbframes.shape[0], k), np.uint8)
     info[:, :bbframes.shape[1]] = bbframes
+    if bch:
+        info[:, bbframes.shape[1]:] = bch_parity(cid, bbframes)
     return ol.ldpc_encode(cid, info)
 
 
@@ -163,10 +243,10 @@ def build_frame(m, plp_stream, l1_post_size, seed, snr_db=None, phase=0.0, l1_ce
     return out
 
 
-def build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, n_blocks, rotation=True):
+def build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, n_blocks, rotation=True, bch=False):
     """TS packets -> the n_blocks FEC blocks of one TI block -> interleaved cell stream. Returns (stream, bbframes)."""
     frames, used = bbframes_hem(ts, K_BCH[cid], n_blocks)
-    cw = fec_encode(cid, scramble(frames))
+    cw = fec_encode(cid, scramble(frames), bch=bch)
     cells = cells_from_codewords(cw, mod, fec_type, code_rate, rotation)
     return interleave_ti_block(cells), frames, used
 

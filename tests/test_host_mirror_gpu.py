@@ -77,6 +77,31 @@ def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod):
     assert np.array_equal(got[:, 1:], np.concatenate(want))
 
 
+def test_bch_class_with_outer_code(driver, tmp_path):
+    """bch_decoder.outer_code (not in the reference, whose decoder is a TODO, bch_decoder.cpp:136). The LDPC stage hands over
+    valid LDPC words only, so the damage is put where just the outer code sees it: the words that get LDPC-encoded differ from
+    BCH codewords in a few bits. Frames with up to t such bits come out repaired, the others flagged and passed as they are."""
+    fec_type, cod = 0, 2
+    cid = ol.code_id(fec_type, cod)
+    m, t, kb, nb = ol.bch_params(cid)
+    rng = np.random.Generator(np.random.PCG64(16))
+    msg = rng.integers(0, 2, (32, kb), dtype=np.uint8)
+    words = np.concatenate([msg, t2_tx.bch_parity(cid, msg)], axis=1)
+    errs = rng.integers(0, t + 3, 32)
+    errs[:3] = (0, t, t + 1)
+    sent = words.copy()
+    for f in range(32):
+        sent[f, rng.choice(nb, errs[f], replace=False)] ^= 1
+    _, llr = ol.make_llr(cid, 32, 0.55, 17, info=sent)                            # LDPC-encodes the damaged words
+    llr.tofile(tmp_path / "llr.i8")
+    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod, "outer")
+    status = [int(l.split()[1]) for l in err.splitlines() if l.startswith("outer ")]
+    assert status == [int(e) if e <= t else -1 for e in errs]
+    got = np.fromfile(tmp_path / "out.u8", np.uint8).reshape(-1, 1 + kb)[:, 1:]
+    want = np.where((errs <= t)[:, None], words[:, :kb], sent[:, :kb])
+    assert np.array_equal(got, ol.ora_bch_descramble(cid, np.concatenate([want, np.zeros((32, nb - kb), np.uint8)], axis=1)))
+
+
 def test_p1_class(driver, tmp_path):
     rng = np.random.Generator(np.random.PCG64(8))
     noise = lambda n, s: ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * s).astype(np.complex64)

@@ -82,6 +82,46 @@ def test_iq_to_ts(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, sa
     rx.close()
 
 
+def test_outer_code_in_the_batch_receiver(torch_cuda):
+    """t2gpu_rx_set_outer_code: with real BCH parity on air every decoded FEC frame checks clean and the output is what the
+    reference-shaped path gives; with the parity field left zero (which the reference never notices, bch_decoder.cpp:136) the
+    same frames are reported as beyond correction and still pass through untouched."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 1, 2, 0, 24), 150, 1, 0, 1, 12.0, 8
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    nb = t2_tx.plp_blocks_per_frame(m, lps, 16200 // (2 * (mod + 1)))
+    k_bch = t2_tx.K_BCH[cid]
+    n_frames = 2
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, 5)
+    outs = {}
+    for bch in (True, False):
+        frames = []
+        for f in range(n_frames):
+            cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, f * nb, nb, k_bch), nb, bch=bch)
+            frames.append(t2_tx.build_frame(m, cells, lps, 9 + f, snr_db=None, phase=0.0))
+        rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames)
+        i16, q16, _ = t2_tx.iq_stream(frames, rx.geometry.guard_interval_size, s2, snr, 11)
+        di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
+        count = rx.execute_dev(di, dq, n_frames, first_call=True)
+        plain_bits, plain_trials = rx.fetch(count)
+        assert (plain_trials >= 0).all()
+        rx.set_outer_code(True)
+        assert rx.execute_dev(di, dq, n_frames, first_call=True) == count
+        bits, trials = rx.fetch(count)
+        status = rx.outer_code_status(count)
+        assert np.array_equal(trials, plain_trials) and np.array_equal(bits, plain_bits)
+        outs[bch] = (bits, status)
+        rx.set_outer_code(False)
+        with pytest.raises(Exception):
+            rx.outer_code_status(count)
+        rx.close()
+    assert not outs[True][1].any()                                  # real parity: every frame a codeword
+    assert (outs[False][1] == -1).all()                             # zero parity: not one
+    assert np.array_equal(outs[True][0], outs[False][0])            # the message bits are the same stream either way
+
+
 def test_pipelined_schedule_equals_plain_calls(torch_cuda):
     """receiver.pipeline_step (four streams, stages of neighbouring buffers overlapped) returns, one call late, exactly what the
     plain call sequence returns for the same buffers."""
