@@ -64,3 +64,33 @@ def test_a_buffer_of_frames_on_the_device(cid):
     # then the reference's stage proper: parity strip + descrambler on the corrected words
     out = dec.execute_dev(d).cpu().numpy()
     assert (out == ol.ora_bch_descramble(cid, cw)).all()
+
+
+def test_more_frames_than_workgroups():
+    """9000 short frames in one call (the launch caps its grid at 8192 workgroups and strides): sparse damage, everything repaired."""
+    import torch
+    cid = 1
+    m, t, kb, nb = ol.bch_params(cid)
+    rng = np.random.default_rng(77)
+    n = 9000
+    base = _codewords(cid, 8, rng)
+    cw = base[rng.integers(0, 8, n)] ^ base[rng.integers(0, 8, n)]
+    errs = np.where(rng.random(n) < 0.1, rng.integers(1, t + 1, n), 0)
+    bad = cw.copy()
+    for f in np.nonzero(errs)[0]:
+        bad[f, rng.choice(nb, errs[f], replace=False)] ^= 1
+    d = torch.from_numpy(bad).cuda()
+    st = bch_decoder(0, 1).correct_dev(d)
+    assert (st.cpu().numpy() == errs).all() and (d.cpu().numpy() == cw).all()
+
+
+def test_bad_arguments_are_refused():
+    import torch
+    from sdr_receiver_dvb_t2_amd._lib import lib
+    d = torch.zeros(7200 + 8, dtype=torch.uint8, device="cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    l = lib()
+    assert l.t2gpu_bch_decode_dev(0, 0, d.data_ptr() + 1, 1, st.data_ptr(), None) == -1      # not 8-byte aligned
+    assert l.t2gpu_bch_decode_dev(0, 7, d.data_ptr(), 1, st.data_ptr(), None) == -1          # no such code
+    assert l.t2gpu_bch_decode_dev(0, 0, d.data_ptr(), 0, st.data_ptr(), None) == -1
+    assert l.t2gpu_bch_decode_dev(0, 0, d.data_ptr(), 1, st.data_ptr(), None) == 1 and int(st[0]) == 0   # all-zero word: a codeword
