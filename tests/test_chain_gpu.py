@@ -58,6 +58,13 @@ def ts_slice(ts, frame_pos, nb, k_bch):
     # 256-QAM: the reference's int8 cast wraps on the outer points at every SNR (see include/t2gpu.h, t2gpu_demap_configure);
     # with the clamping extension the same chain decodes CFG-A
     ("CFG-A 32K ext PP7 256-QAM 64800 r3/4 (clamped LLRs)", (5, 1, 6, 4, 0, 59), 350, 3, 1, 3, 22.0, True),
+    # the rest of SURVEY.md 8(f)-4: QPSK, the remaining pilot patterns, tone reservation, the remaining code rates
+    ("16K normal PP1 GI1/4 QPSK 16200 r4/5", (4, 0, 0, 3, 0, 17), 150, 0, 0, 4, 9.0, False),
+    ("32K normal PP8 GI1/16 QPSK 64800 r5/6 (FEC block larger than LDS: per-cell TI path)", (5, 0, 7, 1, 0, 30), 300, 0, 1, 5, 10.0, False),
+    ("32K ext PP6 GI1/16 tone reservation, 64-QAM 64800 r4/5", (5, 1, 5, 1, 2, 41), 400, 2, 1, 4, 20.0, False),
+    ("16K ext PP3 GI1/8 tone reservation, 16-QAM 64800 r1/2", (4, 1, 2, 2, 2, 33), 200, 1, 1, 0, 11.0, False),
+    ("16K normal PP5 GI1/16 16-QAM 16200 r2/3", (4, 0, 4, 1, 0, 45), 150, 1, 0, 2, 13.0, False),
+    ("32K ext PP4 GI1/32 64-QAM 16200 r5/6", (5, 1, 3, 0, 0, 60), 350, 2, 0, 5, 21.0, False),
 ])
 def test_transport_stream_round_trip(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, saturate):
     got, ts, nb = run_chain(torch_cuda, mode, lps, mod, fec_type, code_rate, snr, n_frames=1, seed=11, saturate=saturate)
