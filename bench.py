@@ -31,6 +31,10 @@ LDPC_HBM_BYTES_PER_FRAME = 64800 + 48600    # LLR in + one-bit-p
 # bench's launch of 3232 frames x 25 sweeps): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE,
 # KiB -> bytes
 LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 6.078e6 + 1.0823e7) * 1024 / 3232 / 25
+# the bound that does apply to this kernel: vector-ALU issue. SQ_INSTS_VALU per frame-sweep from the same PMC pass (1.1908e10 wave
+# instructions per launch of 3232 frames x 25 sweeps), 4 cycles of a SIMD each, 4 SIMDs x 256 CUs at the 2.4 GHz peak engine clock
+LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.1908e10 / 3232 / 25
+VALU_ISSUE_SLOTS_PER_S = 4 * 256 * 2.4e9 / 4
 MODE = (5, 1, 6, 4, 0, 59)                  # FFTSIZE_32K, extended, PP7, GI 1/128, no PAPR, 59 data symbols
 L1_POST_SIZE = 350
 PLP = (3, 1, 3, 1)                          # 256-QAM, normal FEC frame, r = 3/4, rotated
@@ -232,8 +236,11 @@ def main():
                          "traffic": round(LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP * ldpc_frames * args.trials),
                          "kernel": "ldpc_decode_kernel<12,12,4>", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
                          "share_of_step": round(avg_ldpc_s / (max_s / args.steps), 3),
+                         "valu_issue_frac": round(LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP * ldpc_frames * args.trials / avg_ldpc_s / VALU_ISSUE_SLOTS_PER_S, 3),
                          "note": "the LDPC is VALU/LDS-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once; "
-                                 "traffic = PMC-measured bytes per frame-sweep (profiles/r01_rx_pmc.txt) x frames x sweeps"},
+                                 "traffic = PMC-measured bytes per frame-sweep (profiles/r01_rx_pmc.txt) x frames x sweeps (the check-node records, "
+                                 "streaming through L2 / Infinity Cache); valu_issue_frac = PMC-measured vector instructions of this workload / "
+                                 "the measured launch time / the chip's vector issue rate: the bound this kernel actually runs against"},
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
