@@ -145,7 +145,12 @@ __device__ __forceinline__ int8_t cast_i8_trunc(float v)
 }
 
 // frames_per_sums: FEC frames that share one statistics triple (one TI block); sums of TI block t at sums + t * sums_stride
-__global__ __launch_bounds__(256) void demap_llr_kernel(DemapParams p, const float2 *__restrict__ cells,
+// One workgroup stages a whole FEC frame (up to 64 800 B of LDS, so two workgroups per CU): the more wavefronts it has, the more
+// cell loads are in flight per CU -- 1024 lanes instead of 256 (measured: see DESIGN.md K-demap)
+#ifndef T2_DEMAP_THREADS
+#define T2_DEMAP_THREADS 1024
+#endif
+__global__ __launch_bounds__(T2_DEMAP_THREADS) void demap_llr_kernel(DemapParams p, const float2 *__restrict__ cells,
                                                        const float *__restrict__ sums, int8_t *__restrict__ out, int frames_per_sums,
                                                        int sums_stride)
 {
@@ -192,7 +197,7 @@ hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_fra
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(256), p.fec_size, s, p, cells, sums, out, frames_per_sums, sums_stride);
+    hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(T2_DEMAP_THREADS), p.fec_size, s, p, cells, sums, out, frames_per_sums, sums_stride);
     return hipGetLastError();
 }
 
@@ -247,7 +252,10 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 // Cell n = row * cols + col of the TI block sits at interleaver address d = col * rows + row; FEC block b owns columns
 // 5b .. 5b+4 and perm maps its d range onto its own output range (time_deinterleaver.cpp:174-266: the cell permutation is
 // block-local), so a workgroup needs nothing but its block's cells.
-__global__ __launch_bounds__(512) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
+#ifndef T2_TI_THREADS
+#define T2_TI_THREADS 1024
+#endif
+__global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
                                                       const float2 *__restrict__ cells, long in_stride, float2 *__restrict__ out,
                                                       long out_stride)
 {
@@ -282,7 +290,7 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(num_blocks * frames)), dim3(512), lds, s, p, lost_by_block, num_blocks, cells, in_stride,
+    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(num_blocks * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks, cells, in_stride,
                        out, out_stride);
     return hipGetLastError();
 }
