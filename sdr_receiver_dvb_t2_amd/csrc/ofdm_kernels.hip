@@ -212,7 +212,10 @@ __device__ __forceinline__ int eq_skew(int i) { return i + (i >> 5); }
 // EQ_SPLIT lanes share one segment: every lane runs the (cheap) angle / amplitude recurrences over all cells, so all see the
 // reference's exact sequence of values, and does the table reads, divisions and the store for every EQ_SPLIT-th data cell.
 // Four times the wavefronts for the same LDS footprint, which is what hides the latency of this kernel.
-constexpr int EQ_SPLIT = 4;
+#ifndef T2_EQ_SPLIT
+#define T2_EQ_SPLIT 4
+#endif
+constexpr int EQ_SPLIT = T2_EQ_SPLIT;
 
 __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
                                                           const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
