@@ -43,7 +43,7 @@ def ts_from_bits(bits_host, trials_host, group=32, need_plp=0, tags=None, bbdh=N
 class t2_chain(object):
     def __init__(self, fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data, l1_post_size,
                  plp_mod, plp_fec_type, plp_cod, plp_rotation, plp_num_blocks, max_frames=4, device=0, ldpc_group=32,
-                 ldpc_trials=25, saturate_llr=False, time_il_length=1, plps=None, need_plp=0):
+                 ldpc_trials=25, saturate_llr=False, time_il_length=1, plps=None, need_plp=0, outer_code=False):
         """plps (optional): several PLPs in the frame, a list of dicts with num_blocks and start (L1-post dynamic: PLP_NUM_BLOCKS,
         PLP_START) and optionally plp_rotation, time_il_length, plp_num_blocks_max, id; list position = PLP index. All PLPs
         share plp_mod / plp_fec_type / plp_cod: the reference decodes a SIMD batch with the code of its first frame whichever
@@ -89,6 +89,9 @@ class t2_chain(object):
         self.ldpc = ldpc_decoder(plp_fec_type, plp_cod, max_frames=max_frames * plp_num_blocks + 64, device=device,
                                  group=ldpc_group, trials=ldpc_trials)
         self.bch = bch_decoder(plp_fec_type, plp_cod)
+        # opt-in BCH check / correction in front of the descrambler (the reference has none, bch_decoder.cpp:136); status of the
+        # last call (bits corrected per FEC frame, -1 = beyond t) in self.outer_code_status
+        self.outer_code, self.outer_code_status = bool(outer_code), None
         self.group = ldpc_group
         self._l = lib()
         self._bbdh = self._l.t2gpu_bbdh_create(need_plp)
@@ -181,6 +184,8 @@ class t2_chain(object):
         if self.time_ldpc:
             e1.record()
             self.ldpc_events.append((e0, e1, ready))
+        if self.outer_code:
+            self.outer_code_status = self.bch.correct_dev(bits)
         out = self.bch.execute_dev(bits)
         rest = total - ready
         if rest:
@@ -233,6 +238,8 @@ class t2_chain(object):
         if self.time_ldpc:
             e1.record()
             self.ldpc_events.append((e0, e1, count))
+        if self.outer_code:
+            self.outer_code_status = self.bch.correct_dev(bits)
         return self.bch.execute_dev(bits), trials
 
     def ts_from_bits(self, bits_host, trials_host, tags=None):

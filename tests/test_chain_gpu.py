@@ -18,7 +18,7 @@ def torch_cuda(built):
     return torch
 
 
-def run_chain(torch, mode, l1_post_size, mod, fec_type, code_rate, snr_db, n_frames, seed, saturate=False, expect_ok=True):
+def run_chain(torch, mode, l1_post_size, mod, fec_type, code_rate, snr_db, n_frames, seed, saturate=False, expect_ok=True, bch=False):
     import sdr_receiver_dvb_t2_amd as pkg
     m = ol.ora_mode(*mode)
     cid = ol.code_id(fec_type, code_rate)
@@ -28,16 +28,19 @@ def run_chain(torch, mode, l1_post_size, mod, fec_type, code_rate, snr_db, n_fra
     ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
     syms, pos = [], 0
     for f in range(n_frames):
-        stream, frames, used_bits = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, pos, nb, k_bch), nb)
+        stream, frames, used_bits = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, pos, nb, k_bch), nb, bch=bch)
         syms.append(t2_tx.build_frame(m, stream, l1_post_size, seed + f, snr_db=snr_db, phase=0.4 * (f + 1)))
         pos += nb
-    chain = pkg.t2_chain(*mode, l1_post_size, mod, fec_type, code_rate, 1, nb, max_frames=n_frames, saturate_llr=saturate)
+    chain = pkg.t2_chain(*mode, l1_post_size, mod, fec_type, code_rate, 1, nb, max_frames=n_frames, saturate_llr=saturate,
+                         outer_code=bch)
     x = torch.from_numpy(np.stack(syms).view(np.float32).reshape(n_frames, m.len_frame, m.fft_size, 2)).cuda()
     bits, trials = chain.demod_dev(x, flush=True)
     torch.cuda.synchronize()
     trials = trials.cpu().numpy()
     if expect_ok:
         assert (trials >= 0).all(), trials
+    if bch:                                                       # real BCH parity on air: every decoded frame checks clean
+        assert not chain.outer_code_status.cpu().numpy().any()
     got = chain.ts_from_bits(bits.cpu().numpy(), trials)
     chain.close()
     return got, ts, nb
@@ -67,7 +70,9 @@ def ts_slice(ts, frame_pos, nb, k_bch):
     ("32K ext PP4 GI1/32 64-QAM 16200 r5/6", (5, 1, 3, 0, 0, 60), 350, 2, 0, 5, 21.0, False),
 ])
 def test_transport_stream_round_trip(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, saturate):
-    got, ts, nb = run_chain(torch_cuda, mode, lps, mod, fec_type, code_rate, snr, n_frames=1, seed=11, saturate=saturate)
+    # every second case also carries real BCH parity and runs the opt-in outer-code stage
+    got, ts, nb = run_chain(torch_cuda, mode, lps, mod, fec_type, code_rate, snr, n_frames=1, seed=11, saturate=saturate,
+                            bch=(mod + code_rate) % 2 == 0)
     cid = ol.code_id(fec_type, code_rate)
     dfl_bytes = ((t2_tx.K_BCH[cid] - 80) // 8)
     sent = ts.reshape(-1)
