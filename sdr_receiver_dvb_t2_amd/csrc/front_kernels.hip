@@ -248,6 +248,85 @@ __global__ __launch_bounds__(256) void front_decimate_kernel(FrontParams p)
                            add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
 }
 
+// ---- Farrow + /2 decimator in one pass: the resampled stream (twice the input rate, 8 B per cell written and read again by the
+// two kernels above: half of the front end's HBM traffic) never leaves the CU. A workgroup needs cells m0 .. m0 + 573 of the
+// resampled stream for its 256 outputs; its lanes take the input samples that own those cells (from the owner of the first to the owner of the
+// last: about 290) and run front_farrow_kernel's arithmetic on each, storing into LDS. Same values bit
+// for bit (tests/test_front_gpu.py runs both forms). The last 63 cells still go to p.interp: front_finish_kernel carries them over.
+__device__ __forceinline__ int find_run_out(const FrontRun *__restrict__ runs, int n, long o)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (runs[mid].o0 <= o) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+constexpr int FD_THREADS = 256;       // 256 outputs per workgroup need about 290 input samples: a short second pass (320 lanes measured slower)
+__global__ __launch_bounds__(FD_THREADS) void front_farrow_decimate_kernel(FrontParams p)
+{
+    __shared__ float2 w[2 * 256 + 64];
+    const long k0 = (long)blockIdx.x * 256;
+    const long m0 = 2 * k0 + (1 - p.decim_phase);
+    const long avail = 63 + p.n_interp;
+    constexpr int W = 2 * 256 + 62;
+    for (int t = threadIdx.x; t < W; t += FD_THREADS) w[t] = m0 + t < 63 ? p.interp[m0 + t] : make_float2(0.f, 0.f);   // carried cells; zeros behind the end
+    // input samples whose outputs fall into the window: from the owner of its first cell to the owner of its last
+    const long oA = m0 > 63 ? m0 - 63 : 0, oB = (m0 + W - 1 < avail ? m0 + W - 1 : avail - 1) - 63;
+    __syncthreads();
+    if (oA <= oB) {
+        const FrontRun ra = p.far_runs[find_run_out(p.far_runs, p.n_far_runs, oA)], rb = p.far_runs[find_run_out(p.far_runs, p.n_far_runs, oB)];
+        const long i_first = (long)ra.i0 + (uint32_t)(oA - ra.o0) / (uint32_t)ra.cnt, i_last = (long)rb.i0 + (uint32_t)(oB - rb.o0) / (uint32_t)rb.cnt;
+        for (long i = i_first + threadIdx.x; i <= i_last; i += FD_THREADS) {
+            const FrontRun run = p.far_runs[find_run(p.far_runs, p.n_far_runs, i)];
+            const long k = i - run.i0;
+            float x1 = (float)(run.base + (double)k * run.step);
+            long o = (long)run.o0 + k * run.cnt;
+            const float delay_x = run.aux;
+            const float2 in = p.derot[3 + i], d1 = p.derot[2 + i], d2 = p.derot[1 + i], d3 = p.derot[i];
+            float a0[2], a1[2], a2[2], a3[2];
+            const float vin[2] = {in.x, in.y}, v1[2] = {d1.x, d1.y}, v2[2] = {d2.x, d2.y}, v3[2] = {d3.x, d3.y};
+            for (int c = 0; c < 2; ++c) {
+                const float even1 = add_r(v3[c], vin[c]), even2 = add_r(v2[c], v1[c]);
+                const float odd1 = sub_r(v3[c], vin[c]), odd2 = sub_r(v2[c], v1[c]);
+                a0[c] = sub_r(mul_r(9.0f / 16.0f, even2), mul_r(1.0f / 16.0f, even1));
+                a1[c] = sub_r(mul_r(1.0f / 8.0f, odd1), mul_r(11.0f / 8.0f, odd2));
+                a2[c] = mul_r(1.0f / 4.0f, sub_r(even1, even2));
+                a3[c] = sub_r(mul_r(3.0f / 2.0f, odd2), mul_r(1.0f / 2.0f, odd1));
+            }
+            while (x1 < 0.5f) {
+                const float x2 = mul_r(x1, x1), x3 = mul_r(x2, x1);
+                float v[2];
+                for (int c = 0; c < 2; ++c) v[c] = add_r(add_r(add_r(mul_r(a3[c], x3), mul_r(a2[c], x2)), mul_r(a1[c], x1)), a0[c]);
+                const long t = 63 + o - m0;
+                if (t >= 0 && t < W) w[t] = make_float2(v[0], v[1]);
+                if (o >= p.n_interp - 63) p.interp[63 + o] = make_float2(v[0], v[1]);   // the tail the next call starts from
+                ++o;
+                x1 = add_r(x1, delay_x);
+            }
+        }
+    }
+    __syncthreads();
+    const long k = k0 + threadIdx.x;
+    if (threadIdx.x >= 256 || k >= p.n_out) return;
+    const float2 *x = w + 2 * threadIdx.x;
+    float lane_r[4], lane_i[4];
+    for (int q = 0; q < 4; ++q) {
+        float ar = 0.0f, ai = 0.0f;
+        for (int blk = 0; blk < 4; ++blk) {
+            const int c = 16 * blk + q;
+            const float2 x0 = x[c], x1 = x[c + 4], x2 = x[c + 8], x3 = x[c + 12];
+            const float h0 = c_taps[c], h1 = c_taps[c + 4], h2 = c_taps[c + 8], h3 = c_taps[c + 12];
+            ar = add_r(ar, add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
+            ai = add_r(ai, add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+        }
+        lane_r[q] = ar; lane_i[q] = ai;
+    }
+    p.out[k] = make_float2(add_r(add_r(add_r(lane_r[0], lane_r[1]), lane_r[2]), lane_r[3]),
+                           add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
+}
+
 // c1, c2, level_detect from the sign statistics of `len` samples (dvbt2_demodulator.cpp:227-235)
 __device__ __forceinline__ void front_iq_estimate(FrontState &s, double t1, double t2, double t3, float len)
 {
@@ -363,9 +442,20 @@ void launch_front(const FrontParams &p, hipStream_t stream)
         hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(front_derotate_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
     }
-    if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))
-        hipLaunchKernelGGL(front_farrow_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
-    if (p.n_out > 0 && (p.stages & FRONT_STAGE_DECIMATE)) hipLaunchKernelGGL(front_decimate_kernel, dim3((unsigned)((p.n_out + 255) / 256)), dim3(256), 0, stream, p);
+#ifndef T2_FRONT_FUSED
+#define T2_FRONT_FUSED 1
+#endif
+    const bool both = (p.stages & FRONT_STAGE_FARROW) && (p.stages & FRONT_STAGE_DECIMATE);
+    if (T2_FRONT_FUSED && both && p.n > 0) {
+        // one pass, nothing of the resampled stream in HBM but its last 63 cells; enough workgroups that their 574-cell windows
+        // also cover the cells behind the last complete output (they are part of what the next call starts from)
+        const long by_out = (p.n_out + 255) / 256, by_cells = p.n_interp / 512 + 1;
+        hipLaunchKernelGGL(front_farrow_decimate_kernel, dim3((unsigned)(by_out > by_cells ? by_out : by_cells)), dim3(FD_THREADS), 0, stream, p);
+    } else {
+        if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))
+            hipLaunchKernelGGL(front_farrow_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);
+        if (p.n_out > 0 && (p.stages & FRONT_STAGE_DECIMATE)) hipLaunchKernelGGL(front_decimate_kernel, dim3((unsigned)((p.n_out + 255) / 256)), dim3(256), 0, stream, p);
+    }
     hipLaunchKernelGGL(front_finish_kernel, dim3(1), dim3(256), 0, stream, p);
 }
 
