@@ -326,7 +326,9 @@ long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len,
 /* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
 int t2gpu_front_state(t2gpu_front *h, float *out8);
 /* intermediate streams of the last call, for tests: which 0 = de-rotated samples (n_in cells), 1 = resampled (before the
- * decimator). Synchronises. Returns the number of cells copied. */
+ * decimator). Synchronises. Returns the number of cells copied. Since t2gpu_front_execute runs the Farrow stage and the decimator
+ * as one kernel, stream 1 holds real data in its last 63 cells only (what the next call starts from); its length is right, the
+ * cells before are whatever the buffer held. t2gpu_farrow_execute is the way to look at resampled cells. */
 long t2gpu_front_debug_stream(t2gpu_front *h, int which, float *out, long cap_cells);
 
 /* Stand-alone stages with the call shape of the reference classes (host buffers; state kept in the handle):
