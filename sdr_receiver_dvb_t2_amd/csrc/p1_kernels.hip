@@ -122,6 +122,52 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
         const int cnt = min(2048, N - n);
         for (int k = tid; k < cnt; k += 256) sc[k] = corr[n + k];
         __syncthreads();
+#ifndef T2_P1_OLD
+        // The stretch is one state machine, but a lone lane reading LDS once per sample spends its time on LDS latency: the first
+        // wavefront runs it in step (every lane the same values), fetching 64 samples with one LDS read and handing them out of
+        // a register with v_readlane; only lane 0's copies are stored.
+        if (tid < 64) {
+            P1State l = st;
+            // every lane holds the same state: say so, and the branches below become scalar branches instead of EXEC masking
+            auto uf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+            l.correlation = uf(l.correlation); l.begin_threshold = uf(l.begin_threshold); l.end_threshold = uf(l.end_threshold);
+            l.max_correlation = uf(l.max_correlation);
+            l.correlation_detect = __builtin_amdgcn_readfirstlane(l.correlation_detect);
+            l.idx_buffer = __builtin_amdgcn_readfirstlane(l.idx_buffer);
+            const int cnt_u = __builtin_amdgcn_readfirstlane(cnt);
+            int k = 0;
+            float cv = 0.0f;
+            int k_max = -1;                 // where the maximum moved to in this stretch: its correlator output is fetched once, at the end
+            for (; k < cnt_u; ++k) {
+                if ((k & 63) == 0) cv = k + tid < cnt_u ? sc[k + tid] : 0.0f;
+                if (l.correlation_detect) {
+                    if (++l.idx_buffer > 2048) {           // :101-104: reset_buffer() clears the correlator
+                        l.correlation_detect = 0; l.max_correlation = 0.0f; l.idx_buffer = 0;
+                        if (!(l.correlation < l.end_threshold)) {     // otherwise the reference falls into :106 with idx_buffer = 0
+                            if (tid == 0) { res.status = 2; res.consumed = n + k; s_stop = 1; }   // the caller restarts the search at this sample
+                            break;
+                        }
+                    }
+                    if (l.correlation < l.end_threshold) {   // :106
+                        if (tid == 0) { res.status = 1; res.consumed = n + k + 1; res.idx_buffer_sym = l.idx_buffer; s_stop = 1; }
+                        break;
+                    }
+                }
+                const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), k & 63));
+                l.correlation = c;
+                if (c > l.begin_threshold) {
+                    l.correlation_detect = 1;
+                    if (c > l.max_correlation) {
+                        l.max_correlation = c;
+                        k_max = k;          // on the rising flank of the peak every sample is a new maximum: no global load per sample
+                        l.idx_buffer = 0;
+                    }
+                } else if (!l.correlation_detect) { ++k; break; }   // back to the parallel skip
+            }
+            if (k_max >= 0) { const float2 o = outv[n + k_max]; l.arg_max_re = o.x; l.arg_max_im = o.y; }
+            if (tid == 0) { st = l; s_first = k; }
+        }
+#else
         if (tid == 0) {
             P1State l = st;                 // registers for the sequential stretch
             int k = 0;
@@ -154,6 +200,7 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
             st = l;
             s_first = k;
         }
+#endif
         __syncthreads();
         if (s_stop) break;
         n += s_first;
