@@ -105,9 +105,16 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
             if (tid == 0) s_first = N;
             __syncthreads();
             for (int base = n; base < N && s_first == N; base += 4096) {
+                // sixteen independent loads per lane, then the first crossing among them (a loop that stops at the first crossing
+                // would wait for one global load after the other)
+                const int lim = min(N, base + 4096);
+                const float thr = st.begin_threshold;
+                float vals[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int k = base + tid + 256 * u; vals[u] = k < lim ? corr[k] : thr; }
                 int mine = N;
-                for (int k = base + tid; k < min(N, base + 4096); k += 256)
-                    if (corr[k] > st.begin_threshold) { mine = k; break; }
+#pragma unroll
+                for (int u = 15; u >= 0; --u) if (vals[u] > thr) mine = base + tid + 256 * u;
                 if (mine < N) atomicMin(&s_first, mine);
                 __syncthreads();
             }
