@@ -388,6 +388,9 @@ typedef struct {
 t2gpu_p1 *t2gpu_p1_create(int max_samples, int device);
 void t2gpu_p1_destroy(t2gpu_p1 *h);
 int t2gpu_p1_reset(t2gpu_p1 *h);
+/* tests: on = run the threshold / arg-max state machine (p1_symbol.cpp:93-109,162-170) sample by sample only, as the reference
+ * writes it, instead of taking whole stretches in closed form; decisions are the same either way (tests/test_p1_gpu.py) */
+int t2gpu_p1_set_serial_detector(t2gpu_p1 *h, int on);
 int t2gpu_p1_execute_dev(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *d_in, int *consume,
                          int reset_flag, t2gpu_p1_result *res, void *stream);
 int t2gpu_p1_execute(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *in, int *consume, int reset_flag,

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "t2gpu_p1_create": (_vp, [ctypes.c_int, ctypes.c_int]),
     "t2gpu_p1_destroy": (None, [_vp]),
     "t2gpu_p1_reset": (ctypes.c_int, [_vp]),
+    "t2gpu_p1_set_serial_detector": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_p1_execute_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_p1_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_p1_execute_batch_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),

@@ -51,6 +51,7 @@ struct P1Params {
     float2 *p1_fft;                        // [n_windows][1024] fft-shifted spectrum of part A (kept for inspection)
     int reset_flag;
     int gain_changed;                      // :88-91: thresholds follow the level estimate once the gain is settled
+    int serial_detector;                   // tests: the threshold state machine sample by sample only (no closed-form stretches)
     float level_detect;
 };
 

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(P1_TILE) void p1_correlate_kernel(P1Params p)
 __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
 {
     __shared__ float sc[2048];
-    __shared__ int s_first, s_stop;
+    __shared__ int s_first, s_stop, s_end;
+    __shared__ unsigned long long s_best;
     __shared__ P1State st;                  // the detector state lives in LDS / registers during the pass, global memory only at both ends
     const int tid = threadIdx.x;
     P1Result &res = p.result[blockIdx.x];
@@ -128,7 +129,54 @@ __global__ __launch_bounds__(256) void p1_detect_kernel(P1Params p)
         // sequential stretch of up to 2048 samples from LDS
         const int cnt = min(2048, N - n);
         for (int k = tid; k < cnt; k += 256) sc[k] = corr[n + k];
+        if (tid == 0) { s_end = cnt; s_best = 0ull; }
         __syncthreads();
+#ifndef T2_P1_SERIAL
+        // The common stretch in closed form, all lanes: the search is (or becomes, with sample 0) active and its sample counter
+        // cannot reach 2048 inside the stretch. Then the loop below does nothing but (i) stop at the first k whose PREVIOUS
+        // correlation is under the end threshold and (ii) keep the first strict maximum among the samples above the begin
+        // threshold that come before that k; the counter is the distance from that maximum (or its old value plus the samples
+        // seen). Everything else -- a stretch entered below the threshold, a counter that may overflow (:101-104) -- goes through
+        // the sequential form, which is the reference's loop as written.
+        const bool d0 = st.correlation_detect != 0;
+        const bool fast = !p.serial_detector && (d0 || sc[0] > st.begin_threshold) && st.idx_buffer + cnt <= 2048;
+        if (fast) {
+            const int kd = d0 ? 0 : 1;                         // first sample whose iteration starts with the search active
+            const float c_prev = st.correlation, thr_b = st.begin_threshold, thr_e = st.end_threshold;
+            for (int k = kd + tid; k < cnt; k += 256)
+                if ((k ? sc[k - 1] : c_prev) < thr_e) { atomicMin(&s_end, k); break; }
+            __syncthreads();
+            const int k_end = s_end;                           // cnt: the stretch ends with the search still active
+            unsigned long long best = 0ull;                    // (value, first index): correlations are norms, their bit patterns order like the values
+            for (int k = tid; k < k_end; k += 256)
+                if (sc[k] > thr_b) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(sc[k]) << 32) | (0xffffffffu - (unsigned)k);
+                    best = key > best ? key : best;
+                }
+            if (best) atomicMax(&s_best, best);
+            __syncthreads();
+            if (tid == 0) {
+                P1State l = st;
+                const bool stop = k_end < cnt;
+                const int last = stop ? k_end : cnt - 1;       // last iteration that starts with the search active
+                const unsigned long long b = s_best;
+                const float m = __uint_as_float((unsigned)(b >> 32));
+                l.correlation_detect = 1;
+                if (b && m > l.max_correlation) {
+                    const int k_max = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
+                    const float2 o = outv[n + k_max];
+                    l.max_correlation = m; l.arg_max_re = o.x; l.arg_max_im = o.y;
+                    l.idx_buffer = last - k_max;
+                } else {
+                    l.idx_buffer += last - kd + 1;
+                }
+                l.correlation = stop ? (k_end ? sc[k_end - 1] : c_prev) : sc[cnt - 1];
+                if (stop) { res.status = 1; res.consumed = n + k_end + 1; res.idx_buffer_sym = l.idx_buffer; s_stop = 1; }
+                st = l;
+                s_first = stop ? k_end : cnt;
+            }
+        } else
+#endif
 #ifndef T2_P1_OLD
         // The stretch is one state machine, but a lone lane reading LDS once per sample spends its time on LDS latency: the first
         // wavefront runs it in step (every lane the same values), fetching 64 samples with one LDS read and handing them out of

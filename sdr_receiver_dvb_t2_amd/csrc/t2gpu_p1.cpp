@@ -22,6 +22,7 @@ struct t2gpu_p1 {
     // host mirror of the scalars the batch form seeds every window with
     float begin_threshold = 5.0e+5f;
     int p1_decoded = 0;
+    int serial_detector = 0;
 };
 static constexpr int MAX_WINDOWS = 1024;
 
@@ -88,6 +89,13 @@ extern "C" int t2gpu_p1_reset(t2gpu_p1 *h)
     return 0;
 }
 
+extern "C" int t2gpu_p1_set_serial_detector(t2gpu_p1 *h, int on)
+{
+    if (!h) { set_error("t2gpu_p1_set_serial_detector: null handle"); return -1; }
+    h->serial_detector = on != 0;
+    return 0;
+}
+
 extern "C" int t2gpu_p1_execute_dev(t2gpu_p1 *h, int gain_changed, float level_detect, int len_in, const float *d_in, int *consume,
                                     int reset_flag, t2gpu_p1_result *res, void *stream_)
 {
@@ -105,7 +113,7 @@ extern "C" int t2gpu_p1_execute_dev(t2gpu_p1 *h, int gain_changed, float level_d
         P1Params p{};
         p.xb = h->d_xb; p.base = h->d_xb + P1_HIST; p.win = h->d_win; p.n_windows = 1; p.hist = P1_HIST; p.n = n; p.fq_shift = h->d_fq; p.twiddle = h->d_tw; p.corr = h->d_corr; p.out = h->d_out;
         p.state = h->d_state; p.result = h->d_result; p.p1_fft = h->d_fft; p.reset_flag = reset_flag;
-        p.gain_changed = gain_changed; p.level_detect = level_detect;
+        p.gain_changed = gain_changed; p.level_detect = level_detect; p.serial_detector = h->serial_detector;
         launch_p1(p, stream);
         T2_HIP(hipGetLastError());
         T2_HIP(hipMemcpyAsync(h->h_result, h->d_result, sizeof(P1Result), hipMemcpyDeviceToHost, stream));
@@ -156,7 +164,7 @@ extern "C" int t2gpu_p1_execute_batch_dev(t2gpu_p1 *h, int gain_changed, float l
     P1Params p{};
     p.xb = nullptr; p.base = reinterpret_cast<const float2 *>(d_stream); p.win = h->d_win; p.n_windows = n_windows; p.hist = 0; p.n = longest;
     p.fq_shift = h->d_fq; p.twiddle = h->d_tw; p.corr = h->d_corr; p.out = h->d_out; p.state = h->d_state + 1; p.result = h->d_result;
-    p.p1_fft = h->d_fft; p.reset_flag = reset_flag; p.gain_changed = 0; p.level_detect = 0.0f;
+    p.p1_fft = h->d_fft; p.reset_flag = reset_flag; p.gain_changed = 0; p.level_detect = 0.0f; p.serial_detector = h->serial_detector;
     launch_p1(p, stream);
     T2_HIP(hipGetLastError());
     T2_HIP(hipMemcpyAsync(h->h_result, h->d_result, n_windows * sizeof(P1Result), hipMemcpyDeviceToHost, stream));

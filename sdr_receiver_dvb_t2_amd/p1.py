@@ -30,6 +30,10 @@ class p1_symbol(object):
     def reset(self):
         self._l.t2gpu_p1_reset(self.h)
 
+    def set_serial_detector(self, on=True):
+        """Tests: the detector's state machine sample by sample only (the closed-form stretches off)."""
+        self._l.t2gpu_p1_set_serial_detector(self.h, int(on))
+
     def execute(self, x, consume=0, gain_changed=False, level_detect=0.0, reset=False):
         """x: complex64 host array. Returns (detected, consume, result) like the reference's execute()."""
         x = np.ascontiguousarray(x, np.complex64)

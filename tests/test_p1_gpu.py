@@ -103,6 +103,37 @@ def test_p1_split_calls_and_dev_entry(torch_cuda):
         assert all(abs(a - b) <= 2 for a, b in zip(found_g, ends))
 
 
+@pytest.mark.parametrize("scale", [0.02, 0.1, 0.4])
+def test_detector_stretches_equal_the_sample_by_sample_form(torch_cuda, scale):
+    """The detector takes whole stretches in closed form where it can. Thresholds pulled down into the noise (level estimate scaled
+    by `scale`) make the search start, stop, restart and overflow its 2048-sample buffer hundreds of times; with the same
+    correlation values underneath, every decision must equal the sample-by-sample form's, whatever the call boundaries."""
+    from sdr_receiver_dvb_t2_amd import p1 as p1mod
+    x, _ = stream(55, [(0, 10), (1, 9)], snr_noise=0.05)
+    rng = np.random.Generator(np.random.PCG64(int(scale * 1000)))
+    x = np.concatenate([x, noise(rng, 30000, 0.08)]) + noise(rng, len(x) + 30000, 0.03)
+    level = float(np.mean(np.abs(x.real)) * np.mean(np.abs(x.imag))) * scale
+    cuts = sorted(set(rng.integers(1, len(x), 12).tolist())) + [len(x)]
+    a, b = p1mod.p1_symbol(max_samples=len(x)), p1mod.p1_symbol(max_samples=len(x))
+    b.set_serial_detector(True)
+    events, lo, first = 0, 0, True
+    for hi in cuts:
+        seg = np.ascontiguousarray(x[lo:hi])
+        ca = 0
+        while ca < len(seg):
+            da, ca2, ra = a.execute(seg, ca, first, level)
+            db, cb2, rb = b.execute(seg, ca, first, level)
+            first = False
+            assert (da, ca2) == (db, cb2)
+            assert (ra.detected, ra.idx_buffer_sym, ra.p1_decoded, ra.preamble, ra.fft_mode, ra.shift, ra.s1, ra.s2) == \
+                (rb.detected, rb.idx_buffer_sym, rb.p1_decoded, rb.preamble, rb.fft_mode, rb.shift, rb.s1, rb.s2)
+            assert (ra.max_correlation, tuple(ra.arg_max), ra.coarse_freq_offset) == (rb.max_correlation, tuple(rb.arg_max), rb.coarse_freq_offset)
+            events += 1
+            ca = ca2
+        lo = hi
+    assert events > len(cuts)                                   # the search really stopped and restarted inside calls
+
+
 def test_p1_no_false_alarm_and_weak_signal(torch_cuda):
     from sdr_receiver_dvb_t2_amd import p1 as p1mod
     rng = np.random.Generator(np.random.PCG64(99))
