@@ -107,17 +107,31 @@ __global__ __launch_bounds__(256) void front_dc_scan_kernel(FrontParams p)
     __shared__ Lin wave_tot[4];
     const int tid = threadIdx.x, nb = p.n_blocks;
     const int per = (nb + 255) / 256, b0 = tid * per, b1 = min(nb, b0 + per);
+    // one workgroup, ~120 aggregates per lane: eight loads in flight per lane instead of one (same operations in the same order)
+    constexpr int U = 8;
     Lin l{1.0, 0.0, 0.0};
-    for (int b = b0; b < b1; ++b) { const double *v = p.blk + 4 * (long)b; l = compose(l, Lin{v[0], v[1], v[2]}); }
+    for (int b = b0; b < b1; b += U) {
+        Lin w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const double *v = p.blk + 4 * (long)min(b + u, b1 - 1); w[u] = Lin{v[0], v[1], v[2]}; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (b + u < b1) l = compose(l, w[u]);
+    }
     Lin total;
     const Lin ex = block_scan_exclusive(l, wave_tot, &total);
     const double s_re = p.state->dc_re, s_im = p.state->dc_im;
     double re = ex.a * s_re + ex.re, im = ex.a * s_im + ex.im;
-    for (int b = b0; b < b1; ++b) {
-        double *v = p.blk + 4 * (long)b;
-        const Lin w{v[0], v[1], v[2]};
-        v[0] = re; v[1] = im;
-        re = w.a * re + w.re; im = w.a * im + w.im;
+    for (int b = b0; b < b1; b += U) {
+        Lin w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const double *v = p.blk + 4 * (long)min(b + u, b1 - 1); w[u] = Lin{v[0], v[1], v[2]}; }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (b + u < b1) {
+                double *v = p.blk + 4 * (long)(b + u);
+                v[0] = re; v[1] = im;
+                re = w[u].a * re + w[u].re; im = w[u].a * im + w[u].im;
+            }
     }
     __syncthreads();
     if (tid == 0) { p.state->dc_re = total.a * s_re + total.re; p.state->dc_im = total.a * s_im + total.im; }
@@ -343,7 +357,17 @@ __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
     double t[3] = {0.0, 0.0, 0.0};
-    for (int b = tid; b < ((p.stages & FRONT_STAGE_DEROTATE) ? p.n_blocks : 0); b += 256) { const double *v = p.theta_part + 4 * (long)b; t[0] += v[0]; t[1] += v[1]; t[2] += v[2]; }
+    const int nbk = (p.stages & FRONT_STAGE_DEROTATE) ? p.n_blocks : 0;
+    for (int b = tid; b < nbk; b += 256 * 8) {                 // eight loads in flight per lane; the additions keep their order
+        double v[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double *q = p.theta_part + 4 * (long)min(b + 256 * u, nbk - 1);
+            v[u][0] = q[0]; v[u][1] = q[1]; v[u][2] = q[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (b + 256 * u < nbk) { t[0] += v[u][0]; t[1] += v[u][1]; t[2] += v[u][2]; }
+    }
     for (int c = 0; c < 3; ++c) red[c][tid] = t[c];
     const bool carry_d = (p.stages & FRONT_STAGE_FARROW) && tid < 3;
     const bool carry_i = (p.stages & FRONT_STAGE_DECIMATE) && tid >= 64 && tid < 64 + 63;
