@@ -277,7 +277,10 @@ __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p
     // Same float operations in the same order as the reference's loop; only the two table reads of eight cells are issued
     // together ahead of their use (the angle / amplitude recurrences do not depend on them), which hides the L2 latency that a
     // lone wavefront per workgroup cannot hide by itself.
-    constexpr int U = 8;
+#ifndef T2_EQ_U
+#define T2_EQ_U 8
+#endif
+    constexpr int U = T2_EQ_U;
     for (int i0 = pl + 1; i0 < pr; i0 += U) {
         float amp[U], cr[U], sr[U];
         int dd[U];
