@@ -233,9 +233,17 @@ float ora_atan2_approx(float y, float x)
 /* ofdm_cell: the fft-shifted symbol (fft_size complex, re/im interleaved); map/refer: this symbol's tables; h: h_odd when
  * idx_symbol is even, h_even when odd (caller picks, :148-149). out: c_data cells (c_p2 for a P2 symbol's tables). sync[0] = phase_offset,
  * sync[1] = sample_rate_offset. Returns the number of cells written. */
-int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *map, const float *refer, const int *h,
-                    float *out, float *sync)
+/* kind: 0 = P2 symbol (p2_symbol.cpp:89-262), 1 = data symbol, 2 = frame-closing symbol (fc_symbol.cpp:82-271). The three
+ * functions are the same estimator; what differs in the reference BINARY (built -Ofast, sdr_receiver_dvb_t2.pro:33-39) is the
+ * pilot amplitude: in p2_symbol / fc_symbol amp_pilot never changes inside the function, so gcc's -freciprocal-math turns
+ * `sqrt(norm(cell)) / amp_pilot` into a product with 1/amp_pilot computed once; in data_symbol amp_pilot alternates between the
+ * continual and scattered value and the division stays. Pinned against oracle/_ref/libref_t2sym.so (tests/test_ref_pins.py):
+ * data symbols bit-exact; P2 / FC bit-exact except cells whose table index int(angle * k + 32767) sits on a rounding boundary
+ * (2 of 22 432 in the CFG-A fixture, |difference| < 3e-4) -- with a true division 40 % of the P2 cells differ in the last bits. */
+int ora_symbol_equalise(const ora_mode *m, int kind, const float *ofdm_cell_full, const int *map, const float *refer, const int *h,
+                        float *out, float *sync)
 {
+    const int recip = kind != 1;
     ora_lut_init();
     const float *oc = ofdm_cell_full + 2 * (size_t)m->l_nulls;
     const int k_total = m->k_total, half_total = k_total / 2;
@@ -250,7 +258,7 @@ int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *m
         float er = cr * pr, ei = ci * pr;
         sp1r += er; sp1i += ei;
         angle_est = ora_atan2_approx(ei, er);
-        amp_est = sqrtf(cr * cr + ci * ci) / amp_pilot;
+        amp_est = recip ? sqrtf(cr * cr + ci * ci) * (1.0f / amp_pilot) : sqrtf(cr * cr + ci * ci) / amp_pilot;
     }
     for (int pass = 0; pass < 2; ++pass) {
         int lo = pass == 0 ? 1 : half_total + 1, hi = pass == 0 ? half_total : k_total;
@@ -275,7 +283,7 @@ int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *m
                 else if (dif_angle < -M_PIf) dif_angle = M_PIf * 2.0f + dif_angle;
                 if (pass == 0) sum_angle_1 += angle; else sum_angle_2 += angle;
                 delta_angle = (dif_angle) / (idx_data + 1);
-                amp = sqrtf(cr * cr + ci * ci) / amp_pilot;
+                amp = recip ? sqrtf(cr * cr + ci * ci) * (1.0f / amp_pilot) : sqrtf(cr * cr + ci * ci) / amp_pilot;
                 amp_pilot = amp_sp;
                 delta_amp = (amp - amp_est) / (idx_data + 1);
                 for (int j = 0; j < idx_data; ++j) {
@@ -308,4 +316,11 @@ int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *m
     }
     free(buf);
     return d;
+}
+
+/* kind inferred for callers that only equalise P2 / data symbols */
+int ora_data_symbol(const ora_mode *m, const float *ofdm_cell_full, const int *map, const float *refer, const int *h,
+                    float *out, float *sync)
+{
+    return ora_symbol_equalise(m, map[0] == P2CARRIER ? 0 : 1, ofdm_cell_full, map, refer, h, out, sync);
 }

@@ -291,9 +291,9 @@ def ora_data_symbol(m, idx_symbol, ofdm_cell):
     ncell = [m.c_p2, m.c_data, m.n_fc][kind]
     out = np.zeros(ncell, np.complex64)
     sync = np.zeros(2, np.float32)
-    fn = oracle().ora_data_symbol
-    fn.argtypes = [ctypes.c_void_p] * 7
-    n = fn(ctypes.addressof(m), x.ctypes.data, mp.ctypes.data, rf.ctypes.data, h.ctypes.data, out.ctypes.data, sync.ctypes.data)
+    fn = oracle().ora_symbol_equalise
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+    n = fn(ctypes.addressof(m), kind, x.ctypes.data, mp.ctypes.data, rf.ctypes.data, h.ctypes.data, out.ctypes.data, sync.ctypes.data)
     assert n == ncell, (n, ncell)
     return out, float(sync[0]), float(sync[1])
 
@@ -504,3 +504,303 @@ class OraP1(object):
         if getattr(self, "h", None):
             self.o.ora_p1_destroy(self.h)
             self.h = None
+
+
+# ---- the reference's own Qt classes compiled where they lie (oracle/_ref/libref_t2sym.so, libref_t2rx.so; container only) ----
+def _ref_lib(name):
+    if name not in _cache:
+        path = os.path.join(ROOT, "oracle", "_ref", "lib%s.so" % name)
+        try:
+            _cache[name] = ctypes.CDLL(path) if os.path.exists(path) else None
+        except OSError:                                    # e.g. on the GPU box: the FFTW binary the reference ships is not there
+            _cache[name] = None
+    return _cache[name]
+
+
+DVBT2_FIELDS = ("preamble", "bandwidth", "miso", "miso_group", "fft_mode", "fft_size", "guard_interval_mode", "guard_interval_size",
+                "carrier_mode", "l_nulls", "pilot_pattern", "papr_mode", "l1_mod", "l1_cod", "l1_fec_type", "l1_post_size",
+                "l1_post_info_size", "c_p2", "n_p2", "c_data", "c_fc", "n_fc", "k_total", "k_ext", "k_offset", "len_frame", "n_data",
+                "n_t2", "l_fc", "t2_version")
+L1_PRE_NAMES = ("type", "bwt_ext", "s1", "s2_field1", "s2_field2", "l1_repetition_flag", "guard_interval", "papr", "l1_post_mod", "l1_cod",
+                "l1_fec_type", "l1_post_size", "l1_post_info_size", "pilot_pattern", "tx_id_availability", "cell_id", "network_id",
+                "t2_system_id", "num_t2_frames", "num_data_symbols", "regen_flag", "l1_post_extension", "num_rf", "current_rf_index",
+                "t2_version", "l1_post_scrambled", "t2_base_lite", "reserved", "crc_32")
+
+
+class RefSym(object):
+    """The reference's pilot_generator / address_freq_deinterleaver / p2_symbol / data_symbol / fc_symbol, driven in the order
+    dvbt2_demodulator drives them (oracle/ref_t2sym.cpp). None-returning constructor helper: RefSym.open(...) gives None when the
+    library is not available."""
+
+    @staticmethod
+    def available():
+        return _ref_lib("ref_t2sym") is not None
+
+    def __init__(self, preamble, fft_mode, strict=False):
+        L = _ref_lib("ref_t2sym_strict" if strict else "ref_t2sym")
+        L.ref_sym_new.restype = ctypes.c_void_p
+        L.ref_sym_new.argtypes = [ctypes.c_int, ctypes.c_int]
+        for fn, n in (("ref_sym_params", 2), ("ref_sym_data_init", 1)):
+            getattr(L, fn).argtypes = [ctypes.c_void_p] * n
+        L.ref_sym_set_l1_pre.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+        L.ref_sym_p2.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 6
+        L.ref_sym_data.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
+        L.ref_sym_fc.argtypes = [ctypes.c_void_p] * 4
+        L.ref_sym_carriers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.ref_sym_freq_deint.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self.L, self.h = L, L.ref_sym_new(preamble, fft_mode)
+
+    def params(self):
+        v = np.zeros(30, np.int32)
+        self.L.ref_sym_params(self.h, v.ctypes.data)
+        return dict(zip(DVBT2_FIELDS, (int(x) for x in v)))
+
+    def set_l1_pre(self, bwt_ext, guard_interval, papr, pilot_pattern, num_data_symbols):
+        self.L.ref_sym_set_l1_pre(self.h, bwt_ext, guard_interval, papr, pilot_pattern, num_data_symbols)
+
+    def data_init(self):
+        return self.L.ref_sym_data_init(self.h)
+
+    def p2(self, ofdm_cell, demod_init):
+        p = self.params()
+        x = np.ascontiguousarray(ofdm_cell, np.complex64)
+        assert x.size == p["fft_size"]
+        out = np.zeros(p["c_p2"], np.complex64)
+        pre, post = np.zeros(29, np.int32), np.zeros(4096, np.int32)
+        flags, sync = np.zeros(2, np.int32), np.zeros(2, np.float32)
+        n = self.L.ref_sym_p2(self.h, int(demod_init), x.ctypes.data, out.ctypes.data, pre.ctypes.data, post.ctypes.data,
+                              flags.ctypes.data, sync.ctypes.data)
+        return dict(cells=out, l1_pre=dict(zip(L1_PRE_NAMES, (int(v) for v in pre))) if flags[0] else None,
+                    l1_post=post[:n].copy() if n else None, crc_pre=bool(flags[0]), crc_post=bool(flags[1]),
+                    sample_rate_offset=np.float32(sync[0]), phase_offset=np.float32(sync[1]))
+
+    def data(self, idx_symbol, ofdm_cell):
+        p = self.params()
+        x = np.ascontiguousarray(ofdm_cell, np.complex64)
+        out, sync = np.zeros(p["c_data"], np.complex64), np.zeros(2, np.float32)
+        self.L.ref_sym_data(self.h, idx_symbol, x.ctypes.data, out.ctypes.data, sync.ctypes.data)
+        return out, np.float32(sync[0]), np.float32(sync[1])
+
+    def fc(self, ofdm_cell):
+        p = self.params()
+        x = np.ascontiguousarray(ofdm_cell, np.complex64)
+        out, sync = np.zeros(p["n_fc"], np.complex64), np.zeros(2, np.float32)
+        self.L.ref_sym_fc(self.h, x.ctypes.data, out.ctypes.data, sync.ctypes.data)
+        return out, np.float32(sync[0]), np.float32(sync[1])
+
+    def carriers(self, kind, idx_symbol):
+        k = self.params()["k_total"]
+        mp, rf = np.zeros(k, np.int32), np.zeros(k, np.float32)
+        self.L.ref_sym_carriers(self.h, kind, idx_symbol, mp.ctypes.data, rf.ctypes.data)
+        return mp, rf
+
+    def freq_deint(self, kind):
+        p = self.params()
+        n = (p["c_p2"], p["c_data"], p["n_fc"])[kind]
+        he, ho = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.L.ref_sym_freq_deint(self.h, kind, he.ctypes.data, ho.ctypes.data)
+        return he, ho
+
+
+def unpack_l1_post(v):
+    """ref_sym_p2's flat l1_post -> dict (scalars, rf list, plp list with their dynamic part, aux list)."""
+    names = ("sub_slices_per_frame", "num_plp", "num_aux", "aux_config_rfu", "fef_type", "fef_length", "fef_interval", "fef_length_msb",
+             "reserved_2", "frame_idx", "sub_slice_interval", "type_2_start", "l1_change_counter", "start_rf_idx", "dyn_reserved_1",
+             "dyn_reserved_3", "num_rf")
+    v = [int(x) for x in v]
+    d = dict(zip(names, v[:17]))
+    p = 17
+    d["rf"] = [(v[p + 2 * i], v[p + 2 * i + 1]) for i in range(d["num_rf"])]
+    p += 2 * d["num_rf"]
+    plp_names = ("id", "plp_type", "plp_payload_type", "ff_flag", "first_rf_idx", "first_frame_idx", "plp_group_id", "plp_cod", "plp_mod",
+                 "plp_rotation", "plp_fec_type", "plp_num_blocks_max", "frame_interval", "time_il_length", "time_il_type",
+                 "in_band_a_flag", "in_band_b_flag", "reserved_1", "plp_mode", "static_flag", "static_padding_flag",
+                 "dyn_id", "dyn_start", "dyn_num_blocks", "dyn_reserved_2")
+    d["plp"] = []
+    for _ in range(d["num_plp"]):
+        d["plp"].append(dict(zip(plp_names, v[p:p + 25])))
+        p += 25
+    d["aux"] = [(v[p + 2 * i], v[p + 2 * i + 1]) for i in range(d["num_aux"])]
+    return d
+
+
+def pack_l1_post(plps, frame_idx=0):
+    """[(21 configurable ints as dict, dynamic dict)] -> the flat int array ref_t2rx's l1_holder reads."""
+    names = ("id", "plp_type", "plp_payload_type", "ff_flag", "first_rf_idx", "first_frame_idx", "plp_group_id", "plp_cod", "plp_mod",
+             "plp_rotation", "plp_fec_type", "plp_num_blocks_max", "frame_interval", "time_il_length", "time_il_type", "in_band_a_flag",
+             "in_band_b_flag", "reserved_1", "plp_mode", "static_flag", "static_padding_flag")
+    v = [len(plps)]
+    for cfg, dyn in plps:
+        v += [int(cfg.get(n, 0)) for n in names]
+        v += [int(dyn.get("id", cfg.get("id", 0))), int(dyn.get("start", 0)), int(dyn.get("num_blocks", 0)), 0]
+    v.append(frame_idx)
+    return np.array(v, np.int32)
+
+
+class _Taps(object):
+    def _drain(self, fn, which, dtype):
+        out = []
+        meta = (ctypes.c_int * 4)()
+        while True:
+            n = fn(self.h, which, meta, None, 0)
+            if n < 0:
+                break
+            buf = np.zeros(n, np.uint8)
+            fn(self.h, which, meta, buf.ctypes.data, n)
+            out.append((tuple(meta), buf.view(dtype).copy()))
+        return out
+
+
+class RefFec(_Taps):
+    """The reference's time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder -> bb_de_header chain on its own
+    QThreads (oracle/ref_t2rx.cpp). taps: 0 ti_block cells, 1 LLR batches, 2 LDPC bits, 3 descrambled BBFRAMEs, 5 messages."""
+
+    @staticmethod
+    def available(strict=False):
+        return _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx") is not None
+
+    def __init__(self, ts_path, need_plp=0, strict=False):
+        L = _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx")
+        L.ref_fec_new.restype = ctypes.c_void_p
+        L.ref_fec_new.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.ref_fec_keep.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.ref_fec_start.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.ref_fec_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.ref_fec_cells.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.ref_fec_tap.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ref_fec_close.argtypes = [ctypes.c_void_p]
+        self.L, self.ts_path = L, ts_path
+        self.h = L.ref_fec_new(ts_path.encode(), need_plp)
+
+    def start(self, l1_post_size, l1_post):
+        self.L.ref_fec_start(self.h, l1_post_size, l1_post.ctypes.data)
+
+    def frame(self, l1_post, cells):
+        c = np.ascontiguousarray(cells, np.complex64)
+        self.L.ref_fec_frame(self.h, l1_post.ctypes.data, c.size, c.ctypes.data)
+
+    def cells(self, cells):
+        c = np.ascontiguousarray(cells, np.complex64)
+        self.L.ref_fec_cells(self.h, c.size, c.ctypes.data)
+
+    def taps(self, which):
+        dt = {0: np.complex64, 1: np.int8, 2: np.uint8, 3: np.uint8, 5: np.uint8}[which]
+        return self._drain(self.L.ref_fec_tap, which, dt)
+
+    def ts(self):
+        self.L.ref_fec_close(self.h)
+        return np.fromfile(self.ts_path, np.uint8)
+
+
+class RefBbdh(_Taps):
+    """bb_de_header alone (bb_de_header.cpp:84-448): descrambled BBFRAME bits in, what it writes to its TS file out."""
+
+    def __init__(self, ts_path, need_plp=0, num_plp=1):
+        L = _ref_lib("ref_t2rx")
+        L.ref_bbdh_new.restype = ctypes.c_void_p
+        L.ref_bbdh_new.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        L.ref_bbdh_execute.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.ref_bbdh_tap.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ref_bbdh_close.argtypes = [ctypes.c_void_p]
+        self.L, self.ts_path = L, ts_path
+        self.h = L.ref_bbdh_new(ts_path.encode(), need_plp, num_plp)
+
+    def execute(self, plp_id, bits):
+        b = np.ascontiguousarray(bits, np.uint8)
+        self.L.ref_bbdh_execute(self.h, plp_id, b.size, b.ctypes.data)
+
+    def messages(self):
+        return [bytes(b).decode() for _, b in self._drain(self.L.ref_bbdh_tap, 5, np.uint8)]
+
+    def ts(self):
+        self.L.ref_bbdh_close(self.h)
+        return np.fromfile(self.ts_path, np.uint8)
+
+
+RX_STATE = ("c1", "c2", "level_detect", "phase_nco", "frequency_nco", "phase_est_filtered", "frequency_est_filtered",
+            "sample_rate_est_filtered", "resample", "next_symbol_type", "idx_symbol", "symbol_size", "idx_buffer_sym", "est_chunk", "chunk",
+            "p2_init", "demodulator_init", "deint_start", "crc32_l1_pre", "guard_interval_size", "fft_size", "dc_re", "dc_im")
+SIG_FIELDS = ("change_frequency", "coarse_freq_offset", "frequency_changed", "change_gain", "gain_offset", "gain_changed",
+              "correct_resample", "reset", "p1_reset")
+
+
+class RefRx(_Taps):
+    """The reference's dvbt2_demodulator (whole receiver) fed through its slot execute(len, i, q, signal_estimate*)."""
+
+    @staticmethod
+    def available(strict=False):
+        return _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx") is not None
+
+    def __init__(self, ts_path, id_device=0, sample_rate=64.0e6 / 7.0, need_plp=0, strict=False):
+        L = _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx")
+        L.ref_rx_new.restype = ctypes.c_void_p
+        L.ref_rx_new.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_char_p, ctypes.c_int]
+        L.ref_rx_keep.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.ref_rx_execute.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.ref_rx_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.ref_rx_set_loops.argtypes = [ctypes.c_void_p] + [ctypes.c_float] * 6
+        L.ref_rx_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.ref_rx_tap.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ref_rx_close.argtypes = [ctypes.c_void_p]
+        self.L, self.ts_path = L, ts_path
+        self.h = L.ref_rx_new(id_device, sample_rate, ts_path.encode(), need_plp)
+        self.sig = np.zeros(9, np.float64)
+
+    def keep(self, which, on):
+        self.L.ref_rx_keep(self.h, which, int(on))
+
+    def execute(self, i16, q16):
+        i16 = np.ascontiguousarray(i16, np.int16)
+        q16 = np.ascontiguousarray(q16, np.int16)
+        self.L.ref_rx_execute(self.h, i16.size, i16.ctypes.data, q16.ctypes.data, self.sig.ctypes.data)
+
+    def state(self):
+        v = np.zeros(23, np.float64)
+        self.L.ref_rx_state(self.h, v.ctypes.data)
+        return dict(zip(RX_STATE, v))
+
+    def set_loops(self, c1=0.0, c2=1.0, phase_est_filtered=0.0, frequency_est_filtered=0.0, phase_nco=0.0, frequency_nco=0.0):
+        self.L.ref_rx_set_loops(self.h, c1, c2, phase_est_filtered, frequency_est_filtered, phase_nco, frequency_nco)
+
+    def buffer(self, which, n):
+        out = np.zeros(n, np.complex64)
+        self.L.ref_rx_buffer(self.h, which, n, out.ctypes.data)
+        return out
+
+    def taps(self, which):
+        dt = {0: np.complex64, 1: np.int8, 2: np.uint8, 3: np.uint8, 4: np.complex64, 5: np.uint8}[which]
+        return self._drain(self.L.ref_rx_tap, which, dt)
+
+    def ts(self):
+        self.L.ref_rx_close(self.h)
+        return np.fromfile(self.ts_path, np.uint8)
+
+    def run_recording(self, i16, q16, buf):
+        """rx_sdrplay::start's loop (rx_sdrplay.cpp:135-261) over a recording: reset(), then per buffer set_rf_frequency /
+        set_gain bookkeeping and execute(). A recording cannot be re-tuned, so it must carry no carrier offset worth a re-tune
+        (|coarse_freq_offset| < 10 Hz). Returns the per-buffer states."""
+        s = self.sig
+        rf = [626.0e6]
+
+        def reset():
+            s[7] = 0; s[1] = 0.0; s[0] = 1; s[6] = 0.0; s[4] = 0; s[3] = 1
+
+        def set_rf():
+            if not s[2]:
+                s[2] = 1
+            if s[0]:
+                s[0] = 0; s[2] = 0
+                s[6] = s[1] / rf[0]
+                rf[0] += s[1]
+        reset()
+        set_rf()
+        log = []
+        for pos in range(0, len(i16) - buf + 1, buf):
+            if s[7]:
+                reset(); set_rf()
+                continue
+            set_rf()
+            s[5] = 1
+            self.execute(i16[pos:pos + buf], q16[pos:pos + buf])
+            log.append(self.state())
+        return log

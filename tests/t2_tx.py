@@ -394,3 +394,45 @@ def iq_stream(frames, guard, s2, snr_db, seed, rms=0.22, scale_bits=14, s1=0):
     i16 = np.clip(np.rint(x.real * q), -32768, 32767).astype(np.int16)
     q16 = np.clip(np.rint(x.imag * q), -32768, 32767).astype(np.int16)
     return i16, q16, len(parts[0])
+
+
+# ------------------------------------------------------------------------------------------------ whole-receiver test stream
+def rx_test_stream(n_frames, seed, cfo_hz, spoil_frame=None, l1_post_mod=0, plp=(1, 0, 1, 12.0)):
+    """int16 I/Q of n_frames T2 frames (16K extended PP7 GI 1/32, 24 data symbols + frame-closing symbol, 16-QAM 16200 r=3/5, real L1
+    signalling) with a carrier offset, padded to whole 2^18-sample buffers. Returns (mode, I, Q, buffer length, per-frame TS marks). spoil_frame: the P2 symbol of
+    that frame is blanked (L1-pre cannot pass its CRC there). plp = (modulation, fec type, code rate, SNR dB). The REFERENCE itself
+    only runs a subset: L1-post BPSK overruns a zero-size buffer (p2_symbol.cpp:405-409 allocates l1_post_size * l1_post_mod * 2) and
+    16-QAM / 256-QAM on 16200-bit frames never close a FEC block (llr_demapper.cpp:301,340: 16 / 32 LLRs per step do not divide
+    16200), so reference-run fixtures use l1_post_mod=1 and e.g. plp=(2, 0, 0, 18.0)."""
+    mode, lps, s2 = (4, 1, 6, 0, 0, 24), 400, 8
+    mod, fec_type, code_rate, snr = plp
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb = plp_blocks_per_frame(m, lps, cpf)
+    k_bch = K_BCH[cid]
+    per = nb * (k_bch // 1496 + 1)
+    ts = ts_packets(n_frames * per + 8, seed)
+    pre = dict(type=0, bwt_ext=mode[1], s1=0, s2_field1=4, guard_interval=mode[3], papr=0, l1_post_mod=l1_post_mod, l1_cod=0, l1_fec_type=0,
+               l1_post_size=lps, pilot_pattern=mode[2], num_t2_frames=2, num_data_symbols=mode[5], num_rf=1, t2_version=2)
+    plp = [dict(id=0, plp_type=1, plp_cod=code_rate, plp_mod=mod, plp_rotation=1, plp_fec_type=fec_type, plp_num_blocks_max=nb,
+                frame_interval=1, time_il_length=1, time_il_type=0, plp_mode=1)]
+    info = l1_post_bits(dict(), plp, [dict(id=0, start=0, num_blocks=nb)])
+    pre["l1_post_info_size"] = len(info)
+    l1c = np.concatenate([l1_pre_cells(pre, 3), l1_post_cells(info, l1_post_mod, lps, 4)])
+    frames = []
+    for f in range(n_frames):
+        cells, _, _ = build_plp_frame_cells(cid, mod, fec_type, code_rate, ts[f * per:(f + 1) * per], nb)
+        fr = build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c)
+        if f == spoil_frame:
+            fr[0] = 0
+        frames.append(fr)
+    i16, q16, flen = iq_stream(frames, m.fft_size // 32, s2, snr, seed)
+    x = (i16.astype(np.float64) + 1j * q16.astype(np.float64)) * np.exp(1j * (2 * np.pi * cfo_hz / (64e6 / 7) * np.arange(len(i16)) + 0.7))
+    buf = 1 << 18
+    x = np.concatenate([x, np.zeros((-len(x)) % buf)])
+    i16, q16 = np.rint(x.real).astype(np.int16), np.rint(x.imag).astype(np.int16)
+    dfl_bytes = (k_bch - 80) // 8
+    per_frame = (nb * dfl_bytes) // 187 - 1
+    marks = [ts[f * per:f * per + per_frame - 1].tobytes() for f in range(n_frames)]
+    return m, i16, q16, buf, marks

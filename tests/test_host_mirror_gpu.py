@@ -163,40 +163,10 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
 
 
 def _unconfigured_stream(tmp_path, n_frames, seed, cfo_hz, spoil_frame=None):
-    """int16 I/Q of n_frames T2 frames (16K extended PP7 GI 1/32, 24 data symbols + frame-closing symbol, 16-QAM 16200 r=3/5, real L1
-    signalling) with a carrier offset, written to tmp_path as i.s16 / q.s16 in 2^18-sample buffers. spoil_frame: the P2 symbol of
-    that frame is blanked (L1-pre cannot pass its CRC there)."""
-    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 0, 0, 24), 400, 1, 0, 1, 12.0, 8
-    m = ol.ora_mode(*mode)
-    cid = ol.code_id(fec_type, code_rate)
-    cpf = 16200 // (2 * (mod + 1))
-    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
-    k_bch = t2_tx.K_BCH[cid]
-    per = nb * (k_bch // 1496 + 1)
-    ts = t2_tx.ts_packets(n_frames * per + 8, seed)
-    pre = dict(type=0, bwt_ext=mode[1], s1=0, s2_field1=4, guard_interval=mode[3], papr=0, l1_post_mod=0, l1_cod=0, l1_fec_type=0,
-               l1_post_size=lps, pilot_pattern=mode[2], num_t2_frames=2, num_data_symbols=mode[5], num_rf=1, t2_version=2)
-    plp = [dict(id=0, plp_type=1, plp_cod=code_rate, plp_mod=mod, plp_rotation=1, plp_fec_type=fec_type, plp_num_blocks_max=nb,
-                frame_interval=1, time_il_length=1, time_il_type=0, plp_mode=1)]
-    info = t2_tx.l1_post_bits(dict(), plp, [dict(id=0, start=0, num_blocks=nb)])
-    pre["l1_post_info_size"] = len(info)
-    l1c = np.concatenate([t2_tx.l1_pre_cells(pre, 3), t2_tx.l1_post_cells(info, 0, lps, 4)])
-    frames = []
-    for f in range(n_frames):
-        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts[f * per:(f + 1) * per], nb)
-        fr = t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1c)
-        if f == spoil_frame:
-            fr[0] = 0
-        frames.append(fr)
-    i16, q16, flen = t2_tx.iq_stream(frames, m.fft_size // 32, s2, snr, seed)
-    x = (i16.astype(np.float64) + 1j * q16.astype(np.float64)) * np.exp(1j * (2 * np.pi * cfo_hz / (64e6 / 7) * np.arange(len(i16)) + 0.7))
-    buf = 1 << 18
-    x = np.concatenate([x, np.zeros((-len(x)) % buf)])
-    np.rint(x.real).astype(np.int16).tofile(tmp_path / "i.s16")
-    np.rint(x.imag).astype(np.int16).tofile(tmp_path / "q.s16")
-    dfl_bytes = (k_bch - 80) // 8
-    per_frame = (nb * dfl_bytes) // 187 - 1
-    marks = [ts[f * per:f * per + per_frame - 1].tobytes() for f in range(n_frames)]
+    """t2_tx.rx_test_stream written to tmp_path as i.s16 / q.s16 in 2^18-sample buffers."""
+    m, i16, q16, buf, marks = t2_tx.rx_test_stream(n_frames, seed, cfo_hz, spoil_frame)
+    i16.tofile(tmp_path / "i.s16")
+    q16.tofile(tmp_path / "q.s16")
     return m, buf, marks
 
 
