@@ -208,12 +208,18 @@ int t2gpu_ti_frame_plan(int num_plp, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn
  * the bytes to UDP 127.0.0.1:7654 or a file, here they are returned: the return value is the number of TS bytes placed in
  * out (out_cap >= len_in/8 + 376), or -1 BBHEADER CRC-8 error (frame dropped, :108-113), -2 frame skipped (other PLP,
  * :139-142, or SYNCD = 65535, :160-163), -3 bad arguments. *ts_errors counts packets flagged with TEI (normal mode).
- * t2gpu_bbdh_mode: 0 normal mode, 1 high-efficiency mode of the last accepted frame. */
+ * t2gpu_bbdh_mode: 0 normal mode, 1 high-efficiency mode of the last accepted frame. t2gpu_bbdh_resync_count: how many times
+ * the last call raised the reference's "Baseband header resynchronizing." (:218,235,369,384).
+ * Bounds (the reference has none: it trusts SYNCD / DFL, and in normal mode consumes 8 bits per packet more than it takes off
+ * DFL, :290-321): bits past len_in read as 0, never as memory; a frame whose SYNCD / DFL would write more than out_cap bytes is
+ * refused with -3 and the packet state is reset. Byte-identical to the reference's class on tests/golden/t2fec_golden.npz
+ * ("bbdh/...": HEM, NM as written, lost frames, other PLP, broken header, SYNCD 0xFFFF). */
 typedef struct t2gpu_bbdh t2gpu_bbdh;
 t2gpu_bbdh *t2gpu_bbdh_create(int need_plp);
 void t2gpu_bbdh_destroy(t2gpu_bbdh *h);
 int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap, int *ts_errors);
 int t2gpu_bbdh_mode(const t2gpu_bbdh *h);
+int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h);
 
 /* ---------------------------------------------------------------- OFDM side: FFT and data-symbol equaliser ----------
  * Mode arguments are the reference's dvbt2_parameters fields (src/DVB_T2/dvbt2_definition.h:215-248): fft_mode
@@ -309,6 +315,7 @@ int t2gpu_front_reset(t2gpu_front *h); /* dvbt2_demodulator::reset, :111-127 */
 int t2gpu_front_reset_loops(t2gpu_front *h);
 /* frequency_nco = value (set_guard_interval_by_brute_force zeroes it, :486-487) */
 int t2gpu_front_set_frequency_nco(t2gpu_front *h, float frequency_nco);
+int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2); /* c1 / c2 as a previous execute() left them (:228-234); test set-up */
 /* One execute() of the reference = several calls here when the loops are closed (one per chunk). hold = 1: the calls only add
  * to the sign statistics; t2gpu_front_commit_iq at the end of the execute() derives c1 / c2 / level_detect from all of them
  * (:227-235) for the NEXT execute(), as the reference does. hold = 0 (default): every call is an execute() of its own. */

@@ -55,7 +55,9 @@ public:
     void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, int8_t *in)
     {
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
-        t2gpu_ldpc *&h = gpu_[p.plp_fec_type & 1][p.plp_cod % 6];
+        if (p.plp_cod < 0 || p.plp_cod > 5 || p.plp_fec_type < 0 || p.plp_fec_type > 1)    // T2-Lite codes 6, 7: not in the reference's switch (:173-246)
+            fail("ldpc_decoder: PLP_COD / PLP_FEC_TYPE outside the reference's twelve codes");
+        t2gpu_ldpc *&h = gpu_[p.plp_fec_type][p.plp_cod];
         if (!h && !(h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
         int k_ldpc = 0;
         t2gpu_ldpc_info(h, nullptr, &k_ldpc, nullptr, nullptr);
@@ -90,7 +92,9 @@ public:
     void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, uint8_t *in)
     {
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
-        const int k_ldpc = ldpc_k(p.plp_fec_type, p.plp_cod), frames = len_in / k_ldpc;
+        const int k_ldpc = ldpc_k(p.plp_fec_type, p.plp_cod);
+        if (k_ldpc < 0) fail("bch_decoder: PLP_COD outside the reference's twelve codes");
+        const int frames = len_in / k_ldpc;
         out_.resize((size_t)len_in);
         if (outer_code) {
             outer_code_status.assign((size_t)frames, 0);
@@ -105,7 +109,8 @@ private:
     static int ldpc_k(int fec_type, int cod)
     {
         static const int kn[6] = {32400, 38880, 43200, 48600, 51840, 54000}, ks[6] = {7200, 9720, 10800, 11880, 12600, 13320};
-        return fec_type ? kn[cod % 6] : ks[cod % 6];                  // k_ldpc, ldpc_decoder.cpp:177-246
+        if (cod < 0 || cod > 5) return -1;
+        return fec_type ? kn[cod] : ks[cod];                          // k_ldpc, ldpc_decoder.cpp:177-246
     }
     std::vector<uint8_t> out_;
 };

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "t2gpu_l1_post_parse": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int]),
     "t2gpu_front_reset_loops": (ctypes.c_int, [_vp]),
     "t2gpu_front_set_frequency_nco": (ctypes.c_int, [_vp, ctypes.c_float]),
+    "t2gpu_front_set_iq": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_front_hold_iq": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_front_commit_iq": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_sync_reset": (None, [_vp, ctypes.c_float]),
@@ -87,6 +88,7 @@ PROTOTYPES = {
     "t2gpu_bbdh_destroy": (None, [_vp]),
     "t2gpu_bbdh_execute": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     "t2gpu_bbdh_mode": (ctypes.c_int, [_vp]),
+    "t2gpu_bbdh_resync_count": (ctypes.c_int, [_vp]),
     "t2gpu_ofdm_create": (_vp, [ctypes.c_int] * 8),
     "t2gpu_ofdm_destroy": (None, [_vp]),
     "t2gpu_fft_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),

@@ -24,14 +24,30 @@ struct t2gpu_bbdh {
     bool split = false;
     uint8_t buffer[188];
     int last_mode = -1;
+    int resync = 0;                                    // "Baseband header resynchronizing." raised by the last call (:218,235,369,384)
 };
 
-static inline uint8_t take_byte(const uint8_t *&in)
-{
-    uint8_t t = 0;
-    for (int n = 7; n >= 0; --n) t |= (uint8_t)((*in++ & 1) << n);
-    return t;
-}
+// Bit reader bounded by the frame: the reference trusts SYNCD / DFL and, in normal mode, consumes 8 bits per packet more than it
+// takes off DFL (:290-321), so it reads past the frame it was given. Bits past the end read as 0 here (what the reference sees
+// when the frame sits in a zeroed buffer) -- never memory outside bits[0 .. len_in).
+struct BitSrc {
+    const uint8_t *p, *end;
+    uint8_t byte()
+    {
+        uint8_t t = 0;
+        for (int n = 7; n >= 0; --n, ++p) if (p < end) t |= (uint8_t)((*p & 1) << n);
+        return t;
+    }
+    void skip(long n) { p += n; }                      // may run past end: byte() then yields zeros
+};
+// Byte sink bounded by out_cap: the reference's buffer is a fixed 53840/8 + 376 bytes (:35-38) which a wild SYNCD overruns; here
+// the frame is refused instead (full = true -> -3).
+struct ByteSink {
+    uint8_t *o, *end;
+    int n = 0;
+    bool full = false;
+    void put(uint8_t v) { if (o < end) { *o++ = v; ++n; } else full = true; }
+};
 
 extern "C" t2gpu_bbdh *t2gpu_bbdh_create(int need_plp)
 {
@@ -54,13 +70,14 @@ extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const u
                                   int *ts_errors)
 {
     if (!h || !bits || !out || len_in < BBH_BITS || out_cap < len_in / 8 + 2 * TS_LEN) { set_error("t2gpu_bbdh_execute: bad arguments"); return -3; }
-    const uint8_t *in = bits;
-    int errors = 0, len_out = 0;
-    uint8_t *o = out, *tei = nullptr;
+    BitSrc in{bits, bits + len_in};
+    ByteSink snk{out, out + out_cap};
+    int errors = 0;
+    uint8_t *tei = nullptr;
     // BBHEADER CRC over its 80 bits: remainder 0 = normal mode, 0xAB = high-efficiency mode (CRC-8 xor MODE), :70-82,101-113
     uint8_t c = 0;
     for (int i = 0; i < BBH_BITS; ++i) {
-        uint8_t b = (uint8_t)((in[i] & 1) ^ (c & 0x01));
+        uint8_t b = (uint8_t)((bits[i] & 1) ^ (c & 0x01));
         c >>= 1;
         if (b) c ^= CRC_POLY;
     }
@@ -69,60 +86,62 @@ extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const u
     else if (c == CRC_POLY) hem = 1;
     else return -1;                                    // "Baseband header CRC8 error.": frame dropped
     h->last_mode = hem;
-    in += 2 + 1 + 1 + 1 + 1 + 2;                       // TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT
-    in += 8;                                           // ISI
     if (h->need_plp != plp_id) return -2;              // :139-142
+    const uint8_t *hp = bits + 16;                     // MATYPE (TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT | ISI): not used by the data path
     int upl = 0, dfl = 0, sync = 0, syncd = 0;
-    for (int i = 15; i >= 0; --i) upl |= (*in++ & 1) << i;
-    for (int i = 15; i >= 0; --i) dfl |= (*in++ & 1) << i;
-    for (int i = 7; i >= 0; --i) sync |= (*in++ & 1) << i;
-    for (int i = 15; i >= 0; --i) syncd |= (*in++ & 1) << i;
+    for (int i = 15; i >= 0; --i) upl |= (*hp++ & 1) << i;
+    for (int i = 15; i >= 0; --i) dfl |= (*hp++ & 1) << i;
+    for (int i = 7; i >= 0; --i) sync |= (*hp++ & 1) << i;
+    for (int i = 15; i >= 0; --i) syncd |= (*hp++ & 1) << i;
     (void)upl; (void)sync;
     if (syncd == 65535) return -2;                     // no user packet starts in this frame (:160-163)
-    in += 8;                                           // CRC-8 field
-    if (dfl > len_in - BBH_BITS) { set_error("t2gpu_bbdh_execute: DFL exceeds the frame"); return -3; }
+    in.skip(BBH_BITS);
+    h->resync = 0;
 
-    if (!hem) {                                        // ---- normal mode (:166-335): CRC-8 of the previous packet replaces the sync byte
+    if (!hem) {                                        // ---- normal mode (:166-322): CRC-8 of the previous packet replaces the sync byte
         if (h->split) {
             h->split = false;
-            if (h->idx_buffer > 0) { *o++ = h->buffer[0]; ++len_out; tei = o; }
-            for (int i = 1; i < h->idx_buffer; ++i) { *o++ = h->buffer[i]; ++len_out; }
+            if (h->idx_buffer > 0) { snk.put(h->buffer[0]); tei = snk.full ? nullptr : snk.o; }
+            for (int i = 1; i < h->idx_buffer; ++i) snk.put(h->buffer[i]);
             const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
             if (len_split <= syncd_byte) {
-                const int take = (len_split == syncd_byte) ? len_split : syncd_byte;
+                const int take = (len_split == syncd_byte) ? len_split : syncd_byte;     // as written: the longer run when they disagree
                 for (int i = 0; i < take; ++i) {
-                    uint8_t t = take_byte(in);
+                    uint8_t t = in.byte();
                     h->crc = h->crc_table[t ^ h->crc];
-                    *o++ = t; ++len_out; ++h->idx_packet;
+                    snk.put(t); ++h->idx_packet;
                 }
-                uint8_t t = take_byte(in);
-                if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                uint8_t t = in.byte();
+                if (t != h->crc) { ++errors; if (tei && tei < snk.end) *tei |= TEI; }
                 h->crc = 0;
+                if (len_split != syncd_byte) ++h->resync;
             } else {
-                for (int i = 0; i < syncd_byte; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
-                for (int i = 0; i < len_split - syncd_byte; ++i) { *o++ = 0xF0; ++len_out; ++h->idx_packet; }
+                for (int i = 0; i < syncd_byte; ++i) { snk.put(in.byte()); ++h->idx_packet; }
+                for (int i = 0; i < len_split - syncd_byte; ++i) { snk.put(0xF0); ++h->idx_packet; }
                 ++errors;
-                if (tei) *tei |= TEI;
+                if (tei && tei < snk.end) *tei |= TEI;
+                ++h->resync;
             }
         } else {
-            in += syncd + 8;
+            in.skip(syncd + 8);
         }
         dfl -= syncd + 8;
-        while (dfl > 0) {
+        while (dfl > 0 && !snk.full) {
             if (dfl < BIT_PACKET) {
                 h->split = true;
                 const int len_split = dfl / 8;
                 h->idx_buffer = 0;
-                for (int i = 0; i < len_split; ++i) {
+                for (int i = 0; i < len_split && h->idx_buffer < TS_LEN; ++i) {
                     if (h->idx_packet == TS_LEN) {
                         h->idx_packet = 0;
-                        uint8_t t = take_byte(in);
-                        if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                        uint8_t t = in.byte();
+                        if (t != h->crc) { ++errors; if (tei && tei < snk.end) *tei |= TEI; }
                         h->crc = 0;
                         h->buffer[h->idx_buffer++] = 0x47;
                         ++h->idx_packet;
+                        if (h->idx_buffer == TS_LEN) break;
                     }
-                    uint8_t t = take_byte(in);
+                    uint8_t t = in.byte();
                     h->crc = h->crc_table[t ^ h->crc];
                     h->buffer[h->idx_buffer++] = t;
                     ++h->idx_packet;
@@ -131,62 +150,71 @@ extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const u
             } else {
                 if (h->idx_packet == TS_LEN) {
                     h->idx_packet = 0;
-                    uint8_t t = take_byte(in);
-                    if (t != h->crc) { ++errors; if (tei) *tei |= TEI; }
+                    uint8_t t = in.byte();             // the CRC byte: consumed, but DFL is NOT reduced for it (the reference's slip, :290-300)
+                    if (t != h->crc) { ++errors; if (tei && tei < snk.end) *tei |= TEI; }
                     h->crc = 0;
                 }
                 if (h->idx_packet == 0) {
-                    *o++ = 0x47; ++len_out; ++h->idx_packet;
-                    tei = o;
+                    snk.put(0x47); ++h->idx_packet;
+                    tei = snk.full ? nullptr : snk.o;
                 }
-                uint8_t t = take_byte(in);
+                uint8_t t = in.byte();
                 h->crc = h->crc_table[t ^ h->crc];
-                *o++ = t; ++len_out; ++h->idx_packet;
+                snk.put(t); ++h->idx_packet;
                 dfl -= 8;
             }
         }
-    } else {                                           // ---- high-efficiency mode (:336-432): 187-byte packets, sync re-inserted
+    } else {                                           // ---- high-efficiency mode (:323-417): 187-byte packets, sync re-inserted
         if (h->split) {
             h->split = false;
-            for (int i = 0; i < h->idx_buffer; ++i) { *o++ = h->buffer[i]; ++len_out; }
+            for (int i = 0; i < h->idx_buffer; ++i) snk.put(h->buffer[i]);
             const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
             if (len_split <= syncd_byte) {
-                for (int i = 0; i < len_split; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
-                if (len_split < syncd_byte) in += syncd - len_split * 8;
+                for (int i = 0; i < len_split; ++i) { snk.put(in.byte()); ++h->idx_packet; }
+                if (len_split < syncd_byte) { in.skip(syncd - len_split * 8); ++h->resync; }
             } else {
-                for (int i = 0; i < syncd_byte; ++i) { *o++ = take_byte(in); ++len_out; ++h->idx_packet; }
-                for (int i = 0; i < len_split - syncd_byte; ++i) { *o++ = 0xF0; ++len_out; ++h->idx_packet; }
+                for (int i = 0; i < syncd_byte; ++i) { snk.put(in.byte()); ++h->idx_packet; }
+                for (int i = 0; i < len_split - syncd_byte; ++i) { snk.put(0xF0); ++h->idx_packet; }
+                ++h->resync;
             }
         } else {
-            in += syncd;
+            in.skip(syncd);
         }
         dfl -= syncd;
-        while (dfl > 0) {
+        while (dfl > 0 && !snk.full) {
             if (dfl < BIT_PACKET) {
                 h->split = true;
                 const int len_split = dfl / 8;
                 h->idx_buffer = 0;
-                for (int i = 0; i < len_split; ++i) {
+                for (int i = 0; i < len_split && h->idx_buffer < TS_LEN; ++i) {
                     if (h->idx_packet == TS_LEN) {
                         h->idx_packet = 0;
                         h->buffer[h->idx_buffer++] = 0x47;
                         ++h->idx_packet;
+                        if (h->idx_buffer == TS_LEN) break;
                     }
-                    h->buffer[h->idx_buffer++] = take_byte(in);
+                    h->buffer[h->idx_buffer++] = in.byte();
                     ++h->idx_packet;
                 }
                 dfl = 0;
             } else {
                 if (h->idx_packet == TS_LEN || h->idx_packet == 0) {
                     h->idx_packet = 0;
-                    *o++ = 0x47; ++len_out; ++h->idx_packet;
+                    snk.put(0x47); ++h->idx_packet;
                 } else {
-                    *o++ = take_byte(in); ++len_out; ++h->idx_packet;
+                    snk.put(in.byte()); ++h->idx_packet;
                     dfl -= 8;
                 }
             }
         }
     }
+    if (snk.full) {                                    // SYNCD / DFL ask for more bytes than the contract's out_cap: refuse, resynchronise on the next frame
+        h->split = false; h->idx_packet = 0; h->idx_buffer = 0; h->crc = 0;
+        set_error("t2gpu_bbdh_execute: SYNCD/DFL of this frame would overrun the output buffer");
+        return -3;
+    }
     if (ts_errors) *ts_errors = errors;
-    return len_out;
+    return snk.n;
 }
+
+extern "C" int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h) { return h ? h->resync : 0; }

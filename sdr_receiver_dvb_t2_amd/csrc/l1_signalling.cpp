@@ -95,7 +95,13 @@ extern "C" int t2gpu_l1_post_parse(const float *l1_post_cells, const t2gpu_l1_pr
     BitReader r{bits.data(), 0};
     memset(post, 0, sizeof(*post));
     post->sub_slices_per_frame = r.get(15); post->num_plp = r.get(8); post->num_aux = r.get(4); post->aux_config_rfu = r.get(8);
-    if (post->num_plp > max_plp || pre->num_rf > 7) { set_error("t2gpu_l1_post_parse: more PLPs / RFs than the caller provides room for"); return -1; }
+    if (post->num_plp > max_plp || pre->num_rf > 7 || pre->num_rf < 0) { set_error("t2gpu_l1_post_parse: more PLPs / RFs than the caller provides room for"); return -1; }
+    {   // the signalled counts fix the length of everything that follows (EN 302 755 7.2.3): check it BEFORE walking the fields -- the
+        // reference indexes its bit array with offsets derived from the same counts and never looks at the block size (:680-697)
+        const long need = 35L + 35L * pre->num_rf + ((pre->s2_field2 & 1) ? 34 : 0) + 89L * post->num_plp + 32 + 32L * post->num_aux
+                          + 71 + 48L * post->num_plp + 8 + 48L * post->num_aux;
+        if (need > pre->l1_post_info_size) { set_error("t2gpu_l1_post_parse: fields run past L1_POST_INFO_SIZE"); return -1; }
+    }
     for (int i = 0; i < pre->num_rf; ++i) { post->rf_idx[i] = r.get(3); post->frequency[i] = (uint32_t)r.get(32); }
     if (pre->s2_field2 & 1) { post->fef_type = r.get(4); post->fef_length = r.get(22); post->fef_interval = r.get(8); }
     for (int i = 0; i < post->num_plp; ++i) {

@@ -34,6 +34,10 @@ struct EqParams {
     // LDS staging of the equaliser (EQ_GROUP consecutive segments per workgroup): the widest carrier span / data-cell span any
     // group of this table covers (host-computed, sizes the dynamic LDS)
     int lds_span = 0, lds_dspan = 0;
+    // P2 and frame-closing tables: the pilot amplitude never changes inside p2_symbol::execute / fc_symbol::execute, and the
+    // reference binary (-Ofast, sdr_receiver_dvb_t2.pro:33-39) evaluates sqrt(norm(cell)) / amp_pilot as a product with
+    // 1 / amp_pilot there; data_symbol::execute, whose amplitude alternates, keeps the division. Pinned by tests/golden/t2sym_golden.npz.
+    int recip_amp = 0;
 };
 constexpr int EQ_GROUP = 64;
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,

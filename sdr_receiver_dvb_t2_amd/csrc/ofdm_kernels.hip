@@ -194,12 +194,13 @@ __device__ __forceinline__ float atan2_approx_dev(float y, float x)         // D
 
 struct PilotEst { float angle, amp, er, ei; };
 
-__device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, float amp_pilot)
+__device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, float amp_pilot, int recip)
 {
     PilotEst p;
     p.er = cell.x * refer; p.ei = cell.y * refer;                              // est_pilot = cell * pilot_refer
     p.angle = atan2_approx_dev(p.ei, p.er);
-    p.amp = sqrtf(cell.x * cell.x + cell.y * cell.y) / amp_pilot;              // sqrt(norm(cell)) / amp_pilot
+    const float mag = sqrtf(cell.x * cell.x + cell.y * cell.y);
+    p.amp = recip ? mag * (1.0f / amp_pilot) : mag / amp_pilot;                // sqrt(norm(cell)) / amp_pilot (EqParams::recip_amp)
     return p;
 }
 
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p
     // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
     // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
     const uint8_t tl = l_map[pl - c0], tr = l_map[pr - c0];
-    const PilotEst L = pilot_estimate(ld(pl), refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
-    const PilotEst R = pilot_estimate(ld(pr), refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp));
+    const PilotEst L = pilot_estimate(ld(pl), refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
+    const PilotEst R = pilot_estimate(ld(pr), refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
     float dif_angle = R.angle - L.angle;
     if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                      // as written in the reference (:189-191)
     else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;

@@ -333,6 +333,10 @@ extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells,
 extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out)
 {
     if (!h || !cells || !out || !h->num_blocks) { set_error("t2gpu_ti_push: bad arguments"); return -1; }
+    if (n_cells < 0 || (long)h->pos + n_cells > (long)h->p.ti_block_size) {      // before anything is copied into the staging buffer
+        set_error("t2gpu_ti_push: n_cells runs past the TI block");
+        return -1;
+    }
     T2_HIP(hipSetDevice(h->device));
     const size_t cap = (size_t)h->num_blocks_max * h->cells_per_fec * 8;
     if (!h->d_in) { T2_HIP(hipMalloc(&h->d_in, cap)); T2_HIP(hipMalloc(&h->d_out, cap)); }
@@ -386,13 +390,12 @@ extern "C" int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *
     static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
     uint8_t *d_in = nullptr, *d_out = nullptr;
     const size_t in_b = (size_t)n_frames * k_ldpc[id], out_b = (size_t)n_frames * ldpc_k_bch(id);
-    T2_HIP(hipMalloc(&d_in, in_b));
-    T2_HIP(hipMalloc(&d_out, out_b));
-    T2_HIP(hipMemcpy(d_in, bits, in_b, hipMemcpyHostToDevice));
-    int kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, d_out, nullptr);
-    if (kb > 0) {
-        T2_HIP(hipDeviceSynchronize());
-        T2_HIP(hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost));
+    int kb = -1;                                                              // staging buffers are released on every path
+    if (hip_ok(hipMalloc(&d_in, in_b), "hipMalloc") && hip_ok(hipMalloc(&d_out, out_b), "hipMalloc") &&
+        hip_ok(hipMemcpy(d_in, bits, in_b, hipMemcpyHostToDevice), "hipMemcpy")) {
+        kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, d_out, nullptr);
+        if (kb > 0 && !(hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
+                        hip_ok(hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost), "hipMemcpy"))) kb = -1;
     }
     hipFree(d_in); hipFree(d_out);
     return kb;

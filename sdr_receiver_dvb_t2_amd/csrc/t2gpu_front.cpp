@@ -227,6 +227,20 @@ extern "C" int t2gpu_front_set_frequency_nco(t2gpu_front *h, float frequency_nco
     return 0;
 }
 
+// c1 / c2 as a previous execute() would have left them (dvbt2_demodulator.cpp:228-234): lets a test start the sample loop from the
+// state the reference's object was in when a fixture was recorded
+extern "C" int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2)
+{
+    if (!h) return -1;
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize(h->last_stream));
+    FrontState s;
+    T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+    s.c1 = c1; s.c2 = c2;
+    T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    return 0;
+}
+
 extern "C" int t2gpu_front_hold_iq(t2gpu_front *h, int hold)
 {
     if (!h) return -1;

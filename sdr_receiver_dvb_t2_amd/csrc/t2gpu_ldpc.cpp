@@ -150,6 +150,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         set_error("t2gpu_ldpc_execute_dev: bad arguments");
         return -1;
     }
+    T2_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int group = h->group;
     const int nbatches = (n_frames + group - 1) / group;

@@ -171,13 +171,19 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     up(&h->d_seg_count, segcount.data(), segcount.size() * 4);
     up(&h->d_h_even, he.data(), he.size() * 4);
     up(&h->d_h_odd, ho.data(), ho.size() * 4);
-    // the P2 symbol: one table row of its own (pilots every 3rd / 6th carrier, c_p2 cells, P2 frequency de-interleaver)
+    // the P2 symbol: one table row of its own (pilots every 3rd / 6th carrier, c_p2 cells, P2 frequency de-interleaver) -- built
+    // for EXTENDED carriers whatever the mode: the reference's p2_symbol keeps the tables of init_dvbt2 (dvbt2_p2_parameters_init
+    // forces CARRIERS_EXTENDED, dvbt2_definition.cpp:88-90) and never rebuilds them after L1-pre, so a normal-carrier signal's P2 is
+    // read with k_ext noise carriers on either side taken for pilots (c_p2 is the same in both modes, the data cells line up)
+    T2Mode mP2;
+    mode_from_args(mP2, fft_mode, 1, pilot_pattern, guard_interval_mode, papr_mode, n_data);
+    const int K2 = mP2.k_total;
     std::vector<uint8_t> mp2; std::vector<float> rf2; std::vector<int4> seg2;
-    t2_symbol_carriers(m, 0, mp2, rf2);
-    if (build_segments(mp2, K, seg2) != m.c_p2) { set_error("P2 carrier map does not hold c_p2 data cells"); t2gpu_ofdm_destroy(h); return nullptr; }
+    t2_symbol_carriers(mP2, 0, mp2, rf2);
+    if (build_segments(mp2, K2, seg2) != m.c_p2) { set_error("P2 carrier map does not hold c_p2 data cells"); t2gpu_ofdm_destroy(h); return nullptr; }
     const int32_t nseg2 = (int32_t)seg2.size();
     std::vector<int32_t> he2, ho2;
-    t2_freq_deint(m, 0, he2, ho2);
+    t2_freq_deint(mP2, 0, he2, ho2);
     up(&h->d_map_p2, mp2.data(), mp2.size());
     up(&h->d_refer_p2, rf2.data(), rf2.size() * 4);
     up(&h->d_segs_p2, seg2.data(), seg2.size() * sizeof(int4));
@@ -213,8 +219,10 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     if (m.l_fc)
         h->eq_fc = EqParams{N, m.l_nulls, K, m.n_fc, m.len_frame - 1, nseg3, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_fc, h->d_refer_fc,
                             h->d_segs_fc, h->d_seg_count_fc, h->d_h_even_fc, h->d_h_odd_fc, h->d_lut, h->d_lut + 65536};
-    h->eq_p2 = EqParams{N, m.l_nulls, K, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
+    h->eq_p2 = EqParams{N, mP2.l_nulls, K2, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
                         h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut, h->d_lut + 65536};
+    h->eq_p2.recip_amp = 1;
+    h->eq_fc.recip_amp = 1;
     // widest carrier / data-cell span of any EQ_GROUP consecutive segments, per table (sizes the equaliser's LDS staging)
     auto spans = [](const std::vector<int4> &sg, int &span, int &dspan) {
         for (size_t g0 = 0; g0 < sg.size(); g0 += EQ_GROUP) {

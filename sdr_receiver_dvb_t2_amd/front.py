@@ -41,6 +41,10 @@ class front_end(object):
         if self._l.t2gpu_front_reset(self.h) != 0:
             _err("t2gpu_front_reset")
 
+    def set_iq(self, c1, c2):
+        if self._l.t2gpu_front_set_iq(self.h, float(c1), float(c2)) != 0:
+            _err("t2gpu_front_set_iq")
+
     @staticmethod
     def _loops(n_chunks, pe, fe, rs):
         pe = np.ascontiguousarray(np.zeros(n_chunks) if pe is None else pe, np.float32)

@@ -55,3 +55,68 @@ def test_drop_rules(l):
     n, out, _ = run(l, h, np.ascontiguousarray(frames[0]))
     assert n > 0 and out[0] == 0x47
     l.t2gpu_bbdh_destroy(h)
+
+
+# ---- against the reference's own class (tests/golden/t2fec_golden.npz "bbdh/...", made by tests/golden/make_t2_golden.py) ----
+import os
+
+import bbdh_cases
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t2fec_golden.npz")) as z:
+        return {k[len("bbdh/bbdh/"):]: z[k] for k in z.files if k.startswith("bbdh/bbdh/")}
+
+
+@pytest.mark.parametrize("name", list(bbdh_cases.cases()))
+def test_equals_the_reference_class(l, gold, name):
+    """Every TS byte bb_de_header::execute wrote for these BBFRAME sequences -- high-efficiency and normal mode (the latter with
+    the reference's DFL slip), lost frames (both re-synchronisation branches), a frame of another PLP, a broken header CRC,
+    SYNCD = 0xFFFF, a multiple-input-stream header -- and its message counts."""
+    k_bch, frames, plps = bbdh_cases.cases()[name]
+    h = l.t2gpu_bbdh_create(0)
+    got, rcs, resync, errs = [], [], 0, 0
+    for bits, plp in zip(frames, plps):
+        n, out, err = run(l, h, np.ascontiguousarray(bits), plp)
+        rcs.append(n)
+        if n >= 0:
+            got.append(out)
+            resync += l.t2gpu_bbdh_resync_count(h)
+            errs += 1 if err else 0
+    l.t2gpu_bbdh_destroy(h)
+    got = np.concatenate(got) if got else np.zeros(0, np.uint8)
+    assert np.array_equal(got, gold["ts_" + name])
+    msgs = [str(s) for s in gold["msg_" + name]]
+    assert resync == sum("resynchronizing" in s for s in msgs)
+    assert errs == sum(s == "TS error." for s in msgs)
+    assert rcs.count(-1) == sum("CRC8" in s for s in msgs)
+
+
+def test_wild_syncd_and_dfl_stay_inside_the_buffers(l):
+    """SYNCD is 16 bits the reference trusts. A CRC-valid header with SYNCD = 60000 after a pending split packet asks
+    for 7500 bytes from a 7032-bit frame: reads stay inside the frame (zeros beyond), writes inside out_cap (the frame is refused
+    with -3 when they would not fit), and the next good frame decodes again. Run under guard bytes on both sides."""
+    k_bch = bbdh_cases.K_BCH
+    ts = t2_tx.ts_packets(60, 5)
+    for maker, hem in ((bbdh_cases.hem_frames, True), (bbdh_cases.nm_frames, False)):
+        fr = maker(ts, 4)
+        wild = fr[1].copy()
+        dfl = int("".join(str(b) for b in wild[32:48]), 2)
+        wild[:80] = bbdh_cases._header(dfl, 60000, hem, upl=(0 if hem else 1504), sync=(0 if hem else 0x47))
+        big = fr[1].copy()
+        big[:80] = bbdh_cases._header(65528, int("".join(str(b) for b in big[56:72]), 2), hem, upl=(0 if hem else 1504), sync=(0 if hem else 0x47))
+        h = l.t2gpu_bbdh_create(0)
+        guard = 4096
+        for frame in (fr[0], wild, fr[2], big, fr[3]):
+            inbuf = np.full(guard + k_bch + guard, 0xA5, np.uint8)
+            inbuf[guard:guard + k_bch] = frame
+            cap = k_bch // 8 + 400
+            outbuf = np.full(guard + cap + guard, 0x5A, np.uint8)
+            err = ctypes.c_int(0)
+            n = l.t2gpu_bbdh_execute(h, 0, k_bch, inbuf[guard:].ctypes.data, outbuf[guard:].ctypes.data, cap, ctypes.byref(err))
+            assert n <= cap
+            assert (outbuf[:guard] == 0x5A).all() and (outbuf[guard + cap:] == 0x5A).all()
+            if n > 0:                                              # nothing of the guard pattern was read into the output
+                assert not np.array_equal(outbuf[guard:guard + 8], np.full(8, 0xA5, np.uint8))
+        l.t2gpu_bbdh_destroy(h)
