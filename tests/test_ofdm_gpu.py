@@ -117,8 +117,11 @@ def test_p2_equaliser_matches_oracle(torch_cuda, mode):
     syms = np.stack([make_symbol(m, 0, seed=s) for s in range(3)])
     cells, sync = ctx.eq_p2_dev(torch.from_numpy(syms.view(np.float32).reshape(3, m.fft_size, 2)).cuda())
     cells = cells.cpu().numpy(); sync = sync.cpu().numpy()
+    # P2 is read with the extended-carrier tables whatever the mode (p2_symbol::init -> dvbt2_p2_parameters_init,
+    # dvbt2_definition.cpp:88-90; pinned by tests/golden/t2sym_golden.npz "n32k_pp4")
+    mp2 = ol.ora_mode(mode[0], 1, *mode[2:])
     for b in range(3):
-        want, pho, sro = ol.ora_data_symbol(m, 0, syms[b])
+        want, pho, sro = ol.ora_data_symbol(mp2, 0, syms[b])
         got = (cells[b, :, 0] + 1j * cells[b, :, 1]).astype(np.complex64)
         assert np.array_equal(got, want)
         assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
