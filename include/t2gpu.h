@@ -507,6 +507,19 @@ int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, in
                          uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
 int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect, float *ldpc_ms);
 int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials);
+/* Per-stage durations of the last call, from HIP events recorded on the call's stream between the stages (waits for the call):
+ * ms[T2GPU_RX_STAGES] in the order front end, P1 (incl. the call's one host round trip), guard correlation, FFT, equalisers +
+ * frequency de-interleave, time / cell de-interleave, demapper, LDPC, BCH stub / descrambler; -1 = stage not run by that call. */
+#define T2GPU_RX_STAGES 9
+int t2gpu_rx_stage_ms(t2gpu_rx *h, float *ms);
+/* BASELINE.json config 2 as a call of its own: FFT (guard dropped by addressing) + P2 / data / FC equalisers with frequency
+ * de-interleave + time / cell de-interleave + demapper over the n_frames frames whose stream and frame positions the last
+ * t2gpu_rx_front_dev / t2gpu_rx_execute_dev left in the handle. Enqueue only. */
+int t2gpu_rx_fft_eq_demap_dev(t2gpu_rx *h, int n_frames, void *stream);
+/* The synchronisation sums the reference forms in every symbol (p2_symbol.cpp:253-258, data_symbol.cpp:319-324, fc_symbol.cpp:
+ * 257-262) as the last call left them: (phase_offset, sample_rate_offset) per symbol, [P2 of every frame][data symbols, frame
+ * major][FC of every frame]. Synchronises. */
+int t2gpu_rx_sync_sums(t2gpu_rx *h, int n_frames, float *sync2);
 /* opt-in (off by default = the reference's behaviour, bch_decoder.cpp:136): run t2gpu_bch_decode_dev on the LDPC output of every
  * back half before the descrambler; t2gpu_rx_outer_code_status (synchronises) copies the per-FEC-frame status of the last back
  * half (bits corrected, -1 = more than t errors; frames of batches the LDPC stage dropped carry whatever the decoder left). */

@@ -81,6 +81,9 @@ PROTOTYPES = {
     "t2gpu_rx_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_rx_results": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "t2gpu_rx_fetch": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_rx_stage_ms": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_fft_eq_demap_dev": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "t2gpu_rx_sync_sums": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "t2gpu_rx_set_outer_code": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_rx_outer_code_status": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "t2gpu_ti_frame_plan": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int]),

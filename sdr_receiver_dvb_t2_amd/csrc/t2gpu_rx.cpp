@@ -42,6 +42,10 @@ struct t2gpu_rx {
     bool outer_code = false;
     hipEvent_t ev_ldpc0 = nullptr, ev_ldpc1 = nullptr;
     bool timed = false;
+    // stage boundaries of the last call, recorded on the stream the kernels run on (t2gpu_rx_stage_ms)
+    hipEvent_t ev[T2GPU_RX_STAGES + 1] = {};
+    bool ev_set[T2GPU_RX_STAGES + 1] = {};
+    float *d_sync = nullptr;                  // sample_rate_offset / phase_offset of every symbol (data_symbol.cpp:319-324): always computed
     std::vector<t2gpu_p1_result> p1_res;
     std::vector<long> p2_start;
 };
@@ -60,6 +64,16 @@ void free_all(t2gpu_rx *h)
     hipFree(h->d_ti_out); hipFree(h->d_sums); hipFree(h->d_cp); hipFree(h->d_llr); hipFree(h->d_bits); hipFree(h->d_out); hipFree(h->d_trials); hipFree(h->d_outer);
     if (h->ev_ldpc0) hipEventDestroy(h->ev_ldpc0);
     if (h->ev_ldpc1) hipEventDestroy(h->ev_ldpc1);
+    for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
+    hipFree(h->d_sync);
+}
+
+// stage k ends here: event k + 1 (event 0 = start of the call)
+bool mark(t2gpu_rx *h, int k, hipStream_t s)
+{
+    if (hipEventRecord(h->ev[k], s) != hipSuccess) return false;
+    h->ev_set[k] = true;
+    return true;
 }
 
 template <class T> bool dev_alloc(T *&p, size_t count) { return hipMalloc(&p, count * sizeof(T)) == hipSuccess; }
@@ -116,7 +130,9 @@ extern "C" t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *c, int device)
          dev_alloc(h->d_out, (size_t)(nb + 64) * h->k_bch) && dev_alloc(h->d_trials, (size_t)(nb + 64) / group + 2) &&
          hipMemset(h->d_stream, 0, 2 * (size_t)(n_max + 64) * 4) == hipSuccess && hipMemset(h->d_cells, 0, 2 * (size_t)F * h->frame_cells * 4) == hipSuccess &&
          hipMemset(h->d_ti_out, 0, 2 * (size_t)F * h->n_ti * 4) == hipSuccess && hipMemset(h->d_sums, 0, (size_t)F * 16) == hipSuccess &&
-         hipEventCreate(&h->ev_ldpc0) == hipSuccess && hipEventCreate(&h->ev_ldpc1) == hipSuccess;
+         hipEventCreate(&h->ev_ldpc0) == hipSuccess && hipEventCreate(&h->ev_ldpc1) == hipSuccess &&
+         dev_alloc(h->d_sync, 2 * (size_t)F * h->n_sym);
+    for (int k = 0; ok && k <= T2GPU_RX_STAGES; ++k) ok = hipEventCreate(&h->ev[k]) == hipSuccess;
     if (!ok) {
         if (h->front && h->p1 && h->ofdm && h->ti && h->demap && h->ldpc) set_error("t2gpu_rx_create: device allocation failed");
         free_all(h);
@@ -152,6 +168,8 @@ extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t
     if (!h || !d_i || !d_q || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_front_dev: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     const int32_t n_in = (int32_t)((long)n_frames * h->frame_len);
+    for (bool &b : h->ev_set) b = false;
+    if (!mark(h, 0, (hipStream_t)stream)) return -1;
     const long cells = t2gpu_front_execute_dev(h->front, 1, &n_in, nullptr, nullptr, nullptr, d_i, d_q, h->d_stream,
                                                (long)h->cfg.max_frames * h->frame_len + 4096, nullptr, stream);
     if (cells < 0) return -1;
@@ -161,6 +179,7 @@ extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t
         if (t2gpu_front_state(h->front, st) != 0) return -1;
         level_detect = st[6];
     }
+    if (!mark(h, 1, (hipStream_t)stream)) return -1;                                    // T2GPU_RX_STAGE_FRONT done
     std::vector<long> starts(n_frames);
     std::vector<int> lens(n_frames), cons(n_frames);
     for (int f = 0; f < n_frames; ++f) {
@@ -177,11 +196,53 @@ extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t
             return -2;
         }
     }
+    if (!mark(h, 2, (hipStream_t)stream)) return -1;                                    // P1
     const long first = h->p2_start[0];
     if (t2gpu_cp_correlate_stream_dev(h->d_stream, first, h->frame_len, h->n_sym, n_frames * h->n_sym, h->fft_size, h->guard, h->d_cp, stream) != 0) return -1;
+    if (!mark(h, 3, (hipStream_t)stream)) return -1;                                    // guard correlation
     if (t2gpu_fft_execute_strided_dev(h->ofdm, h->d_stream, first + h->guard, h->frame_len, h->n_sym, h->sym_size, h->d_spec, n_frames * h->n_sym,
                                       stream) != 0) return -1;
+    if (!mark(h, 4, (hipStream_t)stream)) return -1;                                    // FFT
     return 0;
+}
+
+namespace {
+// equalisers -> time de-interleaver -> demapper on the spectra in d_spec (stages 4..6)
+int rx_eq_ti_demap(t2gpu_rx *h, int F, hipStream_t s)
+{
+    // P2, data symbols, frame-closing symbol: read in place from the spectra, written in place into the cell streams (P2 without
+    // its L1 cells, time_deinterleaver.cpp:296-300). The per-symbol synchronisation sums the reference always forms
+    // (p2_symbol.cpp:253-258, data_symbol.cpp:319-324, fc_symbol.cpp:257-262) are formed too; with the loops open nobody reads them.
+    const int a = h->c_p2 - h->p2_skip;
+    float *sy = h->d_sync;
+    if (t2gpu_eq_p2_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, sy, s) < 0) return -1;
+    if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, sy + 2 * (size_t)F, s) < 0) return -1;
+    if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data,
+                                          sy + 2 * (size_t)F * (1 + h->n_dat), s) < 0)
+        return -1;
+    if (!mark(h, 5, s)) return -1;                                                      // equalisers
+    // TI block of every frame in one launch, statistics in one launch, LLRs in one launch
+    if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
+    if (!mark(h, 6, s)) return -1;                                                      // time / cell de-interleaver
+    if (t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0) return -1;
+    if (t2gpu_demap_llr_batch_dev(h->demap, h->d_ti_out, F, h->n_ti, h->d_sums, 4, h->d_llr, s) < 0) return -1;
+    if (!mark(h, 7, s)) return -1;                                                      // demapper
+    return 0;
+}
+}  // namespace
+
+// BASELINE config 2: FFT (guard dropped) + equalisers / frequency de-interleave + time de-interleave + demap of the frames the last
+// front half left in the handle (stream, frame positions). Enqueue only.
+extern "C" int t2gpu_rx_fft_eq_demap_dev(t2gpu_rx *h, int n_frames, void *stream)
+{
+    if (!h || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_fft_eq_demap_dev: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    for (bool &b : h->ev_set) b = false;
+    if (!mark(h, 3, (hipStream_t)stream)) return -1;
+    if (t2gpu_fft_execute_strided_dev(h->ofdm, h->d_stream, h->p2_start[0] + h->guard, h->frame_len, h->n_sym, h->sym_size, h->d_spec,
+                                      n_frames * h->n_sym, stream) != 0) return -1;
+    if (!mark(h, 4, (hipStream_t)stream)) return -1;
+    return rx_eq_ti_demap(h, n_frames, (hipStream_t)stream);
 }
 
 // back half: equalisers, time de-interleaver, demapper, LDPC (every FEC frame, the tail batch short), descrambler
@@ -191,24 +252,16 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out
     T2_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
-    // P2, data symbols, frame-closing symbol: read in place from the spectra, written in place into the cell streams (P2 without
-    // its L1 cells, time_deinterleaver.cpp:296-300)
-    const int a = h->c_p2 - h->p2_skip;
-    if (t2gpu_eq_p2_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, nullptr, s) < 0) return -1;
-    if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, nullptr, s) < 0) return -1;
-    if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data, nullptr, s) < 0)
-        return -1;
-    // TI block of every frame in one launch, statistics in one launch, LLRs in one launch
-    if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
-    if (t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0) return -1;
-    if (t2gpu_demap_llr_batch_dev(h->demap, h->d_ti_out, F, h->n_ti, h->d_sums, 4, h->d_llr, s) < 0) return -1;
+    if (rx_eq_ti_demap(h, F, s) != 0) return -1;
     const int count = F * nb;
     T2_HIP(hipEventRecord(h->ev_ldpc0, s));
     if (t2gpu_ldpc_execute_dev(h->ldpc, h->d_llr, count, h->d_bits, nullptr, h->d_trials, s) != 0) return -1;
     T2_HIP(hipEventRecord(h->ev_ldpc1, s));
     h->timed = true;
+    if (!mark(h, 8, s)) return -1;                                                      // LDPC
     if (h->outer_code && t2gpu_bch_decode_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_outer, s) < 0) return -1;
     if (t2gpu_bch_descramble_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_out, s) < 0) return -1;
+    if (!mark(h, 9, s)) return -1;                                                      // BCH stub / descrambler
     if (d_bits_out) *d_bits_out = h->d_out;
     if (d_trials_out) *d_trials_out = h->d_trials;
     return count;
@@ -246,6 +299,31 @@ extern "C" int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, 
     }
     if (n_frames == 0) return 0;                           // a pure timing query: no read-back of the decoder's status word
     return t2gpu_ldpc_status(h->ldpc) == 0 ? 0 : -1;
+}
+
+// Durations of the stages of the last call from the events recorded between them (milliseconds; -1 for a stage the call did not
+// run). Waits for the call. Stage k = time between event k and event k + 1; the P1 stage contains the one host round trip of a
+// call (its decisions are host data).
+extern "C" int t2gpu_rx_stage_ms(t2gpu_rx *h, float *ms)
+{
+    if (!h || !ms) { set_error("t2gpu_rx_stage_ms: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    for (int k = 0; k < T2GPU_RX_STAGES; ++k) {
+        ms[k] = -1.0f;
+        if (!h->ev_set[k] || !h->ev_set[k + 1]) continue;
+        T2_HIP(hipEventSynchronize(h->ev[k + 1]));
+        T2_HIP(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+    }
+    return 0;
+}
+
+extern "C" int t2gpu_rx_sync_sums(t2gpu_rx *h, int n_frames, float *sync2)
+{
+    if (!h || !sync2 || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_sync_sums: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipDeviceSynchronize());
+    T2_HIP(hipMemcpy(sync2, h->d_sync, (size_t)n_frames * h->n_sym * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable)

@@ -248,6 +248,23 @@ class t2_rx(object):
         self._check(self._l.t2gpu_rx_outer_code_status(self._h, count, st.ctypes.data), "t2gpu_rx_outer_code_status")
         return st
 
+    STAGES = ("front", "p1", "guard_corr", "fft", "equalise", "ti", "demap", "ldpc", "descramble")
+
+    def stage_ms(self):
+        """Durations (ms) of the stages of the last call from HIP events on its stream; waits for it. -1: not run."""
+        ms = (ctypes.c_float * 9)()
+        self._check(self._l.t2gpu_rx_stage_ms(self._h, ms), "t2gpu_rx_stage_ms")
+        return dict(zip(self.STAGES, (float(v) for v in ms)))
+
+    def fft_eq_demap_dev(self, n_frames, stream=None):
+        """BASELINE config 2 on the frames of the last front half: FFT + equalisers + time de-interleave + demap. Enqueue only."""
+        return self._check(self._l.t2gpu_rx_fft_eq_demap_dev(self._h, n_frames, self._stream(stream)), "t2gpu_rx_fft_eq_demap_dev")
+
+    def sync_sums(self, n_frames):
+        out = np.zeros((n_frames * self.geometry.n_sym, 2), np.float32)
+        self._check(self._l.t2gpu_rx_sync_sums(self._h, n_frames, out.ctypes.data), "t2gpu_rx_sync_sums")
+        return out
+
     def last_ldpc_ms(self):
         """Duration of the last LDPC launch (HIP events on the stream it ran on); waits for it."""
         ms = ctypes.c_float(0)
