@@ -1,0 +1,337 @@
+// ldpc_cn3.h -- the check-node update of ldpc_cn2.h (one check node on two adjacent lanes) for TWO FEC frames at once: the two
+// frames of a workgroup share the graph, so every address, every LDS access and every DPP exchange serves both, and the int8
+// arithmetic runs in the two 16-bit halves of a register (v_pk_*_i16: two values per lane per issue slot). GPU only.
+//
+// Layout. LLR byte of bit a of frame f at LDS address base + 2a + f: one ds_read_u16 / ds_write_b16 moves both frames' values.
+// Messages are kept as the reference keeps them -- one int8 per link and frame, clamp(out, -32, 31) (algorithms.hh:288-291) --
+// in the lane's record: slot v of the lane -> bytes (2(v&1), 2(v&1)+1) = (frame A, frame B) of record dword v >> 1. The 2-bit codes
+// + two minima of ldpc_cn.h / ldpc_cn2.h are the compact form for one frame per register; with two frames per register the
+// message bytes are what the packed subtract consumes directly (two SDWA subtracts per slot for both frames).
+//
+// Semantics, slot numbering, layer kinds and phase structure are those of ldpc_cn.h / ldpc_cn2.h, function by function (each names
+// the one it restates); results are LLR-exact against the same goldens (tests/test_ldpc_gpu.py).
+#pragma once
+#include "ldpc_cn.h"
+
+namespace t2gpu {
+
+typedef short p16 __attribute__((ext_vector_type(2)));     // (frame A, frame B)
+__device__ __forceinline__ p16 p_of(uint32_t v) { return __builtin_bit_cast(p16, v); }
+__device__ __forceinline__ uint32_t u_of(p16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ p16 p_set(int a) { return (p16){(short)a, (short)a}; }
+__device__ __forceinline__ p16 p_min(p16 a, p16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ p16 p_max(p16 a, p16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ p16 p_clamp(p16 v, int lo, int hi) { return p_min(p_max(v, p_set(lo)), p_set(hi)); }
+__device__ __forceinline__ int p_a(p16 v) { return (int)v.x; }      // frame A / frame B value, sign-extended
+__device__ __forceinline__ int p_b(p16 v) { return (int)v.y; }
+
+// value of v in the partner lane (lane ^ 1)
+__device__ __forceinline__ uint32_t p2_xu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ p16 p2_x(p16 v) { return p_of(p2_xu(u_of(v))); }
+
+// f of ldpc_cn.h on raw magnitudes 0..255, both frames
+__device__ __forceinline__ p16 p2_f(p16 a) { return p_clamp(a - p_set(1), 0, 126); }
+
+// (LLR bytes A, B in bytes 0, 1 of raw) - (message bytes A, B in bytes 2*odd, 2*odd + 1 of msg), sign-extended, one frame per half.
+// Both sign extensions ride on the subtract (SDWA byte selects); the second one writes the upper half and keeps the lower.
+__device__ __forceinline__ p16 p2_llr_minus_msg(uint32_t raw, uint32_t msg, int odd)
+{
+    uint32_t d;
+    if (odd) {
+        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2" : "=v"(d) : "v"(raw), "v"(msg));
+        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3" : "+v"(d) : "v"(raw), "v"(msg));
+    } else {
+        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(raw), "v"(msg));
+        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(d) : "v"(raw), "v"(msg));
+    }
+    return p_of(d);
+}
+
+// the two smallest of the union of two sorted pairs (pl_merge2)
+__device__ __forceinline__ void p2_merge2(p16 a0, p16 a1, p16 b0, p16 b1, p16 &m0, p16 &m1)
+{
+    m0 = p_min(a0, b0);
+    m1 = p_min(p_max(a0, b0), p_min(a1, b1));
+}
+// t2_min2: fold a into the sorted pair (m0 <= m1)
+__device__ __forceinline__ void p2_min2(p16 a, p16 &m0, p16 &m1)
+{
+    m1 = p_min(m1, p_max(m0, a));
+    m0 = p_min(m0, a);
+}
+
+template <int CNT>
+struct P2Regs {
+    static constexpr int DEG = CNT + 2, H = (DEG + 1) / 2, W = (H + 1) / 2;   // slots of the node / of one lane / record dwords of one lane
+    int addr[H];                // LDS address of the slot's LLR pair (absent slot: < 0)
+    p16 in[H], mag[H];          // in = sat(L - old message); raw magnitude (255 for an absent slot)
+    uint32_t mo[W], mn[W];      // old / new message bytes
+    p16 p0, p1;                 // node-wide over the non-conflict slots: two smallest raw magnitudes
+    uint32_t psx;               //   ... and the sign xor (bits 15 / 31)
+    p16 m0, m1f, dm;            // node-wide over all slots: raw minimum, f(min1), f(min0) - f(min1)
+    uint32_t sx;
+    int h;
+};
+
+template <int CNT>
+__device__ __forceinline__ bool p2_present(const P2Regs<CNT> &r, int v) { return (2 * v + 1 <= CNT) || r.addr[v] >= 0; }
+
+// pl_read_slot
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_read_slot(const LMEM &L, P2Regs<CNT> &r, int v)
+{
+    const bool present = p2_present(r, v);
+    const uint32_t raw = present ? L.ld16(r.addr[v]) : 0u;
+    const p16 x = p_clamp(p2_llr_minus_msg(raw, r.mo[v >> 1], v & 1), -128, 127);
+    r.in[v] = present ? x : p_set(0);
+    r.mag[v] = present ? p_max(x, p_set(0) - x) : p_set(255);
+}
+
+// pl_load. ent_lds: LDS address of the layer's entries as (base + 2 * (bit base - shift), shift) pairs; j2 = 2 j.
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_load(const LMEM &L, int ent_lds, int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r)
+{
+    constexpr int H = P2Regs<CNT>::H, W = P2Regs<CNT>::W;
+    r.h = h;
+#pragma unroll
+    for (int w = 0; w < W; ++w) r.mn[w] = 0u;
+    uint2 e[H];
+    const int j2 = 2 * j, jw2 = j2 + 720;
+    const int mine = ent_lds + 8 * h;                              // the odd lane reads the odd entries
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        const int c0 = 2 * v, c1 = 2 * v + 1;
+        if (c1 < CNT) e[v] = L.ld_pair(mine + 8 * c0);
+        else if (c0 < CNT) e[v] = L.ld_pair(ent_lds + 8 * c0);
+        else e[v] = make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        const int c0 = 2 * v, c1 = 2 * v + 1;
+        const int link = (int)e[v].x + (j >= (int)e[v].y ? j2 : jw2);
+        if (c1 < CNT) r.addr[v] = link;                             // information slots on both lanes
+        else if (c0 < CNT) r.addr[v] = h ? a_p0 : link;             // c1 == CNT: own parity bit on the odd lane
+        else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
+        else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
+    }
+    uint32_t raw[H];
+#pragma unroll
+    for (int v = 0; v < H; ++v) raw[v] = p2_present(r, v) ? L.ld16(r.addr[v]) : 0u;
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        const bool present = p2_present(r, v);
+        const p16 x = p_clamp(p2_llr_minus_msg(raw[v], r.mo[v >> 1], v & 1), -128, 127);
+        r.in[v] = present ? x : p_set(0);
+        r.mag[v] = present ? p_max(x, p_set(0) - x) : p_set(255);
+    }
+}
+
+// pl_partial: over the node's slots c >= nc (both lanes), result node-wide in p0 / p1 / psx
+template <int CNT>
+__device__ __forceinline__ void p2_partial(P2Regs<CNT> &r, int nc)
+{
+    constexpr int H = P2Regs<CNT>::H;
+    p16 m0 = p_set(255), m1 = p_set(255);
+    uint32_t sx = 0;
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        if (2 * v + 1 >= nc) {                                      // uniform: at least the odd lane's slot counts
+            const bool mine = (2 * v >= nc) || r.h;
+            p2_min2(mine ? r.mag[v] : p_set(255), m0, m1);
+            sx ^= mine ? u_of(r.in[v]) : 0u;
+        }
+    }
+    p2_merge2(m0, m1, p2_x(m0), p2_x(m1), r.p0, r.p1);
+    r.psx = sx ^ p2_xu(sx);
+}
+
+__device__ __forceinline__ void p2_set_minima(p16 a0, p16 a1, p16 &m0, p16 &m1f, p16 &dm)
+{
+    m0 = a0;
+    m1f = p2_f(a1);
+    dm = p2_f(a0) - m1f;
+}
+
+// pl_merge: fold the conflict slots c < nc into the partial result, apply f. NV = the most slots v a lane can have below nc.
+template <int CNT, int NV>
+__device__ __forceinline__ void p2_merge(P2Regs<CNT> &r, int nc)
+{
+    p16 m0 = p_set(255), m1 = p_set(255);
+    uint32_t sx = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < P2Regs<CNT>::H && 2 * v < nc) {                     // uniform: at least the even lane's slot is a conflict slot
+            const bool mine = (2 * v + 1 < nc) || !r.h;
+            p2_min2(mine ? r.mag[v] : p_set(255), m0, m1);
+            sx ^= mine ? u_of(r.in[v]) : 0u;
+        }
+    }
+    p16 c0, c1, a0, a1;
+    p2_merge2(m0, m1, p2_x(m0), p2_x(m1), c0, c1);
+    sx ^= p2_xu(sx);
+    p2_merge2(c0, c1, r.p0, r.p1, a0, a1);
+    p2_set_minima(a0, a1, r.m0, r.m1f, r.dm);
+    r.sx = sx ^ r.psx;
+}
+
+// pl_write_slot for lane slot v: a-posteriori update L = sat(in + out) and the new message clamp(out, -32, 31), both frames
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bool store)
+{
+    const bool present = p2_present(r, v);
+    const p16 s = p_min(r.mag[v] - r.m0, p_set(1));      // 0 where the slot holds the raw minimum (an absent slot carries 255), else 1
+    const p16 other = s * r.dm + r.m1f;                  // f(min1) for the minimum's slot, f(min0) for the others
+    const p16 sm = p_of(r.sx ^ u_of(r.in[v])) >> p_set(15);   // 0 / -1: sign of the product of the other inputs
+    const p16 sgn = p_of(u_of(sm) | 0x00010001u);        // +1 / -1
+    const p16 out = other * sgn;
+    const p16 ln = p_clamp(out + r.in[v], -128, 127);
+    if (present && store) L.st16(r.addr[v], __builtin_amdgcn_perm(0u, u_of(ln), 0x0c0c0200u));
+    const p16 msg = p_clamp(out, -32, 31);
+    // bytes 0, 2 of msg -> bytes (0, 1) or (2, 3) of the record dword
+    if (v & 1) r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x06040100u);
+    else r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x03020604u);
+}
+
+// pl_phase_a. pair_rec: [2][360] chain-walk records, one array per frame
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r, uint32_t *pair_rec)
+{
+    constexpr int H = P2Regs<CNT>::H;
+    p2_load<CNT>(L, d.ent_lds, j, h, a_p0, a_p1, r);
+    if (d.kind == T2_LAYER_PLAIN) {
+        p2_partial<CNT>(r, 0);
+        p2_set_minima(r.p0, r.p1, r.m0, r.m1f, r.dm);
+        r.sx = r.psx;
+#pragma unroll
+        for (int v = 0; v < H; ++v) p2_write_slot<CNT>(L, r, v, true);
+    } else if (d.kind == T2_LAYER_PAIR) {
+        p2_partial<CNT>(r, 2);
+        const uint32_t partner_m0 = p2_xu(r.mo[0]);      // the odd lane's slot v = 0 is the node's slot 1: its old message is msg1
+        if (j < d.step) {                       // chain start: its two group bits (slot 0 on the even lane, slot 1 on the odd one) now
+            p2_merge<CNT, 1>(r, 2);
+            p2_write_slot<CNT>(L, r, 0, true);
+        } else if (h == 0) {                    // t2_pair_record, one per frame
+            const p16 cap = p2_f(r.p0);
+            pair_rec[j] = t2_pair_pack((int)(int8_t)(partner_m0 & 0xffu), p_a(cap), p_a(r.in[0]), (r.psx & 0x8000u) != 0);
+            pair_rec[360 + j] = t2_pair_pack((int)(int8_t)((partner_m0 >> 8) & 0xffu), p_b(cap), p_b(r.in[0]), (r.psx & 0x80000000u) != 0);
+        }
+    } else {
+        p2_partial<CNT>(r, d.nc);
+    }
+}
+
+// Chain walks run one frame per lane on the unpacked recurrence of ldpc_cn.h (t2_pair_step): the walk is a latency chain, so the two
+// frames' chains walking side by side on different lanes cost the time of one. base2 = LDS address of bit 0 of the group for this
+// frame (lds base + 2 * bit base + frame); positions advance by 2 bytes.
+template <class LMEM>
+__device__ __forceinline__ void p2_pair_walk_segments(LMEM &L, const LayerDesc &d, int node, int frame, const uint32_t *pair_rec)
+{
+    const uint32_t e0 = d.e0;
+    const int base2 = 2 * (int)(e0 & 0xffffu) + L.off() + frame, s0 = (int)(e0 >> 16), step = d.step;
+    const int last = 360 - step;                          // nodes below `last` have a successor
+    int m = node - s0;                                    // position of the node's slot-0 bit inside its 360-bit group
+    m += (m < 0) ? 360 : 0;
+    bool go = false;
+    int X = 0;
+    if (node < step) {                                    // chain start: its bit was finished in phase A
+        go = true;
+        X = (int)L.ld(base2 + 2 * m);
+    } else if (node < last) {
+        const PairRec r = t2_pair_unpack(pair_rec[node]);
+        if (r.cap == 0) {                                 // segment head: output independent of the input (ldpc_cn2.h)
+            go = true;
+            X = r.in0;
+            L.st(base2 + 2 * m, (int8_t)X);
+        }
+    }
+    int jj = node + step;
+    uint32_t nxt = (go && jj < last) ? pair_rec[jj] : 0u;
+    while (go && jj < last) {
+        const PairRec r = t2_pair_unpack(nxt);
+        if (r.cap == 0) break;                            // the next node heads a segment of its own
+        jj += step;
+        nxt = pair_rec[jj < 359 ? jj : 359];
+        const unsigned t = (unsigned)(m + step);
+        m = (int)(t < t - 360u ? t : t - 360u);           // (m + step) mod 360
+        X = t2_pair_step(r, X);
+        L.st(base2 + 2 * m, (int8_t)X);
+    }
+}
+
+// t2_pair_walk for short chains (lane < step walks chain lane, lane + step, ...), one frame
+template <class LMEM>
+__device__ __forceinline__ void p2_pair_walk(LMEM &L, const LayerDesc &d, int lane, int frame, const uint32_t *pair_rec)
+{
+    const uint32_t e0 = d.e0;
+    const int base2 = 2 * (int)(e0 & 0xffffu) + L.off() + frame, s0 = (int)(e0 >> 16), step = d.step;
+    int m = lane - s0;
+    m += (m < 0) ? 360 : 0;
+    int X = (int)L.ld(base2 + 2 * m);
+    for (int jj = lane + step; jj + step < 360; jj += step) {     // nodes that have a successor
+        const PairRec r = t2_pair_unpack(pair_rec[jj]);
+        const unsigned t = (unsigned)(m + step);
+        m = (int)(t < t - 360u ? t : t - 360u);
+        X = t2_pair_step(r, X);
+        L.st(base2 + 2 * m, (int8_t)X);
+    }
+}
+
+// pl_pair_finish
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_pair_finish(LMEM &L, const LayerDesc &d, int j, P2Regs<CNT> &r)
+{
+    constexpr int H = P2Regs<CNT>::H;
+    if (j < d.step) {
+#pragma unroll
+        for (int v = 1; v < H; ++v) p2_write_slot<CNT>(L, r, v, true);
+        return;
+    }
+    const bool has_succ = j + d.step < 360;
+    if (r.h || !has_succ) p2_read_slot<CNT>(L, r, 0);     // slot 1 always, slot 0 when the node ends its chain
+    p2_merge<CNT, 1>(r, 2);
+#pragma unroll
+    for (int v = 0; v < H; ++v) p2_write_slot<CNT>(L, r, v, !(v == 0 && !r.h && has_succ));
+}
+
+// pl_generic_level_nc
+template <int CNT, int NC, class LMEM>
+__device__ __forceinline__ void p2_generic_level_nc(LMEM &L, int lv, uint32_t info, P2Regs<CNT> &r)
+{
+    if ((int)(info & 0xff) != lv) return;
+    constexpr int NV = (NC + 1) / 2;
+    if (lv > 1) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if ((2 * v + 1 < NC) || !r.h) p2_read_slot<CNT>(L, r, v);
+    }
+    p2_merge<CNT, NV>(r, NC);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        if ((2 * v + 1 < NC) || !r.h) p2_write_slot<CNT>(L, r, v, true);
+}
+
+template <int CNT, int NCMAX = T2_LDPC_NC_MAX, class LMEM>
+__device__ __forceinline__ void p2_generic_level(LMEM &L, const LayerDesc &d, int lv, uint32_t info, P2Regs<CNT> &r)
+{
+    switch (d.nc) {
+#define T2_NC_(n) case n: if constexpr (n <= CNT && n <= NCMAX) p2_generic_level_nc<CNT, n>(L, lv, info, r); break;
+        T2_NC_(2) T2_NC_(3) T2_NC_(4) T2_NC_(5) T2_NC_(6) T2_NC_(7) T2_NC_(8) T2_NC_(9) T2_NC_(10)
+#undef T2_NC_
+    default: break;
+    }
+}
+
+// pl_generic_finish
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_generic_finish(LMEM &L, const LayerDesc &d, P2Regs<CNT> &r)
+{
+    constexpr int H = P2Regs<CNT>::H;
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        if (2 * v + 1 >= d.nc) {
+            if ((2 * v >= d.nc) || r.h) p2_write_slot<CNT>(L, r, v, true);
+        }
+    }
+}
+
+}  // namespace t2gpu

@@ -1,0 +1,417 @@
+// ldpc_kernel2.hip -- the decoder of ldpc_kernel.hip with TWO FEC frames per workgroup (ldpc_cn3.h): frames 2m and 2m + 1 of a
+// SIMD batch share a workgroup, their LLR bytes interleaved in LDS, every address / LDS access / DPP exchange serving both and the
+// int8 arithmetic running in the 16-bit halves of the registers. Same mapping otherwise: two lanes per check node (720 of 768
+// lanes), LLRs resident in LDS for the whole decode, per-link messages (one byte per link and frame, as in the reference) streaming
+// through L2 one layer ahead, the reference's ascending-j order kept exactly in PAIR / GENERIC layers, SIMD batches of `group`
+// frames stopping together through one atomic word per (batch, trial).
+//
+// Replaces the compute of ldpc_decoder::execute (/root/reference/src/DVB_T2/ldpc_decoder.cpp:157-301) and
+// LDPCDecoder::{bad,update,operator()} (/root/reference/src/DVB_T2/LDPC/layered_decoder.hh:65-110,168-180).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ldpc_kernel.h"
+#include "ldpc_cn3.h"
+
+namespace t2gpu {
+namespace {
+
+typedef __attribute__((address_space(3))) int8_t lds2_i8;
+struct LdsMem2 {
+    uint32_t base;
+    __device__ __forceinline__ int off() const { return (int)base; }
+    __device__ __forceinline__ int8_t ld(int a) const { return *reinterpret_cast<const lds2_i8 *>((uint32_t)a); }
+    __device__ __forceinline__ void st(int a, int8_t v) { *reinterpret_cast<lds2_i8 *>((uint32_t)a) = v; }
+    __device__ __forceinline__ uint32_t ld16(int a) const
+    {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uint32_t)a);
+    }
+    __device__ __forceinline__ void st16(int a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uint32_t)a) = (uint16_t)v; }
+    __device__ __forceinline__ uint2 ld_pair(int a) const
+    {
+        const __attribute__((address_space(3))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a);
+        return make_uint2(q[0], q[1]);
+    }
+};
+
+constexpr int kThreads2 = 768;
+
+__device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int parity_prev_bit(int k, int q, int i, int j)
+{
+    if (i > 0) return k + 360 * (i - 1) + j;
+    return j > 0 ? k + 360 * (q - 1) + j - 1 : -1;
+}
+
+// ---- bit-parallel parity check of both frames (LDPCDecoder::bad, layered_decoder.hh:65-82; see ldpc_kernel.hip) -----------------
+// Sign words as there: 13 dwords per 360-bit group (bits 0..359 + a copy of bits 0..55), one array per frame. A dword of the
+// interleaved LLR bytes holds (A_k, B_k, A_k+1, B_k+1).
+__device__ __forceinline__ uint32_t has_zero_byte2(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
+__device__ __forceinline__ void sign_bits2(uint32_t v, uint32_t &a2, uint32_t &b2)
+{
+    const uint32_t t = (v >> 7) & 0x01010101u;
+    const uint32_t a = t & 0x00010001u, b = (t >> 8) & 0x00010001u;
+    a2 = (a | (a >> 15)) & 3u;
+    b2 = (b | (b >> 15)) & 3u;
+}
+__device__ __forceinline__ uint32_t sign_window2(const uint32_t *S, int g, int m)
+{
+    const uint32_t *w = S + g * 13 + (m >> 5);
+    return __builtin_amdgcn_alignbit(w[1], w[0], (uint32_t)(m & 31));
+}
+// sign words (bits 32 kk .. 32 kk + 31 of group g) of both frames; zero bits 7/23 = frame A has an exactly-zero LLR, 15/31 = frame B
+__device__ __forceinline__ void sign_word2(const int8_t *Lm, int g, int kk, uint32_t &wa, uint32_t &wb, uint32_t *zero)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(Lm + 2 * (g * 360 + 32 * kk));     // 64 bytes = 32 bits of either frame
+    const int nq = (kk == 11) ? 1 : 4;          // dword 11 holds only bits 352..359: 16 bytes
+    wa = 0; wb = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+        if (x < nq) {
+            const uint4 v = src[x];
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                uint32_t a2, b2;
+                *zero |= has_zero_byte2(d[y]);
+                sign_bits2(d[y], a2, b2);
+                wa |= a2 << (8 * x + 2 * y);
+                wb |= b2 << (8 * x + 2 * y);
+            }
+        }
+}
+__device__ __forceinline__ uint32_t layer_syndrome2(const uint32_t *S, const LdpcLayerDev &ly, const uint32_t *__restrict__ ent, int gp0, int q,
+                                                    int i, int tj)
+{
+    const int j0 = 32 * tj;
+    uint32_t syn = S[(gp0 + i) * 13 + tj];
+    if (i > 0) syn ^= S[(gp0 + i - 1) * 13 + tj];
+    else syn ^= (tj == 0) ? (S[(gp0 + q - 1) * 13] << 1) : sign_window2(S, gp0 + q - 1, j0 - 1);
+    for (int c = 0; c < ly.cnt; ++c) {
+        const uint32_t e = ent[c];
+        const int g = (int)__umulhi(e & 0xffffu, 11930465u);                 // base / 360
+        int m = j0 - (int)(e >> 16);
+        m += (m < 0) ? 360 : 0;
+        syn ^= sign_window2(S, g, m);
+    }
+    return syn & ((tj == 11) ? 0xffu : 0xffffffffu);
+}
+__device__ __forceinline__ void finish_group2(uint32_t *S, int g)
+{
+    const uint32_t d0 = S[g * 13], d1 = S[g * 13 + 1];
+    S[g * 13 + 11] = (S[g * 13 + 11] & 0xffu) | (d0 << 8);
+    S[g * 13 + 12] = (d0 >> 24) | (d1 << 8);
+}
+
+// per thread: bit 0 = frame A saw a zero LLR or a failing check, bit 1 = frame B
+__device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA, uint32_t *SB, const LdpcLayerDev *__restrict__ layers,
+                                                 const uint32_t *__restrict__ entries, int n, int k, int q, int tid, int *s_ctl)
+{
+    const int ngroups = n / 360, gp0 = k / 360;
+    uint32_t zero = 0;
+    int probe = 0;
+    // Probe (ldpc_kernel.hip): the 360 checks of layer 1 need the sign words of ~14 groups only, and a frame that has not converged
+    // almost always fails there. When BOTH frames fail the probe the workgroup is done; otherwise the full check runs for both.
+    if (q > 1) {
+        const LdpcLayerDev ly = layers[1];
+        const uint32_t *ent = entries + ly.first_entry;
+        const int ng = ly.cnt + 2;
+        if (tid < ng * 12) {
+            const int gi = tid / 12, kk = tid - gi * 12;
+            const int g = gi < ly.cnt ? (int)__umulhi(ent[gi] & 0xffffu, 11930465u) : gp0 + (gi - ly.cnt);
+            uint32_t wa, wb;
+            sign_word2(Lm, g, kk, wa, wb, &zero);
+            SA[g * 13 + kk] = wa; SB[g * 13 + kk] = wb;
+        }
+        lds_barrier2();
+        if (tid < ng) {
+            const int g = tid < ly.cnt ? (int)__umulhi(ent[tid] & 0xffffu, 11930465u) : gp0 + (tid - ly.cnt);
+            finish_group2(SA, g); finish_group2(SB, g);
+        }
+        lds_barrier2();
+        int bad = ((zero & 0x00800080u) ? 1 : 0) | ((zero & 0x80008000u) ? 2 : 0);
+        if (tid < 12) {
+            if (layer_syndrome2(SA, ly, ent, gp0, q, 1, tid)) bad |= 1;
+            if (layer_syndrome2(SB, ly, ent, gp0, q, 1, tid)) bad |= 2;
+        }
+        const int pa = __syncthreads_or(bad & 1), pb = __syncthreads_or(bad & 2);
+        probe = (pa ? 1 : 0) | (pb ? 2 : 0);
+        if (probe == 3) return 3;
+    }
+    (void)s_ctl;
+    for (int task = tid; task < ngroups * 12; task += kThreads2) {
+        const int g = task / 12, kk = task - g * 12;
+        uint32_t wa, wb;
+        sign_word2(Lm, g, kk, wa, wb, &zero);
+        SA[g * 13 + kk] = wa; SB[g * 13 + kk] = wb;
+    }
+    lds_barrier2();
+    for (int g = tid; g < ngroups; g += kThreads2) { finish_group2(SA, g); finish_group2(SB, g); }
+    lds_barrier2();
+    int bad = probe | ((zero & 0x00800080u) ? 1 : 0) | ((zero & 0x80008000u) ? 2 : 0);
+    for (int task = tid; task < q * 12; task += kThreads2) {
+        const int i = task / 12, tj = task - i * 12;
+        const LdpcLayerDev ly = layers[i];
+        if (layer_syndrome2(SA, ly, entries + ly.first_entry, gp0, q, i, tj)) bad |= 1;
+        if (layer_syndrome2(SB, ly, entries + ly.first_entry, gp0, q, i, tj)) bad |= 2;
+    }
+    return bad;
+}
+
+template <int CNT, int NCMAX>
+__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
+                                              P2Regs<CNT> &r, uint32_t *pair_rec)
+{
+    if (active) p2_phase_a<CNT>(L, d, j, h, a0, a1, r, pair_rec);
+    if (d.kind == T2_LAYER_PAIR) {
+        lds_barrier2();
+        __builtin_amdgcn_s_setprio(3);
+        // frame A's chains on lanes 0..359, frame B's on lanes 384..743 (whole wavefronts apart), side by side
+        const int t = (int)threadIdx.x, frame = t >= 384 ? 1 : 0, node = t - 384 * frame;
+        if (node < 360) {
+            if (d.lmax >= 12) p2_pair_walk_segments(L, d, node, frame, pair_rec + 360 * frame);
+            else if (node < d.step) p2_pair_walk(L, d, node, frame, pair_rec + 360 * frame);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        lds_barrier2();
+        if (active) p2_pair_finish<CNT>(L, d, j, r);
+    } else if (d.kind == T2_LAYER_GENERIC) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int lv = 1; lv <= d.lmax; ++lv) {
+            if (active) p2_generic_level<CNT, NCMAX>(L, d, lv, info, r);
+            lds_barrier2();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (active) p2_generic_finish<CNT>(L, d, r);
+    }
+    lds_barrier2();
+}
+
+// one layer for a compile-time link count: record in, update, record out. RW = record dwords per lane in memory (>= P2Regs::W).
+template <int CNT, int NCMAX>
+__device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
+                                            const uint32_t *rec_in, uint32_t *__restrict__ rec_out, uint32_t *pair_rec)
+{
+    P2Regs<CNT> r;
+    constexpr int W = P2Regs<CNT>::W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) r.mo[w] = rec_in[w];
+    layer_update2<CNT, NCMAX>(L, d, j, h, active, a0, a1, info, r, pair_rec);
+    if (active) {
+        if constexpr (W <= 4) {
+            uint4 o = make_uint4(r.mn[0], W > 1 ? r.mn[1] : 0u, W > 2 ? r.mn[2] : 0u, W > 3 ? r.mn[3] : 0u);
+            *reinterpret_cast<uint4 *>(rec_out) = o;
+        } else {
+            *reinterpret_cast<uint4 *>(rec_out) = make_uint4(r.mn[0], r.mn[1], r.mn[2], r.mn[3]);
+            *reinterpret_cast<uint2 *>(rec_out + 4) = make_uint2(r.mn[4], W > 5 ? r.mn[5] : 0u);
+        }
+    }
+}
+
+template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
+__global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
+                                                                   const uint32_t *__restrict__ cninfo, const uint32_t *__restrict__ entries2,
+                                                                   LdpcKernelParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *Lm = lds;                                                // [n][2] interleaved LLR bytes
+    int *s_ctl = reinterpret_cast<int *>(lds + p.lds_ctl_offset);
+    uint32_t *pair_rec = reinterpret_cast<uint32_t *>(lds + p.lds_rec_offset);     // [2][360]
+    uint32_t *SA = reinterpret_cast<uint32_t *>(lds + p.lds_sign_offset), *SB = SA + (p.n / 360) * 13;
+    uint32_t *lds_ent = reinterpret_cast<uint32_t *>(lds + p.lds_ent_offset);
+    for (int x = threadIdx.x; x < 2 * p.n_entries; x += kThreads2) lds_ent[x] = entries2[x];      // made visible by the first barrier below
+    LdsMem2 L{(uint32_t)(uintptr_t)(lds2_i8 *)Lm};
+
+    const int tid = threadIdx.x;
+    const int j = tid >> 1, h = tid & 1;
+    const bool active = j < 360;
+    if (L.off() != p.lds_base) {                     // the split table was built for another LDS layout: refuse, loudly
+        if (tid == 0) *p.error = 2;
+        return;
+    }
+    constexpr int RW = (HI + 2 + 1) / 2 > 8 ? 8 : 4;                 // record dwords per lane in memory: W <= 4 -> 4, else 8
+    const int group = p.group, wg_per_batch = group >> 1;
+    const int slot = blockIdx.x / wg_per_batch, member = blockIdx.x % wg_per_batch;
+    const int nslots = gridDim.x / wg_per_batch;
+    const int nbatches = (p.n_frames + group - 1) / group;
+    uint32_t *state = reinterpret_cast<uint32_t *>(p.state) + (size_t)blockIdx.x * p.q * 720 * RW;
+
+    if (tid == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int batch = slot; batch < nbatches; batch += nslots) {
+        const int frame_a = batch * group + 2 * member, frame_b = frame_a + 1;
+        const bool have_a = frame_a < p.n_frames, have_b = frame_b < p.n_frames;
+        const int nhave = (have_a ? 1 : 0) + (have_b ? 1 : 0);
+        int members = p.n_frames - batch * group;
+        members = members > group ? group : members;
+
+        if (have_a) {
+            // interleave the two frames' LLR bytes: (a0 a1 a2 a3), (b0 b1 b2 b3) -> (a0 b0 a1 b1), (a2 b2 a3 b3)
+            const uint32_t *sa = reinterpret_cast<const uint32_t *>(p.llr + (size_t)frame_a * p.n);
+            const uint32_t *sb = reinterpret_cast<const uint32_t *>(p.llr + (size_t)(have_b ? frame_b : frame_a) * p.n);
+            uint2 *dst = reinterpret_cast<uint2 *>(Lm);
+            for (int x = tid; x < p.n / 4; x += kThreads2) {
+                const uint32_t a = sa[x], b = sb[x];
+                dst[x] = make_uint2(__builtin_amdgcn_perm(b, a, 0x05010400u), __builtin_amdgcn_perm(b, a, 0x07030602u));
+            }
+            uint4 *st4 = reinterpret_cast<uint4 *>(state);
+            for (int x = tid; x < p.q * 720 * RW / 4; x += kThreads2) st4[x] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+
+        int trials = p.max_trials;
+        int result;
+        for (int t = 0;; ++t) {
+            // ---- parity check of both frames (LDPCDecoder::bad)
+            const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl) : 0;
+            const int bad_a = __syncthreads_or(bad & 1), bad_b = __syncthreads_or(bad & 2);
+            const int clean = (have_a && !bad_a ? 1 : 0) + (have_b && !bad_b ? 1 : 0);
+            int all_ok = clean == nhave;
+            if (group > 2 && have_a) {
+                // one word per (batch, trial): high half counts frames arrived, low half counts parity-clean frames
+                if (tid == 0) {
+                    unsigned *w = p.sync + (size_t)batch * (p.max_trials + 1) + t;
+                    atomicAdd(w, ((unsigned)nhave << 16) | (unsigned)clean);
+                    int verdict = -1;
+                    // a workgroup with a frame that still fails knows the verdict without waiting: the batch goes on
+                    if (!all_ok) verdict = 0;
+                    else {
+                        const long long t0 = wall_clock64();
+                        for (;;) {
+                            const unsigned v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((int)(v >> 16) >= members) { verdict = ((int)(v & 0xffffu) == members); break; }
+                            if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            if (wall_clock64() - t0 > p.spin_timeout_ticks) {
+                                __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                    s_ctl[0] = verdict;
+                }
+                __syncthreads();
+                const int verdict = s_ctl[0];
+                __syncthreads();
+                if (verdict < 0) { result = -3; break; }
+                all_ok = verdict;
+            }
+            if (all_ok) { result = trials; break; }
+            if (--trials < 0) { result = -1; break; }
+
+            // ---- one layered update sweep (LDPCDecoder::update)
+            if (have_a) {
+                uint32_t nxt[RW];
+                if (active) {
+                    const uint4 *q4 = reinterpret_cast<const uint4 *>(state + (size_t)tid * RW);
+#pragma unroll
+                    for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) nxt[w] = 0u;
+                }
+                uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
+                for (int i = 0; i < p.q; ++i) {
+                    const LdpcLayerDev ly = layers[i];
+                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
+                                entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
+                    const uint32_t info = info_nxt;
+                    const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
+                    const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
+                    const int a1 = a1b >= 0 ? L.off() + 2 * a1b : -1;
+                    uint32_t cur[RW];
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) cur[w] = nxt[w];
+                    if (active && i + 1 < p.q) {                                     // prefetch the next layer's record (and node)
+                        const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
+#pragma unroll
+                        for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
+                        info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
+                    }
+                    uint32_t *rec_out = state + ((size_t)i * 720 + tid) * RW;
+                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_step2<CNT, NCMAX>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec)));
+                }
+            }
+            __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep
+        }
+
+        // ---- outputs: hard decision of the information bits (ldpc_decoder.cpp:270-277), one bit per byte, frame by frame
+        if (have_a) {
+            const uint2 *src = reinterpret_cast<const uint2 *>(Lm);
+            if (p.bits) {
+                uint32_t *oa = reinterpret_cast<uint32_t *>(p.bits + (size_t)frame_a * p.k);
+                uint32_t *ob = reinterpret_cast<uint32_t *>(p.bits + (size_t)(have_b ? frame_b : frame_a) * p.k);
+                for (int x = tid; x < p.k / 4; x += kThreads2) {
+                    const uint2 v = src[x];                          // (a0 b0 a1 b1), (a2 b2 a3 b3)
+                    const uint32_t a = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u), b = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+                    oa[x] = (a >> 7) & 0x01010101u;
+                    if (have_b) ob[x] = (b >> 7) & 0x01010101u;
+                }
+            }
+            if (p.llr_out) {
+                uint32_t *oa = reinterpret_cast<uint32_t *>(p.llr_out + (size_t)frame_a * p.n);
+                uint32_t *ob = reinterpret_cast<uint32_t *>(p.llr_out + (size_t)(have_b ? frame_b : frame_a) * p.n);
+                for (int x = tid; x < p.n / 4; x += kThreads2) {
+                    const uint2 v = src[x];
+                    oa[x] = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);
+                    if (have_b) ob[x] = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+                }
+            }
+            if (tid == 0 && member == 0) p.trials_left[batch] = result;
+        }
+        __syncthreads();
+    }
+}
+
+typedef void (*ldpc2_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, const uint32_t *, LdpcKernelParams);
+ldpc2_kernel_fn pick_kernel2(int min_cnt, int max_cnt)
+{
+    if (min_cnt == max_cnt) {
+        switch (max_cnt) {
+        case 5: return ldpc_decode2_kernel<5, 5, 2>;      // N 1/2
+        case 8: return ldpc_decode2_kernel<8, 8, 4>;      // N 2/3
+        case 9: return ldpc_decode2_kernel<9, 9, 4>;      // N 3/5
+        case 12: return ldpc_decode2_kernel<12, 12, 4>;   // N 3/4
+        case 16: return ldpc_decode2_kernel<16, 16, 7>;   // N 4/5
+        case 20: return ldpc_decode2_kernel<20, 20, 6>;   // N 5/6
+        default: break;
+        }
+    }
+    if (max_cnt <= 8) return ldpc_decode2_kernel<1, 8>;
+    if (min_cnt >= 7 && max_cnt <= 12) return ldpc_decode2_kernel<7, 12>;
+    if (min_cnt >= 13 && max_cnt <= 17) return ldpc_decode2_kernel<13, 17>;
+    if (min_cnt >= 16 && max_cnt <= 20) return ldpc_decode2_kernel<16, 20>;
+    return ldpc_decode2_kernel<1, 20>;
+}
+
+}  // namespace
+
+// link-count ceiling of the variant pick_kernel2 chooses (its HI): fixes the record stride in memory
+static int picked_hi(int min_cnt, int max_cnt)
+{
+    if (min_cnt == max_cnt && (max_cnt == 5 || max_cnt == 8 || max_cnt == 9 || max_cnt == 12 || max_cnt == 16 || max_cnt == 20)) return max_cnt;
+    if (max_cnt <= 8) return 8;
+    if (min_cnt >= 7 && max_cnt <= 12) return 12;
+    if (min_cnt >= 13 && max_cnt <= 17) return 17;
+    return 20;
+}
+int ldpc_kernel2_record_dwords(int min_cnt, int max_cnt) { return (picked_hi(min_cnt, max_cnt) + 2 + 1) / 2 > 8 ? 8 : 4; }
+
+hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes)
+{
+    ldpc2_kernel_fn fn = pick_kernel2(min_cnt, max_cnt);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipFuncAttributes attr;
+    if ((e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(fn))) != hipSuccess) return e;
+    *static_lds_bytes = (int)attr.sharedSizeBytes;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads2, lds_bytes);
+}
+
+hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
+{
+    ldpc2_kernel_fn fn = pick_kernel2(min_cnt, max_cnt);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads2), lds_bytes, stream, p.layers, p.entries, p.cninfo, p.entries2, p);
+    return hipGetLastError();
+}
+
+}  // namespace t2gpu

@@ -31,7 +31,23 @@ struct t2gpu_ldpc {
     uint8_t *d_out = nullptr;
     int *d_trials = nullptr;
     int last_status = 0;
+    // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
+    bool packed_ok = false;
+    int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
+        p_rec_dwords = 0;
+    uint32_t *d_entries2p = nullptr;
+    uint32_t *d_state2 = nullptr;
+    size_t state2_blocks = 0;
 };
+
+// The packed variant decodes frames 2m, 2m + 1 of a batch in one workgroup: it needs an even group (the reference's SIMD batch is 32).
+// T2GPU_LDPC_PACKED=0 forces the one-frame kernel (A/B measurements, diagnostics with the in-kernel profiler).
+static bool use_packed(const t2gpu_ldpc *h)
+{
+    if (!h->packed_ok || (h->group & 1) || h->d_prof) return false;
+    if (const char *e = std::getenv("T2GPU_LDPC_PACKED")) if (std::atoi(e) == 0) return false;
+    return h->p_blocks_per_cu * h->num_cu >= h->group / 2;
+}
 
 static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->blocks_per_cu; }
 
@@ -108,6 +124,38 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 
     h->state_blocks = (size_t)resident_blocks(h);
     if ((e = hipMalloc(&h->d_state, h->state_blocks * h->g.q * 360 * sizeof(uint2))) != hipSuccess) return fail("hipMalloc state", e);
+    {   // the two-frame variant: LDS = interleaved LLRs of both frames | control words | 2 x 360 chain records | sign words of both
+        // frames | the table entries as (LDS address of bit 0 of the link's run, shift) pairs
+        const int n2 = 2 * h->g.n;
+        h->p_lds_ctl_offset = (n2 + 15) & ~15;
+        h->p_lds_rec_offset = h->p_lds_ctl_offset + 64;
+        h->p_lds_sign_offset = h->p_lds_rec_offset + 2 * 360 * 4;
+        h->p_lds_ent_offset = (h->p_lds_sign_offset + 2 * (h->g.n / 360) * 13 * 4 + 7) & ~7;
+        h->p_lds_bytes = h->p_lds_ent_offset + (int)h->g.entries.size() * 8;
+        h->p_rec_dwords = ldpc_kernel2_record_dwords(h->g.min_cnt, h->g.max_cnt);
+        if (h->p_lds_bytes <= (int)prop.sharedMemPerBlock || h->p_lds_bytes <= 160 * 1024) {
+            hipError_t e2 = ldpc_kernel2_attributes(h->g.min_cnt, h->g.max_cnt, h->p_lds_bytes, &h->p_blocks_per_cu, &h->p_lds_base);
+            if (e2 == hipSuccess && h->p_blocks_per_cu >= 1) {
+                if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {
+                    const int v = std::atoi(lim);
+                    if (v >= 1 && v < h->p_blocks_per_cu) h->p_blocks_per_cu = v;
+                }
+                std::vector<uint32_t> e2p(2 * h->g.entries.size());
+                for (size_t i = 0; i < h->g.entries.size(); ++i) {
+                    const uint32_t base = h->g.entries[i] & 0xffffu, shift = h->g.entries[i] >> 16;
+                    e2p[2 * i] = (uint32_t)h->p_lds_base + 2u * (base - shift);      // the address is this + 2 * (j >= shift ? j : j + 360)
+                    e2p[2 * i + 1] = shift;
+                }
+                h->state2_blocks = (size_t)h->num_cu * h->p_blocks_per_cu;
+                if ((e = hipMalloc(&h->d_entries2p, e2p.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
+                if ((e = hipMemcpy(h->d_entries2p, e2p.data(), e2p.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+                if ((e = hipMalloc(&h->d_state2, h->state2_blocks * h->g.q * 720 * h->p_rec_dwords * 4)) != hipSuccess) return fail("hipMalloc state", e);
+                h->packed_ok = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     h->sync_words = (size_t)(max_frames + 1) * 64;   // enough for group >= 1 and max_trials <= 63
     if ((e = hipMalloc(&h->d_sync, h->sync_words * 4)) != hipSuccess) return fail("hipMalloc sync", e);
     if ((e = hipMalloc(&h->d_error, 4)) != hipSuccess) return fail("hipMalloc", e);
@@ -120,7 +168,7 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
     hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
-    hipFree(h->d_resident);
+    hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     delete h;
 }
@@ -154,29 +202,32 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     hipStream_t s = (hipStream_t)stream;
     const int group = h->group;
     const int nbatches = (n_frames + group - 1) / group;
-    int maxslots = resident_blocks(h) / group;
+    const bool packed = use_packed(h);
+    const int wg_per_batch = packed ? group / 2 : group;                      // two frames per workgroup in the packed variant
+    int maxslots = (packed ? h->num_cu * h->p_blocks_per_cu : resident_blocks(h)) / wg_per_batch;
     if (maxslots < 1) { set_error("device cannot keep one batch resident"); return -1; }
     if (const char *lim = std::getenv("T2GPU_LDPC_MAX_SLOTS")) {              // experiments: leave part of the device to other streams
         const int v = std::atoi(lim);
         if (v >= 1 && v < maxslots) maxslots = v;
     }
     int nslots = nbatches < maxslots ? nbatches : maxslots;
-    int grid = nslots * group;
+    int grid = nslots * wg_per_batch;
     if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }
 
     T2_HIP(hipMemsetAsync(h->d_sync, 0, (size_t)nbatches * (h->max_trials + 1) * 4, s));
     T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
-    p.layers = h->d_layers; p.entries = h->d_entries; p.entries2 = h->d_entries2; p.lds_base = h->lds_base; p.cninfo = h->d_cninfo;
+    p.layers = h->d_layers; p.entries = h->d_entries; p.entries2 = packed ? h->d_entries2p : h->d_entries2;
+    p.lds_base = packed ? h->p_lds_base : h->lds_base; p.cninfo = h->d_cninfo;
     p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
-    p.state = h->d_state; p.sync = h->d_sync; p.error = h->d_error;
+    p.state = packed ? reinterpret_cast<uint2 *>(h->d_state2) : h->d_state; p.sync = h->d_sync; p.error = h->d_error;
     p.spin_timeout_ticks = 200000000LL;   // 2 s at 100 MHz
-    p.lds_ctl_offset = h->lds_ctl_offset;
-    p.lds_rec_offset = h->lds_rec_offset;
-    p.lds_sign_offset = h->lds_sign_offset;
-    p.lds_ent_offset = h->lds_ent_offset;
+    p.lds_ctl_offset = packed ? h->p_lds_ctl_offset : h->lds_ctl_offset;
+    p.lds_rec_offset = packed ? h->p_lds_rec_offset : h->lds_rec_offset;
+    p.lds_sign_offset = packed ? h->p_lds_sign_offset : h->lds_sign_offset;
+    p.lds_ent_offset = packed ? h->p_lds_ent_offset : h->lds_ent_offset;
     p.n_entries = (int)h->g.entries.size();
     p.prof = h->d_prof;
     p.resident = h->d_resident;
@@ -188,7 +239,8 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     if (const char *r = std::getenv("T2GPU_LDPC_ROUNDS_PER_LAUNCH")) rounds = std::atoi(r);
     if (rounds < 1 || (long)rounds * nslots >= nbatches) {
         h->resident_total += (unsigned)grid;
-        T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s));
+        else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
         return 0;
     }
     for (int b0 = 0; b0 < nbatches; b0 += rounds * nslots) {
@@ -202,8 +254,9 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         q.trials_left = d_trials_left + b0;
         q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
         const int slots = std::min(nslots, nb);
-        h->resident_total += (unsigned)(slots * group);
-        T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
+        h->resident_total += (unsigned)(slots * wg_per_batch);
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s));
+        else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
     }
     return 0;
 }
