@@ -34,7 +34,7 @@ __device__ __forceinline__ p16 p2_f(p16 a) { return p_clamp(a - p_set(1), 0, 126
 
 // (LLR bytes A, B in bytes 0, 1 of raw) - (message bytes A, B in bytes 2*odd, 2*odd + 1 of msg), sign-extended, one frame per half.
 // Both sign extensions ride on the subtract (SDWA byte selects); the second one writes the upper half and keeps the lower.
-__device__ __forceinline__ p16 p2_llr_minus_msg(uint32_t raw, uint32_t msg, int odd)
+__device__ __forceinline__ p16 p2_llr_minus_msg(uint16_t raw, uint32_t msg, int odd)
 {
     uint32_t d;
     if (odd) {
@@ -81,30 +81,35 @@ template <int CNT, class LMEM>
 __device__ __forceinline__ void p2_read_slot(const LMEM &L, P2Regs<CNT> &r, int v)
 {
     const bool present = p2_present(r, v);
-    const uint32_t raw = present ? L.ld16(r.addr[v]) : 0u;
+    const uint16_t raw = present ? L.ld16(r.addr[v]) : (uint16_t)0;
     const p16 x = p_clamp(p2_llr_minus_msg(raw, r.mo[v >> 1], v & 1), -128, 127);
     r.in[v] = present ? x : p_set(0);
     r.mag[v] = present ? p_max(x, p_set(0) - x) : p_set(255);
 }
 
-// pl_load. ent_lds: LDS address of the layer's entries as (base + 2 * (bit base - shift), shift) pairs; j2 = 2 j.
+// the lane's table entries of a layer: slot v <- entry 2v + h (information slots), from the LDS copy, issued together
 template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_load(const LMEM &L, int ent_lds, int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r)
+__device__ __forceinline__ void p2_entries(const LMEM &L, int ent_lds, int h, uint2 (&e)[(CNT + 3) / 2])
 {
-    constexpr int H = P2Regs<CNT>::H, W = P2Regs<CNT>::W;
-    r.h = h;
-#pragma unroll
-    for (int w = 0; w < W; ++w) r.mn[w] = 0u;
-    uint2 e[H];
-    const int j2 = 2 * j, jw2 = j2 + 720;
     const int mine = ent_lds + 8 * h;                              // the odd lane reads the odd entries
 #pragma unroll
-    for (int v = 0; v < H; ++v) {
+    for (int v = 0; v < (CNT + 3) / 2; ++v) {
         const int c0 = 2 * v, c1 = 2 * v + 1;
         if (c1 < CNT) e[v] = L.ld_pair(mine + 8 * c0);
         else if (c0 < CNT) e[v] = L.ld_pair(ent_lds + 8 * c0);
         else e[v] = make_uint2(0u, 0u);
     }
+}
+
+// pl_load. e: the lane's entries as (base + 2 * (bit base - shift), shift) pairs (p2_entries); j2 = 2 j.
+template <int CNT, class LMEM>
+__device__ __forceinline__ void p2_load(const LMEM &L, const uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r)
+{
+    constexpr int H = P2Regs<CNT>::H, W = P2Regs<CNT>::W;
+    r.h = h;
+#pragma unroll
+    for (int w = 0; w < W; ++w) r.mn[w] = 0u;
+    const int j2 = 2 * j, jw2 = j2 + 720;
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         const int c0 = 2 * v, c1 = 2 * v + 1;
@@ -114,9 +119,9 @@ __device__ __forceinline__ void p2_load(const LMEM &L, int ent_lds, int j, int h
         else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
         else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
     }
-    uint32_t raw[H];
+    uint16_t raw[H];
 #pragma unroll
-    for (int v = 0; v < H; ++v) raw[v] = p2_present(r, v) ? L.ld16(r.addr[v]) : 0u;
+    for (int v = 0; v < H; ++v) raw[v] = p2_present(r, v) ? L.ld16(r.addr[v]) : (uint16_t)0;
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         const bool present = p2_present(r, v);
@@ -194,10 +199,11 @@ __device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bo
 
 // pl_phase_a. pair_rec: [2][360] chain-walk records, one array per frame
 template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r, uint32_t *pair_rec)
+__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1,
+                                           P2Regs<CNT> &r, uint32_t *pair_rec)
 {
     constexpr int H = P2Regs<CNT>::H;
-    p2_load<CNT>(L, d.ent_lds, j, h, a_p0, a_p1, r);
+    p2_load<CNT>(L, e, j, h, a_p0, a_p1, r);
     if (d.kind == T2_LAYER_PLAIN) {
         p2_partial<CNT>(r, 0);
         p2_set_minima(r.p0, r.p1, r.m0, r.m1f, r.dm);

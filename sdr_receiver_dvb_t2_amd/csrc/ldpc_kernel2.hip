@@ -21,7 +21,8 @@ struct LdsMem2 {
     __device__ __forceinline__ int off() const { return (int)base; }
     __device__ __forceinline__ int8_t ld(int a) const { return *reinterpret_cast<const lds2_i8 *>((uint32_t)a); }
     __device__ __forceinline__ void st(int a, int8_t v) { *reinterpret_cast<lds2_i8 *>((uint32_t)a) = v; }
-    __device__ __forceinline__ uint32_t ld16(int a) const
+    // the LLR pair as ds_read_u16 delivers it; typed 16 bit so that no zero-extension is materialised (only bytes 0, 1 are ever read)
+    __device__ __forceinline__ uint16_t ld16(int a) const
     {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uint32_t)a);
     }
@@ -159,10 +160,10 @@ __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA,
 }
 
 template <int CNT, int NCMAX>
-__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
-                                              P2Regs<CNT> &r, uint32_t *pair_rec)
+__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, const uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a0, int a1,
+                                              uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec)
 {
-    if (active) p2_phase_a<CNT>(L, d, j, h, a0, a1, r, pair_rec);
+    if (active) p2_phase_a<CNT>(L, d, e, j, h, a0, a1, r, pair_rec);
     if (d.kind == T2_LAYER_PAIR) {
         lds_barrier2();
         __builtin_amdgcn_s_setprio(3);
@@ -188,15 +189,27 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, in
 }
 
 // one layer for a compile-time link count: record in, update, record out. RW = record dwords per lane in memory (>= P2Regs::W).
-template <int CNT, int NCMAX>
+// UNI (every layer of the code has CNT links): epf holds this layer's table entries on entry and the NEXT layer's on return -- their
+// LDS reads are issued ahead of this layer's LLR reads and so cost no round trip of their own (with one workgroup per CU there is
+// no neighbour to fill a wavefront's waits).
+template <int CNT, int NCMAX, bool UNI>
 __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
-                                            const uint32_t *rec_in, uint32_t *__restrict__ rec_out, uint32_t *pair_rec)
+                                            const uint32_t *rec_in, uint32_t *__restrict__ rec_out, uint32_t *pair_rec,
+                                            uint2 (&epf)[(CNT + 3) / 2], int next_ent_lds)
 {
     P2Regs<CNT> r;
-    constexpr int W = P2Regs<CNT>::W;
+    constexpr int W = P2Regs<CNT>::W, H = P2Regs<CNT>::H;
 #pragma unroll
     for (int w = 0; w < W; ++w) r.mo[w] = rec_in[w];
-    layer_update2<CNT, NCMAX>(L, d, j, h, active, a0, a1, info, r, pair_rec);
+    uint2 e[H];
+    if constexpr (UNI) {
+#pragma unroll
+        for (int v = 0; v < H; ++v) e[v] = epf[v];
+        if (active && next_ent_lds) p2_entries<CNT>(L, next_ent_lds, h, epf);
+    } else {
+        if (active) p2_entries<CNT>(L, d.ent_lds, h, e);
+    }
+    layer_update2<CNT, NCMAX>(L, d, e, j, h, active, a0, a1, info, r, pair_rec);
     if (active) {
         if constexpr (W <= 4) {
             uint4 o = make_uint4(r.mn[0], W > 1 ? r.mn[1] : 0u, W > 2 ? r.mn[2] : 0u, W > 3 ? r.mn[3] : 0u);
@@ -207,6 +220,12 @@ __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int 
         }
     }
 }
+
+#define T2_PROF2_T(var) long long var = p.prof ? (long long)__builtin_readcyclecounter() : 0
+#define T2_PROF2_ADD(slot, t0)                                                                                  \
+    do {                                                                                                        \
+        if (p.prof && threadIdx.x == 0) p.prof[blockIdx.x * 8 + (slot)] += (long long)__builtin_readcyclecounter() - (t0); \
+    } while (0)
 
 template <int LO, int HI, int NCMAX = T2_LDPC_NC_MAX>
 __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLayerDev *__restrict__ layers, const uint32_t *__restrict__ entries,
@@ -236,6 +255,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
     const int nbatches = (p.n_frames + group - 1) / group;
     uint32_t *state = reinterpret_cast<uint32_t *>(p.state) + (size_t)blockIdx.x * p.q * 720 * RW;
 
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 6] = wall_clock64();
     if (tid == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int batch = slot; batch < nbatches; batch += nslots) {
         const int frame_a = batch * group + 2 * member, frame_b = frame_a + 1;
@@ -262,10 +282,13 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
         int result;
         for (int t = 0;; ++t) {
             // ---- parity check of both frames (LDPCDecoder::bad)
+            T2_PROF2_T(tp0);
             const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl) : 0;
             const int bad_a = __syncthreads_or(bad & 1), bad_b = __syncthreads_or(bad & 2);
             const int clean = (have_a && !bad_a ? 1 : 0) + (have_b && !bad_b ? 1 : 0);
             int all_ok = clean == nhave;
+            T2_PROF2_ADD(0, tp0);
+            T2_PROF2_T(tp1);
             if (group > 2 && have_a) {
                 // one word per (batch, trial): high half counts frames arrived, low half counts parity-clean frames
                 if (tid == 0) {
@@ -295,6 +318,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                 if (verdict < 0) { result = -3; break; }
                 all_ok = verdict;
             }
+            T2_PROF2_ADD(1, tp1);
             if (all_ok) { result = trials; break; }
             if (--trials < 0) { result = -1; break; }
 
@@ -310,6 +334,11 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                     for (int w = 0; w < RW; ++w) nxt[w] = 0u;
                 }
                 uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
+                constexpr bool UNI = LO == HI;
+                uint2 epf[(HI + 3) / 2];
+                if constexpr (UNI) {
+                    if (active) p2_entries<HI>(L, L.off() + p.lds_ent_offset + 8 * layers[0].first_entry, h, epf);
+                }
                 for (int i = 0; i < p.q; ++i) {
                     const LdpcLayerDev ly = layers[i];
                     LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
@@ -328,7 +357,14 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                         info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
                     }
                     uint32_t *rec_out = state + ((size_t)i * 720 + tid) * RW;
-                    T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, (layer_step2<CNT, NCMAX>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec)));
+                    T2_PROF2_T(tp2);
+                    const int next_ent = i + 1 < p.q ? L.off() + p.lds_ent_offset + 8 * layers[i + 1].first_entry : 0;
+                    if constexpr (UNI) {
+                        layer_step2<HI, NCMAX, true>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec, epf, next_ent);
+                    } else {
+                        T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec, none, 0); }));
+                    }
+                    T2_PROF2_ADD(2 + ly.kind, tp2);
                 }
             }
             __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep
@@ -360,6 +396,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
         }
         __syncthreads();
     }
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 7] = wall_clock64();
 }
 
 typedef void (*ldpc2_kernel_fn)(const LdpcLayerDev *, const uint32_t *, const uint32_t *, const uint32_t *, LdpcKernelParams);

@@ -41,10 +41,10 @@ struct t2gpu_ldpc {
 };
 
 // The packed variant decodes frames 2m, 2m + 1 of a batch in one workgroup: it needs an even group (the reference's SIMD batch is 32).
-// T2GPU_LDPC_PACKED=0 forces the one-frame kernel (A/B measurements, diagnostics with the in-kernel profiler).
+// T2GPU_LDPC_PACKED=0 forces the one-frame kernel (A/B measurements).
 static bool use_packed(const t2gpu_ldpc *h)
 {
-    if (!h->packed_ok || (h->group & 1) || h->d_prof) return false;
+    if (!h->packed_ok || (h->group & 1)) return false;
     if (const char *e = std::getenv("T2GPU_LDPC_PACKED")) if (std::atoi(e) == 0) return false;
     return h->p_blocks_per_cu * h->num_cu >= h->group / 2;
 }
