@@ -24,3 +24,64 @@ def aggregate_timing(local_seconds, local_units, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def frame_alignment(fec_frames_per_t2_frame, group=32):
+    """Smallest number of T2 frames whose FEC frames are a whole number of reference SIMD batches: shard boundaries at multiples of
+    it leave every batch of `group` FEC frames exactly as a single sequential receiver would form it (llr_demapper.cpp:742-760 fills a
+    batch across T2-frame boundaries), so drops and stop decisions are the same whichever GPU decodes a batch."""
+    from math import gcd
+    return group // gcd(group, fec_frames_per_t2_frame)
+
+
+class ordered_receiver(object):
+    """A stream of T2 frames over N devices with the transport stream coming out of ONE de-framer in frame order.
+
+    Every rank decodes a contiguous, batch-aligned range of the frames on its own GPU -- no collective on the data path. What crosses
+    ranks is the result: the descrambled BBFRAMEs (packed to bits) and the per-batch LDPC verdicts are gathered to rank 0 in rank
+    order = frame order, where the sequential epilogue runs as in the reference: bb_de_header carries a split TS packet (and in normal
+    mode the running CRC-8) from one BBFRAME into the next (bb_de_header.cpp:166-322), so it must see the frames of all ranks as one
+    stream. `decode(lo, hi)` -> (uint8 [n_fec][k_bch] one bit per byte, int32 trials per SIMD batch) for T2 frames [lo, hi); in
+    production it is a t2_rx on the rank's GPU, in the CPU tests a stub."""
+
+    def __init__(self, decode, fec_frames_per_t2_frame, group=32, need_plp=0, dist=None):
+        self.decode, self.per_frame, self.group, self.need_plp, self.dist = decode, fec_frames_per_t2_frame, group, need_plp, dist
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self._bbdh = None
+
+    def close(self):
+        if self._bbdh is not None:
+            from ._lib import lib
+            lib().t2gpu_bbdh_destroy(self._bbdh)
+            self._bbdh = None
+
+    def execute(self, total_frames):
+        """Decode `total_frames` T2 frames (this rank its share); returns the TS bytes on rank 0, None elsewhere."""
+        import numpy as np
+        align = frame_alignment(self.per_frame, self.group)
+        lo, hi = shard_frames(total_frames, self.world, self.rank, align)
+        if hi > lo:
+            bits, trials = self.decode(lo, hi)
+            bits = np.ascontiguousarray(bits, np.uint8)
+            mine = (np.packbits(bits, axis=1), bits.shape[1], np.ascontiguousarray(trials, np.int32))
+        else:
+            mine = (np.zeros((0, 0), np.uint8), 0, np.zeros(0, np.int32))
+        if self.world > 1:
+            parts = [None] * self.world if self.rank == 0 else None
+            self.dist.gather_object(mine, parts, dst=0)              # rank order = frame order; small (k_bch / 8 bytes per FEC frame)
+        else:
+            parts = [mine]
+        if self.rank != 0:
+            return None
+        from .chain import ts_from_bits
+        from ._lib import lib
+        if self._bbdh is None:
+            self._bbdh = lib().t2gpu_bbdh_create(self.need_plp)      # ONE de-framer for the whole stream: its packet state crosses ranks
+        out = []
+        for packed, k_bch, trials in parts:
+            if packed.shape[0] == 0:
+                continue
+            bits = np.unpackbits(packed, axis=1)[:, :k_bch]
+            out.append(ts_from_bits(bits, trials, self.group, self.need_plp, bbdh=self._bbdh))
+        return np.concatenate(out) if out else np.zeros(0, np.uint8)

@@ -235,3 +235,39 @@ def test_closed_loop_tracks_cfo_and_decodes(torch_cuda):
             sent = ts_slice(ts, f * nb, nb, k_bch).reshape(-1)                   # the first frame lines up with a fresh de-framer)
             assert np.array_equal(got[:per_frame * 188], sent[:per_frame * 188])
     rx.close()
+
+
+def test_ordered_receiver_on_one_gpu_equals_one_call(torch_cuda):
+    """shard.ordered_receiver (the multi-GPU form: ranks decode batch-aligned shares, rank 0 de-frames everything in frame order)
+    driven with a real t2_rx as its decoder, world size 1: the TS equals that of one call over the whole buffer. The N > 1 merge is
+    covered with gloo in tests/test_shard.py; what runs on each GPU is this decoder."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    from sdr_receiver_dvb_t2_amd.chain import ts_from_bits
+    from sdr_receiver_dvb_t2_amd.shard import ordered_receiver
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 16.0, 8
+    n_frames, seed = 3, 5
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    nb = t2_tx.plp_blocks_per_frame(m, lps, 2700)
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
+    frames = []
+    for f in range(n_frames):
+        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, f * nb, nb, k_bch), nb)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0))
+    i16, q16, frame_len = t2_tx.iq_stream(frames, m.fft_size // 128, s2, snr, seed)
+    d_i, d_q = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
+    rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames)
+    count = rx.execute_dev(d_i, d_q, n_frames, first_call=True)
+    bits, trials = rx.fetch(count)
+    want = ts_from_bits(bits, trials)
+
+    def decode(lo, hi):
+        n = rx.execute_dev(d_i[lo * frame_len:], d_q[lo * frame_len:], hi - lo, first_call=True)
+        return rx.fetch(n)
+    orx = ordered_receiver(decode, nb, 32, 0, None)
+    got = orx.execute(n_frames)
+    assert got.size > 50000 and np.array_equal(got, want)
+    orx.close()
+    rx.close()
