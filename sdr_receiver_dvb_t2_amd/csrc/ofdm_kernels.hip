@@ -61,6 +61,9 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
     constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    // 32K: one workgroup per symbol. Inside a grid-stride loop the compiler carried state across the back edge of the fully unrolled
+    // body and spilled 142 of the 128 registers a 1024-lane workgroup may have (572 B of scratch per lane, 1.6x the algorithmic HBM
+    // bytes, profiles/r01_rx_pmc.txt); straight-line it spills 20. 16K (512 lanes, 256 registers, no spills) keeps its persistent loop.
     for (int sym = blockIdx.x; sym < n_symbols; sym += gridDim.x) {
         // symbol `sym` of the batch starts at first + (sym / per_frame) * frame_stride + (sym % per_frame) * sym_stride cells
         const float2 *x = in + lay.first + (long)(sym / lay.per_frame) * lay.frame_stride + (long)(sym % lay.per_frame) * lay.sym_stride;
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
                 y[(kb + N / 2) & (N - 1)] = make_float2(b[r].x, b[r].y);
             }
         }
+        if constexpr (T2 == 32) break;                        // 32K: a single trip, no back edge (see above)
     }
 }
 
@@ -143,7 +147,7 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
                       hipStream_t s, const FftLayout *layout)
 {
     const FftLayout lay = layout ? *layout : FftLayout{0, 0, n_symbols > 0 ? n_symbols : 1, fft_size};
-    const int blocks = n_symbols < max_blocks ? n_symbols : max_blocks;
+    const int blocks = (fft_size == 32768 || n_symbols < max_blocks) ? n_symbols : max_blocks;   // 32K: one workgroup per symbol
     if (fft_size == 32768) {
         const int lds_bytes = 32 * 1024 * 4 > 32 * 32 * 33 * 4 ? 32 * 1024 * 4 : 32 * 32 * 33 * 4;
         static bool set = false;
