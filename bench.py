@@ -28,10 +28,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/*_rx_pmc.txt, tools/pmc_passes.sh: this
-# bench's launch, frames x 25 sweeps): 2 x FETCH_SIZE (gfx950 half-count correction, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes
-LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 6.078e6 + 1.0823e7) * 1024 / 3232 / 25
-LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.1908e10 / 3232 / 25
+# memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/r02_rx_pmc.txt, tools/pmc_passes.sh: this
+# bench's launch of 7676 frames x 25 sweeps of ldpc_decode2_kernel<12,12,4>): 2 x FETCH_SIZE (gfx950 half-count correction,
+# MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes. It is the per-link message bytes of the two-frame kernel (one byte per link and
+# frame, 16 B per lane and layer, read and written once per sweep) streaming through L2 / Infinity Cache.
+LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 2.4533e7 + 5.0858e7) * 1024 / 7676 / 25
+# SQ_INSTS_VALU of the same launch; a wave instruction occupies a SIMD for 4 cycles, 4 SIMDs x 256 CUs, 2.4 GHz (GRBM_GUI_ACTIVE of the
+# launch / its duration = 2.39 GHz per XCD)
+LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.7927e10 / 7676 / 25
 VALU_ISSUE_SLOTS_PER_S = 4 * 256 * 2.4e9 / 4
 
 # BASELINE.json configs that run on one GPU. mode = (fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data),
@@ -313,7 +317,7 @@ def main():
             ldpc_frames = count
             avg_ldpc_s = (sum(ldpc_ms) / len(ldpc_ms)) / 1e3
             achieved = sb["ldpc"] / avg_ldpc_s / 1e9
-            dom = {"kernel": "ldpc_decode_kernel", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
+            dom = {"kernel": "ldpc_decode2_kernel (two FEC frames per workgroup, packed 16-bit halves)", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
                    "traffic": round(LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP * ldpc_frames * args.trials) if args.config == 3 else None,
                    "share_of_step": round(avg_ldpc_s / (max_s / args.steps), 3),
                    "valu_issue_frac": round(LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP * ldpc_frames * args.trials / avg_ldpc_s / VALU_ISSUE_SLOTS_PER_S, 3)

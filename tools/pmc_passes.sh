@@ -5,10 +5,10 @@
 set -e
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-clamped-variant --steps 2 --warmup 1"
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1"
 cd /tmp && export TMPDIR=/tmp
 run() { rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}_$1 -o p -- $CMD > $ROOT/gpurun_out/pmc_${TAG}_$1.json 2> $ROOT/gpurun_out/pmc_${TAG}_$1.err || true; }
-run sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+run sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 cd $ROOT

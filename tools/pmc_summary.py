@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise tools/pmc_passes.sh output: per-launch counter values of the LDPC kernel (and totals of the other t2gpu kernels)."""
+"""Summarise tools/pmc_passes.sh output: per-launch counter values of the LDPC kernel, and for every other kernel of the library (the
+front-end and P1 kernels live in an anonymous namespace: named by their function) the per-launch average and the launch count."""
 import csv, glob, os, sys
 from collections import defaultdict
 tag = sys.argv[1]
@@ -18,20 +19,24 @@ for name in ("sq", "fetch", "write"):
         key = (k, int(row["Dispatch_Id"]))
         per[key][row["Counter_Name"]] += float(row["Counter_Value"])
         dur[key] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
-    ldpc = sorted(k for k in per if "ldpc_decode_kernel" in k[0])
-    print("## pass %s: ldpc_decode_kernel, one column per launch (%d launches), then duration in us" % (name, len(ldpc)))
+    ldpc = sorted(k for k in per if "ldpc_decode" in k[0])
+    print("## pass %s: %s, one column per launch (%d launches), then duration in us" % (name, ldpc[0][0].split("(")[0].split("::")[-1] if ldpc else "ldpc", len(ldpc)))
     counters = sorted({c for k in ldpc for c in per[k]})
     for c in counters:
         print("%-24s %s" % (c, " ".join("%.6g" % per[k][c] for k in ldpc)))
     print("%-24s %s" % ("dur_us", " ".join("%.1f" % dur[k] for k in ldpc)))
     other = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(int)
+    tdur = defaultdict(float)
     for (k, d), cs in per.items():
-        if "ldpc_decode_kernel" in k:
+        if "ldpc_decode" in k:
             continue
-        short = k.split("(")[0].split("::")[-1][:40]
+        short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("::")[-1][:44]
+        launches[short] += 1
+        tdur[short] += dur[(k, d)]
         for c, v in cs.items():
             other[short][c] += v
-    if name != "sq":
-        print("## pass %s: other kernels, summed over all launches of the run" % name)
-        for k in sorted(other):
-            print("%-42s %s" % (k, " ".join("%s=%.6g" % (c, v) for c, v in sorted(other[k].items()))))
+    print("## pass %s: other kernels, AVERAGE PER LAUNCH (launches, avg us)" % name)
+    for k in sorted(other):
+        n = launches[k]
+        print("%-46s n=%-3d %9.1f us  %s" % (k, n, tdur[k] / n, " ".join("%s=%.6g" % (c, v / n) for c, v in sorted(other[k].items()))))

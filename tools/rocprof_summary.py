@@ -15,9 +15,9 @@ def main():
         lines.append("%-70s %8d %14.3f %14.3f %8.3f" % (name[:70], calls, tot, avg, pct))
     try:
         k = c.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size, "
-                      "min(duration), max(duration), count(*) from kernels where name like 't2gpu%' group by name").fetchall()
+                      "min(duration), max(duration), count(*) from kernels where name like '%t2gpu%' or name like '%front_%' or name like '%p1_%' or name like '%cp_correlate%' group by name").fetchall()
         lines.append("")
-        lines.append("# t2gpu kernels: grid, workgroup, dynamic LDS, VGPR, AGPR, SGPR, scratch, min/max duration (ns), launches")
+        lines.append("# library kernels: grid, workgroup, dynamic LDS, VGPR, AGPR, SGPR, scratch, min/max duration (ns), launches")
         for r in k:
             lines.append("  " + " | ".join(str(x) for x in r))
     except sqlite3.Error as e:

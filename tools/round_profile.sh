@@ -8,7 +8,7 @@ rm -rf gpurun_out/prof_$TAG; mkdir -p gpurun_out/prof_$TAG
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3
 timeout 600 python bench.py --steps 10 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline --no-clamped-variant --steps 6 --warmup 1 \
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o $TAG -- python $R/bench.py --no-cpu-baseline --no-extra-legs --steps 6 --warmup 1 \
     > $R/gpurun_out/bench_under_rocprof_$TAG.json 2> $R/gpurun_out/prof_$TAG.err
 cd $R
 python tools/rocprof_summary.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) gpurun_out/${TAG}_kernel_stats.txt | head -8
