@@ -61,6 +61,8 @@ def ts_slice(ts, frame_pos, nb, k_bch):
     # 256-QAM: the reference's int8 cast wraps on the outer points at every SNR (see include/t2gpu.h, t2gpu_demap_configure);
     # with the clamping extension the same chain decodes CFG-A
     ("CFG-A 32K ext PP7 256-QAM 64800 r3/4 (clamped LLRs)", (5, 1, 6, 4, 0, 59), 350, 3, 1, 3, 22.0, True),
+    # BASELINE config 5's workload: CFG-A with r = 2/3 (demux_256_fec_size_normal_2_3, llr_demapper.cpp:677), same extension
+    ("CFG-C 32K ext PP7 256-QAM 64800 r2/3 (clamped LLRs)", (5, 1, 6, 4, 0, 59), 350, 3, 1, 2, 22.0, True),
     # the rest of SURVEY.md 8(f)-4: QPSK, the remaining pilot patterns, tone reservation, the remaining code rates
     ("16K normal PP1 GI1/4 QPSK 16200 r4/5", (4, 0, 0, 3, 0, 17), 150, 0, 0, 4, 9.0, False),
     ("32K normal PP8 GI1/16 QPSK 64800 r5/6 (FEC block larger than LDS: per-cell TI path)", (5, 0, 7, 1, 0, 30), 300, 0, 1, 5, 10.0, False),

@@ -271,3 +271,36 @@ def test_ordered_receiver_on_one_gpu_equals_one_call(torch_cuda):
     assert got.size > 50000 and np.array_equal(got, want)
     orx.close()
     rx.close()
+
+
+def test_stage_timers_config2_entry_point_and_sync_sums(torch_cuda):
+    """t2gpu_rx_stage_ms (HIP events between the stages of a call), t2gpu_rx_fft_eq_demap_dev (BASELINE config 2: FFT + equalisers +
+    de-interleave + demap of the frames the last call left in the handle) and t2gpu_rx_sync_sums (the per-symbol synchronisation
+    sums the reference always forms; they equal what the stand-alone equaliser entry points return for the same spectra)."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    mode, lps, mod, fec_type, code_rate, snr, s2 = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 16.0, 8
+    n_frames, seed = 2, 9
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    nb = t2_tx.plp_blocks_per_frame(m, lps, 2700)
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
+    frames = []
+    for f in range(n_frames):
+        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, f * nb, nb, k_bch), nb)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0))
+    i16, q16, frame_len = t2_tx.iq_stream(frames, m.fft_size // 128, s2, snr, seed)
+    rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames)
+    count = rx.execute_dev(torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda(), n_frames, first_call=True)
+    ms = rx.stage_ms()
+    assert set(ms) == set(rx.STAGES) and all(v > 0 for v in ms.values()), ms
+    assert ms["ldpc"] == pytest.approx(rx.last_ldpc_ms(), rel=0.2)
+    bits0, trials0 = rx.fetch(count)
+    sync0 = rx.sync_sums(n_frames)
+    assert sync0.shape == (n_frames * m.len_frame, 2) and np.isfinite(sync0).all() and np.abs(sync0[:, 0]).max() > 0
+    rx.fft_eq_demap_dev(n_frames)
+    ms2 = rx.stage_ms()
+    assert all(ms2[k] > 0 for k in ("fft", "equalise", "ti", "demap")) and all(ms2[k] < 0 for k in ("front", "p1", "guard_corr", "ldpc", "descramble"))
+    assert np.array_equal(rx.sync_sums(n_frames), sync0)                       # the same spectra equalised again: the same sums
+    rx.close()
