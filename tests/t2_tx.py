@@ -1,8 +1,10 @@
-"""Transmitter-side model of the DVB-T2 chain (test infrastructure): ETSI EN 302 755 forward operations written
-independently of the receiver restatements -- mode adaptation (BBFRAMEs in HEM), BB scrambling, (BCH parity left zero:
-the reference ignores it, bch_decoder.cpp:136), LDPC encoding, bit interleaving + demultiplexing, QAM mapping, constellation
-rotation with cyclic Q delay, cell and time interleaving. It uses only the permutation TABLES of the receiver (inverted),
-never its processing code, so that "what the receiver recovers == what was sent" is a genuine end-to-end check."""
+"""Transmitter-side model of the DVB-T2 chain (test infrastructure): ETSI EN 302 755 forward operations -- mode adaptation
+(BBFRAMEs in HEM), BB scrambling, (BCH parity left zero: the reference ignores it, bch_decoder.cpp:136), LDPC encoding, bit
+interleaving + demultiplexing, QAM mapping, constellation rotation with cyclic Q delay, cell and time interleaving, framing, P1.
+It is NOT independent of the oracle: it inverts the oracle's permutation tables, PRBS and parity-check matrices. What makes its
+streams a meaningful stimulus is that the reference itself, compiled from /root/reference (oracle/ref_t2rx.cpp), decodes them:
+tests/golden/make_t2_golden.py feeds these streams to the reference's FEC chain and to its whole dvbt2_demodulator and the fixtures
+hold what it produced (the TS bytes equal the payload sent)."""
 import os
 
 import numpy as np
