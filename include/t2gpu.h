@@ -69,6 +69,8 @@ int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out
  * sums over all workgroups of the last launch: [0] parity check, [1] batch rendezvous, [2] PLAIN, [3] PAIR, [4] GENERIC
  * layers (shader clock cycles of wave 0). out8 may be NULL. */
 int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8);
+/* diagnostics: cycles workgroup 0 spent in each layer (first 64 layers) since t2gpu_ldpc_profile armed the counters */
+int t2gpu_ldpc_profile_layers(t2gpu_ldpc *h, long long *out64);
 /* after a synchronised execute: 0 = clean, 1 = a batch rendezvous timed out (results invalid) */
 int t2gpu_ldpc_status(t2gpu_ldpc *h);
 

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_ldpc_profile_layers": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),
     "t2gpu_demap_destroy": (None, [_vp]),
     "t2gpu_demap_configure": (ctypes.c_int, [_vp, ctypes.c_int]),

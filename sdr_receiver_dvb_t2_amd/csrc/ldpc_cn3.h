@@ -223,6 +223,20 @@ __device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const ui
         }
     } else {
         p2_partial<CNT>(r, d.nc);
+        if (d.band) {
+            // t2 band record of the node, one per frame: dword 0 = old messages of conflict slots 0..3, dword 1 = the partial result
+            // (two smallest raw magnitudes of the other slots, their sign product in bit 16). Slots 0, 2 live on the even lane (bytes
+            // 0/1 and 2/3 of its first record dword = frame A/B), slots 1, 3 on the odd one.
+            const uint32_t po = p2_xu(r.mo[0]);
+            if (h == 0) {
+                const uint32_t ma = __builtin_amdgcn_perm(po, r.mo[0], 0x06020400u), mb = __builtin_amdgcn_perm(po, r.mo[0], 0x07030501u);
+                const uint32_t p0 = u_of(r.p0), p1 = u_of(r.p1);
+                const uint32_t qa = (p0 & 0xffu) | ((p1 & 0xffu) << 8) | (((r.psx >> 15) & 1u) << 16);
+                const uint32_t qb = ((p0 >> 16) & 0xffu) | (((p1 >> 16) & 0xffu) << 8) | ((r.psx >> 31) << 16);
+                L.st_pair(d.band_rec_lds + 8 * j, ma, qa);
+                L.st_pair(d.band_rec_lds + 2880 + 8 * j, mb, qb);
+            }
+        }
     }
 }
 
@@ -337,6 +351,146 @@ __device__ __forceinline__ void p2_generic_finish(LMEM &L, const LayerDesc &d, P
         if (2 * v + 1 >= d.nc) {
             if ((2 * v >= d.nc) || r.h) p2_write_slot<CNT>(L, r, v, true);
         }
+    }
+}
+
+// ---- band walk (GENERIC layers with at most four conflict slots, ldpc_graph.h) ---------------------------------------------------
+// Lane group c < D walks nodes c, c + D, c + 2D, ... : band t = nodes [D t, D t + D) at step t, in the reference's ascending-j order
+// band by band (nodes of a band share no bit). A step is the conflict-slot part of the check-node update on plain 32-bit integers,
+// one frame per lane -- inputs L - old message of the conflict slots, merged with the node's partial result from phase A, new
+// a-posteriori values of those slots stored to the LLR memory -- and it leaves the inputs behind for the finish (p2_band_finish),
+// which builds the messages. A node is spread over LPN = 4, 2 or 1 adjacent lanes (slot c on sub-lane c mod LPN; minima and sign
+// product meet through quad DPP): the walk is one wavefront issuing for one band at a time, so the step costs its instruction
+// count, and LPN is the most that keeps D x LPN lanes inside the wavefront. The value slot 0 hands to node j + D (its slot 1) stays
+// in registers: no LDS round trip on the recurrence. pf: everything else a node reads was written two bands earlier or more, so
+// its loads are issued one step ahead. LDS accesses of a wavefront execute in order: no barrier between bands.
+template <int CTRL>
+__device__ __forceinline__ int p2_quad(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+template <int NC, int LPN, bool PF, class LMEM>
+__device__ __forceinline__ void p2_band_walk(LMEM &L, const LayerDesc &d, int lane, int frame)
+{
+    constexpr int K = 4 / LPN;                                      // slots a lane serves (slot c = sub + LPN k; absent when c >= NC)
+    const int D = d.band, sub = lane & (LPN - 1);
+    const int rec_lds = d.band_rec_lds + 2880 * frame;
+    int in_at = d.band_in_lds + 1440 * frame + sub + 4 * (lane / LPN);
+    int at[K], es[K], sh[K];
+    bool has[K];
+    int j = lane / LPN;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = sub + LPN * k;
+        has[k] = NC == 4 || c < NC;
+        const uint2 e = L.ld_pair(d.ent_lds + 8 * (has[k] ? c : 0));
+        es[k] = (int)e.y;
+        at[k] = (int)e.x + frame + 2 * j + (j >= es[k] ? 0 : 720);  // LLR byte of the slot for node j
+        sh[k] = 8 * c;
+    }
+    uint2 rec = L.ld_pair(rec_lds + 8 * j);
+    int Lv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) Lv[k] = (int)L.ld(at[k]);
+    // every load above has landed before the loop: a load still pending at the loop head costs an lgkmcnt(0) there in EVERY step,
+    // which also drains the stores the step before has just issued
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    while (j < 360) {
+        // the next node of this lane group (the last step repeats its own: nothing reads what that loads)
+        const int jn = j + D < 360 ? j + D : j, dj2 = 2 * (jn - j);
+        int an[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) an[k] = at[k] + dj2 - ((j < es[k] && jn >= es[k]) ? 720 : 0);
+        uint2 recn;
+        int Ln[K];
+        if constexpr (PF) {
+            recn = L.ld_pair(rec_lds + 8 * jn);
+#pragma unroll
+            for (int k = 0; k < K; ++k) Ln[k] = (int)L.ld(an[k]);
+        }
+        int x[K], mg[K];
+        int m0 = 0, m1 = 255, sx = (int)(rec.y << 15);              // bit 31 = sign product of the other slots
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int mo = __builtin_amdgcn_sbfe((int)rec.x, sh[k], 8);
+            const int v = t2_clamp(Lv[k] - mo, -128, 127);
+            x[k] = has[k] ? v : 0;
+            mg[k] = has[k] ? (v < 0 ? -v : v) : 255;
+            sx ^= x[k];
+            if (k == 0) m0 = mg[0];
+            else {
+                m1 = min(m1, max(m0, mg[k]));
+                m0 = min(m0, mg[k]);
+            }
+        }
+        if constexpr (LPN >= 2) {
+            const int b0 = p2_quad<0xB1>(m0), b1 = p2_quad<0xB1>(m1);
+            m1 = min(max(m0, b0), min(m1, b1));
+            m0 = min(m0, b0);
+            sx ^= p2_quad<0xB1>(sx);
+        }
+        if constexpr (LPN >= 4) {
+            const int b0 = p2_quad<0x4E>(m0), b1 = p2_quad<0x4E>(m1);
+            m1 = min(max(m0, b0), min(m1, b1));
+            m0 = min(m0, b0);
+            sx ^= p2_quad<0x4E>(sx);
+        }
+        if constexpr (LPN >= 2) sx ^= (int)(rec.y << 15);           // every lane started from the partial sign: an even count cancels
+        {
+            const int p0 = (int)(rec.y & 0xffu), p1 = (int)((rec.y >> 8) & 0xffu);
+            m1 = min(max(m0, p0), min(m1, p1));
+            m0 = min(m0, p0);
+        }
+        int hand = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int other = t2_clamp((mg[k] == m0 ? m1 : m0) - 1, 0, 126);
+            const int sgn = ((sx ^ x[k]) >> 31) | 1;
+            int sum;                                                // +-other + x
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(sum) : "v"(other), "v"(sgn), "v"(x[k]));
+            const int ln = t2_clamp(sum, -128, 127);
+            L.st(has[k] ? at[k] : d.dummy, (int8_t)ln);
+            L.st(has[k] ? in_at + LPN * k : d.dummy, (int8_t)x[k]);
+            if (k == 0) hand = ln;
+        }
+        if constexpr (!PF) {
+            recn = L.ld_pair(rec_lds + 8 * jn);
+#pragma unroll
+            for (int k = 0; k < K; ++k) Ln[k] = (int)L.ld(an[k]);
+        }
+        // slot 1 of node j + D is the bit slot 0 of node j just wrote
+        if constexpr (LPN == 1) Ln[1] = hand;
+        else {
+            const int from0 = p2_quad<(LPN == 2 ? 0xA0 : 0x00)>(hand);
+            Ln[0] = sub == 1 ? from0 : Ln[0];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { Lv[k] = Ln[k]; at[k] = an[k]; }
+        rec = recn;
+        in_at += 4 * D;
+        j += D;
+    }
+}
+
+// what p2_generic_level_nc + p2_generic_finish do, after a band walk: the walk has stored the conflict slots' new LLRs and left their
+// inputs; here the node forms its minima over all slots and the new messages of every slot, and stores the other slots' LLRs.
+template <int CNT, int NC, class LMEM>
+__device__ __forceinline__ void p2_band_finish(LMEM &L, const LayerDesc &d, int j, P2Regs<CNT> &r)
+{
+    constexpr int H = P2Regs<CNT>::H, NV = (NC + 1) / 2;
+    const uint32_t wa = L.ld32(d.band_in_lds + 4 * j), wb = L.ld32(d.band_in_lds + 1440 + 4 * j);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if ((2 * v + 1 < NC) || !r.h) {
+            // byte 2v + h of either word into the high bytes of the two halves, then an arithmetic shift: (frame A, frame B) sign-extended
+            const uint32_t sel = r.h ? (v ? 0x070c030cu : 0x050c010cu) : (v ? 0x060c020cu : 0x040c000cu);
+            const p16 x = p_of(__builtin_amdgcn_perm(wb, wa, sel)) >> p_set(8);
+            r.in[v] = x;
+            r.mag[v] = p_max(x, p_set(0) - x);
+        }
+    }
+    p2_merge<CNT, NV>(r, NC);
+#pragma unroll
+    for (int v = 0; v < H; ++v) {
+        p2_write_slot<CNT>(L, r, v, 2 * v + r.h >= NC);             // the conflict slots' LLRs were stored by the walk
     }
 }
 

@@ -55,6 +55,32 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
             if (d > 180) { std::swap(ents[0], ents[1]); d = 360 - d; }
             L.step = d;
         }
+        if (L.kind == T2_LAYER_GENERIC && L.n_conflict <= 4) {
+            // band walk: D = the smallest (shift_y - shift_x) mod 360 over ordered pairs of conflict entries of one group
+            int D = GROUP, bx = -1, by = -1, at_d = 0;
+            for (int x = 0; x < L.n_conflict; ++x)
+                for (int y = 0; y < L.n_conflict; ++y) {
+                    if (x == y || ents[x].group != ents[y].group) continue;
+                    const int d = ((ents[y].shift - ents[x].shift) % GROUP + GROUP) % GROUP;
+                    if (d < D) { D = d; bx = x; by = y; at_d = 1; }
+                    else if (d == D) ++at_d;
+                }
+            bool far = at_d == 1;
+            for (int x = 0; x < L.n_conflict; ++x)
+                for (int y = 0; y < L.n_conflict; ++y) {
+                    if (x == y || ents[x].group != ents[y].group || (x == bx && y == by)) continue;
+                    const int d = ((ents[y].shift - ents[x].shift) % GROUP + GROUP) % GROUP;
+                    if (d < 2 * D) far = false;
+                }
+            if (D >= 2 && D <= 32 && bx >= 0) {      // two lanes per node at least: D x 2 lanes of one wavefront
+                std::vector<Ent> re;
+                re.push_back(ents[bx]); re.push_back(ents[by]);
+                for (int x = 0; x < L.n_conflict; ++x)
+                    if (x != bx && x != by) re.push_back(ents[x]);
+                for (int x = 0; x < L.n_conflict; ++x) ents[x] = re[x];
+                L.band = D; L.band_prefetch = far ? 1 : 0;
+            }
+        }
         for (const Ent &e : ents) g.entries.push_back((uint32_t)(e.group * GROUP) | ((uint32_t)e.shift << 16));
         g.max_cnt = std::max(g.max_cnt, L.cnt);
         g.min_cnt = std::min(g.min_cnt, L.cnt);
@@ -76,6 +102,16 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
                 lev[j] = (uint8_t)lv;
                 g.cninfo[(size_t)i * GROUP + j] = (uint32_t)lv | (dep << 8) | ((uint32_t)j << 20);
                 lmax = std::max(lmax, lv);
+            }
+            if (L.band) {
+                // every earlier node sharing a bit lies in an earlier band (else the layer keeps the level schedule only)
+                for (int j = 0; j < GROUP && L.band; ++j)
+                    for (int x = 0; x < L.n_conflict && L.band; ++x)
+                        for (int y = 0; y < L.n_conflict; ++y) {
+                            if (x == y || ents[x].group != ents[y].group) continue;
+                            const int m = ((j - ents[x].shift) % GROUP + GROUP) % GROUP, j2 = (ents[y].shift + m) % GROUP;
+                            if (j2 < j && j2 / L.band >= j / L.band) { L.band = 0; L.band_prefetch = 0; break; }
+                        }
             }
             if (L.kind == T2_LAYER_GENERIC) {
                 // thread t of the workgroup takes node order[t]: nodes sorted by level, so that a level step keeps one or two

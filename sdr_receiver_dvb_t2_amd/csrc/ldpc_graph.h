@@ -24,6 +24,12 @@ struct LdpcLayer {
     int n_conflict;    // leading entries that belong to a group appearing more than once in this layer
     int kind;          // T2_LAYER_PLAIN / PAIR / GENERIC (ldpc_cn.h)
     int step;          // PAIR: (shift of slot 1 - shift of slot 0) mod 360, 1..180
+    // GENERIC layers with at most four conflict slots can also be walked in BANDS (ldpc_cn3.h, p2_band_walk): `band` = D, the smallest
+    // index distance of two nodes that share a bit. Nodes [D t, D t + D) are then independent of each other and depend only on bands
+    // before t, which is the reference's ascending-j order again. Slots 0 / 1 are the pair whose bit node j hands to node j + D
+    // (through slot 0 of j, slot 1 of j + D). band_prefetch: every other dependency reaches back two bands or more. 0 = not eligible
+    // (more than four conflict slots, or D > 32: those layers are few-level ones and keep the level schedule).
+    int band = 0, band_prefetch = 0;
 };
 
 struct LdpcGraph {

@@ -11,7 +11,7 @@
 namespace t2gpu {
 
 struct LdpcLayerDev {
-    int first_entry, cnt, lmax, nc, kind, step, pad0, pad1;
+    int first_entry, cnt, lmax, nc, kind, step, band, band_prefetch;   // band: GENERIC layers the two-frame kernel walks in bands (ldpc_graph.h)
 };
 
 struct LdpcKernelParams {
@@ -39,7 +39,8 @@ struct LdpcKernelParams {
     int lds_rec_offset;           // byte offset of the 360 chain-walk records (PAIR layers)
     int lds_sign_offset;          // byte offset of the packed sign words (13 dwords per 360-bit group)
     int lds_ent_offset, n_entries; // pair-lane kernel: byte offset of the LDS copy of entries2, number of entries
-    long long *prof;              // optional [grid][8] cycle counters (diagnostics; null in production)
+    long long *prof;              // optional [prof_blocks][8] cycle counters + [64] per-layer cycles of workgroup 0 (diagnostics; null in production)
+    int prof_blocks;
     unsigned *resident;           // counts workgroups that have started, cumulatively over launches (t2gpu_ldpc_wait_resident)
 };
 

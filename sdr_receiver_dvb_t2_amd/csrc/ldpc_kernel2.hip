@@ -27,6 +27,13 @@ struct LdsMem2 {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uint32_t)a);
     }
     __device__ __forceinline__ void st16(int a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uint32_t)a) = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t ld32(int a) const { return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a); }
+    __device__ __forceinline__ void st32(int a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)a) = v; }
+    __device__ __forceinline__ void st_pair(int a, uint32_t x, uint32_t y)
+    {
+        __attribute__((address_space(3))) uint32_t *q = reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)a);
+        q[0] = x; q[1] = y;
+    }
     __device__ __forceinline__ uint2 ld_pair(int a) const
     {
         const __attribute__((address_space(3))) uint32_t *q = reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a);
@@ -176,6 +183,34 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, co
         __builtin_amdgcn_s_setprio(0);
         lds_barrier2();
         if (active) p2_pair_finish<CNT>(L, d, j, r);
+    } else if (d.kind == T2_LAYER_GENERIC && d.band) {
+        if constexpr (NCMAX >= 3) {
+            lds_barrier2();
+            __builtin_amdgcn_s_setprio(3);
+            // frame A's bands on the first lanes of wavefront 0, frame B's on those of wavefront 6 (another SIMD)
+            const int t = (int)threadIdx.x, frame = t >= 384 ? 1 : 0, lane = t - 384 * frame;
+#define T2_BAND_(NC_, LPN_)                                                          \
+    do {                                                                             \
+        if (lane < LPN_ * d.band) {                                                  \
+            if (d.band_prefetch) p2_band_walk<NC_, LPN_, true>(L, d, lane, frame);   \
+            else p2_band_walk<NC_, LPN_, false>(L, d, lane, frame);                  \
+        }                                                                            \
+    } while (0)
+            if (d.nc == 3) {
+                if (d.band <= 16) T2_BAND_(3, 4);
+                else T2_BAND_(3, 2);
+            } else if constexpr (NCMAX >= 4) {
+                if (d.band <= 16) T2_BAND_(4, 4);
+                else T2_BAND_(4, 2);
+            }
+#undef T2_BAND_
+            __builtin_amdgcn_s_setprio(0);
+            lds_barrier2();
+            if (active) {
+                if (d.nc == 3) p2_band_finish<CNT, 3>(L, d, j, r);
+                else if constexpr (NCMAX >= 4) p2_band_finish<CNT, 4>(L, d, j, r);
+            }
+        }
     } else if (d.kind == T2_LAYER_GENERIC) {
         __builtin_amdgcn_s_setprio(3);
         for (int lv = 1; lv <= d.lmax; ++lv) {
@@ -343,8 +378,10 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                     const LdpcLayerDev ly = layers[i];
                     LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
                                 entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
+                    d.band = (ly.nc <= NCMAX && ly.nc <= ly.cnt) ? ly.band : 0; d.band_prefetch = ly.band_prefetch;
+                    d.band_rec_lds = L.off() + p.lds_sign_offset; d.band_in_lds = L.off() + p.lds_rec_offset;
                     const uint32_t info = info_nxt;
-                    const int jn = ly.kind == T2_LAYER_GENERIC ? (int)(info >> 20) : j;
+                    const int jn = (ly.kind == T2_LAYER_GENERIC && !d.band) ? (int)(info >> 20) : j;
                     const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
                     const int a1 = a1b >= 0 ? L.off() + 2 * a1b : -1;
                     uint32_t cur[RW];
@@ -365,6 +402,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                         T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec, none, 0); }));
                     }
                     T2_PROF2_ADD(2 + ly.kind, tp2);
+                    if (p.prof && blockIdx.x == 0 && tid == 0 && i < 64) p.prof[(size_t)p.prof_blocks * 8 + i] += (long long)__builtin_readcyclecounter() - tp2;
                 }
             }
             __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep

@@ -103,9 +103,11 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     }
 
     std::vector<LdpcLayerDev> ld(h->g.q);
+    const char *band_env = std::getenv("T2GPU_LDPC_BAND");                     // experiments: 0 keeps the level schedule in GENERIC layers
+    const bool band_on = !(band_env && std::atoi(band_env) == 0);
     for (int i = 0; i < h->g.q; ++i)
         ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict,
-                             h->g.layers[i].kind, h->g.layers[i].step, 0, 0};
+                             h->g.layers[i].kind, h->g.layers[i].step, band_on ? h->g.layers[i].band : 0, h->g.layers[i].band_prefetch};
     if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_entries, h->g.entries.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
@@ -130,7 +132,8 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
         h->p_lds_ctl_offset = (n2 + 15) & ~15;
         h->p_lds_rec_offset = h->p_lds_ctl_offset + 64;
         h->p_lds_sign_offset = h->p_lds_rec_offset + 2 * 360 * 4;
-        h->p_lds_ent_offset = (h->p_lds_sign_offset + 2 * (h->g.n / 360) * 13 * 4 + 7) & ~7;
+        // the sign words of the parity check; between checks the same room holds the band-walk records of a layer (2 x 360 x 8 B)
+        h->p_lds_ent_offset = (h->p_lds_sign_offset + std::max(2 * (h->g.n / 360) * 13 * 4, 2 * 360 * 8) + 7) & ~7;
         h->p_lds_bytes = h->p_lds_ent_offset + (int)h->g.entries.size() * 8;
         h->p_rec_dwords = ldpc_kernel2_record_dwords(h->g.min_cnt, h->g.max_cnt);
         if (h->p_lds_bytes <= (int)prop.sharedMemPerBlock || h->p_lds_bytes <= 160 * 1024) {
@@ -230,8 +233,9 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.lds_ent_offset = packed ? h->p_lds_ent_offset : h->lds_ent_offset;
     p.n_entries = (int)h->g.entries.size();
     p.prof = h->d_prof;
+    p.prof_blocks = (int)h->state_blocks;
     p.resident = h->d_resident;
-    if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long), s));
+    if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, (h->state_blocks * 8 + 64) * sizeof(long long), s));
     // One persistent launch walks all batches (best when batches take different numbers of sweeps). T2GPU_LDPC_ROUNDS_PER_LAUNCH=r
     // cuts it into launches of r rounds of `nslots` batches: workgroups of other streams that need a whole CU's LDS (the 32K FFT)
     // then get in at the launch boundaries instead of waiting for the whole decode.
@@ -271,12 +275,19 @@ extern "C" int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream)
     return 0;
 }
 
+extern "C" int t2gpu_ldpc_profile_layers(t2gpu_ldpc *h, long long *out64)
+{
+    if (!h || !h->d_prof || !out64) return -1;
+    T2_HIP(hipMemcpy(out64, h->d_prof + h->state_blocks * 8, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8)
 {
     if (!h) return -1;
     if (!h->d_prof) {           // first call arms the counters for subsequent launches
-        T2_HIP(hipMalloc(&h->d_prof, h->state_blocks * 8 * sizeof(long long)));
-        T2_HIP(hipMemset(h->d_prof, 0, h->state_blocks * 8 * sizeof(long long)));
+        T2_HIP(hipMalloc(&h->d_prof, (h->state_blocks * 8 + 64) * sizeof(long long)));
+        T2_HIP(hipMemset(h->d_prof, 0, (h->state_blocks * 8 + 64) * sizeof(long long)));
     }
     if (out8) {
         std::vector<long long> v(h->state_blocks * 8);

@@ -28,3 +28,9 @@ print("launch %.3f ms, frames %d, avg updates %.2f" % (e0.elapsed_time(e1), fram
 for n, v in zip(names, out):
     print("%-16s %14d cycles  %5.1f %%" % (n, v, 100.0 * v / max(tot, 1)))
 print("workgroup lifetime sum %.3f ms over span %.3f ms -> average %.1f workgroups alive" % (out[6] / 1e5, out[7] / 1e5, out[6] / max(out[7], 1)))
+lay = (ctypes.c_longlong * 64)()
+if pkg.lib().t2gpu_ldpc_profile_layers(dec._h, lay) == 0 and sum(lay):
+    tl = sum(lay)
+    print("per-layer cycles of workgroup 0 (share of its layer time):")
+    print(" ".join("%d:%.1f%%" % (i, 100.0 * lay[i] / tl) for i in range(64) if lay[i]))
+    print("cycles per layer per sweep: " + " ".join("%d:%d" % (i, lay[i] // max(1, int((25 - trials.float()).max()))) for i in range(64) if lay[i]))
