@@ -33,6 +33,8 @@ struct LdpcKernelParams {
     // scratch
     uint2 *state;                 // [grid][q*360] check-node records
     unsigned *sync;               // [batches][max_trials+1], zeroed before launch
+    unsigned *ticket;             // two-frame kernel, optional: [0] = next batch to hand out, [1 + slot * ticket_rounds + r] = batch + 1
+    int ticket_rounds;            //   that slot's workgroups take in their round r; zeroed before launch. Null: batches strided statically
     int *error;                   // zeroed before launch; 1 = batch rendezvous timed out
     long long spin_timeout_ticks; // wall_clock64 ticks (100 MHz)
     int lds_ctl_offset;           // byte offset of the control words behind the LLR array

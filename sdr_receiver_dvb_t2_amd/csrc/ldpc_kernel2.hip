@@ -292,7 +292,39 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
 
     if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + 6] = wall_clock64();
     if (tid == 0) __hip_atomic_fetch_add(p.resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int batch = slot; batch < nbatches; batch += nslots) {
+    for (int round = 0;; ++round) {
+        // Which batch next: by ticket -- the slot's first workgroup draws the next unclaimed batch and posts it, its siblings read
+        // the post -- so that slots whose batches stop early take more of them; without tickets, batch = slot + round * slots.
+        int batch = slot + round * nslots;
+        if (p.ticket) {
+            if (tid == 0) {
+                unsigned *w = p.ticket + 1 + (size_t)slot * p.ticket_rounds + round;
+                unsigned v = 0;
+                if (round >= p.ticket_rounds) v = 0x7fffffffu;
+                else if (member == 0) {
+                    v = atomicAdd(p.ticket, 1u) + 1u;
+                    __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const long long t0 = wall_clock64();
+                    for (;;) {
+                        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v) break;
+                        if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = 0x7fffffffu; break; }
+                        if (wall_clock64() - t0 > p.spin_timeout_ticks) {
+                            __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v = 0x7fffffffu;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                }
+                s_ctl[1] = (int)(v - 1u);
+            }
+            __syncthreads();
+            batch = s_ctl[1];
+            __syncthreads();
+        }
+        if (batch >= nbatches) break;
         const int frame_a = batch * group + 2 * member, frame_b = frame_a + 1;
         const bool have_a = frame_a < p.n_frames, have_b = frame_b < p.n_frames;
         const int nhave = (have_a ? 1 : 0) + (have_b ? 1 : 0);

@@ -21,6 +21,8 @@ struct t2gpu_ldpc {
     uint2 *d_state = nullptr;
     size_t state_blocks = 0;
     unsigned *d_sync = nullptr;
+    unsigned *d_ticket = nullptr;  // batch tickets of the two-frame kernel (ldpc_kernel.h)
+    size_t ticket_words = 0;
     size_t sync_words = 0;
     int *d_error = nullptr;
     unsigned *d_resident = nullptr;     // signal memory: workgroups started, cumulative
@@ -172,7 +174,7 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
     if (!h) return;
     hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
-    hipFree(h->d_sync); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
+    hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     delete h;
 }
 
@@ -227,6 +229,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
     p.state = packed ? reinterpret_cast<uint2 *>(h->d_state2) : h->d_state; p.sync = h->d_sync; p.error = h->d_error;
     p.spin_timeout_ticks = 200000000LL;   // 2 s at 100 MHz
+    p.ticket = nullptr; p.ticket_rounds = 0;
     p.lds_ctl_offset = packed ? h->p_lds_ctl_offset : h->lds_ctl_offset;
     p.lds_rec_offset = packed ? h->p_lds_rec_offset : h->lds_rec_offset;
     p.lds_sign_offset = packed ? h->p_lds_sign_offset : h->lds_sign_offset;
@@ -242,6 +245,18 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     int rounds = 0;
     if (const char *r = std::getenv("T2GPU_LDPC_ROUNDS_PER_LAUNCH")) rounds = std::atoi(r);
     if (rounds < 1 || (long)rounds * nslots >= nbatches) {
+        const char *tk = std::getenv("T2GPU_LDPC_TICKET");                    // experiments: 0 = static striding of the batches
+        if (packed && nbatches > nslots && !(tk && std::atoi(tk) == 0)) {
+            const size_t words = 1 + (size_t)nslots * nbatches;
+            if (words > h->ticket_words) {
+                T2_HIP(hipStreamSynchronize(s));
+                hipFree(h->d_ticket); h->d_ticket = nullptr; h->ticket_words = 0;
+                T2_HIP(hipMalloc(&h->d_ticket, words * 4));
+                h->ticket_words = words;
+            }
+            T2_HIP(hipMemsetAsync(h->d_ticket, 0, words * 4, s));
+            p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
+        }
         h->resident_total += (unsigned)grid;
         if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s));
         else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
