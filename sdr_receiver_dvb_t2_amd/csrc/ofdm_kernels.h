@@ -23,7 +23,7 @@ struct EqParams {
     const int4 *segs;          // [rows][max_seg] (left pilot, right pilot, first de-interleaver index, data cells)
     const int32_t *seg_count;  // [rows]
     const int32_t *h_even, *h_odd;
-    const float *lut_sin, *lut_cos;   // 65536-entry tables of DSP/fast_math.h
+    const float2 *lut_cs;      // the 65536-entry cos / sin tables of DSP/fast_math.h, interleaved: one 8-byte read per cell
     // Frame layout (per_frame > 0): symbol b of the batch is data symbol `first + b % per_frame` of frame b / per_frame; its
     // spectrum is at symbols + (frame * in_syms_per_frame + first + b % per_frame) * fft_size, its cells go to
     // out + frame * out_frame_stride + out_offset + (b % per_frame) * c_data. per_frame == 0: symbols and cells back to back,
@@ -38,8 +38,13 @@ struct EqParams {
     // reference binary (-Ofast, sdr_receiver_dvb_t2.pro:33-39) evaluates sqrt(norm(cell)) / amp_pilot as a product with
     // 1 / amp_pilot there; data_symbol::execute, whose amplitude alternates, keeps the division. Pinned by tests/golden/t2sym_golden.npz.
     int recip_amp = 0;
+    const uint16_t *dcar = nullptr;   // [rows][dcar_stride] carrier index (from the first active carrier) of every data cell, in cell order
+    int dcar_stride = 0;
 };
-constexpr int EQ_GROUP = 64;
+#ifndef T2_EQ_GROUP
+#define T2_EQ_GROUP 32
+#endif
+constexpr int EQ_GROUP = T2_EQ_GROUP;      // segments per equaliser workgroup (ofdm_kernels.hip)
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);
 

@@ -208,30 +208,36 @@ __device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, flo
     return p;
 }
 
-// One workgroup = EQ_GROUP consecutive segments of one symbol, one lane per segment. The group's carriers (one contiguous run),
-// their carrier types and the de-interleaver indices of its data cells are first copied into LDS with coalesced loads -- in
-// global memory neighbouring lanes are a whole pilot spacing (up to 96 carriers = 768 B) apart, which made the kernel fetch five
-// times its algorithmic bytes. The LDS index is skewed by one word per 32 so that the per-lane stride becomes odd (bank-conflict
-// free); real and imaginary parts in separate planes.
-__device__ __forceinline__ int eq_skew(int i) { return i + (i >> 5); }
-// EQ_SPLIT lanes share one segment: every lane runs the (cheap) angle / amplitude recurrences over all cells, so all see the
-// reference's exact sequence of values, and does the table reads, divisions and the store for every EQ_SPLIT-th data cell.
-// Four times the wavefronts for the same LDS footprint, which is what hides the latency of this kernel.
-#ifndef T2_EQ_SPLIT
-#define T2_EQ_SPLIT 4
+// One workgroup = EQ_GROUP consecutive segments of one symbol, in two phases over LDS.
+//   load:    the group's carriers (one contiguous run), their types and the de-interleaver indices of its data cells, coalesced
+//            (in global memory neighbouring segments are a whole pilot spacing -- up to 96 carriers = 768 B -- apart).
+//   phase 1: one lane per segment estimates its two pilots and runs the reference's angle / amplitude recurrences -- repeated
+//            float additions, a serial chain per segment -- leaving (angle, amplitude) of every data cell in LDS.
+//   phase 2: all lanes, one data cell each: table reads, the two divisions, the rotation and the de-interleaved store -- the
+//            reference's per-cell operations on the values phase 1 produced in the reference's order.
+// Every cell is an 8-byte store somewhere in the symbol's 219 KB of output; a 128-byte line is complete only when all groups of the
+// symbol have run, and it reaches HBM once only if it stays in L2 until then. What decides that is how many symbols are in flight per
+// XCD (each XCD has its own 4 MB L2, shared with the incoming spectra): resident workgroups per XCD / groups per symbol. Measured
+// (tools/eq_write_probe.sh, 32K PP7, WRITE_SIZE over algorithmic bytes): 12 symbols in flight 4.3x, 8 -> 2.2x, 4 -> 1.07x. Hence
+// small groups (32 segments: 15 to 145 workgroups per symbol) of many lanes (512) and at most two workgroups per CU (launch_eq_data
+// asks for LDS accordingly), dealt to the XCDs so that all groups of a symbol write through the same L2.
+#ifndef T2_EQ_THREADS
+#define T2_EQ_THREADS 1024
 #endif
-constexpr int EQ_SPLIT = T2_EQ_SPLIT;
+#ifndef T2_EQ_WGS_PER_CU
+#define T2_EQ_WGS_PER_CU 2
+#endif
+constexpr int EQ_THREADS = T2_EQ_THREADS;
 
-__global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
+__global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
                                                           const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
                                                           float4 *__restrict__ pilot_scratch, int n_symbols, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) float eq_lds[];
     const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
     const float PI = 3.14159274101257324219f;
-    // Workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own, and the de-interleaved cells of a symbol are
-    // 8-byte stores scattered over the symbol's whole output: they only merge into full lines if all groups of the symbol write
-    // through the SAME L2. Linear id w -> XCD w % 8; symbol = 8 * (w / 8 / groups) + w % 8, group = (w / 8) % groups.
+    // Workgroups are dealt round-robin to the 8 XCDs: linear id w -> XCD w % 8; symbol = 8 * (w / 8 / groups) + w % 8,
+    // group = (w / 8) % groups.
     const int wg = (int)blockIdx.x;
     const int b = 8 * ((wg >> 3) / groups) + (wg & 7);                          // symbol of the batch
     const int grp = (wg >> 3) % groups;
@@ -243,7 +249,6 @@ __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p
     const int seg0 = grp * EQ_GROUP;
     if (seg0 >= nseg) return;
     const int seg1 = min(nseg, seg0 + EQ_GROUP) - 1;
-    const int seg = seg0 + threadIdx.x / EQ_SPLIT, sub = threadIdx.x % EQ_SPLIT;
     const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
     const uint8_t *map = p.map + (size_t)row * p.k_total;
     const float *refer = p.refer + (size_t)row * p.k_total;
@@ -252,70 +257,99 @@ __global__ __launch_bounds__(EQ_GROUP * EQ_SPLIT) void eq_data_kernel(EqParams p
     const int4 *segs = p.segs + (size_t)row * p.max_seg;
     const int4 sgf = segs[seg0], sgl = segs[seg1];
     const int c0 = sgf.x, span = sgl.y - sgf.x + 1, d0 = sgf.z, dspan = sgl.z + sgl.w - sgf.z;
-    float *l_re = eq_lds, *l_im = l_re + eq_skew(p.lds_span) + 1;
-    uint16_t *l_h = reinterpret_cast<uint16_t *>(l_im + eq_skew(p.lds_span) + 1);
-    uint8_t *l_map = reinterpret_cast<uint8_t *>(l_h + ((p.lds_dspan + 1) & ~1));
-    for (int i = threadIdx.x; i < span; i += EQ_GROUP * EQ_SPLIT) {
-        const float2 v = cell[c0 + i];
-        l_re[eq_skew(i)] = v.x; l_im[eq_skew(i)] = v.y;
-        l_map[i] = map[c0 + i];
+    // LDS: carriers (re, im planes), (angle, amplitude) per data cell, the 16-bit de-interleaver indices
+    float *l_re = eq_lds, *l_im = l_re + p.lds_span;
+    float2 *l_aa = reinterpret_cast<float2 *>(l_im + p.lds_span + (p.lds_span & 1));
+    uint16_t *l_h = reinterpret_cast<uint16_t *>(l_aa + p.lds_dspan);
+    static_assert(EQ_GROUP <= 64 && EQ_THREADS > 64, "phase 1 is wavefront 0, the other wavefronts stage");
+    if (threadIdx.x < 64) {
+        // ---- phase 1 (wavefront 0, beside the staging of the others: it needs its own two pilots only, read straight from memory)
+        const int seg = seg0 + (int)threadIdx.x;
+        if (seg <= seg1) {
+            const int4 sg = segs[seg];                                          // left pilot, right pilot, d start, data count
+            const int pl = sg.x, pr = sg.y, n = sg.w, d = sg.z - d0;
+            const float2 cl = cell[pl], cr = cell[pr];
+            const float refer_l = refer[pl], refer_r = refer[pr];
+            // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
+            // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
+            const uint8_t tl = map[pl], tr = map[pr];
+            const PilotEst L = pilot_estimate(cl, refer_l, tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
+            const PilotEst R = pilot_estimate(cr, refer_r, tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
+            float dif_angle = R.angle - L.angle;
+            if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;              // as written in the reference (:189-191)
+            else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
+            const float delta_angle = dif_angle / (float)(n + 1);
+            const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
+            float angle_est = L.angle, amp_est = L.amp;
+            float2 *aa = l_aa + d;
+#pragma unroll 4
+            for (int k = 0; k < n; ++k) {                                       // one step per DATA cell: reserved tones / the unused
+                angle_est += delta_angle; amp_est += delta_amp;                 // centre pilot between the pilots take none (:198)
+                aa[k] = make_float2(angle_est, amp_est);
+            }
+            // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
+            float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
+            if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);          // first pilot: no angle term (:153-162)
+            ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
+        }
+    } else {
+        // ---- staging: all global reads of a pass are issued before the first LDS store waits for one (a loop of load -> store
+        // pays the memory latency once per trip, and a workgroup has nothing else to do meanwhile)
+        constexpr int LU = 4, ST = EQ_THREADS - 64;
+        const int t0 = (int)threadIdx.x - 64;
+        for (int i0 = t0; i0 < span; i0 += LU * ST) {
+            float2 v[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * ST;
+                v[u] = i < span ? cell[c0 + i] : make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * ST;
+                if (i < span) { l_re[i] = v[u].x; l_im[i] = v[u].y; }
+            }
+        }
+        for (int i0 = t0; i0 < dspan; i0 += LU * ST) {
+            int32_t hv[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * ST;
+                hv[u] = i < dspan ? h[d0 + i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * ST;
+                if (i < dspan) l_h[i] = (uint16_t)hv[u];
+            }
+        }
     }
-    for (int i = threadIdx.x; i < dspan; i += EQ_GROUP * EQ_SPLIT) l_h[i] = (uint16_t)h[d0 + i];
     __syncthreads();
-    if (seg > seg1) return;
-    const int4 sg = segs[seg];                                                  // left pilot, right pilot, d start, data count
-    const int pl = sg.x, pr = sg.y, n = sg.w;
-    int d = sg.z - d0;
-    auto ld = [&](int c) { const int k = eq_skew(c - c0); return make_float2(l_re[k], l_im[k]); };
-    // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
-    // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
-    const uint8_t tl = l_map[pl - c0], tr = l_map[pr - c0];
-    const PilotEst L = pilot_estimate(ld(pl), refer[pl], tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
-    const PilotEst R = pilot_estimate(ld(pr), refer[pr], tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
-    float dif_angle = R.angle - L.angle;
-    if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                      // as written in the reference (:189-191)
-    else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
-    const float delta_angle = dif_angle / (float)(n + 1);
-    const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
-    float angle_est = L.angle, amp_est = L.amp;
-    const float *__restrict__ lut_c = p.lut_cos, *__restrict__ lut_s = p.lut_sin;
-    // Same float operations in the same order as the reference's loop; only the two table reads of eight cells are issued
-    // together ahead of their use (the angle / amplitude recurrences do not depend on them), which hides the L2 latency that a
-    // lone wavefront per workgroup cannot hide by itself.
-#ifndef T2_EQ_U
-#define T2_EQ_U 8
-#endif
-    constexpr int U = T2_EQ_U;
-    for (int i0 = pl + 1; i0 < pr; i0 += U) {
-        float amp[U], cr[U], sr[U];
-        int dd[U];
-        bool mine[U];
+    const float2 *__restrict__ lut = p.lut_cs;
+    const uint16_t *dcar = p.dcar + (size_t)row * p.dcar_stride + d0;
+    constexpr int U = 4;                                                        // cells per lane in flight: the table reads of all of
+    for (int dl0 = threadIdx.x; dl0 < dspan; dl0 += U * EQ_THREADS) {           // them are issued before the first is used
+        float cr[U], sr[U];
+        int car[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            const bool data = i < pr && l_map[i - c0] == T2_DATA;               // reserved tones / the unused centre pilot are skipped
-            if (data) { angle_est += delta_angle; amp_est += delta_amp; }
-            mine[u] = data && (d & (EQ_SPLIT - 1)) == sub;                      // this lane's share: every EQ_SPLIT-th data cell
-            dd[u] = d;
-            d += data ? 1 : 0;
-            amp[u] = amp_est;
-            const int li = mine[u] ? ((int)(angle_est * K_TABLE + 32767) & 65535) : 0;
-            cr[u] = lut_c[li]; sr[u] = lut_s[li];
+            const int dl = dl0 + u * EQ_THREADS;
+            const bool in = dl < dspan;
+            const int li = in ? ((int)(l_aa[dl].x * K_TABLE + 32767) & 65535) : 0;
+            const float2 cs = lut[li];
+            cr[u] = cs.x; sr[u] = cs.y;
+            car[u] = in ? (int)dcar[dl] - c0 : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!mine[u]) continue;
-            const float dr = cr[u] / amp[u], di = sr[u] / amp[u];
-            const float2 c = ld(i0 + u);
-            const int at = (int)l_h[dd[u]] - p.out_skip;
-            if (at >= 0) o[at] = make_float2(c.x * dr + c.y * di, c.y * dr - c.x * di);   // buffer_cell[j] * conj(derotate)
+            const int dl = dl0 + u * EQ_THREADS;
+            if (dl >= dspan) continue;
+            const float amp = l_aa[dl].y;
+            const float dr = cr[u] / amp, di = sr[u] / amp;
+            const float2 v = make_float2(l_re[car[u]], l_im[car[u]]);
+            const int at = (int)l_h[dl] - p.out_skip;
+            if (at >= 0) o[at] = make_float2(v.x * dr + v.y * di, v.y * dr - v.x * di);   // buffer_cell[j] * conj(derotate)
         }
-    }
-    // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
-    float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
-    if (sub == 0) {
-        if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);              // first pilot: no angle term (:153-162)
-        ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
     }
 }
 
@@ -356,8 +390,10 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s)
 {
-    const int words = 2 * (p.lds_span + (p.lds_span >> 5) + 1);                           // two skewed float planes
-    const int lds_bytes = words * 4 + ((p.lds_dspan + 1) & ~1) * 2 + ((p.lds_span + 15) & ~15);
+    int lds_bytes = 2 * (p.lds_span + 1) * 4 + p.lds_dspan * 8 + ((p.lds_dspan + 1) & ~1) * 2;
+    const int lds_floor = 160 * 1024 / (T2_EQ_WGS_PER_CU + 1) + 1024;                     // at most T2_EQ_WGS_PER_CU workgroups per CU (see the kernel)
+    lds_bytes = lds_bytes > lds_floor ? lds_bytes : lds_floor;
+    if (const char *pad = getenv("T2GPU_EQ_LDS_PAD")) lds_bytes += atoi(pad);             // experiments: fewer resident workgroups per CU
     static int attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_data_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -366,7 +402,7 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
     }
     const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
     const unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                   // linear id, see the kernel
-    hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_GROUP * EQ_SPLIT), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
+    hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_THREADS), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
                        groups);
     if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3(n_symbols), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
     return hipGetLastError();

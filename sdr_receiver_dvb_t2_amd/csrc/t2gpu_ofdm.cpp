@@ -88,7 +88,9 @@ struct t2gpu_ofdm {
     EqParams eq{}, eq_p2{}, eq_fc{};
     float2 *d_twiddle = nullptr;
     uint8_t *d_map = nullptr;
-    float *d_refer = nullptr, *d_lut = nullptr;
+    uint16_t *d_dcar = nullptr, *d_dcar_p2 = nullptr, *d_dcar_fc = nullptr;   // carrier of every data cell, per table row
+    float *d_refer = nullptr;
+    float2 *d_lut = nullptr;
     int4 *d_segs = nullptr, *d_segs_p2 = nullptr;
     int32_t *d_seg_count = nullptr, *d_h_even = nullptr, *d_h_odd = nullptr;
     uint8_t *d_map_p2 = nullptr;
@@ -129,11 +131,11 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     // LUT of DSP/fast_math.h:27-42 as the reference binary fills it (-Ofast: i * (1/k) in float, one sincosf)
-    std::vector<float> lut(2 * 65536, 0.0f);
+    std::vector<float2> lut(65536, make_float2(0.0f, 0.0f));                   // (cos, sin)
     {
         const float k_table = 32767.0f / (2.0f * 3.14159274101257324219f);
         const float rk = 1.0f / k_table;
-        for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
+        for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767].y, &lut[i + 32767].x);
     }
     // per data symbol: carrier map, pilot reference, pilot-to-pilot segments
     const int rows = m.n_data - m.l_fc;          // frame-closing symbol is handled by its own stage
@@ -141,14 +143,17 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     std::vector<uint8_t> map((size_t)rows * K);
     std::vector<float> refer((size_t)rows * K);
     std::vector<std::vector<int4>> segs(rows);
+    std::vector<uint16_t> dcar;
     int max_seg = 0;
     for (int r = 0; r < rows; ++r) {
         std::vector<uint8_t> mp; std::vector<float> rf;
         t2_symbol_carriers(m, m.n_p2 + r, mp, rf);
         std::copy(mp.begin(), mp.end(), map.begin() + (size_t)r * K);
         std::copy(rf.begin(), rf.end(), refer.begin() + (size_t)r * K);
+        for (int i = 0; i < K; ++i)
+            if (mp[i] == T2_DATA) dcar.push_back((uint16_t)i);
         int d = build_segments(mp, K, segs[r]);
-        if (d != m.c_data) { set_error("carrier map does not hold c_data data cells"); delete h; return nullptr; }
+        if (d != m.c_data || dcar.size() != (size_t)(r + 1) * m.c_data) { set_error("carrier map does not hold c_data data cells"); delete h; return nullptr; }
         max_seg = std::max(max_seg, (int)segs[r].size());
     }
     std::vector<int4> segflat((size_t)rows * max_seg, make_int4(0, 0, 0, 0));
@@ -164,8 +169,9 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         ok = ok && hip_ok(hipMalloc((void **)dst, bytes), "hipMalloc") && hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy");
     };
     up(&h->d_twiddle, tw.data(), tw.size() * sizeof(float2));
-    up(&h->d_lut, lut.data(), lut.size() * 4);
+    up(&h->d_lut, lut.data(), lut.size() * sizeof(float2));
     up(&h->d_map, map.data(), map.size());
+    up(&h->d_dcar, dcar.data(), dcar.size() * 2);
     up(&h->d_refer, refer.data(), refer.size() * 4);
     up(&h->d_segs, segflat.data(), segflat.size() * sizeof(int4));
     up(&h->d_seg_count, segcount.data(), segcount.size() * 4);
@@ -184,6 +190,10 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     const int32_t nseg2 = (int32_t)seg2.size();
     std::vector<int32_t> he2, ho2;
     t2_freq_deint(mP2, 0, he2, ho2);
+    std::vector<uint16_t> dcar2;
+    for (int i = 0; i < K2; ++i)
+        if (mp2[i] == T2_DATA) dcar2.push_back((uint16_t)i);
+    up(&h->d_dcar_p2, dcar2.data(), dcar2.size() * 2);
     up(&h->d_map_p2, mp2.data(), mp2.size());
     up(&h->d_refer_p2, rf2.data(), rf2.size() * 4);
     up(&h->d_segs_p2, seg2.data(), seg2.size() * sizeof(int4));
@@ -203,6 +213,10 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         std::vector<int32_t> he3, ho3;
         t2_freq_deint(m, 2, he3, ho3);
         std::vector<int32_t> idxfill(max_symbols, fcidx);
+        std::vector<uint16_t> dcar3;
+        for (int i = 0; i < K; ++i)
+            if (mp3[i] == T2_DATA) dcar3.push_back((uint16_t)i);
+        up(&h->d_dcar_fc, dcar3.data(), dcar3.size() * 2);
         up(&h->d_map_fc, mp3.data(), mp3.size());
         up(&h->d_refer_fc, rf3.data(), rf3.size() * 4);
         up(&h->d_segs_fc, seg3.data(), seg3.size() * sizeof(int4));
@@ -215,12 +229,15 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_all + 1) * sizeof(float4)), "hipMalloc");
     if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
     h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map, h->d_refer, h->d_segs,
-                     h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut, h->d_lut + 65536};
+                     h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut};
     if (m.l_fc)
         h->eq_fc = EqParams{N, m.l_nulls, K, m.n_fc, m.len_frame - 1, nseg3, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_fc, h->d_refer_fc,
-                            h->d_segs_fc, h->d_seg_count_fc, h->d_h_even_fc, h->d_h_odd_fc, h->d_lut, h->d_lut + 65536};
+                            h->d_segs_fc, h->d_seg_count_fc, h->d_h_even_fc, h->d_h_odd_fc, h->d_lut};
     h->eq_p2 = EqParams{N, mP2.l_nulls, K2, m.c_p2, 0, (int)nseg2, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map_p2, h->d_refer_p2, h->d_segs_p2,
-                        h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut, h->d_lut + 65536};
+                        h->d_seg_count_p2, h->d_h_even_p2, h->d_h_odd_p2, h->d_lut};
+    h->eq.dcar = h->d_dcar; h->eq.dcar_stride = m.c_data;
+    h->eq_p2.dcar = h->d_dcar_p2; h->eq_p2.dcar_stride = m.c_p2;
+    h->eq_fc.dcar = h->d_dcar_fc; h->eq_fc.dcar_stride = m.n_fc;
     h->eq_p2.recip_amp = 1;
     h->eq_fc.recip_amp = 1;
     // widest carrier / data-cell span of any EQ_GROUP consecutive segments, per table (sizes the equaliser's LDS staging)
@@ -242,6 +259,7 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
     if (!h) return;
     hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
+    hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
     hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
     hipFree(h->d_seg_count_p2); hipFree(h->d_h_even_p2); hipFree(h->d_h_odd_p2);
     hipFree(h->d_map_fc); hipFree(h->d_refer_fc); hipFree(h->d_segs_fc); hipFree(h->d_seg_count_fc); hipFree(h->d_h_even_fc);
