@@ -8,6 +8,13 @@
 // + two minima of ldpc_cn.h / ldpc_cn2.h are the compact form for one frame per register; with two frames per register the
 // message bytes are what the packed subtract consumes directly (two SDWA subtracts per slot for both frames).
 //
+// Scale. Inside a node the int8 quantities are carried times 256, i.e. in the HIGH byte of their 16-bit half: the reference's two
+// saturations to int8 (L - message, input + output) then ARE the 16-bit saturations of v_pk_sub_i16 / v_pk_mad_i16 with the clamp
+// bit -- one instruction each instead of three -- and bytes move between memory and halves with one v_perm_b32 either way. The one
+// value that is not a multiple of 256 is the positive saturation 32767 (for 127 * 256 = 32512): every consumer either takes the
+// high byte (127) or applies f, which caps at 126 * 256 far below, or compares it with values of which it is the largest anyway.
+// Raw magnitudes are unsigned halves: 128 * 256 = 0x8000 (from -128) and the absent slot's 255 * 256 order correctly.
+//
 // Semantics, slot numbering, layer kinds and phase structure are those of ldpc_cn.h / ldpc_cn2.h, function by function (each names
 // the one it restates); results are LLR-exact against the same goldens (tests/test_ldpc_gpu.py).
 #pragma once
@@ -16,55 +23,62 @@
 namespace t2gpu {
 
 typedef short p16 __attribute__((ext_vector_type(2)));     // (frame A, frame B)
+typedef unsigned short q16 __attribute__((ext_vector_type(2)));   // the same halves read as unsigned (raw magnitudes)
 __device__ __forceinline__ p16 p_of(uint32_t v) { return __builtin_bit_cast(p16, v); }
 __device__ __forceinline__ uint32_t u_of(p16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ q16 q_of(p16 v) { return __builtin_bit_cast(q16, v); }
+__device__ __forceinline__ p16 p_ofq(q16 v) { return __builtin_bit_cast(p16, v); }
 __device__ __forceinline__ p16 p_set(int a) { return (p16){(short)a, (short)a}; }
 __device__ __forceinline__ p16 p_min(p16 a, p16 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ p16 p_max(p16 a, p16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ p16 p_clamp(p16 v, int lo, int hi) { return p_min(p_max(v, p_set(lo)), p_set(hi)); }
+// unsigned minimum / maximum of the halves (raw magnitudes)
+__device__ __forceinline__ p16 u_min(p16 a, p16 b) { return p_ofq(__builtin_elementwise_min(q_of(a), q_of(b))); }
+__device__ __forceinline__ p16 u_max(p16 a, p16 b) { return p_ofq(__builtin_elementwise_max(q_of(a), q_of(b))); }
 __device__ __forceinline__ int p_a(p16 v) { return (int)v.x; }      // frame A / frame B value, sign-extended
 __device__ __forceinline__ int p_b(p16 v) { return (int)v.y; }
+constexpr int P2_ONE = 256;                                  // the scale
+constexpr int P2_ABSENT = 0xff00;                            // raw magnitude of a slot the node does not have (255)
 
 // value of v in the partner lane (lane ^ 1)
 __device__ __forceinline__ uint32_t p2_xu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ p16 p2_x(p16 v) { return p_of(p2_xu(u_of(v))); }
 
-// f of ldpc_cn.h on raw magnitudes 0..255, both frames
-__device__ __forceinline__ p16 p2_f(p16 a) { return p_clamp(a - p_set(1), 0, 126); }
+// f of ldpc_cn.h on raw magnitudes, both frames: max(a - 1, 0) capped at 126, times 256
+__device__ __forceinline__ p16 p2_f(p16 a)
+{
+    const q16 d = __builtin_elementwise_sub_sat(q_of(a), (q16){(unsigned short)P2_ONE, (unsigned short)P2_ONE});
+    return p_ofq(__builtin_elementwise_min(d, (q16){(unsigned short)(126 * P2_ONE), (unsigned short)(126 * P2_ONE)}));
+}
 
-// (LLR bytes A, B in bytes 0, 1 of raw) - (message bytes A, B in bytes 2*odd, 2*odd + 1 of msg), sign-extended, one frame per half.
-// Both sign extensions ride on the subtract (SDWA byte selects); the second one writes the upper half and keeps the lower.
+// sat((LLR bytes A, B in bytes 0, 1 of raw) - (message bytes A, B in bytes 2*odd, 2*odd + 1 of msg)), times 256, one frame per
+// half: either pair of bytes goes to the high bytes of the halves with one v_perm_b32, the subtract saturates (v_pk_sub_i16 clamp)
 __device__ __forceinline__ p16 p2_llr_minus_msg(uint16_t raw, uint32_t msg, int odd)
 {
-    uint32_t d;
-    if (odd) {
-        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2" : "=v"(d) : "v"(raw), "v"(msg));
-        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_3" : "+v"(d) : "v"(raw), "v"(msg));
-    } else {
-        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(raw), "v"(msg));
-        asm("v_sub_u16_sdwa %0, sext(%1), sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(d) : "v"(raw), "v"(msg));
-    }
-    return p_of(d);
+    const p16 l = p_of(__builtin_amdgcn_perm(0u, (uint32_t)raw, 0x010c000cu));
+    const p16 m = p_of(__builtin_amdgcn_perm(0u, msg, odd ? 0x030c020cu : 0x010c000cu));
+    return __builtin_elementwise_sub_sat(l, m);
 }
+__device__ __forceinline__ p16 p2_abs(p16 x) { return p_max(x, p_set(0) - x); }   // |-128 * 256| = 0x8000: right as an unsigned half
 
 // the two smallest of the union of two sorted pairs (pl_merge2)
 __device__ __forceinline__ void p2_merge2(p16 a0, p16 a1, p16 b0, p16 b1, p16 &m0, p16 &m1)
 {
-    m0 = p_min(a0, b0);
-    m1 = p_min(p_max(a0, b0), p_min(a1, b1));
+    m0 = u_min(a0, b0);
+    m1 = u_min(u_max(a0, b0), u_min(a1, b1));
 }
 // t2_min2: fold a into the sorted pair (m0 <= m1)
 __device__ __forceinline__ void p2_min2(p16 a, p16 &m0, p16 &m1)
 {
-    m1 = p_min(m1, p_max(m0, a));
-    m0 = p_min(m0, a);
+    m1 = u_min(m1, u_max(m0, a));
+    m0 = u_min(m0, a);
 }
 
 template <int CNT>
 struct P2Regs {
     static constexpr int DEG = CNT + 2, H = (DEG + 1) / 2, W = (H + 1) / 2;   // slots of the node / of one lane / record dwords of one lane
     int addr[H];                // LDS address of the slot's LLR pair (absent slot: < 0)
-    p16 in[H], mag[H];          // in = sat(L - old message); raw magnitude (255 for an absent slot)
+    p16 in[H], mag[H];          // in = sat(L - old message) and its raw magnitude, times 256 (P2_ABSENT for an absent slot)
     uint32_t mo[W], mn[W];      // old / new message bytes
     p16 p0, p1;                 // node-wide over the non-conflict slots: two smallest raw magnitudes
     uint32_t psx;               //   ... and the sign xor (bits 15 / 31)
@@ -82,9 +96,9 @@ __device__ __forceinline__ void p2_read_slot(const LMEM &L, P2Regs<CNT> &r, int 
 {
     const bool present = p2_present(r, v);
     const uint16_t raw = present ? L.ld16(r.addr[v]) : (uint16_t)0;
-    const p16 x = p_clamp(p2_llr_minus_msg(raw, r.mo[v >> 1], v & 1), -128, 127);
+    const p16 x = p2_llr_minus_msg(raw, r.mo[v >> 1], v & 1);
     r.in[v] = present ? x : p_set(0);
-    r.mag[v] = present ? p_max(x, p_set(0) - x) : p_set(255);
+    r.mag[v] = present ? p2_abs(x) : p_set(P2_ABSENT);
 }
 
 // the lane's table entries of a layer: slot v <- entry 2v + h (information slots), from the LDS copy, issued together
@@ -125,9 +139,9 @@ __device__ __forceinline__ void p2_load(const LMEM &L, const uint2 (&e)[(CNT + 3
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         const bool present = p2_present(r, v);
-        const p16 x = p_clamp(p2_llr_minus_msg(raw[v], r.mo[v >> 1], v & 1), -128, 127);
+        const p16 x = p2_llr_minus_msg(raw[v], r.mo[v >> 1], v & 1);
         r.in[v] = present ? x : p_set(0);
-        r.mag[v] = present ? p_max(x, p_set(0) - x) : p_set(255);
+        r.mag[v] = present ? p2_abs(x) : p_set(P2_ABSENT);
     }
 }
 
@@ -136,13 +150,13 @@ template <int CNT>
 __device__ __forceinline__ void p2_partial(P2Regs<CNT> &r, int nc)
 {
     constexpr int H = P2Regs<CNT>::H;
-    p16 m0 = p_set(255), m1 = p_set(255);
+    p16 m0 = p_set(P2_ABSENT), m1 = p_set(P2_ABSENT);
     uint32_t sx = 0;
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         if (2 * v + 1 >= nc) {                                      // uniform: at least the odd lane's slot counts
             const bool mine = (2 * v >= nc) || r.h;
-            p2_min2(mine ? r.mag[v] : p_set(255), m0, m1);
+            p2_min2(mine ? r.mag[v] : p_set(P2_ABSENT), m0, m1);
             sx ^= mine ? u_of(r.in[v]) : 0u;
         }
     }
@@ -161,13 +175,13 @@ __device__ __forceinline__ void p2_set_minima(p16 a0, p16 a1, p16 &m0, p16 &m1f,
 template <int CNT, int NV>
 __device__ __forceinline__ void p2_merge(P2Regs<CNT> &r, int nc)
 {
-    p16 m0 = p_set(255), m1 = p_set(255);
+    p16 m0 = p_set(P2_ABSENT), m1 = p_set(P2_ABSENT);
     uint32_t sx = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (v < P2Regs<CNT>::H && 2 * v < nc) {                     // uniform: at least the even lane's slot is a conflict slot
             const bool mine = (2 * v + 1 < nc) || !r.h;
-            p2_min2(mine ? r.mag[v] : p_set(255), m0, m1);
+            p2_min2(mine ? r.mag[v] : p_set(P2_ABSENT), m0, m1);
             sx ^= mine ? u_of(r.in[v]) : 0u;
         }
     }
@@ -184,17 +198,17 @@ template <int CNT, class LMEM>
 __device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bool store)
 {
     const bool present = p2_present(r, v);
-    const p16 s = p_min(r.mag[v] - r.m0, p_set(1));      // 0 where the slot holds the raw minimum (an absent slot carries 255), else 1
+    const p16 s = u_min(r.mag[v] - r.m0, p_set(1));      // 0 where the slot holds the raw minimum (an absent slot carries 255), else 1
     const p16 other = s * r.dm + r.m1f;                  // f(min1) for the minimum's slot, f(min0) for the others
     const p16 sm = p_of(r.sx ^ u_of(r.in[v])) >> p_set(15);   // 0 / -1: sign of the product of the other inputs
     const p16 sgn = p_of(u_of(sm) | 0x00010001u);        // +1 / -1
     const p16 out = other * sgn;
-    const p16 ln = p_clamp(out + r.in[v], -128, 127);
-    if (present && store) L.st16(r.addr[v], __builtin_amdgcn_perm(0u, u_of(ln), 0x0c0c0200u));
-    const p16 msg = p_clamp(out, -32, 31);
-    // bytes 0, 2 of msg -> bytes (0, 1) or (2, 3) of the record dword
-    if (v & 1) r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x06040100u);
-    else r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x03020604u);
+    const p16 ln = __builtin_elementwise_add_sat(out, r.in[v]);   // sat(in + out): the 16-bit saturation
+    if (present && store) L.st16(r.addr[v], __builtin_amdgcn_perm(0u, u_of(ln), 0x0c0c0301u));
+    const p16 msg = p_clamp(out, -32 * P2_ONE, 31 * P2_ONE);
+    // bytes 1, 3 of msg -> bytes (0, 1) or (2, 3) of the record dword
+    if (v & 1) r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x07050100u);
+    else r.mn[v >> 1] = __builtin_amdgcn_perm(u_of(msg), r.mn[v >> 1], 0x03020705u);
 }
 
 // pl_phase_a. pair_rec: [2][360] chain-walk records, one array per frame
@@ -218,8 +232,8 @@ __device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const ui
             p2_write_slot<CNT>(L, r, 0, true);
         } else if (h == 0) {                    // t2_pair_record, one per frame
             const p16 cap = p2_f(r.p0);
-            pair_rec[j] = t2_pair_pack((int)(int8_t)(partner_m0 & 0xffu), p_a(cap), p_a(r.in[0]), (r.psx & 0x8000u) != 0);
-            pair_rec[360 + j] = t2_pair_pack((int)(int8_t)((partner_m0 >> 8) & 0xffu), p_b(cap), p_b(r.in[0]), (r.psx & 0x80000000u) != 0);
+            pair_rec[j] = t2_pair_pack((int)(int8_t)(partner_m0 & 0xffu), p_a(cap) >> 8, p_a(r.in[0]) >> 8, (r.psx & 0x8000u) != 0);
+            pair_rec[360 + j] = t2_pair_pack((int)(int8_t)((partner_m0 >> 8) & 0xffu), p_b(cap) >> 8, p_b(r.in[0]) >> 8, (r.psx & 0x80000000u) != 0);
         }
     } else {
         p2_partial<CNT>(r, d.nc);
@@ -231,8 +245,8 @@ __device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const ui
             if (h == 0) {
                 const uint32_t ma = __builtin_amdgcn_perm(po, r.mo[0], 0x06020400u), mb = __builtin_amdgcn_perm(po, r.mo[0], 0x07030501u);
                 const uint32_t p0 = u_of(r.p0), p1 = u_of(r.p1);
-                const uint32_t qa = (p0 & 0xffu) | ((p1 & 0xffu) << 8) | (((r.psx >> 15) & 1u) << 16);
-                const uint32_t qb = ((p0 >> 16) & 0xffu) | (((p1 >> 16) & 0xffu) << 8) | ((r.psx >> 31) << 16);
+                const uint32_t qa = ((p0 >> 8) & 0xffu) | (p1 & 0xff00u) | (((r.psx >> 15) & 1u) << 16);
+                const uint32_t qb = (p0 >> 24) | ((p1 >> 16) & 0xff00u) | ((r.psx >> 31) << 16);
                 L.st_pair(d.band_rec_lds + 8 * j, ma, qa);
                 L.st_pair(d.band_rec_lds + 2880 + 8 * j, mb, qb);
             }
@@ -480,11 +494,11 @@ __device__ __forceinline__ void p2_band_finish(LMEM &L, const LayerDesc &d, int 
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if ((2 * v + 1 < NC) || !r.h) {
-            // byte 2v + h of either word into the high bytes of the two halves, then an arithmetic shift: (frame A, frame B) sign-extended
+            // byte 2v + h of either word into the high bytes of the two halves: (frame A, frame B) times 256
             const uint32_t sel = r.h ? (v ? 0x070c030cu : 0x050c010cu) : (v ? 0x060c020cu : 0x040c000cu);
-            const p16 x = p_of(__builtin_amdgcn_perm(wb, wa, sel)) >> p_set(8);
+            const p16 x = p_of(__builtin_amdgcn_perm(wb, wa, sel));
             r.in[v] = x;
-            r.mag[v] = p_max(x, p_set(0) - x);
+            r.mag[v] = p2_abs(x);
         }
     }
     p2_merge<CNT, NV>(r, NC);
