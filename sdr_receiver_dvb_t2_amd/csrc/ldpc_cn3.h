@@ -301,8 +301,14 @@ __device__ __forceinline__ void p2_pair_walk(LMEM &L, const LayerDesc &d, int la
     int m = lane - s0;
     m += (m < 0) ? 360 : 0;
     int X = (int)L.ld(base2 + 2 * m);
-    for (int jj = lane + step; jj + step < 360; jj += step) {     // nodes that have a successor
-        const PairRec r = t2_pair_unpack(pair_rec[jj]);
+    // the records are read one node ahead of the recurrence (they do not depend on it): a step then costs its arithmetic, not
+    // an LDS round trip on top
+    int jj = lane + step;
+    uint32_t nxt = pair_rec[jj < 359 ? jj : 359];
+    for (; jj + step < 360; jj += step) {                         // nodes that have a successor
+        const PairRec r = t2_pair_unpack(nxt);
+        const int jn = jj + step;
+        nxt = pair_rec[jn < 359 ? jn : 359];
         const unsigned t = (unsigned)(m + step);
         m = (int)(t < t - 360u ? t : t - 360u);
         X = t2_pair_step(r, X);
