@@ -278,7 +278,7 @@ __device__ __forceinline__ int find_run_out(const FrontRun *__restrict__ runs, i
 }
 
 constexpr int FD_THREADS = 256;       // 256 outputs per workgroup need about 290 input samples: a short second pass (320 lanes measured slower)
-__global__ __launch_bounds__(FD_THREADS, 8) void front_farrow_decimate_kernel(FrontParams p)
+__global__ __launch_bounds__(FD_THREADS, 7) void front_farrow_decimate_kernel(FrontParams p)
 {
     __shared__ float2 w[2 * 256 + 64];
     const long k0 = (long)blockIdx.x * 256;
