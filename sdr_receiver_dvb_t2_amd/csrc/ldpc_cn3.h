@@ -230,10 +230,17 @@ __device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const ui
         if (j < d.step) {                       // chain start: its two group bits (slot 0 on the even lane, slot 1 on the odd one) now
             p2_merge<CNT, 1>(r, 2);
             p2_write_slot<CNT>(L, r, 0, true);
-        } else if (h == 0) {                    // t2_pair_record, one per frame
-            const p16 cap = p2_f(r.p0);
-            pair_rec[j] = t2_pair_pack((int)(int8_t)(partner_m0 & 0xffu), p_a(cap) >> 8, p_a(r.in[0]) >> 8, (r.psx & 0x8000u) != 0);
-            pair_rec[360 + j] = t2_pair_pack((int)(int8_t)((partner_m0 >> 8) & 0xffu), p_b(cap) >> 8, p_b(r.in[0]) >> 8, (r.psx & 0x80000000u) != 0);
+        } else if (h == 0) {
+            // t2_pair_record / t2_pair_pack for both frames at once, in the halves: k1 = (neg ? msg1 : -msg1) - 1, cap = f(p0), in0 and
+            // the sign field (neg ? 3 : 1) are formed times 256 (the sign field plain) and their bytes gathered with four v_perm_b32
+            const p16 m1 = p_of(__builtin_amdgcn_perm(0u, partner_m0, 0x010c000cu));      // slot 1's old messages, times 256
+            const p16 pos = p_of(~r.psx) >> p_set(15);                                    // -1 where the other slots' sign product is +
+            const p16 k1 = p_of(u_of(m1) ^ u_of(pos)) - pos - p_set(P2_ONE);
+            const uint32_t sg = ((r.psx >> 14) & 0x00020002u) | 0x00010001u;
+            const uint32_t t = __builtin_amdgcn_perm(u_of(p2_f(r.p0)), u_of(k1), 0x07030501u);   // (k1 A, cap A, k1 B, cap B)
+            const uint32_t u = __builtin_amdgcn_perm(sg, u_of(r.in[0]), 0x06030401u);            // (in0 A, sign A, in0 B, sign B)
+            pair_rec[j] = __builtin_amdgcn_perm(u, t, 0x05040100u);
+            pair_rec[360 + j] = __builtin_amdgcn_perm(u, t, 0x07060302u);
         }
     } else {
         p2_partial<CNT>(r, d.nc);
