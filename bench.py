@@ -276,7 +276,7 @@ def main():
     rx.close()
 
     extra = {}
-    if rank == 0 and full and not args.no_extra_legs:
+    if rank == 0 and world == 1 and full and not args.no_extra_legs:     # N = 1 only: timed_leg's barriers are collective
         # (i) the BASELINE config's "50 iters" point beside the reference's own TRIALS = 25
         r50 = make_rx(False, F, 50)
         r50.execute_dev(d_i, d_q, F, first_call=True)
