@@ -208,11 +208,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # dry run of the N > 1 control flow on a one-GPU box: T2GPU_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses gloo (RCCL
+    # refuses two ranks on one device); the driver's runs use one GPU per rank and RCCL
+    one_device = os.environ.get("T2GPU_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = CONFIGS[args.config]
     w = Workload(cfg)
@@ -272,7 +280,7 @@ def main():
     # measured slower, so there is no overlap to lose.
     elapsed, stage_acc, ldpc_ms = timed_leg(rx, args.steps, args.warmup, level)
     ref_trials = rx.fetch(count)[1] if full else None
-    max_s, units = aggregate_timing(elapsed, F * args.steps, dist if world > 1 else None, dev)
+    max_s, units = aggregate_timing(elapsed, F * args.steps, dist if world > 1 else None, None if one_device else dev)
     rx.close()
 
     extra = {}
