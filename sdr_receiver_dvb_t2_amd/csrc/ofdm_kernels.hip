@@ -354,36 +354,55 @@ __global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const f
 }
 
 // phase_offset = atan2(sum_pilot_2) + atan2(sum_pilot_1), sample_rate_offset = sum_angle_2 - sum_angle_1 (:319-324)
-// The sums are float additions in carrier order (the reference's loop order): a serial chain per symbol. One wavefront per symbol:
-// the 64 lanes fetch 64 pilots' terms at a time (one coalesced 1 KB read), lane k's float4 is broadcast with v_readlane and every
-// lane adds it to its (identical) accumulators -- the chain runs out of registers, the memory system sees whole lines. (One THREAD per
-// symbol, 64 symbols per wavefront, touched 64 different lines per load and took 0.47 ms per 2280 symbols; this takes 0.0x.)
-__device__ __forceinline__ float bcast(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
-
+// The sums are float additions in carrier order (the reference's loop order): serial chains per symbol -- six of them, (re, im, angle)
+// over the pilots of the lower half of the spectrum and the same over the upper half, and they do not depend on each other. One
+// wavefront per symbol: all lanes stage the symbol's per-pilot terms in LDS (coalesced 16-byte reads, eight in flight per lane), then
+// lanes 0..5 take one chain each and add their component pilot by pilot. A chain step is one LDS read and one add. (One thread per
+// symbol doing everything: 0.47 ms per 2280 symbols; one wavefront with v_readlane broadcasts into identical accumulators: 0.03 ms
+// for the data symbols but 0.18 ms for the 38 P2 symbols, whose 4640 pilots each were ~90 cycles apiece in one chain of three.)
 __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *__restrict__ symbol_index, const float4 *__restrict__ pilot_scratch,
                                                      float2 *__restrict__ sync, int n_symbols)
 {
+    extern __shared__ __attribute__((aligned(16))) float sy_lds[];             // [nseg + 1][4]
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_symbols) return;
     const int nseg = p.seg_count[(p.per_frame ? p.first + b % p.per_frame : symbol_index[b]) - p.n_p2];
     const float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
-    float s1r = 0, s1i = 0, s2r = 0, s2i = 0, a1 = 0, a2 = 0;
-    {
-        const float4 v0 = ps[0];
-        s1r += v0.x; s1i += v0.y;
+    float4 *l4 = reinterpret_cast<float4 *>(sy_lds);
+    int lower = 0;                                                              // entries 1..nseg whose pilot lies in the lower half
+    constexpr int U = 8;
+    for (int k0 = lane; k0 <= nseg; k0 += 64 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int k = k0 + 64 * u; v[u] = k <= nseg ? ps[k] : make_float4(0.f, 0.f, 0.f, 1.f); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u;
+            if (k <= nseg) { l4[k] = v[u]; lower += (k >= 1 && v[u].w == 0.0f) ? 1 : 0; }
+        }
     }
-    float4 nxt = (1 + lane <= nseg) ? ps[1 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 1; k0 <= nseg; k0 += 64) {
-        const float4 cur = nxt;
-        if (k0 + 64 <= nseg) nxt = (k0 + 64 + lane <= nseg) ? ps[k0 + 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cnt = min(64, nseg - k0 + 1);
-        // pilots are in carrier order, so the chunk's first-half pilots (w == 0) come first: count them once instead of testing each
-        const int n1 = __popcll(__ballot(lane < cnt && cur.w == 0.0f));
-#pragma unroll 8
-        for (int t = 0; t < n1; ++t) { s1r += bcast(cur.x, t); s1i += bcast(cur.y, t); a1 += bcast(cur.z, t); }
-#pragma unroll 8
-        for (int t = n1; t < cnt; ++t) { s2r += bcast(cur.x, t); s2i += bcast(cur.y, t); a2 += bcast(cur.z, t); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lower += __shfl_xor(lower, d, 64);
+    __syncthreads();
+    // pilots are in carrier order: entries 1..lower feed the first set of sums, lower+1..nseg the second; entry 0 is the first pilot
+    // of the symbol, which has no angle term (:153-162) and opens the first set's (re, im)
+    const int comp = lane % 3, second = lane / 3;                               // lanes 0..2: first set, 3..5: second
+    float acc = 0.0f;
+    if (lane < 6) {
+        int k = second ? lower + 1 : (comp == 2 ? 1 : 0);
+        const int kend = second ? nseg : lower;
+        const float *q = sy_lds + comp;
+        for (; k + 8 <= kend + 1; k += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = q[4 * (k + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; k <= kend; ++k) acc += q[4 * k];
     }
+    const float s1r = __shfl(acc, 0, 64), s1i = __shfl(acc, 1, 64), a1 = __shfl(acc, 2, 64);
+    const float s2r = __shfl(acc, 3, 64), s2i = __shfl(acc, 4, 64), a2 = __shfl(acc, 5, 64);
     if (lane == 0) sync[b] = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
 }
 
@@ -404,7 +423,16 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
     const unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                   // linear id, see the kernel
     hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_THREADS), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
                        groups);
-    if (sync) hipLaunchKernelGGL(eq_sync_kernel, dim3(n_symbols), dim3(64), 0, s, p, symbol_index, pilot_scratch, sync, n_symbols);
+    if (sync) {
+        const int sy_bytes = (p.max_seg + 1) * 16;
+        static int sy_attr = 0;
+        if (sy_bytes > 64 * 1024 && sy_bytes > sy_attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, sy_bytes);
+            if (e != hipSuccess) return e;
+            sy_attr = sy_bytes;
+        }
+        hipLaunchKernelGGL(eq_sync_kernel, dim3(n_symbols), dim3(64), sy_bytes, s, p, symbol_index, pilot_scratch, sync, n_symbols);
+    }
     return hipGetLastError();
 }
 
