@@ -40,7 +40,8 @@ __device__ __forceinline__ Lin shfl_up_lin(const Lin &v, int d)
 // wavefront totals through 96 bytes of LDS. Returns the EXCLUSIVE prefix of this thread; *total receives the workgroup's
 // composition. These kernels run beside the LDPC decoder of another stream, whose persistent workgroups leave only ~12 KB of
 // LDS per CU: keeping LDS use tiny is what lets them overlap (receiver.pipeline_step).
-__device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[4] */, Lin *total)
+template <int NW = 4>
+__device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[NW] */, Lin *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -54,7 +55,7 @@ __device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[
     if (lane == 0) ex = Lin{1.0, 0.0, 0.0};
     Lin pre{1.0, 0.0, 0.0};
     for (int w = 0; w < wave; ++w) pre = compose(pre, wave_tot[w]);
-    if (total) { Lin t{1.0, 0.0, 0.0}; for (int w = 0; w < 4; ++w) t = compose(t, wave_tot[w]); *total = t; }
+    if (total) { Lin t{1.0, 0.0, 0.0}; for (int w = 0; w < NW; ++w) t = compose(t, wave_tot[w]); *total = t; }
     return compose(pre, ex);
 }
 
@@ -85,6 +86,17 @@ __device__ __forceinline__ Lin thread_lin(const float xr[4], const float xi[4], 
     return l;
 }
 
+// Where block b's aggregate (and later the averager value before block b) lives in p.blk: the level-2 scan is ONE workgroup whose
+// lane t owns the contiguous blocks [t * per, t * per + per); stored in block order, a load instruction of that kernel touched 64
+// lines 9 KB apart and the kernel ran at the address rate of one CU (190 us per 73 600 blocks). Stored lane-interleaved -- block
+// t * per + k at slot k * 256 + t -- the same loads are contiguous across the wavefront.
+#ifndef T2_DC_LANES
+#define T2_DC_LANES 512
+#endif
+constexpr int DC_LANES = T2_DC_LANES;      // lanes of the level-2 scan's one workgroup
+__device__ __forceinline__ long dc_slot(int b, int per) { return (long)(b % per) * DC_LANES + b / per; }
+__device__ __forceinline__ int dc_per(int n_blocks) { return (n_blocks + DC_LANES - 1) / DC_LANES; }
+
 // ---- level 1: per-workgroup aggregate of the dc recurrence
 __global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
 {
@@ -98,38 +110,37 @@ __global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
         if ((tid & (2 * s - 1)) == 0) sh[tid] = compose(sh[tid], sh[tid + s]);
         __syncthreads();
     }
-    if (tid == 0) { double *o = p.blk + 4 * (long)blockIdx.x; o[0] = sh[0].a; o[1] = sh[0].re; o[2] = sh[0].im; }
+    if (tid == 0) { double *o = p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks)); o[0] = sh[0].a; o[1] = sh[0].re; o[2] = sh[0].im; }
 }
 
 // ---- level 2: scan over the workgroup aggregates (one workgroup); blk[b] becomes the averager value BEFORE block b
-__global__ __launch_bounds__(256) void front_dc_scan_kernel(FrontParams p)
+__global__ __launch_bounds__(DC_LANES) void front_dc_scan_kernel(FrontParams p)
 {
-    __shared__ Lin wave_tot[4];
+    __shared__ Lin wave_tot[DC_LANES / 64];
     const int tid = threadIdx.x, nb = p.n_blocks;
-    const int per = (nb + 255) / 256, b0 = tid * per, b1 = min(nb, b0 + per);
-    // one workgroup, ~120 aggregates per lane: eight loads in flight per lane instead of one (same operations in the same order)
-    constexpr int U = 8;
+    const int per = dc_per(nb), b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
+    // several loads in flight per lane instead of one (same operations in the same order); 1024 lanes leave 64 VGPRs per lane
+    constexpr int U = DC_LANES > 512 ? 3 : 8;
     Lin l{1.0, 0.0, 0.0};
     for (int b = b0; b < b1; b += U) {
         Lin w[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const double *v = p.blk + 4 * (long)min(b + u, b1 - 1); w[u] = Lin{v[0], v[1], v[2]}; }
+        for (int u = 0; u < U; ++u) { const double4 v = *reinterpret_cast<const double4 *>(p.blk + 4 * dc_slot(min(b + u, b1 - 1), per)); w[u] = Lin{v.x, v.y, v.z}; }
 #pragma unroll
         for (int u = 0; u < U; ++u) if (b + u < b1) l = compose(l, w[u]);
     }
     Lin total;
-    const Lin ex = block_scan_exclusive(l, wave_tot, &total);
+    const Lin ex = block_scan_exclusive<DC_LANES / 64>(l, wave_tot, &total);
     const double s_re = p.state->dc_re, s_im = p.state->dc_im;
     double re = ex.a * s_re + ex.re, im = ex.a * s_im + ex.im;
     for (int b = b0; b < b1; b += U) {
         Lin w[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const double *v = p.blk + 4 * (long)min(b + u, b1 - 1); w[u] = Lin{v[0], v[1], v[2]}; }
+        for (int u = 0; u < U; ++u) { const double4 v = *reinterpret_cast<const double4 *>(p.blk + 4 * dc_slot(min(b + u, b1 - 1), per)); w[u] = Lin{v.x, v.y, v.z}; }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (b + u < b1) {
-                double *v = p.blk + 4 * (long)(b + u);
-                v[0] = re; v[1] = im;
+                *reinterpret_cast<double2 *>(p.blk + 4 * dc_slot(b + u, per)) = make_double2(re, im);
                 re = w[u].a * re + w[u].re; im = w[u].a * im + w[u].im;
             }
     }
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
     const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * 4;
     float xr[4], xi[4]; int valid;
     load4(p, s0, xr, xi, valid);
-    const double *start = p.blk + 4 * (long)blockIdx.x;
+    const double *start = p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks));
     const Lin ex = block_scan_exclusive(thread_lin(xr, xi, valid), wave_tot, nullptr);
     double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
     const float c1 = p.state->c1, c2 = p.state->c2;
@@ -463,7 +474,7 @@ void launch_front(const FrontParams &p, hipStream_t stream)
     }
     if (p.n > 0 && (p.stages & FRONT_STAGE_DEROTATE)) {
         hipLaunchKernelGGL(front_dc_block_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(DC_LANES), 0, stream, p);
         hipLaunchKernelGGL(front_derotate_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
     }
 #ifndef T2_FRONT_FUSED

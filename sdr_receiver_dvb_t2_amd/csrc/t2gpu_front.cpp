@@ -160,7 +160,7 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         const float rk = 1.0f / k_table;
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
-    bool ok = hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, nb * 4 * sizeof(double)) == hipSuccess &&
+    bool ok = hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
               hipMalloc(&h->d_derot, ((size_t)max_samples + 3) * sizeof(float2)) == hipSuccess &&
               hipMalloc(&h->d_interp, ((size_t)h->interp_cap + 63) * sizeof(float2)) == hipSuccess &&
