@@ -300,8 +300,48 @@ __global__ __launch_bounds__(FD_THREADS, 7) void front_farrow_decimate_kernel(Fr
     // input samples whose outputs fall into the window: from the owner of its first cell to the owner of its last
     const long oA = m0 > 63 ? m0 - 63 : 0, oB = (m0 + W - 1 < avail ? m0 + W - 1 : avail - 1) - 63;
     __syncthreads();
-    if (oA <= oB) {
-        const FrontRun ra = p.far_runs[find_run_out(p.far_runs, p.n_far_runs, oA)], rb = p.far_runs[find_run_out(p.far_runs, p.n_far_runs, oB)];
+    const int run_a = oA <= oB ? find_run_out(p.far_runs, p.n_far_runs, oA) : 0, run_b = oA <= oB ? find_run_out(p.far_runs, p.n_far_runs, oB) : 0;
+    if (oA <= oB && run_a == run_b) {
+        // The whole window inside one run (runs are up to 2^24 samples long while the loops stand still): position, output index and
+        // the outputs-per-sample count come from that one record through scalar registers, in 32-bit arithmetic relative to the
+        // window; the reference's `while (x1 < 0.5f)` makes exactly cnt trips for every sample of a run (front_plan.cpp). Same values.
+        const FrontRun run = p.far_runs[run_a];
+        const int cnt = run.cnt;
+        const long i_first = (long)run.i0 + (uint32_t)(oA - run.o0) / (uint32_t)cnt, i_last = (long)run.i0 + (uint32_t)(oB - run.o0) / (uint32_t)cnt;
+        const int nin = (int)(i_last - i_first) + 1, kf = (int)(i_first - run.i0);
+        const uint32_t tb = (uint32_t)(63 + (long)run.o0 - m0);                 // window index of output o: 63 + o - m0 = tb + k * cnt (mod 2^32)
+        const long tail = (long)p.n_interp - m0;                                // window index from which cells are also the next call's prefix
+        const int tail_t = tail > W + 8 ? 0x7fffffff : (tail < -(1 << 30) ? -(1 << 30) : (int)tail);
+        const float2 *src = p.derot + i_first;
+        float2 *keep = p.interp + m0;
+        const float delay_x = run.aux;
+        for (int il = threadIdx.x; il < nin; il += FD_THREADS) {
+            const float2 in = src[3 + il], d1 = src[2 + il], d2 = src[1 + il], d3 = src[il];
+            const int k = kf + il;
+            float x1 = (float)(run.base + (double)k * run.step);
+            int t = (int)(tb + (uint32_t)k * (uint32_t)cnt);
+            float a0[2], a1[2], a2[2], a3[2];
+            const float vin[2] = {in.x, in.y}, v1[2] = {d1.x, d1.y}, v2[2] = {d2.x, d2.y}, v3[2] = {d3.x, d3.y};
+            for (int c = 0; c < 2; ++c) {
+                const float even1 = add_r(v3[c], vin[c]), even2 = add_r(v2[c], v1[c]);
+                const float odd1 = sub_r(v3[c], vin[c]), odd2 = sub_r(v2[c], v1[c]);
+                a0[c] = sub_r(mul_r(9.0f / 16.0f, even2), mul_r(1.0f / 16.0f, even1));
+                a1[c] = sub_r(mul_r(1.0f / 8.0f, odd1), mul_r(11.0f / 8.0f, odd2));
+                a2[c] = mul_r(1.0f / 4.0f, sub_r(even1, even2));
+                a3[c] = sub_r(mul_r(3.0f / 2.0f, odd2), mul_r(1.0f / 2.0f, odd1));
+            }
+            for (int c = 0; c < cnt; ++c) {
+                const float x2 = mul_r(x1, x1), x3 = mul_r(x2, x1);
+                float v[2];
+                for (int q = 0; q < 2; ++q) v[q] = add_r(add_r(add_r(mul_r(a3[q], x3), mul_r(a2[q], x2)), mul_r(a1[q], x1)), a0[q]);
+                if (t >= 0 && t < W) w[t] = make_float2(v[0], v[1]);
+                if (t >= tail_t) keep[t] = make_float2(v[0], v[1]);             // the tail the next call starts from
+                ++t;
+                x1 = add_r(x1, delay_x);
+            }
+        }
+    } else if (oA <= oB) {
+        const FrontRun ra = p.far_runs[run_a], rb = p.far_runs[run_b];
         const long i_first = (long)ra.i0 + (uint32_t)(oA - ra.o0) / (uint32_t)ra.cnt, i_last = (long)rb.i0 + (uint32_t)(oB - rb.o0) / (uint32_t)rb.cnt;
         for (long i = i_first + threadIdx.x; i <= i_last; i += FD_THREADS) {
             const FrontRun run = p.far_runs[find_run(p.far_runs, p.n_far_runs, i)];
