@@ -288,14 +288,24 @@ __device__ __forceinline__ int find_run_out(const FrontRun *__restrict__ runs, i
     return lo;
 }
 
-constexpr int FD_THREADS = 256;       // 256 outputs per workgroup need about 290 input samples: a short second pass (320 lanes measured slower)
-__global__ __launch_bounds__(FD_THREADS, 7) void front_farrow_decimate_kernel(FrontParams p)
+#ifndef T2_FD_OUT
+#define T2_FD_OUT 1024
+#endif
+#ifndef T2_FD_WAVES
+#define T2_FD_WAVES 7
+#endif
+// outputs per workgroup: FD_OUT need about FD_OUT + 34 input samples, so the Farrow passes of 256 lanes end with one mostly empty pass
+// whatever FD_OUT is -- the larger, the less that costs. Measured with the one-run path (tools/front_shape_probe.sh, us per 75 M
+// samples): 256 -> 840, 512 -> 795, 768 -> 738, 1024 -> 701, 1536 -> 915, 2048 -> 848 (LDS 17 KB at 1024: still seven workgroups
+// of four wavefronts per CU); held to 68 VGPRs (7 wavefronts per SIMD; 8 spills and costs 30 %).
+constexpr int FD_THREADS = 256, FD_OUT = T2_FD_OUT;
+__global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate_kernel(FrontParams p)
 {
-    __shared__ float2 w[2 * 256 + 64];
-    const long k0 = (long)blockIdx.x * 256;
+    __shared__ float2 w[2 * FD_OUT + 64];
+    const long k0 = (long)blockIdx.x * FD_OUT;
     const long m0 = 2 * k0 + (1 - p.decim_phase);
     const long avail = 63 + p.n_interp;
-    constexpr int W = 2 * 256 + 62;
+    constexpr int W = 2 * FD_OUT + 62;
     for (int t = threadIdx.x; t < W; t += FD_THREADS) w[t] = m0 + t < 63 ? p.interp[m0 + t] : make_float2(0.f, 0.f);   // carried cells; zeros behind the end
     // input samples whose outputs fall into the window: from the owner of its first cell to the owner of its last
     const long oA = m0 > 63 ? m0 - 63 : 0, oB = (m0 + W - 1 < avail ? m0 + W - 1 : avail - 1) - 63;
@@ -373,23 +383,25 @@ __global__ __launch_bounds__(FD_THREADS, 7) void front_farrow_decimate_kernel(Fr
         }
     }
     __syncthreads();
-    const long k = k0 + threadIdx.x;
-    if (threadIdx.x >= 256 || k >= p.n_out) return;
-    const float2 *x = w + 2 * threadIdx.x;
-    float lane_r[4], lane_i[4];
-    for (int q = 0; q < 4; ++q) {
-        float ar = 0.0f, ai = 0.0f;
-        for (int blk = 0; blk < 4; ++blk) {
-            const int c = 16 * blk + q;
-            const float2 x0 = x[c], x1 = x[c + 4], x2 = x[c + 8], x3 = x[c + 12];
-            const float h0 = c_taps[c], h1 = c_taps[c + 4], h2 = c_taps[c + 8], h3 = c_taps[c + 12];
-            ar = add_r(ar, add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
-            ai = add_r(ai, add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+    for (int ko = threadIdx.x; ko < FD_OUT; ko += FD_THREADS) {
+        const long k = k0 + ko;
+        if (k >= p.n_out) break;
+        const float2 *x = w + 2 * ko;
+        float lane_r[4], lane_i[4];
+        for (int q = 0; q < 4; ++q) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int blk = 0; blk < 4; ++blk) {
+                const int c = 16 * blk + q;
+                const float2 x0 = x[c], x1 = x[c + 4], x2 = x[c + 8], x3 = x[c + 12];
+                const float h0 = c_taps[c], h1 = c_taps[c + 4], h2 = c_taps[c + 8], h3 = c_taps[c + 12];
+                ar = add_r(ar, add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
+                ai = add_r(ai, add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+            }
+            lane_r[q] = ar; lane_i[q] = ai;
         }
-        lane_r[q] = ar; lane_i[q] = ai;
+        p.out[k] = make_float2(add_r(add_r(add_r(lane_r[0], lane_r[1]), lane_r[2]), lane_r[3]),
+                               add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
     }
-    p.out[k] = make_float2(add_r(add_r(add_r(lane_r[0], lane_r[1]), lane_r[2]), lane_r[3]),
-                           add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
 }
 
 // c1, c2, level_detect from the sign statistics of `len` samples (dvbt2_demodulator.cpp:227-235)
@@ -522,9 +534,9 @@ void launch_front(const FrontParams &p, hipStream_t stream)
 #endif
     const bool both = (p.stages & FRONT_STAGE_FARROW) && (p.stages & FRONT_STAGE_DECIMATE);
     if (T2_FRONT_FUSED && both && p.n > 0) {
-        // one pass, nothing of the resampled stream in HBM but its last 63 cells; enough workgroups that their 574-cell windows
+        // one pass, nothing of the resampled stream in HBM but its last 63 cells; enough workgroups that their windows
         // also cover the cells behind the last complete output (they are part of what the next call starts from)
-        const long by_out = (p.n_out + 255) / 256, by_cells = p.n_interp / 512 + 1;
+        const long by_out = (p.n_out + FD_OUT - 1) / FD_OUT, by_cells = p.n_interp / (2 * FD_OUT) + 1;
         hipLaunchKernelGGL(front_farrow_decimate_kernel, dim3((unsigned)(by_out > by_cells ? by_out : by_cells)), dim3(FD_THREADS), 0, stream, p);
     } else {
         if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))
