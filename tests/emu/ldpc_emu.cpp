@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <map>
 #include <vector>
 #include "../../sdr_receiver_dvb_t2_amd/csrc/ldpc_cn.h"
 #include "../../sdr_receiver_dvb_t2_amd/csrc/ldpc_graph.h"
@@ -129,4 +130,54 @@ extern "C" int emu_ldpc_max_conflict(int code_id)
     int m = 0;
     for (const LdpcLayer &l : g.layers) if (l.kind == T2_LAYER_GENERIC) m = std::max(m, l.n_conflict);
     return m;
+}
+
+// Independent check of the band-walk description of GENERIC layers (ldpc_graph.h: band, band_prefetch; the two-frame kernel's
+// p2_band_walk relies on it). For every band layer, by brute force over the 360 nodes and their conflict entries:
+//   1: two nodes that share a bit never lie in the same band, and the earlier node lies in the earlier band (ascending-j order
+//      band by band is then the reference's order);
+//   2: the bit node j reaches through entry 0 is the bit node j + D reaches through entry 1, and no node between them touches it
+//      (the value handed down in a register is the value the reference would read);
+//   3: with band_prefetch, whatever else a node of band t reads was last written in band t - 2 or earlier (loads one band ahead).
+// Returns 0, or 100 * layer + rule on the first violation; *n_band = number of band layers of the code.
+extern "C" int emu_ldpc_band_check(int code_id, int *n_band)
+{
+    LdpcGraph g;
+    if (!ldpc_build_graph(code_id, g)) return -1;
+    *n_band = 0;
+    for (int i = 0; i < g.q; ++i) {
+        const LdpcLayer &L = g.layers[i];
+        if (!L.band) continue;
+        ++*n_band;
+        if (L.kind != T2_LAYER_GENERIC || L.n_conflict > 4 || L.band > 32) return 100 * i + 9;
+        const int D = L.band, nc = L.n_conflict;
+        std::vector<int> grp(nc), sh(nc);
+        for (int c = 0; c < nc; ++c) { const uint32_t e = g.entries[L.first_entry + c]; grp[c] = (int)(e & 0xffffu) / 360; sh[c] = (int)(e >> 16); }
+        auto bit = [&](int j, int c) { return grp[c] * 360 + ((j - sh[c]) % 360 + 360) % 360; };
+        // touchers of every bit in node order
+        std::map<int, std::vector<std::pair<int, int>>> touch;       // bit -> (node, entry), ascending node
+        for (int j = 0; j < 360; ++j)
+            for (int c = 0; c < nc; ++c) touch[bit(j, c)].push_back({j, c});
+        for (auto &kv : touch) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end());
+            for (size_t a = 0; a + 1 < v.size(); ++a)
+                if (v[a].first / D >= v[a + 1].first / D) return 100 * i + 1;
+        }
+        for (int j = 0; j + D < 360; ++j) {
+            if (bit(j, 0) != bit(j + D, 1)) return 100 * i + 2;
+            const auto &v = touch[bit(j, 0)];
+            for (size_t a = 0; a + 1 < v.size(); ++a)
+                if (v[a].first == j && v[a + 1].first != j + D) return 100 * i + 2;
+        }
+        if (L.band_prefetch)
+            for (int j = D; j < 360; ++j)
+                for (int c = 0; c < nc; ++c) {
+                    if (c == 1) continue;
+                    const auto &v = touch[bit(j, c)];
+                    for (size_t a = 1; a < v.size(); ++a)
+                        if (v[a].first == j && v[a].second == c && v[a - 1].first / D > j / D - 2) return 100 * i + 3;
+                }
+    }
+    return 0;
 }

@@ -76,3 +76,16 @@ def test_zero_llr_is_bad():
     llr[0, 5] = 0
     t, bits, lo = ol.ora_decode(cid, llr)
     assert t == 24 and lo[0, 5] > 0
+
+
+@pytest.mark.parametrize("code_id", range(12))
+def test_band_walk_description_of_generic_layers(code_id):
+    """ldpc_graph.cpp marks GENERIC layers the two-frame kernel may walk in bands (band = D, slots 0 / 1 = the pair handed down in a
+    register, band_prefetch). tests/emu checks the three properties the walk relies on by brute force over nodes and bits; N 3/4 (id 9)
+    must have its layers 5 (D = 31) and 42 (D = 11) among them -- they are a fifth of a sweep otherwise."""
+    import ctypes
+    emu = ol.emu()
+    n = ctypes.c_int(0)
+    assert emu.emu_ldpc_band_check(code_id, ctypes.byref(n)) == 0
+    if code_id == 9:
+        assert n.value == 2
