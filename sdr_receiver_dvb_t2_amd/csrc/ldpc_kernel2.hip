@@ -348,6 +348,17 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
         int trials = p.max_trials;
         int result;
         for (int t = 0;; ++t) {
+            // the first layer's records of the coming sweep are fetched ahead of the parity check (they were written a sweep ago;
+            // read at the head of the sweep, all twelve wavefronts sat out the L2 round trip together)
+            uint32_t first_rec[RW];
+            if (have_a && active) {
+                const uint4 *q4 = reinterpret_cast<const uint4 *>(state + (size_t)tid * RW);
+#pragma unroll
+                for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; first_rec[4 * w] = v.x; first_rec[4 * w + 1] = v.y; first_rec[4 * w + 2] = v.z; first_rec[4 * w + 3] = v.w; }
+            } else {
+#pragma unroll
+                for (int w = 0; w < RW; ++w) first_rec[w] = 0u;
+            }
             // ---- parity check of both frames (LDPCDecoder::bad)
             T2_PROF2_T(tp0);
             const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl) : 0;
@@ -392,14 +403,8 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             // ---- one layered update sweep (LDPCDecoder::update)
             if (have_a) {
                 uint32_t nxt[RW];
-                if (active) {
-                    const uint4 *q4 = reinterpret_cast<const uint4 *>(state + (size_t)tid * RW);
 #pragma unroll
-                    for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
-                } else {
-#pragma unroll
-                    for (int w = 0; w < RW; ++w) nxt[w] = 0u;
-                }
+                for (int w = 0; w < RW; ++w) nxt[w] = first_rec[w];
                 uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
                 constexpr bool UNI = LO == HI;
                 uint2 epf[(HI + 3) / 2];
