@@ -46,11 +46,45 @@ __device__ __forceinline__ void fft_reg(cf (&v)[32])
         }
     }
 }
+// w^k for k = 1 .. 31 from w, w^2, w^4, w^8, w^16 (pw[0..4], table values): the product over the set bits of k, at most four
+// multiplications deep.
+// The stage twiddles W_N^(t k) are powers of the lane's own W_N^t: read per (lane, k) from the table they were 62 eight-byte
+// gathers per lane and symbol -- as many bytes as the symbol itself, 30 to 64 distinct lines per load instruction -- and the kernel
+// ran at the address rate of the CU; as powers they cost five reads and ~50 complex multiplications per stage.
+template <int K>
+__device__ __forceinline__ cf cpow_bits(const cf (&pw)[5])
+{
+    static_assert(K >= 1 && K < 32, "exponent");
+    constexpr int lo = K & -K;                                   // lowest set bit
+    constexpr int idx = lo == 1 ? 0 : lo == 2 ? 1 : lo == 4 ? 2 : lo == 8 ? 3 : 4;
+    if constexpr ((K & (K - 1)) == 0) return pw[idx];
+    else return cmul(cpow_bits<(K & (K - 1))>(pw), pw[idx]);
+}
+// pw[b] = W_N^(m 2^b), each read from the table (squaring the first would double its angle error every time)
+__device__ __forceinline__ void cpow_table(const float2 *__restrict__ twiddle, int m, int mask, cf (&pw)[5])
+{
+#pragma unroll
+    for (int b = 0; b < 5; ++b) { const float2 w = twiddle[(m << b) & mask]; pw[b] = cf{w.x, w.y}; }
+}
+template <int R, int I = 1>
+__device__ __forceinline__ void twiddle_powers(cf (&v)[32], const cf (&pw)[5]);
+
 template <int R> __device__ __forceinline__ constexpr int bitrev(int i)
 {
     int r = 0;
     for (int b = 1, s = R >> 1; s >= 1; b <<= 1, s >>= 1) if (i & b) r |= s;
     return r;
+}
+
+// v[r] *= w^bitrev(r) for r = 1 .. 31
+template <int R, int I>
+__device__ __forceinline__ void twiddle_powers(cf (&v)[32], const cf (&pw)[5])
+{
+    if constexpr (I < 32) {
+        constexpr int k = bitrev<R>(I);
+        v[I] = cmul(v[I], cpow_bits<k>(pw));
+        twiddle_powers<R, I + 1>(v, pw);
+    }
 }
 
 // T2 = 32: N = 32768, 1024 threads. T2 = 16: N = 16384, 512 threads.
@@ -73,10 +107,10 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
 #pragma unroll
         for (int j = 0; j < 32; ++j) { const float2 a = x[tid + T * j]; v[j] = {a.x, a.y}; }
         fft_reg<32>(v);
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {                       // twiddle W_N^(t*k1), k1 = bitrev(r)
-            const int k1 = bitrev<32>(r);
-            if (k1) { const float2 w = twiddle[(tid * k1) & (N - 1)]; v[r] = cmul(v[r], cf{w.x, w.y}); }
+        {                                                    // twiddle W_N^(t*k1), k1 = bitrev(r): powers of W_N^t
+            cf pw[5];
+            cpow_table(twiddle, tid, N - 1, pw);
+            twiddle_powers<32>(v, pw);
         }
         // ---- exchange 1: thread (k1, t1) := id k1*T2 + t1 collects y_k1[t1 + T2*t2], t2 = 0..31
         cf u[32];
@@ -95,10 +129,10 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
         }
         // ---- stage B: 32-point DFT over t2 -> q1; twiddle W_T^(t1*q1) = W_N^(32*t1*q1)
         fft_reg<32>(u);
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int q1 = bitrev<32>(r);
-            if (q1) { const float2 w = twiddle[(32 * t1n * q1) & (N - 1)]; u[r] = cmul(u[r], cf{w.x, w.y}); }
+        {                                                    // powers of W_N^(32*t1)
+            cf pw[5];
+            cpow_table(twiddle, 32 * t1n, N - 1, pw);
+            twiddle_powers<32>(u, pw);
         }
         // ---- exchange 2: rows (q1, k1) of T2 values over t1, pitch 33. New thread id' -> pairs (q1, k1) with k1 fastest:
         //      32K: one pair per thread (q1 = id'/32, k1 = id'%32), 32 values; 16K: two pairs per thread, 16 values each.
