@@ -159,25 +159,45 @@ __global__ __launch_bounds__(T2_DEMAP_THREADS) void demap_llr_kernel(DemapParams
     const float precision = sums[(size_t)(f / frames_per_sums) * sums_stride + 2];
     const float2 *src = cells + (size_t)f * p.cells_per_fec;
     const int levels = p.mod + 1;
-    for (int c = threadIdx.x; c < p.cells_per_fec; c += blockDim.x) {
-        float2 v = src[c];
-        if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
-        if (p.mod == 0) {                                                  // quantize(): clamps (llr_demapper.cpp:770-776)
-            float a = rintf(mul_r(v.x, precision)), b = rintf(mul_r(v.y, precision));
-            a = fminf(fmaxf(a, -128.0f), 127.0f); b = fminf(fmaxf(b, -128.0f), 127.0f);
-            stage[2 * c] = (int8_t)a; stage[2 * c + 1] = (int8_t)b;
-            continue;
+    // a lane's cells of a pass and their LDS positions (an L2-resident table) are all read before the first is used: with two
+    // workgroups per CU -- a frame each in LDS -- nothing else covers a round trip per cell (387 -> 325 us per 7676 frames)
+    constexpr int U = 4;                       // 8 (a whole 256-QAM frame in one pass) needs more than the 64 VGPRs two 1024-lane workgroups leave: 405 us
+    const uint32_t *addr32 = reinterpret_cast<const uint32_t *>(p.address);   // one dword per cell and level: the two LDS positions
+    for (int c0 = threadIdx.x; c0 < p.cells_per_fec; c0 += U * blockDim.x) {
+        float2 cell[U];
+        uint32_t pos[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * blockDim.x;
+            const bool in = c < p.cells_per_fec;
+            cell[u] = in ? src[c] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) pos[u][l] = (in && l < levels && p.mod != 0) ? addr32[c * levels + l] : 0u;
         }
-        const uint16_t *a = p.address + c * p.bits_per_cell;
-        float thr = p.d * (float)(1 << p.mod);
-        for (int l = 0; l < levels; ++l) {
-            float lx = rintf(mul_r(v.x, precision)), ly = rintf(mul_r(v.y, precision));
-            if (p.saturate) { lx = fminf(fmaxf(lx, -128.0f), 127.0f); ly = fminf(fmaxf(ly, -128.0f), 127.0f); }
-            stage[a[2 * l]] = cast_i8_trunc(lx);
-            stage[a[2 * l + 1]] = cast_i8_trunc(ly);
-            v.x = sub_r(fabsf(v.x), thr);
-            v.y = sub_r(fabsf(v.y), thr);
-            thr *= 0.5f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * blockDim.x;
+            if (c >= p.cells_per_fec) break;
+            float2 v = cell[u];
+            if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
+            if (p.mod == 0) {                                              // quantize(): clamps (llr_demapper.cpp:770-776)
+                float a = rintf(mul_r(v.x, precision)), b = rintf(mul_r(v.y, precision));
+                a = fminf(fmaxf(a, -128.0f), 127.0f); b = fminf(fmaxf(b, -128.0f), 127.0f);
+                stage[2 * c] = (int8_t)a; stage[2 * c + 1] = (int8_t)b;
+                continue;
+            }
+            float thr = p.d * (float)(1 << p.mod);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                if (l >= levels) break;
+                float lx = rintf(mul_r(v.x, precision)), ly = rintf(mul_r(v.y, precision));
+                if (p.saturate) { lx = fminf(fmaxf(lx, -128.0f), 127.0f); ly = fminf(fmaxf(ly, -128.0f), 127.0f); }
+                stage[pos[u][l] & 0xffffu] = cast_i8_trunc(lx);
+                stage[pos[u][l] >> 16] = cast_i8_trunc(ly);
+                v.x = sub_r(fabsf(v.x), thr);
+                v.y = sub_r(fabsf(v.y), thr);
+                thr *= 0.5f;
+            }
         }
     }
     __syncthreads();
