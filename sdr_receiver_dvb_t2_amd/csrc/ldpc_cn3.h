@@ -231,6 +231,7 @@ __device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const ui
             p2_merge<CNT, 1>(r, 2);
             p2_write_slot<CNT>(L, r, 0, true);
         } else if (h == 0) {
+            L.st16(d.pair_flag_lds + 2 * j, 0u);          // "the bit this node shares with its predecessor is final": not yet (both frames)
             // t2_pair_record / t2_pair_pack for both frames at once, in the halves: k1 = (neg ? msg1 : -msg1) - 1, cap = f(p0), in0 and
             // the sign field (neg ? 3 : 1) are formed times 256 (the sign field plain) and their bytes gathered with four v_perm_b32
             const p16 m1 = p_of(__builtin_amdgcn_perm(0u, partner_m0, 0x010c000cu));      // slot 1's old messages, times 256
@@ -274,6 +275,7 @@ __device__ __forceinline__ void p2_pair_walk_segments(LMEM &L, const LayerDesc &
     m += (m < 0) ? 360 : 0;
     bool go = false;
     int X = 0;
+    const int flag = d.pair_flag_lds + frame;             // flag of node n at flag + 2 n: set once the bit n shares with n - step is final
     if (node < step) {                                    // chain start: its bit was finished in phase A
         go = true;
         X = (int)L.ld(base2 + 2 * m);
@@ -286,6 +288,7 @@ __device__ __forceinline__ void p2_pair_walk_segments(LMEM &L, const LayerDesc &
         }
     }
     int jj = node + step;
+    if (go && jj < 360) L.st(flag + 2 * jj, (int8_t)1);   // after the read / store above: LDS accesses of a wavefront execute in order
     uint32_t nxt = (go && jj < last) ? pair_rec[jj] : 0u;
     while (go && jj < last) {
         const PairRec r = t2_pair_unpack(nxt);
@@ -296,6 +299,7 @@ __device__ __forceinline__ void p2_pair_walk_segments(LMEM &L, const LayerDesc &
         m = (int)(t < t - 360u ? t : t - 360u);           // (m + step) mod 360
         X = t2_pair_step(r, X);
         L.st(base2 + 2 * m, (int8_t)X);
+        L.st(flag + 2 * jj, (int8_t)1);
     }
 }
 
@@ -308,9 +312,11 @@ __device__ __forceinline__ void p2_pair_walk(LMEM &L, const LayerDesc &d, int la
     int m = lane - s0;
     m += (m < 0) ? 360 : 0;
     int X = (int)L.ld(base2 + 2 * m);
+    const int flag = d.pair_flag_lds + frame;
     // the records are read one node ahead of the recurrence (they do not depend on it): a step then costs its arithmetic, not
     // an LDS round trip on top
     int jj = lane + step;
+    L.st(flag + 2 * jj, (int8_t)1);                               // node lane + step may read its bit (after the read above)
     uint32_t nxt = pair_rec[jj < 359 ? jj : 359];
     for (; jj + step < 360; jj += step) {                         // nodes that have a successor
         const PairRec r = t2_pair_unpack(nxt);
@@ -320,6 +326,7 @@ __device__ __forceinline__ void p2_pair_walk(LMEM &L, const LayerDesc &d, int la
         m = (int)(t < t - 360u ? t : t - 360u);
         X = t2_pair_step(r, X);
         L.st(base2 + 2 * m, (int8_t)X);
+        L.st(flag + 2 * jn, (int8_t)1);
     }
 }
 
@@ -333,6 +340,10 @@ __device__ __forceinline__ void p2_pair_finish(LMEM &L, const LayerDesc &d, int 
         for (int v = 1; v < H; ++v) p2_write_slot<CNT>(L, r, v, true);
         return;
     }
+    // wait until the walks of both frames have passed this node's predecessor (no barrier behind the walks: a wavefront goes on as
+    // soon as its own nodes are served, so the finishes of the early nodes run beside the walks of the late ones)
+    while (L.ld16_volatile(d.pair_flag_lds + 2 * j) != 0x0101u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const bool has_succ = j + d.step < 360;
     if (r.h || !has_succ) p2_read_slot<CNT>(L, r, 0);     // slot 1 always, slot 0 when the node ends its chain
     p2_merge<CNT, 1>(r, 2);

@@ -26,6 +26,10 @@ struct LdsMem2 {
     {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uint32_t)a);
     }
+    __device__ __forceinline__ uint16_t ld16_volatile(int a) const
+    {
+        return *reinterpret_cast<const volatile __attribute__((address_space(3))) uint16_t *>((uint32_t)a);
+    }
     __device__ __forceinline__ void st16(int a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uint32_t)a) = (uint16_t)v; }
     __device__ __forceinline__ uint32_t ld32(int a) const { return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uint32_t)a); }
     __device__ __forceinline__ void st32(int a, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uint32_t)a) = v; }
@@ -181,8 +185,7 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, co
             else if (node < d.step) p2_pair_walk(L, d, node, frame, pair_rec + 360 * frame);
         }
         __builtin_amdgcn_s_setprio(0);
-        lds_barrier2();
-        if (active) p2_pair_finish<CNT>(L, d, j, r);
+        if (active) p2_pair_finish<CNT>(L, d, j, r);       // polls the walks' ready flags: no barrier here
     } else if (d.kind == T2_LAYER_GENERIC && d.band) {
         if constexpr (NCMAX >= 3) {
             lds_barrier2();
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                                 entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
                     d.band = (ly.nc <= NCMAX && ly.nc <= ly.cnt) ? ly.band : 0; d.band_prefetch = ly.band_prefetch;
                     d.band_rec_lds = L.off() + p.lds_sign_offset; d.band_in_lds = L.off() + p.lds_rec_offset;
+                    d.pair_flag_lds = L.off() + p.lds_sign_offset;
                     const uint32_t info = info_nxt;
                     const int jn = (ly.kind == T2_LAYER_GENERIC && !d.band) ? (int)(info >> 20) : j;
                     const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
