@@ -342,7 +342,10 @@ __device__ __forceinline__ void p2_pair_finish(LMEM &L, const LayerDesc &d, int 
     }
     // wait until the walks of both frames have passed this node's predecessor (no barrier behind the walks: a wavefront goes on as
     // soon as its own nodes are served, so the finishes of the early nodes run beside the walks of the late ones)
-    while (L.ld16_volatile(d.pair_flag_lds + 2 * j) != 0x0101u) __builtin_amdgcn_s_sleep(1);
+#ifndef T2_PAIR_SLEEP
+#define T2_PAIR_SLEEP 1
+#endif
+    while (L.ld16_volatile(d.pair_flag_lds + 2 * j) != 0x0101u) { if (T2_PAIR_SLEEP) __builtin_amdgcn_s_sleep(T2_PAIR_SLEEP); }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const bool has_succ = j + d.step < 360;
     if (r.h || !has_succ) p2_read_slot<CNT>(L, r, 0);     // slot 1 always, slot 0 when the node ends its chain
