@@ -7,7 +7,7 @@ cp libt2gpu.so /tmp/ab_new.so
 for r in 1 2 3; do
   for f in /tmp/ab_new.so libt2gpu_*.so.keep; do
     cp $f libt2gpu.so.tmp && mv libt2gpu.so.tmp libt2gpu.so
-    echo "$(basename $f): $(python $ROOT/tools/ldpc_phase_profile.py 7680 32 ${1:-noise} 2>&1 | grep launch)"
+    echo "$(basename $f): $(python $ROOT/tools/ldpc_phase_profile.py 7680 32 ${1:-noise} ${2:-3} 2>&1 | grep launch)"
   done
 done
 cp /tmp/ab_new.so libt2gpu.so

@@ -8,14 +8,15 @@ import sdr_receiver_dvb_t2_amd as pkg
 import oracle_lib as ol
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 group = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-cid = 9
+rate = int(sys.argv[4]) if len(sys.argv) > 4 else 3           # code rate id of the 64800 code (3 = 3/4, 2 = 2/3 ...)
+cid = 6 + rate
 if len(sys.argv) > 3 and sys.argv[3] == "noise":       # the bench's load: nothing converges, every batch runs all 25 sweeps
     llr = np.random.default_rng(1).integers(-20, 21, size=(256, 64800), dtype=np.int8)
 else:
     info, llr = ol.make_llr(cid, min(frames, 256), 0.60, 1)
 llr = np.tile(llr, ((frames + 255) // 256, 1))[:frames]
 x = torch.from_numpy(np.ascontiguousarray(llr)).cuda()
-dec = pkg.ldpc_decoder(1, 3, max_frames=frames, group=group)
+dec = pkg.ldpc_decoder(1, rate, max_frames=frames, group=group)
 dec.execute_dev(x); torch.cuda.synchronize()
 pkg.lib().t2gpu_ldpc_profile(dec._h, None)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
