@@ -108,6 +108,29 @@ __device__ __forceinline__ uint32_t layer_syndrome2(const uint32_t *S, const Ldp
     }
     return syn & ((tj == 11) ? 0xffu : 0xffffffffu);
 }
+// the same with the layer's table entries taken from their LDS copy ((lds_base + 2 (bit base - shift), shift) pairs): no memory
+// round trip inside the check
+__device__ __forceinline__ int ent_group_lds(const uint32_t *lds_ent, int lds_base, int c, int *shift)
+{
+    const int x = (int)lds_ent[2 * c], sh = (int)lds_ent[2 * c + 1];
+    *shift = sh;
+    return (int)__umulhi((uint32_t)(((x - lds_base) >> 1) + sh), 11930465u);   // bit base / 360
+}
+__device__ __forceinline__ uint32_t layer_syndrome2_lds(const uint32_t *S, int cnt, const uint32_t *lds_ent, int lds_base, int gp0, int q, int i, int tj)
+{
+    const int j0 = 32 * tj;
+    uint32_t syn = S[(gp0 + i) * 13 + tj];
+    if (i > 0) syn ^= S[(gp0 + i - 1) * 13 + tj];
+    else syn ^= (tj == 0) ? (S[(gp0 + q - 1) * 13] << 1) : sign_window2(S, gp0 + q - 1, j0 - 1);
+    for (int c = 0; c < cnt; ++c) {
+        int sh;
+        const int g = ent_group_lds(lds_ent, lds_base, c, &sh);
+        int m = j0 - sh;
+        m += (m < 0) ? 360 : 0;
+        syn ^= sign_window2(S, g, m);
+    }
+    return syn & ((tj == 11) ? 0xffu : 0xffffffffu);
+}
 __device__ __forceinline__ void finish_group2(uint32_t *S, int g)
 {
     const uint32_t d0 = S[g * 13], d1 = S[g * 13 + 1];
@@ -115,40 +138,49 @@ __device__ __forceinline__ void finish_group2(uint32_t *S, int g)
     S[g * 13 + 12] = (d0 >> 24) | (d1 << 8);
 }
 
-// per thread: bit 0 = frame A saw a zero LLR or a failing check, bit 1 = frame B
+// per thread: bit 0 = frame A saw a zero LLR or a failing check, bit 1 = frame B; bit 2 = bits 0 / 1 are already the workgroup's
+// verdict (the probe failed for both frames). probe_first / probe_cnt: first table entry and link count of layer 1; lds_ent: the
+// LDS copy of the table entries, lds_base: the LDS address of the LLR array they were made for.
 __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA, uint32_t *SB, const LdpcLayerDev *__restrict__ layers,
-                                                 const uint32_t *__restrict__ entries, int n, int k, int q, int tid, int *s_ctl)
+                                                 const uint32_t *__restrict__ entries, int n, int k, int q, int tid, int *s_ctl,
+                                                 int probe_first, int probe_cnt, const uint32_t *lds_ent, int lds_base)
 {
     const int ngroups = n / 360, gp0 = k / 360;
     uint32_t zero = 0;
     int probe = 0;
     // Probe (ldpc_kernel.hip): the 360 checks of layer 1 need the sign words of ~14 groups only, and a frame that has not converged
     // almost always fails there. When BOTH frames fail the probe the workgroup is done; otherwise the full check runs for both.
+    // The probe runs once per sweep for every frame pair that is still decoding: it reads nothing from memory (table entries from
+    // their LDS copy) and ends in ONE barrier (the wavefronts' verdicts are OR-ed into an LDS word).
     if (q > 1) {
-        const LdpcLayerDev ly = layers[1];
-        const uint32_t *ent = entries + ly.first_entry;
-        const int ng = ly.cnt + 2;
+        const uint32_t *ent = lds_ent + 2 * probe_first;
+        const int ng = probe_cnt + 2;
+        if (tid == 0) s_ctl[2] = 0;
         if (tid < ng * 12) {
             const int gi = tid / 12, kk = tid - gi * 12;
-            const int g = gi < ly.cnt ? (int)__umulhi(ent[gi] & 0xffffu, 11930465u) : gp0 + (gi - ly.cnt);
+            int sh;
+            const int g = gi < probe_cnt ? ent_group_lds(ent, lds_base, gi, &sh) : gp0 + (gi - probe_cnt);
             uint32_t wa, wb;
             sign_word2(Lm, g, kk, wa, wb, &zero);
             SA[g * 13 + kk] = wa; SB[g * 13 + kk] = wb;
         }
         lds_barrier2();
         if (tid < ng) {
-            const int g = tid < ly.cnt ? (int)__umulhi(ent[tid] & 0xffffu, 11930465u) : gp0 + (tid - ly.cnt);
+            int sh;
+            const int g = tid < probe_cnt ? ent_group_lds(ent, lds_base, tid, &sh) : gp0 + (tid - probe_cnt);
             finish_group2(SA, g); finish_group2(SB, g);
         }
         lds_barrier2();
         int bad = ((zero & 0x00800080u) ? 1 : 0) | ((zero & 0x80008000u) ? 2 : 0);
         if (tid < 12) {
-            if (layer_syndrome2(SA, ly, ent, gp0, q, 1, tid)) bad |= 1;
-            if (layer_syndrome2(SB, ly, ent, gp0, q, 1, tid)) bad |= 2;
+            if (layer_syndrome2_lds(SA, probe_cnt, ent, lds_base, gp0, q, 1, tid)) bad |= 1;
+            if (layer_syndrome2_lds(SB, probe_cnt, ent, lds_base, gp0, q, 1, tid)) bad |= 2;
         }
-        const int pa = __syncthreads_or(bad & 1), pb = __syncthreads_or(bad & 2);
-        probe = (pa ? 1 : 0) | (pb ? 2 : 0);
-        if (probe == 3) return 3;
+        const int wave_bad = (__ballot(bad & 1) ? 1 : 0) | (__ballot(bad & 2) ? 2 : 0);
+        if ((tid & 63) == 0 && wave_bad) atomicOr(&s_ctl[2], wave_bad);
+        lds_barrier2();
+        probe = s_ctl[2];
+        if (probe == 3) return 3 | 4;
     }
     (void)s_ctl;
     for (int task = tid; task < ngroups * 12; task += kThreads2) {
@@ -278,6 +310,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
     uint32_t *lds_ent = reinterpret_cast<uint32_t *>(lds + p.lds_ent_offset);
     for (int x = threadIdx.x; x < 2 * p.n_entries; x += kThreads2) lds_ent[x] = entries2[x];      // made visible by the first barrier below
     LdsMem2 L{(uint32_t)(uintptr_t)(lds2_i8 *)Lm};
+    const int probe_first = p.q > 1 ? layers[1].first_entry : 0, probe_cnt = p.q > 1 ? layers[1].cnt : 0;   // the parity probe's layer
 
     const int tid = threadIdx.x;
     const int j = tid >> 1, h = tid & 1;
@@ -364,8 +397,11 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             }
             // ---- parity check of both frames (LDPCDecoder::bad)
             T2_PROF2_T(tp0);
-            const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl) : 0;
-            const int bad_a = __syncthreads_or(bad & 1), bad_b = __syncthreads_or(bad & 2);
+            const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl, probe_first, probe_cnt, lds_ent,
+                                                       L.off()) : 0;
+            int bad_a, bad_b;
+            if (bad & 4) { bad_a = bad & 1; bad_b = bad & 2; }       // uniform: the probe's verdict, already the workgroup's
+            else { bad_a = __syncthreads_or(bad & 1); bad_b = __syncthreads_or(bad & 2); }
             const int clean = (have_a && !bad_a ? 1 : 0) + (have_b && !bad_b ? 1 : 0);
             int all_ok = clean == nhave;
             T2_PROF2_ADD(0, tp0);
