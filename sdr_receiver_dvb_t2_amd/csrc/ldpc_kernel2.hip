@@ -143,11 +143,39 @@ __device__ __forceinline__ void finish_group2(uint32_t *S, int g)
 // LDS copy of the table entries, lds_base: the LDS address of the LLR array they were made for.
 __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA, uint32_t *SB, const LdpcLayerDev *__restrict__ layers,
                                                  const uint32_t *__restrict__ entries, int n, int k, int q, int tid, int *s_ctl,
-                                                 int probe_first, int probe_cnt, const uint32_t *lds_ent, int lds_base)
+                                                 int probe_first, int probe_cnt, const uint32_t *lds_ent, int lds_base, int trial)
 {
     const int ngroups = n / 360, gp0 = k / 360;
     uint32_t zero = 0;
     int probe = 0;
+    // Before the probe, its first 32 checks alone (nodes 0..31 of layer 1): one lane per (group, node) reads the LLR pair that node
+    // sees in that group, a wavefront ballot IS the 32-bit sign window of two groups, the windows are XOR-ed into one LDS word per
+    // frame -- one LDS read per lane and one barrier. A frame pair that is still far from a codeword fails here in both frames and
+    // is done; only otherwise the probe proper (three barriers) and the full check run. Two accumulator pairs, used alternately:
+    // the one for the next sweep is cleared behind this sweep's barrier.
+    if (q > 1 && probe_cnt + 2 <= kThreads2 / 32) {
+        const uint32_t *ent = lds_ent + 2 * probe_first;
+        int *acc = s_ctl + 4 + 2 * (trial & 1);
+        const int gi = tid >> 5, i = tid & 31;
+        uint32_t v = 0;
+        if (gi < probe_cnt + 2) {
+            int sh = 0;
+            const int g = gi < probe_cnt ? ent_group_lds(ent, lds_base, gi, &sh) : gp0 + (gi - probe_cnt);
+            int b = (sh ? 360 - sh : 0) + i;                         // node i sees bit (i - shift) mod 360 of the group
+            b -= b >= 360 ? 360 : 0;
+            v = *reinterpret_cast<const uint16_t *>(Lm + 2 * (360 * g + b));
+        }
+        const unsigned long long ba = __ballot(v & 0x0080u), bb = __ballot(v & 0x8000u);
+        if ((tid & 63) == 0) {
+            const uint32_t wa = (uint32_t)ba ^ (uint32_t)(ba >> 32), wb = (uint32_t)bb ^ (uint32_t)(bb >> 32);
+            if (wa) atomicXor(reinterpret_cast<unsigned *>(acc), wa);
+            if (wb) atomicXor(reinterpret_cast<unsigned *>(acc) + 1, wb);
+        }
+        lds_barrier2();
+        const int fail_a = acc[0] != 0, fail_b = acc[1] != 0;
+        if (tid == 0) { s_ctl[4 + 2 * ((trial + 1) & 1)] = 0; s_ctl[5 + 2 * ((trial + 1) & 1)] = 0; }
+        if (fail_a && fail_b) return 3 | 4;
+    }
     // Probe (ldpc_kernel.hip): the 360 checks of layer 1 need the sign words of ~14 groups only, and a frame that has not converged
     // almost always fails there. When BOTH frames fail the probe the workgroup is done; otherwise the full check runs for both.
     // The probe runs once per sweep for every frame pair that is still decoding: it reads nothing from memory (table entries from
@@ -379,6 +407,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             uint4 *st4 = reinterpret_cast<uint4 *>(state);
             for (int x = tid; x < p.q * 720 * RW / 4; x += kThreads2) st4[x] = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (tid < 4) s_ctl[4 + tid] = 0;                 // the parity check's 32-check accumulators
         __syncthreads();
 
         int trials = p.max_trials;
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             // ---- parity check of both frames (LDPCDecoder::bad)
             T2_PROF2_T(tp0);
             const int bad = have_a ? frames_parity_bad(Lm, SA, SB, layers, entries, p.n, p.k, p.q, tid, s_ctl, probe_first, probe_cnt, lds_ent,
-                                                       L.off()) : 0;
+                                                       L.off(), t) : 0;
             int bad_a, bad_b;
             if (bad & 4) { bad_a = bad & 1; bad_b = bad & 2; }       // uniform: the probe's verdict, already the workgroup's
             else { bad_a = __syncthreads_or(bad & 1); bad_b = __syncthreads_or(bad & 2); }
