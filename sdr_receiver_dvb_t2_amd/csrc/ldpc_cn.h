@@ -293,6 +293,7 @@ struct LayerDesc {
                                       // add / shift / mask per link that unpacking costs every wavefront in every layer
     int ent_lds = 0;                  // pair-lane kernel: LDS address of a copy of those pairs (ldpc_cn2.h)
     int pair_flag_lds = 0;            // two-frame kernel, PAIR layers: LDS address of the per-node ready flags [360][2 frames] (ldpc_cn3.h)
+    int no_close = 0;                 // two-frame kernel: the layer ends without the workgroup barrier (ldpc_graph.h)
     int band = 0, band_prefetch = 0;  // two-frame kernel: band walk of a GENERIC layer (ldpc_graph.h), with the LDS addresses of its
     int band_rec_lds = 0, band_in_lds = 0;   // per-node records [2][360] x 8 B and of the inputs it leaves behind [2][360] x 4 B
 };

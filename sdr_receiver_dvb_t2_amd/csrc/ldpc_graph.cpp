@@ -130,6 +130,28 @@ bool ldpc_build_graph(int code_id, LdpcGraph &g)
         else if (L.kind == T2_LAYER_GENERIC) g.serial_steps += lmax;
         g.links_total += GROUP * (L.cnt + 2) - (i == 0 ? 1 : 0);
     }
+    // closing barriers the two-frame kernel may leave out (LdpcLayer::no_close)
+    {
+        auto groups_of = [&](int i) {
+            std::vector<int> v;
+            for (int c = 0; c < g.layers[i].cnt; ++c) v.push_back((int)(g.entries[g.layers[i].first_entry + c] & 0xffffu) / GROUP);
+            return v;
+        };
+        auto simple = [&](int i) { return g.layers[i].kind == T2_LAYER_PLAIN || g.layers[i].kind == T2_LAYER_PAIR; };
+        std::vector<int> open = groups_of(0);
+        bool open_pair = g.layers[0].kind == T2_LAYER_PAIR;
+        for (int i = 0; i + 1 < g.q; ++i) {
+            const std::vector<int> nxt = groups_of(i + 1);
+            const bool next_pair = g.layers[i + 1].kind == T2_LAYER_PAIR;
+            bool ok = simple(i) && simple(i + 1) && !(next_pair && open_pair);
+            for (int a : nxt)
+                for (int b : open) ok = ok && a != b;
+            g.layers[i].no_close = ok ? 1 : 0;
+            if (ok && !next_pair) { open.insert(open.end(), nxt.begin(), nxt.end()); }
+            else { open = nxt; open_pair = false; }               // a closing barrier, or the next layer's inner one, closes all before
+            open_pair = open_pair || next_pair;
+        }
+    }
     return true;
 }
 

@@ -30,6 +30,11 @@ struct LdpcLayer {
     // (through slot 0 of j, slot 1 of j + D). band_prefetch: every other dependency reaches back two bands or more. 0 = not eligible
     // (more than four conflict slots, or D > 32: those layers are few-level ones and keep the level schedule).
     int band = 0, band_prefetch = 0;
+    // The two-frame kernel may run on into the next layer without the workgroup barrier that closes this one: both layers are PLAIN or
+    // PAIR (node j on the same lane pair in both, so the parity bits they share go through one wavefront's in-order LDS), not both
+    // PAIR (they would share the chain-record scratch), and the next layer's information-bit groups are disjoint from those of
+    // every layer still open since the last barrier (a PAIR layer's inner barrier closes everything before it).
+    int no_close = 0;
 };
 
 struct LdpcGraph {

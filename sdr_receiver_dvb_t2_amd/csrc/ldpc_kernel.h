@@ -11,7 +11,7 @@
 namespace t2gpu {
 
 struct LdpcLayerDev {
-    int first_entry, cnt, lmax, nc, kind, step, band, band_prefetch;   // band: GENERIC layers the two-frame kernel walks in bands (ldpc_graph.h)
+    int first_entry, cnt, lmax, nc, kind, step, band, band_prefetch;   // band_prefetch bit 1: no closing barrier (ldpc_graph.h: no_close);   // band: GENERIC layers the two-frame kernel walks in bands (ldpc_graph.h)
 };
 
 struct LdpcKernelParams {

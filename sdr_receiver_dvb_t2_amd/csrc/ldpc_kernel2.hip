@@ -283,7 +283,7 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, co
         __builtin_amdgcn_s_setprio(0);
         if (active) p2_generic_finish<CNT>(L, d, r);
     }
-    lds_barrier2();
+    if (!d.no_close) lds_barrier2();
 }
 
 // one layer for a compile-time link count: record in, update, record out. RW = record dwords per lane in memory (>= P2Regs::W).
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                     const LdpcLayerDev ly = layers[i];
                     LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
                                 entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
-                    d.band = (ly.nc <= NCMAX && ly.nc <= ly.cnt) ? ly.band : 0; d.band_prefetch = ly.band_prefetch;
+                    d.band = (ly.nc <= NCMAX && ly.nc <= ly.cnt) ? ly.band : 0; d.band_prefetch = ly.band_prefetch & 1; d.no_close = ly.band_prefetch >> 1;
                     d.band_rec_lds = L.off() + p.lds_sign_offset; d.band_in_lds = L.off() + p.lds_rec_offset;
                     d.pair_flag_lds = L.off() + p.lds_sign_offset;
                     const uint32_t info = info_nxt;

@@ -107,9 +107,12 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     std::vector<LdpcLayerDev> ld(h->g.q);
     const char *band_env = std::getenv("T2GPU_LDPC_BAND");                     // experiments: 0 keeps the level schedule in GENERIC layers
     const bool band_on = !(band_env && std::atoi(band_env) == 0);
+    const char *open_env = std::getenv("T2GPU_LDPC_OPEN_LAYERS");           // experiments: 0 closes every layer with a barrier
+    const bool open_on = !(open_env && std::atoi(open_env) == 0);
     for (int i = 0; i < h->g.q; ++i)
         ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict,
-                             h->g.layers[i].kind, h->g.layers[i].step, band_on ? h->g.layers[i].band : 0, h->g.layers[i].band_prefetch};
+                             h->g.layers[i].kind, h->g.layers[i].step, band_on ? h->g.layers[i].band : 0,
+                             h->g.layers[i].band_prefetch | (open_on ? h->g.layers[i].no_close << 1 : 0)};
     if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_entries, h->g.entries.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);

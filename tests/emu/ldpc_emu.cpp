@@ -181,3 +181,35 @@ extern "C" int emu_ldpc_band_check(int code_id, int *n_band)
     }
     return 0;
 }
+
+// Independent check of LdpcLayer::no_close (closing barriers the two-frame kernel leaves out): walking the layers, every layer that
+// starts while earlier ones are still open (no barrier since) must be PLAIN or PAIR like them, share no information-bit group with
+// any of them, and not be a second PAIR layer among them; a PAIR layer's inner barrier closes all layers before it. Returns 0 or
+// 100 * layer + rule; *n_open = number of barriers left out.
+extern "C" int emu_ldpc_open_check(int code_id, int *n_open)
+{
+    LdpcGraph g;
+    if (!ldpc_build_graph(code_id, g)) return -1;
+    *n_open = 0;
+    std::vector<int> open;                                      // layers not yet closed by a barrier
+    for (int i = 0; i < g.q; ++i) {
+        const LdpcLayer &L = g.layers[i];
+        const bool simple = L.kind == T2_LAYER_PLAIN || L.kind == T2_LAYER_PAIR;
+        if (!open.empty()) {
+            if (!simple) return 100 * i + 1;
+            for (int o : open) {
+                const LdpcLayer &O = g.layers[o];
+                if (!(O.kind == T2_LAYER_PLAIN || O.kind == T2_LAYER_PAIR)) return 100 * i + 1;
+                if (O.kind == T2_LAYER_PAIR && L.kind == T2_LAYER_PAIR) return 100 * i + 2;
+                for (int a = 0; a < L.cnt; ++a)
+                    for (int b = 0; b < O.cnt; ++b)
+                        if ((g.entries[L.first_entry + a] & 0xffffu) / 360 == (g.entries[O.first_entry + b] & 0xffffu) / 360) return 100 * i + 3;
+            }
+        }
+        if (L.kind == T2_LAYER_PAIR) open.clear();               // its inner barrier
+        if (i + 1 == g.q && L.no_close) return 100 * i + 4;      // the last layer always closes
+        if (L.no_close) { open.push_back(i); ++*n_open; }
+        else open.clear();
+    }
+    return 0;
+}

@@ -89,3 +89,16 @@ def test_band_walk_description_of_generic_layers(code_id):
     assert emu.emu_ldpc_band_check(code_id, ctypes.byref(n)) == 0
     if code_id == 9:
         assert n.value == 2
+
+
+@pytest.mark.parametrize("code_id", range(12))
+def test_layers_left_open_share_nothing(code_id):
+    """ldpc_graph.cpp marks layers the two-frame kernel does not close with a workgroup barrier (no_close). tests/emu re-derives the
+    condition by brute force: whatever runs without a barrier in between is PLAIN / PAIR, shares no information-bit group and holds
+    at most one PAIR layer. N 3/4 must have some (11 of its 44 inner transitions are eligible)."""
+    import ctypes
+    emu = ol.emu()
+    n = ctypes.c_int(0)
+    assert emu.emu_ldpc_open_check(code_id, ctypes.byref(n)) == 0
+    if code_id == 9:
+        assert n.value >= 8
