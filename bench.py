@@ -32,10 +32,10 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/
 # bench's launch of 7676 frames x 25 sweeps of ldpc_decode2_kernel<12,12,4>): 2 x FETCH_SIZE (gfx950 half-count correction,
 # MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes. It is the per-link message bytes of the two-frame kernel (one byte per link and
 # frame, 16 B per lane and layer, read and written once per sweep) streaming through L2 / Infinity Cache.
-LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 2.4553e7 + 5.0848e7) * 1024 / 7676 / 25
+LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 2.4553e7 + 5.0817e7) * 1024 / 7676 / 25
 # SQ_INSTS_VALU of the same launch; a wave instruction occupies a SIMD for 4 cycles, 4 SIMDs x 256 CUs, 2.4 GHz (GRBM_GUI_ACTIVE of the
 # launch / its duration = 2.39 GHz per XCD)
-LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.6245e10 / 7676 / 25
+LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.6021e10 / 7676 / 25
 VALU_ISSUE_SLOTS_PER_S = 4 * 256 * 2.4e9 / 4
 
 # BASELINE.json configs that run on one GPU. mode = (fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data),
