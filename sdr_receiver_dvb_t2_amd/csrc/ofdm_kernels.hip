@@ -60,11 +60,12 @@ __device__ __forceinline__ cf cpow_bits(const cf (&pw)[5])
     if constexpr ((K & (K - 1)) == 0) return pw[idx];
     else return cmul(cpow_bits<(K & (K - 1))>(pw), pw[idx]);
 }
-// pw[b] = W_N^(m 2^b), each read from the table (squaring the first would double its angle error every time)
-__device__ __forceinline__ void cpow_table(const float2 *__restrict__ twiddle, int m, int mask, cf (&pw)[5])
+// pw[b] = W_N^(m 2^b), each a table value (squaring the first would double its angle error every time), from five planes laid out
+// so that a wavefront's lanes read consecutive entries (t2gpu_ofdm.cpp)
+__device__ __forceinline__ void cpow_table(const float2 *__restrict__ planes, int plane_len, int lane_index, cf (&pw)[5])
 {
 #pragma unroll
-    for (int b = 0; b < 5; ++b) { const float2 w = twiddle[(m << b) & mask]; pw[b] = cf{w.x, w.y}; }
+    for (int b = 0; b < 5; ++b) { const float2 w = planes[b * plane_len + lane_index]; pw[b] = cf{w.x, w.y}; }
 }
 template <int R, int I = 1>
 __device__ __forceinline__ void twiddle_powers(cf (&v)[32], const cf (&pw)[5]);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
         fft_reg<32>(v);
         {                                                    // twiddle W_N^(t*k1), k1 = bitrev(r): powers of W_N^t
             cf pw[5];
-            cpow_table(twiddle, tid, N - 1, pw);
+            cpow_table(twiddle + N, T, tid, pw);
             twiddle_powers<32>(v, pw);
         }
         // ---- exchange 1: thread (k1, t1) := id k1*T2 + t1 collects y_k1[t1 + T2*t2], t2 = 0..31
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
         fft_reg<32>(u);
         {                                                    // powers of W_N^(32*t1)
             cf pw[5];
-            cpow_table(twiddle, 32 * t1n, N - 1, pw);
+            cpow_table(twiddle + N + 5 * T, T2, t1n, pw);
             twiddle_powers<32>(u, pw);
         }
         // ---- exchange 2: rows (q1, k1) of T2 values over t1, pitch 33. New thread id' -> pairs (q1, k1) with k1 fastest:

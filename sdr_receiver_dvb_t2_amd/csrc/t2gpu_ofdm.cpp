@@ -125,10 +125,18 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
     const int N = m.fft_size, K = m.k_total;
     // FFT twiddles W_N^m in double, stored as float
-    std::vector<float2> tw(N);
-    for (int i = 0; i < N; ++i) {
-        const double a = -2.0 * M_PI * (double)i / (double)N;
-        tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    // then, for the kernel's stage twiddles (powers of W^t, ofdm_kernels.hip: cpow_table): W^(t 2^b) for the T = N / 32 lanes, five
+    // planes of T (a wavefront reads 64 consecutive entries), and W^(32 t1 2^b) for t1 < T / 32, five planes
+    const int T = N / 32, T2 = T / 32;
+    std::vector<float2> tw(N + 5 * T + 5 * T2);
+    auto wn = [&](long m) {
+        const double a = -2.0 * M_PI * (double)(m % N) / (double)N;
+        return make_float2((float)std::cos(a), (float)std::sin(a));
+    };
+    for (int i = 0; i < N; ++i) tw[i] = wn(i);
+    for (int b = 0; b < 5; ++b) {
+        for (int t = 0; t < T; ++t) tw[N + b * T + t] = wn((long)t << b);
+        for (int t1 = 0; t1 < T2; ++t1) tw[N + 5 * T + b * T2 + t1] = wn((long)(32 * t1) << b);
     }
     // LUT of DSP/fast_math.h:27-42 as the reference binary fills it (-Ofast: i * (1/k) in float, one sincosf)
     std::vector<float2> lut(65536, make_float2(0.0f, 0.0f));                   // (cos, sin)
