@@ -59,18 +59,22 @@ __device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[
     return compose(pre, ex);
 }
 
-__device__ __forceinline__ void load4(const FrontParams &p, long s0, float xr[4], float xi[4], int &valid)
+// a lane's FRONT_PER consecutive samples (four at a time as two 8-byte reads where the layout allows)
+__device__ __forceinline__ void load_samples(const FrontParams &p, long s0, float (&xr)[FRONT_PER], float (&xi)[FRONT_PER], int &valid)
 {
-    valid = (int)min(4L, max(0L, (long)p.n - s0));
-    if (p.stride == 1 && valid == 4 && ((((uintptr_t)p.i_in | (uintptr_t)p.q_in) & 7) == 0)) {
-        const short4 vi = *reinterpret_cast<const short4 *>(p.i_in + s0);
-        const short4 vq = *reinterpret_cast<const short4 *>(p.q_in + s0);
-        xr[0] = (float)vi.x * p.short_to_float; xr[1] = (float)vi.y * p.short_to_float;
-        xr[2] = (float)vi.z * p.short_to_float; xr[3] = (float)vi.w * p.short_to_float;
-        xi[0] = (float)vq.x * p.short_to_float; xi[1] = (float)vq.y * p.short_to_float;
-        xi[2] = (float)vq.z * p.short_to_float; xi[3] = (float)vq.w * p.short_to_float;
+    valid = (int)min((long)FRONT_PER, max(0L, (long)p.n - s0));
+    if (p.stride == 1 && valid == FRONT_PER && ((((uintptr_t)p.i_in | (uintptr_t)p.q_in) & 7) == 0)) {
+#pragma unroll
+        for (int g = 0; g < FRONT_PER / 4; ++g) {
+            const short4 vi = *reinterpret_cast<const short4 *>(p.i_in + s0 + 4 * g);
+            const short4 vq = *reinterpret_cast<const short4 *>(p.q_in + s0 + 4 * g);
+            xr[4 * g] = (float)vi.x * p.short_to_float; xr[4 * g + 1] = (float)vi.y * p.short_to_float;
+            xr[4 * g + 2] = (float)vi.z * p.short_to_float; xr[4 * g + 3] = (float)vi.w * p.short_to_float;
+            xi[4 * g] = (float)vq.x * p.short_to_float; xi[4 * g + 1] = (float)vq.y * p.short_to_float;
+            xi[4 * g + 2] = (float)vq.z * p.short_to_float; xi[4 * g + 3] = (float)vq.w * p.short_to_float;
+        }
     } else {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < FRONT_PER; ++k) {
             const long j = (s0 + k) * p.stride;                                  // dvbt2_demodulator.cpp:176-178
             xr[k] = k < valid ? (float)p.i_in[j] * p.short_to_float : 0.0f;
             xi[k] = k < valid ? (float)p.q_in[j] * p.short_to_float : 0.0f;
@@ -78,10 +82,10 @@ __device__ __forceinline__ void load4(const FrontParams &p, long s0, float xr[4]
     }
 }
 
-__device__ __forceinline__ Lin thread_lin(const float xr[4], const float xi[4], int valid)
+__device__ __forceinline__ Lin thread_lin(const float (&xr)[FRONT_PER], const float (&xi)[FRONT_PER], int valid)
 {
     Lin l{1.0, 0.0, 0.0};
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < FRONT_PER; ++k)
         if (k < valid) { l.a *= (1.0 - DC_ALPHA); l.re = (1.0 - DC_ALPHA) * l.re + DC_ALPHA * (double)xr[k]; l.im = (1.0 - DC_ALPHA) * l.im + DC_ALPHA * (double)xi[k]; }
     return l;
 }
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
 {
     __shared__ Lin sh[256];
     const int tid = threadIdx.x;
-    float xr[4], xi[4]; int valid;
-    load4(p, (long)blockIdx.x * FRONT_BLOCK + tid * 4, xr, xi, valid);
+    float xr[FRONT_PER], xi[FRONT_PER]; int valid;
+    load_samples(p, (long)blockIdx.x * FRONT_BLOCK + tid * FRONT_PER, xr, xi, valid);
     sh[tid] = thread_lin(xr, xi, valid);
     __syncthreads();
     for (int s = 1; s < 256; s <<= 1) {
@@ -172,10 +176,14 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
 {
     __shared__ Lin wave_tot[4];
     __shared__ double red[3][4];
+    // a lane's FRONT_PER results are FRONT_PER x 8 bytes apart from its neighbour's: stored from the lanes they were 32 lines per
+    // store instruction (the kernel doubled its time at 8 samples per lane); through LDS (rows padded by one cell) they leave as
+    // whole 512-byte runs per wavefront
+    __shared__ float2 sh_out[256 * (FRONT_PER + 1)];
     const int tid = threadIdx.x;
-    const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * 4;
-    float xr[4], xi[4]; int valid;
-    load4(p, s0, xr, xi, valid);
+    const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * FRONT_PER;
+    float xr[FRONT_PER], xi[FRONT_PER]; int valid;
+    load_samples(p, s0, xr, xi, valid);
     const double *start = p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks));
     const Lin ex = block_scan_exclusive(thread_lin(xr, xi, valid), wave_tot, nullptr);
     double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
         const float off = wrap_2pi(sub_r(fnco, run.aux));                       // :194-200
         const int li = (int)(off * K_TABLE + 32767) & 65535;                    // fast_math.h:47-58
         const float nr = p.lut_cos[li], ni = p.lut_sin[li];
-        p.derot[3 + i] = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
+        sh_out[tid * (FRONT_PER + 1) + k] = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { t1 += __shfl_down(t1, d, 64); t2 += __shfl_down(t2, d, 64); t3 += __shfl_down(t3, d, 64); }
@@ -209,6 +217,12 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
     if (tid == 0) {
         double *o = p.theta_part + 4 * (long)blockIdx.x;
         for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    }
+    const long b0 = (long)blockIdx.x * FRONT_BLOCK;
+#pragma unroll
+    for (int g = 0; g < FRONT_PER; ++g) {
+        const int e = g * 256 + tid;
+        if (b0 + e < p.n) p.derot[3 + b0 + e] = sh_out[(e / FRONT_PER) * (FRONT_PER + 1) + e % FRONT_PER];
     }
 }
 
