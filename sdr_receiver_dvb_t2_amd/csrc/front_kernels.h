@@ -5,7 +5,7 @@
 #include <cstdint>
 #include "front_plan.h"
 
-constexpr int FRONT_BLOCK = 2048;          // input samples per workgroup in the dc / de-rotation kernels (256 lanes x FRONT_PER)
+constexpr int FRONT_BLOCK = 4096;          // input samples per workgroup in the dc / de-rotation kernels (256 lanes x FRONT_PER)
 constexpr int FRONT_PER = FRONT_BLOCK / 256;
 constexpr int FRONT_RUN_STRIDE = 256;      // one entry of the run-index arrays per this many input samples
 
