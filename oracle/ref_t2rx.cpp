@@ -212,6 +212,19 @@ void ref_fec_cells(void *hv, int len, const float *cells)
     std::memcpy(h->cells.data(), cells, sizeof(complex) * len);
     h->ti->execute(len, h->cells.data());
 }
+/* the LDPC stage's public slot by itself: ldpc_decoder::execute(idx_plp_simd, l1_post, len_in = fec_size * 32, int8 LLRs)
+ * (ldpc_decoder.h:90, .cpp:157-301) on the decoder object of this chain -- its bit_bch signal then drives bch_decoder and
+ * bb_de_header exactly as when the demapper is the caller (taps 2, 3, 5 and the TS file). This is how 256-QAM payload bits get a
+ * reference-built pin although the reference's own demapper never produces a decodable 256-QAM batch. */
+void ref_fec_ldpc_execute(void *hv, const int *l1_post, const int *idx_plp_simd, int len, const int8_t *llr)
+{
+    ref_fec *h = static_cast<ref_fec *>(hv);
+    h->l1.set(l1_post);
+    int plp[SIZEOF_SIMD];
+    std::memcpy(plp, idx_plp_simd, sizeof plp);
+    std::vector<int8_t> in(llr, llr + len);
+    h->ti->qam->decoder->execute(plp, h->l1.post, len, in.data());
+}
 int ref_fec_tap(void *hv, int which, int *meta, void *out, int cap) { return tap_get(static_cast<ref_fec *>(hv)->t, which, meta, out, cap); }
 void ref_fec_close(void *hv) { close_ts_file(static_cast<ref_fec *>(hv)->ti->qam->decoder->decoder->deheader); }
 

@@ -135,6 +135,58 @@ def case_fec(name):
     return out
 
 
+def case_ldpc_in(name):
+    """The reference's LDPC stage driven through its public slot ldpc_decoder::execute (ldpc_decoder.h:90) with clamped 256-QAM
+    LLRs, SIMD batch after SIMD batch; bch_decoder and bb_de_header follow through the reference's own signal connections."""
+    llr, frames, ts, l1 = rc.ldpc_in_case(name)
+    mod, fec_type, code_rate, nb, snr, seed = rc.LDPC_IN_CASES[name]
+    cid = ol.code_id(fec_type, code_rate)
+    tmp = tempfile.mkdtemp()
+    r = ol.RefFec(os.path.join(tmp, "ref.ts"), 0)
+    for b in range(nb // 32):
+        r.ldpc_execute(l1, llr[32 * b:32 * b + 32])
+    ld, bb, msg = r.taps(2), r.taps(3), r.taps(5)
+    ts_out = r.ts()
+    k = ol.ldpc_params(cid)[1]
+    B = np.concatenate([x[1] for x in ld]).reshape(-1, k)
+    D = np.stack([x[1] for x in bb])
+    pk = ts_out[:ts_out.size // 188 * 188].reshape(-1, 188)
+    return {"in_sha": np.array(rc.sha(llr)), "llr_first": llr[0].copy(), "saturated_frac": np.float32((np.abs(llr.astype(np.int32)) >= 127).mean()),
+            "ldpc_batches": np.int32(len(ld)), "ldpc_crc": rc.crc_rows(B), "ldpc_first": np.packbits(B[0]),
+            "bb_count": np.int32(len(bb)), "bb_crc": rc.crc_rows(D), "bb_first": np.packbits(D[0]),
+            "sent_bbframes_crc": rc.crc_rows(frames), "ts_len": np.int64(ts_out.size), "ts_packet_crc": rc.crc_rows(pk),
+            "ts_head": ts_out[:188 * 4].copy(), "ts_tail": ts_out[-188 * 2:].copy(),
+            "messages": np.array([bytes(b).decode() for _, b in msg])}
+
+
+def case_carry(name):
+    """The reference's FEC chain (time_deinterleaver -> ... -> bb_de_header) over several T2 frames whose FEC block count is not a
+    multiple of 32: what it has emitted after every frame shows the SIMD batches straddling the frames (llr_demapper.cpp:742-764)."""
+    cells, sent, l1 = rc.carry_case(name)
+    c, mod, fec_type, code_rate, n, cpf, cid = rc.carry_geometry(name)
+    tmp = tempfile.mkdtemp()
+    r = ol.RefFec(os.path.join(tmp, "ref.ts"), 0)
+    r.keep(0, False)
+    r.start(c["lps"], l1)
+    after, llr, ld, bb = [], [], [], []
+    for q in cells:
+        r.frame(l1, np.concatenate([np.zeros(1840 + c["lps"], np.complex64), rc.dequantise(q, rc.GRID_CELL)]))
+        llr += r.taps(1)
+        ld += r.taps(2)
+        bb += r.taps(3)
+        after.append([len(llr), len(ld), len(bb)])
+    ts_out = r.ts()
+    k = ol.ldpc_params(cid)[1]
+    B = np.concatenate([x[1] for x in ld]).reshape(-1, k)
+    D = np.stack([x[1] for x in bb])
+    L = np.concatenate([x[1] for x in llr]).reshape(-1, n)
+    pk = ts_out[:ts_out.size // 188 * 188].reshape(-1, 188)
+    return {"in_sha": np.array(rc.sha(np.stack(cells))), "emitted_after_frame": np.array(after, np.int32), "llr_crc": rc.crc_rows(L),
+            "ldpc_crc": rc.crc_rows(B), "bb_crc": rc.crc_rows(D), "bb_plp": np.array([x[0][1] for x in bb], np.int32),
+            "sent_bbframes_crc": rc.crc_rows(sent), "ts_len": np.int64(ts_out.size), "ts_packet_crc": rc.crc_rows(pk),
+            "ts_head": ts_out[:188 * 4].copy(), "ts": ts_out}
+
+
 def case_bbdh(_):
     """bb_de_header::execute alone on hand-made BBFRAMEs: HEM and NM streams, packets straddling frames, a frame for another
     PLP, a broken header CRC, SYNCD = 0xFFFF, a SYNCD that disagrees with the running packet (both directions)."""
@@ -185,8 +237,10 @@ def case_rx(_):
 
 
 KINDS = {"sym": (case_sym, list(rc.SYM_MODES)), "p1": (case_p1, ["p1"]), "fec": (case_fec, list(rc.FEC_CASES)), "bbdh": (case_bbdh, ["bbdh"]),
+         "ldpc_in": (case_ldpc_in, list(rc.LDPC_IN_CASES)), "carry": (case_carry, list(rc.CARRY_CASES)),
          "front": (case_front, ["front"]), "rx": (case_rx, ["rx"])}
-FILES = {"t2sym_golden.npz": ("sym", "p1"), "t2fec_golden.npz": ("fec", "bbdh"), "t2rx_golden.npz": ("front", "rx")}
+FILES = {"t2sym_golden.npz": ("sym", "p1"), "t2fec_golden.npz": ("fec", "bbdh"), "t2rx_golden.npz": ("front", "rx"),
+         "t2batch_golden.npz": ("ldpc_in", "carry")}
 
 
 def run_case(kind, name, path):

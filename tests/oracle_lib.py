@@ -669,6 +669,7 @@ class RefFec(_Taps):
         L.ref_fec_cells.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.ref_fec_tap.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.ref_fec_close.argtypes = [ctypes.c_void_p]
+        L.ref_fec_ldpc_execute.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self.L, self.ts_path = L, ts_path
         self.h = L.ref_fec_new(ts_path.encode(), need_plp)
 
@@ -682,6 +683,16 @@ class RefFec(_Taps):
     def cells(self, cells):
         c = np.ascontiguousarray(cells, np.complex64)
         self.L.ref_fec_cells(self.h, c.size, c.ctypes.data)
+
+    def keep(self, which, on):
+        self.L.ref_fec_keep(self.h, which, int(on))
+
+    def ldpc_execute(self, l1_post, llr32, plp_simd=None):
+        """ldpc_decoder::execute (the public slot, ldpc_decoder.h:90) on one SIMD batch: int8 [32][fec_size]."""
+        a = np.ascontiguousarray(llr32, np.int8)
+        assert a.shape[0] == 32
+        idx = np.zeros(32, np.int32) if plp_simd is None else np.ascontiguousarray(plp_simd, np.int32)
+        self.L.ref_fec_ldpc_execute(self.h, l1_post.ctypes.data, idx.ctypes.data, a.size, a.ctypes.data)
 
     def taps(self, which):
         dt = {0: np.complex64, 1: np.int8, 2: np.uint8, 3: np.uint8, 5: np.uint8}[which]

@@ -14,6 +14,7 @@ import oracle_lib as ol
 K_BCH = [7032, 9552, 10632, 11712, 12432, 13152, 32208, 38688, 43040, 48408, 51648, 53840]
 ROT = [0.506145483, 0.293215314, 0.150098316, 0.062418810]
 NORM = [0.707106781, 0.316227766, 0.15430335, 0.076696499]
+NORM32 = [np.float32(v) for v in NORM]
 
 
 def crc8_d5(bits):
