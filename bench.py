@@ -6,16 +6,19 @@
 
 Default workload (BASELINE.json config 3, "CFG-A"; --config 5 = the same with r = 2/3, --config 4 = 16K / 64-QAM / 16200 r = 1/2,
 --config 2 = FFT + equalise + de-interleave + demap only): F complete T2 frames per GPU per step -- 8 MHz, 32K extended, GI 1/128, PP7,
-1 P2 + 59 data symbols, one PLP, rotated 256-QAM, LDPC 64800 r=3/4, 202 FEC blocks per frame -- synthetic, built by the
-transmitter model in tests/t2_tx.py (P1 + cyclic prefixes + AWGN), resident in HBM as the int16 I/Q samples a tuner
-delivers at 64/7 Msps (the dvbt2_demodulator::execute boundary) before the clock starts. One step = front end (dc / IQ
-imbalance / NCO / Farrow x2 / 64-tap decimator) -> P1 detection at every frame start -> guard-interval correlation of
-every symbol -> FFT with the guard dropped -> P2/data equaliser + frequency de-interleave -> time/cell de-interleave ->
-demap -> LDPC (reference SIMD-batch rule, 25 trials) -> BB descramble for all F frames, tracking loops open (zeros and
-the nominal resample). Rank 0 prints ONE JSON line: `value` = input IQ samples per second; `roofline` is for the dominant
-kernel (LDPC) from HIP events around its launches inside the timed region, `roofline.kernels` has every stage (algorithmic HBM
-bytes / measured stage time); `cpu_baseline` times the same chain on ALL host cores (one process per core: oracle restatement +
-the reference's own LDPC where oracle/_ref is loadable) on one frame each, and names the CPU.
+1 P2 + 59 data symbols, real L1-pre / L1-post signalling in every P2 symbol, one PLP, rotated 256-QAM, LDPC 64800 r=3/4, 202 FEC
+blocks per frame -- synthetic, built by the transmitter model in tests/t2_tx.py (P1 + cyclic prefixes + AWGN), resident in HBM as the
+int16 I/Q samples a tuner delivers at 64/7 Msps (the dvbt2_demodulator::execute boundary) before the clock starts. One step = front
+end (dc / IQ imbalance / NCO / Farrow x2 / 64-tap decimator) -> P1 detection at every frame start -> guard-interval correlation of
+every symbol -> FFT with the guard dropped -> P2/data equaliser + frequency de-interleave -> time/cell de-interleave -> demap -> LDPC
+(reference SIMD-batch rule: batches of 32 formed across frames, 25 trials) -> BB descramble + bit packing -> [host worker of the library,
+overlapped with the next step: L1-pre / L1-post parse + CRC-32 of every frame, batch drop rule, BBFRAME de-framing -> TS] for all F
+frames, tracking loops open (zeros and the nominal resample). F is a multiple of the frame alignment (16 for CFG-A: 16 x 202 FEC blocks
+= 101 batches of 32), so no step ends inside a SIMD batch. The clock stops when the TS bytes of the last step are on the host.
+Rank 0 prints ONE JSON line: `value` = input IQ samples per second; `roofline` is for the dominant kernel (LDPC) from HIP events around
+its launches inside the timed region, `roofline.kernels` has every stage (algorithmic HBM bytes of SURVEY.md 8d / measured stage
+time); `cpu_baseline` times the same chain on ALL host cores (one process per core: oracle restatement + the reference's own LDPC where
+oracle/_ref is loadable) on one frame each, and names the CPU.
 """
 import argparse
 import json
@@ -28,28 +31,25 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# memory-side traffic per FEC frame and sweep from the committed PMC passes (profiles/r02_rx_pmc.txt, tools/pmc_passes.sh: this
-# bench's launch of 7676 frames x 25 sweeps of ldpc_decode2_kernel<12,12,4>): 2 x FETCH_SIZE (gfx950 half-count correction,
-# MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes. It is the per-link message bytes of the two-frame kernel (one byte per link and
-# frame, 16 B per lane and layer, read and written once per sweep) streaming through L2 / Infinity Cache.
-LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP = (2 * 2.4553e7 + 5.0817e7) * 1024 / 7676 / 25
-# SQ_INSTS_VALU of the same launch; a wave instruction occupies a SIMD for 4 cycles, 4 SIMDs x 256 CUs, 2.4 GHz (GRBM_GUI_ACTIVE of the
-# launch / its duration = 2.39 GHz per XCD)
-LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP = 1.6021e10 / 7676 / 25
-VALU_ISSUE_SLOTS_PER_S = 4 * 256 * 2.4e9 / 4
+CLOCK_HZ = 2.4e9                            # MI355X_MICROARCH.md; GRBM_GUI_ACTIVE of the LDPC launch / its duration = 2.39 GHz
+# Hardware counters of the dominant kernel come from the committed PMC passes of THIS workload (tools/pmc_passes.sh -> tools/pmc_summary.py ->
+# profiles/ldpc_counters.json: per-launch averages of ldpc_decode2_kernel, separate --pmc runs as MI355X_MICROARCH.md prescribes) and are scaled
+# by frames x sweeps; the launch duration they are divided by is measured live in this run.
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "ldpc_counters.json")
+LDPC_LINKS = {(1, 3): 226799, (1, 2): 215999, (0, 0): 48599}       # edges per frame of the benchmarked codes (t2gpu_ldpc_graph_stats)
 
 # BASELINE.json configs that run on one GPU. mode = (fft_mode, carrier_mode, pilot_pattern, guard_interval_mode, papr_mode, n_data),
-# plp = (modulation, fec_type, code_rate, rotation); frames = T2 frames per GPU per step (chosen so that the FEC frames fill whole
-# rounds of the decoder's 16 resident SIMD-batch slots: 38 x 202 = 7676 frames = 240 batches = 15 rounds; with 16 frames the 101
-# batches took 7 rounds for 6.3 rounds of work)
+# plp = (modulation, fec_type, code_rate, rotation); frames = T2 frames per GPU per step: a multiple of the frame alignment (no step
+# ends inside a SIMD batch) that fills whole rounds of the decoder's 16 resident batch slots: 48 x 202 = 9696 FEC frames = 303 batches
+# = 18.9 rounds (38 frames in round 2 were 239 batches + a 28-frame tail the reference would never form)
 CONFIGS = {
-    2: dict(name="config 2 (CFG-A, FFT + equalise + de-interleave + demap only)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 3, 1), frames=38, s2=10,
+    2: dict(name="config 2 (CFG-A, FFT + equalise + de-interleave + demap only)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 3, 1), frames=48, s2=10,
             metric="IQ Msamples/s through FFT + equaliser + demap (32K, 256-QAM)"),
-    3: dict(name="config 3 (CFG-A)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 3, 1), frames=38, s2=10,
+    3: dict(name="config 3 (CFG-A)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 3, 1), frames=48, s2=10,
             metric="IQ Msamples/s demod->TS (32K, 256-QAM, LDPC 64800 r=3/4)"),
-    4: dict(name="config 4 (CFG-B)", mode=(4, 1, 6, 4, 0, 40), lps=200, plp=(2, 0, 0, 1), frames=40, s2=8,
+    4: dict(name="config 4 (CFG-B)", mode=(4, 1, 6, 4, 0, 40), lps=200, plp=(2, 0, 0, 1), frames=64, s2=8,
             metric="IQ Msamples/s demod->TS (16K, 64-QAM, LDPC 16200 r=1/2)"),
-    5: dict(name="config 5 (CFG-C)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 2, 1), frames=38, s2=10,
+    5: dict(name="config 5 (CFG-C)", mode=(5, 1, 6, 4, 0, 59), lps=350, plp=(3, 1, 2, 1), frames=48, s2=10,
             metric="IQ Msamples/s demod->TS (32K, 256-QAM, LDPC 64800 r=2/3)"),
 }
 K_LDPC = {0: (7200, 9720, 10800, 11880, 12600, 13320), 1: (32400, 38880, 43200, 48600, 51840, 54000)}
@@ -57,49 +57,55 @@ K_BCH = {0: (7032, 9552, 10632, 11712, 12432, 13152), 1: (32208, 38688, 43040, 4
 
 
 class Workload(object):
+    """Geometry of a config from the PRODUCT's own mode tables (t2gpu_ofdm_mode_info; host only, no GPU needed)."""
+
     def __init__(self, cfg):
-        import oracle_lib as ol
-        import t2_tx
+        import ctypes
+        import sdr_receiver_dvb_t2_amd as pkg
         self.cfg, self.mode, self.lps, self.plp = cfg, cfg["mode"], cfg["lps"], cfg["plp"]
-        self.m = ol.ora_mode(*self.mode)
-        m = self.m
-        self.guard = {0: m.fft_size // 32, 1: m.fft_size // 16, 2: m.fft_size // 8, 3: m.fft_size // 4, 4: m.fft_size // 128}[self.mode[3]]
-        self.sym = m.fft_size + self.guard
-        self.frame_samples = 2048 + m.len_frame * self.sym
+        info = (ctypes.c_int * 12)()
+        assert pkg.lib().t2gpu_ofdm_mode_info(*self.mode, info) == 0
+        (self.fft_size, self.k_total, _, _, _, self.c_p2, self.c_data, self.n_fc, _, self.l_fc, self.len_frame, self.guard) = (int(v) for v in info)
+        self.n_data = self.mode[5]
+        self.sym = self.fft_size + self.guard
+        self.frame_samples = 2048 + self.len_frame * self.sym
         self.fec_size = 64800 if self.plp[1] else 16200
         self.bpc = 2 * (self.plp[0] + 1)
         self.cpf = self.fec_size // self.bpc
-        self.cid = ol.code_id(self.plp[1], self.plp[2])
-        self.nb = t2_tx.plp_blocks_per_frame(m, self.lps, self.cpf)
-        self.frame_cells = (m.c_p2 - 1840 - self.lps) + (m.n_data - m.l_fc) * m.c_data + m.l_fc * m.n_fc
+        self.cid = 6 * self.plp[1] + self.plp[2]
+        self.frame_cells = (self.c_p2 - 1840 - self.lps) + (self.n_data - self.l_fc) * self.c_data + self.l_fc * self.n_fc
+        self.nb = self.frame_cells // self.cpf                                    # FEC blocks of the one PLP that fills the frame
         self.k_ldpc, self.k_bch = K_LDPC[self.plp[1]][self.plp[2]], K_BCH[self.plp[1]][self.plp[2]]
 
     def stage_bytes(self, F):
         """ALGORITHMIC HBM bytes of every stage for F frames (each datum once in, once out; tables excluded)."""
-        m = self.m
-        syms = F * m.len_frame
+        syms = F * self.len_frame
         cells = F * self.nb * self.cpf
         return {
             "front": 12 * F * self.frame_samples,                                    # int16 I/Q in, complex64 out
             "guard_corr": syms * 2 * self.guard * 8,
-            "fft": syms * 16 * m.fft_size,
-            "equalise": F * 8 * (m.k_total * m.len_frame + m.c_p2 + (m.n_data - m.l_fc) * m.c_data + m.l_fc * m.n_fc),
+            "fft": syms * 16 * self.fft_size,
+            "equalise": F * 8 * (self.k_total * self.len_frame + self.c_p2 + (self.n_data - self.l_fc) * self.c_data + self.l_fc * self.n_fc),
             "ti": 16 * cells,
-            "demap": cells * (8 + 8 + self.bpc),                                     # statistics pass, LLR pass in, LLRs out
+            "demap": cells * (8 + self.bpc),                                         # cells in once, one LLR byte per bit out (8d: 16 B per 256-QAM cell)
             "ldpc": F * self.nb * (self.fec_size + self.k_ldpc),
-            "descramble": F * self.nb * (self.k_ldpc + self.k_bch),
+            "descramble": F * self.nb * (self.k_ldpc + self.k_bch // 8),             # bit-bytes in, packed bytes out (8d)
         }
 
 
 def make_frames(w, n_unique, snr_db, seed):
     """n_unique synthetic frames of workload w as int16 I/Q at the tuner interface: (I [n][frame_samples], Q, sent TS packets)."""
+    import oracle_lib as ol
     import t2_tx
+    m = ol.ora_mode(*w.mode)
+    assert t2_tx.plp_blocks_per_frame(m, w.lps, w.cpf) == w.nb
     per = w.nb * (w.k_bch // 1496 + 1)
     frames, sent = [], []
     for f in range(n_unique):
         ts = t2_tx.ts_packets(per, seed + f)
         stream, _, _ = t2_tx.build_plp_frame_cells(w.cid, w.plp[0], w.plp[1], w.plp[2], ts, w.nb)
-        frames.append(t2_tx.build_frame(w.m, stream, w.lps, seed + 100 + f, snr_db=None, phase=0.0))
+        l1 = t2_tx.l1_cells(w.mode, w.lps, w.plp[0], w.plp[1], w.plp[2], w.nb, frame_idx=f)
+        frames.append(t2_tx.build_frame(m, stream, w.lps, seed + 100 + f, snr_db=None, phase=0.0, l1_cells=l1))
         sent.append(ts)
     i16, q16, flen = t2_tx.iq_stream(frames, w.guard, w.cfg["s2"], snr_db, seed)
     assert flen == w.frame_samples
@@ -108,13 +114,14 @@ def make_frames(w, n_unique, snr_db, seed):
 
 def _cpu_worker(args):
     """One frame (int16 I/Q) through the CPU chain on one core, over and over for `seconds`: oracle front end (dc / IQ / NCO,
-    Farrow, decimator), P1 detector, guard correlation, numpy FFT, oracle equaliser / de-interleavers / demapper (C restatement), the
-    reference's own LDPC build when loadable (else the C restatement), oracle descrambler. Returns (passes, elapsed, LDPC kind)."""
+    Farrow, decimator), P1 detector, guard correlation, numpy FFT, oracle equaliser / L1 parse / de-interleavers / demapper (C
+    restatement), the reference's own LDPC build when loadable (else the C restatement), oracle descrambler. Returns (passes, elapsed,
+    LDPC kind)."""
     cfg_id, i16, q16, seconds, full = args
     import numpy as np
     import oracle_lib as ol
     w = Workload(CONFIGS[cfg_id])
-    m = w.m
+    m = ol.ora_mode(*w.mode)
     ldpc, kind = (ol.ref_decode, "reference LDPC + port") if ol.ref() is not None else (ol.ora_decode, "port")
     ti = ol.OraTi(w.cpf, w.nb)
     t0 = time.perf_counter()
@@ -176,9 +183,53 @@ def cpu_chain_baseline(cfg_id, w, i16, q16, full):
             "best_single_core": round(one, 3),
             "sample": "%d processes x ~12 s (%.1f s wall), each passing one %s frame from int16 I/Q over and over (front end, P1, %d symbols"
                       "%s); stages: oracle C restatement + numpy FFT, LDPC = %s"
-                      % (cores, wall, w.cfg["name"], w.m.len_frame,
+                      % (cores, wall, w.cfg["name"], w.len_frame,
                          ", %d of %d FEC blocks in whole SIMD batches of 32 through the LDPC, 25 trials each" % ((w.nb // 32) * 32, w.nb) if full
                          else ", up to the LLRs", res[0][2])}
+
+
+def packet_hashes(packets):
+    """64-bit mixing hash of every 188-byte row (to count transport-stream packets that are among those sent)."""
+    import numpy as np
+    wts = (np.arange(1, 189, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    out = np.empty(packets.shape[0], np.uint64)
+    for a in range(0, packets.shape[0], 65536):
+        out[a:a + 65536] = (packets[a:a + 65536].astype(np.uint64) * wts[None, :]).sum(axis=1, dtype=np.uint64)
+    return out
+
+
+def ldpc_counters(cfg_id, frames, sweeps, launch_s, links_per_frame, occ):
+    """north_star's LDPC figures: PMC counters of the committed passes (per launch of the profiled workload) scaled to this run's
+    frames x sweeps, over this run's measured launch time."""
+    try:
+        c = json.load(open(COUNTERS_FILE))
+    except (OSError, ValueError):
+        return None
+    if c.get("config") != cfg_id:
+        return None
+    scale = frames * sweeps / float(c["frames"] * c["sweeps"])
+    valu = c["SQ_INSTS_VALU"] * scale                                   # wave instructions
+    cus, waves_cu = occ["cus"], occ["workgroups_per_cu"] * occ["waves_per_workgroup"]
+    cu_cycles = launch_s * CLOCK_HZ * cus
+    out = {
+        "traffic": round((2 * c["FETCH_SIZE_KiB"] + c["WRITE_SIZE_KiB"]) * 1024 * scale),
+        "occupancy_waves_per_cu": waves_cu, "occupancy_max_waves_per_cu": 32,
+        "workgroups_per_cu": occ["workgroups_per_cu"], "lds_bytes_per_workgroup": occ["lds_bytes_per_workgroup"],
+        "lds_busy_frac": round(c["SQ_LDS_IDX_ACTIVE"] * scale / cu_cycles, 3),
+        "lds_bank_conflict_frac_of_lds_busy": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3),
+        "wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+        "valu_lane_insts_per_edge_update": round(valu * 64 / (links_per_frame * frames * sweeps), 2),
+        "valu_wave_insts_per_simd_cycle": round(valu / (cu_cycles * 4), 3),
+        "lds_algorithmic_TBs": round(4.0 * links_per_frame * frames * sweeps / launch_s / 1e12, 2),
+        "counters_from": "profiles/ldpc_counters.json (%s), scaled by frames x sweeps" % c.get("source", "?"),
+    }
+    vr = c.get("valu_cycles_per_wave_inst")                              # tools/ubench/valu_rate: measured issue cost of the op classes
+    if vr:
+        out["valu_cycles_per_wave_inst_measured"] = vr
+        mix = c.get("valu_mix_cycles")                                   # op-mix weighted cycles per instruction of the kernel's ISA listing
+        if mix:
+            out["valu_issue_frac"] = round(valu * mix / (cu_cycles * 4), 3)
+    return out
 
 
 def main():
@@ -191,8 +242,9 @@ def main():
     ap.add_argument("--snr", type=float, default=22.0)
     ap.add_argument("--trials", type=int, default=25, help="LDPC trial limit (the reference's TRIALS = 25, ldpc_decoder.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the informative legs: 50-trial point, clamped-LLR variant (profiling runs)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the informative legs: 50-trial point, clamped-LLR variant, config 5 (profiling runs)")
     ap.add_argument("--no-clamped-variant", action="store_true", help="(kept for old command lines) same as --no-extra-legs")
+    ap.add_argument("--no-ts-end", action="store_true", help="leave the library's host end (L1 parse + de-framing worker) off")
     args = ap.parse_args()
     if args.no_clamped_variant:
         args.no_extra_legs = True
@@ -201,7 +253,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sdr_receiver_dvb_t2_amd as pkg
-    from sdr_receiver_dvb_t2_amd.shard import shard_frames, aggregate_timing
+    from sdr_receiver_dvb_t2_amd.shard import shard_frames, aggregate_timing, frame_alignment
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,117 +274,145 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = CONFIGS[args.config]
-    w = Workload(cfg)
-    full = args.config != 2
-    frames_per_gpu = args.frames or cfg["frames"]
-    # weak scaling: every GPU demodulates frames_per_gpu whole T2 frames per step (frames are independent: no collective)
-    lo, hi = shard_frames(frames_per_gpu * world, world, rank, align=1)
-    F = hi - lo
     from sdr_receiver_dvb_t2_amd.receiver import t2_rx
-    from sdr_receiver_dvb_t2_amd.chain import ts_from_bits
-    ui, uq, sent = make_frames(w, 2, args.snr if args.config != 4 else 16.0, seed=20250614 + 10 * rank)
-    nb, FS = w.nb, w.frame_samples
-    d_i = torch.from_numpy(np.concatenate([ui] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)     # int16 [F * frame_samples]
-    d_q = torch.from_numpy(np.concatenate([uq] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)
 
-    # The receiver is the library's batch object (t2gpu_rx_*, csrc/t2gpu_rx.cpp): buffers, stage sequencing and launches are C++
-    # behind the C ABI; this script hands over two device pointers per step and reads results back. torch is the allocator of the
-    # input buffers and the process-group plumbing, nothing else.
-    def make_rx(saturate, frames, trials):
-        return t2_rx(*w.mode, w.lps, *w.plp, nb, max_frames=frames, ldpc_trials=trials, saturate_llr=saturate, device=local_rank)
+    def run_config(cfg_id, steps, warmup, extras):
+        """One bench line's worth of measurement for a config; returns the dict to print (rank 0) or None."""
+        cfg = CONFIGS[cfg_id]
+        w = Workload(cfg)
+        full = cfg_id != 2
+        frames_per_gpu = args.frames or cfg["frames"]
+        align = frame_alignment(w.nb, 32)
+        if full and frames_per_gpu % align:
+            frames_per_gpu = max(align, frames_per_gpu // align * align)              # no step ends inside a SIMD batch
+        # weak scaling: every GPU demodulates frames_per_gpu whole T2 frames per step (frames are independent: no collective)
+        lo, hi = shard_frames(frames_per_gpu * world, world, rank, align=1)
+        F = hi - lo
+        ui, uq, sent = make_frames(w, 2, args.snr if cfg_id != 4 else 16.0, seed=20250614 + 10 * rank)
+        nb, FS = w.nb, w.frame_samples
+        d_i = torch.from_numpy(np.concatenate([ui] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)     # int16 [F * frame_samples]
+        d_q = torch.from_numpy(np.concatenate([uq] * ((F + 1) // 2))[:F].reshape(-1)).to(dev)
 
-    def timed_leg(rx, steps, warmup, level):
-        """W untimed + K timed steps bracketed by barrier + synchronize; returns (seconds, per-stage ms sums, LDPC ms list)."""
-        for _ in range(max(warmup, 1)):
-            step(rx, level)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        acc, ldpc = {}, []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(rx, level)
-            for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
-                if v >= 0:
-                    acc[k] = acc.get(k, 0.0) + v
-            if full:
-                ldpc.append(rx.last_ldpc_ms())
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        return time.perf_counter() - t0, acc, ldpc
+        # The receiver is the library's batch object (t2gpu_rx_*, csrc/t2gpu_rx.cpp): buffers, stage sequencing, launches and the host
+        # end (L1 parse + de-framing worker thread) are C++ behind the C ABI; this script hands over two device pointers per step and reads
+        # TS bytes and counters back. torch is the allocator of the input buffers and the process-group plumbing, nothing else.
+        def make_rx(saturate, frames, trials):
+            rx = t2_rx(*w.mode, w.lps, *w.plp, nb, max_frames=frames, ldpc_trials=trials, saturate_llr=saturate, device=local_rank)
+            if full and not args.no_ts_end:
+                rx.ts_enable(0, l1_check=True)
+            return rx
 
-    if full:
-        def step(rx, level):
-            return rx.execute_dev(d_i, d_q, F, level)
-    else:
-        def step(rx, level):                       # config 2: the frames' stream and positions stay in the handle from the set-up call
-            return rx.fft_eq_demap_dev(F)
+        if full:
+            def step(rx, level):
+                return rx.execute_dev(d_i, d_q, F, level)
+        else:
+            def step(rx, level):                       # config 2: the frames' stream and positions stay in the handle from the set-up call
+                return rx.fft_eq_demap_dev(F)
 
-    rx = make_rx(False, F, args.trials)            # reference semantics: truncating int8 cast in the demapper
-    assert rx.frame_len == FS
-    count = rx.execute_dev(d_i, d_q, F, first_call=True)                               # thresholds from the level estimate
-    level = rx.results(F)["level_detect"]
-    # One step = one call = the whole chain over one buffer of F frames (front end .. descrambler), drained by the host once per
-    # call because the P1 decisions are host data. Running stages of neighbouring buffers beside the decoder on other streams
-    # measured slower (DESIGN.md section 6), so there is no overlap to lose.
-    elapsed, stage_acc, ldpc_ms = timed_leg(rx, args.steps, args.warmup, level)
-    ref_trials = rx.fetch(count)[1] if full else None
-    max_s, units = aggregate_timing(elapsed, F * args.steps, dist if world > 1 else None, None if one_device else dev)
-    rx.close()
+        def timed_leg(rx, steps, warmup, level, keep_ts=False):
+            """W untimed + K timed steps bracketed by barrier + synchronize; the clock stops when the last step's TS bytes are on the host.
+            Returns (seconds, per-stage ms sums, LDPC ms list, TS bytes of the timed steps, the bytes themselves if keep_ts)."""
+            ts_on = full and not args.no_ts_end
+            for _ in range(max(warmup, 1)):
+                step(rx, level)
+            torch.cuda.synchronize(dev)
+            if ts_on:
+                rx.ts_read(wait_all=True)                                              # warm-up output is not counted
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            acc, ldpc, ts_bytes, kept = {}, [], 0, []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(rx, level)
+                for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
+                    if v >= 0:
+                        acc[k] = acc.get(k, 0.0) + v
+                if full:
+                    ldpc.append(rx.last_ldpc_ms())
+                if ts_on:                              # what the worker has finished meanwhile (it runs beside the next step)
+                    b = rx.ts_read(wait_all=False)
+                    ts_bytes += b.size
+                    if keep_ts:
+                        kept.append(b)
+            if ts_on:
+                b = rx.ts_read(wait_all=True)          # the last step's frames de-framed: demod -> TS is complete
+                ts_bytes += b.size
+                if keep_ts:
+                    kept.append(b)
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0, acc, ldpc, ts_bytes, (np.concatenate(kept) if kept else None)
 
-    extra = {}
-    if rank == 0 and world == 1 and full and not args.no_extra_legs:     # N = 1 only: timed_leg's barriers are collective
-        # (i) the BASELINE config's "50 iters" point beside the reference's own TRIALS = 25
-        r50 = make_rx(False, F, 50)
-        r50.execute_dev(d_i, d_q, F, first_call=True)
-        e50, _, l50 = timed_leg(r50, 2, 1, level)
-        r50.close()
-        extra["trials_50"] = {"msamples_per_s": round(2 * F * FS / e50 / 1e6, 1), "ldpc_ms": round(sum(l50) / len(l50), 3),
-                              "note": "same workload with the LDPC trial limit at 50 (BASELINE.json config text); the reference itself stops at 25"}
-        # (ii) clamped LLRs (extension) -> the same frames decode; checks the TS bytes
-        c2 = make_rx(True, 2, args.trials)
-        n2 = c2.execute_dev(d_i[:2 * FS], d_q[:2 * FS], 2, first_call=True)
-        b2, t2h = c2.fetch(n2)
-        got = ts_from_bits(b2, t2h)
-        c2.close()
-        want = sent[0].reshape(-1)
-        npk = (nb * ((w.k_bch - 80) // 8)) // 187 - 1
-        ok = bool((t2h >= 0).all()) and bool(np.array_equal(got[:npk * 188], want[:npk * 188]))
-        c3 = make_rx(True, F, args.trials)
-        c3.execute_dev(d_i, d_q, F, first_call=True)
-        e3, _, _ = timed_leg(c3, 3, 2, level)
-        c3.close()
-        extra["clamped_llr_variant"] = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "ts_matches_sent": ok,
-                                        "avg_ldpc_updates": round(float((args.trials - t2h).mean()), 2),
-                                        "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
+        rx = make_rx(False, F, args.trials)            # reference semantics: truncating int8 cast in the demapper
+        assert rx.frame_len == FS
+        count = rx.execute_dev(d_i, d_q, F, first_call=True)                               # thresholds from the level estimate
+        assert not full or (count == F * nb and rx.carry == 0)
+        level = rx.results(F)["level_detect"]
+        occ = rx.ldpc_occupancy()
+        # One step = one call = the whole chain over one buffer of F frames (front end .. descrambler + packing), drained by the host once
+        # per call because the P1 decisions are host data; the host end (copies on their own stream, worker thread) overlaps the next step.
+        elapsed, stage_acc, ldpc_ms, ts_bytes, _ = timed_leg(rx, steps, warmup, level)
+        ref_trials = rx.fetch_packed(count)[1] if full else None
+        counters = rx.ts_counters() if full and not args.no_ts_end else None
+        max_s, units = aggregate_timing(elapsed, F * steps, dist if world > 1 else None, None if one_device else dev)
+        rx.close()
 
-    if rank == 0:
+        extra = {}
+        if rank == 0 and world == 1 and full and extras:     # N = 1 only: timed_leg's barriers are collective
+            # (i) the BASELINE config's "50 iters" point beside the reference's own TRIALS = 25
+            r50 = make_rx(False, F, 50)
+            r50.execute_dev(d_i, d_q, F, first_call=True)
+            e50, _, l50, _, _ = timed_leg(r50, 2, 1, level)
+            r50.close()
+            extra["trials_50"] = {"msamples_per_s": round(2 * F * FS / e50 / 1e6, 1), "ldpc_ms": round(sum(l50) / len(l50), 3),
+                                  "note": "same workload with the LDPC trial limit at 50 (BASELINE.json config text); the reference itself stops at 25"}
+            # (ii) clamped LLRs (extension) -> the same frames decode; demod -> TS with every byte checked
+            c3 = make_rx(True, F, args.trials)
+            c3.execute_dev(d_i, d_q, F, first_call=True)
+            e3, _, _, tsb, ts = timed_leg(c3, 3, 2, level, keep_ts=True)
+            t3 = c3.fetch_packed(F * nb)[1]
+            k3 = c3.ts_counters() if not args.no_ts_end else None
+            c3.close()
+            var = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "avg_ldpc_updates": round(float((args.trials - t3).mean()), 2),
+                   "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
+            if ts is not None:
+                pk = ts[:ts.size // 188 * 188].reshape(-1, 188)
+                good = np.isin(packet_hashes(pk), np.concatenate([packet_hashes(s) for s in sent]))
+                per_frame = (nb * ((w.k_bch - 80) // 8)) // 187 - 1                     # whole packets one T2 frame's BBFRAMEs carry
+                var.update({"ts_bytes_per_s": round(tsb / e3, 1), "ts_mbit_per_s": round(tsb * 8 / e3 / 1e6, 1), "ts_packets": int(pk.shape[0]),
+                            "ts_packets_that_were_sent": int(good.sum()),
+                            "ts_matches_sent": bool(good.sum() >= 3 * F * per_frame and pk.shape[0] - good.sum() <= 3 * F * 2),
+                            "bytes_d2h_per_fec_frame": w.k_bch // 8, "host_end_counters": k3})
+            extra["clamped_llr_variant"] = var
+
+        if rank != 0:
+            return None
         msps = units * FS / max_s / 1e6
         sb = w.stage_bytes(F)
         kernels = []
         for k in ("front", "guard_corr", "fft", "equalise", "ti", "demap", "ldpc", "descramble"):
             if k in stage_acc and stage_acc[k] > 0:
-                ms = stage_acc[k] / args.steps
+                ms = stage_acc[k] / steps
                 gbs = sb[k] / (ms * 1e-3) / 1e9
                 kernels.append({"stage": k, "ms": round(ms, 4), "algorithmic_bytes": int(sb[k]), "achieved_GBs": round(gbs, 1),
                                 "frac": round(gbs / HBM_PEAK_GBS, 4)})
         if "p1" in stage_acc:
-            kernels.append({"stage": "p1 (incl. the step's one host round trip)", "ms": round(stage_acc["p1"] / args.steps, 4)})
+            kernels.append({"stage": "p1 (incl. the step's one host round trip)", "ms": round(stage_acc["p1"] / steps, 4)})
         if full:
-            ldpc_frames = count
             avg_ldpc_s = (sum(ldpc_ms) / len(ldpc_ms)) / 1e3
             achieved = sb["ldpc"] / avg_ldpc_s / 1e9
             dom = {"kernel": "ldpc_decode2_kernel (two FEC frames per workgroup, packed 16-bit halves)", "avg_launch_ms": round(avg_ldpc_s * 1e3, 3),
-                   "traffic": round(LDPC_TRAFFIC_BYTES_PER_FRAME_SWEEP * ldpc_frames * args.trials) if args.config == 3 else None,
-                   "share_of_step": round(avg_ldpc_s / (max_s / args.steps), 3),
-                   "valu_issue_frac": round(LDPC_VALU_WAVE_INSTS_PER_FRAME_SWEEP * ldpc_frames * args.trials / avg_ldpc_s / VALU_ISSUE_SLOTS_PER_S, 3)
-                   if args.config == 3 else None,
-                   "note": "the LDPC is VALU/LDS-bound by construction (DESIGN.md): HBM sees each LLR once and each bit once; traffic = "
-                           "PMC-measured bytes per frame-sweep (profiles/) x frames x sweeps (the check-node records, streaming through L2 / "
-                           "Infinity Cache); valu_issue_frac = PMC-measured vector instructions / measured launch time / the chip's vector issue rate"}
+                   "share_of_step": round(avg_ldpc_s / (max_s / steps), 3), "traffic": None,
+                   "note": "HBM algorithmic bytes over the launch time, as the contract defines it; the kernel itself is bound by vector issue and "
+                           "LDS latency inside one resident workgroup per CU (DESIGN.md K-ldpc): the LDS / occupancy / issue figures north_star asks "
+                           "for are the keys below"}
+            sweeps = args.trials if ref_trials is None or (ref_trials < 0).all() else None
+            if sweeps is not None:                         # every batch ran all its sweeps: the counters scale exactly
+                pmc = ldpc_counters(cfg_id, count, sweeps, avg_ldpc_s, LDPC_LINKS.get((w.plp[1], w.plp[2]), 0), occ)
+                if pmc:
+                    dom.update(pmc)
         else:
             top = max((k for k in kernels if "frac" in k), key=lambda k: k["ms"])
             achieved = top["achieved_GBs"]
@@ -340,29 +420,49 @@ def main():
         dropped = int((ref_trials < 0).sum()) if ref_trials is not None else 0
         out = {
             "metric": cfg["metric"],
-            "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(max_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(msps, 1), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(max_s / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16 in, f32 (front end, OFDM, demap) + int8 (LDPC)", "data": "synthetic",
-            "config": {"workload": "%s: %d T2 frames/GPU/step = %d symbols of %dK, %d FEC frames (%d bits, code rate id %d, %d-QAM), %s; "
-                                   "tracking loops open (the per-symbol synchronisation sums are formed, nobody reads them); one call of the "
-                                   "library's batch receiver per step, drained per call; reference arithmetic incl. the wrapping int8 LLR cast"
-                                   "%s; L1 parsing and TS de-framing (host code) are not inside the timed region (%d samples per frame)"
-                                   % (cfg["name"], F, F * w.m.len_frame, w.m.fft_size // 1024, F * nb, w.fec_size, w.plp[2], 1 << w.bpc,
+            "config": {"workload": "%s: %d T2 frames/GPU/step = %d symbols of %dK, %d FEC frames (%d bits, code rate id %d, %d-QAM) = %d SIMD batches of 32 "
+                                   "formed across frames as the reference forms them, %s; tracking loops open (the per-symbol synchronisation sums are formed, "
+                                   "nobody reads them); one call of the library's batch receiver per step; reference arithmetic incl. the wrapping int8 LLR cast"
+                                   "%s; %s (%d samples per frame)"
+                                   % (cfg["name"], F, F * w.len_frame, w.fft_size // 1024, F * nb, w.fec_size, w.plp[2], 1 << w.bpc, (F * nb) // 32,
                                       ("from int16 I/Q at the dvbt2_demodulator::execute boundary; stages on GPU: front end (dc, IQ imbalance, NCO, "
                                        "Farrow x2, 64-tap decimator), P1 detect, guard correlation, FFT, P2+data equaliser/freq-deint, TI/cell-deint, "
-                                       "demap, LDPC (group 32, max %d trials), BB descramble (t2gpu_rx_execute_dev)" % args.trials) if full else
+                                       "demap, LDPC (group 32, max %d trials), BB descramble + bit packing (t2gpu_rx_execute_dev)" % args.trials) if full else
                                       "from the decimated stream in HBM; stages: FFT (guard dropped), P2+data equaliser/freq-deint, TI/cell-deint, demap "
                                       "(t2gpu_rx_fft_eq_demap_dev)",
                                       (", so %d of %d SIMD batches run all trials and are dropped as the reference would" % (dropped, len(ref_trials)))
-                                      if ref_trials is not None and dropped else "", FS),
+                                      if ref_trials is not None and dropped else "",
+                                      "the host end (per-frame L1-pre/L1-post parse + CRC-32, batch drop rule, BBFRAME de-framing -> TS) runs on the library's worker "
+                                      "thread inside the timed region, overlapped with the next step" if full and not args.no_ts_end else
+                                      "L1 parsing and TS de-framing (host code) are not inside the timed region", FS),
                        "ldpc_codewords_per_s": round(count / avg_ldpc_s, 1) if full else None,
                        "parallelism": "frame-shard x%d, no collective" % world},
             "roofline": dict({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 5)}, **dom, kernels=kernels),
         }
+        if counters is not None:
+            out["host_end"] = {"ts_bytes": ts_bytes, "ts_bytes_per_s": round(ts_bytes / max_s, 1), "bytes_d2h_per_fec_frame": w.k_bch // 8, "counters": counters}
         out.update(extra)
+        out["_cpu_args"] = (cfg_id, w, ui[0], uq[0], full)
+        return out
+
+    out = run_config(args.config, args.steps, args.warmup, extras=not args.no_extra_legs)
+    if rank == 0:
+        cpu_args = out.pop("_cpu_args")
+    if args.config == 3 and not args.no_extra_legs:
+        # BASELINE.json configs[4] (r = 2/3) as an extra key of the same line: with N > 1 the scaling run then reports both codes
+        c5 = run_config(5, 2, 1, extras=False)
+        if rank == 0:
+            c5.pop("_cpu_args")
+            out["config_5"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
+                               "ldpc_codewords_per_s": c5["config"]["ldpc_codewords_per_s"], "ldpc_ms": c5["roofline"]["avg_launch_ms"],
+                               "n_gpus": world, "workload": c5["config"]["workload"][:120] + " ..."}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_chain_baseline(args.config, w, ui[0], uq[0], full)
+            out["cpu_baseline"] = cpu_chain_baseline(*cpu_args)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -62,6 +62,9 @@ int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uin
  * batch meet at every sweep, so kernels of another stream that grab the CUs first stall whole batches; with this wait they
  * start once the decoder is placed and use what it leaves. */
 int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream);
+/* What a decode occupies: out6 = {workgroups resident per CU, wavefronts per workgroup, dynamic LDS bytes per workgroup, FEC frames per
+ * workgroup, CUs of the device, SIMD batches resident at once} for the kernel variant the handle's configuration selects. */
+int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6);
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);
@@ -140,6 +143,10 @@ int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_strid
  * one bit per byte; out: [n_frames][k_bch]. Returns k_bch. */
 int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_out, void *stream);
 int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out);
+/* K-descramble-pack (a15 + the byte packing part of a16): the same XOR with the result packed MSB first, k_bch / 8
+ * bytes per frame -- the byte assembly bb_de_header::execute does bit by bit (bb_de_header.cpp:84-448) done where the bits are.
+ * in: [n_frames][k_ldpc] one bit per byte (values 0 / 1, 8-byte aligned rows); out: [n_frames][k_bch / 8]. Returns k_bch / 8. */
+int t2gpu_bch_descramble_pack_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_bytes, void *stream);
 
 /* Outer code applied for real (NOT what the reference does: bch_decoder.cpp:136 is "// TODO BCH decode", so a
  * drop-in caller goes straight to t2gpu_bch_descramble). The code of EN 302 755 clause 6.1.1 for the (k_bch, n_bch) pairs of
@@ -220,6 +227,10 @@ typedef struct t2gpu_bbdh t2gpu_bbdh;
 t2gpu_bbdh *t2gpu_bbdh_create(int need_plp);
 void t2gpu_bbdh_destroy(t2gpu_bbdh *h);
 int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap, int *ts_errors);
+/* The same on a PACKED BBFRAME: len_in bits in (len_in + 7) / 8 bytes, MSB first -- the byte assembly of bb_de_header.cpp:84-448
+ * (`temp |= *in++ << n`, n = 7..0) already done on the device by t2gpu_bch_descramble_pack_dev / t2gpu_rx. Same results, same
+ * state: calls of the two forms may be mixed on one handle. */
+int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bytes, uint8_t *out, int out_cap, int *ts_errors);
 int t2gpu_bbdh_mode(const t2gpu_bbdh *h);
 int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h);
 
@@ -278,6 +289,10 @@ int t2gpu_eq_p2_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames,
                            long cells_frame_stride, int skip_cells, float *d_sync, void *stream);
 int t2gpu_eq_fc_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
                            long cells_frame_stride, long cells_offset, float *d_sync, void *stream);
+/* t2gpu_eq_p2_frames_dev that also keeps the skipped cells: the L1-pre / L1-post cells of frame f at d_l1_cells + 2 * f * skip_cells
+ * floats (what t2gpu_l1_pre_parse / t2gpu_l1_post_parse read; p2_symbol.cpp:264-299 hands the same cells to l1_pre_info). */
+int t2gpu_eq_p2_frames_l1_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                              long cells_frame_stride, int skip_cells, float *d_l1_cells, float *d_sync, void *stream);
 /* host only: {fft_size, k_total, k_ext, k_offset, l_nulls, c_p2, c_data, n_fc, c_fc, l_fc, len_frame, guard_interval_size}
  * (dvbt2_{p2,bwt_ext,data}_parameters_init, src/DVB_T2/dvbt2_definition.cpp:20-648) */
 int t2gpu_ofdm_mode_info(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode, int n_data,
@@ -477,19 +492,36 @@ int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
  * buffers that hold n_frames whole T2 frames starting at a P1 symbol, in one object: int16 I/Q in device memory ->
  * descrambled BBFRAME bits in device memory. Front end (nominal resample, loops open) -> P1 search at every frame start ->
  * guard-interval correlation of every symbol -> FFT (guard dropped by addressing) -> P2 / data / frame-closing equalisers ->
- * time de-interleaver -> demapper -> LDPC (all FEC frames of the buffer, SIMD batches of ldpc_group, the tail batch short) ->
- * BB descrambler. Every frame is independent given the mode, so all frames of the buffer share each launch.
+ * time de-interleaver -> demapper -> LDPC -> BB descrambler + bit packing (K-descramble-pack) -> [host worker: per-frame L1 parse,
+ * BBFRAME de-framing -> TS]. Every frame is independent given the mode, so all frames of the buffer share each launch.
+ * SIMD batches are formed as the reference forms them (llr_demapper.cpp:742-764, `static int blocks`): the 32-frame LLR buffer fills
+ * across TI blocks, T2 frames and CALLS, and only complete batches of ldpc_group frames go to the LDPC stage; the frames of an
+ * incomplete batch wait in the handle (t2gpu_rx_carry) and lead the next call's batches, so a stream cut into calls anywhere gives the
+ * batches -- hence the stop / drop decisions -- of a sequential reference. t2gpu_rx_flush_dev (end of stream; an addition, the
+ * reference never decodes the tail) decodes the waiting frames as one short batch behind the rows of the last back half.
+ * t2gpu_rx_reset drops the waiting frames and restarts the frame counters (a new stream on the same handle).
  * The mode is the caller's (what L1-pre / L1-post signal: fields as in dvbt2_parameters / l1_postsignalling_plp); one PLP
  * starting at cell 0 with one TI block per frame -- the reference's tested configuration; other layouts go through the
  * stage entry points (t2gpu_ti_frame_plan).
  * t2gpu_rx_front_dev / t2gpu_rx_back_dev are the two halves of t2gpu_rx_execute_dev for callers that software-pipeline buffers
  * (front half of buffer k, back half of buffer k-1); the back half works on the spectra the last front half left.
- * Returns: front 0 / back and execute the number of FEC frames decoded; -1 stage error, -2 P1 missing or frames not equally spaced.
- * d_bits_out: [fec frames][k_bch] one bit per byte; d_trials_out: per SIMD batch, trials left or -1 = dropped by the reference
- * (ldpc_decoder.cpp:264-268). Both point into the handle and stay valid until the next back half.
+ * Returns: front 0 / back and execute the number of FEC frames decoded BY THIS CALL (whole batches: carried + new frames);
+ * -1 stage error, -2 P1 missing or frames not equally spaced.
+ * d_bytes_out: [fec frames][k_bch / 8] descrambled BBFRAMEs, packed MSB first (t2gpu_bbdh_execute_packed reads them);
+ * d_trials_out: per SIMD batch, trials left or -1 = dropped by the reference (ldpc_decoder.cpp:264-268). Both point into the handle
+ * and stay valid until the next back half.
  * t2gpu_rx_results (synchronises): P1 decisions, first P2 sample of every frame, guard correlations [frames * n_sym][4], the
  * level estimate of the last buffer (dvbt2_demodulator.cpp:235), duration of the last LDPC launch in ms. Any pointer may be NULL.
- * t2gpu_rx_fetch (synchronises): the bits / trials of the last back half into host memory. */
+ * t2gpu_rx_fetch_packed / t2gpu_rx_fetch (synchronise): rows / trials of the last back half (and flush) into host memory, packed
+ * (k_bch / 8 bytes per frame over the bus either way) or one bit per byte (unpacked on the host: the reference's bit_descramble form).
+ * The host end: t2gpu_rx_ts_enable starts a worker thread in the handle; from then on every back half / flush queues, behind its
+ * kernels, the copies of its packed BBFRAMEs, batch verdicts and the L1 cells of its P2 symbols to pinned memory, and the worker --
+ * while the device runs later calls -- does what the reference does per frame on the host: L1-pre / L1-post parse with CRC-32
+ * (p2_symbol.cpp:301-718; l1_check != 0: BBFRAMEs of a T2 frame whose CRC fails or whose signalling -- carrier mode, guard
+ * interval, PAPR, pilot pattern, data symbols, L1-post size, the first PLP's modulation / code / FEC type / rotation / TI mode and
+ * its dynamic PLP_NUM_BLOCKS -- differs from the handle's configuration are withheld and counted: the reference resets on an
+ * L1-pre failure and pushes misplaced cells on the others, dvbt2_demodulator.cpp:373-425), the batch drop rule, and
+ * bb_de_header::execute (bb_de_header.cpp:84-448). t2gpu_rx_ts_read hands out the TS bytes in order. */
 typedef struct {
     int32_t id_device;                /* id_device_t: 0 SDRplay, 1 AirSpy, 2 PlutoSDR (scale and stride of the int16 input) */
     float sample_rate;                /* 0 = 64e6 / 7 */
@@ -504,14 +536,30 @@ void t2gpu_rx_destroy(t2gpu_rx *h);
 int t2gpu_rx_info(const t2gpu_rx *h, t2gpu_rx_geometry *out);
 int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect /* <= 0: the handle's own */,
                        int first_call, void *stream);
-int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
+int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream);
 int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call,
-                         uint8_t **d_bits_out, int32_t **d_trials_out, void *stream);
+                         uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream);
+int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream);
+int t2gpu_rx_carry(const t2gpu_rx *h);
+int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6);          /* t2gpu_ldpc_occupancy of the handle's decoder */
+int t2gpu_rx_reset(t2gpu_rx *h);
 int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect, float *ldpc_ms);
 int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials);
+int t2gpu_rx_fetch_packed(t2gpu_rx *h, int n_fec_frames, uint8_t *bytes, int32_t *trials);
+typedef struct {
+    int64_t t2_frames, l1_pre_crc_errors, l1_post_crc_errors, l1_mismatches;   /* per T2 frame (l1_check) */
+    int64_t fec_frames, fec_frames_dropped_ldpc, fec_frames_dropped_l1;        /* per FEC frame */
+    int64_t bbheader_crc_errors, ts_packet_errors, resync;                     /* de-framer messages (bb_de_header.cpp:108,218,235,...) */
+    int64_t ts_bytes, ts_bytes_pending, device_errors;
+} t2gpu_rx_ts_counters;
+int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check);
+long t2gpu_rx_ts_read(t2gpu_rx *h, uint8_t *out, long cap, int wait_all);
+int t2gpu_rx_ts_counters_get(t2gpu_rx *h, int wait_all, t2gpu_rx_ts_counters *out);
 /* Per-stage durations of the last call, from HIP events recorded on the call's stream between the stages (waits for the call):
  * ms[T2GPU_RX_STAGES] in the order front end, P1 (incl. the call's one host round trip), guard correlation, FFT, equalisers +
- * frequency de-interleave, time / cell de-interleave, demapper, LDPC, BCH stub / descrambler; -1 = stage not run by that call. */
+ * frequency de-interleave, time / cell de-interleave, demapper, LDPC, BCH stub / descrambler + bit packing; -1 = stage not run by
+ * that call. One set of events per handle: valid for a call that has drained before the next one records (the function waits for
+ * both ends of every interval; with calls overlapped on several streams the intervals mix calls). */
 #define T2GPU_RX_STAGES 9
 int t2gpu_rx_stage_ms(t2gpu_rx *h, float *ms);
 /* BASELINE.json config 2 as a call of its own: FFT (guard dropped by addressing) + P2 / data / FC equalisers with frequency

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_ldpc_occupancy": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile_layers": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),
@@ -74,6 +75,17 @@ PROTOTYPES = {
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_eq_p2_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp]),
     "t2gpu_eq_fc_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp]),
+    "t2gpu_eq_p2_frames_l1_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_bch_descramble_pack_dev": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_bbdh_execute_packed": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_rx_flush_dev": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_carry": (ctypes.c_int, [_vp]),
+    "t2gpu_rx_ldpc_occupancy": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_reset": (ctypes.c_int, [_vp]),
+    "t2gpu_rx_fetch_packed": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    "t2gpu_rx_ts_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "t2gpu_rx_ts_read": (ctypes.c_long, [_vp, _vp, ctypes.c_long, ctypes.c_int]),
+    "t2gpu_rx_ts_counters_get": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "t2gpu_rx_create": (_vp, [_vp, ctypes.c_int]),
     "t2gpu_rx_destroy": (None, [_vp]),
     "t2gpu_rx_info": (ctypes.c_int, [_vp, _vp]),

@@ -29,16 +29,30 @@ struct t2gpu_bbdh {
 
 // Bit reader bounded by the frame: the reference trusts SYNCD / DFL and, in normal mode, consumes 8 bits per packet more than it
 // takes off DFL (:290-321), so it reads past the frame it was given. Bits past the end read as 0 here (what the reference sees
-// when the frame sits in a zeroed buffer) -- never memory outside bits[0 .. len_in).
+// when the frame sits in a zeroed buffer) -- never memory outside the frame. Two input forms: one bit per byte (the reference's
+// stage interface, bch_decoder.h:41 -> bb_de_header.h:59) and packed, MSB first (what K-descramble-pack delivers: k_bch / 8 bytes
+// per BBFRAME instead of k_bch, and a byte-aligned run is one load per output byte).
 struct BitSrc {
-    const uint8_t *p, *end;
+    const uint8_t *base;
+    long pos, len;                                     // in bits
+    bool packed;
+    int bit(long i) const
+    {
+        if (i < 0 || i >= len) return 0;
+        return packed ? (base[i >> 3] >> (7 - (i & 7))) & 1 : base[i] & 1;
+    }
     uint8_t byte()
     {
-        uint8_t t = 0;
-        for (int n = 7; n >= 0; --n, ++p) if (p < end) t |= (uint8_t)((*p & 1) << n);
+        uint8_t t;
+        if (packed && (pos & 7) == 0 && pos >= 0 && pos + 8 <= len) t = base[pos >> 3];
+        else {
+            t = 0;
+            for (int n = 7; n >= 0; --n) t |= (uint8_t)(bit(pos + (7 - n)) << n);
+        }
+        pos += 8;
         return t;
     }
-    void skip(long n) { p += n; }                      // may run past end: byte() then yields zeros
+    void skip(long n) { pos += n; }                    // may run past the end: byte() then yields zeros
 };
 // Byte sink bounded by out_cap: the reference's buffer is a fixed 53840/8 + 376 bytes (:35-38) which a wild SYNCD overruns; here
 // the frame is refused instead (full = true -> -3).
@@ -66,18 +80,20 @@ extern "C" t2gpu_bbdh *t2gpu_bbdh_create(int need_plp)
 extern "C" void t2gpu_bbdh_destroy(t2gpu_bbdh *h) { delete h; }
 extern "C" int t2gpu_bbdh_mode(const t2gpu_bbdh *h) { return h ? h->last_mode : -1; }
 
-extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap,
-                                  int *ts_errors)
+namespace {
+int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool packed, uint8_t *out, int out_cap, int *ts_errors)
 {
     if (!h || !bits || !out || len_in < BBH_BITS || out_cap < len_in / 8 + 2 * TS_LEN) { set_error("t2gpu_bbdh_execute: bad arguments"); return -3; }
-    BitSrc in{bits, bits + len_in};
+    h->resync = 0;                                     // status of THIS call, whichever way it returns
+    if (ts_errors) *ts_errors = 0;
+    BitSrc in{bits, 0, len_in, packed};
     ByteSink snk{out, out + out_cap};
     int errors = 0;
     uint8_t *tei = nullptr;
     // BBHEADER CRC over its 80 bits: remainder 0 = normal mode, 0xAB = high-efficiency mode (CRC-8 xor MODE), :70-82,101-113
     uint8_t c = 0;
     for (int i = 0; i < BBH_BITS; ++i) {
-        uint8_t b = (uint8_t)((bits[i] & 1) ^ (c & 0x01));
+        uint8_t b = (uint8_t)(in.bit(i) ^ (c & 0x01));
         c >>= 1;
         if (b) c ^= CRC_POLY;
     }
@@ -87,21 +103,22 @@ extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const u
     else return -1;                                    // "Baseband header CRC8 error.": frame dropped
     h->last_mode = hem;
     if (h->need_plp != plp_id) return -2;              // :139-142
-    const uint8_t *hp = bits + 16;                     // MATYPE (TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT | ISI): not used by the data path
+    long hp = 16;                                      // MATYPE (TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT | ISI): not used by the data path
     int upl = 0, dfl = 0, sync = 0, syncd = 0;
-    for (int i = 15; i >= 0; --i) upl |= (*hp++ & 1) << i;
-    for (int i = 15; i >= 0; --i) dfl |= (*hp++ & 1) << i;
-    for (int i = 7; i >= 0; --i) sync |= (*hp++ & 1) << i;
-    for (int i = 15; i >= 0; --i) syncd |= (*hp++ & 1) << i;
+    for (int i = 15; i >= 0; --i) upl |= in.bit(hp++) << i;
+    for (int i = 15; i >= 0; --i) dfl |= in.bit(hp++) << i;
+    for (int i = 7; i >= 0; --i) sync |= in.bit(hp++) << i;
+    for (int i = 15; i >= 0; --i) syncd |= in.bit(hp++) << i;
     (void)upl; (void)sync;
     if (syncd == 65535) return -2;                     // no user packet starts in this frame (:160-163)
     in.skip(BBH_BITS);
-    h->resync = 0;
 
     if (!hem) {                                        // ---- normal mode (:166-322): CRC-8 of the previous packet replaces the sync byte
         if (h->split) {
             h->split = false;
-            if (h->idx_buffer > 0) { snk.put(h->buffer[0]); tei = snk.full ? nullptr : snk.o; }
+            // as written (:168-171): buffer[0] goes out and the TEI pointer sits behind it whether or not the previous frame left
+            // any byte (a DFL remainder under 8 bits leaves idx_buffer = 0: the byte is then whatever buffer[0] last held)
+            snk.put(h->buffer[0]); tei = snk.full ? nullptr : snk.o;
             for (int i = 1; i < h->idx_buffer; ++i) snk.put(h->buffer[i]);
             const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
             if (len_split <= syncd_byte) {
@@ -215,6 +232,20 @@ extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const u
     }
     if (ts_errors) *ts_errors = errors;
     return snk.n;
+}
+}  // namespace
+
+extern "C" int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, uint8_t *out, int out_cap,
+                                  int *ts_errors)
+{
+    return bbdh_run(h, plp_id, len_in, bits, false, out, out_cap, ts_errors);
+}
+
+// The same on a packed BBFRAME: len_in bits in (len_in + 7) / 8 bytes, MSB first (t2gpu_bch_descramble_pack_dev, t2gpu_rx).
+extern "C" int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bytes, uint8_t *out, int out_cap,
+                                         int *ts_errors)
+{
+    return bbdh_run(h, plp_id, len_in, bytes, true, out, out_cap, ts_errors);
 }
 
 extern "C" int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h) { return h ? h->resync : 0; }

@@ -9,6 +9,11 @@ namespace t2gpu {
 hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs, uint8_t *out,
                                  hipStream_t s);
 
+// K-descramble-pack: out[f][j] = (in[f][8j..8j+7] packed MSB first) ^ prbs_packed[j], j < k_bch / 8 (bch_decoder.cpp:136-142 +
+// the byte assembly of bb_de_header.cpp:84-448)
+hipError_t launch_bch_descramble_pack(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs_packed, uint8_t *out,
+                                      hipStream_t s);
+
 struct DemapParams {
     int mod;                 // 0 QPSK, 1 16-QAM, 2 64-QAM, 3 256-QAM
     int fec_size, bits_per_cell, cells_per_fec;

@@ -36,6 +36,55 @@ hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, 
     return hipGetLastError();
 }
 
+// K-descramble-pack: the same XOR, with the bit -> byte packing of bb_de_header::execute (bb_de_header.cpp:84-448: every byte it
+// emits is assembled MSB first from 8 bit-bytes) done where the bits already are: out[f][j] = pack(in[f][8j .. 8j+7] ^ prbs), k_bch / 8
+// bytes per BBFRAME. HBM-bound: k_ldpc-strided bit-bytes in (8 per lane and load: a wavefront reads 512 contiguous bytes), packed
+// bytes out (rows of k_bch / 8 bytes are not word aligned for most codes, so a lane stores its byte: 64 contiguous bytes per
+// wavefront store, one ninth of the traffic). The PRBS comes packed too (one byte per output byte, 6.7 KB, cache resident).
+// A bit-byte is 0 or 1 (LDPC hard decisions); the multiply gathers the 8 low bits of a little-endian 64-bit word, first byte
+// into the top bit of the result.
+constexpr int PACK_UNROLL = 4;
+__global__ __launch_bounds__(256) void bch_descramble_pack_kernel(const uint8_t *__restrict__ bits, long total_bytes, int k_ldpc, int row_bytes,
+                                                                 const uint8_t *__restrict__ prbs_packed, uint8_t *__restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i0 < total_bytes; i0 += PACK_UNROLL * stride) {
+        uint2 v[PACK_UNROLL];
+        int j[PACK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PACK_UNROLL; ++u) {
+            const long i = i0 + u * stride;
+            v[u] = make_uint2(0u, 0u); j[u] = 0;
+            if (i < total_bytes) {
+                const long f = i / row_bytes;
+                j[u] = (int)(i - f * row_bytes);
+                v[u] = *reinterpret_cast<const uint2 *>(bits + f * k_ldpc + 8L * j[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PACK_UNROLL; ++u) {
+            const long i = i0 + u * stride;
+            if (i < total_bytes) {
+                // bytes b0..b3 of a word w (each 0 / 1): (w * 0x08040201) >> 24 gives b0 << 3 | b1 << 2 | b2 << 1 | b3 in its low nibble
+                const uint32_t hi = ((v[u].x & 0x01010101u) * 0x08040201u) >> 24, lo = ((v[u].y & 0x01010101u) * 0x08040201u) >> 24;
+                out[i] = (uint8_t)((((hi & 15u) << 4) | (lo & 15u)) ^ prbs_packed[j[u]]);
+            }
+        }
+    }
+}
+
+hipError_t launch_bch_descramble_pack(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs_packed, uint8_t *out,
+                                      hipStream_t s)
+{
+    const long total = (long)n_frames * (k_bch / 8);
+    long blocks = (total + 256L * PACK_UNROLL - 1) / (256L * PACK_UNROLL);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bch_descramble_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, bits, total, k_ldpc, k_bch / 8, prbs_packed, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------- demapper
 // Replaces llr_demapper::execute and qpsk/qam16/qam64/qam256 (/root/reference/src/DVB_T2/llr_demapper.cpp:132-158,
 // 160-228, 230-364, 366-535, 537-768). Floating-point products and sums are written with the non-contracting

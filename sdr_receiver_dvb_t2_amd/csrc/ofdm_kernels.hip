@@ -383,7 +383,9 @@ __global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const f
             const float dr = cr[u] / amp, di = sr[u] / amp;
             const float2 v = make_float2(l_re[car[u]], l_im[car[u]]);
             const int at = (int)l_h[dl] - p.out_skip;
-            if (at >= 0) o[at] = make_float2(v.x * dr + v.y * di, v.y * dr - v.x * di);   // buffer_cell[j] * conj(derotate)
+            const float2 eq = make_float2(v.x * dr + v.y * di, v.y * dr - v.x * di);     // buffer_cell[j] * conj(derotate)
+            if (at >= 0) o[at] = eq;
+            else if (p.skip_out) p.skip_out[(size_t)fr * p.out_skip + l_h[dl]] = eq;
         }
     }
 }

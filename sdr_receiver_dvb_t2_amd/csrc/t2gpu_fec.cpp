@@ -354,6 +354,7 @@ extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float
 static std::mutex g_prbs_mutex;
 static std::map<int, uint8_t *> g_prbs;      // per device
 
+// bit-per-byte sequence [54000] followed by the same sequence packed MSB first [6750]
 static const uint8_t *prbs_on_device(int device)
 {
     std::lock_guard<std::mutex> lk(g_prbs_mutex);
@@ -361,8 +362,11 @@ static const uint8_t *prbs_on_device(int device)
     if (it != g_prbs.end()) return it->second;
     std::vector<uint8_t> bits;
     bb_prbs(bits, 54000);
+    bits.resize(54000 + 6750, 0);
+    for (int j = 0; j < 6750; ++j)
+        for (int n = 0; n < 8; ++n) bits[54000 + j] |= (uint8_t)((bits[8 * j + n] & 1) << (7 - n));
     uint8_t *d = nullptr;
-    if (!hip_ok(hipMalloc(&d, 54000), "hipMalloc") || !hip_ok(hipMemcpy(d, bits.data(), 54000, hipMemcpyHostToDevice), "hipMemcpy"))
+    if (!hip_ok(hipMalloc(&d, bits.size()), "hipMalloc") || !hip_ok(hipMemcpy(d, bits.data(), bits.size(), hipMemcpyHostToDevice), "hipMemcpy"))
         return nullptr;
     g_prbs[device] = d;
     return d;
@@ -380,6 +384,20 @@ extern "C" int t2gpu_bch_descramble_dev(int fec_type, int code_rate, const uint8
     static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
     T2_HIP(launch_bch_descramble(d_bits, n_frames, k_ldpc[id], ldpc_k_bch(id), prbs, d_out, (hipStream_t)stream));
     return ldpc_k_bch(id);
+}
+
+extern "C" int t2gpu_bch_descramble_pack_dev(int fec_type, int code_rate, const uint8_t *d_bits, int n_frames, uint8_t *d_bytes,
+                                             void *stream)
+{
+    const int id = ldpc_code_id(fec_type, code_rate);
+    if (id < 0 || !d_bits || !d_bytes || n_frames < 1) { set_error("t2gpu_bch_descramble_pack_dev: bad arguments"); return -1; }
+    int device = 0;
+    T2_HIP(hipGetDevice(&device));
+    const uint8_t *prbs = prbs_on_device(device);
+    if (!prbs) return -1;
+    static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
+    T2_HIP(launch_bch_descramble_pack(d_bits, n_frames, k_ldpc[id], ldpc_k_bch(id), prbs + 54000, d_bytes, (hipStream_t)stream));
+    return ldpc_k_bch(id) / 8;
 }
 
 extern "C" int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *bits, int n_frames, uint8_t *out)

@@ -52,6 +52,8 @@ static bool use_packed(const t2gpu_ldpc *h)
 }
 
 static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->blocks_per_cu; }
+// the in-kernel profile is indexed by the workgroup id of whichever kernel runs: room for the larger of the two grids
+static size_t prof_blocks(const t2gpu_ldpc *h) { return std::max(h->state_blocks, h->state2_blocks); }
 
 extern "C" int t2gpu_ldpc_graph_stats(int fec_type, int code_rate, int *links_total, int *layers,
                                       int *levels_total, int *max_cnt)
@@ -199,6 +201,21 @@ extern "C" int t2gpu_ldpc_info(const t2gpu_ldpc *h, int *fec_size, int *k_ldpc, 
     return 0;
 }
 
+// What the decode launches occupy on the device: {workgroups resident per CU, wavefronts per workgroup, dynamic LDS bytes per workgroup,
+// FEC frames per workgroup, CUs, SIMD batches resident at once}
+extern "C" int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6)
+{
+    if (!h || !out6) { set_error("t2gpu_ldpc_occupancy: bad arguments"); return -1; }
+    const bool packed = use_packed(h);
+    out6[0] = packed ? h->p_blocks_per_cu : h->blocks_per_cu;
+    out6[1] = T2GPU_LDPC_THREADS / 64;                                                   // 768 lanes: two per check node of a layer (ldpc_cn2.h / ldpc_cn3.h)
+    out6[2] = packed ? h->p_lds_bytes : h->lds_bytes;
+    out6[3] = packed ? 2 : 1;
+    out6[4] = h->num_cu;
+    out6[5] = (h->num_cu * out6[0]) / (packed ? std::max(h->group / 2, 1) : h->group);
+    return 0;
+}
+
 extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uint8_t *d_bits,
                                       int8_t *d_llr_out, int *d_trials_left, void *stream)
 {
@@ -239,9 +256,9 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.lds_ent_offset = packed ? h->p_lds_ent_offset : h->lds_ent_offset;
     p.n_entries = (int)h->g.entries.size();
     p.prof = h->d_prof;
-    p.prof_blocks = (int)h->state_blocks;
+    p.prof_blocks = (int)prof_blocks(h);
     p.resident = h->d_resident;
-    if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, (h->state_blocks * 8 + 64) * sizeof(long long), s));
+    if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, (prof_blocks(h) * 8 + 64) * sizeof(long long), s));
     // One persistent launch walks all batches (best when batches take different numbers of sweeps). T2GPU_LDPC_ROUNDS_PER_LAUNCH=r
     // cuts it into launches of r rounds of `nslots` batches: workgroups of other streams that need a whole CU's LDS (the 32K FFT)
     // then get in at the launch boundaries instead of waiting for the whole decode.
@@ -296,7 +313,7 @@ extern "C" int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream)
 extern "C" int t2gpu_ldpc_profile_layers(t2gpu_ldpc *h, long long *out64)
 {
     if (!h || !h->d_prof || !out64) return -1;
-    T2_HIP(hipMemcpy(out64, h->d_prof + h->state_blocks * 8, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    T2_HIP(hipMemcpy(out64, h->d_prof + prof_blocks(h) * 8, 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -304,21 +321,22 @@ extern "C" int t2gpu_ldpc_profile(t2gpu_ldpc *h, long long *out8)
 {
     if (!h) return -1;
     if (!h->d_prof) {           // first call arms the counters for subsequent launches
-        T2_HIP(hipMalloc(&h->d_prof, (h->state_blocks * 8 + 64) * sizeof(long long)));
-        T2_HIP(hipMemset(h->d_prof, 0, (h->state_blocks * 8 + 64) * sizeof(long long)));
+        T2_HIP(hipMalloc(&h->d_prof, (prof_blocks(h) * 8 + 64) * sizeof(long long)));
+        T2_HIP(hipMemset(h->d_prof, 0, (prof_blocks(h) * 8 + 64) * sizeof(long long)));
     }
     if (out8) {
-        std::vector<long long> v(h->state_blocks * 8);
+        const size_t nblk = prof_blocks(h);
+        std::vector<long long> v(nblk * 8);
         T2_HIP(hipMemcpy(v.data(), h->d_prof, v.size() * sizeof(long long), hipMemcpyDeviceToHost));
         for (int k = 0; k < 6; ++k) {
             long long sum = 0;
-            for (size_t b = 0; b < h->state_blocks; ++b) sum += v[b * 8 + k];
+            for (size_t b = 0; b < nblk; ++b) sum += v[b * 8 + k];
             out8[k] = sum;
         }
         // [6] = sum of workgroup lifetimes, [7] = span first start .. last end (100 MHz wall clock ticks)
         long long life = 0, t_min = 0, t_max = 0;
         bool first = true;
-        for (size_t b = 0; b < h->state_blocks; ++b) {
+        for (size_t b = 0; b < nblk; ++b) {
             long long a = v[b * 8 + 6], z = v[b * 8 + 7];
             if (!a || !z) continue;
             life += z - a;

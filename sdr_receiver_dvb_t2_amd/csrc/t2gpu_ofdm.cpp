@@ -364,8 +364,24 @@ extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
 
 // The P2 / frame-closing symbol of every frame read in place from the frames' spectra and written in place into the frames' cell
 // streams (as t2gpu_eq_data_frames_dev does for the data symbols): no gather of the symbols, no copy of the cells.
+namespace {
+int eq_p2_frames(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells, long cells_frame_stride,
+                 int skip_cells, float *d_l1_cells, float *d_sync, void *stream);
+}
 extern "C" int t2gpu_eq_p2_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
                                       long cells_frame_stride, int skip_cells, float *d_sync, void *stream)
+{
+    return eq_p2_frames(h, d_spectrum, n_frames, syms_per_frame, d_cells, cells_frame_stride, skip_cells, nullptr, d_sync, stream);
+}
+// the same, with the skipped cells (L1-pre + L1-post) of frame f stored at d_l1_cells + 2 * f * skip_cells
+extern "C" int t2gpu_eq_p2_frames_l1_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
+                                         long cells_frame_stride, int skip_cells, float *d_l1_cells, float *d_sync, void *stream)
+{
+    return eq_p2_frames(h, d_spectrum, n_frames, syms_per_frame, d_cells, cells_frame_stride, skip_cells, d_l1_cells, d_sync, stream);
+}
+namespace {
+int eq_p2_frames(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells, long cells_frame_stride,
+                 int skip_cells, float *d_l1_cells, float *d_sync, void *stream)
 {
     if (!h || !d_spectrum || !d_cells || n_frames < 1 || n_frames > h->max_symbols || syms_per_frame < 1 || skip_cells < 0 ||
         skip_cells > h->m.c_p2 || cells_frame_stride < h->m.c_p2 - skip_cells) {
@@ -375,10 +391,12 @@ extern "C" int t2gpu_eq_p2_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, in
     EqParams p = h->eq_p2;
     p.per_frame = 1; p.first = 0; p.in_syms_per_frame = syms_per_frame;
     p.out_frame_stride = cells_frame_stride; p.out_offset = 0; p.out_skip = skip_cells;
+    p.skip_out = reinterpret_cast<float2 *>(d_l1_cells);
     T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, n_frames, reinterpret_cast<float2 *>(d_cells),
                           h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.c_p2 - skip_cells;
 }
+}  // namespace
 
 extern "C" int t2gpu_eq_fc_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, float *d_cells,
                                       long cells_frame_stride, long cells_offset, float *d_sync, void *stream)

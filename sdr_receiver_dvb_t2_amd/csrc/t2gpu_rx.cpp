@@ -4,15 +4,26 @@
 // Call sequence per buffer (reference: /root/reference/src/DVB_T2/dvbt2_demodulator.cpp): front end (:145-226) -> P1 detection at
 // every frame start (p1_symbol::execute via symbol_acquisition :279-310) -> guard-interval correlation of every symbol
 // (:321-330) -> FFT with the guard dropped by addressing (:332-334) -> P2 / data / frame-closing equalisers -> time
-// de-interleaver -> demapper -> LDPC -> BCH stub. The tracking loops run open: a synchronous source needs none, and what the
-// loops would consume (P1 position and offset, guard correlation) is handed back. This is what bench.py times; the closed-loop,
-// symbol-by-symbol form is t2gpu_demod.cpp.
+// de-interleaver -> demapper -> LDPC -> BCH stub + bit packing -> (host worker) L1 parse + BBFRAME de-framing -> TS. The tracking
+// loops run open: a synchronous source needs none, and what the loops would consume (P1 position and offset, guard correlation) is
+// handed back. This is what bench.py times; the closed-loop, symbol-by-symbol form is t2gpu_demod.cpp.
+//
+// SIMD batches are formed as the reference forms them (llr_demapper.cpp:742-764: `static int blocks`, the 32-frame LLR buffer
+// fills across TI blocks and T2 frames and only a full one is handed to the LDPC stage): the LLR frames of an incomplete batch stay
+// at the head of the LLR buffer in the handle and the next call's frames are demapped behind them. t2gpu_rx_flush_dev (end of
+// stream; the reference has no such thing and simply never decodes the tail) decodes the remainder as one short batch.
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace t2gpu;
@@ -48,6 +59,50 @@ struct t2gpu_rx {
     float *d_sync = nullptr;                  // sample_rate_offset / phase_offset of every symbol (data_symbol.cpp:319-324): always computed
     std::vector<t2gpu_p1_result> p1_res;
     std::vector<long> p2_start;
+    // SIMD-batch formation across calls
+    int group = T2GPU_SIMD_BATCH;
+    int carry = 0;                            // LLR frames of the incomplete batch at the head of d_llr
+    int last_ready = 0;                       // FEC frames the last back half (+ flush) decoded: rows of d_pack / entries of d_trials
+    long fec_seq = 0;                         // running FEC-frame number of the first frame of the next decode
+    long t2_seq = 0;                          // running T2-frame number of the first frame of the next back half
+    uint8_t *d_pack = nullptr;                // descrambled BBFRAMEs, packed MSB first: [frames][k_bch / 8]
+    float *d_l1 = nullptr;                    // equalised L1-pre + L1-post cells of every P2 symbol: [F][p2_skip][2]
+    struct TsEnd *ts = nullptr;               // host end of the path (t2gpu_rx_ts_enable)
+};
+
+// ---- the host end: per-frame L1 parse (CRC-32 gating, dynamic signalling against the configured mode) and BBFRAME de-framing on a
+// worker thread, overlapped with the device work of later calls. Replaces, for the batch form, p2_symbol::l1_pre_info / l1_post_info
+// as called per P2 symbol (p2_symbol.cpp:301-718, dvbt2_demodulator.cpp:373-425) and bb_de_header::execute per BBFRAME
+// (bb_de_header.cpp:84-448; the drop of undecodable SIMD batches is ldpc_decoder.cpp:264-268).
+struct TsJob {
+    int slot = 0, fec_frames = 0, t2_frames = 0;
+    long fec_first = 0, t2_first = 0;
+};
+struct TsSlot {
+    uint8_t *pack = nullptr;                  // pinned: [frames][k_bch / 8]
+    int32_t *trials = nullptr;                // pinned: [batches]
+    float *l1 = nullptr;                      // pinned: [F][p2_skip][2]
+    hipEvent_t ready = nullptr;
+    bool busy = false;
+};
+struct TsEnd {
+    static constexpr int SLOTS = 3;
+    t2gpu_rx *rx = nullptr;
+    t2gpu_bbdh *bbdh = nullptr;
+    int need_plp = 0, l1_check = 0;
+    TsSlot slot[SLOTS];
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::deque<TsJob> jobs;
+    int next_slot = 0, in_flight = 0;
+    bool stop = false;
+    hipStream_t copy_stream = nullptr;        // the device -> host copies run beside the next call's kernels
+    hipEvent_t decoded = nullptr;             // recorded on the call's stream behind K-descramble-pack
+    hipEvent_t last_copy = nullptr;           // `ready` of the newest job: the next back half waits for it before it overwrites the rows
+    std::vector<uint8_t> ts;                  // TS bytes not yet read
+    std::deque<std::pair<long, int>> l1_status;   // (running T2-frame number, status bits) of frames whose FEC frames may still come
+    t2gpu_rx_ts_counters n{};
 };
 
 namespace {
@@ -65,7 +120,30 @@ void free_all(t2gpu_rx *h)
     if (h->ev_ldpc0) hipEventDestroy(h->ev_ldpc0);
     if (h->ev_ldpc1) hipEventDestroy(h->ev_ldpc1);
     for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
-    hipFree(h->d_sync);
+    hipFree(h->d_sync); hipFree(h->d_pack); hipFree(h->d_l1);
+}
+
+void ts_stop(t2gpu_rx *h)
+{
+    TsEnd *t = h->ts;
+    if (!t) return;
+    {
+        std::lock_guard<std::mutex> lk(t->m);
+        t->stop = true;
+    }
+    t->cv_job.notify_all();
+    if (t->worker.joinable()) t->worker.join();
+    for (TsSlot &sl : t->slot) {
+        if (sl.pack) hipHostFree(sl.pack);
+        if (sl.trials) hipHostFree(sl.trials);
+        if (sl.l1) hipHostFree(sl.l1);
+        if (sl.ready) hipEventDestroy(sl.ready);
+    }
+    if (t->bbdh) t2gpu_bbdh_destroy(t->bbdh);
+    if (t->copy_stream) hipStreamDestroy(t->copy_stream);
+    if (t->decoded) hipEventDestroy(t->decoded);
+    delete t;
+    h->ts = nullptr;
 }
 
 // stage k ends here: event k + 1 (event 0 = start of the call)
@@ -122,6 +200,8 @@ extern "C" t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *c, int device)
              t2gpu_ti_begin(h->ti, c->plp_num_blocks) == 0;
     }
     const int group = c->ldpc_group > 0 ? c->ldpc_group : T2GPU_SIMD_BATCH;
+    h->group = group;
+    ok = ok && dev_alloc(h->d_pack, (size_t)(nb + 64) * (h->k_bch / 8)) && dev_alloc(h->d_l1, 2 * (size_t)F * std::max(h->p2_skip, 1));
     ok = ok && dev_alloc(h->d_stream, 2 * (size_t)(n_max + 64)) && dev_alloc(h->d_spec, 2 * (size_t)F * h->n_sym * h->fft_size) &&
          dev_alloc(h->d_p2_in, 2 * (size_t)F * h->fft_size) && dev_alloc(h->d_p2_cells, 2 * (size_t)F * h->c_p2) &&
          dev_alloc(h->d_fc_cells, 2 * (size_t)F * std::max(h->n_fc, 1)) && dev_alloc(h->d_cells, 2 * (size_t)F * h->frame_cells) &&
@@ -149,6 +229,7 @@ extern "C" void t2gpu_rx_destroy(t2gpu_rx *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    ts_stop(h);
     free_all(h);
     delete h;
 }
@@ -207,15 +288,17 @@ extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t
 }
 
 namespace {
-// equalisers -> time de-interleaver -> demapper on the spectra in d_spec (stages 4..6)
-int rx_eq_ti_demap(t2gpu_rx *h, int F, hipStream_t s)
+// equalisers -> time de-interleaver -> demapper on the spectra in d_spec (stages 4..6); the LLR frames land behind the `llr_at`
+// frames already waiting in d_llr
+int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
 {
     // P2, data symbols, frame-closing symbol: read in place from the spectra, written in place into the cell streams (P2 without
-    // its L1 cells, time_deinterleaver.cpp:296-300). The per-symbol synchronisation sums the reference always forms
-    // (p2_symbol.cpp:253-258, data_symbol.cpp:319-324, fc_symbol.cpp:257-262) are formed too; with the loops open nobody reads them.
+    // its L1 cells, time_deinterleaver.cpp:296-300; those go to d_l1 for the host's per-frame L1 parse). The per-symbol
+    // synchronisation sums the reference always forms (p2_symbol.cpp:253-258, data_symbol.cpp:319-324, fc_symbol.cpp:257-262) are
+    // formed too; with the loops open nobody reads them.
     const int a = h->c_p2 - h->p2_skip;
     float *sy = h->d_sync;
-    if (t2gpu_eq_p2_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, sy, s) < 0) return -1;
+    if (t2gpu_eq_p2_frames_l1_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, h->d_l1, sy, s) < 0) return -1;
     if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, sy + 2 * (size_t)F, s) < 0) return -1;
     if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data,
                                           sy + 2 * (size_t)F * (1 + h->n_dat), s) < 0)
@@ -225,14 +308,32 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, hipStream_t s)
     if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
     if (!mark(h, 6, s)) return -1;                                                      // time / cell de-interleaver
     if (t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0) return -1;
-    if (t2gpu_demap_llr_batch_dev(h->demap, h->d_ti_out, F, h->n_ti, h->d_sums, 4, h->d_llr, s) < 0) return -1;
+    if (t2gpu_demap_llr_batch_dev(h->demap, h->d_ti_out, F, h->n_ti, h->d_sums, 4, h->d_llr + (size_t)llr_at * h->fec_size, s) < 0) return -1;
     if (!mark(h, 7, s)) return -1;                                                      // demapper
     return 0;
 }
+
+// LDPC + (opt-in outer code) + K-descramble-pack of d_llr[0 .. count) into rows `at`.. of d_bits / d_pack, trials from batch `at / group`
+int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s)
+{
+    uint8_t *bits = h->d_bits + (size_t)at * h->k_ldpc;
+    T2_HIP(hipEventRecord(h->ev_ldpc0, s));
+    if (t2gpu_ldpc_execute_dev(h->ldpc, h->d_llr, count, bits, nullptr, h->d_trials + at / h->group, s) != 0) return -1;
+    T2_HIP(hipEventRecord(h->ev_ldpc1, s));
+    h->timed = true;
+    if (!mark(h, 8, s)) return -1;                                                      // LDPC
+    if (h->outer_code && t2gpu_bch_decode_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, bits, count, h->d_outer + at, s) < 0) return -1;
+    if (t2gpu_bch_descramble_pack_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, bits, count, h->d_pack + (size_t)at * (h->k_bch / 8), s) < 0) return -1;
+    if (!mark(h, 9, s)) return -1;                                                      // BCH stub / descrambler + bit packing
+    return 0;
+}
+
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s);
 }  // namespace
 
 // BASELINE config 2: FFT (guard dropped) + equalisers / frequency de-interleave + time de-interleave + demap of the frames the last
-// front half left in the handle (stream, frame positions). Enqueue only.
+// front half left in the handle (stream, frame positions). Enqueue only. The LLRs overwrite the head of the LLR buffer: not to be
+// mixed with back halves on a handle that carries an incomplete batch.
 extern "C" int t2gpu_rx_fft_eq_demap_dev(t2gpu_rx *h, int n_frames, void *stream)
 {
     if (!h || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_fft_eq_demap_dev: bad arguments"); return -1; }
@@ -242,37 +343,273 @@ extern "C" int t2gpu_rx_fft_eq_demap_dev(t2gpu_rx *h, int n_frames, void *stream
     if (t2gpu_fft_execute_strided_dev(h->ofdm, h->d_stream, h->p2_start[0] + h->guard, h->frame_len, h->n_sym, h->sym_size, h->d_spec,
                                       n_frames * h->n_sym, stream) != 0) return -1;
     if (!mark(h, 4, (hipStream_t)stream)) return -1;
-    return rx_eq_ti_demap(h, n_frames, (hipStream_t)stream);
+    h->carry = 0;
+    return rx_eq_ti_demap(h, n_frames, 0, (hipStream_t)stream);
 }
 
-// back half: equalisers, time de-interleaver, demapper, LDPC (every FEC frame, the tail batch short), descrambler
-extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bits_out, int32_t **d_trials_out, void *stream)
+// back half: equalisers, time de-interleaver, demapper; then LDPC + descrambler + bit packing of every COMPLETE SIMD batch (the
+// frames waiting from earlier calls first), the rest waits in the handle. Returns the number of FEC frames decoded by this call.
+extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream)
 {
     if (!h || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_back_dev: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
-    if (rx_eq_ti_demap(h, F, s) != 0) return -1;
-    const int count = F * nb;
-    T2_HIP(hipEventRecord(h->ev_ldpc0, s));
-    if (t2gpu_ldpc_execute_dev(h->ldpc, h->d_llr, count, h->d_bits, nullptr, h->d_trials, s) != 0) return -1;
-    T2_HIP(hipEventRecord(h->ev_ldpc1, s));
-    h->timed = true;
-    if (!mark(h, 8, s)) return -1;                                                      // LDPC
-    if (h->outer_code && t2gpu_bch_decode_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_outer, s) < 0) return -1;
-    if (t2gpu_bch_descramble_dev(h->cfg.plp_fec_type, h->cfg.plp_cod, h->d_bits, count, h->d_out, s) < 0) return -1;
-    if (!mark(h, 9, s)) return -1;                                                      // BCH stub / descrambler
-    if (d_bits_out) *d_bits_out = h->d_out;
+    // the host end's copies of the previous decode run on their own stream: they must be through before this call overwrites the rows
+    if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(s, h->ts->last_copy, 0));
+    if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
+    const int total = h->carry + F * nb;
+    const int ready = (total / h->group) * h->group;
+    if (ready > 0 && rx_decode(h, ready, 0, s) != 0) return -1;
+    const int rest = total - ready;
+    if (rest > 0 && ready > 0)                                   // ready >= group > rest: source and destination do not overlap
+        T2_HIP(hipMemcpyAsync(h->d_llr, h->d_llr + (size_t)ready * h->fec_size, (size_t)rest * h->fec_size, hipMemcpyDeviceToDevice, s));
+    h->carry = rest;
+    h->last_ready = ready;
+    if (h->ts && ts_submit(h, ready, 0, F, s) != 0) return -1;
+    h->fec_seq += ready;
+    h->t2_seq += F;
+    if (d_bytes_out) *d_bytes_out = h->d_pack;
     if (d_trials_out) *d_trials_out = h->d_trials;
-    return count;
+    return ready;
+}
+
+// End of stream: the frames still waiting for a full batch are decoded as one short batch (an addition: the reference never decodes
+// them). Their rows follow those of the last back half in the output buffers. Returns the number of FEC frames flushed.
+extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
+{
+    if (!h) { set_error("t2gpu_rx_flush_dev: null handle"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int n = h->carry;
+    if (n == 0) return 0;
+    const int at = h->last_ready;                                // a multiple of the group: trials of the short batch at at / group
+    if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(s, h->ts->last_copy, 0));
+    if (rx_decode(h, n, at, s) != 0) return -1;
+    h->carry = 0;
+    h->last_ready = at + n;
+    if (h->ts && ts_submit(h, n, at, 0, s) != 0) return -1;
+    h->fec_seq += n;
+    return n;
+}
+
+extern "C" int t2gpu_rx_carry(const t2gpu_rx *h) { return h ? h->carry : -1; }
+extern "C" int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6) { return h ? t2gpu_ldpc_occupancy(h->ldpc, out6) : -1; }
+
+extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
+{
+    if (!h) { set_error("t2gpu_rx_reset: null handle"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipDeviceSynchronize());
+    if (h->ts) {
+        std::unique_lock<std::mutex> lk(h->ts->m);
+        h->ts->cv_done.wait(lk, [&] { return h->ts->in_flight == 0; });
+        h->ts->l1_status.clear();
+    }
+    h->carry = 0; h->last_ready = 0; h->fec_seq = 0; h->t2_seq = 0;
+    return 0;
 }
 
 extern "C" int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call,
-                                    uint8_t **d_bits_out, int32_t **d_trials_out, void *stream)
+                                    uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream)
 {
     const int rc = t2gpu_rx_front_dev(h, d_i, d_q, n_frames, level_detect, first_call, stream);
     if (rc != 0) return rc;
-    return t2gpu_rx_back_dev(h, n_frames, d_bits_out, d_trials_out, stream);
+    return t2gpu_rx_back_dev(h, n_frames, d_bytes_out, d_trials_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host end
+namespace {
+// status bits of a T2 frame's L1 signalling
+constexpr int L1_PRE_OK = 1, L1_POST_OK = 2, L1_MATCH = 4;
+
+int l1_frame_status(const t2gpu_rx *h, const float *cells)
+{
+    const t2gpu_rx_config &c = h->cfg;
+    t2gpu_l1_pre pre;
+    if (t2gpu_l1_pre_parse(cells, &pre) != 1) return 0;
+    int st = L1_PRE_OK;
+    bool match = pre.bwt_ext == c.carrier_mode && pre.guard_interval == c.guard_interval_mode && pre.papr == c.papr_mode &&
+                 pre.pilot_pattern == c.pilot_pattern && pre.num_data_symbols == c.n_data && pre.l1_post_size == c.l1_post_size;
+    if (!match) return st;                                       // L1-post cannot be located with another L1_POST_SIZE
+    t2gpu_l1_post post;
+    t2gpu_l1_plp plp[16];
+    t2gpu_l1_dyn_plp dyn[16];
+    if (t2gpu_l1_post_parse(cells + 2 * L1_PRE_CELL, &pre, &post, plp, dyn, 16) != 1) return st;
+    st |= L1_POST_OK;
+    int first = -1;                                              // the PLP that starts the frame (time_deinterleaver.cpp:302-304)
+    for (int i = 0; i < post.num_plp && i < 16; ++i) if (dyn[i].start == 0) first = i;
+    match = first >= 0 && plp[first].plp_mod == c.plp_mod && plp[first].plp_cod == c.plp_cod && plp[first].plp_fec_type == c.plp_fec_type &&
+            (plp[first].plp_rotation != 0) == (c.plp_rotation != 0) && plp[first].time_il_type == 0 && plp[first].time_il_length == 1 &&
+            dyn[first].num_blocks == c.plp_num_blocks;
+    return match ? st | L1_MATCH : st;
+}
+
+void ts_worker(TsEnd *t)
+{
+    t2gpu_rx *h = t->rx;
+    hipSetDevice(h->device);
+    const int row = h->k_bch / 8, nb = h->cfg.plp_num_blocks;
+    std::vector<uint8_t> out((size_t)row + 2 * 188 + 64);
+    std::vector<uint8_t> local;
+    for (;;) {
+        TsJob j;
+        {
+            std::unique_lock<std::mutex> lk(t->m);
+            t->cv_job.wait(lk, [&] { return t->stop || !t->jobs.empty(); });
+            if (t->jobs.empty()) return;                         // stop, nothing queued
+            j = t->jobs.front();
+            t->jobs.pop_front();
+        }
+        TsSlot &sl = t->slot[j.slot];
+        const bool ok = hipEventSynchronize(sl.ready) == hipSuccess;
+        t2gpu_rx_ts_counters d{};
+        local.clear();
+        if (ok) {
+            std::vector<std::pair<long, int>> st;
+            if (t->l1_check)
+                for (int f = 0; f < j.t2_frames; ++f) {
+                    const int v = l1_frame_status(h, sl.l1 + 2 * (size_t)f * h->p2_skip);
+                    st.emplace_back(j.t2_first + f, v);
+                    ++d.t2_frames;
+                    if (!(v & L1_PRE_OK)) ++d.l1_pre_crc_errors;
+                    else if (!(v & L1_POST_OK)) ++d.l1_post_crc_errors;
+                    else if (!(v & L1_MATCH)) ++d.l1_mismatches;
+                }
+            else d.t2_frames = j.t2_frames;
+            std::deque<std::pair<long, int>> known;
+            {
+                std::lock_guard<std::mutex> lk(t->m);
+                for (auto &e : st) t->l1_status.push_back(e);
+                const long oldest = j.fec_first / nb;            // T2 frame of the first FEC frame of this job
+                while (!t->l1_status.empty() && t->l1_status.front().first < oldest) t->l1_status.pop_front();
+                known = t->l1_status;
+            }
+            for (int i = 0; i < j.fec_frames; ++i) {
+                ++d.fec_frames;
+                if (sl.trials[i / h->group] < 0) { ++d.fec_frames_dropped_ldpc; continue; }        // ldpc_decoder.cpp:264-268
+                if (t->l1_check) {
+                    const long tf = (j.fec_first + i) / nb;
+                    int v = 0;
+                    for (auto &e : known) if (e.first == tf) v = e.second;
+                    if (v != (L1_PRE_OK | L1_POST_OK | L1_MATCH)) { ++d.fec_frames_dropped_l1; continue; }
+                }
+                int err = 0;
+                const int n = t2gpu_bbdh_execute_packed(t->bbdh, t->need_plp, h->k_bch, sl.pack + (size_t)i * row, out.data(), (int)out.size(), &err);
+                if (n == -1) ++d.bbheader_crc_errors;
+                d.ts_packet_errors += err;
+                d.resync += t2gpu_bbdh_resync_count(t->bbdh);
+                if (n > 0) local.insert(local.end(), out.begin(), out.begin() + n);
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(t->m);
+            t->ts.insert(t->ts.end(), local.begin(), local.end());
+            t->n.t2_frames += d.t2_frames; t->n.l1_pre_crc_errors += d.l1_pre_crc_errors; t->n.l1_post_crc_errors += d.l1_post_crc_errors;
+            t->n.l1_mismatches += d.l1_mismatches; t->n.fec_frames += d.fec_frames; t->n.fec_frames_dropped_ldpc += d.fec_frames_dropped_ldpc;
+            t->n.fec_frames_dropped_l1 += d.fec_frames_dropped_l1; t->n.bbheader_crc_errors += d.bbheader_crc_errors;
+            t->n.ts_packet_errors += d.ts_packet_errors; t->n.resync += d.resync; t->n.ts_bytes += (long)local.size();
+            if (!ok) ++t->n.device_errors;
+            sl.busy = false;
+            --t->in_flight;
+        }
+        t->cv_done.notify_all();
+    }
+}
+
+// queue the device -> host copies of one decode (packed BBFRAME rows at.., their trials, the L1 cells of the call's T2 frames) behind it
+// on the stream and hand the job to the worker. Blocks only when all slots are still in use (the host end is SLOTS calls behind).
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s)
+{
+    TsEnd *t = h->ts;
+    if (fec_frames == 0 && t2_frames == 0) return 0;
+    int k;
+    {
+        std::unique_lock<std::mutex> lk(t->m);
+        k = t->next_slot;
+        t->cv_done.wait(lk, [&] { return !t->slot[k].busy; });
+        t->slot[k].busy = true;
+        t->next_slot = (k + 1) % TsEnd::SLOTS;
+        ++t->in_flight;
+    }
+    TsSlot &sl = t->slot[k];
+    const int row = h->k_bch / 8;
+    hipStream_t cs = t->copy_stream;
+    bool ok = hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
+    if (ok && fec_frames > 0) {
+        ok = hipMemcpyAsync(sl.trials, h->d_trials + at / h->group, (size_t)((fec_frames + h->group - 1) / h->group) * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+             hipMemcpyAsync(sl.pack, h->d_pack + (size_t)at * row, (size_t)fec_frames * row, hipMemcpyDeviceToHost, cs) == hipSuccess;
+    }
+    if (ok && t2_frames > 0 && t->l1_check)
+        ok = hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
+    ok = ok && hipEventRecord(sl.ready, cs) == hipSuccess;
+    t->last_copy = ok ? sl.ready : nullptr;
+    TsJob j;
+    j.slot = k; j.fec_frames = ok ? fec_frames : 0; j.t2_frames = ok ? t2_frames : 0; j.fec_first = h->fec_seq; j.t2_first = h->t2_seq;
+    {
+        std::lock_guard<std::mutex> lk(t->m);
+        t->jobs.push_back(j);
+    }
+    t->cv_job.notify_one();
+    if (!ok) { set_error("t2gpu_rx: device -> host copy of the decoded frames failed"); return -1; }
+    return 0;
+}
+}  // namespace
+
+// From now on every back half / flush also copies its packed BBFRAMEs (k_bch / 8 bytes per FEC frame), the batch verdicts and the
+// L1 cells of its T2 frames to pinned host memory behind the decode, and a worker thread of the handle turns them into TS bytes
+// while the device runs the next calls: per T2 frame L1-pre / L1-post parse with CRC-32 (l1_check != 0: BBFRAMEs of a T2 frame whose
+// CRCs fail or whose signalling differs from the handle's configuration are withheld and counted), per FEC frame the reference's
+// batch drop rule and bb_de_header. need_plp: bb_de_header::set_out's PLP (bb_de_header.cpp:500-525).
+extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
+{
+    if (!h) { set_error("t2gpu_rx_ts_enable: null handle"); return -1; }
+    if (h->ts) return 0;                                         // already running (need_plp / l1_check of the first call stay)
+    T2_HIP(hipSetDevice(h->device));
+    TsEnd *t = new TsEnd();
+    t->rx = h; t->need_plp = need_plp; t->l1_check = l1_check;
+    t->bbdh = t2gpu_bbdh_create(need_plp);
+    const size_t frames = (size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + 64;
+    bool ok = t->bbdh != nullptr;
+    for (TsSlot &sl : t->slot) {
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&sl.pack), frames * (h->k_bch / 8), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&sl.trials), (frames / h->group + 2) * 4, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&sl.l1), (size_t)h->cfg.max_frames * std::max(h->p2_skip, 1) * 8, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming) == hipSuccess;
+    h->ts = t;
+    if (!ok) { ts_stop(h); set_error("t2gpu_rx_ts_enable: pinned host memory allocation failed"); return -1; }
+    t->worker = std::thread(ts_worker, t);
+    return 0;
+}
+
+// TS bytes the worker has produced so far, oldest first; wait_all != 0 first waits until every call enqueued so far has been de-framed.
+// Returns the number of bytes copied (<= cap); the rest stays queued.
+extern "C" long t2gpu_rx_ts_read(t2gpu_rx *h, uint8_t *out, long cap, int wait_all)
+{
+    if (!h || !h->ts || (!out && cap > 0) || cap < 0) { set_error("t2gpu_rx_ts_read: bad arguments, or the TS end is not enabled"); return -1; }
+    TsEnd *t = h->ts;
+    std::unique_lock<std::mutex> lk(t->m);
+    if (wait_all) t->cv_done.wait(lk, [&] { return t->in_flight == 0; });
+    const long n = std::min<long>(cap, (long)t->ts.size());
+    if (n > 0) {
+        std::memcpy(out, t->ts.data(), (size_t)n);
+        t->ts.erase(t->ts.begin(), t->ts.begin() + n);
+    }
+    return n;
+}
+
+extern "C" int t2gpu_rx_ts_counters_get(t2gpu_rx *h, int wait_all, t2gpu_rx_ts_counters *out)
+{
+    if (!h || !h->ts || !out) { set_error("t2gpu_rx_ts_counters_get: bad arguments, or the TS end is not enabled"); return -1; }
+    TsEnd *t = h->ts;
+    std::unique_lock<std::mutex> lk(t->m);
+    if (wait_all) t->cv_done.wait(lk, [&] { return t->in_flight == 0; });
+    *out = t->n;
+    out->ts_bytes_pending = (long)t->ts.size();
+    return 0;
 }
 
 extern "C" int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect,
@@ -311,6 +648,7 @@ extern "C" int t2gpu_rx_stage_ms(t2gpu_rx *h, float *ms)
     for (int k = 0; k < T2GPU_RX_STAGES; ++k) {
         ms[k] = -1.0f;
         if (!h->ev_set[k] || !h->ev_set[k + 1]) continue;
+        T2_HIP(hipEventSynchronize(h->ev[k]));                   // both ends: a later call may have re-recorded event k already
         T2_HIP(hipEventSynchronize(h->ev[k + 1]));
         T2_HIP(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
     }
@@ -337,7 +675,7 @@ extern "C" int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable)
 
 extern "C" int t2gpu_rx_outer_code_status(t2gpu_rx *h, int n_fec_frames, int32_t *status)
 {
-    if (!h || !status || n_fec_frames < 0 || n_fec_frames > h->cfg.max_frames * h->cfg.plp_num_blocks || !h->outer_code) {
+    if (!h || !status || n_fec_frames < 0 || n_fec_frames > h->last_ready || !h->outer_code) {
         set_error("t2gpu_rx_outer_code_status: bad arguments, or the outer code is not enabled on this handle");
         return -1;
     }
@@ -347,13 +685,29 @@ extern "C" int t2gpu_rx_outer_code_status(t2gpu_rx *h, int n_fec_frames, int32_t
     return n_fec_frames;
 }
 
-extern "C" int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials)
+// rows of the last back half (+ flush): packed BBFRAMEs (k_bch / 8 bytes each, MSB first) and the verdict of every SIMD batch
+extern "C" int t2gpu_rx_fetch_packed(t2gpu_rx *h, int n_fec_frames, uint8_t *bytes, int32_t *trials)
 {
-    if (!h || n_fec_frames < 0 || n_fec_frames > h->cfg.max_frames * h->cfg.plp_num_blocks) { set_error("t2gpu_rx_fetch: bad arguments"); return -1; }
+    if (!h || n_fec_frames < 0 || n_fec_frames > h->last_ready) {
+        set_error("t2gpu_rx_fetch_packed: bad arguments (more frames than the last back half and flush decoded)");
+        return -1;
+    }
     T2_HIP(hipSetDevice(h->device));
     T2_HIP(hipDeviceSynchronize());
-    const int group = h->cfg.ldpc_group > 0 ? h->cfg.ldpc_group : T2GPU_SIMD_BATCH;
-    if (bits && n_fec_frames) T2_HIP(hipMemcpy(bits, h->d_out, (size_t)n_fec_frames * h->k_bch, hipMemcpyDeviceToHost));
-    if (trials && n_fec_frames) T2_HIP(hipMemcpy(trials, h->d_trials, (size_t)((n_fec_frames + group - 1) / group) * 4, hipMemcpyDeviceToHost));
+    if (bytes && n_fec_frames) T2_HIP(hipMemcpy(bytes, h->d_pack, (size_t)n_fec_frames * (h->k_bch / 8), hipMemcpyDeviceToHost));
+    if (trials && n_fec_frames) T2_HIP(hipMemcpy(trials, h->d_trials, (size_t)((n_fec_frames + h->group - 1) / h->group) * 4, hipMemcpyDeviceToHost));
     return t2gpu_ldpc_status(h->ldpc) == 0 ? 0 : -1;
+}
+
+// the same with one bit per byte (the reference's bit_descramble form, bch_decoder.h): the packed rows cross the bus, the host unpacks
+extern "C" int t2gpu_rx_fetch(t2gpu_rx *h, int n_fec_frames, uint8_t *bits, int32_t *trials)
+{
+    if (!h) { set_error("t2gpu_rx_fetch: null handle"); return -1; }
+    const int row = h->k_bch / 8;
+    std::vector<uint8_t> packed(bits ? (size_t)std::max(n_fec_frames, 0) * row : 0);
+    const int rc = t2gpu_rx_fetch_packed(h, n_fec_frames, bits ? packed.data() : nullptr, trials);
+    if (rc != 0 || !bits) return rc;
+    for (size_t i = 0; i < packed.size(); ++i)
+        for (int n = 0; n < 8; ++n) bits[8 * i + n] = (uint8_t)((packed[i] >> (7 - n)) & 1);
+    return 0;
 }

@@ -204,6 +204,20 @@ class bch_decoder(object):
             check(rc, "t2gpu_bch_descramble_dev")
         return out
 
+    def execute_packed_dev(self, bits):
+        """K-descramble-pack: [n][k_ldpc] device bits -> [n][k_bch / 8] device bytes (descrambled, MSB first): the byte assembly of
+        bb_de_header.cpp:84-448 done on the device; t2gpu_bbdh_execute_packed reads the rows."""
+        import torch
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous()
+        n_frames = bits.shape[0]
+        k_bch = {0: (7032, 9552, 10632, 11712, 12432, 13152), 1: (32208, 38688, 43040, 48408, 51648, 53840)}[self.fec_type][self.cod]
+        out = torch.empty((n_frames, k_bch // 8), dtype=torch.uint8, device=bits.device)
+        stream = torch.cuda.current_stream(bits.device).cuda_stream
+        rc = self._l.t2gpu_bch_descramble_pack_dev(self.fec_type, self.cod, bits.data_ptr(), n_frames, out.data_ptr(), stream)
+        if rc < 0:
+            check(rc, "t2gpu_bch_descramble_pack_dev")
+        return out
+
     def correct_dev(self, bits):
         """Apply the outer code in place on [n_frames][k_ldpc] device bits (opt-in: the reference does not, bch_decoder.cpp:136).
         Returns an int32 device tensor: bits corrected per frame, -1 = more than t errors (frame untouched)."""

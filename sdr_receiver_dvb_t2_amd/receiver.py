@@ -182,6 +182,12 @@ class rx_geometry(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in "frame_len n_sym fft_size guard_interval_size frame_cells fec_frames_per_t2_frame k_bch k_ldpc".split()]
 
 
+class rx_ts_counters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in "t2_frames l1_pre_crc_errors l1_post_crc_errors l1_mismatches fec_frames fec_frames_dropped_ldpc "
+                                              "fec_frames_dropped_l1 bbheader_crc_errors ts_packet_errors resync ts_bytes ts_bytes_pending "
+                                              "device_errors".split()]
+
+
 class t2_rx(object):
     """The same batch receiver as ``t2_receiver`` with nothing but the C ABI underneath (``t2gpu_rx_*``, csrc/t2gpu_rx.cpp): buffers,
     stage sequencing and launches live in the library; Python hands over two device pointers per buffer. This is what bench.py times."""
@@ -227,17 +233,58 @@ class t2_rx(object):
     def back_dev(self, n_frames, stream=None):
         return self._check(self._l.t2gpu_rx_back_dev(self._h, n_frames, None, None, self._stream(stream)), "t2gpu_rx_back_dev")
 
-    def execute_dev(self, d_i, d_q, n_frames, level_detect=0.0, first_call=False, stream=None):
+    def execute_dev(self, d_i, d_q, n_frames, level_detect=0.0, first_call=False, stream=None, flush=False):
         """d_i, d_q: int16 device tensors with n_frames whole frames from a P1 symbol on. Enqueues the whole path; returns the
-        number of FEC frames decoded (results: fetch / results)."""
-        return self._check(self._l.t2gpu_rx_execute_dev(self._h, d_i.data_ptr(), d_q.data_ptr(), n_frames, float(level_detect),
-                                                        int(first_call), None, None, self._stream(stream)), "t2gpu_rx_execute_dev")
+        number of FEC frames decoded by this call: the complete SIMD batches of (frames waiting from earlier calls + this call's), as
+        the reference forms them (llr_demapper.cpp:742-764); the rest waits in the handle (``carry``). flush=True (end of a stream)
+        also decodes the waiting frames as one short batch, which the reference never does. Results: fetch / fetch_packed / results."""
+        n = self._check(self._l.t2gpu_rx_execute_dev(self._h, d_i.data_ptr(), d_q.data_ptr(), n_frames, float(level_detect),
+                                                     int(first_call), None, None, self._stream(stream)), "t2gpu_rx_execute_dev")
+        return n + self.flush_dev(stream) if flush else n
+
+    def flush_dev(self, stream=None):
+        return self._check(self._l.t2gpu_rx_flush_dev(self._h, self._stream(stream)), "t2gpu_rx_flush_dev")
+
+    @property
+    def carry(self):
+        return self._l.t2gpu_rx_carry(self._h)
+
+    def reset(self):
+        self._check(self._l.t2gpu_rx_reset(self._h), "t2gpu_rx_reset")
+
+    def ldpc_occupancy(self):
+        v = (ctypes.c_int * 6)()
+        self._check(self._l.t2gpu_rx_ldpc_occupancy(self._h, v), "t2gpu_rx_ldpc_occupancy")
+        return dict(zip(("workgroups_per_cu", "waves_per_workgroup", "lds_bytes_per_workgroup", "frames_per_workgroup", "cus", "batches_resident"),
+                        (int(x) for x in v)))
 
     def fetch(self, count):
+        """(bits uint8 [count][k_bch] one bit per byte, trials-left int32 per SIMD batch) of the last back half (+ flush)."""
         bits = np.empty((count, self.k_bch), np.uint8)
         trials = np.empty(((count + self.group - 1) // self.group,), np.int32)
         self._check(self._l.t2gpu_rx_fetch(self._h, count, bits.ctypes.data, trials.ctypes.data), "t2gpu_rx_fetch")
         return bits, trials
+
+    def fetch_packed(self, count):
+        """(bytes uint8 [count][k_bch / 8] packed MSB first, trials-left int32 per SIMD batch): what crosses the bus."""
+        rows = np.empty((count, self.k_bch // 8), np.uint8)
+        trials = np.empty(((count + self.group - 1) // self.group,), np.int32)
+        self._check(self._l.t2gpu_rx_fetch_packed(self._h, count, rows.ctypes.data, trials.ctypes.data), "t2gpu_rx_fetch_packed")
+        return rows, trials
+
+    # ---- the host end inside the library: per-frame L1 parse + BBFRAME de-framing on a worker thread, overlapped with later calls
+    def ts_enable(self, need_plp=0, l1_check=True):
+        self._check(self._l.t2gpu_rx_ts_enable(self._h, need_plp, int(bool(l1_check))), "t2gpu_rx_ts_enable")
+
+    def ts_read(self, wait_all=True, cap=1 << 26):
+        out = np.empty(cap, np.uint8)
+        n = self._check(self._l.t2gpu_rx_ts_read(self._h, out.ctypes.data, cap, int(wait_all)), "t2gpu_rx_ts_read")
+        return out[:n].copy()
+
+    def ts_counters(self, wait_all=True):
+        c = rx_ts_counters()
+        self._check(self._l.t2gpu_rx_ts_counters_get(self._h, int(wait_all), ctypes.byref(c)), "t2gpu_rx_ts_counters_get")
+        return {n: int(getattr(c, n)) for n, _ in rx_ts_counters._fields_}
 
     def set_outer_code(self, enable=True):
         """Opt-in BCH check / correction of the LDPC output before the descrambler (the reference does none, bch_decoder.cpp:136)."""

@@ -66,6 +66,14 @@ def cases():
         dfl = int("".join(str(b) for b in hdr[32:48]), 2)
         idle[:80] = _header(dfl, 0xFFFF, tag == "hem", upl=(0 if tag == "hem" else 1504), sync=(0 if tag == "hem" else 0x47))
         out[tag + "_syncd_ffff"] = (K_BCH, [fr[0], fr[1], fr[2], idle, fr[4], fr[5]], [0] * 6)
+        # a data field that ends less than 8 bits into a packet: the frame leaves split = true with NO byte buffered; in normal
+        # mode the reference then emits buffer[0] of an earlier frame regardless (bb_de_header.cpp:168-171)
+        odd = fr.copy()
+        hdr = list(odd[2, :80])
+        syncd = int("".join(str(b) for b in hdr[56:72]), 2)
+        dfl2 = syncd + (0 if tag == "hem" else 8) + 1504 * 2 + 4
+        odd[2, :80] = _header(dfl2, syncd, tag == "hem", upl=(0 if tag == "hem" else 1504), sync=(0 if tag == "hem" else 0x47))
+        out[tag + "_dfl_ends_under_a_byte"] = (K_BCH, [odd[i] for i in (0, 1, 2, 3, 4)], [0] * 5)
     mis = hem.copy()                                                     # multiple input streams: ISI carried in the header
     for f in range(4):
         hdr = _header(((K_BCH - 80) // 8) * 8, int("".join(str(b) for b in mis[f, 56:72]), 2), True, sis=0, isi=5)

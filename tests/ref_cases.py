@@ -286,12 +286,17 @@ def carry_case(name):
     return cells, np.concatenate(sent), ol.pack_l1_post([(cfg, dict(start=0, num_blocks=c["nb"]))])
 
 
-def carry_iq(name):
-    """The same payload as whole T2 frames at the tuner interface (int16 I/Q, P1 + cyclic prefixes + AWGN): what t2gpu_rx is fed."""
+l1_cells = t2_tx.l1_cells
+
+
+def carry_iq(name, l1_variant=None):
+    """The same payload as whole T2 frames at the tuner interface (int16 I/Q, P1 + cyclic prefixes + AWGN), with real L1 signalling in
+    every P2 symbol: what t2gpu_rx is fed. l1_variant: {frame: dict(num_blocks=.. | spoil_post=True)} for the L1-gating tests."""
     c, mod, fec_type, code_rate, n, cpf, cid = carry_geometry(name)
     m = ol.ora_mode(*c["mode"])
     guard = {0: m.fft_size // 32, 1: m.fft_size // 16, 2: m.fft_size // 8, 3: m.fft_size // 4, 4: m.fft_size // 128}[c["mode"][3]]
-    frames = [t2_tx.build_frame(m, stream, c["lps"], c["seed"] + 200 + f, snr_db=None, phase=0.0)
+    frames = [t2_tx.build_frame(m, stream, c["lps"], c["seed"] + 200 + f, snr_db=None, phase=0.0,
+                                l1_cells=l1_cells(c["mode"], c["lps"], mod, fec_type, code_rate, c["nb"], frame_idx=f, **((l1_variant or {}).get(f, {}))))
               for f, (stream, _, _) in enumerate(carry_payload(name))]
     i16, q16, flen = t2_tx.iq_stream(frames, guard, c["s2"], c["iq_snr"], c["seed"])
     return i16.reshape(c["frames"], flen), q16.reshape(c["frames"], flen)

@@ -343,6 +343,22 @@ def l1_post_cells(info_bits, l1_post_mod, l1_post_size, seed=0, scrambled=False)
 
 
 # ------------------------------------------------------------------------------------------------ P1 preamble (EN 302 755 9.8)
+def l1_cells(mode, lps, mod, fec_type, code_rate, nb, frame_idx=0, num_blocks=None, spoil_post=False):
+    """L1-pre (BPSK) + L1-post (QPSK) cells of a P2 symbol signalling OFDM mode `mode` and one rotated PLP from cell 0 with nb FEC
+    blocks (num_blocks: the dynamic PLP_NUM_BLOCKS if it differs; spoil_post: one L1-post cell inverted, so its CRC-32 fails)."""
+    pre = dict(type=0, bwt_ext=mode[1], s1=0, s2_field1=(4 if mode[0] == 4 else 5), guard_interval=mode[3], papr=mode[4], l1_post_mod=1,
+               l1_cod=0, l1_fec_type=0, l1_post_size=lps, pilot_pattern=mode[2], num_t2_frames=2, num_data_symbols=mode[5], num_rf=1,
+               t2_version=2, cell_id=0x1234, network_id=0x3085, t2_system_id=0x8001, tx_id_availability=0)
+    plp = [dict(id=0, plp_type=1, plp_payload_type=3, plp_group_id=1, plp_cod=code_rate, plp_mod=mod, plp_rotation=1, plp_fec_type=fec_type,
+                plp_num_blocks_max=nb, frame_interval=1, time_il_length=1, time_il_type=0, plp_mode=1)]
+    info = l1_post_bits(dict(frame_idx=frame_idx, l1_change_counter=0), plp, [dict(id=0, start=0, num_blocks=nb if num_blocks is None else num_blocks)])
+    pre["l1_post_info_size"] = len(info)
+    post = np.array(l1_post_cells(info, 1, lps, 4))
+    if spoil_post:
+        post[5] = -post[5]                                       # two payload bits inverted behind the CRC-32
+    return np.concatenate([l1_pre_cells(pre, 3), post])
+
+
 def p1_symbol(s1, s2):
     """The 2048-sample P1 symbol (C-A-B structure) signalling S1 (3 bit) and S2 (4 bit), unit mean power in part A.
     Modulation signalling sequence = S1 pattern | S2 pattern | S1 pattern (384 bit), DBPSK, scrambled with the PRBS

@@ -70,7 +70,7 @@ def test_iq_to_ts(torch_cuda, name, mode, lps, mod, fec_type, code_rate, snr, sa
     from sdr_receiver_dvb_t2_amd.receiver import t2_rx
     nat = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames, saturate_llr=saturate)
     assert nat.frame_len == frame_len
-    count = nat.execute_dev(torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda(), n_frames, first_call=True)
+    count = nat.execute_dev(torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda(), n_frames, first_call=True, flush=True)
     assert count == n_frames * nb
     nbits, ntrials = nat.fetch(count)
     info = nat.results(n_frames)
@@ -104,11 +104,11 @@ def test_outer_code_in_the_batch_receiver(torch_cuda):
         rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames)
         i16, q16, _ = t2_tx.iq_stream(frames, rx.geometry.guard_interval_size, s2, snr, 11)
         di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
-        count = rx.execute_dev(di, dq, n_frames, first_call=True)
+        count = rx.execute_dev(di, dq, n_frames, first_call=True, flush=True)
         plain_bits, plain_trials = rx.fetch(count)
         assert (plain_trials >= 0).all()
         rx.set_outer_code(True)
-        assert rx.execute_dev(di, dq, n_frames, first_call=True) == count
+        assert rx.execute_dev(di, dq, n_frames, first_call=True, flush=True) == count
         bits, trials = rx.fetch(count)
         status = rx.outer_code_status(count)
         assert np.array_equal(trials, plain_trials) and np.array_equal(bits, plain_bits)
@@ -259,12 +259,12 @@ def test_ordered_receiver_on_one_gpu_equals_one_call(torch_cuda):
     i16, q16, frame_len = t2_tx.iq_stream(frames, m.fft_size // 128, s2, snr, seed)
     d_i, d_q = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
     rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=n_frames)
-    count = rx.execute_dev(d_i, d_q, n_frames, first_call=True)
+    count = rx.execute_dev(d_i, d_q, n_frames, first_call=True, flush=True)
     bits, trials = rx.fetch(count)
     want = ts_from_bits(bits, trials)
 
     def decode(lo, hi):
-        n = rx.execute_dev(d_i[lo * frame_len:], d_q[lo * frame_len:], hi - lo, first_call=True)
+        n = rx.execute_dev(d_i[lo * frame_len:], d_q[lo * frame_len:], hi - lo, first_call=True, flush=True)
         return rx.fetch(n)
     orx = ordered_receiver(decode, nb, 32, 0, None)
     got = orx.execute(n_frames)

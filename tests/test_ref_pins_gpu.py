@@ -39,6 +39,11 @@ def grx():
     return _load("t2rx_golden.npz")
 
 
+@pytest.fixture(scope="module")
+def gbatch():
+    return _load("t2batch_golden.npz")
+
+
 def dev(torch, x):
     return torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(x.shape + (2,))).cuda()
 
@@ -205,6 +210,133 @@ def test_fec_chain_against_the_reference(torch_cuda, gfec, name):
     assert np.array_equal(np.concatenate(got), g["ts"])
     for obj in (ti, dm, dec):
         obj.close()
+
+
+def deframe_packed(rows, k_bch, need_plp=0):
+    """packed BBFRAME rows -> TS bytes through t2gpu_bbdh_execute_packed"""
+    import sdr_receiver_dvb_t2_amd as pkg
+    l = pkg.lib()
+    h = l.t2gpu_bbdh_create(need_plp)
+    got = []
+    for r in rows:
+        o = np.zeros(k_bch // 8 + 400, np.uint8)
+        k = l.t2gpu_bbdh_execute_packed(h, need_plp, k_bch, np.ascontiguousarray(r).ctypes.data, o.ctypes.data, o.size, None)
+        if k > 0:
+            got.append(o[:k])
+    l.t2gpu_bbdh_destroy(h)
+    return np.concatenate(got) if got else np.zeros(0, np.uint8)
+
+
+@pytest.mark.parametrize("name", list(rc.LDPC_IN_CASES))
+def test_ldpc_stage_256qam_payload_against_the_reference(torch_cuda, gbatch, name):
+    """BASELINE configs 3 and 5 behind the demapper, against reference-built code: the clamped 256-QAM LLRs the reference's
+    ldpc_decoder::execute slot was fed (ldpc_decoder.h:90; two SIMD batches) through K-ldpc -> K-descramble / K-descramble-pack ->
+    t2gpu_bbdh: every hard bit, every descrambled BBFRAME bit and every TS byte equal what the reference's ldpc_decoder ->
+    bch_decoder -> bb_de_header emitted. Packed and bit-per-byte forms agree."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    g = sub(gbatch, "ldpc_in", name)
+    llr, frames, ts, l1 = rc.ldpc_in_case(name)
+    assert rc.sha(llr) == str(g["in_sha"]), "regenerated LLRs differ from the ones the reference saw"
+    mod, fec_type, code_rate, nb, snr, seed = rc.LDPC_IN_CASES[name]
+    k_bch = t2_tx.K_BCH[ol.code_id(fec_type, code_rate)]
+    dec = pkg.ldpc_decoder(fec_type, code_rate, max_frames=nb)
+    bits, trials = dec.execute_dev(torch.from_numpy(llr).cuda())
+    torch.cuda.synchronize()
+    assert dec.status() == 0 and (trials.cpu().numpy() >= 0).all() and int(g["ldpc_batches"]) == nb // 32
+    B = bits.cpu().numpy()
+    assert np.array_equal(rc.crc_rows(B), g["ldpc_crc"]) and np.array_equal(np.packbits(B[0]), g["ldpc_first"])
+    bch = pkg.bch_decoder(fec_type, code_rate)
+    D = bch.execute_dev(bits).cpu().numpy()
+    assert np.array_equal(rc.crc_rows(D), g["bb_crc"]) and np.array_equal(np.packbits(D[0]), g["bb_first"])
+    P = bch.execute_packed_dev(bits).cpu().numpy()
+    assert P.shape == (nb, k_bch // 8) and np.array_equal(P, np.packbits(D, axis=1))
+    got = deframe_packed(P, k_bch)
+    assert got.size == int(g["ts_len"]) and np.array_equal(rc.crc_rows(got[:got.size // 188 * 188].reshape(-1, 188)), g["ts_packet_crc"])
+    assert np.array_equal(got[:752], g["ts_head"]) and np.array_equal(got[-376:], g["ts_tail"])
+    dec.close()
+
+
+@pytest.mark.parametrize("name", list(rc.CARRY_CASES))
+def test_batch_receiver_carries_simd_batches_across_calls_like_the_reference(torch_cuda, gbatch, name):
+    """t2gpu_rx against the reference's FEC chain over three T2 frames of 40 FEC blocks (llr_demapper.cpp:742-764: the 32-frame LLR
+    buffer fills across frames, a short batch is never decoded). The reference emitted one batch after each frame (FEC blocks 0-31,
+    32-63, 64-95) and kept 24. Three calls of one frame each: the same counts, the same BBFRAMEs in the same batches, and -- through
+    the library's own host end (worker thread: L1 parse of every P2 symbol + de-framer) -- the reference's TS file byte for byte. One
+    call over all three frames gives the same rows. The flush (an addition) then delivers the 24 frames the reference keeps."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    g = sub(gbatch, "carry", name)
+    c, mod, fec_type, code_rate, n, cpf, cid = rc.carry_geometry(name)
+    nb, nf = c["nb"], c["frames"]
+    k_bch = t2_tx.K_BCH[cid]
+    _, sent, _ = rc.carry_case(name)
+    assert np.array_equal(rc.crc_rows(sent), g["sent_bbframes_crc"])
+    i16, q16 = rc.carry_iq(name)
+    d_i, d_q = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
+    want_counts = np.diff(np.concatenate([[0], g["emitted_after_frame"][:, 2]]))          # BBFRAMEs the reference emitted per frame
+    rx = t2_rx(*c["mode"], c["lps"], mod, fec_type, code_rate, 1, nb, max_frames=nf)
+    rx.ts_enable(0, l1_check=True)
+    rows, level = [], 0.0
+    for f in range(nf):
+        count = rx.execute_dev(d_i[f], d_q[f], 1, level_detect=level, first_call=(f == 0))
+        assert count == want_counts[f] and rx.carry == (f + 1) * nb - int(g["emitted_after_frame"][f, 2])
+        r, t = rx.fetch_packed(count)
+        assert (t >= 0).all()
+        rows.append(r)
+        level = rx.results(1)["level_detect"]
+    rows = np.concatenate(rows)
+    bits = np.unpackbits(rows, axis=1)
+    assert np.array_equal(rc.crc_rows(bits), g["bb_crc"])                                  # = the reference's bit_descramble output
+    ts = rx.ts_read(wait_all=True)
+    assert np.array_equal(ts, g["ts"])                                                     # = the reference's TS file
+    n = rx.ts_counters()
+    assert n["t2_frames"] == nf and n["fec_frames"] == len(rows) and n["ts_bytes"] == ts.size
+    assert n["l1_pre_crc_errors"] == n["l1_post_crc_errors"] == n["l1_mismatches"] == n["fec_frames_dropped_l1"] == n["fec_frames_dropped_ldpc"] == 0
+    # end of stream: the frames the reference never decodes
+    rest = rx.flush_dev()
+    assert rest == nf * nb - len(rows) and rx.carry == 0
+    r2, t2 = rx.fetch_packed(int(want_counts[-1]) + rest)
+    assert (t2 >= 0).all() and np.array_equal(r2[:int(want_counts[-1])], rows[-int(want_counts[-1]):])
+    tail = np.unpackbits(r2[int(want_counts[-1]):], axis=1)
+    assert np.array_equal(rc.crc_rows(tail), g["sent_bbframes_crc"][len(rows):])
+    assert rx.ts_read(wait_all=True).size > 0
+    rx.close()
+    # one call over the whole buffer: the same batches
+    one = t2_rx(*c["mode"], c["lps"], mod, fec_type, code_rate, 1, nb, max_frames=nf)
+    count = one.execute_dev(d_i.reshape(-1), d_q.reshape(-1), nf, first_call=True)
+    assert count == len(rows) and one.carry == nf * nb - len(rows)
+    r1, t1 = one.fetch_packed(count)
+    assert (t1 >= 0).all() and np.array_equal(r1, rows)
+    assert np.array_equal(deframe_packed(r1, k_bch), g["ts"])
+    one.close()
+
+
+def test_batch_receiver_gates_frames_on_their_l1_signalling(torch_cuda):
+    """The host end's per-frame L1 parse (p2_symbol.cpp:301-718 per P2 symbol): a T2 frame whose L1-post fails its CRC-32 and one
+    whose dynamic PLP_NUM_BLOCKS differs from the configuration have their BBFRAMEs withheld and counted; the others flow."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    name = "b40x3"
+    c, mod, fec_type, code_rate, n, cpf, cid = rc.carry_geometry(name)
+    nb, nf = c["nb"], c["frames"]
+    i16, q16 = rc.carry_iq(name, l1_variant={1: dict(spoil_post=True)})
+    rx = t2_rx(*c["mode"], c["lps"], mod, fec_type, code_rate, 1, nb, max_frames=nf)
+    rx.ts_enable(0, l1_check=True)
+    count = rx.execute_dev(torch.from_numpy(i16).cuda().reshape(-1), torch.from_numpy(q16).cuda().reshape(-1), nf, first_call=True, flush=True)
+    assert count == nf * nb
+    ts = rx.ts_read(wait_all=True)
+    k = rx.ts_counters()
+    assert k["t2_frames"] == nf and k["l1_post_crc_errors"] == 1 and k["l1_pre_crc_errors"] == 0 and k["l1_mismatches"] == 0
+    assert k["fec_frames"] == nf * nb and k["fec_frames_dropped_l1"] == nb and k["ts_bytes"] == ts.size
+    rx.close()
+    i16, q16 = rc.carry_iq(name, l1_variant={2: dict(num_blocks=nb - 1)})
+    rx = t2_rx(*c["mode"], c["lps"], mod, fec_type, code_rate, 1, nb, max_frames=nf)
+    rx.ts_enable(0, l1_check=True)
+    rx.execute_dev(torch.from_numpy(i16).cuda().reshape(-1), torch.from_numpy(q16).cuda().reshape(-1), nf, first_call=True, flush=True)
+    k = rx.ts_counters()
+    assert k["l1_mismatches"] == 1 and k["l1_post_crc_errors"] == 0 and k["fec_frames_dropped_l1"] == nb
+    rx.close()
 
 
 def test_front_loop_against_the_reference(torch_cuda, grx):
