@@ -7,6 +7,7 @@
 // file (:433-443); here they are returned to the caller.
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
+#include <algorithm>
 #include <cstring>
 
 using namespace t2gpu;
@@ -53,6 +54,8 @@ struct BitSrc {
         return t;
     }
     void skip(long n) { pos += n; }                    // may run past the end: byte() then yields zeros
+    // n whole bytes that lie byte-aligned inside a packed frame: the caller may copy them in one piece
+    const uint8_t *run(int n) const { return (packed && (pos & 7) == 0 && pos >= 0 && pos + 8L * n <= len) ? base + (pos >> 3) : nullptr; }
 };
 // Byte sink bounded by out_cap: the reference's buffer is a fixed 53840/8 + 376 bytes (:35-38) which a wild SYNCD overruns; here
 // the frame is refused instead (full = true -> -3).
@@ -219,8 +222,18 @@ int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool pa
                     h->idx_packet = 0;
                     snk.put(0x47); ++h->idx_packet;
                 } else {
-                    snk.put(in.byte()); ++h->idx_packet;
-                    dfl -= 8;
+                    // the bytes up to the end of this packet that the loop would emit one by one (each needs dfl >= BIT_PACKET before
+                    // it): from a packed, byte-aligned frame they move in one piece
+                    const int run = std::min(TS_LEN - h->idx_packet, (dfl - BIT_PACKET) / 8 + 1);
+                    const uint8_t *src = run > 8 ? in.run(run) : nullptr;
+                    if (src && snk.end - snk.o >= run) {
+                        std::memcpy(snk.o, src, (size_t)run);
+                        snk.o += run; snk.n += run; in.skip(8L * run);
+                        h->idx_packet += run; dfl -= 8 * run;
+                    } else {
+                        snk.put(in.byte()); ++h->idx_packet;
+                        dfl -= 8;
+                    }
                 }
             }
         }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ldpc_kernel.h"
+#include <cstdlib>
 #include "ldpc_cn3.h"
 
 namespace t2gpu {
@@ -591,6 +592,19 @@ hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int 
 hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
 {
     ldpc2_kernel_fn fn = pick_kernel2(min_cnt, max_cnt);
+    // The workgroups of a SIMD batch meet at every sweep: the grid must be resident as a whole. A cooperative launch makes that the
+    // runtime's promise (it refuses a grid that does not fit and does not start it beside work that would keep part of it out)
+    // instead of an assumption about what else is on the device. T2GPU_LDPC_COOPERATIVE=0: the plain launch (A/B measurements).
+    static const bool cooperative = [] { const char *e = std::getenv("T2GPU_LDPC_COOPERATIVE"); return !(e && std::atoi(e) == 0); }();
+    if (cooperative) {
+        const LdpcLayerDev *layers = p.layers;
+        const uint32_t *entries = p.entries, *cninfo = p.cninfo, *entries2 = p.entries2;
+        LdpcKernelParams q = p;
+        void *args[] = {&layers, &entries, &cninfo, &entries2, &q};
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fn), dim3(grid), dim3(kThreads2), args, (unsigned)lds_bytes, stream);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();                                  // e.g. no cooperative-launch support: fall through to the plain launch
+    }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads2), lds_bytes, stream, p.layers, p.entries, p.cninfo, p.entries2, p);
     return hipGetLastError();
 }

@@ -100,7 +100,8 @@ struct TsEnd {
     hipStream_t copy_stream = nullptr;        // the device -> host copies run beside the next call's kernels
     hipEvent_t decoded = nullptr;             // recorded on the call's stream behind K-descramble-pack
     hipEvent_t last_copy = nullptr;           // `ready` of the newest job: the next back half waits for it before it overwrites the rows
-    std::vector<uint8_t> ts;                  // TS bytes not yet read
+    std::deque<std::vector<uint8_t>> ts;      // TS bytes not yet read: one chunk per job, oldest first
+    size_t ts_head = 0, ts_pending = 0;       // bytes of the first chunk already handed out / bytes waiting in all chunks
     std::deque<std::pair<long, int>> l1_status;   // (running T2-frame number, status bits) of frames whose FEC frames may still come
     t2gpu_rx_ts_counters n{};
 };
@@ -465,6 +466,7 @@ void ts_worker(TsEnd *t)
         const bool ok = hipEventSynchronize(sl.ready) == hipSuccess;
         t2gpu_rx_ts_counters d{};
         local.clear();
+        local.reserve((size_t)j.fec_frames * (row + 64));
         if (ok) {
             std::vector<std::pair<long, int>> st;
             if (t->l1_check)
@@ -499,16 +501,16 @@ void ts_worker(TsEnd *t)
                 if (n == -1) ++d.bbheader_crc_errors;
                 d.ts_packet_errors += err;
                 d.resync += t2gpu_bbdh_resync_count(t->bbdh);
-                if (n > 0) local.insert(local.end(), out.begin(), out.begin() + n);
+                if (n > 0) { local.insert(local.end(), out.begin(), out.begin() + n); d.ts_bytes += n; }
             }
         }
         {
             std::lock_guard<std::mutex> lk(t->m);
-            t->ts.insert(t->ts.end(), local.begin(), local.end());
+            if (!local.empty()) { t->ts_pending += local.size(); t->ts.emplace_back(std::move(local)); local = std::vector<uint8_t>(); }
             t->n.t2_frames += d.t2_frames; t->n.l1_pre_crc_errors += d.l1_pre_crc_errors; t->n.l1_post_crc_errors += d.l1_post_crc_errors;
             t->n.l1_mismatches += d.l1_mismatches; t->n.fec_frames += d.fec_frames; t->n.fec_frames_dropped_ldpc += d.fec_frames_dropped_ldpc;
             t->n.fec_frames_dropped_l1 += d.fec_frames_dropped_l1; t->n.bbheader_crc_errors += d.bbheader_crc_errors;
-            t->n.ts_packet_errors += d.ts_packet_errors; t->n.resync += d.resync; t->n.ts_bytes += (long)local.size();
+            t->n.ts_packet_errors += d.ts_packet_errors; t->n.resync += d.resync; t->n.ts_bytes += d.ts_bytes;
             if (!ok) ++t->n.device_errors;
             sl.busy = false;
             --t->in_flight;
@@ -593,10 +595,13 @@ extern "C" long t2gpu_rx_ts_read(t2gpu_rx *h, uint8_t *out, long cap, int wait_a
     TsEnd *t = h->ts;
     std::unique_lock<std::mutex> lk(t->m);
     if (wait_all) t->cv_done.wait(lk, [&] { return t->in_flight == 0; });
-    const long n = std::min<long>(cap, (long)t->ts.size());
-    if (n > 0) {
-        std::memcpy(out, t->ts.data(), (size_t)n);
-        t->ts.erase(t->ts.begin(), t->ts.begin() + n);
+    long n = 0;
+    while (n < cap && !t->ts.empty()) {
+        std::vector<uint8_t> &c = t->ts.front();
+        const size_t take = std::min<size_t>((size_t)(cap - n), c.size() - t->ts_head);
+        std::memcpy(out + n, c.data() + t->ts_head, take);
+        n += (long)take; t->ts_head += take; t->ts_pending -= take;
+        if (t->ts_head == c.size()) { t->ts.pop_front(); t->ts_head = 0; }
     }
     return n;
 }
@@ -608,7 +613,7 @@ extern "C" int t2gpu_rx_ts_counters_get(t2gpu_rx *h, int wait_all, t2gpu_rx_ts_c
     std::unique_lock<std::mutex> lk(t->m);
     if (wait_all) t->cv_done.wait(lk, [&] { return t->in_flight == 0; });
     *out = t->n;
-    out->ts_bytes_pending = (long)t->ts.size();
+    out->ts_bytes_pending = (long)t->ts_pending;
     return 0;
 }
 

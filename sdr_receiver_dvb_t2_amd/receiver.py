@@ -276,10 +276,13 @@ class t2_rx(object):
     def ts_enable(self, need_plp=0, l1_check=True):
         self._check(self._l.t2gpu_rx_ts_enable(self._h, need_plp, int(bool(l1_check))), "t2gpu_rx_ts_enable")
 
-    def ts_read(self, wait_all=True, cap=1 << 26):
-        out = np.empty(cap, np.uint8)
-        n = self._check(self._l.t2gpu_rx_ts_read(self._h, out.ctypes.data, cap, int(wait_all)), "t2gpu_rx_ts_read")
-        return out[:n].copy()
+    def ts_read(self, wait_all=True):
+        """All TS bytes the worker has finished (wait_all: after every call enqueued so far has been de-framed), oldest first."""
+        c = rx_ts_counters()
+        self._check(self._l.t2gpu_rx_ts_counters_get(self._h, int(wait_all), ctypes.byref(c)), "t2gpu_rx_ts_counters_get")
+        out = np.empty(int(c.ts_bytes_pending), np.uint8)
+        n = self._check(self._l.t2gpu_rx_ts_read(self._h, out.ctypes.data, out.size, 0), "t2gpu_rx_ts_read") if out.size else 0
+        return out[:n]
 
     def ts_counters(self, wait_all=True):
         c = rx_ts_counters()

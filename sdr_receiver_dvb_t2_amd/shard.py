@@ -41,11 +41,13 @@ class ordered_receiver(object):
     ranks is the result: the descrambled BBFRAMEs (packed to bits) and the per-batch LDPC verdicts are gathered to rank 0 in rank
     order = frame order, where the sequential epilogue runs as in the reference: bb_de_header carries a split TS packet (and in normal
     mode the running CRC-8) from one BBFRAME into the next (bb_de_header.cpp:166-322), so it must see the frames of all ranks as one
-    stream. `decode(lo, hi)` -> (uint8 [n_fec][k_bch] one bit per byte, int32 trials per SIMD batch) for T2 frames [lo, hi); in
-    production it is a t2_rx on the rank's GPU, in the CPU tests a stub."""
+    stream. `decode(lo, hi)` -> (uint8 [n_fec][k_bch] one bit per byte, int32 trials per SIMD batch) for T2 frames [lo, hi) -- or, with
+    packed_k_bch = k_bch, the rows already packed MSB first, [n_fec][k_bch / 8], as t2_rx.fetch_packed delivers them; in production it
+    is a t2_rx on the rank's GPU, in the CPU tests a stub."""
 
-    def __init__(self, decode, fec_frames_per_t2_frame, group=32, need_plp=0, dist=None):
+    def __init__(self, decode, fec_frames_per_t2_frame, group=32, need_plp=0, dist=None, packed_k_bch=None):
         self.decode, self.per_frame, self.group, self.need_plp, self.dist = decode, fec_frames_per_t2_frame, group, need_plp, dist
+        self.packed_k_bch = packed_k_bch
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._bbdh = None
@@ -64,7 +66,10 @@ class ordered_receiver(object):
         if hi > lo:
             bits, trials = self.decode(lo, hi)
             bits = np.ascontiguousarray(bits, np.uint8)
-            mine = (np.packbits(bits, axis=1), bits.shape[1], np.ascontiguousarray(trials, np.int32))
+            if self.packed_k_bch:
+                mine = (bits, self.packed_k_bch, np.ascontiguousarray(trials, np.int32))
+            else:
+                mine = (np.packbits(bits, axis=1), bits.shape[1], np.ascontiguousarray(trials, np.int32))
         else:
             mine = (np.zeros((0, 0), np.uint8), 0, np.zeros(0, np.int32))
         if self.world > 1:
@@ -74,14 +79,17 @@ class ordered_receiver(object):
             parts = [mine]
         if self.rank != 0:
             return None
-        from .chain import ts_from_bits
         from ._lib import lib
+        l = lib()
         if self._bbdh is None:
-            self._bbdh = lib().t2gpu_bbdh_create(self.need_plp)      # ONE de-framer for the whole stream: its packet state crosses ranks
+            self._bbdh = l.t2gpu_bbdh_create(self.need_plp)          # ONE de-framer for the whole stream: its packet state crosses ranks
         out = []
         for packed, k_bch, trials in parts:
-            if packed.shape[0] == 0:
-                continue
-            bits = np.unpackbits(packed, axis=1)[:, :k_bch]
-            out.append(ts_from_bits(bits, trials, self.group, self.need_plp, bbdh=self._bbdh))
+            buf = np.zeros(k_bch // 8 + 400, np.uint8)
+            for i in range(packed.shape[0]):
+                if trials[i // self.group] < 0:                      # batch dropped by the LDPC stage (ldpc_decoder.cpp:264-268)
+                    continue
+                n = l.t2gpu_bbdh_execute_packed(self._bbdh, self.need_plp, k_bch, packed[i].ctypes.data, buf.ctypes.data, buf.size, None)
+                if n > 0:
+                    out.append(buf[:n].copy())
         return np.concatenate(out) if out else np.zeros(0, np.uint8)

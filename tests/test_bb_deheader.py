@@ -15,15 +15,21 @@ def l(built):
     return pkg.lib()
 
 
-def run(l, h, frame, plp=0):
+def run(l, h, frame, plp=0, packed=False):
+    """packed: the frame goes in as k_bch / 8 bytes, MSB first (t2gpu_bbdh_execute_packed: what K-descramble-pack delivers)."""
     out = np.zeros(frame.size // 8 + 400, np.uint8)
     err = ctypes.c_int(0)
-    n = l.t2gpu_bbdh_execute(h, plp, frame.size, frame.ctypes.data, out.ctypes.data, out.size, ctypes.byref(err))
+    if packed:
+        rows = np.packbits(frame)
+        n = l.t2gpu_bbdh_execute_packed(h, plp, frame.size, rows.ctypes.data, out.ctypes.data, out.size, ctypes.byref(err))
+    else:
+        n = l.t2gpu_bbdh_execute(h, plp, frame.size, frame.ctypes.data, out.ctypes.data, out.size, ctypes.byref(err))
     return n, out[:max(n, 0)], err.value
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("cid", [9, 8, 0, 6])
-def test_hem_round_trip(l, cid):
+def test_hem_round_trip(l, cid, packed):
     k_bch = t2_tx.K_BCH[cid]
     n_frames = 9
     ts = t2_tx.ts_packets(n_frames * (k_bch // (187 * 8) + 2), seed=cid)
@@ -31,7 +37,7 @@ def test_hem_round_trip(l, cid):
     h = l.t2gpu_bbdh_create(0)
     got = []
     for f in range(n_frames):
-        n, out, err = run(l, h, np.ascontiguousarray(frames[f]))
+        n, out, err = run(l, h, np.ascontiguousarray(frames[f]), packed=packed)
         assert n > 0 and err == 0 and l.t2gpu_bbdh_mode(h) == 1
         got.append(out)
     got = np.concatenate(got)
@@ -69,8 +75,9 @@ def gold():
         return {k[len("bbdh/bbdh/"):]: z[k] for k in z.files if k.startswith("bbdh/bbdh/")}
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("name", list(bbdh_cases.cases()))
-def test_equals_the_reference_class(l, gold, name):
+def test_equals_the_reference_class(l, gold, name, packed):
     """Every TS byte bb_de_header::execute wrote for these BBFRAME sequences -- high-efficiency and normal mode (the latter with
     the reference's DFL slip), lost frames (both re-synchronisation branches), a frame of another PLP, a broken header CRC,
     SYNCD = 0xFFFF, a multiple-input-stream header -- and its message counts."""
@@ -78,7 +85,7 @@ def test_equals_the_reference_class(l, gold, name):
     h = l.t2gpu_bbdh_create(0)
     got, rcs, resync, errs = [], [], 0, 0
     for bits, plp in zip(frames, plps):
-        n, out, err = run(l, h, np.ascontiguousarray(bits), plp)
+        n, out, err = run(l, h, np.ascontiguousarray(bits), plp, packed=packed)
         rcs.append(n)
         if n >= 0:
             got.append(out)

@@ -1,6 +1,8 @@
-// valu_rate.hip -- gfx950 micro-benchmark: cycles per wave64 VALU instruction for the op mix an int8 min-sum decoder
-// can be built from (integer vs fp32 vs packed forms). 4 independent accumulator chains per lane, 1 wave per SIMD
-// (256 threads per block, one block per CU) and again with 2/4 waves per SIMD.  Build: hipcc --offload-arch=gfx950.
+// valu_rate.hip -- gfx950 micro-benchmark in THROUGHPUT form: cycles per wave64 VALU instruction per SIMD for the op classes an int8
+// min-sum decoder is built from (integer vs fp32 vs packed forms). 4 independent accumulator chains per lane; 1, 2, 3, 4 and 8 waves
+// per SIMD (one block per CU; 3 = the occupancy of ldpc_decode2_kernel). Two clocks: wall time x the nominal 2.4 GHz, and the shader
+// clock itself (s_memtime, first start to last end over all waves of CU 0: independent of what the clock actually was).
+// Build: hipcc --offload-arch=gfx950 -O2 valu_rate.hip -o valu_rate.   Output: one line per op, and `json` lines for tools.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -10,13 +12,16 @@
 #define ITER 256
 
 #define KERNEL(NAME, DECL, BODY)                                                        \
-    __global__ void k_##NAME(int *out, int seed)                                          \
+    __global__ void k_##NAME(int *out, int seed, long long *clk)                          \
     {                                                                                     \
         DECL;                                                                             \
+        const long long t0 = __builtin_amdgcn_s_memtime();                                \
         for (int it = 0; it < ITER; ++it) {                                               \
             _Pragma("unroll") for (int r = 0; r < REP / 4; ++r) { BODY; }                 \
         }                                                                                 \
         out[blockIdx.x * blockDim.x + threadIdx.x] = FIN;                                 \
+        const long long t1 = __builtin_amdgcn_s_memtime();                                \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { clk[2 * (threadIdx.x >> 6)] = t0; clk[2 * (threadIdx.x >> 6) + 1] = t1; } \
     }
 
 #define IDECL int a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed + 11, c = seed + 5
@@ -48,8 +53,9 @@ KERNEL(cvt_f32_i32, IDECL, ASM4("v_cvt_f32_i32 %0, %0\n v_cvt_f32_i32 %1, %1\n v
 KERNEL(cvt_f32_ubyte0, IDECL, ASM4("v_cvt_f32_ubyte0 %0, %0\n v_cvt_f32_ubyte0 %1, %1\n v_cvt_f32_ubyte0 %2, %2\n v_cvt_f32_ubyte0 %3, %3"))
 
 struct A2 { unsigned long long x, y; };
-__global__ void k_pk_add_f32(int *out, int seed)
+__global__ void k_pk_add_f32(int *out, int seed, long long *clk)
 {
+    const long long t0 = __builtin_amdgcn_s_memtime();
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, b = {(float)seed, 2.f};
     for (int it = 0; it < ITER; ++it) {
@@ -59,40 +65,65 @@ __global__ void k_pk_add_f32(int *out, int seed)
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (int)(a0.x + a1.x + a2.x + a3.y);
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { clk[2 * (threadIdx.x >> 6)] = t0; clk[2 * (threadIdx.x >> 6) + 1] = t1; }
 }
 
-typedef void (*kfn)(int *, int);
+// further classes the two-frame kernel uses
+KERNEL(and_b32, IDECL, ASM4("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4"))
+KERNEL(lshlrev_b32, IDECL, ASM4("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3"))
+KERNEL(mov_dpp, IDECL, ASM4("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"))
+KERNEL(pk_max_i16, IDECL, ASM4("v_pk_max_i16 %0, %0, %4\n v_pk_max_i16 %1, %1, %4\n v_pk_max_i16 %2, %2, %4\n v_pk_max_i16 %3, %3, %4"))
+KERNEL(pk_mad_i16, IDECL, ASM4("v_pk_mad_i16 %0, %0, %4, %5\n v_pk_mad_i16 %1, %1, %4, %5\n v_pk_mad_i16 %2, %2, %4, %5\n v_pk_mad_i16 %3, %3, %4, %5"))
+KERNEL(pk_ashr_i16, IDECL, ASM4("v_pk_ashrrev_i16 %0, 15, %0\n v_pk_ashrrev_i16 %1, 15, %1\n v_pk_ashrrev_i16 %2, 15, %2\n v_pk_ashrrev_i16 %3, 15, %3"))
+KERNEL(sub_u16_sdwa, IDECL, ASM4("v_sub_u16_sdwa %0, %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u16_sdwa %1, %1, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u16_sdwa %2, %2, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1\n v_sub_u16_sdwa %3, %3, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1"))
+KERNEL(bfi_b32, IDECL, ASM4("v_bfi_b32 %0, %4, %0, %5\n v_bfi_b32 %1, %4, %1, %5\n v_bfi_b32 %2, %4, %2, %5\n v_bfi_b32 %3, %4, %3, %5"))
+KERNEL(cmp_only, IDECL, ASM4("v_cmp_lt_i32 vcc, %0, %4\n v_cmp_lt_i32 vcc, %1, %4\n v_cmp_lt_i32 vcc, %2, %4\n v_cmp_lt_i32 vcc, %3, %4"))
+
+typedef void (*kfn)(int *, int, long long *);
 struct Entry { const char *name; kfn fn; };
 #define E(N) {#N, k_##N}
 
 int main()
 {
-    Entry tests[] = {E(add_u32), E(min_i32), E(med3_i32), E(xor_b32), E(cndmask), E(cmp_cnd), E(sad_u32), E(add3_u32), E(bfe_i32),
-                     E(perm_b32), E(lshl_or), E(pk_add_i16), E(pk_min_i16), E(pk_sub_i16_clamp), E(add_f32), E(min_f32), E(min_f32_abs),
-                     E(med3_f32), E(fma_f32), E(mul_f32), E(cmp_f32_cnd), E(cvt_f32_i32), E(cvt_f32_ubyte0), E(pk_add_f32)};
+    Entry tests[] = {E(add_u32), E(and_b32), E(xor_b32), E(lshlrev_b32), E(min_i32), E(med3_i32), E(cmp_only), E(cmp_cnd), E(sad_u32), E(add3_u32), E(bfe_i32),
+                     E(bfi_b32), E(perm_b32), E(lshl_or), E(mov_dpp), E(sub_u16_sdwa), E(pk_add_i16), E(pk_min_i16), E(pk_max_i16), E(pk_sub_i16_clamp),
+                     E(pk_mad_i16), E(pk_ashr_i16), E(add_f32), E(min_f32), E(med3_f32), E(fma_f32), E(mul_f32), E(pk_add_f32)};
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     double clk = prop.clockRate * 1e3;   // Hz (nominal max)
     int *out; hipMalloc(&out, (size_t)cus * 8 * 1024 * sizeof(int));
-    printf("device %s, %d CUs, clock %.0f MHz\n", prop.name, cus, clk / 1e6);
-    printf("%-20s %12s %12s %12s   (cycles per wave64 instruction per SIMD at nominal clock; wave occupancy 1/2/4 per SIMD)\n", "op", "1w", "2w", "4w");
+    long long *d_clk; hipMalloc(&d_clk, 64 * sizeof(long long));
+    printf("device %s, %d CUs, nominal clock %.0f MHz\n", prop.name, cus, clk / 1e6);
+    const int WPS[] = {1, 2, 3, 4};
+    printf("%-18s", "op");
+    for (int w : WPS) printf("  %dw wall  %dw shdr", w, w);
+    printf("   (cycles per wave64 instruction per SIMD; wall = at the nominal clock, shdr = s_memtime span of CU 0)\n");
     for (auto &t : tests) {
-        printf("%-20s", t.name);
-        for (int wps : {1, 2, 4}) {
+        printf("%-18s", t.name);
+        double shader[4];
+        int k = 0;
+        for (int wps : WPS) {
             int threads = 256 * wps;     // wps waves on each of the 4 SIMDs
-            if (threads > 1024) threads = 1024;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            t.fn<<<cus, threads>>>(out, 1);
+            t.fn<<<cus, threads>>>(out, 1, d_clk);
             hipDeviceSynchronize();
             hipEventRecord(e0);
-            for (int r = 0; r < 5; ++r) t.fn<<<cus, threads>>>(out, r);
+            for (int r = 0; r < 5; ++r) t.fn<<<cus, threads>>>(out, r, d_clk);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double insts_per_simd = 5.0 * (double)ITER * REP * wps;       // wave-instructions issued on each SIMD
             double cyc = (ms * 1e-3) * clk / insts_per_simd;
-            printf(" %12.2f", cyc);
+            long long h[64];
+            hipMemcpy(h, d_clk, sizeof(long long) * 2 * 4 * wps, hipMemcpyDeviceToHost);
+            long long lo = h[0], hi = h[1];
+            for (int w = 0; w < 4 * wps; ++w) { lo = h[2 * w] < lo ? h[2 * w] : lo; hi = h[2 * w + 1] > hi ? h[2 * w + 1] : hi; }
+            shader[k] = (double)(hi - lo) / ((double)ITER * REP * wps);
+            printf("  %7.2f  %7.2f", cyc, shader[k]);
+            ++k;
         }
         printf("\n");
+        printf("json {\"op\": \"%s\", \"cycles_1w\": %.3f, \"cycles_2w\": %.3f, \"cycles_3w\": %.3f, \"cycles_4w\": %.3f}\n", t.name, shader[0], shader[1], shader[2], shader[3]);
     }
     return 0;
 }
