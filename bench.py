@@ -378,7 +378,9 @@ def main():
             var = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "avg_ldpc_updates": round(float((args.trials - t3).mean()), 2),
                    "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
             if ts is not None:
-                pk = ts[:ts.size // 188 * 188].reshape(-1, 188)
+                # the timed steps' bytes start wherever the warm-up's last packet ended: find the packet phase from the sync bytes
+                off = next((o for o in range(188) if ts.size > o + 188 * 64 and (ts[o:o + 188 * 64:188] == 0x47).all()), 0)
+                pk = ts[off:off + (ts.size - off) // 188 * 188].reshape(-1, 188)
                 good = np.isin(packet_hashes(pk), np.concatenate([packet_hashes(s) for s in sent]))
                 per_frame = (nb * ((w.k_bch - 80) // 8)) // 187 - 1                     # whole packets one T2 frame's BBFRAMEs carry
                 var.update({"ts_bytes_per_s": round(tsb / e3, 1), "ts_mbit_per_s": round(tsb * 8 / e3 / 1e6, 1), "ts_packets": int(pk.shape[0]),

@@ -135,6 +135,13 @@ int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
  * out_stride_cells. Same result as t2gpu_ti_begin + one whole-block t2gpu_ti_push_dev per block. Returns n_blocks. */
 int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_stride_cells, float *d_out, long out_stride_cells,
                                 int n_blocks, void *stream);
+/* The same with the demapper's first pass folded in (llr_demapper.cpp:564-676: hard decisions, sum_s, sum_e over the TI block): the
+ * de-interleaver forms them while the cells leave it, one pass over the cells instead of two. d_sums + b * sums_stride receives
+ * (sum_s, sum_e, precision) of TI block b -- what t2gpu_demap_stats_batch_dev(dm, d_out, ...) would deliver (same terms, summed in
+ * double per FEC block first). dm: the demapper of the same modulation / FEC type (its rotation and constellation). Returns n_blocks. */
+int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
+                                      long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
+                                      void *stream);
 
 /* ---------------------------------------------------------------- BB descrambler (the reference's BCH stage) ------
  * Replaces  void bch_decoder::execute(int* idx_plp_simd, l1_postsignalling, int len_in, uint8_t* in)

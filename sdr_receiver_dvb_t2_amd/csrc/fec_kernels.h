@@ -53,3 +53,10 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
                             float2 *out, long out_stride, int frames, hipStream_t s);
 
 }  // namespace t2gpu
+
+namespace t2gpu {
+// whole TI blocks (one workgroup per FEC block) with the demapper's statistics formed on the way out (fec_kernels.hip)
+hipError_t launch_ti_blocks_stats(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
+                                  float2 *out, long out_stride, int frames, const DemapParams &dp, int n_snr, double *partial, float *sums,
+                                  int sums_stride, float precision_override, hipStream_t s);
+}

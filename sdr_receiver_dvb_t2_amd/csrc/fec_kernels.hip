@@ -324,9 +324,13 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 #ifndef T2_TI_THREADS
 #define T2_TI_THREADS 1024
 #endif
+// STATS: the demapper's hard-decision statistics (sum |s|^2, sum |e|^2 over the TI block, llr_demapper.cpp:564-676) formed here,
+// where every de-interleaved cell is in a register on its way out -- one double pair per FEC block, folded per TI block by
+// demap_stats_final_kernel -- instead of a second pass over the cells in HBM (demap_stats_kernel: 8 B per cell read again).
+template <bool STATS>
 __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
                                                       const float2 *__restrict__ cells, long in_stride, float2 *__restrict__ out,
-                                                      long out_stride)
+                                                      long out_stride, DemapParams dp, int n_snr, double *__restrict__ partial)
 {
     extern __shared__ float ti_lds[];                    // [cells_per_fec][2]
     // FEC block b reads the 40-byte runs of columns 5b .. 5b+4 in every row: a 128-byte line holds the runs of three neighbouring
@@ -349,9 +353,33 @@ __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, con
     }
     __syncthreads();
     const bool lost = lost_by_block[b] != 0;
+    double ss = 0.0, se = 0.0;
     for (int t = threadIdx.x; t < C; t += blockDim.x) {
-        if (t == C - 1 && lost) reinterpret_cast<float *>(o)[2 * t] = ti_lds[2 * t];
-        else o[t] = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
+        float2 v = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
+        if (t == C - 1 && lost) {
+            reinterpret_cast<float *>(o)[2 * t] = v.x;
+            if (STATS) v.y = reinterpret_cast<const float *>(o)[2 * t + 1];      // the Q this block never received: what the buffer holds
+        } else o[t] = v;
+        if (STATS && base + t < n_snr) {                                       // the arithmetic of demap_stats_kernel, cell by cell
+            if (dp.rotate) v = derotate(v, dp.rot_c, dp.rot_s);
+            const float sr = slice_axis(dp.mod, v.x, dp.d), si = slice_axis(dp.mod, v.y, dp.d);
+            const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
+            ss += (double)add_r(mul_r(sr, sr), mul_r(si, si));
+            se += (double)add_r(mul_r(er, er), mul_r(ei, ei));
+        }
+    }
+    if (STATS) {
+        __shared__ double red[2][T2_TI_THREADS / 64];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { ss += __shfl_down(ss, d, 64); se += __shfl_down(se, d, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ss; red[1][threadIdx.x >> 6] = se; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, c = 0.0;
+            for (int w = 0; w < (int)blockDim.x / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+            double *q = partial + 2 * ((long)f * num_blocks + b);
+            q[0] = a; q[1] = c;
+        }
     }
 }
 
@@ -361,11 +389,29 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
     const size_t lds = (size_t)p.cells_per_fec * 8;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks, cells, in_stride,
-                       out, out_stride);
+    hipLaunchKernelGGL(ti_block_kernel<false>, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
+                       cells, in_stride, out, out_stride, DemapParams{}, 0, (double *)nullptr);
+    return hipGetLastError();
+}
+
+// The same with the demapper's statistics: partial = [frames][num_blocks] double pairs (scratch), sums + f * sums_stride receives
+// (sum_s, sum_e, precision) of frame f's TI block. n_snr: cells of the TI block that count (all, or the first 2048 for QPSK).
+hipError_t launch_ti_blocks_stats(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
+                                  float2 *out, long out_stride, int frames, const DemapParams &dp, int n_snr, double *partial, float *sums,
+                                  int sums_stride, float precision_override, hipStream_t s)
+{
+    const size_t lds = (size_t)p.cells_per_fec * 8;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ti_block_kernel<true>, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
+                       cells, in_stride, out, out_stride, dp, n_snr, partial);
+    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(frames), dim3(64), 0, s, partial, num_blocks, dp.d, precision_override, sums, sums_stride);
     return hipGetLastError();
 }
 

@@ -306,21 +306,31 @@ __device__ __forceinline__ int find_run_out(const FrontRun *__restrict__ runs, i
 #define T2_FD_OUT 1024
 #endif
 #ifndef T2_FD_WAVES
-#define T2_FD_WAVES 7
+#define T2_FD_WAVES 5
 #endif
 // outputs per workgroup: FD_OUT need about FD_OUT + 34 input samples, so the Farrow passes of 256 lanes end with one mostly empty pass
 // whatever FD_OUT is -- the larger, the less that costs. Measured with the one-run path (tools/front_shape_probe.sh, us per 75 M
-// samples): 256 -> 840, 512 -> 795, 768 -> 738, 1024 -> 701, 1536 -> 915, 2048 -> 848 (LDS 17 KB at 1024: still seven workgroups
-// of four wavefronts per CU); held to 68 VGPRs (7 wavefronts per SIMD; 8 spills and costs 30 %).
+// samples, round 2's one-output-per-lane decimator): 256 -> 840, 512 -> 795, 768 -> 738, 1024 -> 701, 1536 -> 915, 2048 -> 848. With four
+// consecutive outputs per lane (below) the kernel holds 22 cells + 32 accumulators: 82 VGPRs, five wavefronts per SIMD, 19 KB of LDS.
 constexpr int FD_THREADS = 256, FD_OUT = T2_FD_OUT;
+// The decimator stage: a lane computes FD_R = FD_OUT / FD_THREADS CONSECUTIVE outputs, whose 64-cell windows overlap in all but two
+// cells per step: per block of 16 taps it reads 16 + 2 (FD_R - 1) cells once and uses each for every output it belongs to -- 22 LDS
+// reads per 4 outputs and tap block instead of 64 (with one output per lane and pass the kernel spent its time on ds_read_b64: 64
+// reads of 8 bytes per output; the arithmetic is 252 float operations per output either way, in the reference's order). A lane's
+// window starts 2 FD_R cells after its neighbour's: the window is stored with one pad cell after every 8 (index t -> t + t / 8), so
+// that the 64 lanes of a ds_read_b64 fall on 32 distinct bank pairs, two lanes each -- the two-cycle minimum of a 512-byte read.
+constexpr int FD_R = FD_OUT / FD_THREADS;
+static_assert(FD_R == 4 && FD_OUT % FD_THREADS == 0, "the decimator stage is written for four consecutive outputs per lane");
+__device__ __forceinline__ int fd_pad(int t) { return t + (t >> 3); }
+constexpr int FD_W = 2 * FD_OUT + 62;                                           // cells of a workgroup's window
 __global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate_kernel(FrontParams p)
 {
-    __shared__ float2 w[2 * FD_OUT + 64];
+    __shared__ float2 w[FD_W + FD_W / 8 + 8];
     const long k0 = (long)blockIdx.x * FD_OUT;
     const long m0 = 2 * k0 + (1 - p.decim_phase);
     const long avail = 63 + p.n_interp;
     constexpr int W = 2 * FD_OUT + 62;
-    for (int t = threadIdx.x; t < W; t += FD_THREADS) w[t] = m0 + t < 63 ? p.interp[m0 + t] : make_float2(0.f, 0.f);   // carried cells; zeros behind the end
+    for (int t = threadIdx.x; t < W; t += FD_THREADS) w[fd_pad(t)] = m0 + t < 63 ? p.interp[m0 + t] : make_float2(0.f, 0.f);   // carried cells; zeros behind the end
     // input samples whose outputs fall into the window: from the owner of its first cell to the owner of its last
     const long oA = m0 > 63 ? m0 - 63 : 0, oB = (m0 + W - 1 < avail ? m0 + W - 1 : avail - 1) - 63;
     __syncthreads();
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate
                 const float x2 = mul_r(x1, x1), x3 = mul_r(x2, x1);
                 float v[2];
                 for (int q = 0; q < 2; ++q) v[q] = add_r(add_r(add_r(mul_r(a3[q], x3), mul_r(a2[q], x2)), mul_r(a1[q], x1)), a0[q]);
-                if (t >= 0 && t < W) w[t] = make_float2(v[0], v[1]);
+                if (t >= 0 && t < W) w[fd_pad(t)] = make_float2(v[0], v[1]);
                 if (t >= tail_t) keep[t] = make_float2(v[0], v[1]);             // the tail the next call starts from
                 ++t;
                 x1 = add_r(x1, delay_x);
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate
                 float v[2];
                 for (int c = 0; c < 2; ++c) v[c] = add_r(add_r(add_r(mul_r(a3[c], x3), mul_r(a2[c], x2)), mul_r(a1[c], x1)), a0[c]);
                 const long t = 63 + o - m0;
-                if (t >= 0 && t < W) w[t] = make_float2(v[0], v[1]);
+                if (t >= 0 && t < W) w[fd_pad((int)t)] = make_float2(v[0], v[1]);
                 if (o >= p.n_interp - 63) p.interp[63 + o] = make_float2(v[0], v[1]);   // the tail the next call starts from
                 ++o;
                 x1 = add_r(x1, delay_x);
@@ -397,24 +407,45 @@ __global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate
         }
     }
     __syncthreads();
-    for (int ko = threadIdx.x; ko < FD_OUT; ko += FD_THREADS) {
+    {
+        const int ko = FD_R * (int)threadIdx.x;                                 // first of the lane's outputs; its window starts at cell 2 ko
         const long k = k0 + ko;
-        if (k >= p.n_out) break;
-        const float2 *x = w + 2 * ko;
-        float lane_r[4], lane_i[4];
-        for (int q = 0; q < 4; ++q) {
-            float ar = 0.0f, ai = 0.0f;
-            for (int blk = 0; blk < 4; ++blk) {
-                const int c = 16 * blk + q;
-                const float2 x0 = x[c], x1 = x[c + 4], x2 = x[c + 8], x3 = x[c + 12];
-                const float h0 = c_taps[c], h1 = c_taps[c + 4], h2 = c_taps[c + 8], h3 = c_taps[c + 12];
-                ar = add_r(ar, add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
-                ai = add_r(ai, add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+        if (k >= p.n_out) return;
+        const float2 *x = w + 2 * ko + (2 * ko >> 3);                           // fd_pad(2 ko + m) = fd_pad(2 ko) + m + m / 8: 2 ko is a multiple of 8
+        float ar[FD_R][4], ai[FD_R][4];
+#pragma unroll
+        for (int r = 0; r < FD_R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ar[r][q] = 0.0f; ai[r][q] = 0.0f; }
+#pragma unroll 1
+        for (int blk = 0; blk < 4; ++blk) {                                     // not unrolled: 16 taps in scalar registers and 22 cells at a time
+            constexpr int NC = 16 + 2 * (FD_R - 1);
+            float2 c[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const int m = 16 * blk + j; c[j] = x[m + (m >> 3)]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h0 = c_taps[16 * blk + q], h1 = c_taps[16 * blk + q + 4], h2 = c_taps[16 * blk + q + 8], h3 = c_taps[16 * blk + q + 12];
+#pragma unroll
+                for (int r = 0; r < FD_R; ++r) {                                // output ko + r: cells shifted by 2 r (filter_decimator.h:83-115)
+                    const float2 x0 = c[q + 2 * r], x1 = c[q + 2 * r + 4], x2 = c[q + 2 * r + 8], x3 = c[q + 2 * r + 12];
+                    ar[r][q] = add_r(ar[r][q], add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
+                    ai[r][q] = add_r(ai[r][q], add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+                }
             }
-            lane_r[q] = ar; lane_i[q] = ai;
         }
-        p.out[k] = make_float2(add_r(add_r(add_r(lane_r[0], lane_r[1]), lane_r[2]), lane_r[3]),
-                               add_r(add_r(add_r(lane_i[0], lane_i[1]), lane_i[2]), lane_i[3]));
+        float2 o[FD_R];
+#pragma unroll
+        for (int r = 0; r < FD_R; ++r)
+            o[r] = make_float2(add_r(add_r(add_r(ar[r][0], ar[r][1]), ar[r][2]), ar[r][3]), add_r(add_r(add_r(ai[r][0], ai[r][1]), ai[r][2]), ai[r][3]));
+        if (k + FD_R <= p.n_out && (((uintptr_t)(p.out + k)) & 15) == 0) {
+            float4 *dst = reinterpret_cast<float4 *>(p.out + k);
+            dst[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+            dst[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+        } else {
+#pragma unroll
+            for (int r = 0; r < FD_R; ++r) if (k + r < p.n_out) p.out[k + r] = o[r];
+        }
     }
 }
 

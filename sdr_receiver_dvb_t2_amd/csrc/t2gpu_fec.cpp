@@ -311,6 +311,42 @@ extern "C" int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, lo
     return n_blocks;
 }
 
+// t2gpu_ti_execute_blocks_dev + t2gpu_demap_stats_batch_dev in one pass over the cells: the demapper's hard-decision statistics of every
+// TI block are formed by the de-interleaver kernel while the cells leave it (d_sums + f * sums_stride = sum_s, sum_e, precision of block f).
+extern "C" int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
+                                                 long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
+                                                 void *stream)
+{
+    if (!h || !dm || !d_cells || !d_out || !d_sums || n_blocks < 0 || !h->num_blocks || h->pos != 0 || sums_stride < 3 ||
+        dm->p.cells_per_fec != h->cells_per_fec) {
+        set_error("t2gpu_ti_execute_blocks_stats_dev: bad arguments (t2gpu_ti_begin first; de-interleaver and demapper of one modulation / FEC type)");
+        return -1;
+    }
+    if (n_blocks == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)n_blocks * h->num_blocks;                    // double pairs: one per FEC block
+    if (need > (size_t)dm->partial_batches * dm->stats_blocks) {
+        T2_HIP(hipStreamSynchronize(s));
+        double *p = nullptr;
+        const int batches = (int)((need + dm->stats_blocks - 1) / dm->stats_blocks);
+        T2_HIP(hipMalloc(&p, sizeof(double) * 2 * dm->stats_blocks * (size_t)batches));
+        T2_HIP(hipDeviceSynchronize());
+        hipFree(dm->d_partial);
+        dm->d_partial = p; dm->partial_batches = batches;
+    }
+    const int n_snr = dm->p.mod == 0 ? std::min(h->p.ti_block_size, 2048) : h->p.ti_block_size;
+    hipError_t e = launch_ti_blocks_stats(h->p, h->d_lost_blk, h->num_blocks, reinterpret_cast<const float2 *>(d_cells), in_stride_cells,
+                                          reinterpret_cast<float2 *>(d_out), out_stride_cells, n_blocks, dm->p, n_snr, dm->d_partial, d_sums,
+                                          sums_stride, precision_override, s);
+    if (e == hipErrorInvalidValue) {            // FEC block larger than LDS: the two separate passes
+        if (t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream) < 0) return -1;
+        return t2gpu_demap_stats_batch_dev(dm, d_out, out_stride_cells, n_blocks, h->p.ti_block_size, precision_override, d_sums, sums_stride, stream) == 0
+                   ? n_blocks : -1;
+    }
+    T2_HIP(e);
+    return n_blocks;
+}
+
 extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream)
 {
     if (!h || !d_cells || !d_out || n_cells < 0 || !h->num_blocks || h->pos + n_cells > h->p.ti_block_size) {

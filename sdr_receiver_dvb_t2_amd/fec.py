@@ -148,6 +148,20 @@ class time_deinterleaver(object):
             check(rc, "t2gpu_ti_execute_blocks_dev")
         return rc
 
+    def execute_blocks_stats_dev(self, cells, out, demapper, sums, precision_override=0.0):
+        """execute_blocks_dev with the demapper's first pass folded in: sums float32 [n][>= 3] receives (sum_s, sum_e, precision) of
+        every TI block, formed while the cells leave the de-interleaver (one pass over the cells instead of two)."""
+        import torch
+        assert cells.dim() == 3 and out.dim() == 3 and cells.shape[0] == out.shape[0] and cells.stride(1) == 2 and out.stride(1) == 2
+        assert sums.dim() == 2 and sums.shape[0] >= cells.shape[0] and sums.stride(1) == 1 and sums.shape[1] >= 3
+        stream = torch.cuda.current_stream(cells.device).cuda_stream
+        rc = self._l.t2gpu_ti_execute_blocks_stats_dev(self._h, demapper._h, cells.data_ptr(), cells.stride(0) // 2, out.data_ptr(),
+                                                       out.stride(0) // 2, cells.shape[0], float(precision_override), sums.data_ptr(),
+                                                       sums.stride(0), stream)
+        if rc < 0:
+            check(rc, "t2gpu_ti_execute_blocks_stats_dev")
+        return rc
+
     def execute(self, cells, out):
         cells = np.ascontiguousarray(cells, dtype=np.complex64).reshape(-1)
         assert out.dtype == np.complex64 and out.flags.c_contiguous

@@ -170,3 +170,33 @@ def test_demapper_statistics_of_several_ti_blocks_in_one_launch(torch_cuda, mod,
     dm.stats_batch_dev(cells[:, :n], many)
     torch.cuda.synchronize()
     assert torch.equal(one, many) and float(one[:, 2].min()) > 0
+
+
+@pytest.mark.parametrize("mod,fec_type,blocks,rotation", [(3, 1, 202, 1), (3, 0, 9, 1), (2, 1, 5, 0), (1, 1, 4, 1), (0, 0, 3, 1), (1, 0, 1, 1)])
+def test_time_deinterleaver_forms_the_demapper_statistics_on_the_way_out(torch_cuda, mod, fec_type, blocks, rotation):
+    """t2gpu_ti_execute_blocks_stats_dev: the cells are those of t2gpu_ti_execute_blocks_dev bit for bit, and the statistics triple of
+    every TI block is the one the demapper's own first pass (t2gpu_demap_stats_batch_dev) forms from those cells -- the same float
+    terms added in double, per FEC block first instead of per grid stripe: equal to 1e-12 relative before the cast to float, so equal
+    as floats (1 ulp allowed). Covers the parked-Q cell, QPSK's 2048-cell window and a TI block of one FEC block."""
+    torch = torch_cuda
+    import sdr_receiver_dvb_t2_amd as pkg
+    frames = 3
+    a, b = pkg.time_deinterleaver(mod, fec_type, blocks), pkg.time_deinterleaver(mod, fec_type, blocks)
+    n = blocks * a.cells_per_fec
+    dm = pkg.llr_demapper(mod, fec_type, 1, rotation, max_cells=n)
+    rng = np.random.Generator(np.random.PCG64(2000 + mod * 10 + blocks))
+    cells = torch.from_numpy((rng.standard_normal((frames, n + 5, 2)) * 0.7).astype(np.float32)).cuda()
+    hist = torch.from_numpy(rng.standard_normal((frames, n + 5, 2)).astype(np.float32)).cuda()
+    out_a, out_b = hist.clone(), hist.clone()
+    a.l1_dyn(blocks); b.l1_dyn(blocks)
+    assert a.execute_blocks_dev(cells[:, :n], out_a[:, :n]) == frames
+    want = torch.zeros((frames, 4), dtype=torch.float32, device="cuda")
+    dm.stats_batch_dev(out_a[:, :n], want)
+    got = torch.zeros((frames, 4), dtype=torch.float32, device="cuda")
+    assert b.execute_blocks_stats_dev(cells[:, :n], out_b[:, :n], dm, got) == frames
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    w, g = want.cpu().numpy()[:, :3], got.cpu().numpy()[:, :3]
+    assert (w[:, 2] > 0).all() and np.abs(g - w).max() <= 1.2e-7 * np.abs(w).max(), (g, w)
+    assert np.count_nonzero(g.view(np.uint32) != w.view(np.uint32)) <= 1
+    a.close(); b.close(); dm.close()
