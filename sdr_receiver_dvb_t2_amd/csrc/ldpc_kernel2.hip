@@ -595,7 +595,8 @@ hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams 
     // The workgroups of a SIMD batch meet at every sweep: the grid must be resident as a whole. A cooperative launch makes that the
     // runtime's promise (it refuses a grid that does not fit and does not start it beside work that would keep part of it out)
     // instead of an assumption about what else is on the device. T2GPU_LDPC_COOPERATIVE=0: the plain launch (A/B measurements).
-    static const bool cooperative = [] { const char *e = std::getenv("T2GPU_LDPC_COOPERATIVE"); return !(e && std::atoi(e) == 0); }();
+    const char *coop_env = std::getenv("T2GPU_LDPC_COOPERATIVE");
+    const bool cooperative = !(coop_env && std::atoi(coop_env) == 0);
     if (cooperative) {
         const LdpcLayerDev *layers = p.layers;
         const uint32_t *entries = p.entries, *cninfo = p.cninfo, *entries2 = p.entries2;

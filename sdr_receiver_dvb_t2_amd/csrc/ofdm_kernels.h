@@ -30,6 +30,7 @@ struct EqParams {
     // positions from symbol_index[].
     int per_frame = 0, first = 0, in_syms_per_frame = 0;
     long out_frame_stride = 0, out_offset = 0;
+    int row_major = 1;         // frame layout, per_frame > 1: workgroups in table-row order (all frames of a row together); 0 = symbol order
     int out_skip = 0;          // frame layout: the first out_skip cells of the symbol are not stored (the L1 cells of P2), the rest move up
     float2 *skip_out = nullptr;       // frame layout, out_skip > 0: where the skipped cells go instead (frame f at skip_out + f * out_skip) --
                                       // the L1-pre / L1-post cells of every P2 symbol, for the host's per-frame L1 parse

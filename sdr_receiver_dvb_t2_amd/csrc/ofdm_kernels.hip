@@ -274,8 +274,25 @@ __global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const f
     // Workgroups are dealt round-robin to the 8 XCDs: linear id w -> XCD w % 8; symbol = 8 * (w / 8 / groups) + w % 8,
     // group = (w / 8) % groups.
     const int wg = (int)blockIdx.x;
-    const int b = 8 * ((wg >> 3) / groups) + (wg & 7);                          // symbol of the batch
-    const int grp = (wg >> 3) % groups;
+    int b, grp;
+    if (p.per_frame > 1 && p.row_major) {
+        // Frame layout with several symbols per frame (the data symbols): the tables (pilot references, carrier map, segments, the
+        // de-interleaver and carrier indices: ~340 KB per symbol ROW, 20 MB for the 59 rows of CFG-A) are the same for that row of every
+        // frame. Symbol after symbol, every workgroup pulled its row's tables through an L2 that had seen 58 other rows since (reads
+        // 1.7x the algorithmic bytes). Row-major instead: all XCDs work on the same row at the same time, XCD x on frames x, x + 8, ...;
+        // a row's tables enter each L2 once per launch. All groups of a symbol still share one XCD, back to back (see above).
+        const int xcd = wg & 7, i = wg >> 3;
+        const int frames = n_symbols / p.per_frame, fx = (frames + 7) >> 3;
+        const int row = i / (fx * groups), rem = i - row * fx * groups;
+        const int fr_x = rem / groups;
+        grp = rem - fr_x * groups;
+        const int frame = fr_x * 8 + xcd;
+        if (row >= p.per_frame || frame >= frames) return;
+        b = frame * p.per_frame + row;
+    } else {
+        b = 8 * ((wg >> 3) / groups) + (wg & 7);                                // symbol of the batch
+        grp = (wg >> 3) % groups;
+    }
     if (b >= n_symbols) return;
     const int fr = p.per_frame ? b / p.per_frame : 0, lo = p.per_frame ? b - fr * p.per_frame : 0;
     const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];        // position in the T2 frame (P2 = 0)
@@ -457,7 +474,8 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         attr_bytes = lds_bytes;
     }
     const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
-    const unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                   // linear id, see the kernel
+    unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                         // linear id, see the kernel
+    if (p.per_frame > 1 && p.row_major) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * groups);
     hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_THREADS), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
                        groups);
     if (sync) {

@@ -57,6 +57,39 @@ def test_simd_batches_match_oracle(torch_cuda, cid, sigma):
     assert np.array_equal(bits, want_bits)
 
 
+VARIANTS = {
+    "default": {},
+    "one-frame kernel": {"T2GPU_LDPC_PACKED": "0"},                       # the fallback of odd groups / a failed LDS attribute
+    "one-frame kernel, one slot": {"T2GPU_LDPC_PACKED": "0", "T2GPU_LDPC_MAX_SLOTS": "1"},
+    "tickets (batches > slots)": {"T2GPU_LDPC_MAX_SLOTS": "1"},
+    "static striding": {"T2GPU_LDPC_MAX_SLOTS": "1", "T2GPU_LDPC_TICKET": "0"},
+    "every layer closed": {"T2GPU_LDPC_OPEN_LAYERS": "0"},
+    "level schedule in GENERIC layers": {"T2GPU_LDPC_BAND": "0"},
+    "one round per launch": {"T2GPU_LDPC_MAX_SLOTS": "1", "T2GPU_LDPC_ROUNDS_PER_LAUNCH": "1"},
+    "plain launch": {"T2GPU_LDPC_COOPERATIVE": "0"},
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("cid,sigma", [(9, 0.61), (0, 0.92)])
+def test_every_kernel_path_is_llr_exact(torch_cuda, cid, sigma, variant, monkeypatch):
+    """The experiment switches select real code paths (the one-frame kernel is the fallback whenever the packed one cannot run): each
+    of them against the oracle on three batches -- two whole, one of 9 frames (an odd count: the packed kernel's last workgroup holds a
+    single frame) -- with one undecodable frame in batch 1. Per-batch trials-left, every final LLR, every hard bit."""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    frames = 32 * 2 + 9
+    info, llr = ol.make_llr(cid, frames, sigma, seed=777 + cid)
+    rng = np.random.Generator(np.random.PCG64(3))
+    llr[45] = rng.integers(-20, 20, size=llr.shape[1]).astype(np.int8)
+    want_t, want_bits, want_llr = ol.ora_decode_batched(cid, llr, group=32)
+    assert want_t[1] == -1 and want_t[0] >= 0 and want_t[2] >= 0
+    bits, trials, lo = _run(torch_cuda, cid, llr, group=32)
+    assert np.array_equal(trials, want_t)
+    assert np.array_equal(lo, want_llr)
+    assert np.array_equal(bits, want_bits)
+
+
 def test_non_converging_batch_is_reported(torch_cuda):
     """One hopeless frame makes the reference drop the whole batch (-1) while its neighbours keep iterating."""
     cid = 0
