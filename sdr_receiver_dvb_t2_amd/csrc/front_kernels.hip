@@ -38,8 +38,10 @@ __device__ __forceinline__ Lin shfl_up_lin(const Lin &v, int d)
 }
 // Inclusive scan of `v` (composition in thread order) over the 256 threads of a workgroup: wavefront scan by shuffles, the four
 // wavefront totals through 96 bytes of LDS. Returns the EXCLUSIVE prefix of this thread; *total receives the workgroup's
-// composition. These kernels run beside the LDPC decoder of another stream, whose persistent workgroups leave only ~12 KB of
-// LDS per CU: keeping LDS use tiny is what lets them overlap (receiver.pipeline_step).
+// composition. (Round 1 kept every front-end kernel under 12 KB of LDS so that it could run beside the LDPC decoder's persistent
+// workgroups of another stream, receiver.pipeline_step with T2GPU_PIPE_SERIAL=0. That schedule measured slower than the serial one
+// -- a decoder workgroup slowed by a neighbour stalls its whole SIMD batch -- and is not supported by these kernels any more: the
+// de-rotation kernel stages its outputs in 35 KB, the Farrow + decimator kernel its window in 19 KB. Serial is the default.)
 template <int NW = 4>
 __device__ __forceinline__ Lin block_scan_exclusive(Lin v, Lin *wave_tot /* LDS[NW] */, Lin *total)
 {

@@ -80,7 +80,9 @@ class t2_receiver(object):
     # MEASURED (round 1, MI355X, CFG-A): running anything beside the decoder costs more than it hides. The 32 workgroups of a SIMD
     # batch meet at every sweep, so one workgroup slowed by a neighbour on its CU slows its whole batch: the decode goes from
     # 31.3 ms to 35-42 ms (10-step runs) while only ~3 ms of other work is hidden. The default is therefore T2GPU_PIPE_SERIAL=1:
-    # same stages and streams, each call drained before the next; T2GPU_PIPE_SERIAL=0 enables the overlapped schedule.
+    # same stages and streams, each call drained before the next. T2GPU_PIPE_SERIAL=0 still enqueues the overlapped schedule, but since
+    # round 2 the front-end kernels hold 19-35 KB of LDS and cannot be co-resident with the decoder's workgroups: they queue behind it
+    # (or, started first, keep part of the decoder's grid out until they finish). Kept for experiments only.
     def pipeline_step(self, d_i, d_q, n_frames, level_detect, first_call=False):
         torch = self.torch
         c, o = self.chain, self.chain.ofdm

@@ -1,7 +1,9 @@
 """GPU tier, end to end: transport-stream packets go through the transmitter model (tests/t2_tx.py: BBFRAMEs, scrambling,
 LDPC, bit interleaver, rotated QAM, cell + time interleaver, frame builder with pilots, IFFT, AWGN) and come back out of
 the GPU chain (FFT -> equaliser/freq de-interleave -> time/cell de-interleave -> demap -> LDPC -> descramble -> TS) byte for
-byte. This is the 'bit-exact after BCH' criterion of the north star against an independent forward model."""
+byte. A round trip, not an independent pin: tests/t2_tx.py INVERTS the oracle's tables (carrier maps, de-interleaver permutations, bit
+de-interleaver addresses), so it shows that the chain is the inverse of that transmitter; what pins payload bits to the reference
+itself are tests/test_ref_pins_gpu.py (the reference's FEC chain objects, and for 256-QAM its ldpc_decoder::execute slot)."""
 import numpy as np
 import pytest
 

@@ -41,7 +41,8 @@ CLASS = [
     (r"v_pk_(ashr|lshr|lshl)rev_[ib]16", "pk_ashr_i16"), (r"v_perm_b32", "perm_b32"), (r"v_.*_sdwa", "sub_u16_sdwa"), (r"v_.*_dpp|v_mov_b32_dpp", "mov_dpp"),
     (r"v_med3_", "med3_i32"), (r"v_(min|max)_[iu](32|16)", "min_i32"), (r"v_bfe_|v_bfi_|v_alignbit|v_lshl_or|v_and_or|v_or3|v_xad|v_lshl_add|v_add_lshl|v_add3|v_mad_", "add3_u32"),
     (r"v_cmp|v_cmpx", "cmp_only"), (r"v_cndmask", "cmp_cnd"), (r"v_(add|sub|subrev)_(u32|co_u32|nc_u32|u16|i32)", "add_u32"),
-    (r"v_(and|or|xor|not)_b32|v_mov_b32|v_(lshl|lshr|ashr)rev_[bi]32|v_xnor", "xor_b32"), (r"v_readlane|v_readfirstlane|v_writelane", "add_u32"),
+    (r"v_(lshl|lshr|ashr)rev_[bi]32", "lshlrev_b32"), (r"v_(and|or|xor|not)_b32|v_mov_b32|v_xnor", "xor_b32"),
+    (r"v_readlane|v_readfirstlane|v_writelane", "add_u32"),
 ]
 by = collections.Counter()
 other = collections.Counter()
@@ -62,4 +63,8 @@ if other:
     print("  unclassified (taken at 4 cycles): %s" % dict(other))
     tot += 4.0 * sum(other.values())
 print("mix-weighted cycles per VALU wave instruction: %.2f" % (tot / nv))
-print(json.dumps({"valu_mix_cycles": round(tot / nv, 3), "valu_cycles_per_wave_inst": {k: rates[k]["cycles_3w"] for k in by if k in rates}}))
+out = {"valu_mix_cycles": round(tot / nv, 3), "valu_cycles_per_wave_inst": {k: rates[k]["cycles_3w"] for k in by if k in rates},
+       "valu_static_share": {k: round(v / nv, 3) for k, v in by.most_common()}}
+print(json.dumps(out))
+if len(sys.argv) > 4:
+    json.dump(out, open(sys.argv[4], "w"), indent=1)

@@ -56,7 +56,7 @@ try:
            "SQ_LDS_IDX_ACTIVE": ldpc_avg["SQ_LDS_IDX_ACTIVE"], "SQ_LDS_BANK_CONFLICT": ldpc_avg["SQ_LDS_BANK_CONFLICT"], "SQ_WAIT_ANY": ldpc_avg["SQ_WAIT_ANY"],
            "SQ_WAVE_CYCLES": ldpc_avg["SQ_WAVE_CYCLES"], "GRBM_GUI_ACTIVE": ldpc_avg["GRBM_GUI_ACTIVE"], "SQ_INSTS_LDS": ldpc_avg["SQ_INSTS_LDS"],
            "SQ_INSTS_SALU": ldpc_avg["SQ_INSTS_SALU"]}
-    mix = os.path.join(root, "gpurun_out", "ldpc_isa_mix_%s.json" % tag)
+    mix = os.path.join(root, "profiles", "ldpc_isa_mix.json")            # tools/ldpc_isa_mix.py: static op mix x the ubench's per-class cycles
     if os.path.exists(mix):
         out.update(json.load(open(mix)))
     json.dump(out, open(os.path.join(root, "gpurun_out", "ldpc_counters_%s.json" % tag), "w"), indent=1)
