@@ -321,7 +321,11 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize(dev)
-            acc, ldpc, ts_bytes, kept = {}, [], 0, []
+            acc, ldpc, ts_bytes = {}, [], 0
+            if ts_on:                                  # the consumer's buffer: allocated and touched before the clock starts
+                cap = (steps + 1) * F * nb * (w.k_bch // 8 + 64) if keep_ts else F * nb * (w.k_bch // 8 + 64)
+                sink = np.empty(cap, np.uint8)
+                sink.fill(0)
             t0 = time.perf_counter()
             for _ in range(steps):
                 step(rx, level)
@@ -331,19 +335,17 @@ def main():
                 if full:
                     ldpc.append(rx.last_ldpc_ms())
                 if ts_on:                              # what the worker has finished meanwhile (it runs beside the next step)
-                    b = rx.ts_read(wait_all=False)
-                    ts_bytes += b.size
-                    if keep_ts:
-                        kept.append(b)
-            if ts_on:
-                b = rx.ts_read(wait_all=True)          # the last step's frames de-framed: demod -> TS is complete
-                ts_bytes += b.size
-                if keep_ts:
-                    kept.append(b)
+                    ts_bytes += rx.ts_read_into(sink[ts_bytes:] if keep_ts else sink)
+            if ts_on:                                  # the last step's frames de-framed: demod -> TS is complete
+                while True:
+                    n = rx.ts_read_into(sink[ts_bytes:] if keep_ts else sink, wait_all=True)
+                    ts_bytes += n
+                    if n == 0:
+                        break
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
-            return time.perf_counter() - t0, acc, ldpc, ts_bytes, (np.concatenate(kept) if kept else None)
+            return time.perf_counter() - t0, acc, ldpc, ts_bytes, (sink[:ts_bytes] if ts_on and keep_ts else None)
 
         rx = make_rx(False, F, args.trials)            # reference semantics: truncating int8 cast in the demapper
         assert rx.frame_len == FS

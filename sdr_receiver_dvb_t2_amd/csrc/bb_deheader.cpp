@@ -20,6 +20,8 @@ const uint8_t CRC_POLY = 0xAB, TEI = 0x80;
 struct t2gpu_bbdh {
     int need_plp = 0;
     uint8_t crc_table[256];
+    uint8_t hdr_table[256];                            // check_crc8_mode (:70-82) a byte at a time: state' = hdr_table[state ^ bit-reversed byte]
+    uint8_t rev8[256];
     uint8_t crc = 0;
     int idx_packet = 0, idx_buffer = 0;
     bool split = false;
@@ -77,6 +79,14 @@ extern "C" t2gpu_bbdh *t2gpu_bbdh_create(int need_plp)
             else crc <<= 1;
         }
         h->crc_table[i] = (uint8_t)crc;
+        // the header check shifts right and takes the frame's bits in order, i.e. a packed byte's MSB first: eight steps of it from
+        // state c on byte v give T[c ^ rev8(v)], T = eight steps from state x on zero input (the update is linear in (state, input))
+        uint8_t c = (uint8_t)i;
+        for (int k = 0; k < 8; ++k) { const uint8_t b = c & 1; c >>= 1; if (b) c ^= CRC_POLY; }
+        h->hdr_table[i] = c;
+        uint8_t rv = 0;
+        for (int k = 0; k < 8; ++k) rv |= (uint8_t)(((i >> k) & 1) << (7 - k));
+        h->rev8[i] = rv;
     }
     return h;
 }
@@ -95,10 +105,14 @@ int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool pa
     uint8_t *tei = nullptr;
     // BBHEADER CRC over its 80 bits: remainder 0 = normal mode, 0xAB = high-efficiency mode (CRC-8 xor MODE), :70-82,101-113
     uint8_t c = 0;
-    for (int i = 0; i < BBH_BITS; ++i) {
-        uint8_t b = (uint8_t)(in.bit(i) ^ (c & 0x01));
-        c >>= 1;
-        if (b) c ^= CRC_POLY;
+    if (packed) {
+        for (int i = 0; i < BBH_BITS / 8; ++i) c = h->hdr_table[c ^ h->rev8[bits[i]]];
+    } else {
+        for (int i = 0; i < BBH_BITS; ++i) {
+            uint8_t b = (uint8_t)(in.bit(i) ^ (c & 0x01));
+            c >>= 1;
+            if (b) c ^= CRC_POLY;
+        }
     }
     int hem;
     if (c == 0) hem = 0;
@@ -108,10 +122,14 @@ int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool pa
     if (h->need_plp != plp_id) return -2;              // :139-142
     long hp = 16;                                      // MATYPE (TS/GS, SIS/MIS, CCM/ACM, ISSYI, NPD, EXT | ISI): not used by the data path
     int upl = 0, dfl = 0, sync = 0, syncd = 0;
-    for (int i = 15; i >= 0; --i) upl |= in.bit(hp++) << i;
-    for (int i = 15; i >= 0; --i) dfl |= in.bit(hp++) << i;
-    for (int i = 7; i >= 0; --i) sync |= in.bit(hp++) << i;
-    for (int i = 15; i >= 0; --i) syncd |= in.bit(hp++) << i;
+    if (packed) {                                      // the same fields from whole bytes (MSB-first packing = the fields' own bit order)
+        upl = bits[2] << 8 | bits[3]; dfl = bits[4] << 8 | bits[5]; sync = bits[6]; syncd = bits[7] << 8 | bits[8];
+    } else {
+        for (int i = 15; i >= 0; --i) upl |= in.bit(hp++) << i;
+        for (int i = 15; i >= 0; --i) dfl |= in.bit(hp++) << i;
+        for (int i = 7; i >= 0; --i) sync |= in.bit(hp++) << i;
+        for (int i = 15; i >= 0; --i) syncd |= in.bit(hp++) << i;
+    }
     (void)upl; (void)sync;
     if (syncd == 65535) return -2;                     // no user packet starts in this frame (:160-163)
     in.skip(BBH_BITS);
@@ -185,15 +203,26 @@ int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool pa
             }
         }
     } else {                                           // ---- high-efficiency mode (:323-417): 187-byte packets, sync re-inserted
+        // n frame bytes to dst, in one piece where the frame is packed and the run byte-aligned inside it, else bit by bit as written
+        auto take = [&in](uint8_t *dst, int n) {
+            const uint8_t *src = n > 8 ? in.run(n) : nullptr;
+            if (src) { std::memcpy(dst, src, (size_t)n); in.skip(8L * n); }
+            else for (int i = 0; i < n; ++i) dst[i] = in.byte();
+        };
+        auto emit = [&](int n) {                      // ... to the output (the reference's `*out++ = temp` loops)
+            if (n > 0 && snk.end - snk.o >= n) { take(snk.o, n); snk.o += n; snk.n += n; }
+            else for (int i = 0; i < n; ++i) snk.put(in.byte());
+        };
         if (h->split) {
             h->split = false;
-            for (int i = 0; i < h->idx_buffer; ++i) snk.put(h->buffer[i]);
+            if (snk.end - snk.o >= h->idx_buffer) { std::memcpy(snk.o, h->buffer, (size_t)h->idx_buffer); snk.o += h->idx_buffer; snk.n += h->idx_buffer; }
+            else for (int i = 0; i < h->idx_buffer; ++i) snk.put(h->buffer[i]);
             const int len_split = TS_LEN - h->idx_packet, syncd_byte = syncd / 8;
             if (len_split <= syncd_byte) {
-                for (int i = 0; i < len_split; ++i) { snk.put(in.byte()); ++h->idx_packet; }
+                emit(len_split); h->idx_packet += len_split;
                 if (len_split < syncd_byte) { in.skip(syncd - len_split * 8); ++h->resync; }
             } else {
-                for (int i = 0; i < syncd_byte; ++i) { snk.put(in.byte()); ++h->idx_packet; }
+                emit(syncd_byte); h->idx_packet += syncd_byte;
                 for (int i = 0; i < len_split - syncd_byte; ++i) { snk.put(0xF0); ++h->idx_packet; }
                 ++h->resync;
             }
@@ -206,15 +235,16 @@ int bbdh_run(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bits, bool pa
                 h->split = true;
                 const int len_split = dfl / 8;
                 h->idx_buffer = 0;
-                for (int i = 0; i < len_split && h->idx_buffer < TS_LEN; ++i) {
+                for (int i = 0; i < len_split && h->idx_buffer < TS_LEN;) {      // the reference's byte loop (:389-403), run by run
                     if (h->idx_packet == TS_LEN) {
                         h->idx_packet = 0;
                         h->buffer[h->idx_buffer++] = 0x47;
                         ++h->idx_packet;
                         if (h->idx_buffer == TS_LEN) break;
                     }
-                    h->buffer[h->idx_buffer++] = in.byte();
-                    ++h->idx_packet;
+                    const int n = std::min(std::min(len_split - i, TS_LEN - h->idx_packet), TS_LEN - h->idx_buffer);
+                    take(h->buffer + h->idx_buffer, n);
+                    h->idx_buffer += n; h->idx_packet += n; i += n;
                 }
                 dfl = 0;
             } else {

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -100,7 +101,9 @@ struct TsEnd {
     hipStream_t copy_stream = nullptr;        // the device -> host copies run beside the next call's kernels
     hipEvent_t decoded = nullptr;             // recorded on the call's stream behind K-descramble-pack
     hipEvent_t last_copy = nullptr;           // `ready` of the newest job: the next back half waits for it before it overwrites the rows
-    std::deque<std::vector<uint8_t>> ts;      // TS bytes not yet read: one chunk per job, oldest first
+    struct Chunk { std::unique_ptr<uint8_t[]> p; size_t cap = 0, size = 0; };
+    std::deque<Chunk> ts;                     // TS bytes not yet read: one chunk per job, oldest first
+    std::vector<Chunk> pool;                  // chunks handed out completely, reused by the worker (no fresh pages per job)
     size_t ts_head = 0, ts_pending = 0;       // bytes of the first chunk already handed out / bytes waiting in all chunks
     std::deque<std::pair<long, int>> l1_status;   // (running T2-frame number, status bits) of frames whose FEC frames may still come
     t2gpu_rx_ts_counters n{};
@@ -450,8 +453,6 @@ void ts_worker(TsEnd *t)
     t2gpu_rx *h = t->rx;
     hipSetDevice(h->device);
     const int row = h->k_bch / 8, nb = h->cfg.plp_num_blocks;
-    std::vector<uint8_t> out((size_t)row + 2 * 188 + 64);
-    std::vector<uint8_t> local;
     for (;;) {
         TsJob j;
         {
@@ -464,8 +465,16 @@ void ts_worker(TsEnd *t)
         TsSlot &sl = t->slot[j.slot];
         const bool ok = hipEventSynchronize(sl.ready) == hipSuccess;
         t2gpu_rx_ts_counters d{};
-        local.clear();
-        local.reserve((size_t)j.fec_frames * (row + 64));
+        const size_t per = (size_t)row + 2 * 188 + 64;           // the de-framer's out_cap contract: len_in / 8 + 376
+        const size_t need = (size_t)j.fec_frames * per + per;
+        TsEnd::Chunk local;                                      // BBFRAMEs are de-framed straight into the chunk the reader gets
+        {
+            std::lock_guard<std::mutex> lk(t->m);
+            for (size_t k = 0; k < t->pool.size(); ++k)
+                if (t->pool[k].cap >= need) { local = std::move(t->pool[k]); t->pool.erase(t->pool.begin() + (long)k); break; }
+        }
+        if (local.cap < need) { local.p.reset(new uint8_t[need]); local.cap = need; }
+        size_t used = 0;
         if (ok) {
             std::vector<std::pair<long, int>> st;
             if (t->l1_check)
@@ -496,16 +505,18 @@ void ts_worker(TsEnd *t)
                     if (v != (L1_PRE_OK | L1_POST_OK | L1_MATCH)) { ++d.fec_frames_dropped_l1; continue; }
                 }
                 int err = 0;
-                const int n = t2gpu_bbdh_execute_packed(t->bbdh, t->need_plp, h->k_bch, sl.pack + (size_t)i * row, out.data(), (int)out.size(), &err);
+                const int n = t2gpu_bbdh_execute_packed(t->bbdh, t->need_plp, h->k_bch, sl.pack + (size_t)i * row, local.p.get() + used, (int)per, &err);
                 if (n == -1) ++d.bbheader_crc_errors;
                 d.ts_packet_errors += err;
                 d.resync += t2gpu_bbdh_resync_count(t->bbdh);
-                if (n > 0) { local.insert(local.end(), out.begin(), out.begin() + n); d.ts_bytes += n; }
+                if (n > 0) { used += (size_t)n; d.ts_bytes += n; }
             }
         }
+        local.size = ok ? used : 0;
         {
             std::lock_guard<std::mutex> lk(t->m);
-            if (!local.empty()) { t->ts_pending += local.size(); t->ts.emplace_back(std::move(local)); local = std::vector<uint8_t>(); }
+            if (local.size) { t->ts_pending += local.size; t->ts.emplace_back(std::move(local)); }
+            else if (local.cap) t->pool.emplace_back(std::move(local));
             t->n.t2_frames += d.t2_frames; t->n.l1_pre_crc_errors += d.l1_pre_crc_errors; t->n.l1_post_crc_errors += d.l1_post_crc_errors;
             t->n.l1_mismatches += d.l1_mismatches; t->n.fec_frames += d.fec_frames; t->n.fec_frames_dropped_ldpc += d.fec_frames_dropped_ldpc;
             t->n.fec_frames_dropped_l1 += d.fec_frames_dropped_l1; t->n.bbheader_crc_errors += d.bbheader_crc_errors;
@@ -596,11 +607,14 @@ extern "C" long t2gpu_rx_ts_read(t2gpu_rx *h, uint8_t *out, long cap, int wait_a
     if (wait_all) t->cv_done.wait(lk, [&] { return t->in_flight == 0; });
     long n = 0;
     while (n < cap && !t->ts.empty()) {
-        std::vector<uint8_t> &c = t->ts.front();
-        const size_t take = std::min<size_t>((size_t)(cap - n), c.size() - t->ts_head);
-        std::memcpy(out + n, c.data() + t->ts_head, take);
+        TsEnd::Chunk &c = t->ts.front();
+        const size_t take = std::min<size_t>((size_t)(cap - n), c.size - t->ts_head);
+        std::memcpy(out + n, c.p.get() + t->ts_head, take);
         n += (long)take; t->ts_head += take; t->ts_pending -= take;
-        if (t->ts_head == c.size()) { t->ts.pop_front(); t->ts_head = 0; }
+        if (t->ts_head == c.size) {
+            if (t->pool.size() < 4) t->pool.emplace_back(std::move(c));
+            t->ts.pop_front(); t->ts_head = 0;
+        }
     }
     return n;
 }

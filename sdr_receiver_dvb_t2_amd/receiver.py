@@ -286,6 +286,11 @@ class t2_rx(object):
         n = self._check(self._l.t2gpu_rx_ts_read(self._h, out.ctypes.data, out.size, 0), "t2gpu_rx_ts_read") if out.size else 0
         return out[:n]
 
+    def ts_read_into(self, buf, wait_all=False):
+        """The same into a caller's uint8 buffer (no allocation, no page faults in a consumer loop); returns the number of bytes written
+        (<= buf.size; what does not fit stays queued)."""
+        return self._check(self._l.t2gpu_rx_ts_read(self._h, buf.ctypes.data, buf.size, int(wait_all)), "t2gpu_rx_ts_read")
+
     def ts_counters(self, wait_all=True):
         c = rx_ts_counters()
         self._check(self._l.t2gpu_rx_ts_counters_get(self._h, int(wait_all), ctypes.byref(c)), "t2gpu_rx_ts_counters_get")

@@ -387,6 +387,7 @@ def test_whole_receiver_against_the_reference(built, grx, tmp_path):
     mine = set(int(c) for c in rc.crc_rows(ts[:ts.size // 188 * 188].reshape(-1, 188)))
     ref = [int(c) for c in g["ts_packet_crc"]]
     both = [c for c in ref if c in mine]
+    print("whole receiver: %d of the reference's %d packets recovered (%d produced)" % (len(both), len(ref), len(mine)))
     assert len(both) >= 0.8 * len(ref), (len(both), len(ref), len(mine))
     # and frame for frame: every frame the reference recovered after frame 5 is recovered here
     found = [f for f in range(len(marks)) if ts.tobytes().find(marks[f]) >= 0]
