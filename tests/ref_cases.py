@@ -114,6 +114,12 @@ FEC_CASES = {
     "q16_n12": (1, 1, 0, 33, 10.0, 4),        # 16-QAM, 64800, r=1/2
     "qpsk_s34": (0, 0, 3, 40, 6.0, 5),        # QPSK, 16200, r=3/4
     "q64_n35": (2, 1, 1, 32, 15.0, 6),        # 64-QAM, 64800, r=3/5 (demux_64_fec_size_normal_code_3_5)
+    # at the decoding threshold (found with the reference itself): some SIMD batches of the TI block decode in the last sweeps, some are
+    # dropped -- where a one-step LLR difference could flip a batch, decode / drop equality is tested, not assumed
+    "q64_s12_edge": (2, 0, 0, 160, 10.2, 11),   # 64-QAM, 16200, r=1/2: the reference decodes 2 of 5 batches (1 trial left each)
+    "qpsk_n12_edge": (0, 1, 0, 64, 1.0, 12),    # QPSK, 64800, r=1/2: 1 of 2 (2 trials left)
+    "q16_n35_edge": (1, 1, 1, 96, 7.65, 13),    # 16-QAM, 64800, r=3/5: 2 of 3 (2 trials left)
+    "q64_n23_edge": (2, 1, 2, 96, 13.8, 14),    # 64-QAM, 64800, r=2/3: 2 of 3 (0 trials left: decoded by the 25th sweep)
 }
 FEC_L1_POST_SIZE = 200
 

@@ -193,10 +193,12 @@ def test_fec_chain_against_the_reference(torch_cuda, gfec, name):
     if mod == 3:
         assert (t < 0).all()                                                     # the reference drops every 256-QAM batch too
         return
-    B = bits.cpu().numpy()
+    keep = np.repeat(t >= 0, 32)                                                 # frames of the batches that decoded (the reference emits only those)
+    assert keep.any()
+    B = bits.cpu().numpy()[keep]
     assert np.array_equal(rc.crc_rows(B), g["ldpc_crc"]) and np.array_equal(np.packbits(B[0]), g["ldpc_first"])
     bch = pkg.bch_decoder(fec_type, code_rate)
-    D = bch.execute_dev(bits).cpu().numpy()
+    D = bch.execute_dev(bits).cpu().numpy()[keep]
     assert np.array_equal(rc.crc_rows(D), g["bb_crc"]) and np.array_equal(np.packbits(D[0]), g["bb_first"])
     l = pkg.lib()
     h = l.t2gpu_bbdh_create(0)
@@ -244,10 +246,12 @@ def test_ldpc_stage_256qam_payload_against_the_reference(torch_cuda, gbatch, nam
     bits, trials = dec.execute_dev(torch.from_numpy(llr).cuda())
     torch.cuda.synchronize()
     assert dec.status() == 0 and (trials.cpu().numpy() >= 0).all() and int(g["ldpc_batches"]) == nb // 32
-    B = bits.cpu().numpy()
+    keep = np.repeat(t >= 0, 32)                                                 # frames of the batches that decoded (the reference emits only those)
+    assert keep.any()
+    B = bits.cpu().numpy()[keep]
     assert np.array_equal(rc.crc_rows(B), g["ldpc_crc"]) and np.array_equal(np.packbits(B[0]), g["ldpc_first"])
     bch = pkg.bch_decoder(fec_type, code_rate)
-    D = bch.execute_dev(bits).cpu().numpy()
+    D = bch.execute_dev(bits).cpu().numpy()[keep]
     assert np.array_equal(rc.crc_rows(D), g["bb_crc"]) and np.array_equal(np.packbits(D[0]), g["bb_first"])
     P = bch.execute_packed_dev(bits).cpu().numpy()
     assert P.shape == (nb, k_bch // 8) and np.array_equal(P, np.packbits(D, axis=1))
@@ -364,7 +368,8 @@ def test_whole_receiver_against_the_reference(built, grx, tmp_path):
     """int16 I/Q -> TS through t2::dvbt2_demodulator and the stage classes in a plain C++ process (tests/cpp/stage_mirror_test.cpp
     rx) on the stream the REFERENCE's dvbt2_demodulator decoded for the fixture: same acquisition outcome (guard interval found,
     L1 parsed, de-interleaver started), and the TS packets are the reference's, packet for packet, wherever both produced output
-    (acquisition may settle a frame apart: the tracking loops are floats fed by tolerance-equal estimates)."""
+    (all 4614 of them in round 3's runs; the 2 % margin is one frame of acquisition: the tracking loops are floats fed by
+    tolerance-equal estimates)."""
     import zlib
     g = sub(grx, "rx", "rx")
     exe = str(tmp_path / "stage_mirror_test")
@@ -388,7 +393,7 @@ def test_whole_receiver_against_the_reference(built, grx, tmp_path):
     ref = [int(c) for c in g["ts_packet_crc"]]
     both = [c for c in ref if c in mine]
     print("whole receiver: %d of the reference's %d packets recovered (%d produced)" % (len(both), len(ref), len(mine)))
-    assert len(both) >= 0.8 * len(ref), (len(both), len(ref), len(mine))
+    assert len(both) >= 0.98 * len(ref), (len(both), len(ref), len(mine))     # measured: 4614 of 4614 (round 3); the margin is for a frame of acquisition
     # and frame for frame: every frame the reference recovered after frame 5 is recovered here
     found = [f for f in range(len(marks)) if ts.tobytes().find(marks[f]) >= 0]
     assert set(int(f) for f in g["frames_found"] if f >= 6) <= set(found), (found, g["frames_found"])
