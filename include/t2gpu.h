@@ -86,6 +86,11 @@ int t2gpu_ldpc_status(t2gpu_ldpc *h);
  * sums3 = {sum_s, sum_e, precision}: the hard-decision signal / error energies the reference derives its LLR scale
  * 8*norm*sum_s/sum_e from (SNR readout: 20*log10(sum_s/sum_e), llr_demapper.cpp:659). The reference de-rotates its input
  * buffer in place; this implementation de-rotates on the fly and leaves the input untouched.
+ * The two sums are formed as the reference forms them -- SEQUENTIAL float additions in cell order (one vaddss per cell and sum in the
+ * reference binary) -- reproduced bit for bit by a parallel kernel (quantised integer prefix sums inside a binade, real float adds at
+ * binade changes and rounding ties; csrc/fec_kernels.hip: demap_stats_exact_kernel): the scale, hence every LLR, equals what the
+ * reference's arithmetic gives on the same cells. (T2GPU_DEMAP_TREE_STATS=1 selects the tree / double sums of rounds 1-2: ~1e-4 off in
+ * the scale, one LLR step on ~2 % of the positions.)
  * precision_override > 0 fixes the LLR scale instead of measuring it (used by parity tests; 0 = reference behaviour).
  * Grouping the frames into SIMD batches of 32 for the LDPC stage (static `blocks`, llr_demapper.cpp:549-552) is the
  * caller's business: frames leave in arrival order. */
@@ -135,10 +140,9 @@ int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
  * out_stride_cells. Same result as t2gpu_ti_begin + one whole-block t2gpu_ti_push_dev per block. Returns n_blocks. */
 int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, long in_stride_cells, float *d_out, long out_stride_cells,
                                 int n_blocks, void *stream);
-/* The same with the demapper's first pass folded in (llr_demapper.cpp:564-676: hard decisions, sum_s, sum_e over the TI block): the
- * de-interleaver forms them while the cells leave it, one pass over the cells instead of two. d_sums + b * sums_stride receives
- * (sum_s, sum_e, precision) of TI block b -- what t2gpu_demap_stats_batch_dev(dm, d_out, ...) would deliver (same terms, summed in
- * double per FEC block first). dm: the demapper of the same modulation / FEC type (its rotation and constellation). Returns n_blocks. */
+/* t2gpu_ti_execute_blocks_dev followed by the demapper's first pass (t2gpu_demap_stats_batch_dev) on the de-interleaved blocks, as one
+ * call: d_sums + b * sums_stride receives (sum_s, sum_e, precision) of TI block b. dm: the demapper of the same modulation / FEC type.
+ * Returns n_blocks. */
 int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
                                       long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
                                       void *stream);

@@ -14,6 +14,8 @@ hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, 
 hipError_t launch_bch_descramble_pack(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs_packed, uint8_t *out,
                                       hipStream_t s);
 
+long demap_terms_padded(int n_snr);      // term pairs of scratch launch_demap_stats* need per TI block (n_snr rounded up to whole chunks)
+
 struct DemapParams {
     int mod;                 // 0 QPSK, 1 16-QAM, 2 64-QAM, 3 256-QAM
     int fec_size, bits_per_cell, cells_per_fec;
@@ -25,10 +27,10 @@ struct DemapParams {
 };
 // K-snr-reduce: sums[0] = sum |s|^2, sums[1] = sum |e|^2 over the hard decisions of n_snr cells (device doubles),
 // partial[] = scratch of 2*blocks doubles. Second stage folds them and writes float sums[0..2] (s, e, precision).
-hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
+hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float2 *terms, float *sums,
                               float precision_override, hipStream_t s);
 hipError_t launch_demap_stats_batch(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, double *partial,
-                                    int blocks, float *sums, int sums_stride, float precision_override, hipStream_t s);
+                                    int blocks, float2 *terms, float *sums, int sums_stride, float precision_override, hipStream_t s);
 // K-demap-bdi: one workgroup per FEC frame; LLRs staged in LDS in LDPC order, written out coalesced.
 // frames_per_sums / sums_stride: several TI blocks in one launch, each with its own statistics triple (0 = one triple for all)
 hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_frames, const float *sums, int8_t *out, hipStream_t s,
@@ -54,9 +56,3 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
 
 }  // namespace t2gpu
 
-namespace t2gpu {
-// whole TI blocks (one workgroup per FEC block) with the demapper's statistics formed on the way out (fec_kernels.hip)
-hipError_t launch_ti_blocks_stats(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
-                                  float2 *out, long out_stride, int frames, const DemapParams &dp, int n_snr, double *partial, float *sums,
-                                  int sums_stride, float precision_override, hipStream_t s);
-}

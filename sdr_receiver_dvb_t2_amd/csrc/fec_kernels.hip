@@ -1,6 +1,7 @@
 // fec_kernels.hip -- FEC-side streaming kernels for gfx950: BB descrambler (BCH stub), LLR demapper + bit de-interleaver,
 // time / cell de-interleaver with cyclic Q-delay removal. All HBM-bound gather/scatter work; no matrix cores involved.
 #include "fec_kernels.h"
+#include <cstdlib>
 
 // The reference is built without FMA (-mavx2 only): every product and sum rounds on its own. HIP's mul_r/add_r
 // are header-defined plain operators carrying the default "contract" flag, i.e. the compiler still fuses them; the
@@ -96,37 +97,22 @@ __device__ __forceinline__ float2 derotate(float2 v, float c, float s)
     return make_float2(sub_r(mul_r(v.x, c), mul_r(v.y, s)), add_r(mul_r(v.x, s), mul_r(v.y, c)));
 }
 
+// Hard decision on one axis: the comparison trees of llr_demapper.cpp:257-276 (16-QAM), :395-436 (64-QAM), :567-654 (256-QAM) without
+// their branches -- a wavefront's lanes take all sixteen paths of the 256-QAM tree otherwise. The trees compare x > t on the positive
+// side and x < -t on the negative one with t = d * 2, d * 4, ...: the level is the number of thresholds |x| exceeds (strictly), the
+// amplitude d * (2 level + 1) the same float product the tree returns, x = 0 goes with the negatives. 64-QAM, negative side: the
+// reference tests `x > x6` there (:407,427), which a negative x never passes: the outermost point is never decided.
 __device__ __forceinline__ float slice_axis(int mod, float x, float d)
 {
-    const float x2 = d * 2.0f, x4 = d * 4.0f, x6 = d * 6.0f;
-    if (mod == 0) return x > 0 ? d : -d;
-    if (mod == 1) {
-        if (x > 0) return (x > x2) ? d * 3.0f : d;
-        return (x < -x2) ? -(d * 3.0f) : -d;
-    }
-    if (mod == 2) {
-        if (x > 0) {
-            if (x > x4) return (x > x6) ? d * 7.0f : d * 5.0f;
-            return (x > x2) ? d * 3.0f : d;
-        }
-        if (x < -x4) return (x > x6) ? -(d * 7.0f) : -(d * 5.0f);     // llr_demapper.cpp:407,427: '>' as written
-        return (x < -x2) ? -(d * 3.0f) : -d;
-    }
-    const float x8 = d * 8.0f, x10 = d * 10.0f, x12 = d * 12.0f, x14 = d * 14.0f;
-    if (x > 0) {
-        if (x > x8) {
-            if (x > x12) return (x > x14) ? d * 15.0f : d * 13.0f;
-            return (x > x10) ? d * 11.0f : d * 9.0f;
-        }
-        if (x > x4) return (x > x6) ? d * 7.0f : d * 5.0f;
-        return (x > x2) ? d * 3.0f : d;
-    }
-    if (x < -x8) {
-        if (x < -x12) return (x < -x14) ? -(d * 15.0f) : -(d * 13.0f);
-        return (x < -x10) ? -(d * 11.0f) : -(d * 9.0f);
-    }
-    if (x < -x4) return (x < -x6) ? -(d * 7.0f) : -(d * 5.0f);
-    return (x < -x2) ? -(d * 3.0f) : -d;
+    const float a = fabsf(x);
+    int lvl = 0;
+    if (mod >= 1) lvl += a > d * 2.0f ? 1 : 0;
+    if (mod >= 2) { lvl += a > d * 4.0f ? 1 : 0; lvl += a > d * 6.0f ? 1 : 0; }
+    if (mod >= 3) { lvl += a > d * 8.0f ? 1 : 0; lvl += a > d * 10.0f ? 1 : 0; lvl += a > d * 12.0f ? 1 : 0; lvl += a > d * 14.0f ? 1 : 0; }
+    const bool pos = x > 0;
+    if (mod == 2 && !pos) lvl = min(lvl, 2);
+    const float amp = d * (float)(2 * lvl + 1);
+    return pos ? amp : -amp;
 }
 
 // blockIdx.y = TI block of a batch: its cells at cells + y * cells_stride, its partial sums at partial + y * 2 * gridDim.x
@@ -170,19 +156,281 @@ __global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__r
     sums[0] = fs; sums[1] = fe; sums[2] = precision;
 }
 
-hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float *sums,
+// ---- K-snr, exact: the reference's statistics are two SEQUENTIAL float sums over the TI block (llr_demapper.cpp:564-676; in the
+// reference binary one vaddss per cell and sum, in cell order) -- float addition is not associative, and a tree or double-precision sum
+// (demap_stats_kernel above: the round 1-2 form, kept for comparison) differs from it by ~1e-4 relative, i.e. one LLR step on ~2 % of
+// the positions, enough to flip a SIMD batch at the decoding threshold. This kernel reproduces the sequential sum bit for bit, in
+// parallel: while the running sum s stays inside one binade [2^E, 2^(E+1)), fl(s + x) = s + round(x / ulp) ulp with ulp = 2^(E-23) --
+// an INTEGER addition of the terms quantised at that ulp, which is associative -- except where x / ulp sits exactly on a half (the
+// tie is broken by the parity of s / ulp) and at the addition that carries s into the next binade. So: quantise a chunk's terms at the
+// current ulp, prefix-sum them over the workgroup, find the first such event, jump s to just before it in one step, perform that one
+// addition as a real float add, and go on from there (with the new ulp if it changed). A TI block of 1.6 M cells has about 25 events
+// per sum (one per binade, plus ties while s is still small). One workgroup per TI block; the chunks of a block are its cells in
+// order, SEQ_U consecutive cells per lane. Checked against a sequential float loop on tie-heavy data in tests/test_fec_gpu.py.
+constexpr int SEQ_THREADS = 512, SEQ_U = 32, SEQ_CHUNK = SEQ_THREADS * SEQ_U, SEQ_WAVES = SEQ_THREADS / 64;
+constexpr int SEQ_HEAD = 2048;                     // cells summed by the plain sequential loop before the chunked walk starts
+constexpr int SEQ_CAP = 1 << 25;
+constexpr int SEQ_LDS_BYTES = (SEQ_CHUNK + SEQ_THREADS) * 4;      // a chunk of one sum in cell order, one pad word per lane
+static_assert(SEQ_HEAD * 8 <= SEQ_LDS_BYTES && SEQ_HEAD <= SEQ_CHUNK, "the head is staged in the same LDS");                    // quantised terms and their sums saturate here: anything >= 2^24 ends the binade anyway
+
+struct SeqShared {
+    int4 tot[2][1][SEQ_WAVES / 4];                  // [buffer][sum][wavefront]: saturated totals of the quantised terms, bit 30 = a rounding tie among them
+    int scan[SEQ_WAVES];                            // event path
+    int before, first;
+    float x;
+};
+
+__device__ __forceinline__ int sat_add(int a, int b) { return min(a + b, SEQ_CAP); }   // associative on [0, SEQ_CAP]
+// x / ulp rounded to an integer as fl(s + x) rounds it while s stays in its binade; tie: the fraction is exactly one half
+// (then the parity of s / ulp decides). All float operations here are exact (scaling by a power of two, floor, difference).
+__device__ __forceinline__ int seq_quant(float x, float inv_ulp, bool &tie)
+{
+    const float y = fminf(mul_r(x, inv_ulp), (float)SEQ_CAP), m = floorf(y), f = sub_r(y, m);
+    tie = f == 0.5f;
+    return (int)m + (f > 0.5f ? 1 : 0);
+}
+struct SeqScale { float inv_ulp, ulp; int S; };
+__device__ __forceinline__ SeqScale seq_scale(float s)
+{
+    const int E = (int)((__float_as_uint(s) >> 23) & 0xffu) - 127;      // s in [2^E, 2^(E+1)) (the sums are far from the denormals)
+    SeqScale r;
+    r.inv_ulp = __uint_as_float((uint32_t)(127 + 23 - E) << 23);
+    r.ulp = __uint_as_float((uint32_t)(127 + E - 23) << 23);
+    r.S = (int)mul_r(s, r.inv_ulp);                                    // s / ulp: an integer in [2^23, 2^24)
+    return r;
+}
+
+// Event path: one step of the walk over the chunk's terms x (this lane: chunk indices tid * SEQ_U + u) from index a on; returns the
+// new a (SEQ_CHUNK = chunk consumed). s is uniform over the workgroup. Three barriers; taken ~25 times per sum and TI block.
+__device__ __forceinline__ int seq_step(const float (&x)[SEQ_U], int a, float &s, SeqShared &sh)
+{
+    const int tid = (int)threadIdx.x, k0 = tid * SEQ_U, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();                                                   // whoever still reads the shared words of the previous step
+    if (tid == 0) sh.first = SEQ_CHUNK;
+    if (s == 0.0f) {                                                   // 0 + x = x exactly: take the first non-zero term as it is
+        int cand = SEQ_CHUNK;
+#pragma unroll
+        for (int u = SEQ_U - 1; u >= 0; --u) if (k0 + u >= a && x[u] > 0.0f) cand = k0 + u;
+        __syncthreads();
+        if (cand < SEQ_CHUNK) atomicMin(&sh.first, cand);
+        __syncthreads();
+        const int p = sh.first;
+        if (p >= SEQ_CHUNK) return SEQ_CHUNK;
+        if (tid == p / SEQ_U) {
+#pragma unroll
+            for (int u = 0; u < SEQ_U; ++u) if (u == p % SEQ_U) sh.x = x[u];       // (no dynamic register index: that would put x[] in scratch)
+        }
+        __syncthreads();
+        s = sh.x;
+        return p + 1;
+    }
+    const SeqScale sc = seq_scale(s);
+    int pre[SEQ_U], loc = 0, tie_at = SEQ_CHUNK;
+#pragma unroll
+    for (int u = 0; u < SEQ_U; ++u) {
+        int q = 0;
+        if (k0 + u >= a) {
+            bool tie;
+            q = seq_quant(x[u], sc.inv_ulp, tie);
+            if (tie && tie_at == SEQ_CHUNK) tie_at = k0 + u;
+        }
+        loc = sat_add(loc, q);
+        pre[u] = loc;                                                  // inclusive prefix inside the lane
+    }
+    int inc = loc;                                                     // inclusive prefix over the lanes (lane order = cell order)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc = sat_add(inc, o); }
+    if (lane == 63) sh.scan[wave] = inc;
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SEQ_WAVES; ++w) { const int t = sh.scan[w]; if (w < wave) off = sat_add(off, t); total = sat_add(total, t); }
+    off = sat_add(off, __shfl_up(inc, 1, 64) * (lane > 0));            // exclusive prefix of this lane
+    // first term that carries s out of its binade (s / ulp reaches 2^24), or whose rounding is a tie
+    int cand = tie_at;
+#pragma unroll
+    for (int u = SEQ_U - 1; u >= 0; --u) if (k0 + u >= a && sc.S + sat_add(off, pre[u]) >= (1 << 24) && k0 + u < cand) cand = k0 + u;
+    if (cand < SEQ_CHUNK) atomicMin(&sh.first, cand);
+    __syncthreads();
+    const int p = sh.first;
+    if (p >= SEQ_CHUNK) {                                              // no event: the whole rest of the chunk in one integer addition
+        s = mul_r((float)(sc.S + total), sc.ulp);
+        return SEQ_CHUNK;
+    }
+    if (tid == p / SEQ_U) {
+        sh.before = off;                                               // quantised terms a .. p - 1 (no event among them: below 2^24)
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) {
+            if (u == p % SEQ_U) sh.x = x[u];
+            if (u + 1 == p % SEQ_U) sh.before = sat_add(off, pre[u]);
+        }
+    }
+    __syncthreads();
+    s = add_r(mul_r((float)(sc.S + sh.before), sc.ulp), sh.x);         // the event's own addition, as the float addition it is
+    return p + 1;
+}
+
+// The terms of the two sums, one pair per cell, by the whole device (the per-cell arithmetic of llr_demapper.cpp:564-676: de-rotate,
+// slice, |s|^2 and |e|^2 as float): the sequential walk below is one workgroup per TI block and must not carry this work.
+__global__ __launch_bounds__(256) void demap_terms_kernel(DemapParams p, const float2 *__restrict__ cells, int n_snr, long cells_stride,
+                                                         float2 *__restrict__ terms, long terms_stride)
+{
+    cells += (long)blockIdx.y * cells_stride;
+    terms += (long)blockIdx.y * terms_stride;
+    const int padded = (n_snr + SEQ_CHUNK - 1) / SEQ_CHUNK * SEQ_CHUNK;        // zeros behind the block: the walk reads whole chunks unguarded
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) {
+        float2 t = make_float2(0.0f, 0.0f);
+        if (i < n_snr) {
+            float2 v = cells[i];
+            if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
+            const float sr = slice_axis(p.mod, v.x, p.d), si = slice_axis(p.mod, v.y, p.d);
+            const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
+            t = make_float2(add_r(mul_r(sr, sr), mul_r(si, si)), add_r(mul_r(er, er), mul_r(ei, ei)));
+        }
+        terms[i] = t;
+    }
+}
+
+// One workgroup per TI block walks the block's terms in cell order, SEQ_CHUNK at a time. Lane l of wavefront w holds the chunk's terms
+// w * 64 * SEQ_U + r * 128 + 2 l + {0, 1}, r < SEQ_U / 2 (16-byte loads, 1 KB per wavefront and instruction); the common case needs
+// only the chunk's total, which no order affects: without a tie, round-to-nearest-even of x / ulp IS the rounding of the addition.
+// A chunk with an event is transposed through LDS so that every lane holds SEQ_U consecutive terms, and walked by seq_step.
+__device__ __forceinline__ int seq_pos(int wave, int lane, int u) { return wave * 64 * SEQ_U + (u >> 1) * 128 + 2 * lane + (u & 1); }
+
+// blockIdx.x = TI block, blockIdx.y = which sum (0: sum_s, 1: sum_e -- two independent chains, a workgroup each); the workgroup of
+// sum_e waits for sum_s through nothing: the scale is formed by demap_scale_kernel from the two results.
+__global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const float2 *__restrict__ terms, int n_snr, long terms_stride,
+                                                                       float *__restrict__ sums, int sums_stride)
+{
+    __shared__ SeqShared sh;
+    extern __shared__ float seq_tr[];                                  // [SEQ_CHUNK + pad]: a chunk's terms in cell order
+    terms += (long)blockIdx.x * terms_stride;
+    sums += (long)blockIdx.x * sums_stride;
+    const int which = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 *src = reinterpret_cast<const float4 *>(terms) + (wave * 64 * SEQ_U) / 2 + lane;      // + 64 r: this lane's pairs inside a chunk
+    float s = 0.0f;                                                    // the running sum: uniform over the workgroup
+    float4 c[SEQ_U / 2];
+#pragma unroll
+    for (int r = 0; r < SEQ_U / 2; ++r) c[r] = src[64 * r];
+    // The head of the block as the plain loop it is: while the sum is small every few additions change the binade (two thirds of a
+    // block's events fall into its first couple of thousand cells). Staged through LDS; every lane reads the same word (a broadcast)
+    // and runs the same additions: uniform, no exchange.
+    {
+        for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) { const float2 t = terms[k]; seq_tr[k] = which ? t.y : t.x; }    // (zeros behind the block's end)
+        __syncthreads();
+#pragma unroll 16
+        for (int k = 0; k < SEQ_HEAD; ++k) s = add_r(s, seq_tr[k]);
+    }
+    int buf = 0;
+    for (int base = 0; base < n_snr; base += SEQ_CHUNK, buf ^= 1) {
+        float x[SEQ_U];
+#pragma unroll
+        for (int r = 0; r < SEQ_U / 2; ++r) { x[2 * r] = which ? c[r].y : c[r].x; x[2 * r + 1] = which ? c[r].w : c[r].z; }
+        if (base < SEQ_HEAD) {                                         // (first chunk only) the head's terms are in the sum already
+#pragma unroll
+            for (int u = 0; u < SEQ_U; ++u) if (base + seq_pos(wave, lane, u) < SEQ_HEAD) x[u] = 0.0f;
+        }
+        if (base + SEQ_CHUNK < n_snr) {                                // the next chunk's terms travel while this one is summed
+#pragma unroll
+            for (int r = 0; r < SEQ_U / 2; ++r) c[r] = src[(base + SEQ_CHUNK) / 2 + 64 * r];
+        }
+        // common case: no term of the chunk ties and the chunk does not leave the binade -> one reduction, one barrier. Without a tie,
+        // round-to-nearest-even of x / ulp is what the addition's own rounding adds.
+        SeqScale sc;
+        int word = 1 << 30;
+        if (s != 0.0f) {                                               // uniform (a block of zeros stays on the event path)
+            sc = seq_scale(s);
+            int loc = 0;
+            float far = 0.0f;                                          // largest |y - rint(y)| among the terms: 1/2 = a tie
+#pragma unroll
+            for (int u = 0; u < SEQ_U; ++u) {
+                const float y = fminf(mul_r(x[u], sc.inv_ulp), (float)SEQ_CAP), r = rintf(y);
+                loc += (int)r;                                         // <= SEQ_U * 2^25: no overflow
+                far = fmaxf(far, fabsf(sub_r(y, r)));
+            }
+            word = min(loc, SEQ_CAP) | (far == 0.5f ? 1 << 30 : 0);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int o = __shfl_xor(word, d, 64);
+            word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
+        }
+        if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
+        __syncthreads();
+        int total = 0, tie = 0;
+#pragma unroll
+        for (int w = 0; w < SEQ_WAVES / 4; ++w) {
+            const int4 t = sh.tot[buf][0][w];
+            const int v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { total = sat_add(total, v[j] & (SEQ_CAP * 2 - 1)); tie |= v[j] >> 30; }
+        }
+        if (!tie && sc.S + total < (1 << 24)) { s = mul_r((float)(sc.S + total), sc.ulp); continue; }     // uniform
+        // an event in this chunk: in cell order through LDS, SEQ_U consecutive terms per lane (one pad word per lane's run, so that the
+        // lanes' reads spread over the banks), and walked event by event
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) { const int q = seq_pos(wave, lane, u); seq_tr[q + q / SEQ_U] = x[u]; }
+        __syncthreads();
+        float xt[SEQ_U];
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) xt[u] = seq_tr[tid * (SEQ_U + 1) + u];
+        for (int a = 0; a < SEQ_CHUNK;) a = seq_step(xt, a, s, sh);
+        __syncthreads();                                               // seq_tr is written again by the next event chunk
+    }
+    if (threadIdx.x == 0) sums[which] = s;
+}
+
+// precision = 8.0f * NORM * sum_s / sum_e (or the caller's), block by block
+__global__ void demap_scale_kernel(float d, float precision_override, float *__restrict__ sums, int sums_stride, int n_batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_batch) return;
+    float *q = sums + (long)i * sums_stride;
+    float precision = div_r(mul_r(mul_r(8.0f, d), q[0]), q[1]);
+    if (precision_override > 0.0f) precision = precision_override;
+    q[2] = precision;
+}
+
+// T2GPU_DEMAP_TREE_STATS=1: the round 1-2 tree sums (for comparison with the exact form)
+static bool tree_stats() { const char *e = getenv("T2GPU_DEMAP_TREE_STATS"); return e && atoi(e) != 0; }
+
+long demap_terms_padded(int n_snr) { return ((long)n_snr + SEQ_CHUNK - 1) / SEQ_CHUNK * SEQ_CHUNK; }   // term pairs of scratch per TI block
+
+static hipError_t launch_exact(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, float2 *terms, float *sums,
+                               int sums_stride, float precision_override, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demap_stats_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           SEQ_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long padded = demap_terms_padded(n_snr);
+    int bx = (int)((padded + 256 * 4 - 1) / (256 * 4));
+    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+    hipLaunchKernelGGL(demap_terms_kernel, dim3(bx, n_batch), dim3(256), 0, s, p, cells, n_snr, cells_stride, terms, padded);
+    hipLaunchKernelGGL(demap_stats_exact_kernel, dim3(n_batch, 2), dim3(SEQ_THREADS), SEQ_LDS_BYTES, s, terms, n_snr, padded, sums, sums_stride);
+    hipLaunchKernelGGL(demap_scale_kernel, dim3((n_batch + 63) / 64), dim3(64), 0, s, p.d, precision_override, sums, sums_stride, n_batch);
+    return hipGetLastError();
+}
+
+// terms: scratch of n_snr float pairs (exact form); partial / blocks: scratch of the tree form
+hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float2 *terms, float *sums,
                               float precision_override, hipStream_t s)
 {
+    if (!tree_stats()) return launch_exact(p, cells, 0L, n_snr, 1, terms, sums, 0, precision_override, s);
     hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n_snr, partial, 0L);
     hipLaunchKernelGGL(demap_stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, 0);
     return hipGetLastError();
 }
 
-// n_batch TI blocks in one launch pair; partial holds n_batch * blocks pairs. Per block the additions happen in the order of
-// launch_demap_stats, so the sums are the same bit for bit.
+// n_batch TI blocks in one launch pair: every block summed on its own exactly as launch_demap_stats does (terms: n_batch * n_snr pairs)
 hipError_t launch_demap_stats_batch(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, double *partial,
-                                    int blocks, float *sums, int sums_stride, float precision_override, hipStream_t s)
+                                    int blocks, float2 *terms, float *sums, int sums_stride, float precision_override, hipStream_t s)
 {
+    if (!tree_stats()) return launch_exact(p, cells, cells_stride, n_snr, n_batch, terms, sums, sums_stride, precision_override, s);
     hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks, n_batch), dim3(256), 0, s, p, cells, n_snr, partial, cells_stride);
     hipLaunchKernelGGL(demap_stats_final_kernel, dim3(n_batch), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, sums_stride);
     return hipGetLastError();
@@ -324,13 +572,9 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 #ifndef T2_TI_THREADS
 #define T2_TI_THREADS 1024
 #endif
-// STATS: the demapper's hard-decision statistics (sum |s|^2, sum |e|^2 over the TI block, llr_demapper.cpp:564-676) formed here,
-// where every de-interleaved cell is in a register on its way out -- one double pair per FEC block, folded per TI block by
-// demap_stats_final_kernel -- instead of a second pass over the cells in HBM (demap_stats_kernel: 8 B per cell read again).
-template <bool STATS>
 __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
                                                       const float2 *__restrict__ cells, long in_stride, float2 *__restrict__ out,
-                                                      long out_stride, DemapParams dp, int n_snr, double *__restrict__ partial)
+                                                      long out_stride)
 {
     extern __shared__ float ti_lds[];                    // [cells_per_fec][2]
     // FEC block b reads the 40-byte runs of columns 5b .. 5b+4 in every row: a 128-byte line holds the runs of three neighbouring
@@ -353,33 +597,9 @@ __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, con
     }
     __syncthreads();
     const bool lost = lost_by_block[b] != 0;
-    double ss = 0.0, se = 0.0;
     for (int t = threadIdx.x; t < C; t += blockDim.x) {
-        float2 v = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
-        if (t == C - 1 && lost) {
-            reinterpret_cast<float *>(o)[2 * t] = v.x;
-            if (STATS) v.y = reinterpret_cast<const float *>(o)[2 * t + 1];      // the Q this block never received: what the buffer holds
-        } else o[t] = v;
-        if (STATS && base + t < n_snr) {                                       // the arithmetic of demap_stats_kernel, cell by cell
-            if (dp.rotate) v = derotate(v, dp.rot_c, dp.rot_s);
-            const float sr = slice_axis(dp.mod, v.x, dp.d), si = slice_axis(dp.mod, v.y, dp.d);
-            const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
-            ss += (double)add_r(mul_r(sr, sr), mul_r(si, si));
-            se += (double)add_r(mul_r(er, er), mul_r(ei, ei));
-        }
-    }
-    if (STATS) {
-        __shared__ double red[2][T2_TI_THREADS / 64];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { ss += __shfl_down(ss, d, 64); se += __shfl_down(se, d, 64); }
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ss; red[1][threadIdx.x >> 6] = se; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double a = 0.0, c = 0.0;
-            for (int w = 0; w < (int)blockDim.x / 64; ++w) { a += red[0][w]; c += red[1][w]; }
-            double *q = partial + 2 * ((long)f * num_blocks + b);
-            q[0] = a; q[1] = c;
-        }
+        if (t == C - 1 && lost) reinterpret_cast<float *>(o)[2 * t] = ti_lds[2 * t];
+        else o[t] = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
     }
 }
 
@@ -389,29 +609,11 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
     const size_t lds = (size_t)p.cells_per_fec * 8;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ti_block_kernel<false>, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
-                       cells, in_stride, out, out_stride, DemapParams{}, 0, (double *)nullptr);
-    return hipGetLastError();
-}
-
-// The same with the demapper's statistics: partial = [frames][num_blocks] double pairs (scratch), sums + f * sums_stride receives
-// (sum_s, sum_e, precision) of frame f's TI block. n_snr: cells of the TI block that count (all, or the first 2048 for QPSK).
-hipError_t launch_ti_blocks_stats(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
-                                  float2 *out, long out_stride, int frames, const DemapParams &dp, int n_snr, double *partial, float *sums,
-                                  int sums_stride, float precision_override, hipStream_t s)
-{
-    const size_t lds = (size_t)p.cells_per_fec * 8;
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(ti_block_kernel<true>, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
-                       cells, in_stride, out, out_stride, dp, n_snr, partial);
-    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(frames), dim3(64), 0, s, partial, num_blocks, dp.d, precision_override, sums, sums_stride);
+    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
+                       cells, in_stride, out, out_stride);
     return hipGetLastError();
 }
 

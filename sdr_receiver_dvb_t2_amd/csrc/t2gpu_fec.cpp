@@ -56,6 +56,8 @@ struct t2gpu_demap {
     int device = 0, max_cells = 0, stats_blocks = 0, partial_batches = 1;
     uint16_t *d_address = nullptr;
     double *d_partial = nullptr;
+    float2 *d_terms = nullptr;         // the statistics' per-cell terms (|s|^2, |e|^2): scratch of the exact sequential sums
+    size_t terms_cells = 0;
     float *d_sums = nullptr;
     float *d_cells = nullptr;      // host-call staging
     int8_t *d_llr = nullptr;
@@ -105,8 +107,21 @@ extern "C" int t2gpu_demap_configure(t2gpu_demap *h, int saturate)
 extern "C" void t2gpu_demap_destroy(t2gpu_demap *h)
 {
     if (!h) return;
-    hipFree(h->d_address); hipFree(h->d_partial); hipFree(h->d_sums); hipFree(h->d_cells); hipFree(h->d_llr);
+    hipFree(h->d_address); hipFree(h->d_partial); hipFree(h->d_terms); hipFree(h->d_sums); hipFree(h->d_cells); hipFree(h->d_llr);
     delete h;
+}
+
+// scratch for `cells` term pairs (grown on demand; a growth synchronises the stream once)
+static bool ensure_terms(t2gpu_demap *h, size_t cells, hipStream_t s)
+{
+    if (cells <= h->terms_cells) return true;
+    if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return false;
+    float2 *p = nullptr;
+    if (!hip_ok(hipMalloc(&p, cells * sizeof(float2)), "hipMalloc")) return false;
+    if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) { hipFree(p); return false; }
+    hipFree(h->d_terms);
+    h->d_terms = p; h->terms_cells = cells;
+    return true;
 }
 
 extern "C" int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int n_cells, float precision_override,
@@ -118,7 +133,8 @@ extern "C" int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int
     float *sums = d_sums3 ? d_sums3 : h->d_sums;
     const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;       // llr_demapper.cpp:184 (QPSK: first 2048 cells)
     int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
-    T2_HIP(launch_demap_stats(h->p, cells, n_snr, h->d_partial, blocks, sums, precision_override, s));
+    if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr), s)) return -1;
+    T2_HIP(launch_demap_stats(h->p, cells, n_snr, h->d_partial, blocks, h->d_terms, sums, precision_override, s));
     const int n_frames = n_cells / h->p.cells_per_fec;
     if (n_frames > 0) T2_HIP(launch_demap_llr(h->p, cells, n_frames, sums, d_llr, s));
     return n_frames;
@@ -132,7 +148,8 @@ extern "C" int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n
     if (!h || !d_cells || !d_sums3 || n_cells < 1 || n_cells > h->max_cells) { set_error("t2gpu_demap_stats_dev: bad arguments"); return -1; }
     const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;
     const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
-    T2_HIP(launch_demap_stats(h->p, reinterpret_cast<const float2 *>(d_cells), n_snr, h->d_partial, blocks, d_sums3, precision_override,
+    if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr), (hipStream_t)stream)) return -1;
+    T2_HIP(launch_demap_stats(h->p, reinterpret_cast<const float2 *>(d_cells), n_snr, h->d_partial, blocks, h->d_terms, d_sums3, precision_override,
                               (hipStream_t)stream));
     return 0;
 }
@@ -157,8 +174,9 @@ extern "C" int t2gpu_demap_stats_batch_dev(t2gpu_demap *h, const float *d_cells,
     }
     const int n_snr = h->p.mod == 0 ? std::min(cells_per_block, 2048) : cells_per_block;
     const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
+    if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr) * n_blocks, (hipStream_t)stream)) return -1;
     T2_HIP(launch_demap_stats_batch(h->p, reinterpret_cast<const float2 *>(d_cells), cells_stride, n_snr, n_blocks, h->d_partial, blocks,
-                                    d_sums, sums_stride, precision_override, (hipStream_t)stream));
+                                    h->d_terms, d_sums, sums_stride, precision_override, (hipStream_t)stream));
     return 0;
 }
 
@@ -311,40 +329,19 @@ extern "C" int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, lo
     return n_blocks;
 }
 
-// t2gpu_ti_execute_blocks_dev + t2gpu_demap_stats_batch_dev in one pass over the cells: the demapper's hard-decision statistics of every
-// TI block are formed by the de-interleaver kernel while the cells leave it (d_sums + f * sums_stride = sum_s, sum_e, precision of block f).
+// t2gpu_ti_execute_blocks_dev followed by t2gpu_demap_stats_batch_dev on the de-interleaved blocks, as one call
 extern "C" int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
                                                  long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
                                                  void *stream)
 {
-    if (!h || !dm || !d_cells || !d_out || !d_sums || n_blocks < 0 || !h->num_blocks || h->pos != 0 || sums_stride < 3 ||
-        dm->p.cells_per_fec != h->cells_per_fec) {
-        set_error("t2gpu_ti_execute_blocks_stats_dev: bad arguments (t2gpu_ti_begin first; de-interleaver and demapper of one modulation / FEC type)");
+    if (!h || !dm || dm->p.cells_per_fec != h->cells_per_fec) {
+        set_error("t2gpu_ti_execute_blocks_stats_dev: bad arguments (de-interleaver and demapper of one modulation / FEC type)");
         return -1;
     }
-    if (n_blocks == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t need = (size_t)n_blocks * h->num_blocks;                    // double pairs: one per FEC block
-    if (need > (size_t)dm->partial_batches * dm->stats_blocks) {
-        T2_HIP(hipStreamSynchronize(s));
-        double *p = nullptr;
-        const int batches = (int)((need + dm->stats_blocks - 1) / dm->stats_blocks);
-        T2_HIP(hipMalloc(&p, sizeof(double) * 2 * dm->stats_blocks * (size_t)batches));
-        T2_HIP(hipDeviceSynchronize());
-        hipFree(dm->d_partial);
-        dm->d_partial = p; dm->partial_batches = batches;
-    }
-    const int n_snr = dm->p.mod == 0 ? std::min(h->p.ti_block_size, 2048) : h->p.ti_block_size;
-    hipError_t e = launch_ti_blocks_stats(h->p, h->d_lost_blk, h->num_blocks, reinterpret_cast<const float2 *>(d_cells), in_stride_cells,
-                                          reinterpret_cast<float2 *>(d_out), out_stride_cells, n_blocks, dm->p, n_snr, dm->d_partial, d_sums,
-                                          sums_stride, precision_override, s);
-    if (e == hipErrorInvalidValue) {            // FEC block larger than LDS: the two separate passes
-        if (t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream) < 0) return -1;
-        return t2gpu_demap_stats_batch_dev(dm, d_out, out_stride_cells, n_blocks, h->p.ti_block_size, precision_override, d_sums, sums_stride, stream) == 0
-                   ? n_blocks : -1;
-    }
-    T2_HIP(e);
-    return n_blocks;
+    const int rc = t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream);
+    if (rc <= 0) return rc;
+    return t2gpu_demap_stats_batch_dev(dm, d_out, out_stride_cells, n_blocks, h->p.ti_block_size, precision_override, d_sums, sums_stride, stream) == 0
+               ? n_blocks : -1;
 }
 
 extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream)

@@ -158,10 +158,12 @@ def test_p1_against_the_reference(torch_cuda, gsym, tag, splits):
 @pytest.mark.parametrize("name", list(rc.FEC_CASES))
 def test_fec_chain_against_the_reference(torch_cuda, gfec, name):
     """K-ti -> K-snr + K-demap -> K-ldpc -> K-descramble on the cells the reference's stage objects processed:
-    TI block bit-exact (per-FEC-block CRC-32); LLRs of the frames the fixture holds whole within one step on <= 2 % of the
-    positions (north_star's "stated float tolerance on pre-FEC LLRs": the scale 8*norm*sum_s/sum_e comes from two float sums over
-    the whole TI block which the reference adds up sequentially and the device as a tree, ~2e-4 apart; with the scale pinned the
-    LLRs are bit-exact, tests/test_fec_gpu.py); the same SIMD batches decode; hard bits and descrambled BBFRAMEs bit-exact; the
+    TI block bit-exact (per-FEC-block CRC-32); LLRs of the frames the fixture holds whole equal except on <= 1e-4 of the positions
+    (north_star's "stated float tolerance on pre-FEC LLRs"; the device forms the scale 8*norm*sum_s/sum_e from the reference's own
+    sequential float sums, bit-equal to the oracle and to the reference's strict build -- the residue is what -Ofast does to the
+    reference binary's de-rotation, the same bound tests/test_ref_pins.py holds the oracle to); the same SIMD batches decode --
+    including the four cases at the decoding threshold, where some batches of the TI block decode in the last sweeps and others are
+    dropped; hard bits and descrambled BBFRAMEs bit-exact; the
     host de-framer turns them into the reference's TS bytes."""
     torch = torch_cuda
     import sdr_receiver_dvb_t2_amd as pkg
@@ -184,7 +186,7 @@ def test_fec_chain_against_the_reference(torch_cuda, gfec, name):
     for row, want in ((0, g["llr_first"]), (32 * batches - 1, g["llr_last"])):
         d = L[row].astype(np.int32) - want.astype(np.int32)
         d = np.minimum(np.abs(d), 256 - np.abs(d))
-        assert d.max() <= 1 and np.count_nonzero(d) <= n // 50, (row, np.count_nonzero(d))
+        assert d.max() <= 1 and np.count_nonzero(d) <= max(1, n // 10000), (row, np.count_nonzero(d))
     dec = pkg.ldpc_decoder(fec_type, code_rate, max_frames=32 * batches)
     bits, trials = dec.execute_dev(llr[:32 * batches].contiguous())
     torch.cuda.synchronize()
@@ -246,12 +248,10 @@ def test_ldpc_stage_256qam_payload_against_the_reference(torch_cuda, gbatch, nam
     bits, trials = dec.execute_dev(torch.from_numpy(llr).cuda())
     torch.cuda.synchronize()
     assert dec.status() == 0 and (trials.cpu().numpy() >= 0).all() and int(g["ldpc_batches"]) == nb // 32
-    keep = np.repeat(t >= 0, 32)                                                 # frames of the batches that decoded (the reference emits only those)
-    assert keep.any()
-    B = bits.cpu().numpy()[keep]
+    B = bits.cpu().numpy()
     assert np.array_equal(rc.crc_rows(B), g["ldpc_crc"]) and np.array_equal(np.packbits(B[0]), g["ldpc_first"])
     bch = pkg.bch_decoder(fec_type, code_rate)
-    D = bch.execute_dev(bits).cpu().numpy()[keep]
+    D = bch.execute_dev(bits).cpu().numpy()
     assert np.array_equal(rc.crc_rows(D), g["bb_crc"]) and np.array_equal(np.packbits(D[0]), g["bb_first"])
     P = bch.execute_packed_dev(bits).cpu().numpy()
     assert P.shape == (nb, k_bch // 8) and np.array_equal(P, np.packbits(D, axis=1))
