@@ -43,11 +43,22 @@ struct EqParams {
     int recip_amp = 0;
     const uint16_t *dcar = nullptr;   // [rows][dcar_stride] carrier index (from the first active carrier) of every data cell, in cell order
     int dcar_stride = 0;
+    // Output-range form (eq_split_kernel; n_splits > 0): the symbol's c_data output positions are cut into n_splits ranges
+    // [split_q(s), split_q(s + 1)), one workgroup per (symbol, range) keeps its range in LDS and stores it in one contiguous run.
+    const uint16_t *cellq = nullptr;  // [rows][cq_steps / 4][max_seg][4] output position (frequency de-interleaver of the row's parity) of data cells
+                                      // 4 k4 .. 4 k4 + 3 of segment seg at [k4][seg] (a wavefront of segments reads one run of 8-byte words per
+                                      // four steps); 0xffff past a segment's end
+    int cq_steps = 0;                 // steps stored per row: the longest segment of the table, rounded up to EQS_PU
+    const uint32_t *sel = nullptr;    // [rows][c_data] (carrier << 16 | output position) of the data cells, range by range, cell order inside a range
+    int n_splits = 0;
 };
+// first output position of range s (even, so that a range starts on a 16-byte boundary of the symbol's cells)
+__host__ __device__ inline int eq_split_q(int c_data, int n_splits, int s) { return s >= n_splits ? c_data : (int)(((long)c_data * s / n_splits) & ~1L); }
 #ifndef T2_EQ_GROUP
 #define T2_EQ_GROUP 32
 #endif
-constexpr int EQ_GROUP = T2_EQ_GROUP;      // segments per equaliser workgroup (ofdm_kernels.hip)
+constexpr int EQ_GROUP = T2_EQ_GROUP;
+constexpr int EQS_PU = 8;                   // eq_split_kernel reads its destinations EQS_PU steps ahead of the recurrence      // segments per equaliser workgroup (ofdm_kernels.hip)
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);
 

@@ -1,6 +1,7 @@
 // ofdm_kernels.hip -- OFDM-side kernels for gfx950: batched 32K / 16K forward FFT with fftshift, and the data-symbol
 // channel estimator / equaliser fused with the frequency de-interleaver. HBM-bound streaming work; no matrix cores.
 #include "ofdm_kernels.h"
+#include <algorithm>
 
 // data_symbol.cpp arithmetic is restated operation for operation (the reference is built without FMA)
 #pragma clang fp contract(off)
@@ -407,6 +408,155 @@ __global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const f
     }
 }
 
+// ---- output-range form (default) ----------------------------------------------------------------------------------------------
+// eq_data_kernel stores every cell with an 8-byte write somewhere in the symbol's 219 KB of output and depends on L2 to merge them
+// into lines before they leave for HBM, which caps the symbols in flight (above) and with them the loads in flight: 1.2 TB/s.
+// Here the de-interleaver's scatter lands in LDS instead. One workgroup = one symbol x one RANGE of output positions
+// [q0, q1) (a third of a 32K symbol: 73 KB as (re, im) pairs, two workgroups of 512 lanes per CU):
+//   phase 1: one lane per pilot-to-pilot segment of the WHOLE symbol runs the reference's angle / amplitude recurrences (serial
+//            float additions, in the reference's order) and leaves (angle, amplitude) of the cells that land in the range AT THEIR
+//            OUTPUT POSITION in LDS. Every range of the symbol repeats the recurrences; they are ~290 chains of ~95 steps.
+//   phase 2: all lanes over the range's cells in CELL order (host list: ascending carriers, so the spectrum is read in ascending,
+//            half-dense runs): table read, two divisions, rotation -- the reference's per-cell operations -- result back to the
+//            same LDS slot.
+//   phase 3: the range leaves LDS as one contiguous run.
+// Same float operations on the same values as eq_data_kernel: bit-identical output (tests/test_ofdm_gpu.py runs both).
+// Measured (config 3, 2832 data symbols; skipping phases one at a time): reads 0.18 ms, phase 1 0.12, phase 2 0.11, phase 3 0.12 --
+// they add up, two workgroups per CU overlap little of it: 0.52 ms against 0.90 ms of the segment-group kernel. More, smaller ranges
+// repeat phase 1 more often (+0.09 ms per range); a half symbol per workgroup of 1024 lanes leaves one workgroup per CU (0.55 ms).
+// IT = cells per lane (range <= IT * THREADS): every global input of phase 2 (list entry, spectrum cell) is in registers before
+// phase 1 starts, so the recurrences run under their latency and phase 2 waits for LDS and the cos / sin table only.
+template <int IT, int THREADS>
+__global__ __launch_bounds__(THREADS) void eq_split_kernel(EqParams p, const float2 *__restrict__ symbols,
+                                                           const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
+                                                           float4 *__restrict__ pilot_scratch, int n_symbols)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 eqs_buf[];
+    const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
+    const float PI = 3.14159274101257324219f;
+    const int NS = p.n_splits;
+    // workgroup w -> XCD w % 8 (round-robin dispatch). All ranges of a symbol run on one XCD back to back (they read the same
+    // spectrum), and in the frame layout an XCD walks the frames of one table ROW before the next row (the row's lists: 110 KB of
+    // `sel`, 65 KB of `cellq`, enter each L2 once).
+    const int wg = (int)blockIdx.x, xcd = wg & 7, i = wg >> 3;
+    int b, s;
+    if (p.per_frame > 1) {
+        const int frames = n_symbols / p.per_frame, fx = (frames + 7) >> 3;
+        const int row = i / (fx * NS), rem = i - row * fx * NS;
+        const int fr_x = rem / NS;
+        s = rem - fr_x * NS;
+        const int frame = fr_x * 8 + xcd;
+        if (row >= p.per_frame || frame >= frames) return;
+        b = frame * p.per_frame + row;
+    } else {
+        b = 8 * (i / NS) + xcd;
+        s = i % NS;
+    }
+    if (b >= n_symbols) return;
+    const int fr = p.per_frame ? b / p.per_frame : 0, lo = p.per_frame ? b - fr * p.per_frame : 0;
+    const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];
+    const int row = idx_symbol - p.n_p2;
+    const int nseg = p.seg_count[row];
+    const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
+    const uint8_t *map = p.map + (size_t)row * p.k_total;
+    const float *refer = p.refer + (size_t)row * p.k_total;
+    const int4 *segs = p.segs + (size_t)row * p.max_seg;
+    const uint2 *cq = reinterpret_cast<const uint2 *>(p.cellq) + (size_t)row * (p.cq_steps / 4) * p.max_seg;
+    const int q0 = eq_split_q(p.c_data, NS, s), q1 = eq_split_q(p.c_data, NS, s + 1);
+    const unsigned range = (unsigned)(q1 - q0);
+    const int tid = (int)threadIdx.x;
+    // ---- inputs of phase 2: lane cell u is entry tid + u * THREADS of the range's list (lanes past the end repeat entry 0's slot
+    // harmlessly: carrier 0, slot 0, nothing stored)
+    const uint32_t *sel = p.sel + (size_t)row * p.c_data + q0;
+    uint32_t e[IT];
+    float2 v[IT];
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+        const int k = tid + u * THREADS;
+        e[u] = k < (int)range ? sel[k] : (uint32_t)q0;
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) v[u] = cell[e[u] >> 16];
+    // ---- phase 1
+    for (int seg = tid; seg < nseg; seg += THREADS) {
+        const int4 sg = segs[seg];
+        const int pl = sg.x, pr = sg.y, n = sg.w;
+        const uint2 *cqs = cq + seg;
+        const float2 cl = cell[pl], cr = cell[pr];
+        const float refer_l = refer[pl], refer_r = refer[pr];
+        const uint8_t tl = map[pl], tr = map[pr];
+        const PilotEst L = pilot_estimate(cl, refer_l, tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
+        const PilotEst R = pilot_estimate(cr, refer_r, tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
+        float dif_angle = R.angle - L.angle;
+        if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;                  // as written in the reference (:189-191)
+        else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
+        const float delta_angle = dif_angle / (float)(n + 1);
+        const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
+        float angle_est = L.angle, amp_est = L.amp;
+        // destinations: four steps per 8-byte read, EQS_PU steps ahead of the chain; 0xffff past the segment's end
+        static_assert(EQS_PU == 8, "two 8-byte reads per trip");
+        for (int k0 = 0; k0 < n; k0 += 8) {
+            const uint2 w0 = cqs[(size_t)(k0 >> 2) * p.max_seg], w1 = cqs[(size_t)((k0 >> 2) + 1) * p.max_seg];
+            const unsigned q[8] = {w0.x & 0xffffu, w0.x >> 16, w0.y & 0xffffu, w0.y >> 16, w1.x & 0xffffu, w1.x >> 16, w1.y & 0xffffu, w1.y >> 16};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                angle_est += delta_angle; amp_est += delta_amp;
+                eqs_buf[min(q[u] - (unsigned)q0, range)] = make_float2(angle_est, amp_est);   // slot `range`: other ranges' cells, steps past n
+            }
+        }
+        if (s == 0) {
+            float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
+            if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);
+            ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2
+    const float2 *__restrict__ lut = p.lut_cs;
+    constexpr int U = 4;
+#pragma unroll
+    for (int u0 = 0; u0 < IT; u0 += U) {
+        float2 cs[U], aa[U];
+#pragma unroll
+        for (int u = u0; u < u0 + U && u < IT; ++u) {
+            aa[u - u0] = eqs_buf[(e[u] & 0xffffu) - (unsigned)q0];
+            cs[u - u0] = lut[(int)(aa[u - u0].x * K_TABLE + 32767) & 65535];
+        }
+#pragma unroll
+        for (int u = u0; u < u0 + U && u < IT; ++u) {
+            if (tid + u * THREADS >= (int)range) continue;
+            const float amp = aa[u - u0].y;
+            const float dr = cs[u - u0].x / amp, di = cs[u - u0].y / amp;
+            eqs_buf[(e[u] & 0xffffu) - (unsigned)q0] = make_float2(v[u].x * dr + v[u].y * di, v[u].y * dr - v[u].x * di);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3
+    float2 *o = p.per_frame ? out + (size_t)fr * p.out_frame_stride + p.out_offset + (size_t)lo * p.c_data : out + (size_t)b * p.c_data;
+    for (int k = tid; k < (int)range; k += THREADS) {
+        const int q = q0 + k, at = q - p.out_skip;
+        const float2 eq = eqs_buf[k];
+        if (at >= 0) o[at] = eq;
+        else if (p.skip_out) p.skip_out[(size_t)fr * p.out_skip + q] = eq;
+    }
+}
+
+template <int IT, int THREADS>
+static hipError_t launch_eq_split(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
+                                  float4 *pilot_scratch, int bytes, hipStream_t s)
+{
+    static int attr = 0;
+    if (bytes > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_split_kernel<IT, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        attr = bytes;
+    }
+    unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * p.n_splits);
+    if (p.per_frame > 1) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * p.n_splits);
+    hipLaunchKernelGGL((eq_split_kernel<IT, THREADS>), dim3(grid), dim3(THREADS), bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols);
+    return hipGetLastError();
+}
+
 // phase_offset = atan2(sum_pilot_2) + atan2(sum_pilot_1), sample_rate_offset = sum_angle_2 - sum_angle_1 (:319-324)
 // The sums are float additions in carrier order (the reference's loop order): serial chains per symbol -- six of them, (re, im, angle)
 // over the pilots of the lower half of the spectrum and the same over the upper half, and they do not depend on each other. One
@@ -463,6 +613,23 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s)
 {
+    if (p.n_splits > 0) {
+        int range = 0;
+        for (int k = 0; k < p.n_splits; ++k) range = std::max(range, eq_split_q(p.c_data, p.n_splits, k + 1) - eq_split_q(p.c_data, p.n_splits, k));
+        const int bytes = (range + 1) * 8;
+        static const int threads = (getenv("T2GPU_EQ_THREADS") && atoi(getenv("T2GPU_EQ_THREADS")) == 1024) ? 1024 : 512;
+        const int it = (range + threads - 1) / threads;
+        hipError_t e = hipErrorInvalidValue;
+#define T2_EQS(IT_, TH_) e = launch_eq_split<IT_, TH_>(p, symbols, symbol_index, n_symbols, out, pilot_scratch, bytes, s)
+        if (threads != 1024) {
+            if (it <= 8) T2_EQS(8, 512); else if (it <= 14) T2_EQS(14, 512); else if (it <= 18) T2_EQS(18, 512); else if (it <= 28) T2_EQS(28, 512);
+        } else {
+            if (it <= 4) T2_EQS(4, 1024); else if (it <= 7) T2_EQS(7, 1024); else if (it <= 9) T2_EQS(9, 1024); else if (it <= 11) T2_EQS(11, 1024);
+            else if (it <= 14) T2_EQS(14, 1024);
+        }
+#undef T2_EQS
+        if (e != hipSuccess) return e;
+    } else {
     int lds_bytes = 2 * (p.lds_span + 1) * 4 + p.lds_dspan * 8 + ((p.lds_dspan + 1) & ~1) * 2;
     const int lds_floor = 160 * 1024 / (T2_EQ_WGS_PER_CU + 1) + 1024;                     // at most T2_EQ_WGS_PER_CU workgroups per CU (see the kernel)
     lds_bytes = lds_bytes > lds_floor ? lds_bytes : lds_floor;
@@ -478,6 +645,7 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
     if (p.per_frame > 1 && p.row_major) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * groups);
     hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_THREADS), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
                        groups);
+    }
     if (sync) {
         const int sy_bytes = (p.max_seg + 1) * 16;
         static int sy_attr = 0;

@@ -102,6 +102,8 @@ struct t2gpu_ofdm {
     int4 *d_segs_fc = nullptr;
     int32_t *d_seg_count_fc = nullptr, *d_h_even_fc = nullptr, *d_h_odd_fc = nullptr, *d_index_fc = nullptr;
     float4 *d_pilot_scratch = nullptr;
+    uint16_t *d_cellq = nullptr, *d_cellq_p2 = nullptr, *d_cellq_fc = nullptr;   // output-range form of the equaliser (EqParams::cellq, sel)
+    uint32_t *d_sel = nullptr, *d_sel_p2 = nullptr, *d_sel_fc = nullptr;
     // host-call staging
     float2 *d_in = nullptr, *d_out = nullptr, *d_sync = nullptr;
     int32_t *d_index = nullptr;
@@ -212,6 +214,8 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     // the frame-closing symbol (when the mode has one): pilots every dx carriers, n_fc cells, its own de-interleaver
     int nseg3 = 0;
     std::vector<int4> seg3_keep;
+    std::vector<int32_t> he3_keep, ho3_keep;
+    std::vector<uint16_t> dcar3_keep;
     if (m.l_fc) {
         std::vector<uint8_t> mp3; std::vector<float> rf3; std::vector<int4> seg3;
         t2_symbol_carriers(m, m.len_frame - 1, mp3, rf3);
@@ -226,6 +230,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         for (int i = 0; i < K; ++i)
             if (mp3[i] == T2_DATA) dcar3.push_back((uint16_t)i);
         up(&h->d_dcar_fc, dcar3.data(), dcar3.size() * 2);
+        he3_keep = he3; ho3_keep = ho3; dcar3_keep = dcar3;
         up(&h->d_map_fc, mp3.data(), mp3.size());
         up(&h->d_refer_fc, rf3.data(), rf3.size() * 4);
         up(&h->d_segs_fc, seg3.data(), seg3.size() * sizeof(int4));
@@ -249,6 +254,47 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     h->eq_fc.dcar = h->d_dcar_fc; h->eq_fc.dcar_stride = m.n_fc;
     h->eq_p2.recip_amp = 1;
     h->eq_fc.recip_amp = 1;
+    // Output-range form (eq_split_kernel): per table row the output position of every data cell (the de-interleaver of the row's
+    // parity, data_symbol.cpp:148-149) and, range by range, the (carrier, output position) list of the cells that land in it.
+    // Ranges: the fewest that fit 75 KB of LDS each -- two workgroups per CU (T2GPU_EQ_SPLITS=n forces n; 0 = the segment-group kernel eq_data_kernel).
+    {
+        int forced = -1;
+        if (const char *e = getenv("T2GPU_EQ_SPLITS")) forced = atoi(e);
+        auto build = [&](EqParams &q, int n_rows, int first_idx, const std::vector<int32_t> &hev, const std::vector<int32_t> &hod,
+                         const std::vector<uint16_t> &dc, const std::vector<int4> *sg_rows, uint16_t **d_cq, uint32_t **d_sl) {
+            const int C = q.c_data;
+            int ns = forced >= 0 ? forced : (C * 8 + 75 * 1024 - 1) / (75 * 1024);
+            if (ns <= 0 || C / ns + 2 > 14 * 1024 || C >= 65535) { q.n_splits = 0; return; }   // a range is at most 14 cells per lane of 1024 (28 of 512)
+            int steps = 0;
+            for (int r = 0; r < n_rows; ++r)
+                for (const int4 &g : sg_rows[r]) steps = std::max(steps, g.w);
+            steps = (steps + EQS_PU - 1) / EQS_PU * EQS_PU;
+            std::vector<uint16_t> cq((size_t)n_rows * steps * q.max_seg, (uint16_t)0xffff);
+            std::vector<uint32_t> sl((size_t)n_rows * C);
+            std::vector<int> fill(ns);
+            for (int r = 0; r < n_rows; ++r) {
+                const std::vector<int32_t> &hh = ((first_idx + r) & 1) ? hev : hod;
+                for (size_t g = 0; g < sg_rows[r].size(); ++g)
+                    for (int k = 0; k < sg_rows[r][g].w; ++k)
+                        cq[(((size_t)r * (steps / 4) + k / 4) * q.max_seg + g) * 4 + (k & 3)] = (uint16_t)hh[sg_rows[r][g].z + k];
+                for (int sidx = 0; sidx < ns; ++sidx) fill[sidx] = eq_split_q(C, ns, sidx);
+                for (int d = 0; d < C; ++d) {
+                    const int qq = hh[d];
+                    int sidx = (int)((long)qq * ns / C);                         // the range qq falls in (boundaries are rounded down to even)
+                    while (sidx + 1 < ns && qq >= eq_split_q(C, ns, sidx + 1)) ++sidx;
+                    while (sidx > 0 && qq < eq_split_q(C, ns, sidx)) --sidx;
+                    sl[(size_t)r * C + fill[sidx]++] = ((uint32_t)dc[(size_t)r * C + d] << 16) | (uint32_t)qq;
+                }
+            }
+            up(d_cq, cq.data(), cq.size() * 2);
+            up(d_sl, sl.data(), sl.size() * 4);
+            q.cellq = *d_cq; q.cq_steps = steps; q.sel = *d_sl; q.n_splits = ns;
+        };
+        build(h->eq, rows, m.n_p2, he, ho, dcar, segs.data(), &h->d_cellq, &h->d_sel);
+        build(h->eq_p2, 1, 0, he2, ho2, dcar2, &seg2, &h->d_cellq_p2, &h->d_sel_p2);
+        if (m.l_fc) build(h->eq_fc, 1, m.len_frame - 1, he3_keep, ho3_keep, dcar3_keep, &seg3_keep, &h->d_cellq_fc, &h->d_sel_fc);
+        if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
+    }
     // widest carrier / data-cell span of any EQ_GROUP consecutive segments, per table (sizes the equaliser's LDS staging)
     auto spans = [](const std::vector<int4> &sg, int &span, int &dspan) {
         for (size_t g0 = 0; g0 < sg.size(); g0 += EQ_GROUP) {
@@ -269,6 +315,7 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
     hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
+    hipFree(h->d_cellq); hipFree(h->d_cellq_p2); hipFree(h->d_cellq_fc); hipFree(h->d_sel); hipFree(h->d_sel_p2); hipFree(h->d_sel_fc);
     hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
     hipFree(h->d_seg_count_p2); hipFree(h->d_h_even_p2); hipFree(h->d_h_odd_p2);
     hipFree(h->d_map_fc); hipFree(h->d_refer_fc); hipFree(h->d_segs_fc); hipFree(h->d_seg_count_fc); hipFree(h->d_h_even_fc);

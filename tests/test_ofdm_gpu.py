@@ -67,6 +67,17 @@ def test_fft_batch_properties_full_size(torch_cuda):
     ctx.close()
 
 
+@pytest.fixture(params=["default", "0", "3", "5"])
+def eq_form(request, monkeypatch):
+    """Equaliser kernel form, read when the context is created: default = output ranges in LDS (eq_split_kernel, fewest ranges that
+    fit), "3" / "5" = that kernel with three / five ranges per symbol, "0" = segment groups with scattered stores (eq_data_kernel)."""
+    if request.param == "default":
+        monkeypatch.delenv("T2GPU_EQ_SPLITS", raising=False)
+    else:
+        monkeypatch.setenv("T2GPU_EQ_SPLITS", request.param)
+    return request.param
+
+
 def make_symbol(m, idx_symbol, seed, snr_db=25.0):
     """One received data symbol after the FFT (fft-shifted): pilots per the carrier map, random unit-power data cells, a
     smooth two-path channel with a common phase, AWGN."""
@@ -85,7 +96,7 @@ def make_symbol(m, idx_symbol, seed, snr_db=25.0):
 
 @pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (5, 0, 3, 0, 0, 20), (5, 1, 1, 2, 2, 12), (4, 1, 6, 4, 0, 30), (4, 0, 0, 3, 0, 17),
                                   (4, 1, 7, 1, 2, 40)])
-def test_equaliser_matches_oracle(torch_cuda, mode):
+def test_equaliser_matches_oracle(torch_cuda, mode, eq_form):
     import sdr_receiver_dvb_t2_amd as pkg
     torch = torch_cuda
     m = ol.ora_mode(*mode)
@@ -109,7 +120,7 @@ def test_equaliser_matches_oracle(torch_cuda, mode):
 
 
 @pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (4, 1, 6, 4, 0, 30), (5, 0, 1, 2, 0, 12)])
-def test_p2_equaliser_matches_oracle(torch_cuda, mode):
+def test_p2_equaliser_matches_oracle(torch_cuda, mode, eq_form):
     import sdr_receiver_dvb_t2_amd as pkg
     torch = torch_cuda
     m = ol.ora_mode(*mode)
@@ -129,7 +140,7 @@ def test_p2_equaliser_matches_oracle(torch_cuda, mode):
 
 
 @pytest.mark.parametrize("mode", [(5, 1, 3, 2, 0, 20), (4, 1, 1, 3, 0, 9), (4, 0, 4, 1, 2, 45)])
-def test_frame_closing_equaliser_matches_oracle(torch_cuda, mode):
+def test_frame_closing_equaliser_matches_oracle(torch_cuda, mode, eq_form):
     import sdr_receiver_dvb_t2_amd as pkg
     torch = torch_cuda
     m = ol.ora_mode(*mode)
