@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void demap_terms_kernel(DemapParams p, const f
                                                          float2 *__restrict__ terms, long terms_stride)
 {
     cells += (long)blockIdx.y * cells_stride;
-    terms += (long)blockIdx.y * terms_stride;
+    // two planes per TI block (all |s|^2, then all |e|^2): a walk reads its own sum's terms only
+    float *ts = reinterpret_cast<float *>(terms + (long)blockIdx.y * terms_stride), *te = ts + terms_stride;
     const int padded = (n_snr + SEQ_CHUNK - 1) / SEQ_CHUNK * SEQ_CHUNK;        // zeros behind the block: the walk reads whole chunks unguarded
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) {
         float2 t = make_float2(0.0f, 0.0f);
@@ -287,97 +288,124 @@ __global__ __launch_bounds__(256) void demap_terms_kernel(DemapParams p, const f
             const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
             t = make_float2(add_r(mul_r(sr, sr), mul_r(si, si)), add_r(mul_r(er, er), mul_r(ei, ei)));
         }
-        terms[i] = t;
+        ts[i] = t.x;
+        te[i] = t.y;
     }
 }
 
-// One workgroup per TI block walks the block's terms in cell order, SEQ_CHUNK at a time. Lane l of wavefront w holds the chunk's terms
-// w * 64 * SEQ_U + r * 128 + 2 l + {0, 1}, r < SEQ_U / 2 (16-byte loads, 1 KB per wavefront and instruction); the common case needs
-// only the chunk's total, which no order affects: without a tie, round-to-nearest-even of x / ulp IS the rounding of the addition.
+// One workgroup per (TI block, sum) walks the sum's terms in cell order, SEQ_CHUNK at a time. Lane l of wavefront w holds the chunk's
+// terms w * 64 * SEQ_U + r * 256 + 4 l + {0..3}, r < SEQ_U / 4 (16-byte loads, 1 KB per wavefront and instruction); the common case
+// needs only the chunk's total, which no order affects: without a tie, round-to-nearest-even of x / ulp IS the rounding of the addition.
 // A chunk with an event is transposed through LDS so that every lane holds SEQ_U consecutive terms, and walked by seq_step.
-__device__ __forceinline__ int seq_pos(int wave, int lane, int u) { return wave * 64 * SEQ_U + (u >> 1) * 128 + 2 * lane + (u & 1); }
+// The loop is a latency chain (load a chunk, reduce it, next): the terms of the next TWO chunks are in flight while one is summed.
+__device__ __forceinline__ int seq_pos(int wave, int lane, int u) { return wave * 64 * SEQ_U + (u >> 2) * 256 + 4 * lane + (u & 3); }
+constexpr int SEQ_R = SEQ_U / 4;
 
-// blockIdx.x = TI block, blockIdx.y = which sum (0: sum_s, 1: sum_e -- two independent chains, a workgroup each); the workgroup of
-// sum_e waits for sum_s through nothing: the scale is formed by demap_scale_kernel from the two results.
+__device__ __forceinline__ void seq_load(float4 (&c)[SEQ_R], const float4 *src, int base)
+{
+#pragma unroll
+    for (int r = 0; r < SEQ_R; ++r) c[r] = src[base / 4 + 64 * r];
+}
+
+// one chunk: x = this lane's terms (seq_pos order), s = the running sum on entry and exit (uniform)
+__device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s, SeqShared &sh, float *seq_tr)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, buf = (base / SEQ_CHUNK) & 1;
+    if (base < SEQ_HEAD) {                                             // (first chunk only) the head's terms are in the sum already
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) if (base + seq_pos(wave, lane, u) < SEQ_HEAD) x[u] = 0.0f;
+    }
+    // common case: no term of the chunk ties and the chunk does not leave the binade -> one reduction, one barrier. Without a tie,
+    // round-to-nearest-even of x / ulp is what the addition's own rounding adds.
+    SeqScale sc;
+    int word = 1 << 30;
+    if (s != 0.0f) {                                                   // uniform (a block of zeros stays on the event path)
+        sc = seq_scale(s);
+        int loc = 0;
+        float far = 0.0f;                                              // largest |y - rint(y)| among the terms: 1/2 = a tie
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) {
+            const float y = fminf(mul_r(x[u], sc.inv_ulp), (float)SEQ_CAP), r = rintf(y);
+            loc += (int)r;                                             // <= SEQ_U * 2^25: no overflow
+            far = fmaxf(far, fabsf(sub_r(y, r)));
+        }
+        word = min(loc, SEQ_CAP) | (far == 0.5f ? 1 << 30 : 0);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = __shfl_xor(word, d, 64);
+        word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
+    }
+    if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
+    __syncthreads();
+    int total = 0, tie = 0;
+#pragma unroll
+    for (int w = 0; w < SEQ_WAVES / 4; ++w) {
+        const int4 t = sh.tot[buf][0][w];
+        const int v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { total = sat_add(total, v[j] & (SEQ_CAP * 2 - 1)); tie |= v[j] >> 30; }
+    }
+    if (!tie && sc.S + total < (1 << 24)) { s = mul_r((float)(sc.S + total), sc.ulp); return; }      // uniform
+    // an event in this chunk: in cell order through LDS, SEQ_U consecutive terms per lane (one pad word per lane's run, so that the
+    // lanes' reads spread over the banks), and walked event by event
+#pragma unroll
+    for (int u = 0; u < SEQ_U; ++u) { const int q = seq_pos(wave, lane, u); seq_tr[q + q / SEQ_U] = x[u]; }
+    __syncthreads();
+    float xt[SEQ_U];
+#pragma unroll
+    for (int u = 0; u < SEQ_U; ++u) xt[u] = seq_tr[tid * (SEQ_U + 1) + u];
+    for (int a = 0; a < SEQ_CHUNK;) a = seq_step(xt, a, s, sh);
+    __syncthreads();                                                   // seq_tr is written again by the next event chunk
+}
+
+// blockIdx.x = TI block, blockIdx.y = which sum (0: sum_s, 1: sum_e -- two independent chains, a workgroup each); the scale is formed
+// by demap_scale_kernel from the two results.
 __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const float2 *__restrict__ terms, int n_snr, long terms_stride,
                                                                        float *__restrict__ sums, int sums_stride)
 {
     __shared__ SeqShared sh;
     extern __shared__ float seq_tr[];                                  // [SEQ_CHUNK + pad]: a chunk's terms in cell order
-    terms += (long)blockIdx.x * terms_stride;
-    sums += (long)blockIdx.x * sums_stride;
     const int which = (int)blockIdx.y;
+    const float *tp = reinterpret_cast<const float *>(terms + (long)blockIdx.x * terms_stride) + (long)which * terms_stride;   // this sum's plane
+    sums += (long)blockIdx.x * sums_stride;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float4 *src = reinterpret_cast<const float4 *>(terms) + (wave * 64 * SEQ_U) / 2 + lane;      // + 64 r: this lane's pairs inside a chunk
+    const float4 *src = reinterpret_cast<const float4 *>(tp) + (wave * 64 * SEQ_U) / 4 + lane;        // + 64 r: this lane's quads inside a chunk
     float s = 0.0f;                                                    // the running sum: uniform over the workgroup
-    float4 c[SEQ_U / 2];
-#pragma unroll
-    for (int r = 0; r < SEQ_U / 2; ++r) c[r] = src[64 * r];
+    float4 c0[SEQ_R], c1[SEQ_R];
+    seq_load(c0, src, 0);
+    if (SEQ_CHUNK < n_snr) seq_load(c1, src, SEQ_CHUNK);
     // The head of the block as the plain loop it is: while the sum is small every few additions change the binade (two thirds of a
     // block's events fall into its first couple of thousand cells). Staged through LDS; every lane reads the same word (a broadcast)
     // and runs the same additions: uniform, no exchange.
     {
-        for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) { const float2 t = terms[k]; seq_tr[k] = which ? t.y : t.x; }    // (zeros behind the block's end)
+        for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) seq_tr[k] = tp[k];        // (zeros behind the block's end)
         __syncthreads();
 #pragma unroll 16
         for (int k = 0; k < SEQ_HEAD; ++k) s = add_r(s, seq_tr[k]);
+        __syncthreads();                                               // seq_tr is the event path's from here on
     }
-    int buf = 0;
-    for (int base = 0; base < n_snr; base += SEQ_CHUNK, buf ^= 1) {
+#ifdef T2_SEQ_PROF
+    long long t_head = __builtin_amdgcn_s_memtime(); long long hb[6] = {0,0,0,0,0,0}; int hn[6] = {0,0,0,0,0,0};
+#define PROF_CHUNK(B) { const long long t0 = __builtin_amdgcn_s_memtime(); seq_chunk(x, B, s, sh, seq_tr); const long long dt = __builtin_amdgcn_s_memtime() - t0; const int bk = dt < 4000 ? 0 : dt < 8000 ? 1 : dt < 16000 ? 2 : dt < 32000 ? 3 : dt < 64000 ? 4 : 5; _Pragma("unroll") for (int z = 0; z < 6; ++z) if (z == bk) { hb[z] += dt; ++hn[z]; } }
+#else
+#define PROF_CHUNK(B) seq_chunk(x, B, s, sh, seq_tr)
+#endif
+    for (int base = 0; base < n_snr; base += 2 * SEQ_CHUNK) {
         float x[SEQ_U];
 #pragma unroll
-        for (int r = 0; r < SEQ_U / 2; ++r) { x[2 * r] = which ? c[r].y : c[r].x; x[2 * r + 1] = which ? c[r].w : c[r].z; }
-        if (base < SEQ_HEAD) {                                         // (first chunk only) the head's terms are in the sum already
+        for (int r = 0; r < SEQ_R; ++r) { x[4 * r] = c0[r].x; x[4 * r + 1] = c0[r].y; x[4 * r + 2] = c0[r].z; x[4 * r + 3] = c0[r].w; }
+        if (base + 2 * SEQ_CHUNK < n_snr) seq_load(c0, src, base + 2 * SEQ_CHUNK);
+        PROF_CHUNK(base);
+        if (base + SEQ_CHUNK >= n_snr) break;
 #pragma unroll
-            for (int u = 0; u < SEQ_U; ++u) if (base + seq_pos(wave, lane, u) < SEQ_HEAD) x[u] = 0.0f;
-        }
-        if (base + SEQ_CHUNK < n_snr) {                                // the next chunk's terms travel while this one is summed
-#pragma unroll
-            for (int r = 0; r < SEQ_U / 2; ++r) c[r] = src[(base + SEQ_CHUNK) / 2 + 64 * r];
-        }
-        // common case: no term of the chunk ties and the chunk does not leave the binade -> one reduction, one barrier. Without a tie,
-        // round-to-nearest-even of x / ulp is what the addition's own rounding adds.
-        SeqScale sc;
-        int word = 1 << 30;
-        if (s != 0.0f) {                                               // uniform (a block of zeros stays on the event path)
-            sc = seq_scale(s);
-            int loc = 0;
-            float far = 0.0f;                                          // largest |y - rint(y)| among the terms: 1/2 = a tie
-#pragma unroll
-            for (int u = 0; u < SEQ_U; ++u) {
-                const float y = fminf(mul_r(x[u], sc.inv_ulp), (float)SEQ_CAP), r = rintf(y);
-                loc += (int)r;                                         // <= SEQ_U * 2^25: no overflow
-                far = fmaxf(far, fabsf(sub_r(y, r)));
-            }
-            word = min(loc, SEQ_CAP) | (far == 0.5f ? 1 << 30 : 0);
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const int o = __shfl_xor(word, d, 64);
-            word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
-        }
-        if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
-        __syncthreads();
-        int total = 0, tie = 0;
-#pragma unroll
-        for (int w = 0; w < SEQ_WAVES / 4; ++w) {
-            const int4 t = sh.tot[buf][0][w];
-            const int v[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { total = sat_add(total, v[j] & (SEQ_CAP * 2 - 1)); tie |= v[j] >> 30; }
-        }
-        if (!tie && sc.S + total < (1 << 24)) { s = mul_r((float)(sc.S + total), sc.ulp); continue; }     // uniform
-        // an event in this chunk: in cell order through LDS, SEQ_U consecutive terms per lane (one pad word per lane's run, so that the
-        // lanes' reads spread over the banks), and walked event by event
-#pragma unroll
-        for (int u = 0; u < SEQ_U; ++u) { const int q = seq_pos(wave, lane, u); seq_tr[q + q / SEQ_U] = x[u]; }
-        __syncthreads();
-        float xt[SEQ_U];
-#pragma unroll
-        for (int u = 0; u < SEQ_U; ++u) xt[u] = seq_tr[tid * (SEQ_U + 1) + u];
-        for (int a = 0; a < SEQ_CHUNK;) a = seq_step(xt, a, s, sh);
-        __syncthreads();                                               // seq_tr is written again by the next event chunk
+        for (int r = 0; r < SEQ_R; ++r) { x[4 * r] = c1[r].x; x[4 * r + 1] = c1[r].y; x[4 * r + 2] = c1[r].z; x[4 * r + 3] = c1[r].w; }
+        if (base + 3 * SEQ_CHUNK < n_snr) seq_load(c1, src, base + 3 * SEQ_CHUNK);
+        PROF_CHUNK(base + SEQ_CHUNK);
     }
+#ifdef T2_SEQ_PROF
+    if (threadIdx.x == 0 && blockIdx.x < 2) printf("blk %d sum %d: total %lld cycles; chunks <4k %d (%lld) <8k %d (%lld) <16k %d (%lld) <32k %d (%lld) <64k %d (%lld) more %d (%lld)\n", (int)blockIdx.x, which, __builtin_amdgcn_s_memtime() - t_head, hn[0], hb[0], hn[1], hb[1], hn[2], hb[2], hn[3], hb[3], hn[4], hb[4], hn[5], hb[5]);
+#endif
     if (threadIdx.x == 0) sums[which] = s;
 }
 

@@ -101,7 +101,7 @@ struct t2gpu_ofdm {
     float *d_refer_fc = nullptr;
     int4 *d_segs_fc = nullptr;
     int32_t *d_seg_count_fc = nullptr, *d_h_even_fc = nullptr, *d_h_odd_fc = nullptr, *d_index_fc = nullptr;
-    float4 *d_pilot_scratch = nullptr;
+    float4 *d_pilot_scratch = nullptr, *d_pilot_scratch_p2 = nullptr, *d_pilot_scratch_fc = nullptr;   // per table: the three launches of a frame batch may run side by side
     uint16_t *d_cellq = nullptr, *d_cellq_p2 = nullptr, *d_cellq_fc = nullptr;   // output-range form of the equaliser (EqParams::cellq, sel)
     uint32_t *d_sel = nullptr, *d_sel_p2 = nullptr, *d_sel_fc = nullptr;
     // host-call staging
@@ -240,7 +240,10 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         up(&h->d_index_fc, idxfill.data(), idxfill.size() * 4);
     }
     const int max_all = std::max(std::max(max_seg, (int)nseg2), nseg3);
-    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_all + 1) * sizeof(float4)), "hipMalloc");
+    (void)max_all;
+    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch, (size_t)max_symbols * (max_seg + 1) * sizeof(float4)), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch_p2, (size_t)max_symbols * (nseg2 + 1) * sizeof(float4)), "hipMalloc");
+    if (m.l_fc) ok = ok && hip_ok(hipMalloc(&h->d_pilot_scratch_fc, (size_t)max_symbols * (nseg3 + 1) * sizeof(float4)), "hipMalloc");
     if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
     h->eq = EqParams{N, m.l_nulls, K, m.c_data, m.n_p2, max_seg, m.amp_sp, m.amp_cp, m.amp_p2, h->d_map, h->d_refer, h->d_segs,
                      h->d_seg_count, h->d_h_even, h->d_h_odd, h->d_lut};
@@ -313,7 +316,7 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
 {
     if (!h) return;
     hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
-    hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_in); hipFree(h->d_out);
+    hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_pilot_scratch_p2); hipFree(h->d_pilot_scratch_fc); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
     hipFree(h->d_cellq); hipFree(h->d_cellq_p2); hipFree(h->d_cellq_fc); hipFree(h->d_sel); hipFree(h->d_sel_p2); hipFree(h->d_sel_fc);
     hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
@@ -407,7 +410,7 @@ extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     if (ensure_staging(h)) return -1;
     T2_HIP(hipMemsetAsync(h->d_index, 0, (size_t)n_symbols * 4, s));           // every symbol is frame symbol 0
     T2_HIP(launch_eq_data(h->eq_p2, reinterpret_cast<const float2 *>(d_symbols), h->d_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
-                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), s));
+                          h->d_pilot_scratch_p2, reinterpret_cast<float2 *>(d_sync), s));
     return h->m.c_p2;
 }
 
@@ -442,7 +445,7 @@ int eq_p2_frames(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_
     p.out_frame_stride = cells_frame_stride; p.out_offset = 0; p.out_skip = skip_cells;
     p.skip_out = reinterpret_cast<float2 *>(d_l1_cells);
     T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, n_frames, reinterpret_cast<float2 *>(d_cells),
-                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+                          h->d_pilot_scratch_p2, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.c_p2 - skip_cells;
 }
 }  // namespace
@@ -460,7 +463,7 @@ extern "C" int t2gpu_eq_fc_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, in
     p.per_frame = 1; p.first = h->m.len_frame - 1; p.in_syms_per_frame = syms_per_frame;
     p.out_frame_stride = cells_frame_stride; p.out_offset = cells_offset;
     T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, n_frames, reinterpret_cast<float2 *>(d_cells),
-                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+                          h->d_pilot_scratch_fc, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.n_fc;
 }
 
@@ -470,7 +473,7 @@ extern "C" int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     if (!h || !d_symbols || !d_cells || n_symbols < 1 || n_symbols > h->max_symbols) { set_error("t2gpu_eq_fc_execute_dev: bad arguments"); return -1; }
     if (!h->m.l_fc) { set_error("t2gpu_eq_fc_execute_dev: this mode has no frame-closing symbol"); return -1; }
     T2_HIP(launch_eq_data(h->eq_fc, reinterpret_cast<const float2 *>(d_symbols), h->d_index_fc, n_symbols, reinterpret_cast<float2 *>(d_cells),
-                          h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
+                          h->d_pilot_scratch_fc, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.n_fc;
 }
 

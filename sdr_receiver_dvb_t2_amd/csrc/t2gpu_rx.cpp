@@ -53,6 +53,8 @@ struct t2gpu_rx {
     int32_t *d_trials = nullptr, *d_outer = nullptr;
     bool outer_code = false;
     hipEvent_t ev_ldpc0 = nullptr, ev_ldpc1 = nullptr;
+    hipStream_t side = nullptr;               // the P2 / frame-closing equalisers (one small launch per call each) run beside the data symbols'
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timed = false;
     // stage boundaries of the last call, recorded on the stream the kernels run on (t2gpu_rx_stage_ms)
     hipEvent_t ev[T2GPU_RX_STAGES + 1] = {};
@@ -123,6 +125,9 @@ void free_all(t2gpu_rx *h)
     hipFree(h->d_ti_out); hipFree(h->d_sums); hipFree(h->d_cp); hipFree(h->d_llr); hipFree(h->d_bits); hipFree(h->d_out); hipFree(h->d_trials); hipFree(h->d_outer);
     if (h->ev_ldpc0) hipEventDestroy(h->ev_ldpc0);
     if (h->ev_ldpc1) hipEventDestroy(h->ev_ldpc1);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
     hipFree(h->d_sync); hipFree(h->d_pack); hipFree(h->d_l1);
 }
@@ -215,6 +220,8 @@ extern "C" t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *c, int device)
          hipMemset(h->d_stream, 0, 2 * (size_t)(n_max + 64) * 4) == hipSuccess && hipMemset(h->d_cells, 0, 2 * (size_t)F * h->frame_cells * 4) == hipSuccess &&
          hipMemset(h->d_ti_out, 0, 2 * (size_t)F * h->n_ti * 4) == hipSuccess && hipMemset(h->d_sums, 0, (size_t)F * 16) == hipSuccess &&
          hipEventCreate(&h->ev_ldpc0) == hipSuccess && hipEventCreate(&h->ev_ldpc1) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess &&
+         hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess &&
          dev_alloc(h->d_sync, 2 * (size_t)F * h->n_sym);
     for (int k = 0; ok && k <= T2GPU_RX_STAGES; ++k) ok = hipEventCreate(&h->ev[k]) == hipSuccess;
     if (!ok) {
@@ -302,11 +309,17 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
     // formed too; with the loops open nobody reads them.
     const int a = h->c_p2 - h->p2_skip;
     float *sy = h->d_sync;
-    if (t2gpu_eq_p2_frames_l1_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, h->d_l1, sy, s) < 0) return -1;
-    if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, sy + 2 * (size_t)F, s) < 0) return -1;
+    // The P2 launch (one symbol per frame: fewer workgroups than CUs, its synchronisation sums a chain of 4640 pilots per symbol) and
+    // the frame-closing one run on a side stream beside the data symbols' launch: disjoint symbols, cells and scratch.
+    T2_HIP(hipEventRecord(h->ev_fork, s));
+    T2_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if (t2gpu_eq_p2_frames_l1_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, h->d_l1, sy, h->side) < 0) return -1;
     if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data,
-                                          sy + 2 * (size_t)F * (1 + h->n_dat), s) < 0)
+                                          sy + 2 * (size_t)F * (1 + h->n_dat), h->side) < 0)
         return -1;
+    T2_HIP(hipEventRecord(h->ev_join, h->side));
+    if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, sy + 2 * (size_t)F, s) < 0) return -1;
+    T2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     if (!mark(h, 5, s)) return -1;                                                      // equalisers
     // TI block of every frame in one launch, statistics (exact sequential sums, one workgroup per TI block) in one launch, LLRs in one launch
     if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
