@@ -163,15 +163,17 @@ __global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__r
 // parallel: while the running sum s stays inside one binade [2^E, 2^(E+1)), fl(s + x) = s + round(x / ulp) ulp with ulp = 2^(E-23) --
 // an INTEGER addition of the terms quantised at that ulp, which is associative -- except where x / ulp sits exactly on a half (the
 // tie is broken by the parity of s / ulp) and at the addition that carries s into the next binade. So: quantise a chunk's terms at the
-// current ulp, prefix-sum them over the workgroup, find the first such event, jump s to just before it in one step, perform that one
-// addition as a real float add, and go on from there (with the new ulp if it changed). A TI block of 1.6 M cells has about 25 events
+// current ulp, reduce them per wavefront (2048 consecutive cells each); if no total carries the sum out of its binade and nothing ties,
+// the chunk is one integer addition. Otherwise the first wavefront with such an event has its terms prefix-summed over the workgroup,
+// s jumps to just before the event in one step, that one addition is performed as a real float add, and the walk goes on from
+// there (with the new ulp if it changed). A TI block of 1.6 M cells has about 25 events
 // per sum (one per binade, plus ties while s is still small). One workgroup per TI block; the chunks of a block are its cells in
 // order, SEQ_U consecutive cells per lane. Checked against a sequential float loop on tie-heavy data in tests/test_fec_gpu.py.
 constexpr int SEQ_THREADS = 512, SEQ_U = 32, SEQ_CHUNK = SEQ_THREADS * SEQ_U, SEQ_WAVES = SEQ_THREADS / 64;
 constexpr int SEQ_HEAD = 2048;                     // cells summed by the plain sequential loop before the chunked walk starts
 constexpr int SEQ_CAP = 1 << 25;
-constexpr int SEQ_LDS_BYTES = (SEQ_CHUNK + SEQ_THREADS) * 4;      // a chunk of one sum in cell order, one pad word per lane
-static_assert(SEQ_HEAD * 8 <= SEQ_LDS_BYTES && SEQ_HEAD <= SEQ_CHUNK, "the head is staged in the same LDS");                    // quantised terms and their sums saturate here: anything >= 2^24 ends the binade anyway
+constexpr int SEQ_LDS_BYTES = SEQ_THREADS * 4 * 4;                 // one wavefront's run of a chunk (2048 terms) in cell order; the head before that
+static_assert(SEQ_U * 64 == SEQ_THREADS * 4 && SEQ_HEAD * 4 <= SEQ_LDS_BYTES && SEQ_HEAD <= SEQ_CHUNK, "the head is staged in the same LDS");                    // quantised terms and their sums saturate here: anything >= 2^24 ends the binade anyway
 
 struct SeqShared {
     int4 tot[2][1][SEQ_WAVES / 4];                  // [buffer][sum][wavefront]: saturated totals of the quantised terms, bit 30 = a rounding tie among them
@@ -200,39 +202,41 @@ __device__ __forceinline__ SeqScale seq_scale(float s)
     return r;
 }
 
-// Event path: one step of the walk over the chunk's terms x (this lane: chunk indices tid * SEQ_U + u) from index a on; returns the
-// new a (SEQ_CHUNK = chunk consumed). s is uniform over the workgroup. Three barriers; taken ~25 times per sum and TI block.
-__device__ __forceinline__ int seq_step(const float (&x)[SEQ_U], int a, float &s, SeqShared &sh)
+// Event path: one step of the walk over a run of SEQ_THREADS * U terms x in cell order (this lane: run indices tid * U + u) from index
+// a on; returns the new a (CH = run consumed). s is uniform over the workgroup. Three barriers; taken ~25 times per sum and TI block.
+template <int U>
+__device__ __forceinline__ int seq_step(const float (&x)[U], int a, float &s, SeqShared &sh)
 {
-    const int tid = (int)threadIdx.x, k0 = tid * SEQ_U, lane = tid & 63, wave = tid >> 6;
+    constexpr int CH = SEQ_THREADS * U;
+    const int tid = (int)threadIdx.x, k0 = tid * U, lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                                   // whoever still reads the shared words of the previous step
-    if (tid == 0) sh.first = SEQ_CHUNK;
+    if (tid == 0) sh.first = CH;
     if (s == 0.0f) {                                                   // 0 + x = x exactly: take the first non-zero term as it is
-        int cand = SEQ_CHUNK;
+        int cand = CH;
 #pragma unroll
-        for (int u = SEQ_U - 1; u >= 0; --u) if (k0 + u >= a && x[u] > 0.0f) cand = k0 + u;
+        for (int u = U - 1; u >= 0; --u) if (k0 + u >= a && x[u] > 0.0f) cand = k0 + u;
         __syncthreads();
-        if (cand < SEQ_CHUNK) atomicMin(&sh.first, cand);
+        if (cand < CH) atomicMin(&sh.first, cand);
         __syncthreads();
         const int p = sh.first;
-        if (p >= SEQ_CHUNK) return SEQ_CHUNK;
-        if (tid == p / SEQ_U) {
+        if (p >= CH) return CH;
+        if (tid == p / U) {
 #pragma unroll
-            for (int u = 0; u < SEQ_U; ++u) if (u == p % SEQ_U) sh.x = x[u];       // (no dynamic register index: that would put x[] in scratch)
+            for (int u = 0; u < U; ++u) if (u == p % U) sh.x = x[u];       // (no dynamic register index: that would put x[] in scratch)
         }
         __syncthreads();
         s = sh.x;
         return p + 1;
     }
     const SeqScale sc = seq_scale(s);
-    int pre[SEQ_U], loc = 0, tie_at = SEQ_CHUNK;
+    int pre[U], loc = 0, tie_at = CH;
 #pragma unroll
-    for (int u = 0; u < SEQ_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         int q = 0;
         if (k0 + u >= a) {
             bool tie;
             q = seq_quant(x[u], sc.inv_ulp, tie);
-            if (tie && tie_at == SEQ_CHUNK) tie_at = k0 + u;
+            if (tie && tie_at == CH) tie_at = k0 + u;
         }
         loc = sat_add(loc, q);
         pre[u] = loc;                                                  // inclusive prefix inside the lane
@@ -249,20 +253,20 @@ __device__ __forceinline__ int seq_step(const float (&x)[SEQ_U], int a, float &s
     // first term that carries s out of its binade (s / ulp reaches 2^24), or whose rounding is a tie
     int cand = tie_at;
 #pragma unroll
-    for (int u = SEQ_U - 1; u >= 0; --u) if (k0 + u >= a && sc.S + sat_add(off, pre[u]) >= (1 << 24) && k0 + u < cand) cand = k0 + u;
-    if (cand < SEQ_CHUNK) atomicMin(&sh.first, cand);
+    for (int u = U - 1; u >= 0; --u) if (k0 + u >= a && sc.S + sat_add(off, pre[u]) >= (1 << 24) && k0 + u < cand) cand = k0 + u;
+    if (cand < CH) atomicMin(&sh.first, cand);
     __syncthreads();
     const int p = sh.first;
-    if (p >= SEQ_CHUNK) {                                              // no event: the whole rest of the chunk in one integer addition
+    if (p >= CH) {                                              // no event: the whole rest of the chunk in one integer addition
         s = mul_r((float)(sc.S + total), sc.ulp);
-        return SEQ_CHUNK;
+        return CH;
     }
-    if (tid == p / SEQ_U) {
+    if (tid == p / U) {
         sh.before = off;                                               // quantised terms a .. p - 1 (no event among them: below 2^24)
 #pragma unroll
-        for (int u = 0; u < SEQ_U; ++u) {
-            if (u == p % SEQ_U) sh.x = x[u];
-            if (u + 1 == p % SEQ_U) sh.before = sat_add(off, pre[u]);
+        for (int u = 0; u < U; ++u) {
+            if (u == p % U) sh.x = x[u];
+            if (u + 1 == p % U) sh.before = sat_add(off, pre[u]);
         }
     }
     __syncthreads();
@@ -307,56 +311,71 @@ __device__ __forceinline__ void seq_load(float4 (&c)[SEQ_R], const float4 *src, 
     for (int r = 0; r < SEQ_R; ++r) c[r] = src[base / 4 + 64 * r];
 }
 
-// one chunk: x = this lane's terms (seq_pos order), s = the running sum on entry and exit (uniform)
-__device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s, SeqShared &sh, float *seq_tr)
+// one chunk: x = this lane's terms (seq_pos order), s = the running sum on entry and exit (uniform); it = count of total exchanges so
+// far (picks the buffer of sh.tot). Common case: no term of the chunk ties and the chunk does not leave the binade -> one reduction,
+// one barrier; without a tie, round-to-nearest-even of x / ulp is what the addition's own rounding adds. Otherwise the event is
+// narrowed down to the first WAVEFRONT whose 2048 consecutive terms contain it (every wavefront's total and tie flag are known from
+// the reduction): the wavefronts before it are one integer addition, its own terms go through LDS to all lanes, four consecutive
+// terms each, and are walked event by event (seq_step<4>); the wavefronts behind it are reduced again at the scale the sum has then.
+__device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s, SeqShared &sh, float *seq_tr, int &it)
 {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, buf = (base / SEQ_CHUNK) & 1;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (base < SEQ_HEAD) {                                             // (first chunk only) the head's terms are in the sum already
 #pragma unroll
         for (int u = 0; u < SEQ_U; ++u) if (base + seq_pos(wave, lane, u) < SEQ_HEAD) x[u] = 0.0f;
     }
-    // common case: no term of the chunk ties and the chunk does not leave the binade -> one reduction, one barrier. Without a tie,
-    // round-to-nearest-even of x / ulp is what the addition's own rounding adds.
-    SeqScale sc;
-    int word = 1 << 30;
-    if (s != 0.0f) {                                                   // uniform (a block of zeros stays on the event path)
-        sc = seq_scale(s);
-        int loc = 0;
-        float far = 0.0f;                                              // largest |y - rint(y)| among the terms: 1/2 = a tie
+    for (int w_from = 0; w_from < SEQ_WAVES;) {                        // uniform
+        SeqScale sc{0.0f, 0.0f, 0};
+        int word = 1 << 30;
+        if (s != 0.0f) {                                               // uniform (a block of zeros stays on the event path)
+            sc = seq_scale(s);
+            int loc = 0;
+            float far = 0.0f;                                          // largest |y - rint(y)| among the terms: 1/2 = a tie
 #pragma unroll
-        for (int u = 0; u < SEQ_U; ++u) {
-            const float y = fminf(mul_r(x[u], sc.inv_ulp), (float)SEQ_CAP), r = rintf(y);
-            loc += (int)r;                                             // <= SEQ_U * 2^25: no overflow
-            far = fmaxf(far, fabsf(sub_r(y, r)));
+            for (int u = 0; u < SEQ_U; ++u) {
+                const float y = fminf(mul_r(x[u], sc.inv_ulp), (float)SEQ_CAP), r = rintf(y);
+                loc += (int)r;                                         // <= SEQ_U * 2^25: no overflow
+                far = fmaxf(far, fabsf(sub_r(y, r)));
+            }
+            word = min(loc, SEQ_CAP) | (far == 0.5f ? 1 << 30 : 0);
         }
-        word = min(loc, SEQ_CAP) | (far == 0.5f ? 1 << 30 : 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int o = __shfl_xor(word, d, 64);
+            word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
+        }
+        const int buf = it & 1;
+        ++it;
+        if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
+        __syncthreads();
+        int tot[SEQ_WAVES];
+#pragma unroll
+        for (int w = 0; w < SEQ_WAVES / 4; ++w) {
+            const int4 t = sh.tot[buf][0][w];
+            tot[4 * w] = t.x; tot[4 * w + 1] = t.y; tot[4 * w + 2] = t.z; tot[4 * w + 3] = t.w;
+        }
+        int S = sc.S, wev = SEQ_WAVES;                                 // first wavefront >= w_from with an event among its terms
+#pragma unroll
+        for (int w = 0; w < SEQ_WAVES; ++w) {
+            if (w >= w_from && wev == SEQ_WAVES) {
+                const int v = tot[w] & (SEQ_CAP * 2 - 1);
+                if ((tot[w] >> 30) || S + v >= (1 << 24)) wev = w;
+                else S += v;
+            }
+        }
+        if (s != 0.0f) s = mul_r((float)S, sc.ulp);                    // the sum in front of wavefront wev (exact: an integer below 2^24)
+        if (wev == SEQ_WAVES) return;
+        if (wave == wev) {
+#pragma unroll
+            for (int u = 0; u < SEQ_U; ++u) seq_tr[(u >> 2) * 256 + 4 * lane + (u & 3)] = x[u];      // cell order inside the wavefront's run
+        }
+        __syncthreads();
+        const float4 y4 = reinterpret_cast<const float4 *>(seq_tr)[tid];
+        const float xt[4] = {y4.x, y4.y, y4.z, y4.w};
+        for (int a = 0; a < SEQ_THREADS * 4;) a = seq_step<4>(xt, a, s, sh);
+        __syncthreads();                                               // seq_tr is written again by the next event
+        w_from = wev + 1;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const int o = __shfl_xor(word, d, 64);
-        word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
-    }
-    if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
-    __syncthreads();
-    int total = 0, tie = 0;
-#pragma unroll
-    for (int w = 0; w < SEQ_WAVES / 4; ++w) {
-        const int4 t = sh.tot[buf][0][w];
-        const int v[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { total = sat_add(total, v[j] & (SEQ_CAP * 2 - 1)); tie |= v[j] >> 30; }
-    }
-    if (!tie && sc.S + total < (1 << 24)) { s = mul_r((float)(sc.S + total), sc.ulp); return; }      // uniform
-    // an event in this chunk: in cell order through LDS, SEQ_U consecutive terms per lane (one pad word per lane's run, so that the
-    // lanes' reads spread over the banks), and walked event by event
-#pragma unroll
-    for (int u = 0; u < SEQ_U; ++u) { const int q = seq_pos(wave, lane, u); seq_tr[q + q / SEQ_U] = x[u]; }
-    __syncthreads();
-    float xt[SEQ_U];
-#pragma unroll
-    for (int u = 0; u < SEQ_U; ++u) xt[u] = seq_tr[tid * (SEQ_U + 1) + u];
-    for (int a = 0; a < SEQ_CHUNK;) a = seq_step(xt, a, s, sh);
-    __syncthreads();                                                   // seq_tr is written again by the next event chunk
 }
 
 // blockIdx.x = TI block, blockIdx.y = which sum (0: sum_s, 1: sum_e -- two independent chains, a workgroup each); the scale is formed
@@ -381,16 +400,22 @@ __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const fl
     {
         for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) seq_tr[k] = tp[k];        // (zeros behind the block's end)
         __syncthreads();
-#pragma unroll 16
-        for (int k = 0; k < SEQ_HEAD; ++k) s = add_r(s, seq_tr[k]);
+        if (wave == 0) {                                               // one wavefront: eight of them reading every word kept the LDS pipe busy for 2/3 of the loop
+            const float4 *h4 = reinterpret_cast<const float4 *>(seq_tr);
+#pragma unroll 4
+            for (int k = 0; k < SEQ_HEAD / 4; ++k) { const float4 t = h4[k]; s = add_r(add_r(add_r(add_r(s, t.x), t.y), t.z), t.w); }
+            if (lane == 0) sh.x = s;
+        }
         __syncthreads();                                               // seq_tr is the event path's from here on
+        s = sh.x;
     }
 #ifdef T2_SEQ_PROF
     long long t_head = __builtin_amdgcn_s_memtime(); long long hb[6] = {0,0,0,0,0,0}; int hn[6] = {0,0,0,0,0,0};
-#define PROF_CHUNK(B) { const long long t0 = __builtin_amdgcn_s_memtime(); seq_chunk(x, B, s, sh, seq_tr); const long long dt = __builtin_amdgcn_s_memtime() - t0; const int bk = dt < 4000 ? 0 : dt < 8000 ? 1 : dt < 16000 ? 2 : dt < 32000 ? 3 : dt < 64000 ? 4 : 5; _Pragma("unroll") for (int z = 0; z < 6; ++z) if (z == bk) { hb[z] += dt; ++hn[z]; } }
+#define PROF_CHUNK(B) { const long long t0 = __builtin_amdgcn_s_memtime(); seq_chunk(x, B, s, sh, seq_tr, it); const long long dt = __builtin_amdgcn_s_memtime() - t0; const int bk = dt < 4000 ? 0 : dt < 8000 ? 1 : dt < 16000 ? 2 : dt < 32000 ? 3 : dt < 64000 ? 4 : 5; _Pragma("unroll") for (int z = 0; z < 6; ++z) if (z == bk) { hb[z] += dt; ++hn[z]; } }
 #else
-#define PROF_CHUNK(B) seq_chunk(x, B, s, sh, seq_tr)
+#define PROF_CHUNK(B) seq_chunk(x, B, s, sh, seq_tr, it)
 #endif
+    int it = 0;
     for (int base = 0; base < n_snr; base += 2 * SEQ_CHUNK) {
         float x[SEQ_U];
 #pragma unroll
