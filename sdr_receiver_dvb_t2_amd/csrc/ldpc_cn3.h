@@ -53,9 +53,9 @@ __device__ __forceinline__ p16 p2_f(p16 a)
 
 // sat((LLR bytes A, B in bytes 0, 1 of raw) - (message bytes A, B in bytes 2*odd, 2*odd + 1 of msg)), times 256, one frame per
 // half: either pair of bytes goes to the high bytes of the halves with one v_perm_b32, the subtract saturates (v_pk_sub_i16 clamp)
-__device__ __forceinline__ p16 p2_llr_minus_msg(uint16_t raw, uint32_t msg, int odd)
-{
-    const p16 l = p_of(__builtin_amdgcn_perm(0u, (uint32_t)raw, 0x010c000cu));
+__device__ __forceinline__ p16 p2_llr_minus_msg(uint32_t raw, uint32_t msg, int odd)       // raw: the zero-extended 16-bit load (kept 32 bits
+{                                                                                            // wide: as uint16_t it cost a v_and per slot)
+    const p16 l = p_of(__builtin_amdgcn_perm(0u, raw, 0x010c000cu));
     const p16 m = p_of(__builtin_amdgcn_perm(0u, msg, odd ? 0x030c020cu : 0x010c000cu));
     return __builtin_elementwise_sub_sat(l, m);
 }
@@ -95,7 +95,7 @@ template <int CNT, class LMEM>
 __device__ __forceinline__ void p2_read_slot(const LMEM &L, P2Regs<CNT> &r, int v)
 {
     const bool present = p2_present(r, v);
-    const uint16_t raw = present ? L.ld16(r.addr[v]) : (uint16_t)0;
+    const uint32_t raw = present ? (uint32_t)L.ld16(r.addr[v]) : 0u;
     const p16 x = p2_llr_minus_msg(raw, r.mo[v >> 1], v & 1);
     r.in[v] = present ? x : p_set(0);
     r.mag[v] = present ? p2_abs(x) : p_set(P2_ABSENT);
@@ -133,9 +133,9 @@ __device__ __forceinline__ void p2_load(const LMEM &L, const uint2 (&e)[(CNT + 3
         else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
         else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
     }
-    uint16_t raw[H];
+    uint32_t raw[H];
 #pragma unroll
-    for (int v = 0; v < H; ++v) raw[v] = p2_present(r, v) ? L.ld16(r.addr[v]) : (uint16_t)0;
+    for (int v = 0; v < H; ++v) raw[v] = p2_present(r, v) ? (uint32_t)L.ld16(r.addr[v]) : 0u;
 #pragma unroll
     for (int v = 0; v < H; ++v) {
         const bool present = p2_present(r, v);
@@ -198,8 +198,14 @@ template <int CNT, class LMEM>
 __device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bool store)
 {
     const bool present = p2_present(r, v);
-    const p16 s = u_min(r.mag[v] - r.m0, p_set(1));      // 0 where the slot holds the raw minimum (an absent slot carries 255), else 1
-    const p16 other = s * r.dm + r.m1f;                  // f(min1) for the minimum's slot, f(min0) for the others
+    // 0 where the slot holds the raw minimum (an absent slot carries 255), else 1; then f(min1) for the minimum's slot, f(min0) for
+    // the others. As plain C the compiler turns min(d, 1) * dm + m1f into a compare and a select PER HALF plus a v_perm to join them
+    // (five instructions and a hazard nop); these are the three it should be.
+    uint32_t s_, other_;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(s_) : "v"(u_of(r.mag[v])), "v"(u_of(r.m0)));
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(s_) : "v"(s_));
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(other_) : "v"(s_), "v"(u_of(r.dm)), "v"(u_of(r.m1f)));
+    const p16 other = p_of(other_);
     const p16 sm = p_of(r.sx ^ u_of(r.in[v])) >> p_set(15);   // 0 / -1: sign of the product of the other inputs
     const p16 sgn = p_of(u_of(sm) | 0x00010001u);        // +1 / -1
     const p16 out = other * sgn;
