@@ -24,6 +24,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -326,7 +327,25 @@ def main():
                 cap = (steps + 1) * F * nb * (w.k_bch // 8 + 64) if keep_ts else F * nb * (w.k_bch // 8 + 64)
                 sink = np.empty(cap, np.uint8)
                 sink.fill(0)
+            # The TS consumer is a thread of its own, as the reference's UDP / file sink is: it takes what the library's worker has
+            # finished while the main thread is in the next call (ctypes releases the GIL for the call, the copy runs in C).
+            done, got = threading.Event(), [0]
+
+            def consume():
+                while not done.is_set():
+                    n = rx.ts_read_into(sink[got[0]:] if keep_ts else sink)
+                    got[0] += n
+                    if n == 0:
+                        time.sleep(0.0002)
+                while True:                            # the last step's frames de-framed: demod -> TS is complete
+                    n = rx.ts_read_into(sink[got[0]:] if keep_ts else sink, wait_all=True)
+                    got[0] += n
+                    if n == 0:
+                        break
+            consumer = threading.Thread(target=consume) if ts_on else None
             t0 = time.perf_counter()
+            if consumer:
+                consumer.start()
             for _ in range(steps):
                 step(rx, level)
                 for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
@@ -334,14 +353,10 @@ def main():
                         acc[k] = acc.get(k, 0.0) + v
                 if full:
                     ldpc.append(rx.last_ldpc_ms())
-                if ts_on:                              # what the worker has finished meanwhile (it runs beside the next step)
-                    ts_bytes += rx.ts_read_into(sink[ts_bytes:] if keep_ts else sink)
-            if ts_on:                                  # the last step's frames de-framed: demod -> TS is complete
-                while True:
-                    n = rx.ts_read_into(sink[ts_bytes:] if keep_ts else sink, wait_all=True)
-                    ts_bytes += n
-                    if n == 0:
-                        break
+            if consumer:
+                done.set()
+                consumer.join()
+                ts_bytes = got[0]
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()

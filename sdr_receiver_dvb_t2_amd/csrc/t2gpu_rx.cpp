@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -509,14 +510,18 @@ void ts_worker(TsEnd *t)
                 while (!t->l1_status.empty() && t->l1_status.front().first < oldest) t->l1_status.pop_front();
                 known = t->l1_status;
             }
+            long tf_known = -1;                                  // FEC frames come in order: one look-up per T2 frame
+            int v_known = 0;
             for (int i = 0; i < j.fec_frames; ++i) {
                 ++d.fec_frames;
                 if (sl.trials[i / h->group] < 0) { ++d.fec_frames_dropped_ldpc; continue; }        // ldpc_decoder.cpp:264-268
                 if (t->l1_check) {
                     const long tf = (j.fec_first + i) / nb;
-                    int v = 0;
-                    for (auto &e : known) if (e.first == tf) v = e.second;
-                    if (v != (L1_PRE_OK | L1_POST_OK | L1_MATCH)) { ++d.fec_frames_dropped_l1; continue; }
+                    if (tf != tf_known) {
+                        tf_known = tf; v_known = 0;
+                        for (auto &e : known) if (e.first == tf) v_known = e.second;
+                    }
+                    if (v_known != (L1_PRE_OK | L1_POST_OK | L1_MATCH)) { ++d.fec_frames_dropped_l1; continue; }
                 }
                 int err = 0;
                 const int n = t2gpu_bbdh_execute_packed(t->bbdh, t->need_plp, h->k_bch, sl.pack + (size_t)i * row, local.p.get() + used, (int)per, &err);
@@ -623,12 +628,21 @@ extern "C" long t2gpu_rx_ts_read(t2gpu_rx *h, uint8_t *out, long cap, int wait_a
     while (n < cap && !t->ts.empty()) {
         TsEnd::Chunk &c = t->ts.front();
         const size_t take = std::min<size_t>((size_t)(cap - n), c.size - t->ts_head);
-        std::memcpy(out + n, c.p.get() + t->ts_head, take);
-        n += (long)take; t->ts_head += take; t->ts_pending -= take;
-        if (t->ts_head == c.size) {
-            if (t->pool.size() < 4) t->pool.emplace_back(std::move(c));
-            t->ts.pop_front(); t->ts_head = 0;
+        if (t->ts_head + take == c.size) {
+            // the rest of the chunk: taken off the queue and copied WITHOUT the lock (a call's worth of TS is tens of megabytes; the
+            // worker and the next call's ts_submit need the lock meanwhile)
+            TsEnd::Chunk mine = std::move(c);
+            const size_t from = t->ts_head;
+            t->ts.pop_front(); t->ts_head = 0; t->ts_pending -= take;
+            lk.unlock();
+            std::memcpy(out + n, mine.p.get() + from, take);
+            lk.lock();
+            if (t->pool.size() < 4) t->pool.emplace_back(std::move(mine));
+        } else {
+            std::memcpy(out + n, c.p.get() + t->ts_head, take);
+            t->ts_head += take; t->ts_pending -= take;
         }
+        n += (long)take;
     }
     return n;
 }
