@@ -1,5 +1,6 @@
 #!/bin/bash
 # equaliser: output-range kernel vs segment-group kernel -- parity tests, then the stage time for each (ranges, lanes) shape
+# usage: gpurun -- 'bash tools/eq_shapes_ab.sh 0:1024 2:1024 3:512'   (T2GPU_EQ_SPLITS:T2GPU_EQ_THREADS; 0 = segment-group kernel)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 timeout 900 python -m pytest tests/test_ofdm_gpu.py tests/test_chain_gpu.py tests/test_receiver_gpu.py -q -m gpu -x 2>&1 | tail -5
