@@ -147,6 +147,15 @@ int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float 
                                       long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
                                       void *stream);
 
+/* The same in two steps with a stage boundary between them: the de-interleaver (time_deinterleaver::execute) also forms the demapper's
+ * per-cell statistics terms (the |s|^2 and |e|^2 of llr_demapper.cpp:564-676) of the cells it writes -- one pass over the cells for
+ * both -- and the demapper then sums them in the reference's order. t2gpu_ti_execute_blocks_terms_dev returns 1 when the terms were
+ * formed, 0 when only the de-interleaving was done (then t2gpu_demap_stats_batch_dev on d_out is the next step), -1 on error. */
+int t2gpu_ti_execute_blocks_terms_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
+                                      long out_stride_cells, int n_blocks, void *stream);
+int t2gpu_demap_stats_terms_dev(t2gpu_demap *dm, int n_blocks, int cells_per_block, float precision_override, float *d_sums,
+                                int sums_stride, void *stream);
+
 /* ---------------------------------------------------------------- BB descrambler (the reference's BCH stage) ------
  * Replaces  void bch_decoder::execute(int* idx_plp_simd, l1_postsignalling, int len_in, uint8_t* in)
  *           (src/DVB_T2/bch_decoder.h:41, bch_decoder.cpp:63-164). The reference performs no BCH decoding (:136): it

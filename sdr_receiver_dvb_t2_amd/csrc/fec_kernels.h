@@ -51,8 +51,15 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 // blocks of the same geometry in one launch: block f reads cells + f * in_stride, writes out + f * out_stride (in cells).
 // lost_by_block[b] = 1: the reference never stores the parked Q of FEC block b (see t2gpu_ti_begin), the last cell keeps its Q.
 // Returns hipErrorInvalidValue when the FEC block does not fit LDS (QPSK with 64800-bit frames): use the scatter kernels.
+// terms (optional): the demapper's per-cell statistics terms of the first n_snr de-interleaved cells of every TI block, formed while
+// the cells are on their way out (two planes of demap_terms_padded(n_snr) floats per TI block, as demap_terms_kernel writes them)
+struct TiTerms { const DemapParams *dp = nullptr; float2 *terms = nullptr; int n_snr = 0; };
 hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
-                            float2 *out, long out_stride, int frames, hipStream_t s);
+                            float2 *out, long out_stride, int frames, hipStream_t s, const TiTerms *tt = nullptr);
+// the walk + scale of launch_demap_stats_batch's exact form on terms that are already there (launch_ti_blocks with TiTerms)
+bool demap_stats_exact_form();
+hipError_t launch_demap_stats_from_terms(const DemapParams &p, int n_snr, int n_batch, float2 *terms, float *sums, int sums_stride,
+                                         float precision_override, hipStream_t s);
 
 }  // namespace t2gpu
 

@@ -274,6 +274,15 @@ __device__ __forceinline__ int seq_step(const float (&x)[U], int a, float &s, Se
     return p + 1;
 }
 
+// (|s|^2, |e|^2) of one cell: de-rotate, slice, error, both norms as float (llr_demapper.cpp:564-676)
+__device__ __forceinline__ float2 demap_term(const DemapParams &p, float2 v)
+{
+    if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
+    const float sr = slice_axis(p.mod, v.x, p.d), si = slice_axis(p.mod, v.y, p.d);
+    const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
+    return make_float2(add_r(mul_r(sr, sr), mul_r(si, si)), add_r(mul_r(er, er), mul_r(ei, ei)));
+}
+
 // The terms of the two sums, one pair per cell, by the whole device (the per-cell arithmetic of llr_demapper.cpp:564-676: de-rotate,
 // slice, |s|^2 and |e|^2 as float): the sequential walk below is one workgroup per TI block and must not carry this work.
 __global__ __launch_bounds__(256) void demap_terms_kernel(DemapParams p, const float2 *__restrict__ cells, int n_snr, long cells_stride,
@@ -285,13 +294,7 @@ __global__ __launch_bounds__(256) void demap_terms_kernel(DemapParams p, const f
     const int padded = (n_snr + SEQ_CHUNK - 1) / SEQ_CHUNK * SEQ_CHUNK;        // zeros behind the block: the walk reads whole chunks unguarded
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += gridDim.x * blockDim.x) {
         float2 t = make_float2(0.0f, 0.0f);
-        if (i < n_snr) {
-            float2 v = cells[i];
-            if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
-            const float sr = slice_axis(p.mod, v.x, p.d), si = slice_axis(p.mod, v.y, p.d);
-            const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
-            t = make_float2(add_r(mul_r(sr, sr), mul_r(si, si)), add_r(mul_r(er, er), mul_r(ei, ei)));
-        }
+        if (i < n_snr) t = demap_term(p, cells[i]);
         ts[i] = t.x;
         te[i] = t.y;
     }
@@ -461,12 +464,21 @@ static hipError_t launch_exact(const DemapParams &p, const float2 *cells, long c
         attr_set = true;
     }
     const long padded = demap_terms_padded(n_snr);
-    int bx = (int)((padded + 256 * 4 - 1) / (256 * 4));
-    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
-    hipLaunchKernelGGL(demap_terms_kernel, dim3(bx, n_batch), dim3(256), 0, s, p, cells, n_snr, cells_stride, terms, padded);
+    if (cells) {                                                      // (nullptr: the terms are there already, launch_ti_blocks formed them)
+        int bx = (int)((padded + 256 * 4 - 1) / (256 * 4));
+        bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+        hipLaunchKernelGGL(demap_terms_kernel, dim3(bx, n_batch), dim3(256), 0, s, p, cells, n_snr, cells_stride, terms, padded);
+    }
     hipLaunchKernelGGL(demap_stats_exact_kernel, dim3(n_batch, 2), dim3(SEQ_THREADS), SEQ_LDS_BYTES, s, terms, n_snr, padded, sums, sums_stride);
     hipLaunchKernelGGL(demap_scale_kernel, dim3((n_batch + 63) / 64), dim3(64), 0, s, p.d, precision_override, sums, sums_stride, n_batch);
     return hipGetLastError();
+}
+
+bool demap_stats_exact_form() { return !tree_stats(); }
+hipError_t launch_demap_stats_from_terms(const DemapParams &p, int n_snr, int n_batch, float2 *terms, float *sums, int sums_stride,
+                                         float precision_override, hipStream_t s)
+{
+    return launch_exact(p, nullptr, 0L, n_snr, n_batch, terms, sums, sums_stride, precision_override, s);
 }
 
 // terms: scratch of n_snr float pairs (exact form); partial / blocks: scratch of the tree form
@@ -625,9 +637,11 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 #ifndef T2_TI_THREADS
 #define T2_TI_THREADS 1024
 #endif
+// TERMS: the demapper's statistics terms of the cells are formed on the way out (the cells are read once for both)
+template <bool TERMS>
 __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, const uint8_t *__restrict__ lost_by_block, int num_blocks,
                                                       const float2 *__restrict__ cells, long in_stride, float2 *__restrict__ out,
-                                                      long out_stride)
+                                                      long out_stride, DemapParams dp, float *__restrict__ terms, long plane, int n_snr)
 {
     extern __shared__ float ti_lds[];                    // [cells_per_fec][2]
     // FEC block b reads the 40-byte runs of columns 5b .. 5b+4 in every row: a 128-byte line holds the runs of three neighbouring
@@ -650,23 +664,45 @@ __global__ __launch_bounds__(T2_TI_THREADS) void ti_block_kernel(TiParams p, con
     }
     __syncthreads();
     const bool lost = lost_by_block[b] != 0;
+    float *ts = TERMS ? terms + (long)f * 2 * plane + base : nullptr;      // plane of |s|^2, the one of |e|^2 `plane` floats on
     for (int t = threadIdx.x; t < C; t += blockDim.x) {
-        if (t == C - 1 && lost) reinterpret_cast<float *>(o)[2 * t] = ti_lds[2 * t];
-        else o[t] = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
+        float2 v = make_float2(ti_lds[2 * t], ti_lds[2 * t + 1]);
+        if (t == C - 1 && lost) {
+            reinterpret_cast<float *>(o)[2 * t] = v.x;
+            if (TERMS) v.y = o[t].y;                                      // the Q that stays in the caller's buffer (the parked-Q loss)
+        } else o[t] = v;
+        if (TERMS && base + t < n_snr) {
+            const float2 tm = demap_term(dp, v);
+            ts[t] = tm.x;
+            ts[plane + t] = tm.y;
+        }
     }
 }
 
 hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
-                            float2 *out, long out_stride, int frames, hipStream_t s)
+                            float2 *out, long out_stride, int frames, hipStream_t s, const TiTerms *tt)
 {
     const size_t lds = (size_t)p.cells_per_fec * 8;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ti_block_kernel, dim3((unsigned)(8 * ((num_blocks + 7) / 8) * frames)), dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks,
-                       cells, in_stride, out, out_stride);
+    const dim3 grid((unsigned)(8 * ((num_blocks + 7) / 8) * frames));
+    if (tt && tt->terms) {
+        const long plane = demap_terms_padded(tt->n_snr);
+        if (plane > tt->n_snr) {                                         // zeros behind every plane's n_snr terms: the walk reads whole chunks
+            hipError_t e = hipMemset2DAsync(reinterpret_cast<float *>(tt->terms) + tt->n_snr, (size_t)plane * 4, 0, (size_t)(plane - tt->n_snr) * 4,
+                                            (size_t)2 * frames, s);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(ti_block_kernel<true>, grid, dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks, cells, in_stride, out, out_stride,
+                           *tt->dp, reinterpret_cast<float *>(tt->terms), plane, tt->n_snr);
+    } else {
+        hipLaunchKernelGGL(ti_block_kernel<false>, grid, dim3(T2_TI_THREADS), lds, s, p, lost_by_block, num_blocks, cells, in_stride, out, out_stride,
+                           DemapParams{}, (float *)nullptr, 0L, 0);
+    }
     return hipGetLastError();
 }
 

@@ -329,7 +329,45 @@ extern "C" int t2gpu_ti_execute_blocks_dev(t2gpu_ti *h, const float *d_cells, lo
     return n_blocks;
 }
 
-// t2gpu_ti_execute_blocks_dev followed by t2gpu_demap_stats_batch_dev on the de-interleaved blocks, as one call
+// One pass over the cells for the de-interleaver AND the demapper's statistics terms: the de-interleaver forms (|s|^2, |e|^2) of the
+// cells it writes into dm's term planes (whole TI blocks in LDS-sized FEC blocks, exact sums); t2gpu_demap_stats_terms_dev then walks
+// them (4 B per cell and sum). Returns 1 when the terms were formed, 0 when only the de-interleaving was done (tree sums selected, FEC
+// block larger than LDS: t2gpu_demap_stats_batch_dev on d_out is the caller's next step then), -1 on error.
+extern "C" int t2gpu_ti_execute_blocks_terms_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
+                                                 long out_stride_cells, int n_blocks, void *stream)
+{
+    if (!h || !dm || dm->p.cells_per_fec != h->cells_per_fec) {
+        set_error("t2gpu_ti_execute_blocks_terms_dev: bad arguments (de-interleaver and demapper of one modulation / FEC type)");
+        return -1;
+    }
+    const int n_snr = dm->p.mod == 0 ? std::min(h->p.ti_block_size, 2048) : h->p.ti_block_size;
+    const bool fused = demap_stats_exact_form() && d_cells && d_out && n_blocks >= 1 && h->num_blocks && h->pos == 0 &&
+                       (size_t)h->p.cells_per_fec * 8 <= 150 * 1024 && h->p.ti_block_size <= dm->max_cells;
+    if (!fused) return t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream) < 0 ? -1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!ensure_terms(dm, (size_t)demap_terms_padded(n_snr) * n_blocks, s)) return -1;
+    const TiTerms tt{&dm->p, dm->d_terms, n_snr};
+    T2_HIP(launch_ti_blocks(h->p, h->d_lost_blk, h->num_blocks, reinterpret_cast<const float2 *>(d_cells), in_stride_cells,
+                            reinterpret_cast<float2 *>(d_out), out_stride_cells, n_blocks, s, &tt));
+    return 1;
+}
+
+// the exact sums of n_blocks TI blocks from the terms t2gpu_ti_execute_blocks_terms_dev left in dm (same n_blocks, same TI block size)
+extern "C" int t2gpu_demap_stats_terms_dev(t2gpu_demap *dm, int n_blocks, int cells_per_block, float precision_override, float *d_sums,
+                                           int sums_stride, void *stream)
+{
+    if (!dm || !d_sums || n_blocks < 1 || cells_per_block < 1 || sums_stride < 3) { set_error("t2gpu_demap_stats_terms_dev: bad arguments"); return -1; }
+    const int n_snr = dm->p.mod == 0 ? std::min(cells_per_block, 2048) : cells_per_block;
+    if (!dm->d_terms || (size_t)demap_terms_padded(n_snr) * n_blocks > dm->terms_cells) {
+        set_error("t2gpu_demap_stats_terms_dev: no terms of that size (t2gpu_ti_execute_blocks_terms_dev first)");
+        return -1;
+    }
+    T2_HIP(launch_demap_stats_from_terms(dm->p, n_snr, n_blocks, dm->d_terms, d_sums, sums_stride, precision_override, (hipStream_t)stream));
+    return 0;
+}
+
+// t2gpu_ti_execute_blocks_dev followed by t2gpu_demap_stats_batch_dev on the de-interleaved blocks, as one call (one pass over the
+// cells where t2gpu_ti_execute_blocks_terms_dev applies)
 extern "C" int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, const float *d_cells, long in_stride_cells, float *d_out,
                                                  long out_stride_cells, int n_blocks, float precision_override, float *d_sums, int sums_stride,
                                                  void *stream)
@@ -338,8 +376,9 @@ extern "C" int t2gpu_ti_execute_blocks_stats_dev(t2gpu_ti *h, t2gpu_demap *dm, c
         set_error("t2gpu_ti_execute_blocks_stats_dev: bad arguments (de-interleaver and demapper of one modulation / FEC type)");
         return -1;
     }
-    const int rc = t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream);
-    if (rc <= 0) return rc;
+    const int rc = t2gpu_ti_execute_blocks_terms_dev(h, dm, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream);
+    if (rc < 0) return rc;
+    if (rc == 1) return t2gpu_demap_stats_terms_dev(dm, n_blocks, h->p.ti_block_size, precision_override, d_sums, sums_stride, stream) == 0 ? n_blocks : -1;
     return t2gpu_demap_stats_batch_dev(dm, d_out, out_stride_cells, n_blocks, h->p.ti_block_size, precision_override, d_sums, sums_stride, stream) == 0
                ? n_blocks : -1;
 }

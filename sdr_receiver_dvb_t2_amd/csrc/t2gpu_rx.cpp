@@ -323,9 +323,13 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
     T2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     if (!mark(h, 5, s)) return -1;                                                      // equalisers
     // TI block of every frame in one launch, statistics (exact sequential sums, one workgroup per TI block) in one launch, LLRs in one launch
-    if (t2gpu_ti_execute_blocks_dev(h->ti, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s) < 0) return -1;
+    // the de-interleaver forms the statistics terms of the cells it writes (one pass over the cells for both)
+    const int with_terms = t2gpu_ti_execute_blocks_terms_dev(h->ti, h->demap, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s);
+    if (with_terms < 0) return -1;
     if (!mark(h, 6, s)) return -1;                                                      // time / cell de-interleaver
-    if (t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0) return -1;
+    if (with_terms ? t2gpu_demap_stats_terms_dev(h->demap, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0
+                   : t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0)
+        return -1;
     if (t2gpu_demap_llr_batch_dev(h->demap, h->d_ti_out, F, h->n_ti, h->d_sums, 4, h->d_llr + (size_t)llr_at * h->fec_size, s) < 0) return -1;
     if (!mark(h, 7, s)) return -1;                                                      // demapper
     return 0;
