@@ -617,7 +617,8 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         int range = 0;
         for (int k = 0; k < p.n_splits; ++k) range = std::max(range, eq_split_q(p.c_data, p.n_splits, k + 1) - eq_split_q(p.c_data, p.n_splits, k));
         const int bytes = (range + 1) * 8;
-        static const int threads = (getenv("T2GPU_EQ_THREADS") && atoi(getenv("T2GPU_EQ_THREADS")) == 1024) ? 1024 : 512;
+        const char *th_env = getenv("T2GPU_EQ_THREADS");                  // 1024: one workgroup of twice the lanes per range (A/B, tests)
+        const int threads = (th_env && atoi(th_env) == 1024) ? 1024 : 512;
         const int it = (range + threads - 1) / threads;
         hipError_t e = hipErrorInvalidValue;
 #define T2_EQS(IT_, TH_) e = launch_eq_split<IT_, TH_>(p, symbols, symbol_index, n_symbols, out, pilot_scratch, bytes, s)
