@@ -231,6 +231,9 @@ __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA,
     return bad;
 }
 
+#ifndef T2_PAIR_SEG_MIN
+#define T2_PAIR_SEG_MIN 12                 // chains at least this long are walked in segments (cut where a node's output ignores its input)
+#endif
 template <int CNT, int NCMAX>
 __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, const uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a0, int a1,
                                               uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec)
@@ -242,7 +245,7 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, co
         // frame A's chains on lanes 0..359, frame B's on lanes 384..743 (whole wavefronts apart), side by side
         const int t = (int)threadIdx.x, frame = t >= 384 ? 1 : 0, node = t - 384 * frame;
         if (node < 360) {
-            if (d.lmax >= 12) p2_pair_walk_segments(L, d, node, frame, pair_rec + 360 * frame);
+            if (d.lmax >= T2_PAIR_SEG_MIN) p2_pair_walk_segments(L, d, node, frame, pair_rec + 360 * frame);
             else if (node < d.step) p2_pair_walk(L, d, node, frame, pair_rec + 360 * frame);
         }
         __builtin_amdgcn_s_setprio(0);
