@@ -69,6 +69,27 @@ __global__ void k_pk_add_f32(int *out, int seed, long long *clk)
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { clk[2 * (threadIdx.x >> 6)] = t0; clk[2 * (threadIdx.x >> 6) + 1] = t1; }
 }
 
+#define PK_KERNEL(NAME, OPS)                                                                                          \
+    __global__ void k_##NAME(int *out, int seed, long long *clk)                                                       \
+    {                                                                                                                  \
+        const long long t0 = __builtin_amdgcn_s_memtime();                                                             \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                                          \
+        f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, b = {(float)seed, 2.f};          \
+        float s0 = (float)threadIdx.x, s1 = s0 * 3.f, s2 = s0 * 5.f, s3 = s0 * 7.f, sb = (float)seed;                    \
+        for (int it = 0; it < ITER; ++it) {                                                                            \
+            _Pragma("unroll") for (int r = 0; r < REP / 4; ++r)                                                        \
+                asm volatile(OPS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) : "v"(b), "v"(sb)); \
+        }                                                                                                              \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (int)(a0.x + a1.x + a2.x + a3.y + s0 + s1 + s2 + s3);              \
+        const long long t1 = __builtin_amdgcn_s_memtime();                                                             \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { clk[2 * (threadIdx.x >> 6)] = t0; clk[2 * (threadIdx.x >> 6) + 1] = t1; } \
+    }
+// the decimator's own mix, and packed beside plain fp32
+PK_KERNEL(mix_pkmul_pkadd, "v_pk_mul_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8")
+PK_KERNEL(mix_pkadd_add, "v_pk_add_f32 %0, %0, %8\n v_add_f32 %4, %4, %9\n v_pk_add_f32 %2, %2, %8\n v_add_f32 %6, %6, %9")
+PK_KERNEL(mix_pkmul_mul_add, "v_pk_mul_f32 %0, %0, %8\n v_mul_f32 %4, %4, %9\n v_add_f32 %5, %5, %9\n v_pk_add_f32 %1, %1, %8")
+PK_KERNEL(mix_mul_add, "v_mul_f32 %4, %4, %9\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %9\n v_add_f32 %7, %7, %9")
+
 // further classes the two-frame kernel uses
 KERNEL(and_b32, IDECL, ASM4("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4"))
 KERNEL(lshlrev_b32, IDECL, ASM4("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3"))
@@ -80,6 +101,10 @@ KERNEL(sub_u16_sdwa, IDECL, ASM4("v_sub_u16_sdwa %0, %0, %4 dst_sel:WORD_1 dst_u
 KERNEL(bfi_b32, IDECL, ASM4("v_bfi_b32 %0, %4, %0, %5\n v_bfi_b32 %1, %4, %1, %5\n v_bfi_b32 %2, %4, %2, %5\n v_bfi_b32 %3, %4, %3, %5"))
 KERNEL(cmp_only, IDECL, ASM4("v_cmp_lt_i32 vcc, %0, %4\n v_cmp_lt_i32 vcc, %1, %4\n v_cmp_lt_i32 vcc, %2, %4\n v_cmp_lt_i32 vcc, %3, %4"))
 
+// mixes of a fast-class and a slow-class op (two of each per group of four, independent chains): additive or overlapped?
+KERNEL(mix_xor_pkmin, IDECL, ASM4("v_xor_b32 %0, %0, %4\n v_pk_min_i16 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_pk_min_i16 %3, %3, %4"))
+KERNEL(mix_add_perm, IDECL, ASM4("v_add_u32 %0, %0, %4\n v_perm_b32 %1, %1, %4, %5\n v_add_u32 %2, %2, %4\n v_perm_b32 %3, %3, %4, %5"))
+KERNEL(mix_addf_minf, IDECL, ASM4("v_add_f32 %0, %0, %4\n v_min_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_min_f32 %3, %3, %4"))
 typedef void (*kfn)(int *, int, long long *);
 struct Entry { const char *name; kfn fn; };
 #define E(N) {#N, k_##N}
@@ -88,7 +113,7 @@ int main()
 {
     Entry tests[] = {E(add_u32), E(and_b32), E(xor_b32), E(lshlrev_b32), E(min_i32), E(med3_i32), E(cmp_only), E(cmp_cnd), E(sad_u32), E(add3_u32), E(bfe_i32),
                      E(bfi_b32), E(perm_b32), E(lshl_or), E(mov_dpp), E(sub_u16_sdwa), E(pk_add_i16), E(pk_min_i16), E(pk_max_i16), E(pk_sub_i16_clamp),
-                     E(pk_mad_i16), E(pk_ashr_i16), E(add_f32), E(min_f32), E(med3_f32), E(fma_f32), E(mul_f32), E(pk_add_f32)};
+                     E(pk_mad_i16), E(pk_ashr_i16), E(add_f32), E(min_f32), E(med3_f32), E(fma_f32), E(mul_f32), E(pk_add_f32), E(mix_xor_pkmin), E(mix_add_perm), E(mix_addf_minf), E(mix_pkmul_pkadd), E(mix_pkadd_add), E(mix_pkmul_mul_add), E(mix_mul_add)};
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     double clk = prop.clockRate * 1e3;   // Hz (nominal max)
