@@ -66,7 +66,15 @@ static float decim_sum(const float (*w)[2], int comp)
     return ((lane[0] + lane[1]) + lane[2]) + lane[3];
 }
 
-int ora_decim_execute(ora_decim *s, int len_in, const float *in, float *out)
+/* The same sums eight lanes at a time, as the reference's registers hold them (:92-115): lane 2p + comp of a 256-bit register is
+ * component comp of cell p of a group of four; v0..v3 are the four groups of a 16-cell block. gcc's vector extension keeps every
+ * operation in this order (no re-association without -ffast-math) and compiles to the AVX2 forms under -mavx2. decim_sum above is
+ * the scalar statement of the same order and is what ora_decim_execute falls back to in the CPU tier's cross-check
+ * (ora_decim_execute_scalar). */
+typedef float ora_v8f __attribute__((vector_size(32)));
+static inline ora_v8f ld8(const float *p) { ora_v8f v; memcpy(&v, p, sizeof v); return v; }
+
+int ora_decim_execute_scalar(ora_decim *s, int len_in, const float *in, float *out)
 {
     float w[64][2];
     int n_out = 0;
@@ -81,6 +89,41 @@ int ora_decim_execute(ora_decim *s, int len_in, const float *in, float *out)
         }
         memcpy(s->hist, w + 1, sizeof s->hist);
     }
+    return n_out;
+}
+
+int ora_decim_execute(ora_decim *s, int len_in, const float *in, float *out)
+{
+    static float taps2[128] __attribute__((aligned(32)));
+    static int taps_ready = 0;
+    if (!taps_ready) {
+        for (int c = 0; c < 64; c++) taps2[2 * c] = taps2[2 * c + 1] = T2_DECIM_TAPS[c];
+        taps_ready = 1;
+    }
+    /* one contiguous run of cells: the 63 kept ones, then the input (the reference's ring buffer, :80-90, without the wrap) */
+    float *buf = (float *)malloc(sizeof(float) * 2 * (size_t)(63 + len_in));
+    if (!buf) return -1;
+    memcpy(buf, s->hist, sizeof s->hist);
+    memcpy(buf + 126, in, sizeof(float) * 2 * (size_t)len_in);
+    int n_out = 0;
+    for (int x = 0; x < len_in; x++) {
+        if (++s->d != 2) continue;
+        s->d = 0;
+        const float *w = buf + 2 * x;                      /* window of the 64 newest cells, oldest first */
+        ora_v8f sum = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 128; i += 32) {
+            const ora_v8f m0 = ld8(w + i) * ld8(taps2 + i), m1 = ld8(w + i + 8) * ld8(taps2 + i + 8);
+            const ora_v8f m2 = ld8(w + i + 16) * ld8(taps2 + i + 16), m3 = ld8(w + i + 24) * ld8(taps2 + i + 24);
+            const ora_v8f sum0 = m0 + m1, sum1 = m2 + m3;
+            const ora_v8f sumt = sum0 + sum1;
+            sum = sum + sumt;
+        }
+        out[2 * n_out] = ((sum[0] + sum[2]) + sum[4]) + sum[6];
+        out[2 * n_out + 1] = ((sum[1] + sum[3]) + sum[5]) + sum[7];
+        n_out++;
+    }
+    memcpy(s->hist, buf + 2 * (size_t)len_in, sizeof s->hist);
+    free(buf);
     return n_out;
 }
 

@@ -319,17 +319,21 @@ def _c64(x):
 class OraDecim(object):
     """filter_decimator restated; ref=True drives the reference class itself."""
 
-    def __init__(self, ref=False, strict=False):
+    def __init__(self, ref=False, strict=False, scalar=False):
         self.lib = ref_dsp(strict) if ref else oracle()
         self.new, self.free, self.run = ((self.lib.ref_decim_new, self.lib.ref_decim_free, self.lib.ref_decim_execute) if ref else
-                                         (self.lib.ora_decim_create, self.lib.ora_decim_destroy, self.lib.ora_decim_execute))
+                                         (self.lib.ora_decim_create, self.lib.ora_decim_destroy,
+                                          self.lib.ora_decim_execute_scalar if scalar else self.lib.ora_decim_execute))
         self.new.restype = ctypes.c_void_p
         self.free.argtypes = [ctypes.c_void_p]
         self.run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self.h = self.new()
 
-    def __call__(self, x):
+    def __call__(self, x, out=None):
+        """out: a caller's complex64 buffer of len(x) // 2 + 1 cells at least (the result is then a view of it, no copy)."""
         x = _c64(x)
+        if out is not None:
+            return out[:self.run(self.h, len(x), x.ctypes.data, out.ctypes.data)]
         out = np.zeros(len(x) // 2 + 1, np.complex64)
         n = self.run(self.h, len(x), x.ctypes.data, out.ctypes.data)
         return out[:n].copy()
@@ -337,6 +341,32 @@ class OraDecim(object):
     def __del__(self):
         if getattr(self, "h", None):
             self.free(self.h)
+            self.h = None
+
+
+class OraFft(object):
+    """fast_fourier_transform::execute restated (oracle/fft_oracle.c): forward transform of n cells, halves swapped."""
+
+    def __init__(self, n):
+        L = oracle()
+        L.ora_fft_create.restype = ctypes.c_void_p
+        L.ora_fft_create.argtypes = [ctypes.c_int]
+        L.ora_fft_execute.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ora_fft_destroy.argtypes = [ctypes.c_void_p]
+        self.L, self.n = L, n
+        self.h = L.ora_fft_create(n)
+        assert self.h, "fft size must be a power of two"
+
+    def __call__(self, x, shift=True):
+        x = _c64(x)
+        assert x.size == self.n
+        out = np.empty(self.n, np.complex64)
+        self.L.ora_fft_execute(self.h, x.ctypes.data, out.ctypes.data, int(shift))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_fft_destroy(self.h)
             self.h = None
 
 
@@ -353,9 +383,13 @@ class OraFarrow(object):
         self.run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p] + ([] if ref else [ctypes.c_void_p])
         self.h = self.new()
 
-    def __call__(self, x, resample, want_phases=False):
+    def __call__(self, x, resample, want_phases=False, out=None):
+        """out: a caller's complex64 buffer of len(x) / resample + 8 cells at least (result = a view of it; not with want_phases)."""
         x = _c64(x)
         cap = int(len(x) / max(resample, 0.05)) + 8
+        if out is not None and not want_phases:
+            assert out.size >= cap
+            return out[:self.run(self.h, len(x), x.ctypes.data, resample, out.ctypes.data, *(() if self.ref else (None,)))]
         out = np.zeros(cap, np.complex64)
         if self.ref:
             n = self.run(self.h, len(x), x.ctypes.data, resample, out.ctypes.data)
@@ -396,12 +430,12 @@ class OraFront(object):
         self.h = o.ora_front_create(id_device)
         self.stride = 2 if id_device == 1 else 1
 
-    def execute(self, i_in, q_in, chunk_len, phase_est_filtered, frequency_est_filtered):
-        """One execute() call: chunks in order with their loop values. Returns the derotated stream."""
+    def execute(self, i_in, q_in, chunk_len, phase_est_filtered, frequency_est_filtered, out=None):
+        """One execute() call: chunks in order with their loop values. Returns the derotated stream (in `out` when given)."""
         i_in = np.ascontiguousarray(i_in, np.int16)
         q_in = np.ascontiguousarray(q_in, np.int16)
         total = int(np.sum(chunk_len))
-        out = np.zeros(total, np.complex64)
+        out = np.zeros(total, np.complex64) if out is None else out[:total]
         theta = np.zeros(3, np.float32)
         pos = 0
         for n, pe, fe in zip(chunk_len, phase_est_filtered, frequency_est_filtered):

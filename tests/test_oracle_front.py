@@ -34,6 +34,35 @@ def test_decimator_bit_exact_vs_reference_class():
     assert abs(h.real.sum() + 0) > 0 and np.count_nonzero(h) == 32
 
 
+def test_decimator_register_form_equals_the_scalar_statement():
+    """ora_decim_execute forms the sums eight lanes at a time as the reference's AVX2 registers do; the scalar restatement of the same
+    order (decim_sum) gives the same bits for any chunking."""
+    x = _sig(30011, 7)
+    a, b = ol.OraDecim(), ol.OraDecim(scalar=True)
+    pos = 0
+    for n in (1, 2, 3, 63, 64, 65, 1000, 4097, 12001, 12814):
+        ya, yb = a(x[pos:pos + n]), b(x[pos:pos + n])
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+        pos += n
+
+
+@pytest.mark.parametrize("n", [32768, 16384, 1024])
+def test_fft_restatement_against_the_references_fftw_output(n):
+    """oracle/fft_oracle.c against tests/golden/fft_golden.npz (outputs of the FFTW binary the reference ships, on the committed
+    input generator) and against a float64 DFT: 2e-5 of the spectrum's rms, the tolerance the HIP kernel is held to."""
+    import os
+    k = np.arange(n, dtype=np.int64)
+    x = (((k * 7919) % 251 - 125) / 64.0 + 1j * (((k * 104729) % 241 - 120) / 64.0)).astype(np.complex64)
+    f = ol.OraFft(n)
+    y = f(x)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "fft_golden.npz"))
+    rel = lambda a, b: np.abs(a - b).max() / np.sqrt((np.abs(b) ** 2).mean())
+    if "fft_%d" % n in gold:
+        assert rel(y, gold["fft_%d" % n]) < 2e-5
+    assert rel(y, np.fft.fftshift(np.fft.fft(x.astype(np.complex128)))) < 2e-5
+    assert np.array_equal(f(x, shift=False), np.fft.ifftshift(y))      # the shift is the swap of the two halves
+
+
 @needs_ref
 @pytest.mark.parametrize("resample", [0.5, 0.5 - 3 * 8.0e-9, 0.5 + 5 * 8.0e-9, 0.5 * (1 + 1.0e-4), 0.4571, 0.73, 1.0])
 def test_farrow_counts_exact_values_close(resample):
