@@ -324,8 +324,9 @@ def main():
 
     from sdr_receiver_dvb_t2_amd.receiver import t2_rx
 
-    def run_config(cfg_id, steps, warmup, extras):
-        """One bench line's worth of measurement for a config; returns the dict to print (rank 0) or None."""
+    def run_config(cfg_id, steps, warmup, extras, check_ts=False):
+        """One bench line's worth of measurement for a config; returns the dict to print (rank 0) or None. check_ts: keep the TS bytes of
+        the timed steps and count the packets that are among those sent."""
         cfg = CONFIGS[cfg_id]
         w = Workload(cfg)
         full = cfg_id != 2
@@ -352,18 +353,19 @@ def main():
             return rx
 
         if full:
-            def step(rx, level):
-                return rx.execute_dev(d_i, d_q, F, level)
+            def step(rx, level, nf):
+                return rx.execute_dev(d_i, d_q, nf, level)
         else:
-            def step(rx, level):                       # config 2: the frames' stream and positions stay in the handle from the set-up call
-                return rx.fft_eq_demap_dev(F)
+            def step(rx, level, nf):                   # config 2: the frames' stream and positions stay in the handle from the set-up call
+                return rx.fft_eq_demap_dev(nf)
 
-        def timed_leg(rx, steps, warmup, level, keep_ts=False):
+        def timed_leg(rx, steps, warmup, level, keep_ts=False, nf=None):
             """W untimed + K timed steps bracketed by barrier + synchronize; the clock stops when the last step's TS bytes are on the host.
             Returns (seconds, per-stage ms sums, LDPC ms list, TS bytes of the timed steps, the bytes themselves if keep_ts)."""
             ts_on = full and not args.no_ts_end
+            nf = nf or F
             for _ in range(max(warmup, 1)):
-                step(rx, level)
+                step(rx, level, nf)
             torch.cuda.synchronize(dev)
             if ts_on:
                 rx.ts_read(wait_all=True)                                              # warm-up output is not counted
@@ -372,7 +374,7 @@ def main():
             torch.cuda.synchronize(dev)
             acc, ldpc, ts_bytes = {}, [], 0
             if ts_on:                                  # the consumer's buffer: allocated and touched before the clock starts
-                cap = (steps + 1) * F * nb * (w.k_bch // 8 + 64) if keep_ts else F * nb * (w.k_bch // 8 + 64)
+                cap = (steps + 1) * nf * nb * (w.k_bch // 8 + 64) if keep_ts else (nf + 1) * nb * (w.k_bch // 8 + 64)
                 sink = np.empty(cap, np.uint8)
                 sink.fill(0)
             # The TS consumer is a thread of its own, as the reference's UDP / file sink is: it takes what the library's worker has
@@ -395,7 +397,7 @@ def main():
             if consumer:
                 consumer.start()
             for _ in range(steps):
-                step(rx, level)
+                step(rx, level, nf)
                 for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
                     if v >= 0:
                         acc[k] = acc.get(k, 0.0) + v
@@ -410,6 +412,17 @@ def main():
                 dist.barrier()
             return time.perf_counter() - t0, acc, ldpc, ts_bytes, (sink[:ts_bytes] if ts_on and keep_ts else None)
 
+        def ts_check(ts, tsb, secs, n_steps):
+            """TS bytes of n_steps timed steps against the packets that were sent (the bytes start wherever the warm-up's last packet
+            ended: the packet phase is found from the sync bytes)."""
+            off = next((o for o in range(188) if ts.size > o + 188 * 64 and (ts[o:o + 188 * 64:188] == 0x47).all()), 0)
+            pk = ts[off:off + (ts.size - off) // 188 * 188].reshape(-1, 188)
+            good = np.isin(packet_hashes(pk), np.concatenate([packet_hashes(x) for x in sent]))
+            per_frame = (nb * ((w.k_bch - 80) // 8)) // 187 - 1                     # whole packets one T2 frame's BBFRAMEs carry
+            return {"ts_bytes": int(tsb), "ts_bytes_per_s": round(tsb / secs, 1), "ts_mbit_per_s": round(tsb * 8 / secs / 1e6, 1),
+                    "ts_packets": int(pk.shape[0]), "ts_packets_that_were_sent": int(good.sum()),
+                    "ts_matches_sent": bool(good.sum() >= n_steps * F * per_frame and pk.shape[0] - good.sum() <= n_steps * F * 2)}
+
         rx = make_rx(False, F, args.trials)            # reference semantics: truncating int8 cast in the demapper
         assert rx.frame_len == FS
         count = rx.execute_dev(d_i, d_q, F, first_call=True)                               # thresholds from the level estimate
@@ -418,7 +431,7 @@ def main():
         occ = rx.ldpc_occupancy()
         # One step = one call = the whole chain over one buffer of F frames (front end .. descrambler + packing), drained by the host once
         # per call because the P1 decisions are host data; the host end (copies on their own stream, worker thread) overlaps the next step.
-        elapsed, stage_acc, ldpc_ms, ts_bytes, _ = timed_leg(rx, steps, warmup, level)
+        elapsed, stage_acc, ldpc_ms, ts_bytes, ts_kept = timed_leg(rx, steps, warmup, level, keep_ts=check_ts)
         ref_trials = rx.fetch_packed(count)[1] if full else None
         counters = rx.ts_counters() if full and not args.no_ts_end else None
         max_s, units = aggregate_timing(elapsed, F * steps, dist if world > 1 else None, None if one_device else dev)
@@ -443,16 +456,26 @@ def main():
             var = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "avg_ldpc_updates": round(float((args.trials - t3).mean()), 2),
                    "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
             if ts is not None:
-                # the timed steps' bytes start wherever the warm-up's last packet ended: find the packet phase from the sync bytes
-                off = next((o for o in range(188) if ts.size > o + 188 * 64 and (ts[o:o + 188 * 64:188] == 0x47).all()), 0)
-                pk = ts[off:off + (ts.size - off) // 188 * 188].reshape(-1, 188)
-                good = np.isin(packet_hashes(pk), np.concatenate([packet_hashes(s) for s in sent]))
-                per_frame = (nb * ((w.k_bch - 80) // 8)) // 187 - 1                     # whole packets one T2 frame's BBFRAMEs carry
-                var.update({"ts_bytes_per_s": round(tsb / e3, 1), "ts_mbit_per_s": round(tsb * 8 / e3 / 1e6, 1), "ts_packets": int(pk.shape[0]),
-                            "ts_packets_that_were_sent": int(good.sum()),
-                            "ts_matches_sent": bool(good.sum() >= 3 * F * per_frame and pk.shape[0] - good.sum() <= 3 * F * 2),
-                            "bytes_d2h_per_fec_frame": w.k_bch // 8, "host_end_counters": k3})
+                var.update(ts_check(ts, tsb, e3, 3))
+                var.update({"bytes_d2h_per_fec_frame": w.k_bch // 8, "host_end_counters": k3})
             extra["clamped_llr_variant"] = var
+            # (iii) throughput against T2 frames per call of the batch receiver (the headline's 48 fill 18.9 rounds of the decoder's
+            # resident batch slots; one frame = 202 FEC frames = 6.3 SIMD batches, formed across calls exactly as the reference forms them)
+            sweep = []
+            for nf in (1, 2, 4, 8, 16, F):
+                if nf > F:
+                    continue
+                rs = make_rx(False, nf, args.trials)
+                rs.execute_dev(d_i, d_q, nf, first_call=True)
+                k = max(3, min(24, 96 // nf))
+                es, accs, ls, _, _ = timed_leg(rs, k, 2, level, nf=nf)
+                rs.close()
+                sweep.append({"frames_per_call": nf, "msamples_per_s": round(k * nf * FS / es / 1e6, 1), "ms_per_call": round(es / k * 1e3, 3),
+                              "ldpc_ms_per_call": round(sum(ls) / len(ls), 3), "calls_timed": k})
+            top = sweep[-1]["msamples_per_s"]
+            for r in sweep:
+                r["of_full_batch_rate"] = round(r["msamples_per_s"] / top, 3)
+            extra["frames_sweep"] = sweep
 
         if rank != 0:
             return None
@@ -512,11 +535,15 @@ def main():
         }
         if counters is not None:
             out["host_end"] = {"ts_bytes": ts_bytes, "ts_bytes_per_s": round(ts_bytes / max_s, 1), "bytes_d2h_per_fec_frame": w.k_bch // 8, "counters": counters}
+            if ts_kept is not None and ts_kept.size:
+                out["host_end"].update(ts_check(ts_kept, ts_bytes, max_s, steps))
+        out["snr_db"] = snr_db
+        out["stage_ms_sum"] = round(sum(v for k, v in stage_acc.items() if v > 0) / steps, 3)
         out.update(extra)
         out["_cpu_args"] = (cfg_id, w, ui[0], uq[0], full)
         return out
 
-    out = run_config(args.config, args.steps, args.warmup, extras=not args.no_extra_legs)
+    out = run_config(args.config, args.steps, args.warmup, extras=not args.no_extra_legs, check_ts=args.config == 4)
     if rank == 0:
         cpu_args = out.pop("_cpu_args")
     if args.config == 3 and not args.no_extra_legs:
@@ -527,6 +554,21 @@ def main():
             out["config_5"] = {"metric": c5["metric"], "value": c5["value"], "unit": c5["unit"], "ms_per_step": c5["ms_per_step"],
                                "ldpc_codewords_per_s": c5["config"]["ldpc_codewords_per_s"], "ldpc_ms": c5["roofline"]["avg_launch_ms"],
                                "n_gpus": world, "workload": c5["config"]["workload"][:120] + " ..."}
+        if world == 1:
+            # BASELINE.json configs[3] (16K, 64-QAM, 16200 r = 1/2 at 12 dB): the leg that DECODES in the reference's own arithmetic --
+            # its TS leaves the library's host end inside the clock and every packet is compared with the packets sent
+            c4 = run_config(4, 5, 2, extras=False, check_ts=True)
+            c4.pop("_cpu_args")
+            he = c4.get("host_end", {})
+            out["config_4"] = {"metric": c4["metric"], "value": c4["value"], "unit": c4["unit"], "ms_per_step": c4["ms_per_step"],
+                               "stage_ms_sum": c4["stage_ms_sum"], "snr_db": c4["snr_db"],
+                               "ldpc_codewords_per_s": c4["config"]["ldpc_codewords_per_s"], "ldpc_ms": c4["roofline"]["avg_launch_ms"],
+                               "ts_bytes": he.get("ts_bytes"), "ts_mbit_per_s": he.get("ts_mbit_per_s"), "ts_packets": he.get("ts_packets"),
+                               "ts_packets_that_were_sent": he.get("ts_packets_that_were_sent"), "ts_matches_sent": he.get("ts_matches_sent"),
+                               "fec_frames": he.get("counters", {}).get("fec_frames"),
+                               "fec_frames_dropped_ldpc": he.get("counters", {}).get("fec_frames_dropped_ldpc"),
+                               "fec_frames_dropped_l1": he.get("counters", {}).get("fec_frames_dropped_l1"),
+                               "workload": c4["config"]["workload"][:140] + " ..."}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_chain_baseline(*cpu_args)

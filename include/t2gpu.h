@@ -253,6 +253,9 @@ int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bit
 int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bytes, uint8_t *out, int out_cap, int *ts_errors);
 int t2gpu_bbdh_mode(const t2gpu_bbdh *h);
 int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h);
+/* The packet state of a freshly constructed bb_de_header (bb_de_header.cpp:29-54: no split packet pending, idx_packet = 0, crc = 0):
+ * a new stream on the same handle. */
+int t2gpu_bbdh_reset(t2gpu_bbdh *h);
 
 /* ---------------------------------------------------------------- OFDM side: FFT and data-symbol equaliser ----------
  * Mode arguments are the reference's dvbt2_parameters fields (src/DVB_T2/dvbt2_definition.h:215-248): fft_mode

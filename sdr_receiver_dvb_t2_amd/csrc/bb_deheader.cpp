@@ -292,3 +292,10 @@ extern "C" int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, 
 }
 
 extern "C" int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h) { return h ? h->resync : 0; }
+extern "C" int t2gpu_bbdh_reset(t2gpu_bbdh *h)
+{
+    if (!h) return -3;
+    h->crc = 0; h->idx_packet = 0; h->idx_buffer = 0; h->split = false; h->last_mode = -1; h->resync = 0;
+    std::memset(h->buffer, 0, sizeof h->buffer);
+    return 0;
+}

@@ -1,6 +1,7 @@
 // fec_kernels.hip -- FEC-side streaming kernels for gfx950: BB descrambler (BCH stub), LLR demapper + bit de-interleaver,
 // time / cell de-interleaver with cyclic Q-delay removal. All HBM-bound gather/scatter work; no matrix cores involved.
 #include "fec_kernels.h"
+#include "t2gpu_common.h"
 #include <cstdlib>
 
 // The reference is built without FMA (-mavx2 only): every product and sum rounds on its own. HIP's mul_r/add_r
@@ -320,7 +321,11 @@ __device__ __forceinline__ void seq_load(float4 (&c)[SEQ_R], const float4 *src, 
 // narrowed down to the first WAVEFRONT whose 2048 consecutive terms contain it (every wavefront's total and tie flag are known from
 // the reduction): the wavefronts before it are one integer addition, its own terms go through LDS to all lanes, four consecutive
 // terms each, and are walked event by event (seq_step<4>); the wavefronts behind it are reduced again at the scale the sum has then.
-__device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s, SeqShared &sh, float *seq_tr, int &it)
+// nf (per lane): bit 0 = a term of this lane was +-inf, bit 1 = NaN. Such terms (a dead equaliser symbol: 0 * inf) are taken out of
+// the walk -- quantised they would all be "events", tens of thousands of serial steps -- and the result is what the reference's float
+// loop gives for them: NaN once a NaN was added, +inf after an inf (the terms are norms: no inf - inf). One float add per term finds
+// them (fast-class op; the terms are >= 0, so a non-finite one makes the lane's plain sum non-finite).
+__device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s, SeqShared &sh, float *seq_tr, int &it, int &nf)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (base < SEQ_HEAD) {                                             // (first chunk only) the head's terms are in the sum already
@@ -330,6 +335,10 @@ __device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s,
     for (int w_from = 0; w_from < SEQ_WAVES;) {                        // uniform
         SeqScale sc{0.0f, 0.0f, 0};
         int word = 1 << 30;
+        float plain = 0.0f;
+#pragma unroll
+        for (int u = 0; u < SEQ_U; ++u) plain += x[u];
+        const int bad_wave = __ballot(!(plain <= 3.402823466e+38f)) != 0ull ? 1 << 29 : 0;
         if (s != 0.0f) {                                               // uniform (a block of zeros stays on the event path)
             sc = seq_scale(s);
             int loc = 0;
@@ -347,6 +356,7 @@ __device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s,
             const int o = __shfl_xor(word, d, 64);
             word = sat_add(word & (SEQ_CAP * 2 - 1), o & (SEQ_CAP * 2 - 1)) | ((word | o) & (1 << 30));
         }
+        word |= bad_wave;
         const int buf = it & 1;
         ++it;
         if (lane == 0) reinterpret_cast<int *>(sh.tot[buf][0])[wave] = word;
@@ -357,12 +367,24 @@ __device__ __forceinline__ void seq_chunk(float (&x)[SEQ_U], int base, float &s,
             const int4 t = sh.tot[buf][0][w];
             tot[4 * w] = t.x; tot[4 * w + 1] = t.y; tot[4 * w + 2] = t.z; tot[4 * w + 3] = t.w;
         }
+        int anybad = 0;
+#pragma unroll
+        for (int w = 0; w < SEQ_WAVES; ++w) anybad |= tot[w];
+        if (anybad & (1 << 29)) {                                      // uniform, rare: drop the non-finite terms, remember them, same chunk again
+#pragma unroll
+            for (int u = 0; u < SEQ_U; ++u) {
+                const bool fin = fabsf(x[u]) <= 3.402823466e+38f;
+                nf |= fin ? 0 : (x[u] != x[u] ? 2 : 1);
+                x[u] = fin ? x[u] : 0.0f;
+            }
+            continue;
+        }
         int S = sc.S, wev = SEQ_WAVES;                                 // first wavefront >= w_from with an event among its terms
 #pragma unroll
         for (int w = 0; w < SEQ_WAVES; ++w) {
             if (w >= w_from && wev == SEQ_WAVES) {
                 const int v = tot[w] & (SEQ_CAP * 2 - 1);
-                if ((tot[w] >> 30) || S + v >= (1 << 24)) wev = w;
+                if (((tot[w] >> 30) & 1) || S + v >= (1 << 24)) wev = w;
                 else S += v;
             }
         }
@@ -394,6 +416,7 @@ __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const fl
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4 *src = reinterpret_cast<const float4 *>(tp) + (wave * 64 * SEQ_U) / 4 + lane;        // + 64 r: this lane's quads inside a chunk
     float s = 0.0f;                                                    // the running sum: uniform over the workgroup
+    int nf = 0;                                                        // non-finite terms met by this lane (seq_chunk)
     float4 c0[SEQ_R], c1[SEQ_R];
     seq_load(c0, src, 0);
     if (SEQ_CHUNK < n_snr) seq_load(c1, src, SEQ_CHUNK);
@@ -401,7 +424,12 @@ __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const fl
     // block's events fall into its first couple of thousand cells). Staged through LDS; every lane reads the same word (a broadcast)
     // and runs the same additions: uniform, no exchange.
     {
-        for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) seq_tr[k] = tp[k];        // (zeros behind the block's end)
+        for (int k = tid; k < SEQ_HEAD; k += SEQ_THREADS) {                         // (zeros behind the block's end)
+            const float v = tp[k];
+            const bool fin = fabsf(v) <= 3.402823466e+38f;
+            nf |= fin ? 0 : (v != v ? 2 : 1);
+            seq_tr[k] = fin ? v : 0.0f;
+        }
         __syncthreads();
         if (wave == 0) {                                               // one wavefront: eight of them reading every word kept the LDS pipe busy for 2/3 of the loop
             const float4 *h4 = reinterpret_cast<const float4 *>(seq_tr);
@@ -414,9 +442,9 @@ __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const fl
     }
 #ifdef T2_SEQ_PROF
     long long t_head = __builtin_amdgcn_s_memtime(); long long hb[6] = {0,0,0,0,0,0}; int hn[6] = {0,0,0,0,0,0};
-#define PROF_CHUNK(B) { const long long t0 = __builtin_amdgcn_s_memtime(); seq_chunk(x, B, s, sh, seq_tr, it); const long long dt = __builtin_amdgcn_s_memtime() - t0; const int bk = dt < 4000 ? 0 : dt < 8000 ? 1 : dt < 16000 ? 2 : dt < 32000 ? 3 : dt < 64000 ? 4 : 5; _Pragma("unroll") for (int z = 0; z < 6; ++z) if (z == bk) { hb[z] += dt; ++hn[z]; } }
+#define PROF_CHUNK(B) { const long long t0 = __builtin_amdgcn_s_memtime(); seq_chunk(x, B, s, sh, seq_tr, it, nf); const long long dt = __builtin_amdgcn_s_memtime() - t0; const int bk = dt < 4000 ? 0 : dt < 8000 ? 1 : dt < 16000 ? 2 : dt < 32000 ? 3 : dt < 64000 ? 4 : 5; _Pragma("unroll") for (int z = 0; z < 6; ++z) if (z == bk) { hb[z] += dt; ++hn[z]; } }
 #else
-#define PROF_CHUNK(B) seq_chunk(x, B, s, sh, seq_tr, it)
+#define PROF_CHUNK(B) seq_chunk(x, B, s, sh, seq_tr, it, nf)
 #endif
     int it = 0;
     for (int base = 0; base < n_snr; base += 2 * SEQ_CHUNK) {
@@ -434,6 +462,9 @@ __global__ __launch_bounds__(SEQ_THREADS) void demap_stats_exact_kernel(const fl
 #ifdef T2_SEQ_PROF
     if (threadIdx.x == 0 && blockIdx.x < 2) printf("blk %d sum %d: total %lld cycles; chunks <4k %d (%lld) <8k %d (%lld) <16k %d (%lld) <32k %d (%lld) <64k %d (%lld) more %d (%lld)\n", (int)blockIdx.x, which, __builtin_amdgcn_s_memtime() - t_head, hn[0], hb[0], hn[1], hb[1], hn[2], hb[2], hn[3], hb[3], hn[4], hb[4], hn[5], hb[5]);
 #endif
+    const int any_nan = __syncthreads_or(nf & 2), any_inf = __syncthreads_or(nf & 1);
+    if (any_nan) s = __int_as_float(0x7fc00000);
+    else if (any_inf) s = __int_as_float(0x7f800000);
     if (threadIdx.x == 0) sums[which] = s;
 }
 
@@ -456,13 +487,7 @@ long demap_terms_padded(int n_snr) { return ((long)n_snr + SEQ_CHUNK - 1) / SEQ_
 static hipError_t launch_exact(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, float2 *terms, float *sums,
                                int sums_stride, float precision_override, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demap_stats_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           SEQ_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(demap_stats_exact_kernel), SEQ_LDS_BYTES)) return e;
     const long padded = demap_terms_padded(n_snr);
     if (cells) {                                                      // (nullptr: the terms are there already, launch_ti_blocks formed them)
         int bx = (int)((padded + 256 * 4 - 1) / (256 * 4));
@@ -572,13 +597,7 @@ hipError_t launch_demap_llr(const DemapParams &p, const float2 *cells, int n_fra
                             int frames_per_sums, int sums_stride)
 {
     if (frames_per_sums < 1) frames_per_sums = n_frames > 0 ? n_frames : 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(demap_llr_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64800);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(demap_llr_kernel), 64800)) return e;
     hipLaunchKernelGGL(demap_llr_kernel, dim3(n_frames), dim3(T2_DEMAP_THREADS), p.fec_size, s, p, cells, sums, out, frames_per_sums, sums_stride);
     return hipGetLastError();
 }
@@ -685,8 +704,8 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
     const size_t lds = (size_t)p.cells_per_fec * 8;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(ti_block_kernel<false>), (int)lds);
+        if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void *>(ti_block_kernel<true>), (int)lds);
         if (e != hipSuccess) return e;
     }
     const dim3 grid((unsigned)(8 * ((num_blocks + 7) / 8) * frames));

@@ -117,8 +117,11 @@ __device__ __forceinline__ void p2_entries(const LMEM &L, int ent_lds, int h, ui
 }
 
 // pl_load. e: the lane's entries as (base + 2 * (bit base - shift), shift) pairs (p2_entries); j2 = 2 j.
+// next_ent_lds != 0: e is overwritten with the NEXT layer's entries once this layer's addresses are formed -- the reads are issued
+// behind this layer's LLR reads (LDS returns in order: nothing waits for them before the next layer) and land in the registers the
+// next layer reads them from, so the layer loop carries one set of entry registers and no copies
 template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_load(const LMEM &L, const uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r)
+__device__ __forceinline__ void p2_load(const LMEM &L, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r, int next_ent_lds = 0)
 {
     constexpr int H = P2Regs<CNT>::H, W = P2Regs<CNT>::W;
     r.h = h;
@@ -138,6 +141,7 @@ __device__ __forceinline__ void p2_load(const LMEM &L, const uint2 (&e)[(CNT + 3
         // scheduler works on in two, and part the other reads from their zero-extension)
         raw[v] = (uint32_t)L.ld16((2 * v + 1 <= CNT) ? r.addr[v] : max(r.addr[v], 0));
     }
+    if (next_ent_lds) p2_entries<CNT>(L, next_ent_lds, h, e);
     // the old messages' bytes into the halves (nothing here depends on the reads: the compiler fills the address arithmetic's hazard
     // slots with these; explicit scheduling groups -- read after every three instructions -- measured 2 % slower)
     p16 m[H];
@@ -227,11 +231,11 @@ __device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bo
 
 // pl_phase_a. pair_rec: [2][360] chain-walk records, one array per frame
 template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, const uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1,
-                                           P2Regs<CNT> &r, uint32_t *pair_rec)
+__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1,
+                                           P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds = 0)
 {
     constexpr int H = P2Regs<CNT>::H;
-    p2_load<CNT>(L, e, j, h, a_p0, a_p1, r);
+    p2_load<CNT>(L, e, j, h, a_p0, a_p1, r, next_ent_lds);
     if (d.kind == T2_LAYER_PLAIN) {
         p2_partial<CNT>(r, 0);
         p2_set_minima(r.p0, r.p1, r.m0, r.m1f, r.dm);

@@ -235,10 +235,10 @@ __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA,
 #define T2_PAIR_SEG_MIN 12                 // chains at least this long are walked in segments (cut where a node's output ignores its input)
 #endif
 template <int CNT, int NCMAX>
-__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, const uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a0, int a1,
-                                              uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec)
+__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a0, int a1,
+                                              uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds)
 {
-    if (active) p2_phase_a<CNT>(L, d, e, j, h, a0, a1, r, pair_rec);
+    if (active) p2_phase_a<CNT>(L, d, e, j, h, a0, a1, r, pair_rec, next_ent_lds);
     if (d.kind == T2_LAYER_PAIR) {
         lds_barrier2();
         __builtin_amdgcn_s_setprio(3);
@@ -292,8 +292,8 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, co
 
 // one layer for a compile-time link count: record in, update, record out. RW = record dwords per lane in memory (>= P2Regs::W).
 // UNI (every layer of the code has CNT links): epf holds this layer's table entries on entry and the NEXT layer's on return -- their
-// LDS reads are issued ahead of this layer's LLR reads and so cost no round trip of their own (with one workgroup per CU there is
-// no neighbour to fill a wavefront's waits).
+// LDS reads are issued right behind this layer's LLR reads (p2_load) and so cost no round trip of their own (with one workgroup per
+// CU there is no neighbour to fill a wavefront's waits).
 template <int CNT, int NCMAX, bool UNI>
 __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
                                             const uint32_t *rec_in, uint32_t *__restrict__ rec_out, uint32_t *pair_rec,
@@ -303,15 +303,13 @@ __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int 
     constexpr int W = P2Regs<CNT>::W, H = P2Regs<CNT>::H;
 #pragma unroll
     for (int w = 0; w < W; ++w) r.mo[w] = rec_in[w];
-    uint2 e[H];
     if constexpr (UNI) {
-#pragma unroll
-        for (int v = 0; v < H; ++v) e[v] = epf[v];
-        if (active && next_ent_lds) p2_entries<CNT>(L, next_ent_lds, h, epf);
+        layer_update2<CNT, NCMAX>(L, d, epf, j, h, active, a0, a1, info, r, pair_rec, next_ent_lds);
     } else {
+        uint2 e[H];
         if (active) p2_entries<CNT>(L, d.ent_lds, h, e);
+        layer_update2<CNT, NCMAX>(L, d, e, j, h, active, a0, a1, info, r, pair_rec, 0);
     }
-    layer_update2<CNT, NCMAX>(L, d, e, j, h, active, a0, a1, info, r, pair_rec);
     if (active) {
         if constexpr (W <= 4) {
             uint4 o = make_uint4(r.mn[0], W > 1 ? r.mn[1] : 0u, W > 2 ? r.mn[2] : 0u, W > 3 ? r.mn[3] : 0u);
@@ -607,7 +605,11 @@ hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams 
         void *args[] = {&layers, &entries, &cninfo, &entries2, &q};
         const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(fn), dim3(grid), dim3(kThreads2), args, (unsigned)lds_bytes, stream);
         if (e == hipSuccess) return e;
-        (void)hipGetLastError();                                  // e.g. no cooperative-launch support: fall through to the plain launch
+        (void)hipGetLastError();
+        // only a device / runtime WITHOUT cooperative launches falls back to the plain launch; "too large" is exactly what the
+        // cooperative launch is there to catch (a grid that is not co-resident would hang at the first batch rendezvous), and any
+        // other failure is a failure of this call too
+        if (e != hipErrorNotSupported && e != hipErrorInvalidDeviceFunction) return e;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads2), lds_bytes, stream, p.layers, p.entries, p.cninfo, p.entries2, p);
     return hipGetLastError();

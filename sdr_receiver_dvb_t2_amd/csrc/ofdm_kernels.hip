@@ -1,6 +1,7 @@
 // ofdm_kernels.hip -- OFDM-side kernels for gfx950: batched 32K / 16K forward FFT with fftshift, and the data-symbol
 // channel estimator / equaliser fused with the frequency de-interleaver. HBM-bound streaming work; no matrix cores.
 #include "ofdm_kernels.h"
+#include "t2gpu_common.h"
 #include <algorithm>
 
 // data_symbol.cpp arithmetic is restated operation for operation (the reference is built without FMA)
@@ -186,23 +187,11 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
     const int blocks = (fft_size == 32768 || n_symbols < max_blocks) ? n_symbols : max_blocks;   // 32K: one workgroup per symbol
     if (fft_size == 32768) {
         const int lds_bytes = 32 * 1024 * 4 > 32 * 32 * 33 * 4 ? 32 * 1024 * 4 : 32 * 32 * 33 * 4;
-        static bool set = false;
-        if (!set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_fwd_shift_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e != hipSuccess) return e;
-            set = true;
-        }
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fft_fwd_shift_kernel<32>), lds_bytes)) return e;
         hipLaunchKernelGGL(fft_fwd_shift_kernel<32>, dim3(blocks), dim3(1024), lds_bytes, s, in, out, twiddle, n_symbols, lay);
     } else if (fft_size == 16384) {
         const int lds_bytes = 32 * 32 * 33 * 4;      // >= 32*512*4
-        static bool set = false;
-        if (!set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_fwd_shift_kernel<16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e != hipSuccess) return e;
-            set = true;
-        }
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fft_fwd_shift_kernel<16>), lds_bytes)) return e;
         hipLaunchKernelGGL(fft_fwd_shift_kernel<16>, dim3(blocks), dim3(512), lds_bytes, s, in, out, twiddle, n_symbols, lay);
     } else {
         return hipErrorInvalidValue;
@@ -545,12 +534,7 @@ template <int IT, int THREADS>
 static hipError_t launch_eq_split(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                                   float4 *pilot_scratch, int bytes, hipStream_t s)
 {
-    static int attr = 0;
-    if (bytes > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_split_kernel<IT, THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        attr = bytes;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(eq_split_kernel<IT, THREADS>), bytes)) return e;
     unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * p.n_splits);
     if (p.per_frame > 1) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * p.n_splits);
     hipLaunchKernelGGL((eq_split_kernel<IT, THREADS>), dim3(grid), dim3(THREADS), bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols);
@@ -635,12 +619,7 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
     const int lds_floor = 160 * 1024 / (T2_EQ_WGS_PER_CU + 1) + 1024;                     // at most T2_EQ_WGS_PER_CU workgroups per CU (see the kernel)
     lds_bytes = lds_bytes > lds_floor ? lds_bytes : lds_floor;
     if (const char *pad = getenv("T2GPU_EQ_LDS_PAD")) lds_bytes += atoi(pad);             // experiments: fewer resident workgroups per CU
-    static int attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_data_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_bytes = lds_bytes;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(eq_data_kernel), lds_bytes)) return e;
     const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
     unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                         // linear id, see the kernel
     if (p.per_frame > 1 && p.row_major) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * groups);
@@ -649,12 +628,8 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
     }
     if (sync) {
         const int sy_bytes = (p.max_seg + 1) * 16;
-        static int sy_attr = 0;
-        if (sy_bytes > 64 * 1024 && sy_bytes > sy_attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eq_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, sy_bytes);
-            if (e != hipSuccess) return e;
-            sy_attr = sy_bytes;
-        }
+        if (sy_bytes > 64 * 1024)
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(eq_sync_kernel), sy_bytes)) return e;
         hipLaunchKernelGGL(eq_sync_kernel, dim3(n_symbols), dim3(64), sy_bytes, s, p, symbol_index, pilot_scratch, sync, n_symbols);
     }
     return hipGetLastError();

@@ -1,4 +1,7 @@
 #include "t2gpu_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include "../../include/t2gpu.h"
 
 namespace t2gpu {
@@ -11,6 +14,21 @@ bool hip_ok(hipError_t e, const char *what)
     return false;
 }
 const std::string &last_error() { return g_err; }
+
+hipError_t ensure_dynamic_lds(const void *fn, int bytes)
+{
+    static std::mutex m;
+    static std::map<std::pair<int, const void *>, int> have;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(m);
+    int &cur = have[std::make_pair(dev, fn)];
+    if (bytes <= cur) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
 }  // namespace t2gpu
 
 extern "C" int t2gpu_version(void) { return 100; }

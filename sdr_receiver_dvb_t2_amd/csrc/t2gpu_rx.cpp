@@ -65,6 +65,8 @@ struct t2gpu_rx {
     std::vector<long> p2_start;
     // SIMD-batch formation across calls
     int group = T2GPU_SIMD_BATCH;
+    int row_pad = 64;                       // rows beyond max_frames * blocks in every per-FEC-frame buffer: the frames carried between calls
+                                            // (fewer than one group) sit in front of a call's own rows, a flush appends them behind
     int carry = 0;                            // LLR frames of the incomplete batch at the head of d_llr
     int last_ready = 0;                       // FEC frames the last back half (+ flush) decoded: rows of d_pack / entries of d_trials
     long fec_seq = 0;                         // running FEC-frame number of the first frame of the next decode
@@ -202,22 +204,24 @@ extern "C" t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *c, int device)
     h->ofdm = t2gpu_ofdm_create(c->fft_mode, c->carrier_mode, c->pilot_pattern, c->guard_interval_mode, c->papr_mode, c->n_data, F * h->n_sym, device);
     h->ti = t2gpu_ti_create(c->plp_mod, c->plp_fec_type, c->plp_num_blocks, device);
     h->demap = t2gpu_demap_create(c->plp_mod, c->plp_fec_type, c->plp_cod, c->plp_rotation, h->n_ti, device);
-    h->ldpc = t2gpu_ldpc_create(c->plp_fec_type, c->plp_cod, nb + 64, device);
+    const int group = c->ldpc_group > 0 ? c->ldpc_group : T2GPU_SIMD_BATCH;
+    const int pad = std::max(64, group);                         // carry < group rows (a group above 64 ran past nb + 64)
+    h->group = group;
+    h->row_pad = pad;
+    h->ldpc = t2gpu_ldpc_create(c->plp_fec_type, c->plp_cod, nb + pad, device);
     bool ok = h->front && h->p1 && h->ofdm && h->ti && h->demap && h->ldpc;
     if (ok) {
         ok = t2gpu_ldpc_configure(h->ldpc, c->ldpc_group > 0 ? c->ldpc_group : T2GPU_SIMD_BATCH, c->ldpc_trials > 0 ? c->ldpc_trials : 25) == 0 &&
              t2gpu_demap_configure(h->demap, c->saturate_llr) == 0 && t2gpu_ldpc_info(h->ldpc, nullptr, &h->k_ldpc, nullptr, &h->k_bch) == 0 &&
              t2gpu_ti_begin(h->ti, c->plp_num_blocks) == 0;
     }
-    const int group = c->ldpc_group > 0 ? c->ldpc_group : T2GPU_SIMD_BATCH;
-    h->group = group;
-    ok = ok && dev_alloc(h->d_pack, (size_t)(nb + 64) * (h->k_bch / 8)) && dev_alloc(h->d_l1, 2 * (size_t)F * std::max(h->p2_skip, 1));
+    ok = ok && dev_alloc(h->d_pack, (size_t)(nb + pad) * (h->k_bch / 8)) && dev_alloc(h->d_l1, 2 * (size_t)F * std::max(h->p2_skip, 1));
     ok = ok && dev_alloc(h->d_stream, 2 * (size_t)(n_max + 64)) && dev_alloc(h->d_spec, 2 * (size_t)F * h->n_sym * h->fft_size) &&
          dev_alloc(h->d_p2_in, 2 * (size_t)F * h->fft_size) && dev_alloc(h->d_p2_cells, 2 * (size_t)F * h->c_p2) &&
          dev_alloc(h->d_fc_cells, 2 * (size_t)F * std::max(h->n_fc, 1)) && dev_alloc(h->d_cells, 2 * (size_t)F * h->frame_cells) &&
          dev_alloc(h->d_ti_out, 2 * (size_t)F * h->n_ti) && dev_alloc(h->d_sums, (size_t)F * 4) && dev_alloc(h->d_cp, (size_t)F * h->n_sym * 4) &&
-         dev_alloc(h->d_llr, (size_t)(nb + 64) * h->fec_size) && dev_alloc(h->d_bits, (size_t)(nb + 64) * h->k_ldpc) &&
-         dev_alloc(h->d_out, (size_t)(nb + 64) * h->k_bch) && dev_alloc(h->d_trials, (size_t)(nb + 64) / group + 2) &&
+         dev_alloc(h->d_llr, (size_t)(nb + pad) * h->fec_size) && dev_alloc(h->d_bits, (size_t)(nb + pad) * h->k_ldpc) &&
+         dev_alloc(h->d_out, (size_t)(nb + pad) * h->k_bch) && dev_alloc(h->d_trials, (size_t)(nb + pad) / group + 2) &&
          hipMemset(h->d_stream, 0, 2 * (size_t)(n_max + 64) * 4) == hipSuccess && hipMemset(h->d_cells, 0, 2 * (size_t)F * h->frame_cells * 4) == hipSuccess &&
          hipMemset(h->d_ti_out, 0, 2 * (size_t)F * h->n_ti * 4) == hipSuccess && hipMemset(h->d_sums, 0, (size_t)F * 16) == hipSuccess &&
          hipEventCreate(&h->ev_ldpc0) == hipSuccess && hipEventCreate(&h->ev_ldpc1) == hipSuccess &&
@@ -427,6 +431,8 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
         std::unique_lock<std::mutex> lk(h->ts->m);
         h->ts->cv_done.wait(lk, [&] { return h->ts->in_flight == 0; });
         h->ts->l1_status.clear();
+        // a new stream: no half packet of the old one may lead its first BBFRAME; TS bytes already de-framed stay readable
+        t2gpu_bbdh_reset(h->ts->bbdh);
     }
     h->carry = 0; h->last_ready = 0; h->fec_seq = 0; h->t2_seq = 0;
     return 0;
@@ -604,7 +610,7 @@ extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
     TsEnd *t = new TsEnd();
     t->rx = h; t->need_plp = need_plp; t->l1_check = l1_check;
     t->bbdh = t2gpu_bbdh_create(need_plp);
-    const size_t frames = (size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + 64;
+    const size_t frames = (size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + h->row_pad;
     bool ok = t->bbdh != nullptr;
     for (TsSlot &sl : t->slot) {
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&sl.pack), frames * (h->k_bch / 8), hipHostMallocDefault) == hipSuccess &&
@@ -718,7 +724,7 @@ extern "C" int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable)
 {
     if (!h) { set_error("t2gpu_rx_set_outer_code: null handle"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    if (enable && !h->d_outer) T2_HIP(hipMalloc(&h->d_outer, ((size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + 64) * sizeof(int32_t)));
+    if (enable && !h->d_outer) T2_HIP(hipMalloc(&h->d_outer, ((size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + h->row_pad) * sizeof(int32_t)));
     h->outer_code = enable != 0;
     return 0;
 }

@@ -47,6 +47,27 @@ def test_hem_round_trip(l, cid, packed):
     l.t2gpu_bbdh_destroy(h)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_reset_starts_a_new_stream(l, packed):
+    """t2gpu_bbdh_reset = the packet state of a freshly constructed bb_de_header: after frames of one stream (a packet is left split
+    across the frame end), the first frame of ANOTHER stream gives exactly what a new handle gives -- no stale half packet."""
+    k_bch = t2_tx.K_BCH[9]
+    a, _ = t2_tx.bbframes_hem(t2_tx.ts_packets(120, 11), k_bch, 3)
+    b, _ = t2_tx.bbframes_hem(t2_tx.ts_packets(120, 12), k_bch, 2)
+    h, fresh = l.t2gpu_bbdh_create(0), l.t2gpu_bbdh_create(0)
+    for f in range(3):
+        assert run(l, h, np.ascontiguousarray(a[f]), packed=packed)[0] > 0
+    stale = run(l, h, np.ascontiguousarray(b[0]), packed=packed)[1]          # without a reset: the old stream's tail leads
+    assert l.t2gpu_bbdh_reset(h) == 0
+    for f in range(2):
+        n0, want, _ = run(l, fresh, np.ascontiguousarray(b[f]), packed=packed)
+        n1, got, _ = run(l, h, np.ascontiguousarray(b[f]), packed=packed)
+        assert n0 == n1 and np.array_equal(got, want)
+        if f == 0:
+            assert not np.array_equal(got, stale)
+    l.t2gpu_bbdh_destroy(h); l.t2gpu_bbdh_destroy(fresh)
+
+
 def test_drop_rules(l):
     k_bch = t2_tx.K_BCH[9]
     frames, _ = t2_tx.bbframes_hem(t2_tx.ts_packets(80, 1), k_bch, 2)

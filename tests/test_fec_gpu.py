@@ -169,6 +169,43 @@ def test_demapper_statistics_of_several_ti_blocks_in_one_launch(torch_cuda, mod,
     assert torch.equal(one, many) and float(one[:, 2].min()) > 0
 
 
+def test_statistics_with_dead_cells_follow_the_float_loop(torch_cuda):
+    """Cells that are NaN or +-inf (an equaliser symbol with amplitude 0: 0 * inf) in a 202-block TI block: the reference's loop adds
+    their norms like any others -- sum_e is NaN from the first NaN cell on, inf after an inf cell, sum_s stays finite (the slicer maps a
+    NaN to a constellation point). The device takes such terms out of its event walk (they would be tens of thousands of serial steps)
+    and writes what the float loop gives; a block without them next to it in the same launch is untouched. Finishes in milliseconds."""
+    torch = torch_cuda
+    import time
+    import sdr_receiver_dvb_t2_amd as pkg
+    mod, fec_type, blocks = 3, 1, 202
+    n = blocks * (64800 // 8)
+    dm = pkg.llr_demapper(mod, fec_type, 1, 1, max_cells=n)
+    base = qam_cells(mod, n, 20.0, seed=99, rotation=1)
+    variants = []
+    v = base.copy(); v[700000:727404] = np.complex64(complex(np.nan, np.nan)); variants.append(v)          # one dead 32K symbol
+    v = base.copy(); v[5] = np.complex64(complex(np.inf, 0.0)); variants.append(v)                            # an inf inside the head
+    v = base.copy(); v[1200000] = np.complex64(complex(np.inf, 1.0)); v[1300000] = np.complex64(complex(np.nan, 0.0)); variants.append(v)
+    variants.append(base.copy())
+    x = torch.from_numpy(np.stack(variants).view(np.float32).reshape(len(variants), n, 2)).cuda()
+    got = torch.zeros((len(variants), 4), dtype=torch.float32, device="cuda")
+    dm.stats_batch_dev(x, got)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dm.stats_batch_dev(x, got)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.2, "non-finite cells must not turn into a serial walk"
+    g = got.cpu().numpy()
+    for f, c in enumerate(variants):
+        with np.errstate(all="ignore"):
+            _, wsums, _ = ol.ora_demap(mod, fec_type, 1, 1, c)
+        for k in (0, 1):
+            if np.isfinite(wsums[k]):
+                assert g[f, k].view(np.uint32) == wsums[k].view(np.uint32), (f, k, g[f], wsums)
+            else:
+                assert np.isnan(g[f, k]) == np.isnan(wsums[k]) and np.isinf(g[f, k]) == np.isinf(wsums[k]), (f, k, g[f], wsums)
+    dm.close()
+
+
 @pytest.mark.parametrize("mod,fec_type,blocks,rotation", [(3, 1, 202, 1), (3, 0, 9, 1), (2, 1, 5, 0), (1, 1, 4, 1), (0, 0, 3, 1), (1, 0, 1, 1)])
 def test_statistics_are_the_references_sequential_float_sums(torch_cuda, mod, fec_type, blocks, rotation):
     """sum_s / sum_e of whole TI blocks (up to 202 FEC blocks = 1.6 M cells: the sum passes through ~25 binades) against the oracle's
