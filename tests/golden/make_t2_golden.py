@@ -132,6 +132,15 @@ def case_fec(name):
     out["bb_count"] = np.int32(len(bb))
     out["ts"] = ts_out
     out["messages"] = np.array([bytes(b).decode() for _, b in msg])
+    # the same cells through the STRICT build of the reference (oracle/Makefile: -O2 -ffp-contract=off, every float operation in the
+    # order the reference writes it): the LLR rows the GPU tier holds the device to with no tolerance at all
+    if ol.RefFec.available(strict=True):
+        rs = ol.RefFec(os.path.join(tmp, "ref_strict.ts"), 0, strict=True)
+        rs.start(rc.FEC_L1_POST_SIZE, l1)
+        rs.frame(l1, np.concatenate([np.zeros(1840 + rc.FEC_L1_POST_SIZE, np.complex64), cells]))
+        Ls = np.concatenate([x[1] for x in rs.taps(1)]).reshape(-1, n)
+        rs.ts()
+        out.update(llr_crc_strict=rc.crc_rows(Ls), llr_first_strict=Ls[0].copy(), llr_last_strict=Ls[-1].copy())
     return out
 
 
