@@ -251,6 +251,14 @@ int t2gpu_bbdh_execute(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bit
  * (`temp |= *in++ << n`, n = 7..0) already done on the device by t2gpu_bch_descramble_pack_dev / t2gpu_rx. Same results, same
  * state: calls of the two forms may be mixed on one handle. */
 int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, const uint8_t *bytes, uint8_t *out, int out_cap, int *ts_errors);
+/* Many packed BBFRAMEs in stream order through the one de-framer: bb_de_header::execute (bb_de_header.cpp:84-448) called row after row
+ * as bch_decoder emits them (bch_decoder.cpp:140-160), with the LDPC stage's drop rule in front (ldpc_decoder.cpp:264-268: trials[i /
+ * group] < 0 -> the rows of that SIMD batch are never emitted; trials may be NULL). rows + i * row_stride = row i (k_bch / 8 bytes);
+ * TS bytes are appended to out (out_cap >= the bytes the rows carry + k_bch / 8 + 376). counts (6 longs, may be NULL): rows de-framed,
+ * rows dropped by the LDPC rule, BBHEADER CRC errors, frames skipped, TS packets flagged, resynchronisations. Returns TS bytes or -3.
+ * The rank-0 end of the frame-sharded receiver (sdr_receiver_dvb_t2_amd/shard.py) is this one call per gathered share. */
+long t2gpu_bbdh_execute_packed_rows(t2gpu_bbdh *h, int plp_id, int k_bch, const uint8_t *rows, long n_rows, long row_stride,
+                                    const int32_t *trials, int group, uint8_t *out, long out_cap, long *counts);
 int t2gpu_bbdh_mode(const t2gpu_bbdh *h);
 int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h);
 /* The packet state of a freshly constructed bb_de_header (bb_de_header.cpp:29-54: no split packet pending, idx_packet = 0, crc = 0):

@@ -109,6 +109,8 @@ PROTOTYPES = {
     "t2gpu_bbdh_mode": (ctypes.c_int, [_vp]),
     "t2gpu_bbdh_resync_count": (ctypes.c_int, [_vp]),
     "t2gpu_bbdh_reset": (ctypes.c_int, [_vp]),
+    "t2gpu_bbdh_execute_packed_rows": (ctypes.c_long, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_long, _vp, ctypes.c_int, _vp,
+                                                        ctypes.c_long, _vp]),
     "t2gpu_ofdm_create": (_vp, [ctypes.c_int] * 8),
     "t2gpu_ofdm_destroy": (None, [_vp]),
     "t2gpu_fft_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),

@@ -291,6 +291,36 @@ extern "C" int t2gpu_bbdh_execute_packed(t2gpu_bbdh *h, int plp_id, int len_in, 
     return bbdh_run(h, plp_id, len_in, bytes, true, out, out_cap, ts_errors);
 }
 
+// A whole run of packed BBFRAMEs in stream order through the ONE de-framer (the rank-0 end of a frame-sharded receiver, and any
+// caller that has many rows at hand): rows[i] = k_bch bits in k_bch / 8 bytes at rows + i * row_stride; trials (may be null) holds the
+// LDPC verdict of every SIMD batch of `group` rows -- the rows of a batch the decoder gave up on never reach bb_de_header in the
+// reference (ldpc_decoder.cpp:264-268) and are skipped here. TS bytes are appended to out; counts (may be null) receives
+// {rows de-framed, rows dropped by the LDPC rule, BBHEADER CRC errors, frames skipped (other PLP / SYNCD 65535), TS packet errors,
+// resynchronisations}. Returns the number of TS bytes, or -3 (bad arguments / out_cap too small for what the rows carry).
+extern "C" long t2gpu_bbdh_execute_packed_rows(t2gpu_bbdh *h, int plp_id, int k_bch, const uint8_t *rows, long n_rows, long row_stride,
+                                               const int32_t *trials, int group, uint8_t *out, long out_cap, long *counts)
+{
+    if (!h || !rows || !out || n_rows < 0 || k_bch < BBH_BITS || row_stride < (k_bch + 7) / 8 || (trials && group < 1)) {
+        set_error("t2gpu_bbdh_execute_packed_rows: bad arguments");
+        return -3;
+    }
+    const long per = k_bch / 8 + 2 * TS_LEN;                   // the most one frame can emit, and bbdh_run's own out_cap contract
+    long used = 0, c[6] = {0, 0, 0, 0, 0, 0};
+    for (long i = 0; i < n_rows; ++i) {
+        if (trials && trials[i / group] < 0) { ++c[1]; continue; }
+        if (out_cap - used < per) { set_error("t2gpu_bbdh_execute_packed_rows: out_cap too small"); return -3; }
+        int err = 0;
+        const int n = bbdh_run(h, plp_id, k_bch, rows + i * row_stride, true, out + used, (int)per, &err);
+        ++c[0];
+        c[5] += h->resync;
+        if (n > 0) { used += n; c[4] += err; }
+        else if (n == -1) ++c[2];
+        else if (n == -2 || n == -3) ++c[3];            // -3 here: a frame whose SYNCD / DFL would overrun its share of out -- refused, state reset
+    }
+    if (counts) for (int k = 0; k < 6; ++k) counts[k] = c[k];
+    return used;
+}
+
 extern "C" int t2gpu_bbdh_resync_count(const t2gpu_bbdh *h) { return h ? h->resync : 0; }
 extern "C" int t2gpu_bbdh_reset(t2gpu_bbdh *h)
 {

@@ -51,6 +51,7 @@ class ordered_receiver(object):
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._bbdh = None
+        self._out = None
 
     def close(self):
         if self._bbdh is not None:
@@ -59,37 +60,77 @@ class ordered_receiver(object):
             self._bbdh = None
 
     def execute(self, total_frames):
-        """Decode `total_frames` T2 frames (this rank its share); returns the TS bytes on rank 0, None elsewhere."""
+        """Decode `total_frames` T2 frames (this rank its share); returns the TS bytes on rank 0, None elsewhere. The shares travel as
+        two tensors per rank (packed rows, batch verdicts; `dist.gather`, fixed shapes every rank derives from the shard table, the
+        short shares padded) and rank 0 de-frames each share with ONE call into the library (t2gpu_bbdh_execute_packed_rows: the
+        LDPC drop rule and bb_de_header row after row in C). last_counts / last_merge_seconds: what that loop did and how long it took."""
+        import time
         import numpy as np
         align = frame_alignment(self.per_frame, self.group)
-        lo, hi = shard_frames(total_frames, self.world, self.rank, align)
+        shares = [shard_frames(total_frames, self.world, r, align) for r in range(self.world)]
+        lo, hi = shares[self.rank]
+        k_bch = self.packed_k_bch
         if hi > lo:
             bits, trials = self.decode(lo, hi)
             bits = np.ascontiguousarray(bits, np.uint8)
-            if self.packed_k_bch:
-                mine = (bits, self.packed_k_bch, np.ascontiguousarray(trials, np.int32))
+            trials = np.ascontiguousarray(trials, np.int32)
+            if k_bch:
+                rows = bits
             else:
-                mine = (np.packbits(bits, axis=1), bits.shape[1], np.ascontiguousarray(trials, np.int32))
+                k_bch = bits.shape[1]
+                rows = np.packbits(bits, axis=1)
         else:
-            mine = (np.zeros((0, 0), np.uint8), 0, np.zeros(0, np.int32))
+            rows, trials = np.zeros((0, 0), np.uint8), np.zeros(0, np.int32)
+        n_rows = [(b - a) * self.per_frame for a, b in shares]
         if self.world > 1:
-            parts = [None] * self.world if self.rank == 0 else None
-            self.dist.gather_object(mine, parts, dst=0)              # rank order = frame order; small (k_bch / 8 bytes per FEC frame)
+            import torch
+            # every rank needs the row width to shape its tensors: the ranks that decoded something know it
+            kb = torch.tensor([k_bch or 0], dtype=torch.int64)
+            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+            kb = kb.to(dev)
+            self.dist.all_reduce(kb, op=self.dist.ReduceOp.MAX)
+            k_bch = int(kb.item())
+            row_bytes = (k_bch + 7) // 8
+            max_rows = max(n_rows)
+            max_batches = (max_rows + self.group - 1) // self.group
+            t_rows = torch.zeros((max_rows, row_bytes), dtype=torch.uint8)
+            t_tr = torch.zeros(max_batches, dtype=torch.int32)
+            if rows.shape[0]:
+                t_rows[:rows.shape[0]] = torch.from_numpy(rows)
+                t_tr[:trials.shape[0]] = torch.from_numpy(trials)
+            t_rows, t_tr = t_rows.to(dev), t_tr.to(dev)
+            g_rows = [torch.empty_like(t_rows) for _ in range(self.world)] if self.rank == 0 else None
+            g_tr = [torch.empty_like(t_tr) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(t_rows, g_rows, dst=0)                  # rank order = frame order; k_bch / 8 bytes per FEC frame
+            self.dist.gather(t_tr, g_tr, dst=0)
+            if self.rank != 0:
+                return None
+            parts = [(g_rows[r].cpu().numpy()[:n_rows[r]], g_tr[r].cpu().numpy()) for r in range(self.world)]
         else:
-            parts = [mine]
-        if self.rank != 0:
-            return None
+            parts = [(rows, trials)]
         from ._lib import lib
         l = lib()
         if self._bbdh is None:
             self._bbdh = l.t2gpu_bbdh_create(self.need_plp)          # ONE de-framer for the whole stream: its packet state crosses ranks
-        out = []
-        for packed, k_bch, trials in parts:
-            buf = np.zeros(k_bch // 8 + 400, np.uint8)
-            for i in range(packed.shape[0]):
-                if trials[i // self.group] < 0:                      # batch dropped by the LDPC stage (ldpc_decoder.cpp:264-268)
-                    continue
-                n = l.t2gpu_bbdh_execute_packed(self._bbdh, self.need_plp, k_bch, packed[i].ctypes.data, buf.ctypes.data, buf.size, None)
-                if n > 0:
-                    out.append(buf[:n].copy())
-        return np.concatenate(out) if out else np.zeros(0, np.uint8)
+        total_rows = sum(p[0].shape[0] for p in parts)
+        need = total_rows * ((k_bch or 0) // 8) + (k_bch or 0) // 8 + 376 * (total_rows + 1)
+        if self._out is None or self._out.size < need:               # the TS buffer lives across calls; its pages are touched here, once,
+            self._out = np.empty(need, np.uint8)                     # not inside the de-framing loop (first touch costs more than the copy)
+            self._out.fill(0)
+        out = self._out
+        counts, acc = np.zeros(6, np.int64), np.zeros(6, np.int64)
+        used = 0
+        t0 = time.perf_counter()
+        for prow, ptr in parts:
+            if prow.shape[0] == 0:
+                continue
+            prow, ptr = np.ascontiguousarray(prow), np.ascontiguousarray(ptr, np.int32)
+            n = l.t2gpu_bbdh_execute_packed_rows(self._bbdh, self.need_plp, k_bch, prow.ctypes.data, prow.shape[0], prow.strides[0],
+                                                 ptr.ctypes.data, self.group, out[used:].ctypes.data, out.size - used, counts.ctypes.data)
+            if n < 0:
+                raise RuntimeError("t2gpu_bbdh_execute_packed_rows: %s" % l.t2gpu_last_error().decode())
+            used += n
+            acc += counts
+        self.last_merge_seconds = time.perf_counter() - t0
+        self.last_counts = dict(zip(("rows", "dropped_ldpc", "bbheader_crc_errors", "skipped", "ts_packet_errors", "resync"), (int(v) for v in acc)))
+        return out[:used].copy()
