@@ -236,6 +236,47 @@ def cpu_chain_baseline(cfg_id, w, i16, q16, full):
                          else ", up to the LLRs")}
 
 
+DROP_IN_EXE = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "bin", "t2gpu_rx_file")
+DROP_IN_BUF = 172032          # samples per execute() call: norm_blocks x 384 of the reference's SDRplay thread (rx_sdrplay.h:64, rx_sdrplay.cpp:199-261)
+
+
+def drop_in_leg(w, ui, uq, device, frames=14, warm_frames=4):
+    """The slot-shaped path: int16 I/Q in device-buffer-sized calls through t2::dvbt2_demodulator::execute (t2gpu_demod_execute: closed
+    tracking loops, the reference's own acquisition from P1 / guard search / L1-pre / L1-post) and the stage classes of
+    include/t2gpu_stages.hpp wired as the reference wires its objects (time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder ->
+    bb_de_header), in a plain C++ process (examples/t2gpu_rx_file.cpp, built by csrc/Makefile). The first warm_frames frames'
+    worth of buffers (acquisition) run before the program's clock starts."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    if not os.path.exists(DROP_IN_EXE):
+        return {"error": "sdr_receiver_dvb_t2_amd/bin/t2gpu_rx_file not built"}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        reps = (frames + ui.shape[0] - 1) // ui.shape[0]
+        np.concatenate([ui] * reps)[:frames].reshape(-1).tofile(os.path.join(d, "i.s16"))
+        np.concatenate([uq] * reps)[:frames].reshape(-1).tofile(os.path.join(d, "q.s16"))
+        warm = (warm_frames * w.frame_samples + DROP_IN_BUF - 1) // DROP_IN_BUF
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+        t0 = time.perf_counter()
+        p = subprocess.run([DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", "/dev/null", "--buf", str(DROP_IN_BUF),
+                            "--warm", str(warm), "--json", "1", "--device", str(device)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+        wall = time.perf_counter() - t0
+    if p.returncode != 0:
+        return {"error": p.stderr[-400:]}
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    dropped = p.stderr.count("LDPC decoder could not recover the codeword!")
+    return {"value": round(r["msamples_per_s"], 1), "unit": "Msamples/s", "real_time_factor": round(r["msamples_per_s"] / (64.0 / 7.0), 1),
+            "samples_per_call": DROP_IN_BUF, "calls_timed": r["buffers"], "t2_frames_timed": r["t2_frames"], "seconds": round(r["seconds"], 4),
+            "bbframes": r["bbframes"], "ts_bytes": r["ts_bytes"], "simd_batches_dropped_by_ldpc": dropped, "resets": r["resets"],
+            "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2),
+            "entry": "t2::dvbt2_demodulator::execute(len, i, q, signal) per buffer = t2gpu_demod_execute, host buffers between all stage "
+                     "classes as the reference's slots carry them; loops closed, nothing configured (mode from P1 / L1)",
+            "workload": "%s, %d frames of int16 I/Q at %.0f dB, the first %d frames' buffers untimed (acquisition)"
+                        % (w.cfg["name"], frames, w.cfg["snr"], warm_frames)}
+
+
 def packet_hashes(packets):
     """64-bit mixing hash of every 188-byte row (to count transport-stream packets that are among those sent)."""
     import numpy as np
@@ -476,6 +517,8 @@ def main():
             for r in sweep:
                 r["of_full_batch_rate"] = round(r["msamples_per_s"] / top, 3)
             extra["frames_sweep"] = sweep
+            # (iv) the same input through the reference's own call shape (slot by slot, device-buffer-sized calls, loops closed)
+            extra["drop_in"] = drop_in_leg(w, ui, uq, local_rank)
 
         if rank != 0:
             return None

@@ -10,7 +10,10 @@
 //           reference's constructors wire them (include/t2gpu_stages.hpp), every stage a call into libt2gpu.so.
 //
 // build:  g++ -O2 -std=c++17 -I../include t2gpu_rx_file.cpp -L../sdr_receiver_dvb_t2_amd -lt2gpu -Wl,-rpath,$PWD/../sdr_receiver_dvb_t2_amd -o t2gpu_rx_file
-// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 262144] [--device 0]
+// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1]
+//         --buf: samples per execute() call (the reference's SDRplay thread hands over norm_blocks x 384 = 172 032, rx_sdrplay.h:64)
+//         --warm n: the first n buffers (acquisition: P1, guard search, L1) run before the clock starts; --json 1: one JSON line on
+//         stdout with the throughput of the timed buffers (bench.py's drop_in leg reads it)
 #include <arpa/inet.h>
 #include <chrono>
 #include <cstdio>
@@ -41,13 +44,15 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *out_path = nullptr;
-    int udp_port = 0, need_plp = 0, buf_len = 1 << 18, device = 0;
+    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0;
     for (int a = 3; a + 1 < argc; a += 2) {
         if (!std::strcmp(argv[a], "--out")) out_path = argv[a + 1];
         else if (!std::strcmp(argv[a], "--udp")) udp_port = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--plp")) need_plp = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--buf")) buf_len = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--device")) device = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--warm")) warm = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--json")) json = std::atoi(argv[a + 1]);
     }
     if ((!out_path && !udp_port) || buf_len < 4096) return 2;
     const std::vector<int16_t> vi = slurp(argv[1]), vq = slurp(argv[2]);
@@ -109,9 +114,16 @@ int main(int argc, char **argv)
             set_gain();
         };
         reset();
-        const auto t0 = std::chrono::steady_clock::now();
-        size_t pos = 0;
-        for (; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len) {
+        auto t0 = std::chrono::steady_clock::now();
+        size_t pos = 0, timed_from = 0;
+        long frames0 = 0, bb0 = 0, ts0 = 0, n_buf = 0;
+        for (; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len, ++n_buf) {
+            if (n_buf == warm) {                                          // acquisition is behind us: the clock starts here
+                ldpc.flush();
+                const t2gpu_demod_info w = demodulator.status();
+                frames0 = (long)w.frames; bb0 = bbframes; ts0 = ts_bytes; timed_from = pos;
+                t0 = std::chrono::steady_clock::now();
+            }
             frequency_changed = true;                                     // what rf_changed / gr_changed report with the next packets (:216-223)
             gain_changed = true;
             if (signal.reset) { reset(); continue; }                      // :229-235
@@ -119,8 +131,14 @@ int main(int argc, char **argv)
             set_gain();
             demodulator.execute(buf_len, const_cast<int16_t *>(vi.data()) + pos, const_cast<int16_t *>(vq.data()) + pos, &signal);
         }
+        ldpc.flush();                                                     // batches still in the decoder come out (and through BCH / de-framer) inside the clock
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const t2gpu_demod_info st = demodulator.status();
+        if (json)
+            std::printf("{\"samples\": %zu, \"seconds\": %.6f, \"msamples_per_s\": %.3f, \"buffers\": %ld, \"buf_len\": %d, \"t2_frames\": %ld, "
+                        "\"bbframes\": %ld, \"ts_bytes\": %ld, \"symbols\": %ld, \"resets\": %ld, \"deint_start\": %d}\n",
+                        pos - timed_from, secs, (pos - timed_from) / secs / 1e6, n_buf - warm, buf_len, (long)st.frames - frames0, bbframes - bb0,
+                        ts_bytes - ts0, (long)st.symbols, (long)st.resets, (int)st.deint_start);
         std::fprintf(stderr, "%zu samples in %.3f s (%.1f Msamples/s, real time 9.14), %ld symbols, %ld T2 frames, %ld BBFRAMEs, %ld TS bytes\n",
                      pos, secs, pos / secs / 1e6, (long)st.symbols, (long)st.frames, bbframes, ts_bytes);
     } catch (const std::exception &e) {

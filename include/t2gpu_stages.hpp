@@ -72,6 +72,8 @@ public:
         swap_buffer = !swap_buffer;
         if (bit_bch) bit_bch(idx_plp_simd, l1_post, k_ldpc * SIZEOF_SIMD, out.data());
     }
+    // batches still inside the stage are emitted (none: execute() is synchronous in this form)
+    void flush() {}
 private:
     int device_;
     t2gpu_ldpc *gpu_[2][6] = {};
