@@ -68,6 +68,15 @@ int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6);
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);
+/* The same slot split in two, for callers that keep the reference's call shape (one SIMD batch per ldpc_decoder::execute,
+ * ldpc_decoder.h:90) and still want the device busy: t2gpu_ldpc_submit copies `in` to the handle's pinned staging, enqueues copy-in,
+ * decode and copy-out on the handle's own stream and returns (the caller's buffer is free again); t2gpu_ldpc_collect waits for the
+ * result (wait != 0) or polls it (wait == 0: returns 1 when the decode is still running) and hands out pointers into the staging --
+ * the information bits, one per byte, and the per-batch verdicts -- valid until the next submit on this handle. One submit may be
+ * pending per handle; several handles in flight run their batches side by side (t2::ldpc_decoder keeps a ring of them and emits
+ * bit_bch in submission order, include/t2gpu_stages.hpp). */
+int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in);
+int t2gpu_ldpc_collect(t2gpu_ldpc *h, int wait, const uint8_t **out, const int **trials_left, int *n_frames);
 /* diagnostics: the first call arms per-phase cycle counters inside the kernel (off by default); later calls return the
  * sums over all workgroups of the last launch: [0] parity check, [1] batch rendezvous, [2] PLAIN, [3] PAIR, [4] GENERIC
  * layers (shader clock cycles of wave 0). out8 may be NULL. */

@@ -46,8 +46,18 @@ inline void fail(const char *what) { throw std::runtime_error(std::string(what) 
 // ---------------------------------------------------------------------------------------------------------------- LDPC
 class ldpc_decoder {
 public:
-    explicit ldpc_decoder(int device = 0) : device_(device) {}
-    ~ldpc_decoder() { for (auto &row : gpu_) for (auto *h : row) if (h) t2gpu_ldpc_destroy(h); }
+    // in_flight: SIMD batches the stage keeps on the device at once. The reference's stage runs on a thread of its own and its slot is
+    // fed through a queued connection (dvbt2_demodulator.cpp:84-95, main_window wiring): the caller does not wait for the decode. Here
+    // execute() submits the batch (t2gpu_ldpc_submit: copy-in, decode and copy-out on a stream of the handle's own) and returns;
+    // bit_bch is emitted in submission order as results arrive -- on later execute() calls and in flush(). One batch occupies 16 of the
+    // device's 256 CUs, so a caller with the reference's call shape needs several in flight to use the device. in_flight = 1 is the
+    // synchronous form of rounds 2-3.
+    explicit ldpc_decoder(int device = 0, int in_flight = 8) : device_(device), depth_(in_flight < 1 ? 1 : in_flight) {}
+    ~ldpc_decoder()
+    {
+        try { flush(); } catch (...) {}
+        for (auto &ring : gpu_) for (auto &code : ring) for (slot &s : code) if (s.h) t2gpu_ldpc_destroy(s.h);
+    }
     // signals (ldpc_decoder.h:83-87)
     std::function<void(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_out, uint8_t *out)> bit_bch;
     // slot (ldpc_decoder.h:90, ldpc_decoder.cpp:157-301): 32 frames of int8 LLRs in, information bits (one per byte) out through
@@ -57,28 +67,61 @@ public:
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
         if (p.plp_cod < 0 || p.plp_cod > 5 || p.plp_fec_type < 0 || p.plp_fec_type > 1)    // T2-Lite codes 6, 7: not in the reference's switch (:173-246)
             fail("ldpc_decoder: PLP_COD / PLP_FEC_TYPE outside the reference's twelve codes");
-        t2gpu_ldpc *&h = gpu_[p.plp_fec_type][p.plp_cod];
-        if (!h && !(h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
+        std::vector<slot> &ring = gpu_[p.plp_fec_type][p.plp_cod];
+        if (ring.empty()) ring.resize((size_t)depth_);
+        // a free handle of this code's ring; when all are busy, the oldest batch in flight is awaited and emitted first
+        slot *s = nullptr;
+        for (;;) {
+            for (slot &c : ring) if (!c.busy) { s = &c; break; }
+            if (s) break;
+            emit_front(true);
+        }
+        if (!s->h && !(s->h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
+        t2gpu_ldpc_info(s->h, nullptr, &s->k_ldpc, nullptr, nullptr);
+        if (t2gpu_ldpc_submit(s->h, in, len_in) != 0) fail("t2gpu_ldpc_submit");
+        s->busy = true;
+        std::copy(idx_plp_simd, idx_plp_simd + SIZEOF_SIMD, s->idx);
+        s->l1 = l1_post;
+        fifo_.push_back(s);
+        if (depth_ == 1) { emit_front(true); return; }
+        while (!fifo_.empty() && emit_front(false)) {}
+    }
+    // everything still inside the stage comes out (end of stream; a caller that needs the synchronous behaviour calls it after execute)
+    void flush() { while (!fifo_.empty()) emit_front(true); }
+    int in_flight() const { return (int)fifo_.size(); }
+private:
+    struct slot {
+        t2gpu_ldpc *h = nullptr;
+        bool busy = false;
         int k_ldpc = 0;
-        t2gpu_ldpc_info(h, nullptr, &k_ldpc, nullptr, nullptr);
-        std::vector<uint8_t> &out = swap_buffer ? buffer_a : buffer_b;
-        out.resize((size_t)k_ldpc * SIZEOF_SIMD);
-        int trials_left = -1;
-        if (t2gpu_ldpc_execute(h, in, len_in, out.data(), &trials_left) != 0) fail("t2gpu_ldpc_execute");
+        int idx[SIZEOF_SIMD] = {};
+        l1_postsignalling l1;
+    };
+    // the oldest batch in flight: waits for it (or polls); emits bit_bch or the reference's message. false: still decoding.
+    bool emit_front(bool wait)
+    {
+        if (fifo_.empty()) return false;
+        slot *s = fifo_.front();
+        const uint8_t *out = nullptr;
+        const int *trials = nullptr;
+        const int rc = t2gpu_ldpc_collect(s->h, wait ? 1 : 0, &out, &trials, nullptr);
+        if (rc == 1) return false;
+        if (rc != 0) fail("t2gpu_ldpc_collect");
+        fifo_.erase(fifo_.begin());
+        const int trials_left = trials[0];
         if (trials_left < 0) {
             std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials_left);
-            return;
+            s->busy = false;
+            return true;
         }
-        swap_buffer = !swap_buffer;
-        if (bit_bch) bit_bch(idx_plp_simd, l1_post, k_ldpc * SIZEOF_SIMD, out.data());
+        // the result stays in the handle's staging until the handle is submitted to again: it is marked free AFTER the consumer returned
+        if (bit_bch) bit_bch(s->idx, s->l1, s->k_ldpc * SIZEOF_SIMD, const_cast<uint8_t *>(out));
+        s->busy = false;
+        return true;
     }
-    // batches still inside the stage are emitted (none: execute() is synchronous in this form)
-    void flush() {}
-private:
-    int device_;
-    t2gpu_ldpc *gpu_[2][6] = {};
-    std::vector<uint8_t> buffer_a, buffer_b;
-    bool swap_buffer = true;
+    int device_, depth_;
+    std::vector<slot> gpu_[2][6];
+    std::vector<slot *> fifo_;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- BCH stub

@@ -10,7 +10,10 @@
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -23,7 +26,21 @@ constexpr int MAX_PLP = 32;
 constexpr float SAMPLE_RATE_HZ = 1.0f / (1.0e-6f * 7.0f / 64.0f);                  // SAMPLE_RATE, dvbt2_definition.h:36-38
 }
 
+// T2GPU_DEMOD_PROF=1: host wall time of execute() by part, printed when the handle is destroyed (where a closed-loop call spends its time)
+enum { PF_COPY_IN = 0, PF_FRONT, PF_P1, PF_BUFFER, PF_CP, PF_FFT_EQ, PF_SV, PF_CELLS, PF_SIGNAL, PF_L1, PF_TAIL, PF_N };
+static const char *const PF_NAME[PF_N] = {"copy in (H2D)", "front end (plan + launches)", "P1", "symbol buffer (D2D)", "guard corr + sync", "FFT + equaliser launch",
+                                          "sync floats (D2H)", "cells (D2H)", "signals (data / l1_dyn -> de-interleaver ...)", "L1 parse", "commit iq + state"};
+struct DemodProf {
+    bool on = false;
+    double t[PF_N] = {};
+    long n[PF_N] = {};
+    std::chrono::steady_clock::time_point mark;
+    void start() { if (on) mark = std::chrono::steady_clock::now(); }
+    void stop(int k) { if (on) { const auto now = std::chrono::steady_clock::now(); t[k] += std::chrono::duration<double>(now - mark).count(); ++n[k]; mark = now; } }
+};
+
 struct t2gpu_demod {
+    DemodProf prof;
     int device = 0, id_device = 0, stride = 1;
     float sample_rate = 0.0f, level_min = 0.02f, level_max = 0.04f;                 // :31-50
     t2gpu_front *front = nullptr;
@@ -175,8 +192,10 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
     while (consume < len_in) {
         if (h->next_symbol_type == SYMBOL_TYPE_P1) {
             t2gpu_p1_result r;
+            h->prof.start();
             const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, h->d_out, &consume,
                                                  signal_->p1_reset, &r, nullptr);
+            h->prof.stop(PF_P1);
             if (det < 0) return -1;
             if (det == 1) {
                 const int k = r.idx_buffer_sym;                                     // p1_symbol.cpp:97: already in buffer_sym
@@ -208,8 +227,10 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // ---- buffer one symbol, guard correlation, FFT (:312-341)
         const int len_in_sym = len_in - consume, len_out_sym = h->symbol_size - h->idx_buffer_sym;
         const int len_cpy_sym = len_out_sym > len_in_sym ? len_in_sym : len_out_sym;
+        h->prof.start();
         T2_HIP(hipMemcpyAsync(h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym, h->d_out + 2 * (size_t)consume, (size_t)len_cpy_sym * 8,
                               hipMemcpyDeviceToDevice, nullptr));
+        h->prof.stop(PF_BUFFER);
         consume += len_cpy_sym;
         h->idx_buffer_sym += len_cpy_sym;
         if (h->idx_buffer_sym != h->symbol_size) {
@@ -217,12 +238,14 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             continue;
         }
         h->idx_buffer_sym = 0;
+        h->prof.start();
         if (h->crc32_l1_pre) {
             float cp[4];
             if (t2gpu_cp_correlate_dev(h->d_buffer_sym, 1, h->fft_size, h->guard_interval_size, h->d_cp, nullptr) != 0) return -1;
             T2_HIP(hipMemcpy(cp, h->d_cp, sizeof cp, hipMemcpyDeviceToHost));
             t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
         }
+        h->prof.stop(PF_CP);
         if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec, 1, nullptr) != 0)
             return -1;
         h->est_chunk = 0;
@@ -231,11 +254,15 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // ---- the symbol demodulators (:343-427)
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec, h->d_symidx + h->idx_symbol, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
+            h->prof.stop(PF_FFT_EQ);
             T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
+            h->prof.stop(PF_SV);
             if (h->deint_start && h->sig.data) {
                 const float *c = cells_to_host(h, h->c_data);
                 if (!c) return -1;
+                h->prof.stop(PF_CELLS);
                 h->sig.data(h->sig.user, h->c_data, c);
+                h->prof.stop(PF_SIGNAL);
             }
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
@@ -258,6 +285,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
             const float *c = cells_to_host(h, h->c_p2);
             if (!c) return -1;
+            h->prof.start();
             // p2_symbol::execute's tail (p2_symbol.cpp:281-296): L1-pre, then L1-post
             bool crc32_l1_post = false;
             t2gpu_l1_pre pre;
@@ -272,6 +300,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
                 if (1840 + pre.l1_post_size <= h->c_p2)
                     crc32_l1_post = t2gpu_l1_post_parse(c + 2 * 1840, &pre, &h->l1_post, h->plp, h->dyn, MAX_PLP) == 1;
             }
+            h->prof.stop(PF_L1);
             if (h->crc32_l1_pre) {
                 if (h->demodulator_init) {
                     if (crc32_l1_post) {
@@ -281,6 +310,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
                             if (h->sig.amount_plp) h->sig.amount_plp(h->sig.user, h->l1_post.num_plp);
                         }
                         if (h->sig.l1_dyn_execute) h->sig.l1_dyn_execute(h->sig.user, &h->l1_post, h->plp, h->dyn, h->c_p2, c);
+                        h->prof.stop(PF_SIGNAL);
                     }
                     ++h->idx_symbol;
                     h->next_symbol_type = SYMBOL_TYPE_DATA;
@@ -326,6 +356,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
         return nullptr;
     }
     t2gpu_demod *h = new t2gpu_demod();
+    if (const char *e = std::getenv("T2GPU_DEMOD_PROF")) h->prof.on = std::atoi(e) != 0;
     h->device = device; h->id_device = id_device; h->sample_rate = sample_rate;
     h->stride = id_device == 1 ? 2 : 1;                                             // convert_input, :31-50
     h->front = t2gpu_front_create(id_device, sample_rate, CHUNK_MAX, device);
@@ -360,6 +391,14 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    if (h->prof.on) {
+        double tot = 0;
+        for (int k = 0; k < PF_N; ++k) tot += h->prof.t[k];
+        std::fprintf(stderr, "t2gpu_demod profile (host wall time inside execute(), %ld symbols):\n", h->symbols);
+        for (int k = 0; k < PF_N; ++k)
+            std::fprintf(stderr, "  %-46s %9.3f ms  %5.1f %%  %7ld calls  %8.1f us each\n", PF_NAME[k], h->prof.t[k] * 1e3, 100.0 * h->prof.t[k] / (tot > 0 ? tot : 1),
+                         h->prof.n[k], h->prof.n[k] ? h->prof.t[k] * 1e6 / h->prof.n[k] : 0.0);
+    }
     free_all(h);
     delete h;
 }
@@ -392,8 +431,10 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         T2_HIP(hipMalloc(&h->d_q, el * 2));
         h->in_cap = el;
     }
+    h->prof.start();
     T2_HIP(hipMemcpy(h->d_i, i_in, el * 2, hipMemcpyHostToDevice));
     T2_HIP(hipMemcpy(h->d_q, q_in, el * 2, hipMemcpyHostToDevice));
+    h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {
         if (h->est_chunk == 0) {                                                    // :151-155
@@ -407,16 +448,20 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         if (chunk > len_in - idx_in) chunk = len_in - idx_in;
         if (chunk > CHUNK_MAX) { set_error("t2gpu_demod_execute: chunk larger than the work buffers"); return -1; }
         const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+        h->prof.start();
         const long n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
                                                    h->d_q + (size_t)idx_in * h->stride, h->d_out, h->out_cap, nullptr, nullptr);
+        h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
         if (symbol_acquisition(h, (int)n_out, signal_) != 0) return -1;
     }
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
+    h->prof.start();
     if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;
     float st[8];
     if (t2gpu_front_state(h->front, st) != 0) return -1;
+    h->prof.stop(PF_TAIL);
     h->level_detect = st[6];
     if (signal_->gain_changed) {
         if (h->level_detect < h->level_min) { signal_->gain_offset = 1; signal_->change_gain = 1; }

@@ -6,6 +6,7 @@
 #include "t2gpu_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using namespace t2gpu;
@@ -33,6 +34,13 @@ struct t2gpu_ldpc {
     uint8_t *d_out = nullptr;
     int *d_trials = nullptr;
     int last_status = 0;
+    // asynchronous host-call form (t2gpu_ldpc_submit / _collect): pinned staging, a stream and an event of the handle's own
+    int8_t *p_in = nullptr;
+    uint8_t *p_out = nullptr;
+    int *p_trials = nullptr;            // [max_frames] verdicts, then the error word
+    hipStream_t a_stream = nullptr;
+    hipEvent_t a_done = nullptr;
+    int a_frames = 0;                   // frames of the pending submit (0: none)
     // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
     bool packed_ok = false;
     int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
@@ -180,6 +188,9 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
     hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
+    if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
+    if (h->a_done) hipEventDestroy(h->a_done);
+    hipHostFree(h->p_in); hipHostFree(h->p_out); hipHostFree(h->p_trials);
     delete h;
 }
 
@@ -380,4 +391,60 @@ extern "C" int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, u
     T2_HIP(hipMemcpy(out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost));
     T2_HIP(hipMemcpy(trials_left, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost));
     return t2gpu_ldpc_status(h) ? -1 : 0;
+}
+
+// ---- the host-buffer slot, split in two (include/t2gpu.h): submit enqueues copy-in, decode and copy-out on the handle's own stream
+// and returns; collect waits for (or polls) the result. Several handles in flight keep several SIMD batches on the device at once --
+// a caller with the reference's call shape (ldpc_decoder::execute, one batch of 32 per call) otherwise leaves 15/16 of the CUs idle.
+extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
+{
+    if (!h || !in || len_in < h->g.n || len_in % h->g.n) { set_error("t2gpu_ldpc_submit: bad arguments"); return -1; }
+    const int n_frames = len_in / h->g.n;
+    if (n_frames > h->max_frames) { set_error("t2gpu_ldpc_submit: more frames than max_frames"); return -1; }
+    if (h->a_frames) { set_error("t2gpu_ldpc_submit: the previous submit has not been collected"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (!h->a_stream) {
+        T2_HIP(hipStreamCreateWithFlags(&h->a_stream, hipStreamNonBlocking));
+        T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
+        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
+        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_out), (size_t)h->max_frames * h->g.k, hipHostMallocDefault));
+        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_trials), ((size_t)h->max_frames + 1) * sizeof(int), hipHostMallocDefault));
+    }
+    if (!h->d_in) {
+        T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_frames * h->g.n));
+        T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_frames * h->g.k));
+        T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
+    }
+    const int nbatches = (n_frames + h->group - 1) / h->group;
+    std::memcpy(h->p_in, in, (size_t)len_in);                       // the caller's buffer is free again when this returns
+    hipStream_t s = h->a_stream;
+    T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));
+    if (t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s)) return -1;
+    T2_HIP(hipMemcpyAsync(h->p_out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost, s));
+    T2_HIP(hipMemcpyAsync(h->p_trials, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost, s));
+    T2_HIP(hipMemcpyAsync(h->p_trials + h->max_frames, h->d_error, sizeof(int), hipMemcpyDeviceToHost, s));
+    T2_HIP(hipEventRecord(h->a_done, s));
+    h->a_frames = n_frames;
+    return 0;
+}
+
+// wait != 0: blocks until the pending submit is through; wait == 0: returns 1 at once when it is not. On 0, *out points at
+// a_frames * k_ldpc information bits (one per byte) and *trials_left at the per-batch verdicts, both in the handle's pinned staging:
+// valid until the next submit on this handle.
+extern "C" int t2gpu_ldpc_collect(t2gpu_ldpc *h, int wait, const uint8_t **out, const int **trials_left, int *n_frames)
+{
+    if (!h || !out || !trials_left) { set_error("t2gpu_ldpc_collect: bad arguments"); return -1; }
+    if (!h->a_frames) { set_error("t2gpu_ldpc_collect: nothing submitted"); return -1; }
+    if (wait) T2_HIP(hipEventSynchronize(h->a_done));
+    else {
+        const hipError_t e = hipEventQuery(h->a_done);
+        if (e == hipErrorNotReady) return 1;
+        T2_HIP(e);
+    }
+    *out = h->p_out; *trials_left = h->p_trials;
+    if (n_frames) *n_frames = h->a_frames;
+    h->a_frames = 0;
+    h->last_status = h->p_trials[h->max_frames];
+    if (h->last_status) { set_error("LDPC batch rendezvous timed out"); return -1; }
+    return 0;
 }

@@ -76,6 +76,7 @@ int main(int argc, char **argv)
             int idx_plp_simd[t2::SIZEOF_SIMD] = {};
             const size_t batch = (size_t)fec_size * t2::SIZEOF_SIMD;
             for (size_t pos = 0; pos + batch <= llr.size(); pos += batch) ldpc.execute(idx_plp_simd, l1, (int)batch, llr.data() + pos);
+            ldpc.flush();                                              // the stage keeps batches in flight: the last ones come out here
             dump(argv[3], out);
         } else if (mode == "p1") {
             std::vector<t2::complex> in = slurp<t2::complex>(argv[2]);
@@ -135,6 +136,7 @@ int main(int argc, char **argv)
                 else ti.execute(sizes[l], cells.data() + pos);
                 pos += (size_t)sizes[l];
             }
+            ldpc.flush();
             dump(argv[3], out);
             dump(ts_path, ts);
         } else if (mode == "rx") {
@@ -204,6 +206,7 @@ int main(int argc, char **argv)
                              st.guard_interval_size, (long)st.symbols, (long)st.frames, (long)st.resets, st.level_detect, signal.coarse_freq_offset,
                              st.frequency_est_filtered, st.arbitrary_resample);
             }
+            ldpc.flush();
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             std::fprintf(log, "bbframes %ld ts %zu\n", bbframes, ts.size());
             std::fprintf(log, "wall %.3f s for %zu samples = %.2f Msamples/s (real time: 9.14)\n", secs, vi.size(), vi.size() / secs / 1e6);
