@@ -527,7 +527,8 @@ def main():
                 es, accs, ls, _, _ = timed_leg(rs, k, 2, level, nf=nf)
                 rs.close()
                 sweep.append({"frames_per_call": nf, "msamples_per_s": round(k * nf * FS / es / 1e6, 1), "ms_per_call": round(es / k * 1e3, 3),
-                              "ldpc_ms_per_call": round(sum(ls) / len(ls), 3), "calls_timed": k})
+                              "ldpc_ms_per_call": round(sum(ls) / len(ls), 3), "calls_timed": k,
+                              "stage_ms_per_call": {n: round(v / k, 4) for n, v in accs.items() if v > 0}})
             top = sweep[-1]["msamples_per_s"]
             for r in sweep:
                 r["of_full_batch_rate"] = round(r["msamples_per_s"] / top, 3)

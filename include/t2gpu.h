@@ -136,7 +136,8 @@ int t2gpu_demap_llr_batch_dev(t2gpu_demap *h, const float *d_cells, int n_blocks
  * pushed in arrival order, any number per call (the reference pushes one OFDM symbol at a time; the P2 symbol's
  * L1 cells are skipped by the caller, time_deinterleaver.cpp:296-300). out is the caller's TI buffer of
  * num_blocks * cells_per_fec complex cells (the reference's A/B buffer): a push returns 1 when the TI block is complete
- * -- the moment the reference emits ti_block -- else 0. */
+ * -- the moment the reference emits ti_block -- else 0. The host form reads `out` with the first push of a block (cells the scatter
+ * does not reach keep their history) and writes it when the block is complete; in between the block stays on the device. */
 typedef struct t2gpu_ti t2gpu_ti;
 t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, int device);
 void t2gpu_ti_destroy(t2gpu_ti *h);

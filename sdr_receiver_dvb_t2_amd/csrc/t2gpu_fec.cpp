@@ -413,12 +413,16 @@ extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float
     const size_t cap = (size_t)h->num_blocks_max * h->cells_per_fec * 8;
     if (!h->d_in) { T2_HIP(hipMalloc(&h->d_in, cap)); T2_HIP(hipMalloc(&h->d_out, cap)); }
     const size_t blk = (size_t)h->p.ti_block_size * 8;
-    T2_HIP(hipMemcpy(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice));
-    T2_HIP(hipMemcpy(h->d_out, out, blk, hipMemcpyHostToDevice));          // the caller's A/B buffer keeps its history
+    // The TI block lives in the handle between the pushes of a block: the caller's buffer (the reference's A/B buffer, whose cells the
+    // scatter does not reach keep their history) goes up once, with the block's first push, and comes back once, when the block is
+    // complete -- not with every OFDM symbol (60 round trips of 13 MB per 32K frame in rounds 1-3: 0.9 ms per symbol, three quarters of
+    // the slot-shaped path's time). Between those two moments `out` is not touched.
+    if (h->pos == 0) T2_HIP(hipMemcpyAsync(h->d_out, out, blk, hipMemcpyHostToDevice, nullptr));
+    T2_HIP(hipMemcpyAsync(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
     int done = t2gpu_ti_push_dev(h, h->d_in, n_cells, h->d_out, nullptr);
     if (done < 0) return -1;
-    T2_HIP(hipDeviceSynchronize());
-    T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
+    if (done == 1) T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
+    else T2_HIP(hipStreamSynchronize(nullptr));                                 // `cells` is the caller's again
     return done;
 }
 
