@@ -259,7 +259,8 @@ def drop_in_leg(w, ui, uq, device, frames=14, warm_frames=4):
         env = dict(os.environ)
         env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
         t0 = time.perf_counter()
-        p = subprocess.run([DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", "/dev/null", "--buf", str(DROP_IN_BUF),
+        wrap = os.environ.get("T2GPU_DROPIN_WRAPPER", "").split()          # e.g. "rocprofv3 --kernel-trace --stats -d gpurun_out/x --"
+        p = subprocess.run(wrap + [DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", "/dev/null", "--buf", str(DROP_IN_BUF),
                             "--warm", str(warm), "--json", "1", "--device", str(device)],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
         wall = time.perf_counter() - t0

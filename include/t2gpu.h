@@ -18,6 +18,7 @@
  */
 #ifndef T2GPU_H
 #define T2GPU_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -30,6 +31,22 @@ int t2gpu_version(void);
 const char *t2gpu_last_error(void);
 /* number of visible HIP devices (0 when there is none; never fails) */
 int t2gpu_device_count(void);
+
+/* ---------------------------------------------------------------- host-buffer hand-over between stages -----------------------------
+ * The reference's slots carry HOST pointers from stage to stage (ti_block -> llr_demapper::execute -> soft_multiplexer_de_twist ->
+ * ldpc_decoder::execute -> bit_bch -> ...: dvbt2_demodulator.cpp:84-95 and the main window's connect() chain). The host-buffer entry
+ * points below keep that contract -- results are in the caller's buffer when a call returns -- and in addition remember where the
+ * same bytes still are on the device (a "twin", found again by the buffer's address). A stage handed the previous stage's buffer
+ * unmodified, which is what the signal / slot chain does, skips its copy-in. A caller that edits such a buffer between two stages
+ * must say so: T2GPU_HANDOFF=0 in the environment turns every look-up off (rounds 1-3 behaviour: every stage copies in).
+ * For buffers the CALLER owns and fills from other stage outputs (llr_demapper's SIMD batch buffers, llr_demapper.cpp:742-764):
+ * t2gpu_twin_attach gives the buffer a twin kept by the library (and page-locks the buffer), t2gpu_twin_copy is memcpy(dst, src, n)
+ * plus the same copy between the twins, t2gpu_twin_detach releases. All return 0 or -1. */
+int t2gpu_host_pin(void *host, size_t bytes);      /* page-lock a caller's buffer: 0 done, 1 not possible (harmless), -1 bad arguments */
+int t2gpu_host_unpin(void *host);
+int t2gpu_twin_attach(void *host, size_t bytes, int device);
+int t2gpu_twin_detach(void *host);
+int t2gpu_twin_copy(void *dst, const void *src, size_t bytes, int device);
 
 /* ---------------------------------------------------------------- LDPC stage ------------------------------------
  * Replaces  void ldpc_decoder::execute(int* idx_plp_simd, l1_postsignalling l1_post, int len_in, int8_t* in)

@@ -185,33 +185,52 @@ private:
 class llr_demapper {
 public:
     explicit llr_demapper(int device = 0) : device_(device) {}
-    ~llr_demapper() { if (h_) t2gpu_demap_destroy(h_); }
+    ~llr_demapper() { release(); }
     std::function<void(float snr)> signal_noise_ratio;                                                             // llr_demapper.h:38
     std::function<void(int *idx_plp_simd, const l1_postsignalling &, int len_out, int8_t *out)> soft_multiplexer_de_twist;   // :39
     // slot (llr_demapper.h:44-45, llr_demapper.cpp:132-158): one TI block of cells in; LLR frames are collected into batches of
-    // SIZEOF_SIMD and handed on whenever one is full (:742-764), the remainder waits for the next TI block
+    // SIZEOF_SIMD and handed on whenever one is full (:742-764), the remainder waits for the next TI block.
+    // The two batch buffers (the reference's A / B) are page-locked and have a twin on the device that is filled as they are
+    // (t2gpu_twin_copy): ldpc_decoder, handed such a buffer, finds the batch there (t2gpu.h, host-buffer hand-over).
     void execute(int ti_block_size, complex *time_deint_cell, int plp_id, const l1_postsignalling &l1_post)
     {
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)plp_id);
         const int fec_size = p.plp_fec_type ? 64800 : 16200;
-        if (!h_ || key_ != key(p)) {
-            if (h_) t2gpu_demap_destroy(h_);
-            const int cells_max = (p.plp_num_blocks_max > 0 ? p.plp_num_blocks_max : 1) * fec_size / (2 * (p.plp_mod + 1));
-            if (!(h_ = t2gpu_demap_create(p.plp_mod, p.plp_fec_type, p.plp_cod, p.plp_rotation, std::max(cells_max, ti_block_size), device_)))
-                fail("t2gpu_demap_create");
+        const int cpf = fec_size / (2 * (p.plp_mod + 1));
+        if (!h_ || key_ != key(p) || ti_block_size > cells_max_) {
+            if (h_) { t2gpu_demap_destroy(h_); h_ = nullptr; }
+            cells_max_ = std::max((p.plp_num_blocks_max > 0 ? p.plp_num_blocks_max : 1) * cpf, ti_block_size);
+            if (!(h_ = t2gpu_demap_create(p.plp_mod, p.plp_fec_type, p.plp_cod, p.plp_rotation, cells_max_, device_))) fail("t2gpu_demap_create");
             key_ = key(p);
         }
-        frames_.resize((size_t)(ti_block_size / (fec_size / (2 * (p.plp_mod + 1))) + 1) * fec_size);
+        // buffers grow, never shrink, and a batch in the making survives a change of PLP (frames of several PLPs share a SIMD batch,
+        // llr_demapper.cpp:742-764: idx_plp_simd says whose each one is)
+        const size_t need_frames = (size_t)(cells_max_ / cpf + 1) * fec_size, need_batch = (size_t)fec_size * SIZEOF_SIMD;
+        if (frames_.size() < need_frames) {
+            if (!frames_.empty()) t2gpu_host_unpin(frames_.data());
+            frames_.assign(need_frames, 0);
+            t2gpu_host_pin(frames_.data(), frames_.size());
+        }
+        for (std::vector<int8_t> *b : {&buffer_a, &buffer_b}) {
+            if (b->size() >= need_batch) continue;
+            const std::vector<int8_t> keep(*b);
+            if (!b->empty()) t2gpu_twin_detach(b->data());
+            b->assign(need_batch, 0);
+            if (t2gpu_twin_attach(b->data(), b->size(), device_) != 0) fail("t2gpu_twin_attach");
+            if (!keep.empty() && t2gpu_twin_copy(b->data(), keep.data(), keep.size(), device_) != 0) fail("t2gpu_twin_copy");
+        }
         float sums[3] = {0, 0, 0};
         const int frames = t2gpu_demap_execute(h_, reinterpret_cast<const float *>(time_deint_cell), ti_block_size, frames_.data(), sums);
         if (frames < 0) fail("t2gpu_demap_execute");
         if (signal_noise_ratio) signal_noise_ratio(20.0f * std::log10(sums[0] / sums[1]));                       // :659
-        for (int f = 0; f < frames; ++f) {
+        for (int f = 0; f < frames;) {
             std::vector<int8_t> &out = swap_buffer ? buffer_a : buffer_b;
-            out.resize((size_t)fec_size * SIZEOF_SIMD);
-            std::copy(frames_.begin() + (size_t)f * fec_size, frames_.begin() + (size_t)(f + 1) * fec_size, out.begin() + (size_t)blocks * fec_size);
-            idx_plp_simd[blocks] = plp_id;
-            if (++blocks == SIZEOF_SIMD) {
+            const int run = std::min(frames - f, SIZEOF_SIMD - blocks);      // consecutive frames go to consecutive places of one batch: one copy
+            if (t2gpu_twin_copy(out.data() + (size_t)blocks * fec_size, frames_.data() + (size_t)f * fec_size, (size_t)run * fec_size, device_) != 0)
+                fail("t2gpu_twin_copy");
+            for (int k = 0; k < run; ++k) idx_plp_simd[blocks + k] = plp_id;
+            blocks += run; f += run;
+            if (blocks == SIZEOF_SIMD) {
                 blocks = 0;
                 swap_buffer = !swap_buffer;
                 if (soft_multiplexer_de_twist) soft_multiplexer_de_twist(idx_plp_simd, l1_post, fec_size * SIZEOF_SIMD, out.data());
@@ -220,7 +239,14 @@ public:
     }
 private:
     static int key(const t2gpu_l1_plp &p) { return p.plp_mod | (p.plp_fec_type << 4) | (p.plp_cod << 8) | (p.plp_rotation << 12) | (p.plp_num_blocks_max << 13); }
-    int device_, key_ = -1, blocks = 0;
+    void release()
+    {
+        if (!buffer_a.empty()) t2gpu_twin_detach(buffer_a.data());
+        if (!buffer_b.empty()) t2gpu_twin_detach(buffer_b.data());
+        if (!frames_.empty()) t2gpu_host_unpin(frames_.data());
+        if (h_) { t2gpu_demap_destroy(h_); h_ = nullptr; }
+    }
+    int device_, key_ = -1, blocks = 0, cells_max_ = 0;
     t2gpu_demap *h_ = nullptr;
     int idx_plp_simd[SIZEOF_SIMD] = {};
     std::vector<int8_t> frames_, buffer_a, buffer_b;
@@ -246,6 +272,8 @@ public:
         }
         p2_start_idx_cell = 1840 + l1_pre.l1_post_size;
         out_.assign(len_max, complex());
+        t2gpu_host_pin(out_.data(), out_.size() * sizeof(complex));              // the TI block comes down (and goes up) at the link's rate
+        pinned_ = true;
         plp_state_ = 0;
     }
     // :43, cpp:268-288. The PLP / TI-block sequence of the frame follows from the dynamic signalling alone
@@ -279,7 +307,13 @@ private:
             }
         }
     }
-    void release() { for (t2gpu_ti *h : h_) t2gpu_ti_destroy(h); h_.clear(); }
+    void release()
+    {
+        for (t2gpu_ti *h : h_) t2gpu_ti_destroy(h);
+        h_.clear();
+        if (pinned_) { t2gpu_host_unpin(out_.data()); pinned_ = false; }
+    }
+    bool pinned_ = false;
     int device_, p2_start_idx_cell = 0, plp_state_ = 0, pos_ = 0;
     size_t k_ = 0;
     std::vector<t2gpu_ti *> h_;

@@ -50,7 +50,7 @@ struct LdpcKernelParams {
 // and layer ([grid][q][720][dwords], passed through LdpcKernelParams::state), group / 2 workgroups per SIMD batch
 int ldpc_kernel2_record_dwords(int min_cnt, int max_cnt);
 hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes);
-hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);
+hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream, bool allow_cooperative = true);
 
 hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes);
 hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);

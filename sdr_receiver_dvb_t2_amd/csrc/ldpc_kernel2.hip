@@ -590,14 +590,17 @@ hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int 
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads2, lds_bytes);
 }
 
-hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream)
+hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream, bool allow_cooperative)
 {
     ldpc2_kernel_fn fn = pick_kernel2(min_cnt, max_cnt);
     // The workgroups of a SIMD batch meet at every sweep: the grid must be resident as a whole. A cooperative launch makes that the
     // runtime's promise (it refuses a grid that does not fit and does not start it beside work that would keep part of it out)
     // instead of an assumption about what else is on the device. T2GPU_LDPC_COOPERATIVE=0: the plain launch (A/B measurements).
     const char *coop_env = std::getenv("T2GPU_LDPC_COOPERATIVE");
-    const bool cooperative = !(coop_env && std::atoi(coop_env) == 0);
+    // allow_cooperative false: the caller keeps several small launches in flight on streams of their own (t2gpu_ldpc_submit) and has
+    // bounded their total size by the device's resident capacity itself -- cooperative launches of different streams run one after the
+    // other (measured: union of 18 launches = their sum), plain ones side by side
+    const bool cooperative = allow_cooperative && !(coop_env && std::atoi(coop_env) == 0);
     if (cooperative) {
         const LdpcLayerDev *layers = p.layers;
         const uint32_t *entries = p.entries, *cninfo = p.cninfo, *entries2 = p.entries2;

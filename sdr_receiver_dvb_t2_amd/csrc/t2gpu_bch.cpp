@@ -101,6 +101,20 @@ extern "C" int t2gpu_bch_decode(int fec_type, int code_rate, uint8_t *bits, int 
     uint8_t *d_bits = nullptr;
     int32_t *d_status = nullptr;
     const size_t bytes = (size_t)n_frames * n;
+    int device = 0;
+    T2_HIP(hipGetDevice(&device));
+    if (void *twin = const_cast<void *>(t2gpu::twin_lookup(bits, bytes, device))) {
+        // bits straight from the LDPC stage are still on the device (t2gpu.h, host-buffer hand-over): corrected there in place, so that
+        // the twin goes on holding what the host buffer holds, and copied back
+        T2_HIP(hipMalloc(&d_status, (size_t)n_frames * sizeof(int32_t)));
+        int rc = -1;
+        if (t2gpu_bch_decode_dev(fec_type, code_rate, static_cast<uint8_t *>(twin), n_frames, d_status, nullptr) == n_frames &&
+            t2gpu::hip_ok(hipMemcpy(bits, twin, bytes, hipMemcpyDeviceToHost), "hipMemcpy") &&
+            t2gpu::hip_ok(hipMemcpy(status, d_status, (size_t)n_frames * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy"))
+            rc = n_frames;
+        hipFree(d_status);
+        return rc;
+    }
     T2_HIP(hipMalloc(&d_bits, bytes));
     if (!hip_ok(hipMalloc(&d_status, (size_t)n_frames * sizeof(int32_t)), "hipMalloc")) { hipFree(d_bits); return -1; }
     int rc = -1;

@@ -69,7 +69,8 @@ struct t2gpu_demod {
     float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec = nullptr, *d_cells = nullptr, *d_sync = nullptr, *d_cp = nullptr;
     int32_t *d_symidx = nullptr;
     long out_cap = 0;
-    std::vector<float> h_cells;
+    float *h_cells = nullptr;          // pinned: the cells of the symbol just equalised, as the `data` / `l1_dyn_execute` signals carry them
+    float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
 };
 
 namespace {
@@ -86,6 +87,8 @@ void free_all(t2gpu_demod *h)
     if (h->data_ofdm) t2gpu_ofdm_destroy(h->data_ofdm);
     hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out); hipFree(h->d_buffer_sym); hipFree(h->d_spec); hipFree(h->d_cells);
     hipFree(h->d_sync); hipFree(h->d_cp); hipFree(h->d_symidx);
+    if (h->h_cells) twin_retire(h->h_cells);
+    hipHostFree(h->h_cells); hipHostFree(h->h_small);
 }
 
 // dvbt2_demodulator::reset (:111-127)
@@ -177,12 +180,19 @@ int init_data(t2gpu_demod *h)
     return 0;
 }
 
-// cells of the symbol just equalised -> host, for the signal that carries them
-const float *cells_to_host(t2gpu_demod *h, int n)
+// One drain per symbol: the guard correlation, the two synchronisation floats and (when a signal carries them) the symbol's cells are
+// copied to page-locked memory behind the symbol's kernels, and the stream is waited for once (rounds 2-3: three blocking copies).
+// cp (may be null) / sv receive the floats; returns the cells' host address (the twin of d_cells: t2gpu_ti_push finds them on the
+// device) or nullptr on an error.
+const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
 {
-    if ((int)h->h_cells.size() < 2 * n) h->h_cells.resize((size_t)2 * n);
-    if (hipMemcpy(h->h_cells.data(), h->d_cells, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
-    return h->h_cells.data();
+    if (cp && hipMemcpyAsync(h->h_small, h->d_cp, 16, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(h->h_small + 4, h->d_sync, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+    if (n_cells > 0 && hipMemcpyAsync(h->h_cells, h->d_cells, (size_t)n_cells * 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+    if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;
+    if (cp) std::memcpy(cp, h->h_small, 16);
+    std::memcpy(sv, h->h_small + 4, 8);
+    return h->h_cells;
 }
 
 // symbol_acquisition (:267-448). Returns 0, or -1 on an error of a stage.
@@ -239,12 +249,9 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         }
         h->idx_buffer_sym = 0;
         h->prof.start();
-        if (h->crc32_l1_pre) {
-            float cp[4];
-            if (t2gpu_cp_correlate_dev(h->d_buffer_sym, 1, h->fft_size, h->guard_interval_size, h->d_cp, nullptr) != 0) return -1;
-            T2_HIP(hipMemcpy(cp, h->d_cp, sizeof cp, hipMemcpyDeviceToHost));
-            t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
-        }
+        const bool have_cp = h->crc32_l1_pre;                                       // :321-330; its result is read with the symbol's other results
+        float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (have_cp && t2gpu_cp_correlate_dev(h->d_buffer_sym, 1, h->fft_size, h->guard_interval_size, h->d_cp, nullptr) != 0) return -1;
         h->prof.stop(PF_CP);
         if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec, 1, nullptr) != 0)
             return -1;
@@ -255,12 +262,12 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec, h->d_symidx + h->idx_symbol, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
             h->prof.stop(PF_FFT_EQ);
-            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
+            const bool carry = h->deint_start && h->sig.data;
+            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, carry ? h->c_data : 0);
+            if (!c) return -1;
+            if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.stop(PF_SV);
-            if (h->deint_start && h->sig.data) {
-                const float *c = cells_to_host(h, h->c_data);
-                if (!c) return -1;
-                h->prof.stop(PF_CELLS);
+            if (carry) {
                 h->sig.data(h->sig.user, h->c_data, c);
                 h->prof.stop(PF_SIGNAL);
             }
@@ -271,20 +278,19 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             }
         } else if (h->next_symbol_type == SYMBOL_TYPE_FC) {
             if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
-            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
-            if (h->deint_start && h->sig.data) {
-                const float *c = cells_to_host(h, h->n_fc);
-                if (!c) return -1;
-                h->sig.data(h->sig.user, h->n_fc, c);
-            }
+            const bool carry = h->deint_start && h->sig.data;
+            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, carry ? h->n_fc : 0);
+            if (!c) return -1;
+            if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
+            if (carry) h->sig.data(h->sig.user, h->n_fc, c);
             h->next_symbol_type = SYMBOL_TYPE_P1;
             ++h->frames;
         } else {                                                                    // SYMBOL_TYPE_P2
             h->idx_symbol = 0;
             if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
-            T2_HIP(hipMemcpy(sv, h->d_sync, sizeof sv, hipMemcpyDeviceToHost));
-            const float *c = cells_to_host(h, h->c_p2);
+            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, h->c_p2);
             if (!c) return -1;
+            if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.start();
             // p2_symbol::execute's tail (p2_symbol.cpp:281-296): L1-pre, then L1-post
             bool crc32_l1_post = false;
@@ -370,6 +376,9 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells), (size_t)32768 * 8, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocDefault) == hipSuccess;
+    if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device);     // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;

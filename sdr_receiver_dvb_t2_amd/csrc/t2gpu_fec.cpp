@@ -107,6 +107,7 @@ extern "C" int t2gpu_demap_configure(t2gpu_demap *h, int saturate)
 extern "C" void t2gpu_demap_destroy(t2gpu_demap *h)
 {
     if (!h) return;
+    if (h->d_llr) twin_retire_dev(h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell);
     hipFree(h->d_address); hipFree(h->d_partial); hipFree(h->d_terms); hipFree(h->d_sums); hipFree(h->d_cells); hipFree(h->d_llr);
     delete h;
 }
@@ -210,12 +211,18 @@ extern "C" int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cel
         T2_HIP(hipMalloc(&h->d_cells, (size_t)h->max_cells * 8));
         T2_HIP(hipMalloc(&h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell));
     }
-    T2_HIP(hipMemcpy(h->d_cells, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice));
+    // a TI block straight from t2gpu_ti_push is still on the device (include/t2gpu.h, host-buffer hand-over). The demapper de-rotates
+    // its input in place (llr_demapper.cpp:555-557): it works on its own copy, the twin stays what the host buffer holds.
+    const float *twin = static_cast<const float *>(twin_lookup(cells, (size_t)n_cells * 8, h->device));
+    twin_retire_dev(h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell);       // the LLRs of the previous call are about to be overwritten
+    if (twin) T2_HIP(hipMemcpyAsync(h->d_cells, twin, (size_t)n_cells * 8, hipMemcpyDeviceToDevice, nullptr));
+    else T2_HIP(hipMemcpyAsync(h->d_cells, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
     int nf = t2gpu_demap_execute_dev(h, h->d_cells, n_cells, 0.0f, h->d_llr, nullptr, nullptr);
     if (nf < 0) return -1;
-    T2_HIP(hipDeviceSynchronize());
-    T2_HIP(hipMemcpy(llr, h->d_llr, (size_t)nf * h->p.fec_size, hipMemcpyDeviceToHost));
-    if (sums3) T2_HIP(hipMemcpy(sums3, h->d_sums, 12, hipMemcpyDeviceToHost));
+    T2_HIP(hipMemcpyAsync(llr, h->d_llr, (size_t)nf * h->p.fec_size, hipMemcpyDeviceToHost, nullptr));
+    if (sums3) T2_HIP(hipMemcpyAsync(sums3, h->d_sums, 12, hipMemcpyDeviceToHost, nullptr));
+    T2_HIP(hipStreamSynchronize(nullptr));
+    twin_publish(llr, h->d_llr, (size_t)nf * h->p.fec_size, h->device);
     return nf;
 }
 
@@ -258,6 +265,7 @@ extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, 
 extern "C" void t2gpu_ti_destroy(t2gpu_ti *h)
 {
     if (!h) return;
+    if (h->d_out) twin_retire_dev(h->d_out, (size_t)h->num_blocks_max * h->cells_per_fec * 8);
     hipFree(h->d_perm); hipFree(h->d_order); hipFree(h->d_lost); hipFree(h->d_lost_blk); hipFree(h->d_first_q); hipFree(h->d_in); hipFree(h->d_out);
     delete h;
 }
@@ -417,12 +425,23 @@ extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float
     // scatter does not reach keep their history) goes up once, with the block's first push, and comes back once, when the block is
     // complete -- not with every OFDM symbol (60 round trips of 13 MB per 32K frame in rounds 1-3: 0.9 ms per symbol, three quarters of
     // the slot-shaped path's time). Between those two moments `out` is not touched.
-    if (h->pos == 0) T2_HIP(hipMemcpyAsync(h->d_out, out, blk, hipMemcpyHostToDevice, nullptr));
-    T2_HIP(hipMemcpyAsync(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
-    int done = t2gpu_ti_push_dev(h, h->d_in, n_cells, h->d_out, nullptr);
+    // (`out` handed back unmodified from the previous block of this handle: its twin IS d_out, nothing to bring up)
+    if (h->pos == 0) {
+        if (twin_lookup(out, blk, h->device) != h->d_out) T2_HIP(hipMemcpyAsync(h->d_out, out, blk, hipMemcpyHostToDevice, nullptr));
+        twin_retire_dev(h->d_out, cap);                                         // from here on d_out is a block in the making, nobody's twin
+    }
+    // cells straight from an equaliser's output (t2gpu_demod / t2gpu_eq_*_execute): they are still on the device
+    const float *d_cells = static_cast<const float *>(twin_lookup(cells, (size_t)n_cells * 8, h->device));
+    if (!d_cells) {
+        T2_HIP(hipMemcpyAsync(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
+        d_cells = h->d_in;
+    }
+    int done = t2gpu_ti_push_dev(h, d_cells, n_cells, h->d_out, nullptr);
     if (done < 0) return -1;
-    if (done == 1) T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
-    else T2_HIP(hipStreamSynchronize(nullptr));                                 // `cells` is the caller's again
+    if (done == 1) {
+        T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
+        twin_publish(out, h->d_out, blk, h->device);                            // the complete TI block: what llr_demapper is handed next
+    } else if (d_cells == h->d_in) T2_HIP(hipStreamSynchronize(nullptr));       // `cells` is the caller's again
     return done;
 }
 
@@ -480,17 +499,23 @@ extern "C" int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *
 {
     const int id = ldpc_code_id(fec_type, code_rate);
     if (id < 0 || !bits || !out || n_frames < 1) { set_error("t2gpu_bch_descramble: bad arguments"); return -1; }
-    if (!have_device(0, "t2gpu_bch_descramble")) return -1;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || !have_device(device, "t2gpu_bch_descramble")) return -1;
     static const int k_ldpc[12] = {7200, 9720, 10800, 11880, 12600, 13320, 32400, 38880, 43200, 48600, 51840, 54000};
-    uint8_t *d_in = nullptr, *d_out = nullptr;
     const size_t in_b = (size_t)n_frames * k_ldpc[id], out_b = (size_t)n_frames * ldpc_k_bch(id);
-    int kb = -1;                                                              // staging buffers are released on every path
-    if (hip_ok(hipMalloc(&d_in, in_b), "hipMalloc") && hip_ok(hipMalloc(&d_out, out_b), "hipMalloc") &&
-        hip_ok(hipMemcpy(d_in, bits, in_b, hipMemcpyHostToDevice), "hipMemcpy")) {
-        kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, d_out, nullptr);
-        if (kb > 0 && !(hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize") &&
-                        hip_ok(hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost), "hipMemcpy"))) kb = -1;
-    }
-    hipFree(d_in); hipFree(d_out);
+    // staging kept per device and grown on demand (rounds 1-3 allocated and freed it in every call)
+    struct Stage { uint8_t *in = nullptr, *out = nullptr; size_t in_cap = 0, out_cap = 0; };
+    static std::mutex m;
+    static std::map<int, Stage> stages;
+    std::lock_guard<std::mutex> lk(m);
+    Stage &st = stages[device];
+    if (st.in_cap < in_b) { hipFree(st.in); st.in = nullptr; st.in_cap = 0; T2_HIP(hipMalloc(&st.in, in_b)); st.in_cap = in_b; }
+    if (st.out_cap < out_b) { hipFree(st.out); st.out = nullptr; st.out_cap = 0; T2_HIP(hipMalloc(&st.out, out_b)); st.out_cap = out_b; }
+    // bits straight from t2gpu_ldpc_collect / t2gpu_ldpc_execute are still on the device
+    const uint8_t *d_in = static_cast<const uint8_t *>(twin_lookup(bits, in_b, device));
+    if (!d_in) { T2_HIP(hipMemcpyAsync(st.in, bits, in_b, hipMemcpyHostToDevice, nullptr)); d_in = st.in; }
+    const int kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, st.out, nullptr);
+    if (kb < 0) return -1;
+    T2_HIP(hipMemcpy(out, st.out, out_b, hipMemcpyDeviceToHost));
     return kb;
 }

@@ -39,8 +39,9 @@ struct t2gpu_ldpc {
     uint8_t *p_out = nullptr;
     int *p_trials = nullptr;            // [max_frames] verdicts, then the error word
     hipStream_t a_stream = nullptr;
-    hipEvent_t a_done = nullptr;
+    hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
+    bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
     // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
     bool packed_ok = false;
     int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
@@ -190,6 +191,8 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
     if (h->a_done) hipEventDestroy(h->a_done);
+    if (h->a_fence) hipEventDestroy(h->a_fence);
+    if (h->d_out) twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);
     hipHostFree(h->p_in); hipHostFree(h->p_out); hipHostFree(h->p_trials);
     delete h;
 }
@@ -289,7 +292,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
             p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
         }
         h->resident_total += (unsigned)grid;
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s));
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !h->plain_launch));
         else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
         return 0;
     }
@@ -305,7 +308,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
         const int slots = std::min(nslots, nb);
         h->resident_total += (unsigned)(slots * wg_per_batch);
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s));
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s, !h->plain_launch));
         else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
     }
     return 0;
@@ -416,10 +419,27 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
         T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
     }
     const int nbatches = (n_frames + h->group - 1) / h->group;
-    std::memcpy(h->p_in, in, (size_t)len_in);                       // the caller's buffer is free again when this returns
     hipStream_t s = h->a_stream;
-    T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));
-    if (t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s)) return -1;
+    twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
+    if (const void *twin = twin_lookup(in, (size_t)len_in, h->device)) {
+        // a SIMD batch assembled from the demapper's output (t2gpu_twin_copy) is on the device already: its twin is written on the
+        // null stream; this handle's stream takes its copy behind those writes, and the null stream goes on behind that copy
+        if (!h->a_fence) T2_HIP(hipEventCreateWithFlags(&h->a_fence, hipEventDisableTiming));
+        T2_HIP(hipEventRecord(h->a_fence, nullptr));
+        T2_HIP(hipStreamWaitEvent(s, h->a_fence, 0));
+        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, s));
+        T2_HIP(hipEventRecord(h->a_fence, s));
+        T2_HIP(hipStreamWaitEvent(nullptr, h->a_fence, 0));
+    } else {
+        std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns
+        T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));
+    }
+    // several submits run side by side (cooperative launches would not); a submit is at most max_frames = a few SIMD batches, and
+    // the callers' rings (t2::ldpc_decoder: 8 handles of one batch) stay far below the device's resident workgroups
+    h->plain_launch = true;
+    const int rc = t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s);
+    h->plain_launch = false;
+    if (rc) return -1;
     T2_HIP(hipMemcpyAsync(h->p_out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost, s));
     T2_HIP(hipMemcpyAsync(h->p_trials, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost, s));
     T2_HIP(hipMemcpyAsync(h->p_trials + h->max_frames, h->d_error, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -442,6 +462,7 @@ extern "C" int t2gpu_ldpc_collect(t2gpu_ldpc *h, int wait, const uint8_t **out, 
         T2_HIP(e);
     }
     *out = h->p_out; *trials_left = h->p_trials;
+    twin_publish(h->p_out, h->d_out, (size_t)h->a_frames * h->g.k, h->device);   // bch_decoder is handed these bits next
     if (n_frames) *n_frames = h->a_frames;
     h->a_frames = 0;
     h->last_status = h->p_trials[h->max_frames];
