@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                 const uint32_t a = sa[x], b = sb[x];
                 dst[x] = make_uint2(__builtin_amdgcn_perm(b, a, 0x05010400u), __builtin_amdgcn_perm(b, a, 0x07030602u));
             }
-            uint4 *st4 = reinterpret_cast<uint4 *>(state);
-            for (int x = tid; x < p.q * 720 * RW / 4; x += kThreads2) st4[x] = make_uint4(0u, 0u, 0u, 0u);
+            // (no zeroing of the message records: the first sweep of a batch takes every old message as 0 without reading them -- 518 KB
+            // per workgroup and batch neither written nor read back)
         }
         if (tid < 4) s_ctl[4 + tid] = 0;                 // the parity check's 32-check accumulators
         __syncthreads();
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             // the first layer's records of the coming sweep are fetched ahead of the parity check (they were written a sweep ago;
             // read at the head of the sweep, all twelve wavefronts sat out the L2 round trip together)
             uint32_t first_rec[RW];
-            if (have_a && active) {
+            if (have_a && active && t > 0) {
                 const uint4 *q4 = reinterpret_cast<const uint4 *>(state + (size_t)tid * RW);
 #pragma unroll
                 for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; first_rec[4 * w] = v.x; first_rec[4 * w + 1] = v.y; first_rec[4 * w + 2] = v.z; first_rec[4 * w + 3] = v.w; }
@@ -496,9 +496,14 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
 #pragma unroll
                     for (int w = 0; w < RW; ++w) cur[w] = nxt[w];
                     if (active && i + 1 < p.q) {                                     // prefetch the next layer's record (and node)
-                        const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
+                        if (t > 0) {
+                            const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
 #pragma unroll
-                        for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
+                            for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < RW; ++w) nxt[w] = 0u;                 // first sweep of a batch: every old message is 0
+                        }
                         info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
                     }
                     uint32_t *rec_out = state + ((size_t)i * 720 + tid) * RW;
