@@ -99,7 +99,7 @@ int ora_bitdeint_address(int mod, int fec_type, int code_rate, int *address_out)
 #define NORM_FACTOR_QAM64 0.15430335f
 #define NORM_FACTOR_QAM256 0.076696499f
 
-static float slice_axis(int mod, float x, float d)
+static float slice_axis_tree(int mod, float x, float d)
 {
     /* binary trees of llr_demapper.cpp:257-276 (16), :395-436 (64, incl. the '>' typo of :407,427), :567-654 (256) */
     float x2 = d * 2.0f, x4 = d * 4.0f, x6 = d * 6.0f, x8 = d * 8.0f, x10 = d * 10.0f, x12 = d * 12.0f, x14 = d * 14.0f;
@@ -130,6 +130,46 @@ static float slice_axis(int mod, float x, float d)
     }
     if (x < -x4) return (x < -x6) ? -(d * 7.0f) : -(d * 5.0f);
     return (x < -x2) ? -(d * 3.0f) : -d;
+}
+
+/* The same decisions without branches (what -Ofast -mavx2 makes of the trees is compares and blends, not jumps; on noisy cells the
+ * jumps of the literal form above mispredict every other cell and the restatement ran 3x slower than the code it restates): the tree
+ * picks the level by counting the thresholds below |x| -- d * (2 level + 1), the same float product the tree returns -- x = 0 and NaN
+ * go with the negatives, and on the negative side of 64-QAM the outermost point is never decided (the `x > x6` of :407,427).
+ * ora_slice_selfcheck() holds the two forms to each other; the fixtures hold both to the reference. */
+static inline float slice_axis(int mod, float x, float d)
+{
+    const float a = fabsf(x);
+    int lvl = 0;
+    if (mod >= 1) lvl += a > d * 2.0f;
+    if (mod >= 2) { lvl += a > d * 4.0f; lvl += a > d * 6.0f; }
+    if (mod >= 3) { lvl += a > d * 8.0f; lvl += a > d * 10.0f; lvl += a > d * 12.0f; lvl += a > d * 14.0f; }
+    const int pos = x > 0;
+    if (mod == 2 && !pos && lvl > 2) lvl = 2;
+    const float amp = d * (float)(2 * lvl + 1);
+    return pos ? amp : -amp;
+}
+
+/* number of disagreements between the two forms on a dense sweep of x for every modulation (0 expected) */
+int ora_slice_selfcheck(void)
+{
+    static const float NORM[4] = {0.707106781f, 0.316227766f, 0.15430335f, 0.076696499f};
+    int bad = 0;
+    for (int mod = 1; mod <= 3; ++mod) {
+        const float d = NORM[mod];
+        for (int k = -40000; k <= 40000; ++k) {
+            const float x = (float)k * (d / 2000.0f);
+            const float t = slice_axis_tree(mod, x, d), f = slice_axis(mod, x, d);
+            if (!(t == f)) ++bad;
+        }
+        for (int m = 1; m <= 15; ++m) {                      /* the thresholds themselves and their neighbours */
+            const float th = d * (float)m;
+            const float xs[6] = {th, -th, nextafterf(th, 0.0f), nextafterf(th, 100.0f), -nextafterf(th, 0.0f), -nextafterf(th, 100.0f)};
+            for (int q = 0; q < 6; ++q) if (!(slice_axis_tree(mod, xs[q], d) == slice_axis(mod, xs[q], d))) ++bad;
+        }
+        if (!(slice_axis_tree(mod, NAN, d) == slice_axis(mod, NAN, d)) || !(slice_axis_tree(mod, 0.0f, d) == slice_axis(mod, 0.0f, d))) ++bad;
+    }
+    return bad;
 }
 
 static int8_t cast_i8(float v)      /* static_cast<int8_t>(float) as g++ -Ofast -mavx2 emits it: cvttss2si, low byte */

@@ -42,3 +42,14 @@ def test_bb_scrambler_sequence(l):
     # 1 + x^14 + x^15 is maximal length: period 2^15 - 1, balanced up to one bit
     assert np.array_equal(got[:54000 - 32767], got[32767:54000])
     assert abs(int(got[:32767].sum()) - 16384) <= 1
+
+
+def test_oracle_slicer_forms_agree():
+    """oracle/fec_oracle.c carries the reference's decision trees (llr_demapper.cpp:257-276, 395-436, 567-654) literally and in a
+    branch-free form that the cpu_baseline leg runs: the two agree on a dense sweep of every axis, at every threshold and its float
+    neighbours, at 0 and at NaN -- incl. the 64-QAM negative side that never decides the outermost point."""
+    import ctypes
+    import oracle_lib as ol
+    fn = ol.oracle().ora_slice_selfcheck
+    fn.restype = ctypes.c_int
+    assert fn() == 0
