@@ -410,7 +410,7 @@ def main():
             def step(rx, level, nf):                   # config 2: the frames' stream and positions stay in the handle from the set-up call
                 return rx.fft_eq_demap_dev(nf)
 
-        def timed_leg(rx, steps, warmup, level, keep_ts=False, nf=None):
+        def timed_leg(rx, steps, warmup, level, keep_ts=False, nf=None, drain=True):
             """W untimed + K timed steps bracketed by barrier + synchronize; the clock stops when the last step's TS bytes are on the host.
             Returns (seconds, per-stage ms sums, LDPC ms list, TS bytes of the timed steps, the bytes themselves if keep_ts)."""
             ts_on = full and not args.no_ts_end
@@ -447,13 +447,15 @@ def main():
             t0 = time.perf_counter()
             if consumer:
                 consumer.start()
-            for _ in range(steps):
+            for it in range(steps):
                 step(rx, level, nf)
+                if not drain and it + 1 < steps:       # calls follow each other without the host waiting for the device in between
+                    continue
                 for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
                     if v >= 0:
-                        acc[k] = acc.get(k, 0.0) + v
+                        acc[k] = acc.get(k, 0.0) + v * (1 if drain else steps)
                 if full:
-                    ldpc.append(rx.last_ldpc_ms())
+                    ldpc.extend([rx.last_ldpc_ms()] * (1 if drain else steps))
             if consumer:
                 done.set()
                 consumer.join()
@@ -518,21 +520,36 @@ def main():
             extra["clamped_llr_variant"] = var
             # (iii) throughput against T2 frames per call of the batch receiver (the headline's 48 fill 18.9 rounds of the decoder's
             # resident batch slots; one frame = 202 FEC frames = 6.3 SIMD batches, formed across calls exactly as the reference forms them)
+            # Calls are made back to back (the host waits for the device once, behind the last); `overlapped` = the same with the decode of a
+            # call on the handle's own stream (t2gpu_rx_set_overlap), beside the next call's front end .. demapper.
             sweep = []
             for nf in (1, 2, 4, 8, 16, F):
                 if nf > F:
                     continue
-                rs = make_rx(False, nf, args.trials)
-                rs.execute_dev(d_i, d_q, nf, first_call=True)
-                k = max(3, min(24, 96 // nf))
-                es, accs, ls, _, _ = timed_leg(rs, k, 2, level, nf=nf)
-                rs.close()
-                sweep.append({"frames_per_call": nf, "msamples_per_s": round(k * nf * FS / es / 1e6, 1), "ms_per_call": round(es / k * 1e3, 3),
-                              "ldpc_ms_per_call": round(sum(ls) / len(ls), 3), "calls_timed": k,
-                              "stage_ms_per_call": {n: round(v / k, 4) for n, v in accs.items() if v > 0}})
+                row = {"frames_per_call": nf}
+                for mode in ("plain", "overlapped"):
+                    rs = make_rx(False, nf, args.trials)
+                    rs.execute_dev(d_i, d_q, nf, first_call=True)
+                    torch.cuda.synchronize(dev)
+                    if mode == "overlapped":
+                        if rs.carry:
+                            rs.flush_dev()
+                            torch.cuda.synchronize(dev)
+                        rs.set_overlap(True)
+                    k = max(4, min(32, 128 // nf))
+                    es, accs, ls, _, _ = timed_leg(rs, k, 2, level, nf=nf, drain=False)
+                    rs.close()
+                    if mode == "plain":
+                        row.update({"msamples_per_s": round(k * nf * FS / es / 1e6, 1), "ms_per_call": round(es / k * 1e3, 3),
+                                    "ldpc_ms_per_call": round(sum(ls) / len(ls), 3), "calls_timed": k,
+                                    "stage_ms_last_call": {n: round(v / k, 4) for n, v in accs.items() if v > 0}})
+                    else:
+                        row.update({"overlapped_msamples_per_s": round(k * nf * FS / es / 1e6, 1), "overlapped_ms_per_call": round(es / k * 1e3, 3)})
+                sweep.append(row)
             top = sweep[-1]["msamples_per_s"]
             for r in sweep:
                 r["of_full_batch_rate"] = round(r["msamples_per_s"] / top, 3)
+                r["overlapped_of_full_batch_rate"] = round(r["overlapped_msamples_per_s"] / top, 3)
             extra["frames_sweep"] = sweep
             # (iv) the same input through the reference's own call shape (slot by slot, device-buffer-sized calls, loops closed)
             extra["drop_in"] = drop_in_leg(w, ui, uq, local_rank)

@@ -599,6 +599,13 @@ int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, in
                          uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream);
 int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream);
 int t2gpu_rx_carry(const t2gpu_rx *h);
+/* The decode of a call (LDPC, outer code, descrambler + packing) on a stream of the handle's own, so that the NEXT call's front end ..
+ * demapper run beside it where the decoder leaves CUs free: calls of one or two T2 frames are 6 - 13 SIMD batches = 96 - 208 of the 256
+ * workgroups the device keeps resident. Same results, same batch formation. With it on, a call's stream no longer covers the decode:
+ * d_bytes_out / d_trials_out are complete after t2gpu_rx_wait (or any fetch / results / stage_ms / TS read, which wait themselves).
+ * To be switched on a drained handle with no frames waiting for a batch. */
+int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable);
+int t2gpu_rx_wait(t2gpu_rx *h);
 int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6);          /* t2gpu_ldpc_occupancy of the handle's decoder */
 int t2gpu_rx_reset(t2gpu_rx *h);
 int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, long *p2_start, float *cp4, float *level_detect, float *ldpc_ms);

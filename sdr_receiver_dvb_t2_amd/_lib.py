@@ -99,6 +99,8 @@ PROTOTYPES = {
     "t2gpu_rx_create": (_vp, [_vp, ctypes.c_int]),
     "t2gpu_rx_destroy": (None, [_vp]),
     "t2gpu_rx_info": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_set_overlap": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_rx_wait": (ctypes.c_int, [_vp]),
     "t2gpu_rx_front_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     "t2gpu_rx_back_dev": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_rx_execute_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp]),

@@ -49,7 +49,16 @@ struct t2gpu_rx {
     // device buffers
     float *d_stream = nullptr, *d_spec = nullptr, *d_p2_in = nullptr, *d_p2_cells = nullptr, *d_fc_cells = nullptr, *d_cells = nullptr,
           *d_ti_out = nullptr, *d_sums = nullptr, *d_cp = nullptr;
-    int8_t *d_llr = nullptr;
+    int8_t *d_llr = nullptr;                  // the LLR rows the next back half fills (= d_llr_ab[cur])
+    // t2gpu_rx_set_overlap: the decode of a call (LDPC, descrambler + packing) runs on a stream of the handle's own, so that the next
+    // call's front end .. demapper run beside it where the decoder leaves CUs free (calls of one or two T2 frames: 6 - 13 SIMD batches
+    // = 96 - 208 of 256 workgroups). Two LLR buffers alternate: the decoder reads one while the demapper fills the other.
+    bool overlap = false;
+    hipStream_t dec = nullptr;
+    int8_t *d_llr_ab[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipEvent_t ev_demap = nullptr, ev_dec_done[2] = {nullptr, nullptr}, ev_l1_copied = nullptr;
+    bool dec_done_set[2] = {false, false}, l1_copied_set = false;
     uint8_t *d_bits = nullptr, *d_out = nullptr;
     int32_t *d_trials = nullptr, *d_outer = nullptr;
     bool outer_code = false;
@@ -133,6 +142,9 @@ void free_all(t2gpu_rx *h)
     if (h->side) hipStreamDestroy(h->side);
     for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
     hipFree(h->d_sync); hipFree(h->d_pack); hipFree(h->d_l1);
+    if (h->d_llr_ab[1]) hipFree(h->d_llr_ab[1] == h->d_llr ? h->d_llr_ab[0] : h->d_llr_ab[1]);   // (whichever is not d_llr, freed above)
+    if (h->dec) hipStreamDestroy(h->dec);
+    for (hipEvent_t e : {h->ev_demap, h->ev_dec_done[0], h->ev_dec_done[1], h->ev_l1_copied}) if (e) hipEventDestroy(e);
 }
 
 void ts_stop(t2gpu_rx *h)
@@ -340,11 +352,11 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
 }
 
 // LDPC + (opt-in outer code) + K-descramble-pack of d_llr[0 .. count) into rows `at`.. of d_bits / d_pack, trials from batch `at / group`
-int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s)
+int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s, const int8_t *llr = nullptr)
 {
     uint8_t *bits = h->d_bits + (size_t)at * h->k_ldpc;
     T2_HIP(hipEventRecord(h->ev_ldpc0, s));
-    if (t2gpu_ldpc_execute_dev(h->ldpc, h->d_llr, count, bits, nullptr, h->d_trials + at / h->group, s) != 0) return -1;
+    if (t2gpu_ldpc_execute_dev(h->ldpc, llr ? llr : h->d_llr, count, bits, nullptr, h->d_trials + at / h->group, s) != 0) return -1;
     T2_HIP(hipEventRecord(h->ev_ldpc1, s));
     h->timed = true;
     if (!mark(h, 8, s)) return -1;                                                      // LDPC
@@ -354,7 +366,7 @@ int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s)
     return 0;
 }
 
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s);
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after = nullptr);
 }  // namespace
 
 // BASELINE config 2: FFT (guard dropped) + equalisers / frequency de-interleave + time de-interleave + demap of the frames the last
@@ -381,13 +393,43 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
     T2_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
+    const int total = h->carry + F * nb;
+    const int ready = (total / h->group) * h->group, rest = total - ready;
+    if (h->overlap) {
+        // ---- the decode on the handle's own stream (t2gpu_rx_set_overlap)
+        int8_t *llr = h->d_llr, *other = h->d_llr_ab[1 - h->cur];
+        // this buffer was last read by the decode of two calls ago; d_l1 is read by the host end's copy of the previous call
+        if (h->dec_done_set[h->cur]) T2_HIP(hipStreamWaitEvent(s, h->ev_dec_done[h->cur], 0));
+        if (h->l1_copied_set) T2_HIP(hipStreamWaitEvent(s, h->ev_l1_copied, 0));
+        if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
+        T2_HIP(hipEventRecord(h->ev_demap, s));
+        hipStream_t d = h->dec;
+        T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
+        // the host end's copies of the previous decode read the rows this decode overwrites
+        if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(d, h->ts->last_copy, 0));
+        if (ready > 0) {
+            // the frames behind the last complete batch go to the head of the other buffer (its last reader, the previous decode, is
+            // earlier on this stream); the next call's demapper writes behind them
+            if (rest > 0) T2_HIP(hipMemcpyAsync(other, llr + (size_t)ready * h->fec_size, (size_t)rest * h->fec_size, hipMemcpyDeviceToDevice, d));
+            if (rx_decode(h, ready, 0, d, llr) != 0) return -1;
+            T2_HIP(hipEventRecord(h->ev_dec_done[h->cur], d));
+            h->dec_done_set[h->cur] = true;
+            h->cur = 1 - h->cur;
+            h->d_llr = h->d_llr_ab[h->cur];
+        }
+        h->carry = rest;
+        h->last_ready = ready;
+        if (h->ts && ts_submit(h, ready, 0, F, d, h->ev_demap) != 0) return -1;
+        h->fec_seq += ready;
+        h->t2_seq += F;
+        if (d_bytes_out) *d_bytes_out = h->d_pack;
+        if (d_trials_out) *d_trials_out = h->d_trials;
+        return ready;
+    }
     // the host end's copies of the previous decode run on their own stream: they must be through before this call overwrites the rows
     if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(s, h->ts->last_copy, 0));
     if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
-    const int total = h->carry + F * nb;
-    const int ready = (total / h->group) * h->group;
     if (ready > 0 && rx_decode(h, ready, 0, s) != 0) return -1;
-    const int rest = total - ready;
     if (rest > 0 && ready > 0)                                   // ready >= group > rest: source and destination do not overlap
         T2_HIP(hipMemcpyAsync(h->d_llr, h->d_llr + (size_t)ready * h->fec_size, (size_t)rest * h->fec_size, hipMemcpyDeviceToDevice, s));
     h->carry = rest;
@@ -406,7 +448,7 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
 {
     if (!h) { set_error("t2gpu_rx_flush_dev: null handle"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = h->overlap ? h->dec : (hipStream_t)stream;       // (overlap: the waiting frames were put in place on the decode stream)
     const int n = h->carry;
     if (n == 0) return 0;
     const int at = h->last_ready;                                // a multiple of the group: trials of the short batch at at / group
@@ -420,6 +462,33 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
 }
 
 extern "C" int t2gpu_rx_carry(const t2gpu_rx *h) { return h ? h->carry : -1; }
+
+// Decode of a call beside the next call's front half (see the members). To be set on a drained handle with nothing waiting.
+extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
+{
+    if (!h) { set_error("t2gpu_rx_set_overlap: null handle"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipDeviceSynchronize());
+    if (h->carry != 0) { set_error("t2gpu_rx_set_overlap: frames are waiting for a batch (flush or reset first)"); return -1; }
+    if (enable && !h->dec) {
+        const size_t bytes = ((size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + h->row_pad) * h->fec_size;
+        h->d_llr_ab[0] = h->d_llr;
+        T2_HIP(hipMalloc(&h->d_llr_ab[1], bytes));
+        T2_HIP(hipStreamCreateWithFlags(&h->dec, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&h->ev_demap, &h->ev_dec_done[0], &h->ev_dec_done[1], &h->ev_l1_copied}) T2_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        h->cur = 0;
+    }
+    h->overlap = enable != 0;
+    if (!h->overlap && h->dec) { h->cur = 0; h->d_llr = h->d_llr_ab[0]; h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false; }
+    return 0;
+}
+extern "C" int t2gpu_rx_wait(t2gpu_rx *h)
+{
+    if (!h) { set_error("t2gpu_rx_wait: null handle"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (h->dec) T2_HIP(hipStreamSynchronize(h->dec));
+    return 0;
+}
 extern "C" int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6) { return h ? t2gpu_ldpc_occupancy(h->ldpc, out6) : -1; }
 
 extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
@@ -435,6 +504,7 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
         t2gpu_bbdh_reset(h->ts->bbdh);
     }
     h->carry = 0; h->last_ready = 0; h->fec_seq = 0; h->t2_seq = 0;
+    h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false;
     return 0;
 }
 
@@ -560,7 +630,9 @@ void ts_worker(TsEnd *t)
 
 // queue the device -> host copies of one decode (packed BBFRAME rows at.., their trials, the L1 cells of the call's T2 frames) behind it
 // on the stream and hand the job to the worker. Blocks only when all slots are still in use (the host end is SLOTS calls behind).
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s)
+// l1_after (overlap mode): the L1 cells are complete at that event already -- their copy is queued behind it and in front of the decode's
+// (the next call's P2 equaliser, which overwrites them, waits for ev_l1_copied, not for this call's decode)
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after)
 {
     TsEnd *t = h->ts;
     if (fec_frames == 0 && t2_frames == 0) return 0;
@@ -576,12 +648,20 @@ int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s)
     TsSlot &sl = t->slot[k];
     const int row = h->k_bch / 8;
     hipStream_t cs = t->copy_stream;
-    bool ok = hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
+    bool ok = true;
+    const bool l1_now = t2_frames > 0 && t->l1_check;
+    if (l1_now && l1_after) {
+        ok = hipStreamWaitEvent(cs, l1_after, 0) == hipSuccess &&
+             hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+             hipEventRecord(h->ev_l1_copied, cs) == hipSuccess;
+        h->l1_copied_set = ok;
+    }
+    ok = ok && hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
     if (ok && fec_frames > 0) {
         ok = hipMemcpyAsync(sl.trials, h->d_trials + at / h->group, (size_t)((fec_frames + h->group - 1) / h->group) * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
              hipMemcpyAsync(sl.pack, h->d_pack + (size_t)at * row, (size_t)fec_frames * row, hipMemcpyDeviceToHost, cs) == hipSuccess;
     }
-    if (ok && t2_frames > 0 && t->l1_check)
+    if (ok && l1_now && !l1_after)
         ok = hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
     ok = ok && hipEventRecord(sl.ready, cs) == hipSuccess;
     t->last_copy = ok ? sl.ready : nullptr;

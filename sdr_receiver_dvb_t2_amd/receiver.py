@@ -251,6 +251,14 @@ class t2_rx(object):
     def carry(self):
         return self._l.t2gpu_rx_carry(self._h)
 
+    def set_overlap(self, enable=True):
+        """The decode of a call on the handle's own stream, beside the next call's front half (t2gpu_rx_set_overlap): for calls of one or
+        two T2 frames, whose SIMD batches leave CUs free. Results are complete after wait() / any fetch."""
+        self._check(self._l.t2gpu_rx_set_overlap(self._h, int(bool(enable))), "t2gpu_rx_set_overlap")
+
+    def wait(self):
+        self._check(self._l.t2gpu_rx_wait(self._h), "t2gpu_rx_wait")
+
     def reset(self):
         self._check(self._l.t2gpu_rx_reset(self._h), "t2gpu_rx_reset")
 

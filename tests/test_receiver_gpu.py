@@ -304,3 +304,66 @@ def test_stage_timers_config2_entry_point_and_sync_sums(torch_cuda):
     assert all(ms2[k] > 0 for k in ("fft", "equalise", "ti", "demap")) and all(ms2[k] < 0 for k in ("front", "p1", "guard_corr", "ldpc", "descramble"))
     assert np.array_equal(rx.sync_sums(n_frames), sync0)                       # the same spectra equalised again: the same sums
     rx.close()
+
+
+def test_overlapped_decode_equals_plain_calls(torch_cuda):
+    """t2gpu_rx_set_overlap: the decode of a call on the handle's own stream beside the next call's front half (two LLR buffers, the
+    waiting frames carried from one to the other, the L1 cells copied ahead of the decode). Six one-frame calls of a 16K / 64-QAM /
+    16200 r1/2 stream (41 FEC frames per T2 frame: SIMD batches form across calls, 9 .. 27 frames wait in between) with the library's
+    host end on: the same packed rows per call, the same verdicts, the same TS bytes as the plain schedule, and the flush at the end."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    mode, lps, mod, fec_type, code_rate, s2 = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 8
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 16200 // (2 * (mod + 1))
+    nb_full = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    nb = 41                                                        # not a multiple of 32: batches straddle the calls
+    assert nb <= nb_full
+    k_bch = t2_tx.K_BCH[cid]
+    n_frames, seed = 6, 123
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
+    frames, pos = [], 0
+    for f in range(n_frames):
+        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, pos, nb, k_bch), nb)
+        l1 = t2_tx.l1_cells(mode, lps, mod, fec_type, code_rate, nb, frame_idx=f)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1))
+        pos += nb
+    probe = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
+    i16, q16, frame_len = t2_tx.iq_stream(frames, probe.geometry.guard_interval_size, s2, 16.0, seed)
+    assert frame_len == probe.frame_len
+    probe.close()
+    di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
+
+    def run(overlap):
+        rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
+        rx.ts_enable(0, l1_check=True)
+        if overlap:
+            rx.set_overlap(True)
+        rows, verdicts, counts = [], [], []
+        for f in range(n_frames):
+            a = f * frame_len
+            n = rx.execute_dev(di[a:a + frame_len], dq[a:a + frame_len], 1, first_call=(f == 0))
+            counts.append(n)
+            if n:
+                r, t = rx.fetch_packed(n)
+                rows.append(r); verdicts.append(t)
+        n = rx.flush_dev()
+        counts.append(n)
+        if n:
+            r, t = rx.fetch_packed(counts[-2] + n)                  # the rows of the flush follow the last back half's
+            rows.append(r[counts[-2]:]); verdicts.append(t)
+        ts_bytes = rx.ts_read(wait_all=True)
+        c = rx.ts_counters()
+        rx.close()
+        return counts, rows, verdicts, ts_bytes, c
+
+    pc, pr, pv, pts, pcnt = run(False)
+    oc, orr, ov, ots, ocnt = run(True)
+    assert pc == oc and sum(pc) == n_frames * nb and any(0 < x < nb for x in pc[:-1])
+    assert len(pr) == len(orr) and all(np.array_equal(a, b) for a, b in zip(pr, orr))
+    assert all(np.array_equal(a, b) for a, b in zip(pv, ov)) and all((v >= 0).all() for v in pv)
+    assert pts.size > 0 and np.array_equal(pts, ots)
+    for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "l1_pre_crc_errors", "l1_post_crc_errors", "ts_bytes"):
+        assert pcnt[k] == ocnt[k], k
+    assert pcnt["fec_frames_dropped_l1"] == 0 and pcnt["fec_frames"] == n_frames * nb
