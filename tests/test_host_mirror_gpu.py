@@ -25,8 +25,9 @@ def driver(built, tmp_path_factory):
     return out
 
 
-def run(driver, *args):
+def run(driver, *args, env_extra=None):
     env = dict(os.environ)
+    env.update(env_extra or {})
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     p = subprocess.run([driver] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr
@@ -160,6 +161,12 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
     ts = np.fromfile(tmp_path / "ts.u8", np.uint8)
     n_pkts = ((96 - n0) * ((k_bch - 80) // 8)) // 187 - 1
     assert np.array_equal(ts[:n_pkts * 188], ts1.reshape(-1)[:n_pkts * 188])
+    # the same chain with the device twins of the stage outputs switched off (every stage copies its input in, as in rounds 1-3):
+    # the hand-over by address changes where the bytes come from, not one of them
+    run(driver, "cells", tmp_path / "cells.c64", tmp_path / "out0.u8", 1, tmp_path / "ts0.u8", lps, code_rate, len(sizes), *sizes, 2, *plps,
+        env_extra={"T2GPU_HANDOFF": "0"})
+    assert np.array_equal(np.fromfile(tmp_path / "out0.u8", np.uint8), got.reshape(-1))
+    assert np.array_equal(np.fromfile(tmp_path / "ts0.u8", np.uint8), ts)
 
 
 def _unconfigured_stream(tmp_path, n_frames, seed, cfo_hz, spoil_frame=None):
