@@ -240,12 +240,14 @@ DROP_IN_EXE = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "bin", "t2gpu_rx_fil
 DROP_IN_BUF = 172032          # samples per execute() call: norm_blocks x 384 of the reference's SDRplay thread (rx_sdrplay.h:64, rx_sdrplay.cpp:199-261)
 
 
-def drop_in_leg(w, ui, uq, device, frames=14, warm_frames=4):
+def drop_in_leg(w, ui, uq, device, frames=14, warm_frames=4, sent=None, saturate=False, snr_db=None):
     """The slot-shaped path: int16 I/Q in device-buffer-sized calls through t2::dvbt2_demodulator::execute (t2gpu_demod_execute: closed
     tracking loops, the reference's own acquisition from P1 / guard search / L1-pre / L1-post) and the stage classes of
     include/t2gpu_stages.hpp wired as the reference wires its objects (time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder ->
     bb_de_header), in a plain C++ process (examples/t2gpu_rx_file.cpp, built by csrc/Makefile). The first warm_frames frames'
-    worth of buffers (acquisition) run before the program's clock starts."""
+    worth of buffers (acquisition) run before the program's clock starts. sent: the TS packets the frames carry -- every packet that
+    comes out is then looked up among them. saturate: the clamped-LLR extension (the reference's wrapping cast loses every 256-QAM
+    SIMD batch, here as in the batch legs)."""
     import subprocess
     import tempfile
     import numpy as np
@@ -260,24 +262,36 @@ def drop_in_leg(w, ui, uq, device, frames=14, warm_frames=4):
         env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
         t0 = time.perf_counter()
         wrap = os.environ.get("T2GPU_DROPIN_WRAPPER", "").split()          # e.g. "rocprofv3 --kernel-trace --stats -d gpurun_out/x --"
-        p = subprocess.run(wrap + [DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", "/dev/null", "--buf", str(DROP_IN_BUF),
-                            "--warm", str(warm), "--json", "1", "--device", str(device)],
+        ts_path = os.path.join(d, "out.ts")
+        p = subprocess.run(wrap + [DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", ts_path, "--buf", str(DROP_IN_BUF),
+                            "--warm", str(warm), "--json", "1", "--device", str(device), "--saturate", "1" if saturate else "0"],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
         wall = time.perf_counter() - t0
+        ts = np.fromfile(ts_path, np.uint8) if p.returncode == 0 and os.path.exists(ts_path) else np.zeros(0, np.uint8)
     if p.returncode != 0:
         return {"error": p.stderr[-400:]}
-    if os.environ.get("T2GPU_DEMOD_PROF"):
-        sys.stderr.write(p.stderr[p.stderr.find("t2gpu_demod profile"):] if "t2gpu_demod profile" in p.stderr else "")
+    if os.environ.get("T2GPU_DEMOD_PROF") or os.environ.get("T2GPU_RX_PROF"):
+        sys.stderr.write("".join(l + "\n" for l in p.stderr.splitlines() if l.startswith("  ") or l.startswith("t2gpu_demod profile")))
     r = json.loads(p.stdout.strip().splitlines()[-1])
     dropped = p.stderr.count("LDPC decoder could not recover the codeword!")
-    return {"value": round(r["msamples_per_s"], 1), "unit": "Msamples/s", "real_time_factor": round(r["msamples_per_s"] / (64.0 / 7.0), 1),
-            "samples_per_call": DROP_IN_BUF, "calls_timed": r["buffers"], "t2_frames_timed": r["t2_frames"], "seconds": round(r["seconds"], 4),
-            "bbframes": r["bbframes"], "ts_bytes": r["ts_bytes"], "simd_batches_dropped_by_ldpc": dropped, "resets": r["resets"],
-            "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2),
-            "entry": "t2::dvbt2_demodulator::execute(len, i, q, signal) per buffer = t2gpu_demod_execute, host buffers between all stage "
-                     "classes as the reference's slots carry them; loops closed, nothing configured (mode from P1 / L1)",
-            "workload": "%s, %d frames of int16 I/Q at %.0f dB, the first %d frames' buffers untimed (acquisition)"
-                        % (w.cfg["name"], frames, w.cfg["snr"], warm_frames)}
+    out = {"value": round(r["msamples_per_s"], 1), "unit": "Msamples/s", "real_time_factor": round(r["msamples_per_s"] / (64.0 / 7.0), 1),
+           "samples_per_call": DROP_IN_BUF, "calls_timed": r["buffers"], "t2_frames_timed": r["t2_frames"], "seconds": round(r["seconds"], 4),
+           "bbframes": r["bbframes"], "ts_bytes": r["ts_bytes"], "simd_batches_dropped_by_ldpc": dropped, "resets": r["resets"],
+           "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2), "llr_cast": "clamped (extension)" if saturate else "reference (wraps)"}
+    if sent is not None:
+        # whole packets of the program's output (from the start of the file: the first BBFRAME's SYNCD puts it on a packet boundary) among those sent
+        pk = ts[:ts.size // 188 * 188].reshape(-1, 188)
+        pk = pk[pk[:, 0] == 0x47] if pk.size else pk
+        want = np.unique(packet_hashes(np.concatenate(sent)))
+        hit = int(np.isin(packet_hashes(pk), want).sum()) if pk.shape[0] else 0
+        out["ts_packets"] = int(pk.shape[0])
+        out["ts_packets_that_were_sent"] = hit
+        out["ts_matches_sent"] = bool(pk.shape[0] > 0 and hit >= pk.shape[0] - 2 * frames)     # a cut packet at a dropped batch / the stream's first
+    out["entry"] = ("t2::dvbt2_demodulator::execute(len, i, q, signal) per buffer = t2gpu_demod_execute, host buffers between all stage "
+                    "classes as the reference's slots carry them; loops closed, nothing configured (mode from P1 / L1)")
+    out["workload"] = "%s, %d frames of int16 I/Q at %.1f dB, the first %d frames' buffers untimed (acquisition)" % (
+        w.cfg["name"], frames, w.cfg["snr"] if snr_db is None else snr_db, warm_frames)
+    return out
 
 
 def packet_hashes(packets):
@@ -337,6 +351,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informative legs: 50-trial point, clamped-LLR variant, config 5 (profiling runs)")
     ap.add_argument("--no-clamped-variant", action="store_true", help="(kept for old command lines) same as --no-extra-legs")
     ap.add_argument("--only-drop-in", action="store_true", help="run the drop_in leg alone (the slot-shaped path) and print its JSON")
+    ap.add_argument("--saturate", action="store_true", help="with --only-drop-in: the clamped-LLR extension instead of the reference's wrapping cast")
     ap.add_argument("--no-ts-end", action="store_true", help="leave the library's host end (L1 parse + de-framing worker) off")
     args = ap.parse_args()
     if args.no_clamped_variant:
@@ -371,8 +386,8 @@ def main():
 
     if args.only_drop_in:
         w = Workload(CONFIGS[args.config])
-        ui, uq, _ = make_frames(w, 2, args.snr if args.snr is not None else CONFIGS[args.config]["snr"], seed=20250614)
-        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 14)))
+        ui, uq, sent = make_frames(w, 2, args.snr if args.snr is not None else CONFIGS[args.config]["snr"], seed=20250614)
+        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 14, sent=sent, saturate=args.saturate, snr_db=args.snr)))
         return
 
     def run_config(cfg_id, steps, warmup, extras, check_ts=False):
@@ -552,7 +567,15 @@ def main():
                 r["overlapped_of_full_batch_rate"] = round(r["overlapped_msamples_per_s"] / top, 3)
             extra["frames_sweep"] = sweep
             # (iv) the same input through the reference's own call shape (slot by slot, device-buffer-sized calls, loops closed)
-            extra["drop_in"] = drop_in_leg(w, ui, uq, local_rank)
+            # -- with the reference's cast (all 256-QAM batches dropped by the LDPC stage, as in the headline leg), then with clamped LLRs so
+            # that the transport stream comes out and is checked; config 4 (64-QAM: the cast does not wrap) through the same program
+            d_in = drop_in_leg(w, ui, uq, local_rank, sent=sent)
+            d_in["clamped_llr_variant"] = {k: v for k, v in drop_in_leg(w, ui, uq, local_rank, sent=sent, saturate=True).items() if k not in ("entry", "workload", "unit")}
+            if cfg_id != 4:
+                w4 = Workload(CONFIGS[4])
+                ui4, uq4, sent4 = make_frames(w4, 2, CONFIGS[4]["snr"], seed=20250614)
+                d_in["config_4"] = {k: v for k, v in drop_in_leg(w4, ui4, uq4, local_rank, frames=40, warm_frames=12, sent=sent4).items() if k != "entry"}
+            extra["drop_in"] = d_in
 
         if rank != 0:
             return None

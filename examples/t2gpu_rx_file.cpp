@@ -10,10 +10,12 @@
 //           reference's constructors wire them (include/t2gpu_stages.hpp), every stage a call into libt2gpu.so.
 //
 // build:  g++ -O2 -std=c++17 -I../include t2gpu_rx_file.cpp -L../sdr_receiver_dvb_t2_amd -lt2gpu -Wl,-rpath,$PWD/../sdr_receiver_dvb_t2_amd -o t2gpu_rx_file
-// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1]
+// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1] [--saturate 0]
 //         --buf: samples per execute() call (the reference's SDRplay thread hands over norm_blocks x 384 = 172 032, rx_sdrplay.h:64)
 //         --warm n: the first n buffers (acquisition: P1, guard search, L1) run before the clock starts; --json 1: one JSON line on
-//         stdout with the throughput of the timed buffers (bench.py's drop_in leg reads it)
+//         stdout with the throughput of the timed buffers (bench.py's drop_in leg reads it); --saturate 1: LLRs clamped to int8
+//         instead of the reference's wrapping cast (an extension, t2::llr_demapper::saturate_llr -- with the cast a 256-QAM PLP in
+//         AWGN loses every SIMD batch in the LDPC stage, in the reference as here)
 #include <arpa/inet.h>
 #include <chrono>
 #include <cstdio>
@@ -44,7 +46,7 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *out_path = nullptr;
-    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0;
+    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0, saturate = 0;
     for (int a = 3; a + 1 < argc; a += 2) {
         if (!std::strcmp(argv[a], "--out")) out_path = argv[a + 1];
         else if (!std::strcmp(argv[a], "--udp")) udp_port = std::atoi(argv[a + 1]);
@@ -53,6 +55,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[a], "--device")) device = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--warm")) warm = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--json")) json = std::atoi(argv[a + 1]);
+        else if (!std::strcmp(argv[a], "--saturate")) saturate = std::atoi(argv[a + 1]);
     }
     if ((!out_path && !udp_port) || buf_len < 4096) return 2;
     const std::vector<int16_t> vi = slurp(argv[1]), vq = slurp(argv[2]);
@@ -67,14 +70,26 @@ int main(int argc, char **argv)
     try {
         t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f, device);
         t2::llr_demapper qam(device);
+        qam.saturate_llr = saturate != 0;
         t2::ldpc_decoder ldpc(device);
         t2::bch_decoder bch;
         t2::bb_de_header deheader(need_plp);
         long bbframes = 0, ts_bytes = 0;
-        demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
-        qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
-        ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
-        bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; deheader.execute(plp_id, p, len, bits); };
+        // T2GPU_RX_PROF=1: wall time inside each slot (inclusive of the slots it calls in turn), printed at the end
+        const bool prof = std::getenv("T2GPU_RX_PROF") && std::atoi(std::getenv("T2GPU_RX_PROF"));
+        double t_slot[5] = {0, 0, 0, 0, 0};
+        long n_slot[5] = {0, 0, 0, 0, 0};
+        auto timed = [&](int k, auto &&call) {
+            if (!prof) { call(); return; }
+            const auto a = std::chrono::steady_clock::now();
+            call();
+            t_slot[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+            ++n_slot[k];
+        };
+        demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { timed(0, [&] { qam.execute(n, c, plp, p); }); };
+        qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { timed(1, [&] { ldpc.execute(idx, p, len, llr); }); };
+        ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { timed(2, [&] { bch.execute(idx, p, len, bits); }); };
+        bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; timed(3, [&] { deheader.execute(plp_id, p, len, bits); }); };
         deheader.write_out = [&](const uint8_t *b, int n) {
             ts_bytes += n;
             if (file) std::fwrite(b, 1, (size_t)n, file);
@@ -139,6 +154,11 @@ int main(int argc, char **argv)
                         "\"bbframes\": %ld, \"ts_bytes\": %ld, \"symbols\": %ld, \"resets\": %ld, \"deint_start\": %d}\n",
                         pos - timed_from, secs, (pos - timed_from) / secs / 1e6, n_buf - warm, buf_len, (long)st.frames - frames0, bbframes - bb0,
                         ts_bytes - ts0, (long)st.symbols, (long)st.resets, (int)st.deint_start);
+        if (prof) {
+            static const char *const name[4] = {"llr_demapper::execute", "ldpc_decoder::execute", "bch_decoder::execute", "bb_de_header::execute"};
+            for (int k = 0; k < 4; ++k)
+                std::fprintf(stderr, "  %-26s %9.3f ms inclusive  %7ld calls  %8.1f us each\n", name[k], t_slot[k] * 1e3, n_slot[k], n_slot[k] ? t_slot[k] * 1e6 / n_slot[k] : 0.0);
+        }
         std::fprintf(stderr, "%zu samples in %.3f s (%.1f Msamples/s, real time 9.14), %ld symbols, %ld T2 frames, %ld BBFRAMEs, %ld TS bytes\n",
                      pos, secs, pos / secs / 1e6, (long)st.symbols, (long)st.frames, bbframes, ts_bytes);
     } catch (const std::exception &e) {

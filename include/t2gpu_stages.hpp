@@ -188,6 +188,9 @@ public:
     ~llr_demapper() { release(); }
     std::function<void(float snr)> signal_noise_ratio;                                                             // llr_demapper.h:38
     std::function<void(int *idx_plp_simd, const l1_postsignalling &, int len_out, int8_t *out)> soft_multiplexer_de_twist;   // :39
+    // NOT in the reference (t2gpu_demap_configure): clamp the LLRs to int8 instead of the reference's wrapping cast (llr_demapper.cpp:722-737).
+    // With the cast, 256-QAM loses every SIMD batch in AWGN (the outer points wrap at any SNR); off unless the caller sets it.
+    bool saturate_llr = false;
     // slot (llr_demapper.h:44-45, llr_demapper.cpp:132-158): one TI block of cells in; LLR frames are collected into batches of
     // SIZEOF_SIMD and handed on whenever one is full (:742-764), the remainder waits for the next TI block.
     // The two batch buffers (the reference's A / B) are page-locked and have a twin on the device that is filled as they are
@@ -202,6 +205,11 @@ public:
             cells_max_ = std::max((p.plp_num_blocks_max > 0 ? p.plp_num_blocks_max : 1) * cpf, ti_block_size);
             if (!(h_ = t2gpu_demap_create(p.plp_mod, p.plp_fec_type, p.plp_cod, p.plp_rotation, cells_max_, device_))) fail("t2gpu_demap_create");
             key_ = key(p);
+            saturated_ = false;
+        }
+        if (saturated_ != saturate_llr) {
+            if (t2gpu_demap_configure(h_, saturate_llr ? 1 : 0) != 0) fail("t2gpu_demap_configure");
+            saturated_ = saturate_llr;
         }
         // buffers grow, never shrink, and a batch in the making survives a change of PLP (frames of several PLPs share a SIMD batch,
         // llr_demapper.cpp:742-764: idx_plp_simd says whose each one is)
@@ -250,7 +258,7 @@ private:
     t2gpu_demap *h_ = nullptr;
     int idx_plp_simd[SIZEOF_SIMD] = {};
     std::vector<int8_t> frames_, buffer_a, buffer_b;
-    bool swap_buffer = true;
+    bool swap_buffer = true, saturated_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- time de-interleaver

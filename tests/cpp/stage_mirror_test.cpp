@@ -120,8 +120,15 @@ int main(int argc, char **argv)
             t2::bch_decoder bch;
             t2::bb_de_header deheader(need_plp);
             std::vector<uint8_t> out, ts;
-            ti.ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
-            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+            // STAGE_DUMP=<prefix>: what crosses the first two signals is also appended to <prefix>.ti.c64 / <prefix>.llr.i8
+            const char *dump_to = std::getenv("STAGE_DUMP");
+            auto append = [&](const char *ext, const void *p, size_t bytes) {
+                if (!dump_to) return;
+                std::FILE *f = std::fopen((std::string(dump_to) + ext).c_str(), "ab");
+                if (f) { std::fwrite(p, 1, bytes, f); std::fclose(f); }
+            };
+            ti.ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { append(".ti.c64", c, (size_t)n * sizeof(t2::complex)); qam.execute(n, c, plp, p); };
+            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { append(".llr.i8", llr, (size_t)len); ldpc.execute(idx, p, len, llr); };
             ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
             bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) {
                 out.push_back((uint8_t)plp_id);
@@ -151,12 +158,37 @@ int main(int argc, char **argv)
             t2::bb_de_header deheader(need_plp);
             std::vector<uint8_t> ts;
             long bbframes = 0;
-            demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
-            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+            const char *dump_fec = std::getenv("STAGE_DUMP");
+            auto append_fec = [&](const char *ext, const void *p, size_t bytes) {
+                if (!dump_fec) return;
+                std::FILE *f = std::fopen((std::string(dump_fec) + ext).c_str(), "ab");
+                if (f) { std::fwrite(p, 1, bytes, f); std::fclose(f); }
+            };
+            demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) {
+                if (dump_fec) {
+                    const t2gpu_l1_plp &q = p.plp.at((size_t)plp);
+                    std::fprintf(log, "ti_block %d plp %d mod %d cod %d fec %d rot %d blocks_max %d til %d type %d dyn start %d blocks %d\n", n, plp, q.plp_mod, q.plp_cod,
+                                 q.plp_fec_type, q.plp_rotation, q.plp_num_blocks_max, q.time_il_length, q.time_il_type, p.dyn_plp.at((size_t)plp).start, p.dyn_plp.at((size_t)plp).num_blocks);
+                    append_fec(".ti.c64", c, (size_t)n * sizeof(t2::complex));
+                }
+                qam.execute(n, c, plp, p);
+            };
+            qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { append_fec(".llr.i8", llr, (size_t)len); ldpc.execute(idx, p, len, llr); };
             ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
             bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; deheader.execute(plp_id, p, len, bits); };
             deheader.write_out = [&](const uint8_t *b, int n) { ts.insert(ts.end(), b, b + n); };
             demodulator.amount_plp = [&](int n) { std::fprintf(log, "amount_plp %d\n", n); };
+            if (const char *dump_to = std::getenv("STAGE_DUMP")) {             // the cells of every signal, appended to <prefix>.cells.c64 (+ a line per signal in the log)
+                const std::string path = std::string(dump_to) + ".cells.c64";
+                auto append = [path](const t2::complex *c, int n) {
+                    std::FILE *f = std::fopen(path.c_str(), "ab");
+                    if (f) { std::fwrite(c, sizeof(t2::complex), (size_t)n, f); std::fclose(f); }
+                };
+                auto fwd_l1 = demodulator.l1_dyn_execute;
+                auto fwd_data = demodulator.data;
+                demodulator.l1_dyn_execute = [=](const t2::l1_postsignalling &p, int len, t2::complex *c) { std::fprintf(log, "cells p2 %d\n", len); append(c, len); fwd_l1(p, len, c); };
+                demodulator.data = [=](int len, t2::complex *c) { std::fprintf(log, "cells data %d\n", len); append(c, len); fwd_data(len, c); };
+            }
             // ---- the SDR thread (rx_sdrplay.cpp:135-261) over a recording
             t2::signal_estimate signal;
             double rf_frequency = 0, ch_frequency = 626.0e6, tuner_hz = 0;

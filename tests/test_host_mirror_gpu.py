@@ -272,3 +272,53 @@ def test_example_rx_file_program(driver, tmp_path):
         at = want.find(d, pos)
         assert at >= 0
         pos = at + len(d)
+
+
+def test_example_program_on_the_benchmark_mode(tmp_path):
+    """The slot-shaped path on BASELINE config 3's mode (32K extended PP7 GI 1/128, 59 data symbols, one 256-QAM 64800 r=3/4 PLP of 202 FEC
+    blocks per frame), nothing configured. With the reference's int8 cast every SIMD batch of a 256-QAM PLP is lost in the LDPC stage
+    (the outer constellation points wrap, llr_demapper.cpp:722-737) -- the program reports exactly that; with
+    t2::llr_demapper::saturate_llr (the clamping extension) the transport stream of the frames behind the acquisition comes out,
+    every packet one of those sent."""
+    import json
+    exe = str(tmp_path / "t2gpu_rx_file")
+    pkg = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "t2gpu_rx_file.cpp"), "-L" + pkg, "-lt2gpu", "-Wl,-rpath," + pkg, "-o", exe])
+    mode, lps, mod, fec_type, code_rate = (5, 1, 6, 4, 0, 59), 350, 3, 1, 3
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = 64800 // (2 * (mod + 1))
+    nb = t2_tx.plp_blocks_per_frame(m, lps, cpf)
+    k_bch = t2_tx.K_BCH[cid]
+    per = nb * (k_bch // 1496 + 1)
+    frames, sent = [], []
+    for f in range(2):
+        ts = t2_tx.ts_packets(per, 700 + f)
+        stream, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, nb)
+        l1 = t2_tx.l1_cells(mode, lps, mod, fec_type, code_rate, nb, frame_idx=f)
+        frames.append(t2_tx.build_frame(m, stream, lps, 800 + f, snr_db=None, phase=0.0, l1_cells=l1))
+        sent.append(ts)
+    i16, q16, flen = t2_tx.iq_stream(frames, m.fft_size // 128, 10, 21.0, 9)
+    n_frames = 10
+    np.concatenate([i16] * (n_frames // 2)).tofile(tmp_path / "i.s16")
+    np.concatenate([q16] * (n_frames // 2)).tofile(tmp_path / "q.s16")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    want = {bytes(p) for p in np.concatenate(sent)}
+    for saturate in (0, 1):
+        p = subprocess.run([exe, str(tmp_path / "i.s16"), str(tmp_path / "q.s16"), "--out", str(tmp_path / "out.ts"), "--json", "1", "--saturate", str(saturate)],
+                           check=True, env=env, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["deint_start"] == 1 and r["resets"] == 0, r
+        dropped = p.stderr.count("LDPC decoder could not recover the codeword!")
+        got = np.fromfile(tmp_path / "out.ts", np.uint8)
+        if not saturate:
+            assert r["bbframes"] == 0 and got.size == 0 and dropped >= 3 * nb // 32, (r, dropped)
+            continue
+        assert dropped == 0 and r["bbframes"] >= 3 * nb // 32 * 32, (r, dropped)
+        pk = got[:got.size // 188 * 188].reshape(-1, 188)
+        assert pk.shape[0] > 3 * nb * ((k_bch - 80) // 8 // 188) and (pk[:, 0] == 0x47).all()
+        bad = sum(bytes(row) not in want for row in pk)
+        # each T2 frame carries its own packet set: the packet that straddles two frames is half of one and half of the other
+        assert bad <= n_frames, (bad, pk.shape[0])
