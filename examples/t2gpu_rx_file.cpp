@@ -75,21 +75,10 @@ int main(int argc, char **argv)
         t2::bch_decoder bch;
         t2::bb_de_header deheader(need_plp);
         long bbframes = 0, ts_bytes = 0;
-        // T2GPU_RX_PROF=1: wall time inside each slot (inclusive of the slots it calls in turn), printed at the end
-        const bool prof = std::getenv("T2GPU_RX_PROF") && std::atoi(std::getenv("T2GPU_RX_PROF"));
-        double t_slot[5] = {0, 0, 0, 0, 0};
-        long n_slot[5] = {0, 0, 0, 0, 0};
-        auto timed = [&](int k, auto &&call) {
-            if (!prof) { call(); return; }
-            const auto a = std::chrono::steady_clock::now();
-            call();
-            t_slot[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
-            ++n_slot[k];
-        };
-        demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { timed(0, [&] { qam.execute(n, c, plp, p); }); };
-        qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { timed(1, [&] { ldpc.execute(idx, p, len, llr); }); };
-        ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { timed(2, [&] { bch.execute(idx, p, len, bits); }); };
-        bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; timed(3, [&] { deheader.execute(plp_id, p, len, bits); }); };
+        demodulator.deinterleaver->ti_block = [&](int n, t2::complex *c, int plp, const t2::l1_postsignalling &p) { qam.execute(n, c, plp, p); };
+        qam.soft_multiplexer_de_twist = [&](int *idx, const t2::l1_postsignalling &p, int len, int8_t *llr) { ldpc.execute(idx, p, len, llr); };
+        ldpc.bit_bch = [&](int *idx, const t2::l1_postsignalling &p, int len, uint8_t *bits) { bch.execute(idx, p, len, bits); };
+        bch.bit_descramble = [&](int plp_id, const t2::l1_postsignalling &p, int len, uint8_t *bits) { ++bbframes; deheader.execute(plp_id, p, len, bits); };
         deheader.write_out = [&](const uint8_t *b, int n) {
             ts_bytes += n;
             if (file) std::fwrite(b, 1, (size_t)n, file);
@@ -154,11 +143,7 @@ int main(int argc, char **argv)
                         "\"bbframes\": %ld, \"ts_bytes\": %ld, \"symbols\": %ld, \"resets\": %ld, \"deint_start\": %d}\n",
                         pos - timed_from, secs, (pos - timed_from) / secs / 1e6, n_buf - warm, buf_len, (long)st.frames - frames0, bbframes - bb0,
                         ts_bytes - ts0, (long)st.symbols, (long)st.resets, (int)st.deint_start);
-        if (prof) {
-            static const char *const name[4] = {"llr_demapper::execute", "ldpc_decoder::execute", "bch_decoder::execute", "bb_de_header::execute"};
-            for (int k = 0; k < 4; ++k)
-                std::fprintf(stderr, "  %-26s %9.3f ms inclusive  %7ld calls  %8.1f us each\n", name[k], t_slot[k] * 1e3, n_slot[k], n_slot[k] ? t_slot[k] * 1e6 / n_slot[k] : 0.0);
-        }
+        t2::prof_report(stderr);                                          // T2GPU_RX_PROF=1: host time by library call of the stage classes
         std::fprintf(stderr, "%zu samples in %.3f s (%.1f Msamples/s, real time 9.14), %ld symbols, %ld T2 frames, %ld BBFRAMEs, %ld TS bytes\n",
                      pos, secs, pos / secs / 1e6, (long)st.symbols, (long)st.frames, bbframes, ts_bytes);
     } catch (const std::exception &e) {

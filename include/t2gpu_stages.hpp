@@ -18,10 +18,12 @@
 //   dvbt2_demodulator  src/DVB_T2/dvbt2_demodulator.h:56  t2::dvbt2_demodulator   (the boundary slot execute(len, i, q, signal))
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -42,6 +44,48 @@ struct l1_postsignalling {
 };
 
 inline void fail(const char *what) { throw std::runtime_error(std::string(what) + ": " + t2gpu_last_error()); }
+
+// T2GPU_RX_PROF=1: host wall time inside the library calls of the stage classes, by call site (exclusive of the signals a slot emits while
+// it runs: a nested scope's time is taken off its parent's). prof_report() prints the table; nothing is measured without the variable.
+struct prof_table {
+    enum { TI_PUSH = 0, DEMAP, DEMAP_BATCH_COPY, LDPC_SUBMIT, LDPC_WAIT, LDPC_POLL, BCH, DEHEADER, N };
+    bool on = false;
+    double t[N] = {}, child = 0.0;
+    long n[N] = {};
+    prof_table() { const char *e = std::getenv("T2GPU_RX_PROF"); on = e && std::atoi(e) != 0; }
+};
+inline prof_table &prof() { static prof_table p; return p; }
+class prof_scope {
+public:
+    explicit prof_scope(int k) : k_(k), on_(prof().on)
+    {
+        if (!on_) return;
+        saved_child_ = prof().child;
+        prof().child = 0.0;
+        t0_ = std::chrono::steady_clock::now();
+    }
+    ~prof_scope()
+    {
+        if (!on_) return;
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+        prof().t[k_] += dt - prof().child;
+        ++prof().n[k_];
+        prof().child = saved_child_ + dt;
+    }
+private:
+    int k_;
+    bool on_;
+    double saved_child_ = 0.0;
+    std::chrono::steady_clock::time_point t0_;
+};
+inline void prof_report(std::FILE *to)
+{
+    static const char *const name[prof_table::N] = {"time_deinterleaver: t2gpu_ti_push", "llr_demapper: t2gpu_demap_execute", "llr_demapper: batch copies (t2gpu_twin_copy)",
+        "ldpc_decoder: t2gpu_ldpc_submit", "ldpc_decoder: t2gpu_ldpc_collect (waits)", "ldpc_decoder: t2gpu_ldpc_collect (polls)", "bch_decoder: t2gpu_bch_descramble", "bb_de_header: t2gpu_bbdh_execute"};
+    if (!prof().on) return;
+    for (int k = 0; k < prof_table::N; ++k)
+        std::fprintf(to, "  %-46s %9.3f ms  %7ld calls  %8.1f us each\n", name[k], prof().t[k] * 1e3, prof().n[k], prof().n[k] ? prof().t[k] * 1e6 / prof().n[k] : 0.0);
+}
 
 // ---------------------------------------------------------------------------------------------------------------- LDPC
 class ldpc_decoder {
@@ -78,7 +122,10 @@ public:
         }
         if (!s->h && !(s->h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
         t2gpu_ldpc_info(s->h, nullptr, &s->k_ldpc, nullptr, nullptr);
-        if (t2gpu_ldpc_submit(s->h, in, len_in) != 0) fail("t2gpu_ldpc_submit");
+        {
+            prof_scope ps(prof_table::LDPC_SUBMIT);
+            if (t2gpu_ldpc_submit(s->h, in, len_in) != 0) fail("t2gpu_ldpc_submit");
+        }
         s->busy = true;
         std::copy(idx_plp_simd, idx_plp_simd + SIZEOF_SIMD, s->idx);
         s->l1 = l1_post;
@@ -104,7 +151,11 @@ private:
         slot *s = fifo_.front();
         const uint8_t *out = nullptr;
         const int *trials = nullptr;
-        const int rc = t2gpu_ldpc_collect(s->h, wait ? 1 : 0, &out, &trials, nullptr);
+        int rc;
+        {
+            prof_scope ps(wait ? prof_table::LDPC_WAIT : prof_table::LDPC_POLL);
+            rc = t2gpu_ldpc_collect(s->h, wait ? 1 : 0, &out, &trials, nullptr);
+        }
         if (rc == 1) return false;
         if (rc != 0) fail("t2gpu_ldpc_collect");
         fifo_.erase(fifo_.begin());
@@ -145,7 +196,11 @@ public:
             outer_code_status.assign((size_t)frames, 0);
             if (t2gpu_bch_decode(p.plp_fec_type, p.plp_cod, in, frames, outer_code_status.data()) != frames) fail("t2gpu_bch_decode");
         }
-        const int k_bch = t2gpu_bch_descramble(p.plp_fec_type, p.plp_cod, in, frames, out_.data());
+        int k_bch;
+        {
+            prof_scope ps(prof_table::BCH);
+            k_bch = t2gpu_bch_descramble(p.plp_fec_type, p.plp_cod, in, frames, out_.data());
+        }
         if (k_bch < 0) fail("t2gpu_bch_descramble");
         for (int n = 0; n < frames; ++n)
             if (bit_descramble) bit_descramble(idx_plp_simd[n], l1_post, k_bch, out_.data() + (size_t)n * k_bch);
@@ -172,7 +227,11 @@ public:
     {
         buf_.resize((size_t)len_in / 8 + 400);
         int errors = 0;
-        const int n = t2gpu_bbdh_execute(h_, plp_id, len_in, in, buf_.data(), (int)buf_.size(), &errors);
+        int n;
+        {
+            prof_scope ps(prof_table::DEHEADER);
+            n = t2gpu_bbdh_execute(h_, plp_id, len_in, in, buf_.data(), (int)buf_.size(), &errors);
+        }
         if (n > 0 && write_out) write_out(buf_.data(), n);
         else if (n == -1 && ts_stage) ts_stage("Baseband header CRC8 error.");
     }
@@ -228,14 +287,21 @@ public:
             if (!keep.empty() && t2gpu_twin_copy(b->data(), keep.data(), keep.size(), device_) != 0) fail("t2gpu_twin_copy");
         }
         float sums[3] = {0, 0, 0};
-        const int frames = t2gpu_demap_execute(h_, reinterpret_cast<const float *>(time_deint_cell), ti_block_size, frames_.data(), sums);
+        int frames;
+        {
+            prof_scope ps(prof_table::DEMAP);
+            frames = t2gpu_demap_execute(h_, reinterpret_cast<const float *>(time_deint_cell), ti_block_size, frames_.data(), sums);
+        }
         if (frames < 0) fail("t2gpu_demap_execute");
         if (signal_noise_ratio) signal_noise_ratio(20.0f * std::log10(sums[0] / sums[1]));                       // :659
         for (int f = 0; f < frames;) {
             std::vector<int8_t> &out = swap_buffer ? buffer_a : buffer_b;
             const int run = std::min(frames - f, SIZEOF_SIMD - blocks);      // consecutive frames go to consecutive places of one batch: one copy
-            if (t2gpu_twin_copy(out.data() + (size_t)blocks * fec_size, frames_.data() + (size_t)f * fec_size, (size_t)run * fec_size, device_) != 0)
-                fail("t2gpu_twin_copy");
+            {
+                prof_scope ps(prof_table::DEMAP_BATCH_COPY);
+                if (t2gpu_twin_copy(out.data() + (size_t)blocks * fec_size, frames_.data() + (size_t)f * fec_size, (size_t)run * fec_size, device_) != 0)
+                    fail("t2gpu_twin_copy");
+            }
             for (int k = 0; k < run; ++k) idx_plp_simd[blocks + k] = plp_id;
             blocks += run; f += run;
             if (blocks == SIZEOF_SIMD) {
@@ -306,7 +372,11 @@ private:
             t2gpu_ti *h = h_.at(b.plp);
             if (pos_ == b.offset && t2gpu_ti_begin(h, b.num_blocks) != 0) fail("t2gpu_ti_begin");
             const int take = std::min(n, b.offset + b.size - pos_);
-            const int done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(out_.data()));
+            int done;
+            {
+                prof_scope ps(prof_table::TI_PUSH);
+                done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(out_.data()));
+            }
             if (done < 0) fail("t2gpu_ti_push");
             cells += take; n -= take; pos_ += take;
             if (done == 1) {

@@ -48,6 +48,19 @@ void launch_front_commit_iq(FrontState *state, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 
+// One launch for a short call (front_kernels.hip: front_chain_kernel). front_chain_grid: the grid such a call needs, or 0 when the call
+// does not qualify (too long, too many runs, not the whole chain). bar: a device counter of the front end's own, zero at creation;
+// target: what it has been raised to by the launches before this one (each adds 3 x grid).
+constexpr int FRONT_CHAIN_MAX_GRID = 96, FRONT_CHAIN_RUNS = 24;
+struct FrontChainArgs {
+    FrontParams p;
+    unsigned long long *bar, target;
+    int fd_blocks;
+    FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs, then Farrow runs
+};
+int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs);
+void launch_front_chain(FrontChainArgs &a, int grid, hipStream_t stream);
+
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
 // sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).
 // Symbol i starts at first + (i / per_frame) * frame_stride + (i % per_frame) * (guard + fft_size).

@@ -18,6 +18,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef T2_FRONT_FUSED
+#define T2_FRONT_FUSED 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ float mul_r(float a, float b) { return a * b; }
@@ -104,20 +108,21 @@ __device__ __forceinline__ long dc_slot(int b, int per) { return (long)(b % per)
 __device__ __forceinline__ int dc_per(int n_blocks) { return (n_blocks + DC_LANES - 1) / DC_LANES; }
 
 // ---- level 1: per-workgroup aggregate of the dc recurrence
-__global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p)
+__device__ __forceinline__ void front_dc_block_body(const FrontParams &p, const int bid)
 {
     __shared__ Lin sh[256];
     const int tid = threadIdx.x;
     float xr[FRONT_PER], xi[FRONT_PER]; int valid;
-    load_samples(p, (long)blockIdx.x * FRONT_BLOCK + tid * FRONT_PER, xr, xi, valid);
+    load_samples(p, (long)bid * FRONT_BLOCK + tid * FRONT_PER, xr, xi, valid);
     sh[tid] = thread_lin(xr, xi, valid);
     __syncthreads();
     for (int s = 1; s < 256; s <<= 1) {
         if ((tid & (2 * s - 1)) == 0) sh[tid] = compose(sh[tid], sh[tid + s]);
         __syncthreads();
     }
-    if (tid == 0) { double *o = p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks)); o[0] = sh[0].a; o[1] = sh[0].re; o[2] = sh[0].im; }
+    if (tid == 0) { double *o = p.blk + 4 * dc_slot(bid, dc_per(p.n_blocks)); o[0] = sh[0].a; o[1] = sh[0].re; o[2] = sh[0].im; }
 }
+__global__ __launch_bounds__(256) void front_dc_block_kernel(FrontParams p) { front_dc_block_body(p, (int)blockIdx.x); }
 
 // ---- level 2: scan over the workgroup aggregates (one workgroup); blk[b] becomes the averager value BEFORE block b
 __global__ __launch_bounds__(DC_LANES) void front_dc_scan_kernel(FrontParams p)
@@ -174,7 +179,7 @@ __device__ __forceinline__ int find_run(const FrontRun *__restrict__ runs, int n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
+__device__ __forceinline__ void front_derotate_body(const FrontParams &p, const int bid, const double *start /* averager value before this block: re, im */)
 {
     __shared__ Lin wave_tot[4];
     __shared__ double red[3][4];
@@ -183,10 +188,9 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
     // whole 512-byte runs per wavefront
     __shared__ float2 sh_out[256 * (FRONT_PER + 1)];
     const int tid = threadIdx.x;
-    const long s0 = (long)blockIdx.x * FRONT_BLOCK + tid * FRONT_PER;
+    const long s0 = (long)bid * FRONT_BLOCK + tid * FRONT_PER;
     float xr[FRONT_PER], xi[FRONT_PER]; int valid;
     load_samples(p, s0, xr, xi, valid);
-    const double *start = p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks));
     const Lin ex = block_scan_exclusive(thread_lin(xr, xi, valid), wave_tot, nullptr);
     double dre = ex.a * start[0] + ex.re, dim = ex.a * start[1] + ex.im;
     const float c1 = p.state->c1, c2 = p.state->c2;
@@ -217,15 +221,19 @@ __global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
     if ((tid & 63) == 0) { red[0][tid >> 6] = t1; red[1][tid >> 6] = t2; red[2][tid >> 6] = t3; }
     __syncthreads();
     if (tid == 0) {
-        double *o = p.theta_part + 4 * (long)blockIdx.x;
+        double *o = p.theta_part + 4 * (long)bid;
         for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
     }
-    const long b0 = (long)blockIdx.x * FRONT_BLOCK;
+    const long b0 = (long)bid * FRONT_BLOCK;
 #pragma unroll
     for (int g = 0; g < FRONT_PER; ++g) {
         const int e = g * 256 + tid;
         if (b0 + e < p.n) p.derot[3 + b0 + e] = sh_out[(e / FRONT_PER) * (FRONT_PER + 1) + e % FRONT_PER];
     }
+}
+__global__ __launch_bounds__(256) void front_derotate_kernel(FrontParams p)
+{
+    front_derotate_body(p, (int)blockIdx.x, p.blk + 4 * dc_slot((int)blockIdx.x, dc_per(p.n_blocks)));
 }
 
 // ---- Farrow resampler: one lane per input sample (interpolator_farrow.hh:47-66); positions from the run table
@@ -325,10 +333,10 @@ constexpr int FD_R = FD_OUT / FD_THREADS;
 static_assert(FD_R == 4 && FD_OUT % FD_THREADS == 0, "the decimator stage is written for four consecutive outputs per lane");
 __device__ __forceinline__ int fd_pad(int t) { return t + (t >> 3); }
 constexpr int FD_W = 2 * FD_OUT + 62;                                           // cells of a workgroup's window
-__global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate_kernel(FrontParams p)
+__device__ __forceinline__ void front_farrow_decimate_body(const FrontParams &p, const int bid)
 {
     __shared__ float2 w[FD_W + FD_W / 8 + 8];
-    const long k0 = (long)blockIdx.x * FD_OUT;
+    const long k0 = (long)bid * FD_OUT;
     const long m0 = 2 * k0 + (1 - p.decim_phase);
     const long avail = 63 + p.n_interp;
     constexpr int W = 2 * FD_OUT + 62;
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate
         }
     }
 }
+__global__ __launch_bounds__(FD_THREADS, T2_FD_WAVES) void front_farrow_decimate_kernel(FrontParams p) { front_farrow_decimate_body(p, (int)blockIdx.x); }
 
 // c1, c2, level_detect from the sign statistics of `len` samples (dvbt2_demodulator.cpp:227-235)
 __device__ __forceinline__ void front_iq_estimate(FrontState &s, double t1, double t2, double t3, float len)
@@ -462,7 +471,7 @@ __device__ __forceinline__ void front_iq_estimate(FrontState &s, double t1, doub
 }
 
 // ---- end of execute(): statistics -> c1, c2, level (:228-235); carry the delay lines and the decimation phase
-__global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
+__device__ __forceinline__ void front_finish_body(const FrontParams &p)
 {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
@@ -501,6 +510,58 @@ __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p)
         } else {
             front_iq_estimate(s, red[0][0], red[1][0], red[2][0], (float)p.n);
         }
+    }
+}
+__global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p) { front_finish_body(p); }
+
+// ---- the whole chain of one SHORT call in one launch (a symbol's worth of samples: the slot-shaped path hands the front end one
+// chunk per OFDM symbol and waits for its result, so the five launches above -- each a few microseconds of work -- and the copy of
+// the run tables were most of that path's time). The workgroups run the same bodies phase after phase with a barrier across the
+// grid in between; the grid is small (<= FRONT_CHAIN_MAX_GRID workgroups, all resident at once). Same values as the five launches:
+// the level-2 scan is evaluated by every workgroup for itself in front_dc_scan_kernel's order (one block per lane, the same shuffles).
+// The run tables travel in the kernel arguments.
+__device__ __forceinline__ void chain_barrier(unsigned long long *bar, unsigned long long target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void front_chain_kernel(FrontChainArgs a)
+{
+    __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS];
+    __shared__ Lin wave_tot[4];
+    __shared__ double sh_start[2], sh_new_dc[2];
+    const int tid = threadIdx.x, bid = (int)blockIdx.x;
+    const unsigned long long G = gridDim.x;
+    FrontParams p = a.p;
+    for (int t = tid; t < p.n_nco_runs + p.n_far_runs; t += 256) sh_runs[t] = a.runs[t];
+    p.nco_runs = sh_runs; p.far_runs = sh_runs + p.n_nco_runs;
+    __syncthreads();
+    if (bid < p.n_blocks) front_dc_block_body(p, bid);
+    chain_barrier(a.bar, a.target + G);
+    {   // front_dc_scan_kernel with one block per lane (n_blocks <= 256): lane t composes the identity with block t's aggregate
+        Lin l{1.0, 0.0, 0.0};
+        if (tid < p.n_blocks) { const double4 v = *reinterpret_cast<const double4 *>(p.blk + 4 * dc_slot(tid, 1)); l = compose(l, Lin{v.x, v.y, v.z}); }
+        Lin total;
+        const Lin ex = block_scan_exclusive<4>(l, wave_tot, &total);
+        const double s_re = p.state->dc_re, s_im = p.state->dc_im;
+        if (tid == bid) { sh_start[0] = ex.a * s_re + ex.re; sh_start[1] = ex.a * s_im + ex.im; }
+        if (tid == 0) { sh_new_dc[0] = total.a * s_re + total.re; sh_new_dc[1] = total.a * s_im + total.im; }
+        __syncthreads();
+    }
+    if (bid < p.n_blocks) front_derotate_body(p, bid, sh_start);
+    chain_barrier(a.bar, a.target + 2 * G);
+    if (bid < a.fd_blocks) front_farrow_decimate_body(p, bid);
+    chain_barrier(a.bar, a.target + 3 * G);
+    if (bid == 0) {
+        front_finish_body(p);
+        if (tid == 0) { p.state->dc_re = sh_new_dc[0]; p.state->dc_im = sh_new_dc[1]; }
     }
 }
 
@@ -563,7 +624,7 @@ void launch_front_commit_iq(FrontState *state, hipStream_t stream)
     hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state);
 }
 
-void launch_front(const FrontParams &p, hipStream_t stream)
+static void load_taps()
 {
     int dev = 0;
     hipGetDevice(&dev);
@@ -571,20 +632,42 @@ void launch_front(const FrontParams &p, hipStream_t stream)
         hipMemcpyToSymbol(HIP_SYMBOL(c_taps), T2_DECIM_TAPS, sizeof(T2_DECIM_TAPS));
         g_taps_loaded[dev] = true;
     }
+}
+
+static long fd_blocks_of(const FrontParams &p)
+{
+    const long by_out = (p.n_out + FD_OUT - 1) / FD_OUT, by_cells = p.n_interp / (2 * FD_OUT) + 1;
+    return by_out > by_cells ? by_out : by_cells;
+}
+
+int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs)
+{
+    const int all = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;
+    if (!T2_FRONT_FUSED || p.n <= 0 || (p.stages & all) != all || n_nco_runs + n_far_runs > (size_t)FRONT_CHAIN_RUNS) return 0;
+    const long fd = fd_blocks_of(p), g = fd > p.n_blocks ? fd : p.n_blocks;
+    return g <= FRONT_CHAIN_MAX_GRID && p.n_blocks <= 256 ? (int)g : 0;
+}
+
+void launch_front_chain(FrontChainArgs &a, int grid, hipStream_t stream)
+{
+    load_taps();
+    a.fd_blocks = (int)fd_blocks_of(a.p);
+    hipLaunchKernelGGL(front_chain_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+}
+
+void launch_front(const FrontParams &p, hipStream_t stream)
+{
+    load_taps();
     if (p.n > 0 && (p.stages & FRONT_STAGE_DEROTATE)) {
         hipLaunchKernelGGL(front_dc_block_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(front_dc_scan_kernel, dim3(1), dim3(DC_LANES), 0, stream, p);
         hipLaunchKernelGGL(front_derotate_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p);
     }
-#ifndef T2_FRONT_FUSED
-#define T2_FRONT_FUSED 1
-#endif
     const bool both = (p.stages & FRONT_STAGE_FARROW) && (p.stages & FRONT_STAGE_DECIMATE);
     if (T2_FRONT_FUSED && both && p.n > 0) {
         // one pass, nothing of the resampled stream in HBM but its last 63 cells; enough workgroups that their windows
         // also cover the cells behind the last complete output (they are part of what the next call starts from)
-        const long by_out = (p.n_out + FD_OUT - 1) / FD_OUT, by_cells = p.n_interp / (2 * FD_OUT) + 1;
-        hipLaunchKernelGGL(front_farrow_decimate_kernel, dim3((unsigned)(by_out > by_cells ? by_out : by_cells)), dim3(FD_THREADS), 0, stream, p);
+        hipLaunchKernelGGL(front_farrow_decimate_kernel, dim3((unsigned)fd_blocks_of(p)), dim3(FD_THREADS), 0, stream, p);
     } else {
         if (p.n > 0 && (p.stages & FRONT_STAGE_FARROW))
             hipLaunchKernelGGL(front_farrow_kernel, dim3((p.n + 255) / 256), dim3(256), 0, stream, p);

@@ -62,4 +62,11 @@ constexpr int EQS_PU = 8;                   // eq_split_kernel reads its destina
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);
 
+// The results of ONE symbol to page-locked host memory in one launch (the slot-shaped path, t2gpu_demod.cpp): n_cells cells, the guard
+// correlation's four floats (cp4 may be null) and the two synchronisation floats go to h_cells / h_small[0..3] / h_small[4..5] by the
+// kernel's own stores, and *h_flag = seq is stored behind all of them (system scope): the host reads seq there instead of waiting for
+// three copies and the stream. d_count: a zeroed device word of the caller's (left at zero).
+hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *cp4, const float *sync2, float2 *h_cells, float *h_small,
+                                 unsigned *h_flag, unsigned seq, unsigned *d_count, hipStream_t s);
+
 }  // namespace t2gpu

@@ -594,6 +594,39 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
     if (lane == 0) sync[b] = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
 }
 
+__global__ __launch_bounds__(256) void publish_symbol_kernel(const float2 *__restrict__ cells, int n_cells, const float *__restrict__ cp4,
+                                                            const float *__restrict__ sync2, float2 *h_cells, float *h_small, unsigned *h_flag,
+                                                            unsigned seq, unsigned *d_count)
+{
+    const int tid = threadIdx.x;
+    const int pairs = n_cells >> 1;
+    const float4 *src = reinterpret_cast<const float4 *>(cells);
+    float4 *dst = reinterpret_cast<float4 *>(h_cells);
+    for (int i = (int)blockIdx.x * 256 + tid; i < pairs; i += (int)gridDim.x * 256) dst[i] = src[i];
+    if ((n_cells & 1) && blockIdx.x == 0 && tid == 0) h_cells[n_cells - 1] = cells[n_cells - 1];
+    __threadfence_system();                                 // this lane's stores have reached the host before the workgroup is counted
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned before = __hip_atomic_fetch_add(d_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {                      // the last workgroup: everything is over there
+            __hip_atomic_store(d_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cp4) { h_small[0] = cp4[0]; h_small[1] = cp4[1]; h_small[2] = cp4[2]; h_small[3] = cp4[3]; }
+            h_small[4] = sync2[0]; h_small[5] = sync2[1];
+            __threadfence_system();
+            __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *cp4, const float *sync2, float2 *h_cells, float *h_small,
+                                 unsigned *h_flag, unsigned seq, unsigned *d_count, hipStream_t s)
+{
+    int grid = (n_cells / 2 + 1023) / 1024;                 // four 16-byte stores per lane
+    grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
+    hipLaunchKernelGGL(publish_symbol_kernel, dim3((unsigned)grid), dim3(256), 0, s, cells, n_cells, cp4, sync2, h_cells, h_small, h_flag, seq, d_count);
+    return hipGetLastError();
+}
+
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s)
 {

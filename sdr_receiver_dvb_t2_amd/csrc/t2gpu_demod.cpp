@@ -9,7 +9,9 @@
 // two feedback floats and, for P2, the L1 cells.
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
+#include "ofdm_kernels.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -71,6 +73,10 @@ struct t2gpu_demod {
     long out_cap = 0;
     float *h_cells = nullptr;          // pinned: the cells of the symbol just equalised, as the `data` / `l1_dyn_execute` signals carry them
     float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
+    // results by the device's own stores and a sequence word the host reads (symbol_results); T2GPU_DEMOD_SPIN=0: copies + stream wait
+    bool spin = true;
+    unsigned seq = 0;
+    unsigned *h_flag = nullptr, *d_count = nullptr;
 };
 
 namespace {
@@ -89,6 +95,8 @@ void free_all(t2gpu_demod *h)
     hipFree(h->d_sync); hipFree(h->d_cp); hipFree(h->d_symidx);
     if (h->h_cells) twin_retire(h->h_cells);
     hipHostFree(h->h_cells); hipHostFree(h->h_small);
+    if (h->h_flag) hipHostFree(h->h_flag);
+    hipFree(h->d_count);
 }
 
 // dvbt2_demodulator::reset (:111-127)
@@ -186,10 +194,29 @@ int init_data(t2gpu_demod *h)
 // device) or nullptr on an error.
 const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
 {
-    if (cp && hipMemcpyAsync(h->h_small, h->d_cp, 16, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-    if (hipMemcpyAsync(h->h_small + 4, h->d_sync, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-    if (n_cells > 0 && hipMemcpyAsync(h->h_cells, h->d_cells, (size_t)n_cells * 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-    if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;
+    if (h->spin) {
+        // one launch stores cells and floats into the page-locked buffers and raises the sequence word behind them; the host reads that
+        // word (three copies and the stream's completion signal cost the path some 40 us per symbol)
+        const unsigned seq = ++h->seq;
+        if (!hip_ok(t2gpu::launch_publish_symbol(reinterpret_cast<const float2 *>(h->d_cells), n_cells, cp ? h->d_cp : nullptr, h->d_sync,
+                                                 reinterpret_cast<float2 *>(h->h_cells), h->h_small, h->h_flag, seq, h->d_count, nullptr),
+                    "publish_symbol_kernel")) return nullptr;
+        volatile unsigned *flag = h->h_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *flag != seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;    // a failed launch shows here
+                if (*flag != seq) { set_error("t2gpu_demod: the symbol's results did not arrive"); return nullptr; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        if (cp && hipMemcpyAsync(h->h_small, h->d_cp, 16, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+        if (hipMemcpyAsync(h->h_small + 4, h->d_sync, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+        if (n_cells > 0 && hipMemcpyAsync(h->h_cells, h->d_cells, (size_t)n_cells * 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
+        if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;
+    }
     if (cp) std::memcpy(cp, h->h_small, 16);
     std::memcpy(sv, h->h_small + 4, 8);
     return h->h_cells;
@@ -378,6 +405,10 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells), (size_t)32768 * 8, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 64, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
+    if (ok) *h->h_flag = 0;
+    if (const char *e = std::getenv("T2GPU_DEMOD_SPIN")) h->spin = std::atoi(e) != 0;
     if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device);     // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);

@@ -3,6 +3,7 @@
 // scalar tracking loops of symbol_acquisition.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,6 +42,9 @@ struct t2gpu_front {
     std::vector<FrontRun> dev_runs;            // what d_runs holds (nco runs, then Farrow runs)
     size_t dev_nn = 0;
     bool dev_runs_valid = false;
+    // short calls in one launch (front_kernels.hip: front_chain_kernel); T2GPU_FRONT_CHAIN=0 at creation keeps the five launches
+    unsigned long long *d_bar = nullptr, chain_count = 0;
+    bool chain_on = true;
 };
 
 namespace {
@@ -160,7 +164,9 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         const float rk = 1.0f / k_table;
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
-    bool ok = hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
+    if (const char *e = std::getenv("T2GPU_FRONT_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    bool ok = hipMalloc(&h->d_bar, 8) == hipSuccess && hipMemset(h->d_bar, 0, 8) == hipSuccess &&
+              hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
               hipMalloc(&h->d_derot, ((size_t)max_samples + 3) * sizeof(float2)) == hipSuccess &&
               hipMalloc(&h->d_interp, ((size_t)h->interp_cap + 63) * sizeof(float2)) == hipSuccess &&
@@ -181,6 +187,7 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    hipFree(h->d_bar);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
     if (h->h_runs) hipHostFree(h->h_runs);
@@ -290,8 +297,23 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     p.i_in = d_i; p.q_in = d_q; p.n = (int)n; p.n_blocks = (int)((n + FRONT_BLOCK - 1) / FRONT_BLOCK);
     p.n_interp = n_interp; p.out = reinterpret_cast<float2 *>(d_out); p.n_out = n_out;
     p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
-    if (stage_tables(h, (int)n, stream, p) != 0) return -1;
-    launch_front(p, stream);
+    const size_t nn = h->nco_runs.size(), nf = h->far_runs.size();
+    const int chain_grid = h->chain_on ? front_chain_grid(p, nn, nf) : 0;
+    if (chain_grid) {
+        // a symbol's worth of samples: one launch, the run tables in its arguments (no table copy, nothing to wait for)
+        FrontChainArgs a;
+        a.p = p;
+        a.p.n_nco_runs = (int)nn; a.p.n_far_runs = (int)nf;
+        a.p.nco_runs = nullptr; a.p.far_runs = nullptr; a.p.nco_index = nullptr; a.p.far_index = nullptr;
+        if (nn) std::memcpy(a.runs, h->nco_runs.data(), nn * sizeof(FrontRun));
+        if (nf) std::memcpy(a.runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
+        a.bar = h->d_bar; a.target = h->chain_count;
+        launch_front_chain(a, chain_grid, stream);
+        h->chain_count += 3ull * (unsigned long long)chain_grid;
+    } else {
+        if (stage_tables(h, (int)n, stream, p) != 0) return -1;
+        launch_front(p, stream);
+    }
     T2_HIP(hipGetLastError());
     h->decim_phase = (int)((h->decim_phase + n_interp) & 1);
     h->last_stream = stream; h->last_n = n; h->last_n_interp = n_interp;

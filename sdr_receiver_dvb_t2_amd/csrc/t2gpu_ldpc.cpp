@@ -407,7 +407,12 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     if (h->a_frames) { set_error("t2gpu_ldpc_submit: the previous submit has not been collected"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     if (!h->a_stream) {
-        T2_HIP(hipStreamCreateWithFlags(&h->a_stream, hipStreamNonBlocking));
+        // lowest priority: the runtime keeps a separate set of hardware queues per priority, so these streams never share a queue with the
+        // null stream -- a decode of milliseconds in the queue the per-symbol kernels of the caller go through would hold every one of
+        // them up (seen in rocprofv3: the second batch's copy, on the null stream, waited for the first batch's kernel)
+        int prio_least = 0, prio_greatest = 0;
+        T2_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        T2_HIP(hipStreamCreateWithPriority(&h->a_stream, hipStreamNonBlocking, prio_least));
         T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
         T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
         T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_out), (size_t)h->max_frames * h->g.k, hipHostMallocDefault));
@@ -423,13 +428,14 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
     if (const void *twin = twin_lookup(in, (size_t)len_in, h->device)) {
         // a SIMD batch assembled from the demapper's output (t2gpu_twin_copy) is on the device already: its twin is written on the
-        // null stream; this handle's stream takes its copy behind those writes, and the null stream goes on behind that copy
+        // null stream, so the copy into this handle's input is put on the null stream too (in order with those writes, and the twin is
+        // free for the next batch when it is through) and this handle's stream starts behind it. Nothing on the null stream ever waits
+        // for this handle's stream: a wait the other way round held the caller's per-symbol kernels up behind whole decodes whenever two
+        // handles' streams shared a hardware queue.
         if (!h->a_fence) T2_HIP(hipEventCreateWithFlags(&h->a_fence, hipEventDisableTiming));
+        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, nullptr));
         T2_HIP(hipEventRecord(h->a_fence, nullptr));
         T2_HIP(hipStreamWaitEvent(s, h->a_fence, 0));
-        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, s));
-        T2_HIP(hipEventRecord(h->a_fence, s));
-        T2_HIP(hipStreamWaitEvent(nullptr, h->a_fence, 0));
     } else {
         std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns
         T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));

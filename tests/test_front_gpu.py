@@ -144,6 +144,32 @@ def test_front_end_matches_oracle(torch_cuda, id_device, case):
     assert np.array_equal(bits(got), bits(np.concatenate(outs)))
 
 
+def test_short_calls_in_one_launch_equal_the_five_launches(torch_cuda, monkeypatch):
+    """A call of up to a few OFDM symbols' worth of samples runs as ONE launch (front_chain_kernel: the same bodies phase after phase
+    with a barrier across its small grid, run tables in the kernel arguments); T2GPU_FRONT_CHAIN=0 at creation keeps the five
+    launches. Same cells, same carried state, bit for bit -- over calls of one symbol, of a few samples (what the slot-shaped path
+    hands over when the chunk estimate was a sample short), and of a length that does not qualify."""
+    from sdr_receiver_dvb_t2_amd import front
+    n_max = 1 << 19
+    monkeypatch.setenv("T2GPU_FRONT_CHAIN", "0")
+    five = front.front_end(max_samples=n_max)
+    monkeypatch.setenv("T2GPU_FRONT_CHAIN", "1")
+    one = front.front_end(max_samples=n_max)
+    rng = np.random.Generator(np.random.PCG64(77))
+    for call, n in enumerate([70001, 3, 66050, 1, 2047, 4096, 4097, 90000, 300000, 5, 33024]):
+        i_in, q_in = iq16(n, 900 + call)
+        pe = np.float32(rng.standard_normal() * 0.05)
+        fe = np.float32(rng.standard_normal() * (3e-4 if call % 3 else 2e-6))
+        rs = five.resample - rng.integers(-3, 4) * 8.0e-9
+        a, al = five.execute(i_in, q_in, [n], [pe], [fe], [rs])
+        b, bl = one.execute(i_in, q_in, [n], [pe], [fe], [rs])
+        assert al[0] == bl[0] and np.array_equal(bits(a), bits(b)), (call, n)
+        sa, sb = five.state(), one.state()
+        assert all(bits(np.float32(sa[k])) == bits(np.float32(sb[k])) for k in sa), (call, n, sa, sb)
+        assert np.array_equal(bits(five.debug_stream(0, n)), bits(one.debug_stream(0, n)))
+    five.close(); one.close()
+
+
 def test_front_end_dev_entry_and_errors(torch_cuda):
     torch = torch_cuda
     from sdr_receiver_dvb_t2_amd import front
