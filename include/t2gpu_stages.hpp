@@ -21,12 +21,16 @@
 #include <chrono>
 #include <cmath>
 #include <complex>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "t2gpu.h"
@@ -50,27 +54,28 @@ inline void fail(const char *what) { throw std::runtime_error(std::string(what) 
 struct prof_table {
     enum { TI_PUSH = 0, DEMAP, DEMAP_BATCH_COPY, LDPC_SUBMIT, LDPC_WAIT, LDPC_POLL, BCH, DEHEADER, N };
     bool on = false;
-    double t[N] = {}, child = 0.0;
+    double t[N] = {};
     long n[N] = {};
     prof_table() { const char *e = std::getenv("T2GPU_RX_PROF"); on = e && std::atoi(e) != 0; }
 };
 inline prof_table &prof() { static prof_table p; return p; }
+inline double &prof_child() { static thread_local double c = 0.0; return c; }   // time of the scopes nested in the open one, per thread
 class prof_scope {
 public:
     explicit prof_scope(int k) : k_(k), on_(prof().on)
     {
         if (!on_) return;
-        saved_child_ = prof().child;
-        prof().child = 0.0;
+        saved_child_ = prof_child();
+        prof_child() = 0.0;
         t0_ = std::chrono::steady_clock::now();
     }
     ~prof_scope()
     {
         if (!on_) return;
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
-        prof().t[k_] += dt - prof().child;
+        prof().t[k_] += dt - prof_child();
         ++prof().n[k_];
-        prof().child = saved_child_ + dt;
+        prof_child() = saved_child_ + dt;
     }
 private:
     int k_;
@@ -93,15 +98,30 @@ public:
     // in_flight: SIMD batches the stage keeps on the device at once. The reference's stage runs on a thread of its own and its slot is
     // fed through a queued connection (dvbt2_demodulator.cpp:84-95, main_window wiring): the caller does not wait for the decode. Here
     // execute() submits the batch (t2gpu_ldpc_submit: copy-in, decode and copy-out on a stream of the handle's own) and returns;
-    // bit_bch is emitted in submission order as results arrive -- on later execute() calls and in flush(). One batch occupies 16 of the
-    // device's 256 CUs, so a caller with the reference's call shape needs several in flight to use the device. in_flight = 1 is the
-    // synchronous form of rounds 2-3.
-    explicit ldpc_decoder(int device = 0, int in_flight = 8) : device_(device), depth_(in_flight < 1 ? 1 : in_flight) {}
+    // bit_bch is emitted in submission order as results arrive. One batch occupies 16 of the device's 256 CUs, so a caller with the
+    // reference's call shape needs several in flight to use the device. in_flight = 1 is the synchronous form of rounds 2-3.
+    // own_thread = false: bit_bch is emitted on the caller's thread, on later execute() calls and in flush().
+    // own_thread = true: the stage has a thread of its own as the reference's has (ldpc_decoder.cpp:129-133): it waits for the batches in
+    // submission order and emits bit_bch -- and with it whatever the consumer wires behind (bch_decoder, bb_de_header, the sink) -- there,
+    // beside the caller. flush() returns when everything submitted has been emitted; an exception thrown on that thread is rethrown by
+    // the next execute() / flush().
+    explicit ldpc_decoder(int device = 0, int in_flight = 8, bool own_thread = false)
+        : device_(device), depth_(in_flight < 1 ? 1 : in_flight), threaded_(own_thread && in_flight > 1)
+    {
+        if (threaded_) worker_ = std::thread([this] { run(); });
+    }
     ~ldpc_decoder()
     {
         try { flush(); } catch (...) {}
+        if (threaded_) {
+            { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+            cv_work_.notify_all();
+            worker_.join();
+        }
         for (auto &ring : gpu_) for (auto &code : ring) for (slot &s : code) if (s.h) t2gpu_ldpc_destroy(s.h);
     }
+    ldpc_decoder(const ldpc_decoder &) = delete;
+    ldpc_decoder &operator=(const ldpc_decoder &) = delete;
     // signals (ldpc_decoder.h:83-87)
     std::function<void(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_out, uint8_t *out)> bit_bch;
     // slot (ldpc_decoder.h:90, ldpc_decoder.cpp:157-301): 32 frames of int8 LLRs in, information bits (one per byte) out through
@@ -111,31 +131,46 @@ public:
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
         if (p.plp_cod < 0 || p.plp_cod > 5 || p.plp_fec_type < 0 || p.plp_fec_type > 1)    // T2-Lite codes 6, 7: not in the reference's switch (:173-246)
             fail("ldpc_decoder: PLP_COD / PLP_FEC_TYPE outside the reference's twelve codes");
-        std::vector<slot> &ring = gpu_[p.plp_fec_type][p.plp_cod];
-        if (ring.empty()) ring.resize((size_t)depth_);
-        // a free handle of this code's ring; when all are busy, the oldest batch in flight is awaited and emitted first
+        // a free handle of this code's ring; when all are busy, the oldest batch in flight is awaited (and emitted) first
         slot *s = nullptr;
-        for (;;) {
-            for (slot &c : ring) if (!c.busy) { s = &c; break; }
-            if (s) break;
-            emit_front(true);
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            rethrow_locked();
+            std::vector<slot> &ring = gpu_[p.plp_fec_type][p.plp_cod];
+            if (ring.empty()) ring.resize((size_t)depth_);
+            for (;;) {
+                for (slot &c : ring) if (!c.busy) { s = &c; break; }
+                if (s) break;
+                if (threaded_) { cv_free_.wait(lk); rethrow_locked(); }
+                else { lk.unlock(); emit_front(true); lk.lock(); }
+            }
+            s->busy = true;                                      // reserved: nobody else touches it until it is in the queue
         }
-        if (!s->h && !(s->h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) fail("t2gpu_ldpc_create");
+        if (!s->h && !(s->h = t2gpu_ldpc_create(p.plp_fec_type, p.plp_cod, SIZEOF_SIMD, device_))) { release(s); fail("t2gpu_ldpc_create"); }
         t2gpu_ldpc_info(s->h, nullptr, &s->k_ldpc, nullptr, nullptr);
         {
             prof_scope ps(prof_table::LDPC_SUBMIT);
-            if (t2gpu_ldpc_submit(s->h, in, len_in) != 0) fail("t2gpu_ldpc_submit");
+            if (t2gpu_ldpc_submit(s->h, in, len_in) != 0) { release(s); fail("t2gpu_ldpc_submit"); }
         }
-        s->busy = true;
         std::copy(idx_plp_simd, idx_plp_simd + SIZEOF_SIMD, s->idx);
         s->l1 = l1_post;
-        fifo_.push_back(s);
+        { std::lock_guard<std::mutex> lk(m_); fifo_.push_back(s); }
+        if (threaded_) { cv_work_.notify_one(); return; }
         if (depth_ == 1) { emit_front(true); return; }
-        while (!fifo_.empty() && emit_front(false)) {}
+        while (emit_front(false)) {}
     }
     // everything still inside the stage comes out (end of stream; a caller that needs the synchronous behaviour calls it after execute)
-    void flush() { while (!fifo_.empty()) emit_front(true); }
-    int in_flight() const { return (int)fifo_.size(); }
+    void flush()
+    {
+        if (threaded_) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_free_.wait(lk, [this] { return fifo_.empty() || error_; });
+            rethrow_locked();
+        } else {
+            while (emit_front(true)) {}
+        }
+    }
+    int in_flight() const { std::lock_guard<std::mutex> lk(m_); return (int)fifo_.size(); }
 private:
     struct slot {
         t2gpu_ldpc *h = nullptr;
@@ -144,11 +179,13 @@ private:
         int idx[SIZEOF_SIMD] = {};
         l1_postsignalling l1;
     };
-    // the oldest batch in flight: waits for it (or polls); emits bit_bch or the reference's message. false: still decoding.
+    void release(slot *s) { std::lock_guard<std::mutex> lk(m_); s->busy = false; cv_free_.notify_all(); }
+    void rethrow_locked() { if (error_) { std::exception_ptr e = error_; error_ = nullptr; std::rethrow_exception(e); } }
+    // the oldest batch in flight: waits for it (or polls); emits bit_bch or the reference's message. false: nothing there / still decoding.
     bool emit_front(bool wait)
     {
-        if (fifo_.empty()) return false;
-        slot *s = fifo_.front();
+        slot *s = nullptr;
+        { std::lock_guard<std::mutex> lk(m_); if (fifo_.empty()) return false; s = fifo_.front(); }
         const uint8_t *out = nullptr;
         const int *trials = nullptr;
         int rc;
@@ -158,19 +195,43 @@ private:
         }
         if (rc == 1) return false;
         if (rc != 0) fail("t2gpu_ldpc_collect");
-        fifo_.erase(fifo_.begin());
         const int trials_left = trials[0];
-        if (trials_left < 0) {
-            std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials_left);
-            s->busy = false;
-            return true;
-        }
+        if (trials_left < 0) std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials_left);
         // the result stays in the handle's staging until the handle is submitted to again: it is marked free AFTER the consumer returned
-        if (bit_bch) bit_bch(s->idx, s->l1, s->k_ldpc * SIZEOF_SIMD, const_cast<uint8_t *>(out));
-        s->busy = false;
+        else if (bit_bch) bit_bch(s->idx, s->l1, s->k_ldpc * SIZEOF_SIMD, const_cast<uint8_t *>(out));
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fifo_.erase(fifo_.begin());
+            s->busy = false;
+        }
+        cv_free_.notify_all();
         return true;
     }
+    void run()                                                   // the stage's own thread
+    {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [this] { return stop_ || (!fifo_.empty() && !error_); });
+                if (stop_) return;
+            }
+            try {
+                emit_front(true);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                error_ = std::current_exception();
+                for (slot *q : fifo_) q->busy = false;           // what was in flight is lost with the error
+                fifo_.clear();
+                cv_free_.notify_all();
+            }
+        }
+    }
     int device_, depth_;
+    bool threaded_, stop_ = false;
+    mutable std::mutex m_;
+    std::condition_variable cv_work_, cv_free_;
+    std::exception_ptr error_;
+    std::thread worker_;
     std::vector<slot> gpu_[2][6];
     std::vector<slot *> fifo_;
 };
