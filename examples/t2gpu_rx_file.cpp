@@ -62,6 +62,9 @@ int main(int argc, char **argv)
     }
     if ((!out_path && !udp_port) || buf_len < 4096) return 2;
     const std::vector<int16_t> vi = slurp(argv[1]), vq = slurp(argv[2]);
+    // an SDR source hands over the same few buffers again and again and would page-lock them once; the recording stands in for them
+    t2gpu_host_pin(const_cast<int16_t *>(vi.data()), vi.size() * 2);
+    t2gpu_host_pin(const_cast<int16_t *>(vq.data()), vq.size() * 2);
 
     std::FILE *file = out_path ? std::fopen(out_path, "wb") : nullptr;
     int sock = -1;

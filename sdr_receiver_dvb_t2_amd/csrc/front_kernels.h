@@ -44,7 +44,8 @@ struct FrontParams {
 // FRONT_STAGE_HOLD_IQ: this call is one chunk of an execute() that goes on -- its sign statistics are added to the open sums and
 // c1 / c2 / level_detect stay as they are until launch_front_commit_iq (the reference derives them once per execute(), :227-235)
 enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4, FRONT_STAGE_HOLD_IQ = 8 };
-void launch_front_commit_iq(FrontState *state, hipStream_t stream);
+// h_copy / h_flag (may be null): the committed state is also stored to page-locked host memory and *h_flag = seq behind it
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 

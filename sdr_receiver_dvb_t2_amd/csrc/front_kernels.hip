@@ -566,12 +566,17 @@ __global__ __launch_bounds__(256) void front_chain_kernel(FrontChainArgs a)
 }
 
 // end of an execute() whose chunks ran with FRONT_STAGE_HOLD_IQ (:227-235)
-__global__ void front_commit_iq_kernel(FrontState *state)
+__global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq)
 {
     FrontState &s = *state;
     if (s.n_acc > 0.0) front_iq_estimate(s, s.theta_acc[0], s.theta_acc[1], s.theta_acc[2], (float)s.n_acc);
     s.theta_acc[0] = s.theta_acc[1] = s.theta_acc[2] = 0.0;
     s.n_acc = 0.0;
+    if (h_copy) {                                           // the state as it stands now, to page-locked host memory, the sequence word behind it
+        *h_copy = s;
+        __threadfence_system();
+        __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 
@@ -619,9 +624,9 @@ bool g_taps_loaded[16] = {};
 
 }  // namespace
 
-void launch_front_commit_iq(FrontState *state, hipStream_t stream)
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream)
 {
-    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state);
+    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state, h_copy, h_flag, seq);
 }
 
 static void load_taps()

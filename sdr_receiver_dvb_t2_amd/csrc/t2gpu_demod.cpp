@@ -77,11 +77,15 @@ struct t2gpu_demod {
     bool spin = true;
     unsigned seq = 0;
     unsigned *h_flag = nullptr, *d_count = nullptr;
+    // the front end writes a symbol's chunk straight into the symbol buffer (T2GPU_DEMOD_DIRECT=0: into d_out, copied from there)
+    bool direct = true;
+    float *d_bounce = nullptr;
 };
 
 namespace {
 
 constexpr int MAX_SYMBOL = 32768 + 32768 / 4 + P1_LEN;                              // max_len_symbol, :52
+constexpr int SYM_BUF_CELLS = MAX_SYMBOL + 4096;                                    // the symbol buffer: a symbol and what a chunk may overshoot it by
 constexpr int CHUNK_MAX = 2 * (MAX_SYMBOL + P1_LEN) + 4096;                         // input samples of one chunk, resample <= ~1
 
 void free_all(t2gpu_demod *h)
@@ -97,6 +101,7 @@ void free_all(t2gpu_demod *h)
     hipHostFree(h->h_cells); hipHostFree(h->h_small);
     if (h->h_flag) hipHostFree(h->h_flag);
     hipFree(h->d_count);
+    hipFree(h->d_bounce);
 }
 
 // dvbt2_demodulator::reset (:111-127)
@@ -223,20 +228,34 @@ const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
 }
 
 // symbol_acquisition (:267-448). Returns 0, or -1 on an error of a stage.
-int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal_)
+// src: the front end's output of this chunk -- h->d_out, or the symbol buffer itself from idx_buffer_sym on (t2gpu_demod_execute lets the
+// front end write there when the chunk continues a symbol: the copy below is then no copy at all).
+// D2D copy that may be asked to move cells inside one buffer: bounced through d_out's tail when the ranges overlap
+int move_cells(t2gpu_demod *h, float *dst, const float *src, int n)
+{
+    if (n <= 0 || dst == src) return 0;
+    const bool overlap = src < dst + 2 * (size_t)n && dst < src + 2 * (size_t)n;
+    if (!overlap) { T2_HIP(hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr)); return 0; }
+    float *tmp = h->d_bounce;
+    T2_HIP(hipMemcpyAsync(tmp, src, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr));
+    T2_HIP(hipMemcpyAsync(dst, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr));
+    return 0;
+}
+
+int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal_, const float *src)
 {
     int consume = 0;
     while (consume < len_in) {
         if (h->next_symbol_type == SYMBOL_TYPE_P1) {
             t2gpu_p1_result r;
             h->prof.start();
-            const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, h->d_out, &consume,
+            const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, src, &consume,
                                                  signal_->p1_reset, &r, nullptr);
             h->prof.stop(PF_P1);
             if (det < 0) return -1;
             if (det == 1) {
                 const int k = r.idx_buffer_sym;                                     // p1_symbol.cpp:97: already in buffer_sym
-                if (k > 0) T2_HIP(hipMemcpyAsync(h->d_buffer_sym, h->d_out + 2 * (size_t)(consume - k), (size_t)k * 8, hipMemcpyDeviceToDevice, nullptr));
+                if (move_cells(h, h->d_buffer_sym, src + 2 * (size_t)(consume - k), k) != 0) return -1;
                 h->idx_buffer_sym = k;
                 if (r.fft_mode >= 0) { h->fft_mode = r.fft_mode; h->preamble = r.preamble; }
                 signal_->coarse_freq_offset = r.coarse_freq_offset;
@@ -265,8 +284,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         const int len_in_sym = len_in - consume, len_out_sym = h->symbol_size - h->idx_buffer_sym;
         const int len_cpy_sym = len_out_sym > len_in_sym ? len_in_sym : len_out_sym;
         h->prof.start();
-        T2_HIP(hipMemcpyAsync(h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym, h->d_out + 2 * (size_t)consume, (size_t)len_cpy_sym * 8,
-                              hipMemcpyDeviceToDevice, nullptr));
+        if (move_cells(h, h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym, src + 2 * (size_t)consume, len_cpy_sym) != 0) return -1;
         h->prof.stop(PF_BUFFER);
         consume += len_cpy_sym;
         h->idx_buffer_sym += len_cpy_sym;
@@ -398,7 +416,9 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     h->sync = t2gpu_sync_create(sample_rate);
     bool ok = h->front && h->p1 && h->sync;
     ok = ok && hipMalloc(&h->d_out, (size_t)h->out_cap * 8) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)(MAX_SYMBOL + 8) * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_bounce, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
+    if (const char *e = std::getenv("T2GPU_DEMOD_DIRECT")) h->direct = std::atoi(e) != 0;
     ok = ok && hipMalloc(&h->d_spec, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
@@ -414,7 +434,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;
         ok = hipMemcpy(h->d_symidx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemset(h->d_buffer_sym, 0, (size_t)(MAX_SYMBOL + 8) * 8) == hipSuccess;
+             hipMemset(h->d_buffer_sym, 0, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
     }
     if (!ok) {
         if (h->front && h->p1 && h->sync) set_error("t2gpu_demod_create: device allocation failed");
@@ -472,8 +492,11 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         h->in_cap = el;
     }
     h->prof.start();
-    T2_HIP(hipMemcpy(h->d_i, i_in, el * 2, hipMemcpyHostToDevice));
-    T2_HIP(hipMemcpy(h->d_q, q_in, el * 2, hipMemcpyHostToDevice));
+    // in stream order ahead of the kernels that read them; the caller's buffers are free when this call returns (it ends with
+    // t2gpu_front_state, which waits for everything launched here). From page-locked buffers (t2gpu_host_pin) the copies do not block.
+    struct drain_on_error { bool armed = true; ~drain_on_error() { if (armed) hipStreamSynchronize(nullptr); } } drain;   // an early return leaves no copy in flight
+    T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, nullptr));
+    T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, nullptr));
     h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {
@@ -489,12 +512,20 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         if (chunk > CHUNK_MAX) { set_error("t2gpu_demod_execute: chunk larger than the work buffers"); return -1; }
         const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
         h->prof.start();
+        // a chunk that continues (or starts) an OFDM symbol is written where the symbol is collected; its few cells beyond the symbol's
+        // end, if any, are moved by symbol_acquisition. P1 searches read the chunk from d_out.
+        float *dst = h->d_out;
+        long cap = h->out_cap;
+        if (h->direct && h->next_symbol_type != SYMBOL_TYPE_P1) {
+            dst = h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym;
+            cap = SYM_BUF_CELLS - h->idx_buffer_sym;
+        }
         const long n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
-                                                   h->d_q + (size_t)idx_in * h->stride, h->d_out, h->out_cap, nullptr, nullptr);
+                                                   h->d_q + (size_t)idx_in * h->stride, dst, cap, nullptr, nullptr);
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
-        if (symbol_acquisition(h, (int)n_out, signal_) != 0) return -1;
+        if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
@@ -502,6 +533,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     float st[8];
     if (t2gpu_front_state(h->front, st) != 0) return -1;
     h->prof.stop(PF_TAIL);
+    drain.armed = false;                                                            // t2gpu_front_state saw the end of the stream
     h->level_detect = st[6];
     if (signal_->gain_changed) {
         if (h->level_detect < h->level_min) { signal_->gain_offset = 1; signal_->change_gain = 1; }

@@ -2,6 +2,8 @@
 // float accumulators (front_plan.h), device buffers that carry the reference's per-object state between calls, and the
 // scalar tracking loops of symbol_acquisition.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +47,10 @@ struct t2gpu_front {
     // short calls in one launch (front_kernels.hip: front_chain_kernel); T2GPU_FRONT_CHAIN=0 at creation keeps the five launches
     unsigned long long *d_bar = nullptr, chain_count = 0;
     bool chain_on = true;
+    // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
+    FrontState *h_state = nullptr;
+    unsigned *h_flag = nullptr, state_seq = 0;
+    bool state_published = false;      // nothing has touched the device state since the last commit
 };
 
 namespace {
@@ -165,6 +171,10 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
     if (const char *e = std::getenv("T2GPU_FRONT_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocDefault) == hipSuccess) {
+        h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
+        *h->h_flag = 0;
+    }
     bool ok = hipMalloc(&h->d_bar, 8) == hipSuccess && hipMemset(h->d_bar, 0, 8) == hipSuccess &&
               hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
@@ -188,6 +198,7 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     hipFree(h->d_bar);
+    if (h->h_state) hipHostFree(h->h_state);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
     if (h->h_runs) hipHostFree(h->h_runs);
@@ -205,6 +216,7 @@ extern "C" int t2gpu_front_reset(t2gpu_front *h)
     s.c1 = 0.0f; s.c2 = 1.0f;                                                              // dvbt2_demodulator.h:98-99
     s.level_detect = 3.402823466e+38f;                                                     // .h:161
     T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    h->state_published = false;
     T2_HIP(hipMemset(h->d_derot, 0, 3 * sizeof(float2)));
     T2_HIP(hipMemset(h->d_interp, 0, 63 * sizeof(float2)));
     h->phase_nco = 0.0f; h->frequency_nco = 0.0f; h->x1 = -0.5f; h->decim_phase = 0;
@@ -223,6 +235,7 @@ extern "C" int t2gpu_front_reset_loops(t2gpu_front *h)
     T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
     s.dc_re = 0.0; s.dc_im = 0.0;
     T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    h->state_published = false;
     h->phase_nco = 0.0f; h->frequency_nco = 0.0f;
     return 0;
 }
@@ -245,6 +258,7 @@ extern "C" int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2)
     T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
     s.c1 = c1; s.c2 = c2;
     T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
+    h->state_published = false;
     return 0;
 }
 
@@ -259,9 +273,11 @@ extern "C" int t2gpu_front_commit_iq(t2gpu_front *h, void *stream)
 {
     if (!h) return -1;
     T2_HIP(hipSetDevice(h->device));
-    launch_front_commit_iq(h->d_state, (hipStream_t)stream);
+    const unsigned seq = ++h->state_seq;
+    launch_front_commit_iq(h->d_state, h->h_state, h->h_state ? h->h_flag : nullptr, seq, (hipStream_t)stream);
     T2_HIP(hipGetLastError());
     h->last_stream = (hipStream_t)stream;
+    h->state_published = h->h_state != nullptr;
     return 0;
 }
 
@@ -297,6 +313,7 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     p.i_in = d_i; p.q_in = d_q; p.n = (int)n; p.n_blocks = (int)((n + FRONT_BLOCK - 1) / FRONT_BLOCK);
     p.n_interp = n_interp; p.out = reinterpret_cast<float2 *>(d_out); p.n_out = n_out;
     p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
+    h->state_published = false;
     const size_t nn = h->nco_runs.size(), nf = h->far_runs.size();
     const int chain_grid = h->chain_on ? front_chain_grid(p, nn, nf) : 0;
     if (chain_grid) {
@@ -350,9 +367,23 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
 {
     if (!h || !out8) return -1;
     T2_HIP(hipSetDevice(h->device));
-    T2_HIP(hipStreamSynchronize(h->last_stream));
     FrontState s;
-    T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+    bool have = false;
+    if (h->state_published) {
+        // the last thing launched on this front end was a commit: its launch stores the state to page-locked memory and raises the
+        // sequence word (a stream wait and a blocking copy took 95 us per execute() of the slot-shaped path)
+        volatile unsigned *flag = h->h_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *flag != h->state_seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+        if (*flag == h->state_seq) { std::atomic_thread_fence(std::memory_order_acquire); s = *h->h_state; have = true; }
+    }
+    if (!have) {
+        T2_HIP(hipStreamSynchronize(h->last_stream));
+        T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+    }
     out8[0] = (float)s.dc_re; out8[1] = (float)s.dc_im; out8[2] = s.c1; out8[3] = s.c2;
     out8[4] = h->phase_nco; out8[5] = h->frequency_nco; out8[6] = s.level_detect; out8[7] = h->x1;
     return 0;
@@ -383,6 +414,7 @@ extern "C" int t2gpu_decim_execute(t2gpu_front *h, int len_in, const float *in, 
     p.n = 0; p.n_blocks = 0; p.n_interp = len_in; p.out = h->d_out;
     p.n_out = (h->decim_phase + len_in) / 2;
     p.stages = FRONT_STAGE_DECIMATE;
+    h->state_published = false;
     launch_front(p, nullptr);
     T2_HIP(hipGetLastError());
     T2_HIP(hipStreamSynchronize(nullptr));
@@ -411,6 +443,7 @@ extern "C" int t2gpu_farrow_execute(t2gpu_front *h, int len_in, const float *in,
     p.n = len_in; p.n_blocks = (len_in + FRONT_BLOCK - 1) / FRONT_BLOCK; p.n_interp = n_interp; p.n_out = 0;
     p.stages = FRONT_STAGE_FARROW;
     if (stage_tables(h, len_in, nullptr, p) != 0) return -1;
+    h->state_published = false;
     launch_front(p, nullptr);
     T2_HIP(hipGetLastError());
     T2_HIP(hipStreamSynchronize(nullptr));
