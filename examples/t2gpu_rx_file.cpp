@@ -17,7 +17,8 @@
 //         instead of the reference's wrapping cast (an extension, t2::llr_demapper::saturate_llr -- with the cast a 256-QAM PLP in
 //         AWGN loses every SIMD batch in the LDPC stage, in the reference as here); --threads 1 (default): the LDPC stage emits on a
 //         thread of its own, as the reference's stage objects live on their own QThreads -- BCH, de-framing and the sink then run beside
-//         the demodulator; 0: everything on the calling thread
+//         the demodulator; 0: everything on the calling thread. With
+//         1 the time de-interleaver likewise hands its TI blocks (demapping, batch forming, LDPC submission) to a thread of its own
 #include <arpa/inet.h>
 #include <chrono>
 #include <cstdio>
@@ -74,7 +75,7 @@ int main(int argc, char **argv)
         to.sin_family = AF_INET; to.sin_port = htons((uint16_t)udp_port); to.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
     }
     try {
-        t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f, device);
+        t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f, device, threads != 0);
         t2::llr_demapper qam(device);
         qam.saturate_llr = saturate != 0;
         t2::ldpc_decoder ldpc(device, 8, threads != 0);                   // --threads 1: the LDPC stage and what is wired behind it on a thread of their own
@@ -129,6 +130,7 @@ int main(int argc, char **argv)
         long frames0 = 0, bb0 = 0, ts0 = 0, n_buf = 0;
         for (; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len, ++n_buf) {
             if (n_buf == warm) {                                          // acquisition is behind us: the clock starts here
+                demodulator.deinterleaver->flush();
                 ldpc.flush();
                 const t2gpu_demod_info w = demodulator.status();
                 frames0 = (long)w.frames; bb0 = bbframes; ts0 = ts_bytes; timed_from = pos;
@@ -141,6 +143,7 @@ int main(int argc, char **argv)
             set_gain();
             demodulator.execute(buf_len, const_cast<int16_t *>(vi.data()) + pos, const_cast<int16_t *>(vq.data()) + pos, &signal);
         }
+        demodulator.deinterleaver->flush();
         ldpc.flush();                                                     // batches still in the decoder come out (and through BCH / de-framer) inside the clock
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         const t2gpu_demod_info st = demodulator.status();

@@ -391,24 +391,41 @@ private:
 // ---------------------------------------------------------------------------------------------------------------- time de-interleaver
 class time_deinterleaver {
 public:
-    explicit time_deinterleaver(int device = 0) : device_(device) {}
-    ~time_deinterleaver() { release(); }
+    // own_thread = true: ti_block -- and with it the demapper and whatever is wired behind -- is emitted on a thread of the stage's own
+    // (the reference's stages each live on a QThread, time_deinterleaver.cpp:30-36), the caller goes on with the next symbols. The
+    // blocks alternate between two buffers as the reference's do (buffer_a / buffer_b, :313-353); a block is handed over when the
+    // thread is through with the one before, so the buffer being filled is never the one being read. flush() waits for that thread.
+    explicit time_deinterleaver(int device = 0, bool own_thread = false) : device_(device), threaded_(own_thread)
+    {
+        if (threaded_) worker_ = std::thread([this] { run(); });
+    }
+    ~time_deinterleaver()
+    {
+        if (threaded_) {
+            { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+            cv_.notify_all();
+            worker_.join();
+        }
+        release();
+    }
+    time_deinterleaver(const time_deinterleaver &) = delete;
+    time_deinterleaver &operator=(const time_deinterleaver &) = delete;
     std::function<void(int ti_block_size, complex *time_deint_cell, int plp_id, const l1_postsignalling &)> ti_block;   // :38
     // time_deinterleaver.h:33, cpp:38-145: one de-interleaver per PLP (the reference keeps one permutation per PLP)
     void start(const t2gpu_l1_pre &l1_pre, const l1_postsignalling &l1_post)
     {
+        flush();
         release();
-        size_t len_max = 0;
         for (const t2gpu_l1_plp &p : l1_post.plp) {
-            t2gpu_ti *h = t2gpu_ti_create(p.plp_mod, p.plp_fec_type, p.plp_num_blocks_max, device_);
-            if (!h) fail("t2gpu_ti_create");
-            h_.push_back(h);
-            len_max = std::max(len_max, (size_t)p.plp_num_blocks_max * t2gpu_ti_cells_per_fec(h));
+            lane l;
+            for (int k = 0; k < 2; ++k) {
+                if (!(l.h[k] = t2gpu_ti_create(p.plp_mod, p.plp_fec_type, p.plp_num_blocks_max, device_))) fail("t2gpu_ti_create");
+                l.out[k].assign((size_t)p.plp_num_blocks_max * t2gpu_ti_cells_per_fec(l.h[k]), complex());
+                t2gpu_host_pin(l.out[k].data(), l.out[k].size() * sizeof(complex));      // the TI block comes down at the link's rate
+            }
+            lanes_.push_back(std::move(l));
         }
         p2_start_idx_cell = 1840 + l1_pre.l1_post_size;
-        out_.assign(len_max, complex());
-        t2gpu_host_pin(out_.data(), out_.size() * sizeof(complex));              // the TI block comes down (and goes up) at the link's rate
-        pinned_ = true;
         plp_state_ = 0;
     }
     // :43, cpp:268-288. The PLP / TI-block sequence of the frame follows from the dynamic signalling alone
@@ -425,40 +442,91 @@ public:
         push(len_in - p2_start_idx_cell, ofdm_cell + p2_start_idx_cell);
     }
     void execute(int len_in, complex *ofdm_cell) { push(len_in, ofdm_cell); }                  // :45, cpp:290-376
+    // the stage's thread has emitted everything handed to it (a no-op without own_thread); rethrows what that thread threw
+    void flush()
+    {
+        if (!threaded_) return;
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !job_.pending; });
+        rethrow_locked();
+    }
 private:
+    struct lane {                                                // one PLP: two de-interleavers, two output buffers, used in turn
+        t2gpu_ti *h[2] = {nullptr, nullptr};
+        std::vector<complex> out[2];
+        int cur = 0;
+    };
+    struct job { bool pending = false; int size = 0, plp = 0; complex *cells = nullptr; l1_postsignalling l1; };
     void push(int n, complex *cells)
     {
         while (n > 0 && k_ < plan_.size()) {
             const t2gpu_ti_block &b = plan_[k_];
-            t2gpu_ti *h = h_.at(b.plp);
+            lane &l = lanes_.at((size_t)b.plp);
+            t2gpu_ti *h = l.h[l.cur];
             if (pos_ == b.offset && t2gpu_ti_begin(h, b.num_blocks) != 0) fail("t2gpu_ti_begin");
             const int take = std::min(n, b.offset + b.size - pos_);
             int done;
             {
                 prof_scope ps(prof_table::TI_PUSH);
-                done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(out_.data()));
+                done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(l.out[l.cur].data()));
             }
             if (done < 0) fail("t2gpu_ti_push");
             cells += take; n -= take; pos_ += take;
             if (done == 1) {
-                if (ti_block) ti_block(b.size, out_.data(), b.plp, l1_post_);
+                emit(b.size, l.out[l.cur].data(), b.plp);
+                l.cur ^= 1;
                 ++k_;
             }
         }
     }
+    void emit(int size, complex *cells, int plp)
+    {
+        if (!threaded_) { if (ti_block) ti_block(size, cells, plp, l1_post_); return; }
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !job_.pending; });          // the block before this one has been dealt with: its buffer is free again
+        rethrow_locked();
+        job_.pending = true; job_.size = size; job_.plp = plp; job_.cells = cells; job_.l1 = l1_post_;
+        cv_.notify_all();
+    }
+    void run()
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [this] { return stop_ || job_.pending; });
+            if (stop_) return;
+            lk.unlock();
+            try {
+                if (ti_block) ti_block(job_.size, job_.cells, job_.plp, job_.l1);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(m_);
+                error_ = std::current_exception();
+            }
+            lk.lock();
+            job_.pending = false;
+            cv_.notify_all();
+        }
+    }
+    void rethrow_locked() { if (error_) { std::exception_ptr e = error_; error_ = nullptr; std::rethrow_exception(e); } }
     void release()
     {
-        for (t2gpu_ti *h : h_) t2gpu_ti_destroy(h);
-        h_.clear();
-        if (pinned_) { t2gpu_host_unpin(out_.data()); pinned_ = false; }
+        for (lane &l : lanes_)
+            for (int k = 0; k < 2; ++k) {
+                if (l.h[k]) t2gpu_ti_destroy(l.h[k]);
+                if (!l.out[k].empty()) t2gpu_host_unpin(l.out[k].data());
+            }
+        lanes_.clear();
     }
-    bool pinned_ = false;
     int device_, p2_start_idx_cell = 0, plp_state_ = 0, pos_ = 0;
+    bool threaded_, stop_ = false;
     size_t k_ = 0;
-    std::vector<t2gpu_ti *> h_;
+    std::vector<lane> lanes_;
     std::vector<t2gpu_ti_block> plan_;
     l1_postsignalling l1_post_;
-    std::vector<complex> out_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::exception_ptr error_;
+    job job_;
+    std::thread worker_;
 };
 
 // ---------------------------------------------------------------------------------------------------------------- DSP front end
@@ -565,8 +633,9 @@ struct signal_estimate {                                                        
 // The signals stay re-assignable std::function members.
 class dvbt2_demodulator {
 public:
-    dvbt2_demodulator(id_device_t id_device, float sample_rate, int device = 0)
-        : deinterleaver(new time_deinterleaver(device)), h_(t2gpu_demod_create((int)id_device, sample_rate, device))
+    // fec_thread: the time de-interleaver emits on a thread of its own (time_deinterleaver's own_thread)
+    dvbt2_demodulator(id_device_t id_device, float sample_rate, int device = 0, bool fec_thread = false)
+        : deinterleaver(new time_deinterleaver(device, fec_thread)), h_(t2gpu_demod_create((int)id_device, sample_rate, device))
     {
         if (!h_) { delete deinterleaver; fail("t2gpu_demod_create"); }
         l1_dyn_execute = [this](const l1_postsignalling &p, int len, complex *c) { deinterleaver->l1_dyn_execute(p, len, c); };
