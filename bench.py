@@ -286,7 +286,11 @@ def drop_in_leg(w, ui, uq, device, frames=26, warm_frames=10, sent=None, saturat
         hit = int(np.isin(packet_hashes(pk), want).sum()) if pk.shape[0] else 0
         out["ts_packets"] = int(pk.shape[0])
         out["ts_packets_that_were_sent"] = hit
-        out["ts_matches_sent"] = bool(pk.shape[0] > 0 and hit >= pk.shape[0] - 2 * frames)     # a cut packet at a dropped batch / the stream's first
+        if r["bbframes"] == 0 and dropped > 0:
+            out["ts_matches_sent"] = None
+            out["note"] = "no transport stream: every SIMD batch was dropped by the LDPC stage (the reference's wrapping int8 cast on 256-QAM, as in the headline leg)"
+        else:
+            out["ts_matches_sent"] = bool(pk.shape[0] > 0 and hit >= pk.shape[0] - 2 * frames)     # a cut packet at a dropped batch / the stream's first
     out["entry"] = ("t2::dvbt2_demodulator::execute(len, i, q, signal) per buffer = t2gpu_demod_execute, host buffers between all stage "
                     "classes as the reference's slots carry them; loops closed, nothing configured (mode from P1 / L1)")
     out["workload"] = "%s, %d frames of int16 I/Q at %.1f dB, the first %d frames' buffers untimed (acquisition)" % (
