@@ -60,7 +60,7 @@ int main(int argc, char **argv)
             t2::l1_postsignalling l1;
             l1.plp.resize(1);
             l1.plp[0].plp_fec_type = fec_type; l1.plp[0].plp_cod = cod;
-            t2::ldpc_decoder ldpc;
+            t2::ldpc_decoder ldpc(0, 8, std::getenv("STAGE_THREADS") && std::atoi(std::getenv("STAGE_THREADS")) != 0);
             t2::bch_decoder bch;
             bch.outer_code = argc > 6 && std::string(argv[6]) == "outer";       // the library's opt-in BCH correction in front
             std::vector<uint8_t> out;
@@ -114,9 +114,11 @@ int main(int argc, char **argv)
             }
             // the reference's connect() chain from the time de-interleaver down (time_deinterleaver.cpp:30, llr_demapper.cpp:83,
             // ldpc_decoder.cpp:149, bch_decoder.cpp:43)
-            t2::time_deinterleaver ti;
+            // STAGE_THREADS=1: the de-interleaver and the LDPC stage each emit on a thread of their own (as the reference's stage objects do)
+            const bool threads = std::getenv("STAGE_THREADS") && std::atoi(std::getenv("STAGE_THREADS")) != 0;
+            t2::time_deinterleaver ti(0, threads);
             t2::llr_demapper qam;
-            t2::ldpc_decoder ldpc;
+            t2::ldpc_decoder ldpc(0, 8, threads);
             t2::bch_decoder bch;
             t2::bb_de_header deheader(need_plp);
             std::vector<uint8_t> out, ts;
@@ -143,6 +145,7 @@ int main(int argc, char **argv)
                 else ti.execute(sizes[l], cells.data() + pos);
                 pos += (size_t)sizes[l];
             }
+            ti.flush();
             ldpc.flush();
             dump(argv[3], out);
             dump(ts_path, ts);

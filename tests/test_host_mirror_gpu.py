@@ -55,8 +55,8 @@ def test_decimator_and_farrow_classes(driver, tmp_path):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("fec_type,cod", [(0, 0), (1, 3)])
-def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod):
+@pytest.mark.parametrize("fec_type,cod,threads", [(0, 0, 0), (1, 3, 0), (1, 3, 1)])
+def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod, threads):
     """ldpc_decoder.bit_bch -> bch_decoder.execute -> bit_descramble, three SIMD batches, the middle one undecodable: the
     reference prints its message and drops that batch; the other two come out descrambled, frame by frame."""
     cid = ol.code_id(fec_type, cod)
@@ -65,7 +65,7 @@ def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod):
     rng = np.random.Generator(np.random.PCG64(6))
     llr[32:64] = rng.integers(-20, 21, size=(32, n), dtype=np.int8)              # noise only: never converges
     llr.tofile(tmp_path / "llr.i8")
-    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod)
+    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod, env_extra={"STAGE_THREADS": str(threads)})
     assert err.count("LDPC decoder could not recover the codeword!") == 1
     k_bch = t2_tx.K_BCH[cid]
     got = np.fromfile(tmp_path / "out.u8", np.uint8).reshape(-1, 1 + k_bch)
@@ -167,6 +167,12 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
         env_extra={"T2GPU_HANDOFF": "0"})
     assert np.array_equal(np.fromfile(tmp_path / "out0.u8", np.uint8), got.reshape(-1))
     assert np.array_equal(np.fromfile(tmp_path / "ts0.u8", np.uint8), ts)
+    # ... and with the de-interleaver and the LDPC stage on threads of their own (t2::time_deinterleaver / t2::ldpc_decoder own_thread:
+    # TI blocks alternate between two buffers, batches are awaited and emitted beside the caller): same frames in the same order
+    run(driver, "cells", tmp_path / "cells.c64", tmp_path / "out1.u8", 1, tmp_path / "ts1.u8", lps, code_rate, len(sizes), *sizes, 2, *plps,
+        env_extra={"STAGE_THREADS": "1"})
+    assert np.array_equal(np.fromfile(tmp_path / "out1.u8", np.uint8), got.reshape(-1))
+    assert np.array_equal(np.fromfile(tmp_path / "ts1.u8", np.uint8), ts)
 
 
 def _unconfigured_stream(tmp_path, n_frames, seed, cfo_hz, spoil_frame=None):
