@@ -195,16 +195,19 @@ private:
         }
         if (rc == 1) return false;
         if (rc != 0) fail("t2gpu_ldpc_collect");
+        // the result stays in the handle's staging until the handle is submitted to again: it is marked free AFTER the consumer returned
+        // (also when the consumer throws: the batch is then lost, the stage stays usable)
+        struct done_guard {
+            ldpc_decoder *d; slot *s;
+            ~done_guard()
+            {
+                { std::lock_guard<std::mutex> lk(d->m_); d->fifo_.erase(d->fifo_.begin()); s->busy = false; }
+                d->cv_free_.notify_all();
+            }
+        } guard{this, s};
         const int trials_left = trials[0];
         if (trials_left < 0) std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials_left);
-        // the result stays in the handle's staging until the handle is submitted to again: it is marked free AFTER the consumer returned
         else if (bit_bch) bit_bch(s->idx, s->l1, s->k_ldpc * SIZEOF_SIMD, const_cast<uint8_t *>(out));
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fifo_.erase(fifo_.begin());
-            s->busy = false;
-        }
-        cv_free_.notify_all();
         return true;
     }
     void run()                                                   // the stage's own thread
@@ -220,7 +223,11 @@ private:
             } catch (...) {
                 std::lock_guard<std::mutex> lk(m_);
                 error_ = std::current_exception();
-                for (slot *q : fifo_) q->busy = false;           // what was in flight is lost with the error
+                for (slot *q : fifo_) {                          // what was in flight is lost with the error; its handles are made reusable
+                    const uint8_t *o = nullptr; const int *t = nullptr;
+                    (void)t2gpu_ldpc_collect(q->h, 1, &o, &t, nullptr);
+                    q->busy = false;
+                }
                 fifo_.clear();
                 cv_free_.notify_all();
             }

@@ -60,6 +60,7 @@ struct FrontChainArgs {
     FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs, then Farrow runs
 };
 int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs);
+int front_chain_capacity();                    // the largest grid the current device keeps resident for it (<= FRONT_CHAIN_MAX_GRID)
 void launch_front_chain(FrontChainArgs &a, int grid, hipStream_t stream);
 
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.

@@ -665,6 +665,18 @@ static long fd_blocks_of(const FrontParams &p)
     return by_out > by_cells ? by_out : by_cells;
 }
 
+// workgroups of front_chain_kernel the current device keeps resident at once (its barrier needs the whole grid resident: a partitioned
+// device with 32 CUs holds fewer than FRONT_CHAIN_MAX_GRID)
+int front_chain_capacity()
+{
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_chain_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const long cap = (long)per_cu * prop.multiProcessorCount / 2;      // half of it: other streams' workgroups may hold the rest
+    return (int)(cap > FRONT_CHAIN_MAX_GRID ? FRONT_CHAIN_MAX_GRID : cap);
+}
+
 int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs)
 {
     const int all = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;

@@ -47,6 +47,7 @@ struct t2gpu_front {
     // short calls in one launch (front_kernels.hip: front_chain_kernel); T2GPU_FRONT_CHAIN=0 at creation keeps the five launches
     unsigned long long *d_bar = nullptr, chain_count = 0;
     bool chain_on = true;
+    int chain_cap = 0;                 // front_chain_capacity() of the handle's device
     // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
     FrontState *h_state = nullptr;
     unsigned *h_flag = nullptr, state_seq = 0;
@@ -171,6 +172,7 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
     if (const char *e = std::getenv("T2GPU_FRONT_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    h->chain_cap = front_chain_capacity();
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocDefault) == hipSuccess) {
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
         *h->h_flag = 0;
@@ -315,7 +317,8 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
     h->state_published = false;
     const size_t nn = h->nco_runs.size(), nf = h->far_runs.size();
-    const int chain_grid = h->chain_on ? front_chain_grid(p, nn, nf) : 0;
+    int chain_grid = h->chain_on ? front_chain_grid(p, nn, nf) : 0;
+    if (chain_grid > h->chain_cap) chain_grid = 0;
     if (chain_grid) {
         // a symbol's worth of samples: one launch, the run tables in its arguments (no table copy, nothing to wait for)
         FrontChainArgs a;
