@@ -82,6 +82,12 @@ int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream);
 /* What a decode occupies: out6 = {workgroups resident per CU, wavefronts per workgroup, dynamic LDS bytes per workgroup, FEC frames per
  * workgroup, CUs of the device, SIMD batches resident at once} for the kernel variant the handle's configuration selects. */
 int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6);
+/* Workgroups a decode of n_frames launches (resident for its whole duration). t2gpu_ldpc_set_plain_launch(h, 1): the handle's decodes
+ * become ordinary launches instead of cooperative ones, so that decodes of several handles on several streams run side by side
+ * (cooperative launches of different streams run one after the other) -- for callers that keep what is in flight together within the
+ * device's CUs (t2gpu_rx with t2gpu_rx_set_overlap does). */
+int t2gpu_ldpc_launch_workgroups(const t2gpu_ldpc *h, int n_frames);
+int t2gpu_ldpc_set_plain_launch(t2gpu_ldpc *h, int plain);
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);
@@ -601,9 +607,11 @@ int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream);
 int t2gpu_rx_carry(const t2gpu_rx *h);
 /* The decode of a call (LDPC, outer code, descrambler + packing) on a stream of the handle's own, so that the NEXT call's front end ..
  * demapper run beside it where the decoder leaves CUs free: calls of one or two T2 frames are 6 - 13 SIMD batches = 96 - 208 of the 256
- * workgroups the device keeps resident. Same results, same batch formation. With it on, a call's stream no longer covers the decode:
- * d_bytes_out / d_trials_out are complete after t2gpu_rx_wait (or any fetch / results / stage_ms / TS read, which wait themselves).
- * To be switched on a drained handle with no frames waiting for a batch. */
+ * workgroups the device keeps resident. Decodes of at most half the device (one-frame calls) also run beside EACH OTHER, two at a time:
+ * three LLR buffers rotate, two decode sets (decoder state, stream, output rows) alternate; larger ones follow one another on one set.
+ * Same results, same batch formation, same TS. With it on, a call's stream no longer covers the decode:
+ * d_bytes_out / d_trials_out (the rows of THIS call's decode) are complete after t2gpu_rx_wait (or any fetch / results / stage_ms /
+ * TS read, which wait themselves). To be switched on a drained handle with no frames waiting for a batch. */
 int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable);
 int t2gpu_rx_wait(t2gpu_rx *h);
 int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6);          /* t2gpu_ldpc_occupancy of the handle's decoder */

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_occupancy": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_ldpc_launch_workgroups": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_ldpc_set_plain_launch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile_layers": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demap_create": (_vp, [ctypes.c_int] * 6),

@@ -42,6 +42,7 @@ struct t2gpu_ldpc {
     hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
     bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
+    bool plain_always = false;          // t2gpu_ldpc_set_plain_launch
     // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
     bool packed_ok = false;
     int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
@@ -230,6 +231,28 @@ extern "C" int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6)
     return 0;
 }
 
+// Workgroups a decode of n_frames launches (all of them resident for its whole duration), or -1.
+extern "C" int t2gpu_ldpc_launch_workgroups(const t2gpu_ldpc *h, int n_frames)
+{
+    if (!h || n_frames < 1) { set_error("t2gpu_ldpc_launch_workgroups: bad arguments"); return -1; }
+    const int nbatches = (n_frames + h->group - 1) / h->group;
+    const bool packed = use_packed(h);
+    const int wg_per_batch = packed ? h->group / 2 : h->group;
+    const int maxslots = (packed ? h->num_cu * h->p_blocks_per_cu : resident_blocks(h)) / wg_per_batch;
+    if (maxslots < 1) return -1;
+    return (nbatches < maxslots ? nbatches : maxslots) * wg_per_batch;
+}
+
+// plain != 0: the packed kernel's decodes of this handle are ordinary launches, not cooperative ones. Cooperative launches of different
+// streams run one after the other; plain ones run side by side -- the caller then sees to it that what is in flight together fits the
+// device (t2gpu_ldpc_launch_workgroups; the frames of a batch meet at every sweep, so their workgroups must all be resident).
+extern "C" int t2gpu_ldpc_set_plain_launch(t2gpu_ldpc *h, int plain)
+{
+    if (!h) { set_error("t2gpu_ldpc_set_plain_launch: null handle"); return -1; }
+    h->plain_always = plain != 0;
+    return 0;
+}
+
 extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uint8_t *d_bits,
                                       int8_t *d_llr_out, int *d_trials_left, void *stream)
 {
@@ -292,7 +315,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
             p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
         }
         h->resident_total += (unsigned)grid;
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !h->plain_launch));
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
         else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
         return 0;
     }
@@ -308,7 +331,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
         const int slots = std::min(nslots, nb);
         h->resident_total += (unsigned)(slots * wg_per_batch);
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s, !h->plain_launch));
+        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
         else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
     }
     return 0;

@@ -52,13 +52,25 @@ struct t2gpu_rx {
     int8_t *d_llr = nullptr;                  // the LLR rows the next back half fills (= d_llr_ab[cur])
     // t2gpu_rx_set_overlap: the decode of a call (LDPC, descrambler + packing) runs on a stream of the handle's own, so that the next
     // call's front end .. demapper run beside it where the decoder leaves CUs free (calls of one or two T2 frames: 6 - 13 SIMD batches
-    // = 96 - 208 of 256 workgroups). Two LLR buffers alternate: the decoder reads one while the demapper fills the other.
+    // = 96 - 208 of 256 workgroups), and -- while two decodes fit the device together (one-frame calls) -- beside the decode of the call
+    // before. Three LLR buffers rotate (the demapper fills one, up to two decodes read the others; the frames behind a call's last
+    // complete batch are copied to the head of the next buffer), two decode sets alternate (decoder handle with its state, stream,
+    // output rows): decode k runs on set k % 2 from buffer k % 3.
     bool overlap = false;
-    hipStream_t dec = nullptr;
-    int8_t *d_llr_ab[2] = {nullptr, nullptr};
-    int cur = 0;
-    hipEvent_t ev_demap = nullptr, ev_dec_done[2] = {nullptr, nullptr}, ev_l1_copied = nullptr;
-    bool dec_done_set[2] = {false, false}, l1_copied_set = false;
+    int8_t *d_llr_ab[3] = {nullptr, nullptr, nullptr};
+    int cur = 0;                              // LLR buffer the next back half fills
+    int set = 0, last_set = 0;                // decode set of the next decode (when it is a small one) / of the last decode
+    t2gpu_ldpc *ldpc_s[2] = {nullptr, nullptr};
+    hipStream_t dec_s[2] = {nullptr, nullptr};
+    uint8_t *d_bits_s[2] = {nullptr, nullptr}, *d_pack_s[2] = {nullptr, nullptr};
+    int32_t *d_trials_s[2] = {nullptr, nullptr};
+    hipEvent_t ev_demap = nullptr, ev_l1_copied = nullptr;
+    hipEvent_t ev_llr_read[3] = {nullptr, nullptr, nullptr};    // the decode that read buffer b is through
+    hipEvent_t ev_carry[3] = {nullptr, nullptr, nullptr};       // the waiting frames have been copied to the head of buffer b
+    hipEvent_t ev_dec_done[2] = {nullptr, nullptr};             // the last decode of set s is through
+    bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false}, l1_copied_set = false;
+    int in_flight_wg[2] = {0, 0};             // workgroups of the last decode of each set (what may still be resident)
+    int num_cu = 0;
     uint8_t *d_bits = nullptr, *d_out = nullptr;
     int32_t *d_trials = nullptr, *d_outer = nullptr;
     bool outer_code = false;
@@ -97,11 +109,11 @@ struct TsSlot {
     uint8_t *pack = nullptr;                  // pinned: [frames][k_bch / 8]
     int32_t *trials = nullptr;                // pinned: [batches]
     float *l1 = nullptr;                      // pinned: [F][p2_skip][2]
-    hipEvent_t ready = nullptr;
+    hipEvent_t ready = nullptr, l1_ready = nullptr;
     bool busy = false;
 };
 struct TsEnd {
-    static constexpr int SLOTS = 3;
+    static constexpr int SLOTS = 4;           // two decodes in flight, one being de-framed, one being filled
     t2gpu_rx *rx = nullptr;
     t2gpu_bbdh *bbdh = nullptr;
     int need_plp = 0, l1_check = 0;
@@ -113,8 +125,11 @@ struct TsEnd {
     int next_slot = 0, in_flight = 0;
     bool stop = false;
     hipStream_t copy_stream = nullptr;        // the device -> host copies run beside the next call's kernels
+    hipStream_t l1_stream = nullptr;          // overlap mode: the L1 cells' copy on a stream of its own -- behind the rows of earlier decodes
+                                              // on copy_stream it would wait for those decodes, and the next call's P2 equaliser for it
     hipEvent_t decoded = nullptr;             // recorded on the call's stream behind K-descramble-pack
     hipEvent_t last_copy = nullptr;           // `ready` of the newest job: the next back half waits for it before it overwrites the rows
+    hipEvent_t last_copy_s[2] = {nullptr, nullptr};   // overlap mode: the same per decode set (a decode overwrites its own set's rows only)
     struct Chunk { std::unique_ptr<uint8_t[]> p; size_t cap = 0, size = 0; };
     std::deque<Chunk> ts;                     // TS bytes not yet read: one chunk per job, oldest first
     std::vector<Chunk> pool;                  // chunks handed out completely, reused by the worker (no fresh pages per job)
@@ -127,6 +142,9 @@ namespace {
 
 void free_all(t2gpu_rx *h)
 {
+    if (h->d_llr_ab[0]) {                                        // overlap mode was set up: the plain names go back to the objects they own
+        h->d_llr = h->d_llr_ab[0]; h->ldpc = h->ldpc_s[0]; h->d_bits = h->d_bits_s[0]; h->d_pack = h->d_pack_s[0]; h->d_trials = h->d_trials_s[0];
+    }
     if (h->front) t2gpu_front_destroy(h->front);
     if (h->p1) t2gpu_p1_destroy(h->p1);
     if (h->ofdm) t2gpu_ofdm_destroy(h->ofdm);
@@ -142,9 +160,13 @@ void free_all(t2gpu_rx *h)
     if (h->side) hipStreamDestroy(h->side);
     for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
     hipFree(h->d_sync); hipFree(h->d_pack); hipFree(h->d_l1);
-    if (h->d_llr_ab[1]) hipFree(h->d_llr_ab[1] == h->d_llr ? h->d_llr_ab[0] : h->d_llr_ab[1]);   // (whichever is not d_llr, freed above)
-    if (h->dec) hipStreamDestroy(h->dec);
-    for (hipEvent_t e : {h->ev_demap, h->ev_dec_done[0], h->ev_dec_done[1], h->ev_l1_copied}) if (e) hipEventDestroy(e);
+    // overlap mode's second / third copies (index 0 of each is the plain mode's own object, freed with it)
+    for (int b = 1; b < 3; ++b) hipFree(h->d_llr_ab[b]);
+    if (h->ldpc_s[1]) t2gpu_ldpc_destroy(h->ldpc_s[1]);
+    hipFree(h->d_bits_s[1]); hipFree(h->d_pack_s[1]); hipFree(h->d_trials_s[1]);
+    for (hipStream_t st : h->dec_s) if (st) hipStreamDestroy(st);
+    for (hipEvent_t e : {h->ev_demap, h->ev_l1_copied, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
+                         h->ev_dec_done[0], h->ev_dec_done[1]}) if (e) hipEventDestroy(e);
 }
 
 void ts_stop(t2gpu_rx *h)
@@ -162,9 +184,11 @@ void ts_stop(t2gpu_rx *h)
         if (sl.trials) hipHostFree(sl.trials);
         if (sl.l1) hipHostFree(sl.l1);
         if (sl.ready) hipEventDestroy(sl.ready);
+        if (sl.l1_ready) hipEventDestroy(sl.l1_ready);
     }
     if (t->bbdh) t2gpu_bbdh_destroy(t->bbdh);
     if (t->copy_stream) hipStreamDestroy(t->copy_stream);
+    if (t->l1_stream) hipStreamDestroy(t->l1_stream);
     if (t->decoded) hipEventDestroy(t->decoded);
     delete t;
     h->ts = nullptr;
@@ -354,6 +378,7 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
 // LDPC + (opt-in outer code) + K-descramble-pack of d_llr[0 .. count) into rows `at`.. of d_bits / d_pack, trials from batch `at / group`
 int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s, const int8_t *llr = nullptr)
 {
+    // (overlap mode: h->ldpc / d_bits / d_pack / d_trials name the decode set this decode runs on)
     uint8_t *bits = h->d_bits + (size_t)at * h->k_ldpc;
     T2_HIP(hipEventRecord(h->ev_ldpc0, s));
     if (t2gpu_ldpc_execute_dev(h->ldpc, llr ? llr : h->d_llr, count, bits, nullptr, h->d_trials + at / h->group, s) != 0) return -1;
@@ -366,7 +391,7 @@ int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s, const int8_t *llr =
     return 0;
 }
 
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after = nullptr);
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after = nullptr, int set = -1);
 }  // namespace
 
 // BASELINE config 2: FFT (guard dropped) + equalisers / frequency de-interleave + time de-interleave + demap of the frames the last
@@ -396,30 +421,58 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
     const int total = h->carry + F * nb;
     const int ready = (total / h->group) * h->group, rest = total - ready;
     if (h->overlap) {
-        // ---- the decode on the handle's own stream (t2gpu_rx_set_overlap)
-        int8_t *llr = h->d_llr, *other = h->d_llr_ab[1 - h->cur];
-        // this buffer was last read by the decode of two calls ago; d_l1 is read by the host end's copy of the previous call
-        if (h->dec_done_set[h->cur]) T2_HIP(hipStreamWaitEvent(s, h->ev_dec_done[h->cur], 0));
+        // ---- the decode on a stream of the handle's own (t2gpu_rx_set_overlap)
+        const int b = h->cur, nb_ = (h->cur + 1) % 3;
+        // a decode that could not run beside another one like it (more than half the device) stays on set 0 and is launched
+        // cooperatively, as the one-stream schedule of round 4's first form did; smaller ones alternate between the sets, plain launches
+        const int wg_est = ready > 0 ? (h->outer_code ? h->num_cu : t2gpu_ldpc_launch_workgroups(h->ldpc_s[0], ready)) : 0;
+        const bool pair_ok = ready > 0 && 2 * wg_est <= h->num_cu;
+        const int set = pair_ok ? h->set : 0;
+        int8_t *llr = h->d_llr_ab[b];
+        // this buffer was last read by the decode of three calls ago; d_l1 is read by the host end's copy of the previous call
+        if (h->llr_read_set[b]) T2_HIP(hipStreamWaitEvent(s, h->ev_llr_read[b], 0));
         if (h->l1_copied_set) T2_HIP(hipStreamWaitEvent(s, h->ev_l1_copied, 0));
         if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
         T2_HIP(hipEventRecord(h->ev_demap, s));
-        hipStream_t d = h->dec;
-        T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
-        // the host end's copies of the previous decode read the rows this decode overwrites
-        if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(d, h->ts->last_copy, 0));
         if (ready > 0) {
-            // the frames behind the last complete batch go to the head of the other buffer (its last reader, the previous decode, is
-            // earlier on this stream); the next call's demapper writes behind them
-            if (rest > 0) T2_HIP(hipMemcpyAsync(other, llr + (size_t)ready * h->fec_size, (size_t)rest * h->fec_size, hipMemcpyDeviceToDevice, d));
+            hipStream_t d = h->dec_s[set];
+            h->ldpc = h->ldpc_s[set]; h->d_bits = h->d_bits_s[set]; h->d_pack = h->d_pack_s[set]; h->d_trials = h->d_trials_s[set];
+            T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
+            // the frames waiting at the head of this buffer were put there by the previous decode's stream
+            if (h->carry > 0 && h->carry_set[b]) T2_HIP(hipStreamWaitEvent(d, h->ev_carry[b], 0));
+            // the host end's copies of this set's previous decode read the rows this decode overwrites
+            if (h->ts && h->ts->last_copy_s[set]) T2_HIP(hipStreamWaitEvent(d, h->ts->last_copy_s[set], 0));
+            // two decodes side by side only while both fit the device (the frames of a batch meet at every sweep: partly resident grids
+            // of two launches would wait for each other); otherwise behind the other set's decode, as one stream would order them
+            // (the opt-in outer code keeps its per-frame status in one buffer for both sets: its decodes go one after the other)
+            const int wg = wg_est;
+            if (wg < 0) return -1;
+            t2gpu_ldpc_set_plain_launch(h->ldpc, pair_ok ? 1 : 0);
+            if (h->dec_done_set[1 - set] && wg + h->in_flight_wg[1 - set] > h->num_cu) T2_HIP(hipStreamWaitEvent(d, h->ev_dec_done[1 - set], 0));
+            if (rest > 0) {
+                // the frames behind the last complete batch go to the head of the next buffer (its last reader: the decode of two calls ago)
+                if (h->llr_read_set[nb_]) T2_HIP(hipStreamWaitEvent(d, h->ev_llr_read[nb_], 0));
+                T2_HIP(hipMemcpyAsync(h->d_llr_ab[nb_], llr + (size_t)ready * h->fec_size, (size_t)rest * h->fec_size, hipMemcpyDeviceToDevice, d));
+                T2_HIP(hipEventRecord(h->ev_carry[nb_], d));
+                h->carry_set[nb_] = true;
+            }
             if (rx_decode(h, ready, 0, d, llr) != 0) return -1;
-            T2_HIP(hipEventRecord(h->ev_dec_done[h->cur], d));
-            h->dec_done_set[h->cur] = true;
-            h->cur = 1 - h->cur;
+            T2_HIP(hipEventRecord(h->ev_llr_read[b], d));
+            T2_HIP(hipEventRecord(h->ev_dec_done[set], d));
+            h->llr_read_set[b] = true; h->dec_done_set[set] = true; h->in_flight_wg[set] = wg;
+            h->cur = nb_;
             h->d_llr = h->d_llr_ab[h->cur];
+            h->set = pair_ok ? 1 - set : 0;
+            h->last_set = set;
+            h->carry = rest;
+            h->last_ready = ready;
+            if (h->ts && ts_submit(h, ready, 0, F, d, h->ev_demap, set) != 0) return -1;
+        } else {
+            // nothing to decode yet: the frames stay where they are; the host end still gets the call's L1 cells
+            h->carry = rest;
+            h->last_ready = 0;
+            if (h->ts && ts_submit(h, 0, 0, F, s, h->ev_demap, -1) != 0) return -1;
         }
-        h->carry = rest;
-        h->last_ready = ready;
-        if (h->ts && ts_submit(h, ready, 0, F, d, h->ev_demap) != 0) return -1;
         h->fec_seq += ready;
         h->t2_seq += F;
         if (d_bytes_out) *d_bytes_out = h->d_pack;
@@ -448,9 +501,30 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
 {
     if (!h) { set_error("t2gpu_rx_flush_dev: null handle"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    hipStream_t s = h->overlap ? h->dec : (hipStream_t)stream;       // (overlap: the waiting frames were put in place on the decode stream)
     const int n = h->carry;
     if (n == 0) return 0;
+    if (h->overlap) {
+        // the waiting frames sit at the head of buffer `cur` (copied there on a decode stream). They are decoded on the set of the last
+        // decode, on its stream and so behind it, and their rows follow that decode's rows, as in the plain schedule
+        const int b = h->cur, set = h->last_set;
+        const int at = h->dec_done_set[set] ? h->last_ready : 0;
+        hipStream_t d = h->dec_s[set];
+        h->ldpc = h->ldpc_s[set]; h->d_bits = h->d_bits_s[set]; h->d_pack = h->d_pack_s[set]; h->d_trials = h->d_trials_s[set];
+        if (h->carry_set[b]) T2_HIP(hipStreamWaitEvent(d, h->ev_carry[b], 0));
+        T2_HIP(hipEventRecord(h->ev_demap, (hipStream_t)stream));                 // the call's stream may have put frames there itself (calls without a full batch)
+        T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
+        if (h->dec_done_set[1 - set]) T2_HIP(hipStreamWaitEvent(d, h->ev_dec_done[1 - set], 0));   // the end of a stream: nothing runs beside it
+        if (rx_decode(h, n, at, d, h->d_llr_ab[b]) != 0) return -1;
+        T2_HIP(hipEventRecord(h->ev_llr_read[b], d));
+        T2_HIP(hipEventRecord(h->ev_dec_done[set], d));
+        h->llr_read_set[b] = true; h->dec_done_set[set] = true; h->in_flight_wg[set] = h->num_cu;
+        h->carry = 0;
+        h->last_ready = at + n;
+        if (h->ts && ts_submit(h, n, at, 0, d, nullptr, set) != 0) return -1;
+        h->fec_seq += n;
+        return n;
+    }
+    hipStream_t s = (hipStream_t)stream;
     const int at = h->last_ready;                                // a multiple of the group: trials of the short batch at at / group
     if (h->ts && h->ts->last_copy) T2_HIP(hipStreamWaitEvent(s, h->ts->last_copy, 0));
     if (rx_decode(h, n, at, s) != 0) return -1;
@@ -470,23 +544,48 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
     T2_HIP(hipSetDevice(h->device));
     T2_HIP(hipDeviceSynchronize());
     if (h->carry != 0) { set_error("t2gpu_rx_set_overlap: frames are waiting for a batch (flush or reset first)"); return -1; }
-    if (enable && !h->dec) {
-        const size_t bytes = ((size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + h->row_pad) * h->fec_size;
-        h->d_llr_ab[0] = h->d_llr;
-        T2_HIP(hipMalloc(&h->d_llr_ab[1], bytes));
-        T2_HIP(hipStreamCreateWithFlags(&h->dec, hipStreamNonBlocking));
-        for (hipEvent_t *e : {&h->ev_demap, &h->ev_dec_done[0], &h->ev_dec_done[1], &h->ev_l1_copied}) T2_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        h->cur = 0;
+    if (enable && !h->d_llr_ab[0]) {
+        const t2gpu_rx_config &c = h->cfg;
+        const size_t rows = (size_t)c.max_frames * c.plp_num_blocks + h->row_pad;
+        hipDeviceProp_t prop;
+        T2_HIP(hipGetDeviceProperties(&prop, h->device));
+        h->num_cu = prop.multiProcessorCount;
+        h->d_llr_ab[0] = h->d_llr; h->ldpc_s[0] = h->ldpc; h->d_bits_s[0] = h->d_bits; h->d_pack_s[0] = h->d_pack; h->d_trials_s[0] = h->d_trials;
+        bool ok = true;
+        for (int b = 1; b < 3; ++b) ok = ok && hipMalloc(&h->d_llr_ab[b], rows * h->fec_size) == hipSuccess;
+        ok = ok && hipMalloc(&h->d_bits_s[1], rows * h->k_ldpc) == hipSuccess && hipMalloc(&h->d_pack_s[1], rows * (h->k_bch / 8)) == hipSuccess &&
+             hipMalloc(&h->d_trials_s[1], (rows / h->group + 2) * sizeof(int32_t)) == hipSuccess;
+        if (ok) {
+            h->ldpc_s[1] = t2gpu_ldpc_create(c.plp_fec_type, c.plp_cod, (int)rows, h->device);
+            ok = h->ldpc_s[1] && t2gpu_ldpc_configure(h->ldpc_s[1], h->group, c.ldpc_trials > 0 ? c.ldpc_trials : 25) == 0;
+        }
+        // (default priority: at the lowest one the next call's front half, issued later, was dispatched ahead of the decode it is meant
+        // to run beside -- 2- to 16-frame calls lost 2 - 7 %)
+        for (int k = 0; k < 2 && ok; ++k) ok = hipStreamCreateWithFlags(&h->dec_s[k], hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t *e : {&h->ev_demap, &h->ev_l1_copied, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
+                              &h->ev_carry[2], &h->ev_dec_done[0], &h->ev_dec_done[1]})
+            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { set_error("t2gpu_rx_set_overlap: allocation failed"); return -1; }
+    }
+    if (h->d_llr_ab[0]) {
+        // from a known state either way: buffer 0, set 0, nothing in flight (the device is idle here)
+        h->cur = 0; h->set = 0; h->last_set = 0;
+        h->d_llr = h->d_llr_ab[0]; h->ldpc = h->ldpc_s[0]; h->d_bits = h->d_bits_s[0]; h->d_pack = h->d_pack_s[0]; h->d_trials = h->d_trials_s[0];
+        for (bool &v : h->llr_read_set) v = false;
+        for (bool &v : h->carry_set) v = false;
+        h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false;
+        h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
+        if (h->ts) h->ts->last_copy_s[0] = h->ts->last_copy_s[1] = nullptr;
+        for (t2gpu_ldpc *l : h->ldpc_s) if (l) t2gpu_ldpc_set_plain_launch(l, 0);    // (decided per decode in overlap mode)
     }
     h->overlap = enable != 0;
-    if (!h->overlap && h->dec) { h->cur = 0; h->d_llr = h->d_llr_ab[0]; h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false; }
     return 0;
 }
 extern "C" int t2gpu_rx_wait(t2gpu_rx *h)
 {
     if (!h) { set_error("t2gpu_rx_wait: null handle"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    if (h->dec) T2_HIP(hipStreamSynchronize(h->dec));
+    for (hipStream_t st : h->dec_s) if (st) T2_HIP(hipStreamSynchronize(st));
     return 0;
 }
 extern "C" int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6) { return h ? t2gpu_ldpc_occupancy(h->ldpc, out6) : -1; }
@@ -504,7 +603,11 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
         t2gpu_bbdh_reset(h->ts->bbdh);
     }
     h->carry = 0; h->last_ready = 0; h->fec_seq = 0; h->t2_seq = 0;
+    h->set = 0; h->last_set = 0;
+    for (bool &v : h->llr_read_set) v = false;
+    for (bool &v : h->carry_set) v = false;
     h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false;
+    h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
     return 0;
 }
 
@@ -632,7 +735,7 @@ void ts_worker(TsEnd *t)
 // on the stream and hand the job to the worker. Blocks only when all slots are still in use (the host end is SLOTS calls behind).
 // l1_after (overlap mode): the L1 cells are complete at that event already -- their copy is queued behind it and in front of the decode's
 // (the next call's P2 equaliser, which overwrites them, waits for ev_l1_copied, not for this call's decode)
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after)
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after, int set)
 {
     TsEnd *t = h->ts;
     if (fec_frames == 0 && t2_frames == 0) return 0;
@@ -651,9 +754,11 @@ int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s,
     bool ok = true;
     const bool l1_now = t2_frames > 0 && t->l1_check;
     if (l1_now && l1_after) {
-        ok = hipStreamWaitEvent(cs, l1_after, 0) == hipSuccess &&
-             hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess &&
-             hipEventRecord(h->ev_l1_copied, cs) == hipSuccess;
+        hipStream_t ls = t->l1_stream;
+        ok = hipStreamWaitEvent(ls, l1_after, 0) == hipSuccess &&
+             hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, ls) == hipSuccess &&
+             hipEventRecord(h->ev_l1_copied, ls) == hipSuccess && hipEventRecord(sl.l1_ready, ls) == hipSuccess &&
+             hipStreamWaitEvent(cs, sl.l1_ready, 0) == hipSuccess;          // the slot's `ready` (recorded on cs below) covers it
         h->l1_copied_set = ok;
     }
     ok = ok && hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
@@ -665,6 +770,7 @@ int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s,
         ok = hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
     ok = ok && hipEventRecord(sl.ready, cs) == hipSuccess;
     t->last_copy = ok ? sl.ready : nullptr;
+    if (set >= 0) t->last_copy_s[set] = t->last_copy;
     TsJob j;
     j.slot = k; j.fec_frames = ok ? fec_frames : 0; j.t2_frames = ok ? t2_frames : 0; j.fec_first = h->fec_seq; j.t2_first = h->t2_seq;
     {
@@ -696,9 +802,11 @@ extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&sl.pack), frames * (h->k_bch / 8), hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&sl.trials), (frames / h->group + 2) * 4, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&sl.l1), (size_t)h->cfg.max_frames * std::max(h->p2_skip, 1) * 8, hipHostMallocDefault) == hipSuccess &&
-             hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.l1_ready, hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&t->l1_stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming) == hipSuccess;
     h->ts = t;
     if (!ok) { ts_stop(h); set_error("t2gpu_rx_ts_enable: pinned host memory allocation failed"); return -1; }
