@@ -70,6 +70,7 @@ struct t2gpu_rx {
     hipEvent_t ev_dec_done[2] = {nullptr, nullptr};             // the last decode of set s is through
     bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false}, l1_copied_set = false;
     int in_flight_wg[2] = {0, 0};             // workgroups of the last decode of each set (what may still be resident)
+    bool pair_allowed = true;                 // T2GPU_RX_PAIR=0 (read by t2gpu_rx_set_overlap): every decode on set 0, one after the other
     int num_cu = 0;
     uint8_t *d_bits = nullptr, *d_out = nullptr;
     int32_t *d_trials = nullptr, *d_outer = nullptr;
@@ -426,7 +427,7 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
         // a decode that could not run beside another one like it (more than half the device) stays on set 0 and is launched
         // cooperatively, as the one-stream schedule of round 4's first form did; smaller ones alternate between the sets, plain launches
         const int wg_est = ready > 0 ? (h->outer_code ? h->num_cu : t2gpu_ldpc_launch_workgroups(h->ldpc_s[0], ready)) : 0;
-        const bool pair_ok = ready > 0 && 2 * wg_est <= h->num_cu;
+        const bool pair_ok = ready > 0 && h->pair_allowed && 2 * wg_est <= h->num_cu;
         const int set = pair_ok ? h->set : 0;
         int8_t *llr = h->d_llr_ab[b];
         // this buffer was last read by the decode of three calls ago; d_l1 is read by the host end's copy of the previous call
@@ -579,6 +580,7 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         for (t2gpu_ldpc *l : h->ldpc_s) if (l) t2gpu_ldpc_set_plain_launch(l, 0);    // (decided per decode in overlap mode)
     }
     h->overlap = enable != 0;
+    if (const char *e = std::getenv("T2GPU_RX_PAIR")) h->pair_allowed = std::atoi(e) != 0;
     return 0;
 }
 extern "C" int t2gpu_rx_wait(t2gpu_rx *h)

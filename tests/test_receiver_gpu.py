@@ -306,9 +306,10 @@ def test_stage_timers_config2_entry_point_and_sync_sums(torch_cuda):
     rx.close()
 
 
-def test_overlapped_decode_equals_plain_calls(torch_cuda):
-    """t2gpu_rx_set_overlap: the decode of a call on the handle's own stream beside the next call's front half (two LLR buffers, the
-    waiting frames carried from one to the other, the L1 cells copied ahead of the decode). Six one-frame calls of a 16K / 64-QAM /
+def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
+    """t2gpu_rx_set_overlap: the decode of a call on a stream of the handle's own beside the next call's front half, small decodes two at
+    a time (three LLR buffers rotate, the waiting frames carried from one to the next, two decode sets alternate, the L1 cells copied
+    ahead of the decode) -- and with T2GPU_RX_PAIR=0 the form every larger decode takes: one set, one after the other. Six one-frame calls of a 16K / 64-QAM /
     16200 r1/2 stream (41 FEC frames per T2 frame: SIMD batches form across calls, 9 .. 27 frames wait in between) with the library's
     host end on: the same packed rows per call, the same verdicts, the same TS bytes as the plain schedule, and the flush at the end."""
     torch = torch_cuda
@@ -335,10 +336,11 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda):
     probe.close()
     di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
 
-    def run(overlap):
+    def run(overlap, pair=True):
         rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
         rx.ts_enable(0, l1_check=True)
         if overlap:
+            monkeypatch.setenv("T2GPU_RX_PAIR", "1" if pair else "0")
             rx.set_overlap(True)
         rows, verdicts, counts = [], [], []
         for f in range(n_frames):
@@ -367,3 +369,6 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda):
     for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "l1_pre_crc_errors", "l1_post_crc_errors", "ts_bytes"):
         assert pcnt[k] == ocnt[k], k
     assert pcnt["fec_frames_dropped_l1"] == 0 and pcnt["fec_frames"] == n_frames * nb
+    sc, sr, sv, sts, scnt = run(True, pair=False)
+    assert sc == pc and all(np.array_equal(a, b) for a, b in zip(pr, sr)) and all(np.array_equal(a, b) for a, b in zip(pv, sv))
+    assert np.array_equal(pts, sts) and scnt["fec_frames"] == pcnt["fec_frames"]
