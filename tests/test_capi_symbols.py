@@ -132,3 +132,21 @@ def test_conflict_slot_bounds_of_the_normal_codes(built):
     want = {6: 2, 8: 4, 7: 4, 9: 4, 10: 7, 11: 6}
     for cid, bound in want.items():
         assert 0 <= e.emu_ldpc_max_conflict(cid) <= bound, cid
+
+
+def test_host_side_headers_compile_without_a_gpu(built):
+    """include/t2gpu_stages.hpp (the stage classes in the reference's own language) and the two programs written against it -- the
+    example source / sink and the mirror driver of the GPU tier -- are plain C++17 against include/t2gpu.h: they compile here, and
+    the example links against the library (no HIP header, no GPU needed)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    inc = os.path.join(ROOT, "include")
+    for src in (os.path.join(ROOT, "examples", "t2gpu_rx_file.cpp"), os.path.join(ROOT, "tests", "cpp", "stage_mirror_test.cpp")):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + inc, src])
+    pkg = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + inc, os.path.join(ROOT, "examples", "t2gpu_rx_file.cpp"), "-L" + pkg, "-lt2gpu",
+                               "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", os.path.join(d, "t2gpu_rx_file")])
