@@ -423,9 +423,10 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells), (size_t)32768 * 8, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 64, hipHostMallocDefault) == hipSuccess;
+    // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the device stores into these while its kernels run and the host reads them then
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells), (size_t)32768 * 8, hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 64, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) *h->h_flag = 0;
     if (const char *e = std::getenv("T2GPU_DEMOD_SPIN")) h->spin = std::atoi(e) != 0;

@@ -173,7 +173,7 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
     }
     if (const char *e = std::getenv("T2GPU_FRONT_CHAIN")) h->chain_on = std::atoi(e) != 0;
     h->chain_cap = front_chain_capacity();
-    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocDefault) == hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocCoherent) == hipSuccess) {
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
         *h->h_flag = 0;
     }
