@@ -291,18 +291,23 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, ui
 }
 
 // one layer for a compile-time link count: record in, update, record out. RW = record dwords per lane in memory (>= P2Regs::W).
+// The new record is handed back in registers (rec_new): the caller stores it one layer later, so that whatever the vector-memory
+// counter still holds at the head of a layer was issued a whole layer ago.
 // UNI (every layer of the code has CNT links): epf holds this layer's table entries on entry and the NEXT layer's on return -- their
 // LDS reads are issued right behind this layer's LLR reads (p2_load) and so cost no round trip of their own (with one workgroup per
 // CU there is no neighbour to fill a wavefront's waits).
-template <int CNT, int NCMAX, bool UNI>
+template <int CNT, int NCMAX, bool UNI, int RW>
 __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
-                                            const uint32_t *rec_in, uint32_t *__restrict__ rec_out, uint32_t *pair_rec,
+                                            const uint32_t *rec_in, uint32_t (&rec_new)[RW], uint32_t *pair_rec,
                                             uint2 (&epf)[(CNT + 3) / 2], int next_ent_lds)
 {
     P2Regs<CNT> r;
     constexpr int W = P2Regs<CNT>::W, H = P2Regs<CNT>::H;
+    static_assert(W <= RW, "record stride");
 #pragma unroll
     for (int w = 0; w < W; ++w) r.mo[w] = rec_in[w];
+#pragma unroll
+    for (int w = 0; w < W; ++w) r.mn[w] = 0u;
     if constexpr (UNI) {
         layer_update2<CNT, NCMAX>(L, d, epf, j, h, active, a0, a1, info, r, pair_rec, next_ent_lds);
     } else {
@@ -310,15 +315,29 @@ __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int 
         if (active) p2_entries<CNT>(L, d.ent_lds, h, e);
         layer_update2<CNT, NCMAX>(L, d, e, j, h, active, a0, a1, info, r, pair_rec, 0);
     }
-    if (active) {
-        if constexpr (W <= 4) {
-            uint4 o = make_uint4(r.mn[0], W > 1 ? r.mn[1] : 0u, W > 2 ? r.mn[2] : 0u, W > 3 ? r.mn[3] : 0u);
-            *reinterpret_cast<uint4 *>(rec_out) = o;
-        } else {
-            *reinterpret_cast<uint4 *>(rec_out) = make_uint4(r.mn[0], r.mn[1], r.mn[2], r.mn[3]);
-            *reinterpret_cast<uint2 *>(rec_out + 4) = make_uint2(r.mn[4], W > 5 ? r.mn[5] : 0u);
-        }
-    }
+#pragma unroll
+    for (int w = 0; w < RW; ++w) rec_new[w] = w < W ? r.mn[w] : 0u;
+}
+
+// The layer table in registers: lane l of every wavefront holds the four packed dwords of layer base + l (LdpcKernelParams::layer_words);
+// a layer's description is four v_readlane_b32 with the (uniform) layer number as the lane select.
+__device__ __forceinline__ uint4 layer_words_load(const uint4 *__restrict__ words, int q, int base)
+{
+    const int l = base + (int)(threadIdx.x & 63u);
+    return l < q ? words[l] : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void layer_words_get(const uint4 &dsc, int lane, uint32_t (&w)[4])
+{
+    w[0] = (uint32_t)__builtin_amdgcn_readlane((int)dsc.x, lane);
+    w[1] = (uint32_t)__builtin_amdgcn_readlane((int)dsc.y, lane);
+    w[2] = (uint32_t)__builtin_amdgcn_readlane((int)dsc.z, lane);
+    w[3] = (uint32_t)__builtin_amdgcn_readlane((int)dsc.w, lane);
+}
+template <int RW>
+__device__ __forceinline__ void store_record(uint32_t *rec_out, const uint32_t (&v)[RW])
+{
+    *reinterpret_cast<uint4 *>(rec_out) = make_uint4(v[0], v[1], v[2], v[3]);
+    if constexpr (RW > 4) *reinterpret_cast<uint4 *>(rec_out + 4) = make_uint4(v[4], v[5], v[6], v[7]);
 }
 
 #define T2_PROF2_T(var) long long var = p.prof ? (long long)__builtin_readcyclecounter() : 0
@@ -341,6 +360,8 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
     for (int x = threadIdx.x; x < 2 * p.n_entries; x += kThreads2) lds_ent[x] = entries2[x];      // made visible by the first barrier below
     LdsMem2 L{(uint32_t)(uintptr_t)(lds2_i8 *)Lm};
     const int probe_first = p.q > 1 ? layers[1].first_entry : 0, probe_cnt = p.q > 1 ? layers[1].cnt : 0;   // the parity probe's layer
+    uint4 dsc = layer_words_load(p.layer_words, p.q, 0);
+    const int ent_lds0 = L.off() + p.lds_ent_offset;
 
     const int tid = threadIdx.x;
     const int j = tid >> 1, h = tid & 1;
@@ -475,48 +496,70 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                 uint32_t nxt[RW];
 #pragma unroll
                 for (int w = 0; w < RW; ++w) nxt[w] = first_rec[w];
-                uint32_t info_nxt = (active && layers[0].kind == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
+                uint32_t lw[4];
+                layer_words_get(dsc, 0, lw);
+                uint32_t info_nxt = (active && (lw[0] & 3u) == T2_LAYER_GENERIC) ? cninfo[j] : 0u;
                 constexpr bool UNI = LO == HI;
                 uint2 epf[(HI + 3) / 2];
                 if constexpr (UNI) {
-                    if (active) p2_entries<HI>(L, L.off() + p.lds_ent_offset + 8 * layers[0].first_entry, h, epf);
+                    if (active) p2_entries<HI>(L, ent_lds0 + 8 * (int)(lw[1] >> 16), h, epf);
                 }
-                for (int i = 0; i < p.q; ++i) {
-                    const LdpcLayerDev ly = layers[i];
-                    LayerDesc d{entries + ly.first_entry, ly.cnt, ly.lmax, ly.nc, ly.kind, ly.step, L.off() + p.lds_ctl_offset + 32, entries[ly.first_entry],
-                                entries2 + 2 * ly.first_entry, L.off() + p.lds_ent_offset + 8 * ly.first_entry};
-                    d.band = (ly.nc <= NCMAX && ly.nc <= ly.cnt) ? ly.band : 0; d.band_prefetch = ly.band_prefetch & 1; d.no_close = ly.band_prefetch >> 1;
+                uint32_t held[RW];                                          // layer i - 1's new record, stored at the head of layer i
+#pragma unroll
+                for (int w = 0; w < RW; ++w) held[w] = 0u;
+                for (int i0 = 0; i0 < p.q; i0 += 64) {
+                if (i0) dsc = layer_words_load(p.layer_words, p.q, i0);       // codes of more than 64 layers: the table 64 layers at a time
+                const int i1 = i0 + 64 < p.q ? i0 + 64 : p.q;
+                for (int i = i0; i < i1; ++i) {
+                    // the layer's description: four dwords out of registers (v_readlane), nothing from memory (the scalar loads this
+                    // replaces -- layers[i], then entries[first_entry], then layers[i + 1] -- were three dependent round trips that all
+                    // twelve wavefronts sat out together right behind the barrier, every layer)
+                    layer_words_get(dsc, i - i0, lw);
+                    const int kind = (int)(lw[0] & 3u), cnt = (int)((lw[0] >> 2) & 31u), nc = (int)((lw[0] >> 7) & 31u), lmax = (int)((lw[0] >> 12) & 511u);
+                    const int first_entry = (int)(lw[1] >> 16);
+                    LayerDesc d{entries + first_entry, cnt, lmax, nc, kind, (int)(lw[1] & 0xffffu), L.off() + p.lds_ctl_offset + 32, lw[2],
+                                entries2 + 2 * first_entry, ent_lds0 + 8 * first_entry};
+                    d.band = (nc <= NCMAX && nc <= cnt) ? (int)((lw[0] >> 23) & 63u) : 0; d.band_prefetch = (int)((lw[0] >> 21) & 1u); d.no_close = (int)((lw[0] >> 22) & 1u);
                     d.band_rec_lds = L.off() + p.lds_sign_offset; d.band_in_lds = L.off() + p.lds_rec_offset;
                     d.pair_flag_lds = L.off() + p.lds_sign_offset;
-                    const uint32_t info = info_nxt;
-                    const int jn = (ly.kind == T2_LAYER_GENERIC && !d.band) ? (int)(info >> 20) : j;
-                    const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
-                    const int a1 = a1b >= 0 ? L.off() + 2 * a1b : -1;
+                    // this layer's record and node number were fetched a layer ago: consume them HERE, ahead of this head's own loads and
+                    // store -- a wait placed behind those would wait for them too
                     uint32_t cur[RW];
 #pragma unroll
                     for (int w = 0; w < RW; ++w) cur[w] = nxt[w];
-                    if (active && i + 1 < p.q) {                                     // prefetch the next layer's record (and node)
-                        if (t > 0) {
-                            const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
+                    uint32_t info = info_nxt;
+                    if constexpr (RW == 4) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(info) :: "memory");
+                    else asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]), "+v"(info) :: "memory");
+                    const int jn = (kind == T2_LAYER_GENERIC && !d.band) ? (int)(info >> 20) : j;
+                    const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
+                    const int a1 = a1b >= 0 ? L.off() + 2 * a1b : -1;
+                    if (active) {
+                        if (i + 1 < p.q) {                                           // prefetch the next layer's record (and node)
+                            if (t > 0) {
+                                const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
 #pragma unroll
-                            for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
-                        } else {
+                                for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
+                            } else {
 #pragma unroll
-                            for (int w = 0; w < RW; ++w) nxt[w] = 0u;                 // first sweep of a batch: every old message is 0
+                                for (int w = 0; w < RW; ++w) nxt[w] = 0u;                 // first sweep of a batch: every old message is 0
+                            }
+                            info_nxt = (lw[0] >> 29) & 1u ? cninfo[(i + 1) * 360 + j] : 0u;
                         }
-                        info_nxt = layers[i + 1].kind == T2_LAYER_GENERIC ? cninfo[(i + 1) * 360 + j] : 0u;
+                        if (i > 0) store_record<RW>(state + ((size_t)(i - 1) * 720 + tid) * RW, held);
                     }
-                    uint32_t *rec_out = state + ((size_t)i * 720 + tid) * RW;
                     T2_PROF2_T(tp2);
-                    const int next_ent = i + 1 < p.q ? L.off() + p.lds_ent_offset + 8 * layers[i + 1].first_entry : 0;
+                    const int next_ent = lw[3] != 0xffffffffu ? ent_lds0 + 8 * (int)lw[3] : 0;
                     if constexpr (UNI) {
-                        layer_step2<HI, NCMAX, true>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec, epf, next_ent);
+                        layer_step2<HI, NCMAX, true, RW>(L, d, jn, h, active, a0, a1, info, cur, held, pair_rec, epf, next_ent);
                     } else {
-                        T2_LDPC_DISPATCH_RANGE(ly.cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false>(L, d, jn, h, active, a0, a1, info, cur, rec_out, pair_rec, none, 0); }));
+                        T2_LDPC_DISPATCH_RANGE(cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false, RW>(L, d, jn, h, active, a0, a1, info, cur, held, pair_rec, none, 0); }));
                     }
-                    T2_PROF2_ADD(2 + ly.kind, tp2);
+                    T2_PROF2_ADD(2 + kind, tp2);
                     if (p.prof && blockIdx.x == 0 && tid == 0 && i < 64) p.prof[(size_t)p.prof_blocks * 8 + i] += (long long)__builtin_readcyclecounter() - tp2;
                 }
+                }
+                if (active) store_record<RW>(state + ((size_t)(p.q - 1) * 720 + tid) * RW, held);
+                if (p.q > 64) dsc = layer_words_load(p.layer_words, p.q, 0);
             }
             __syncthreads();   // once per sweep: the records written above are re-read by the same thread next sweep
         }

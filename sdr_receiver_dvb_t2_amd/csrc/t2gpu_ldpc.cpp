@@ -16,6 +16,7 @@ struct t2gpu_ldpc {
     int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
     int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0, lds_ent_offset = 0;
     LdpcLayerDev *d_layers = nullptr;
+    uint32_t *d_layer_words = nullptr;   // the same, four packed dwords per layer (ldpc_kernel.h: LdpcKernelParams::layer_words)
     uint32_t *d_entries = nullptr, *d_entries2 = nullptr;
     int lds_base = 0;
     uint32_t *d_cninfo = nullptr;
@@ -126,6 +127,26 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
                              h->g.layers[i].kind, h->g.layers[i].step, band_on ? h->g.layers[i].band : 0,
                              h->g.layers[i].band_prefetch | (open_on ? h->g.layers[i].no_close << 1 : 0)};
     if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
+    {   // the two-frame kernel's form of the same table: four dwords per layer, held in registers (one layer per lane) and read with
+        // v_readlane -- no memory access and no wait at the head of a layer (ldpc_kernel2.hip)
+        std::vector<uint32_t> lw(4 * (size_t)h->g.q);
+        for (int i = 0; i < h->g.q; ++i) {
+            const LdpcLayerDev &l = ld[i];
+            if (l.cnt > 31 || l.nc > 31 || l.lmax > 511 || l.band > 63 || l.step > 0xffff || l.first_entry > 0xffff || l.kind > 3) {
+                set_error("LDPC layer table does not fit its packed form");
+                t2gpu_ldpc_destroy(h);
+                return nullptr;
+            }
+            const bool next_generic = i + 1 < h->g.q && ld[i + 1].kind == 2;     // T2_LAYER_GENERIC
+            lw[4 * i] = (uint32_t)l.kind | (uint32_t)l.cnt << 2 | (uint32_t)l.nc << 7 | (uint32_t)l.lmax << 12 | (uint32_t)(l.band_prefetch & 1) << 21 |
+                        (uint32_t)(l.band_prefetch >> 1) << 22 | (uint32_t)l.band << 23 | (next_generic ? 1u << 29 : 0u);
+            lw[4 * i + 1] = (uint32_t)l.step | (uint32_t)l.first_entry << 16;
+            lw[4 * i + 2] = h->g.entries[l.first_entry];
+            lw[4 * i + 3] = i + 1 < h->g.q ? (uint32_t)ld[i + 1].first_entry : 0xffffffffu;
+        }
+        if ((e = hipMalloc(&h->d_layer_words, lw.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
+        if ((e = hipMemcpy(h->d_layer_words, lw.data(), lw.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+    }
     if ((e = hipMalloc(&h->d_entries, h->g.entries.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemcpy(h->d_layers, ld.data(), ld.size() * sizeof(LdpcLayerDev), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
@@ -187,7 +208,7 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
-    hipFree(h->d_layers); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
+    hipFree(h->d_layers); hipFree(h->d_layer_words); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
@@ -280,7 +301,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
-    p.layers = h->d_layers; p.entries = h->d_entries; p.entries2 = packed ? h->d_entries2p : h->d_entries2;
+    p.layers = h->d_layers; p.layer_words = reinterpret_cast<const uint4 *>(h->d_layer_words); p.entries = h->d_entries; p.entries2 = packed ? h->d_entries2p : h->d_entries2;
     p.lds_base = packed ? h->p_lds_base : h->lds_base; p.cninfo = h->d_cninfo;
     p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
