@@ -86,10 +86,11 @@ struct P2Regs {
     p16 m0, m1f, dm;            // node-wide over all slots: raw minimum, f(min1), f(min0) - f(min1)
     uint32_t sx;
     int h;
+    bool last_present;          // the lane's last slot (the parity slot beyond the information links) holds a bit
 };
 
 template <int CNT>
-__device__ __forceinline__ bool p2_present(const P2Regs<CNT> &r, int v) { return (2 * v + 1 <= CNT) || r.addr[v] >= 0; }
+__device__ __forceinline__ bool p2_present(const P2Regs<CNT> &r, int v) { return (2 * v + 1 <= CNT) || r.last_present; }
 
 // pl_read_slot
 template <int CNT, class LMEM>
@@ -117,14 +118,22 @@ __device__ __forceinline__ void p2_entries(const LMEM &L, int ent_lds, int h, ui
 }
 
 // pl_load. e: the lane's entries as (base + 2 * (bit base - shift), shift) pairs (p2_entries); j2 = 2 j.
-// next_ent_lds != 0: e is overwritten with the NEXT layer's entries once this layer's addresses are formed -- the reads are issued
+// a_par: the ONE parity-bit address this lane needs -- with an even link count the even lane holds the node's own parity bit and the
+// odd lane the previous one in their last slot; with an odd count the odd lane holds the own bit (beside its last information link)
+// and the even lane the previous one -- always a valid address: par_absent marks the one lane whose previous parity bit does not
+// exist (node (0, 0)), it reads the scratch pair at `dummy` and discards it. (Rounds 2-4 passed both addresses with -1 for "absent" and
+// paid a compare, two selects and a max per layer to find out again what the caller knew.)
+// PF: e is overwritten with the NEXT layer's entries (at next_ent_lds) once this layer's addresses are formed -- the reads are issued
 // behind this layer's LLR reads (LDS returns in order: nothing waits for them before the next layer) and land in the registers the
-// next layer reads them from, so the layer loop carries one set of entry registers and no copies
-template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_load(const LMEM &L, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1, P2Regs<CNT> &r, int next_ent_lds = 0)
+// next layer reads them from, so the layer loop carries one set of entry registers and no copies. Compile-time, so that the loads and
+// their consumers stay in one basic block (the zero-extension of a 16-bit load is folded into it only there).
+template <int CNT, bool PF, class LMEM>
+__device__ __forceinline__ void p2_load(const LMEM &L, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_par, bool par_absent, int dummy, P2Regs<CNT> &r,
+                                        int next_ent_lds)
 {
     constexpr int H = P2Regs<CNT>::H, W = P2Regs<CNT>::W;
     r.h = h;
+    r.last_present = (CNT % 2 == 0) ? !par_absent : (h ? false : !par_absent);
 #pragma unroll
     for (int w = 0; w < W; ++w) r.mn[w] = 0u;
     const int j2 = 2 * j, jw2 = j2 + 720;
@@ -134,14 +143,12 @@ __device__ __forceinline__ void p2_load(const LMEM &L, uint2 (&e)[(CNT + 3) / 2]
         const int c0 = 2 * v, c1 = 2 * v + 1;
         const int link = (int)e[v].x + (j >= (int)e[v].y ? j2 : jw2);
         if (c1 < CNT) r.addr[v] = link;                             // information slots on both lanes
-        else if (c0 < CNT) r.addr[v] = h ? a_p0 : link;             // c1 == CNT: own parity bit on the odd lane
-        else if (c0 == CNT) r.addr[v] = h ? a_p1 : a_p0;            // own parity / previous parity
-        else r.addr[v] = h ? -1 : a_p1;                             // c0 == CNT + 1: previous parity, nothing on the odd lane
-        // an absent slot reads address 0 and is discarded below: no branch around the read (which would also cut the block the
-        // scheduler works on in two, and part the other reads from their zero-extension)
-        raw[v] = (uint32_t)L.ld16((2 * v + 1 <= CNT) ? r.addr[v] : max(r.addr[v], 0));
+        else if (c0 < CNT) r.addr[v] = h ? a_par : link;            // c1 == CNT: own parity bit on the odd lane
+        else if (c0 == CNT) r.addr[v] = a_par;                      // own parity (even lane) / previous parity (odd lane)
+        else r.addr[v] = h ? dummy : a_par;                         // c0 == CNT + 1: previous parity, nothing on the odd lane
+        raw[v] = (uint32_t)L.ld16(r.addr[v]);
     }
-    if (next_ent_lds) p2_entries<CNT>(L, next_ent_lds, h, e);
+    if constexpr (PF) p2_entries<CNT>(L, next_ent_lds, h, e);
     // the old messages' bytes into the halves (nothing here depends on the reads: the compiler fills the address arithmetic's hazard
     // slots with these; explicit scheduling groups -- read after every three instructions -- measured 2 % slower)
     p16 m[H];
@@ -230,12 +237,12 @@ __device__ __forceinline__ void p2_write_slot(LMEM &L, P2Regs<CNT> &r, int v, bo
 }
 
 // pl_phase_a. pair_rec: [2][360] chain-walk records, one array per frame
-template <int CNT, class LMEM>
-__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_p0, int a_p1,
-                                           P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds = 0)
+template <int CNT, bool PF, class LMEM>
+__device__ __forceinline__ void p2_phase_a(LMEM &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, int a_par, bool par_absent,
+                                           P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds)
 {
     constexpr int H = P2Regs<CNT>::H;
-    p2_load<CNT>(L, e, j, h, a_p0, a_p1, r, next_ent_lds);
+    p2_load<CNT, PF>(L, e, j, h, a_par, par_absent, d.dummy, r, next_ent_lds);
     if (d.kind == T2_LAYER_PLAIN) {
         p2_partial<CNT>(r, 0);
         p2_set_minima(r.p0, r.p1, r.m0, r.m1f, r.dm);

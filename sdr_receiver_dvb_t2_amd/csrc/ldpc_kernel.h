@@ -19,7 +19,7 @@ struct LdpcKernelParams {
     int n, k, q;
     const LdpcLayerDev *layers;   // [q]
     const uint4 *layer_words;     // [q] the two-frame kernel's packed form: x = kind | cnt << 2 | nc << 7 | lmax << 12 | band_prefetch << 21 | no_close << 22 |
-                                  // band << 23 | (layer i + 1 is GENERIC) << 29, y = step | first_entry << 16, z = entries[first_entry], w = layer i + 1's first_entry
+                                  // band << 23 | (layer i + 1 is GENERIC) << 29, y = step | first_entry << 16, z = entries[first_entry], w = the first_entry of layer (i + 1) mod q
     const uint32_t *entries;      // packed base | shift<<16
     const uint32_t *entries2;     // the same as pairs (base + lds_base, shift): what the check-node load reads
     int lds_base;                 // LDS address of the LLR array the pairs were made for (= the kernel's static LDS size)

@@ -50,12 +50,6 @@ constexpr int kThreads2 = 768;
 
 __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ int parity_prev_bit(int k, int q, int i, int j)
-{
-    if (i > 0) return k + 360 * (i - 1) + j;
-    return j > 0 ? k + 360 * (q - 1) + j - 1 : -1;
-}
-
 // ---- bit-parallel parity check of both frames (LDPCDecoder::bad, layered_decoder.hh:65-82; see ldpc_kernel.hip) -----------------
 // Sign words as there: 13 dwords per 360-bit group (bits 0..359 + a copy of bits 0..55), one array per frame. A dword of the
 // interleaved LLR bytes holds (A_k, B_k, A_k+1, B_k+1).
@@ -234,11 +228,14 @@ __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA,
 #ifndef T2_PAIR_SEG_MIN
 #define T2_PAIR_SEG_MIN 12                 // chains at least this long are walked in segments (cut where a node's output ignores its input)
 #endif
-template <int CNT, int NCMAX>
-__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a0, int a1,
-                                              uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds)
+template <int CNT, int NCMAX, bool PF>
+__device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, uint2 (&e)[(CNT + 3) / 2], int j, int h, bool active, int a_own, int a_prev,
+                                              bool prev_absent, uint32_t info, P2Regs<CNT> &r, uint32_t *pair_rec, int next_ent_lds)
 {
-    if (active) p2_phase_a<CNT>(L, d, e, j, h, a0, a1, r, pair_rec, next_ent_lds);
+    // the one parity bit this lane reads (ldpc_cn3.h, p2_load): the previous layer's on the odd lane of an even link count / the even
+    // lane of an odd one, the node's own on the other
+    const bool prev_lane = (CNT % 2 == 0) == (h == 1);
+    if (active) p2_phase_a<CNT, PF>(L, d, e, j, h, prev_lane ? a_prev : a_own, prev_lane && prev_absent, r, pair_rec, next_ent_lds);
     if (d.kind == T2_LAYER_PAIR) {
         lds_barrier2();
         __builtin_amdgcn_s_setprio(3);
@@ -297,7 +294,7 @@ __device__ __forceinline__ void layer_update2(LdsMem2 &L, const LayerDesc &d, ui
 // LDS reads are issued right behind this layer's LLR reads (p2_load) and so cost no round trip of their own (with one workgroup per
 // CU there is no neighbour to fill a wavefront's waits).
 template <int CNT, int NCMAX, bool UNI, int RW>
-__device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a0, int a1, uint32_t info,
+__device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int j, int h, bool active, int a_own, int a_prev, bool prev_absent, uint32_t info,
                                             const uint32_t *rec_in, uint32_t (&rec_new)[RW], uint32_t *pair_rec,
                                             uint2 (&epf)[(CNT + 3) / 2], int next_ent_lds)
 {
@@ -309,11 +306,11 @@ __device__ __forceinline__ void layer_step2(LdsMem2 &L, const LayerDesc &d, int 
 #pragma unroll
     for (int w = 0; w < W; ++w) r.mn[w] = 0u;
     if constexpr (UNI) {
-        layer_update2<CNT, NCMAX>(L, d, epf, j, h, active, a0, a1, info, r, pair_rec, next_ent_lds);
+        layer_update2<CNT, NCMAX, true>(L, d, epf, j, h, active, a_own, a_prev, prev_absent, info, r, pair_rec, next_ent_lds);
     } else {
         uint2 e[H];
         if (active) p2_entries<CNT>(L, d.ent_lds, h, e);
-        layer_update2<CNT, NCMAX>(L, d, e, j, h, active, a0, a1, info, r, pair_rec, 0);
+        layer_update2<CNT, NCMAX, false>(L, d, e, j, h, active, a_own, a_prev, prev_absent, info, r, pair_rec, 0);
     }
 #pragma unroll
     for (int w = 0; w < RW; ++w) rec_new[w] = w < W ? r.mn[w] : 0u;
@@ -366,6 +363,8 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
     const int tid = threadIdx.x;
     const int j = tid >> 1, h = tid & 1;
     const bool active = j < 360;
+    const uint32_t rec_lane_off = (uint32_t)threadIdx.x * (uint32_t)(((HI + 2 + 1) / 2 > 8 ? 8 : 4) * 4);   // byte offset of the lane's record inside a layer's block
+    const int par0 = L.off() + 2 * (p.k + j);                        // LDS address of the parity bit pair of node j in layer 0
     if (L.off() != p.lds_base) {                     // the split table was built for another LDS layout: refuse, loudly
         if (tid == 0) *p.error = 2;
         return;
@@ -528,15 +527,26 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
 #pragma unroll
                     for (int w = 0; w < RW; ++w) cur[w] = nxt[w];
                     uint32_t info = info_nxt;
-                    if constexpr (RW == 4) asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(info) :: "memory");
-                    else asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]), "+v"(info) :: "memory");
-                    const int jn = (kind == T2_LAYER_GENERIC && !d.band) ? (int)(info >> 20) : j;
-                    const int a0 = L.off() + 2 * (p.k + 360 * i + jn), a1b = parity_prev_bit(p.k, p.q, i, jn);
-                    const int a1 = a1b >= 0 ? L.off() + 2 * a1b : -1;
+                    if constexpr (RW == 4) asm volatile("" :: "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(info) : "memory");
+                    else asm volatile("" :: "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(cur[4]), "v"(cur[5]), "v"(cur[6]), "v"(cur[7]), "v"(info) : "memory");
+                    // the node this lane pair takes and its two parity bits: lane constants plus 720 i, except in the layers that deal
+                    // their nodes by dependency level (GENERIC without a band walk)
+                    // (the two rare cases are real branches -- both conditions are uniform -- with an empty asm inside so that they are not
+                    // turned into selects every layer pays for)
+                    int jn = j, a_own = par0 + 720 * i;
+                    if (kind == T2_LAYER_GENERIC && !d.band) { asm volatile(""); jn = (int)(info >> 20); a_own += 2 * (jn - j); }
+                    int a_prev = a_own - 720;
+                    bool prev_absent = false;
+                    if (i == 0) {                                                    // the wrap: the last layer's bit of node j - 1; none for node 0
+                        asm volatile("");
+                        prev_absent = jn == 0;
+                        a_prev = prev_absent ? d.dummy : a_own + 720 * (p.q - 1) - 2;
+                    }
                     if (active) {
                         if (i + 1 < p.q) {                                           // prefetch the next layer's record (and node)
                             if (t > 0) {
-                                const uint4 *q4 = reinterpret_cast<const uint4 *>(state + ((size_t)(i + 1) * 720 + tid) * RW);
+                                // (a uniform base + the lane's 32-bit offset: the scalar-base addressing form, no 64-bit vector arithmetic per layer)
+                                const uint4 *q4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(state) + (size_t)(i + 1) * (720 * RW * 4) + rec_lane_off);
 #pragma unroll
                                 for (int w = 0; w < RW / 4; ++w) { const uint4 v = q4[w]; nxt[4 * w] = v.x; nxt[4 * w + 1] = v.y; nxt[4 * w + 2] = v.z; nxt[4 * w + 3] = v.w; }
                             } else {
@@ -545,14 +555,14 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
                             }
                             info_nxt = (lw[0] >> 29) & 1u ? cninfo[(i + 1) * 360 + j] : 0u;
                         }
-                        if (i > 0) store_record<RW>(state + ((size_t)(i - 1) * 720 + tid) * RW, held);
+                        if (i > 0) store_record<RW>(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(state) + (size_t)(i - 1) * (720 * RW * 4) + rec_lane_off), held);
                     }
                     T2_PROF2_T(tp2);
-                    const int next_ent = lw[3] != 0xffffffffu ? ent_lds0 + 8 * (int)lw[3] : 0;
+                    const int next_ent = ent_lds0 + 8 * (int)lw[3];                  // (the last layer names layer 0: the next sweep starts there)
                     if constexpr (UNI) {
-                        layer_step2<HI, NCMAX, true, RW>(L, d, jn, h, active, a0, a1, info, cur, held, pair_rec, epf, next_ent);
+                        layer_step2<HI, NCMAX, true, RW>(L, d, jn, h, active, a_own, a_prev, prev_absent, info, cur, held, pair_rec, epf, next_ent);
                     } else {
-                        T2_LDPC_DISPATCH_RANGE(cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false, RW>(L, d, jn, h, active, a0, a1, info, cur, held, pair_rec, none, 0); }));
+                        T2_LDPC_DISPATCH_RANGE(cnt, LO, HI, ({ uint2 none[(CNT + 3) / 2]; layer_step2<CNT, NCMAX, false, RW>(L, d, jn, h, active, a_own, a_prev, prev_absent, info, cur, held, pair_rec, none, 0); }));
                     }
                     T2_PROF2_ADD(2 + kind, tp2);
                     if (p.prof && blockIdx.x == 0 && tid == 0 && i < 64) p.prof[(size_t)p.prof_blocks * 8 + i] += (long long)__builtin_readcyclecounter() - tp2;

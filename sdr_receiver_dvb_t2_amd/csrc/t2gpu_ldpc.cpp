@@ -142,7 +142,7 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
                         (uint32_t)(l.band_prefetch >> 1) << 22 | (uint32_t)l.band << 23 | (next_generic ? 1u << 29 : 0u);
             lw[4 * i + 1] = (uint32_t)l.step | (uint32_t)l.first_entry << 16;
             lw[4 * i + 2] = h->g.entries[l.first_entry];
-            lw[4 * i + 3] = i + 1 < h->g.q ? (uint32_t)ld[i + 1].first_entry : 0xffffffffu;
+            lw[4 * i + 3] = (uint32_t)ld[(i + 1) % h->g.q].first_entry;      // (the last layer names layer 0)
         }
         if ((e = hipMalloc(&h->d_layer_words, lw.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
         if ((e = hipMemcpy(h->d_layer_words, lw.data(), lw.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
