@@ -37,11 +37,18 @@ int t2gpu_device_count(void);
  * ldpc_decoder::execute -> bit_bch -> ...: dvbt2_demodulator.cpp:84-95 and the main window's connect() chain). The host-buffer entry
  * points below keep that contract -- results are in the caller's buffer when a call returns -- and in addition remember where the
  * same bytes still are on the device (a "twin", found again by the buffer's address). A stage handed the previous stage's buffer
- * unmodified, which is what the signal / slot chain does, skips its copy-in. A caller that edits such a buffer between two stages
- * must say so: T2GPU_HANDOFF=0 in the environment turns every look-up off (rounds 1-3 behaviour: every stage copies in).
+ * unmodified, which is what the signal / slot chain does, skips its copy-in -- ONCE THE CALLER HAS SAID that its buffers travel
+ * unmodified: t2gpu_handoff_enable(1), process-wide, returns the previous setting. Off by default: every host-buffer entry point is then
+ * a function of the bytes it is handed (each stage copies its input in), whatever was done to a buffer between two stages. The stage
+ * classes of t2gpu_stages.hpp switch it on (they hand each other's buffers on untouched, as the reference's objects do). With the switch
+ * on, an entry made on the way is still checked against the buffer it was made for -- its first and last 64 bytes and its length are
+ * hashed when the entry is made and compared at the look-up, so a buffer that was released and whose address now holds other data
+ * falls back to the copy-in -- but an edit in the middle of a handed-on buffer is the caller's to announce (switch off, or do not
+ * reuse the buffer). Entries go when the handle that made them overwrites the device side or is destroyed.
  * For buffers the CALLER owns and fills from other stage outputs (llr_demapper's SIMD batch buffers, llr_demapper.cpp:742-764):
  * t2gpu_twin_attach gives the buffer a twin kept by the library (and page-locks the buffer), t2gpu_twin_copy is memcpy(dst, src, n)
  * plus the same copy between the twins, t2gpu_twin_detach releases. All return 0 or -1. */
+int t2gpu_handoff_enable(int on);                 /* 0 / 1; returns the previous setting */
 int t2gpu_host_pin(void *host, size_t bytes);      /* page-lock a caller's buffer: 0 done, 1 not possible (harmless), -1 bad arguments */
 int t2gpu_host_unpin(void *host);
 int t2gpu_twin_attach(void *host, size_t bytes, int device);

@@ -49,6 +49,12 @@ struct l1_postsignalling {
 
 inline void fail(const char *what) { throw std::runtime_error(std::string(what) + ": " + t2gpu_last_error()); }
 
+// The stage classes hand each other's output buffers on untouched, as the reference's objects do through its signal / slot chain, and
+// say so to the library once (t2gpu.h, host-buffer hand-over: off at the plain C ABI). A program that edits a stage's buffer between two
+// stages calls t2::handoff(false) after constructing its stages.
+inline void handoff(bool on) { t2gpu_handoff_enable(on ? 1 : 0); }
+inline void handoff_default() { static const int once = (t2gpu_handoff_enable(1), 0); (void)once; }
+
 // T2GPU_RX_PROF=1: host wall time inside the library calls of the stage classes, by call site (exclusive of the signals a slot emits while
 // it runs: a nested scope's time is taken off its parent's). prof_report() prints the table; nothing is measured without the variable.
 struct prof_table {
@@ -108,6 +114,7 @@ public:
     explicit ldpc_decoder(int device = 0, int in_flight = 8, bool own_thread = false)
         : device_(device), depth_(in_flight < 1 ? 1 : in_flight), threaded_(own_thread && in_flight > 1)
     {
+        handoff_default();
         if (threaded_) worker_ = std::thread([this] { run(); });
     }
     ~ldpc_decoder()
@@ -253,6 +260,7 @@ public:
     // outer_code_status holds, per FEC frame of the last call, the bits corrected or -1 (more than t errors, frame untouched)
     bool outer_code = false;
     std::vector<int32_t> outer_code_status;
+    bch_decoder() { handoff_default(); }
     void execute(int *idx_plp_simd, const l1_postsignalling &l1_post, int len_in, uint8_t *in)
     {
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
@@ -311,7 +319,7 @@ private:
 // ---------------------------------------------------------------------------------------------------------------- LLR demapper
 class llr_demapper {
 public:
-    explicit llr_demapper(int device = 0) : device_(device) {}
+    explicit llr_demapper(int device = 0) : device_(device) { handoff_default(); }
     ~llr_demapper() { release(); }
     std::function<void(float snr)> signal_noise_ratio;                                                             // llr_demapper.h:38
     std::function<void(int *idx_plp_simd, const l1_postsignalling &, int len_out, int8_t *out)> soft_multiplexer_de_twist;   // :39
@@ -404,6 +412,7 @@ public:
     // thread is through with the one before, so the buffer being filled is never the one being read. flush() waits for that thread.
     explicit time_deinterleaver(int device = 0, bool own_thread = false) : device_(device), threaded_(own_thread)
     {
+        handoff_default();
         if (threaded_) worker_ = std::thread([this] { run(); });
     }
     ~time_deinterleaver()

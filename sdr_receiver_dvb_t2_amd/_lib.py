@@ -24,6 +24,7 @@ PROTOTYPES = {
     "t2gpu_last_error": (ctypes.c_char_p, []),
     "t2gpu_host_pin": (ctypes.c_int, [_vp, ctypes.c_size_t]),
     "t2gpu_host_unpin": (ctypes.c_int, [_vp]),
+    "t2gpu_handoff_enable": (ctypes.c_int, [ctypes.c_int]),
     "t2gpu_twin_attach": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_int]),
     "t2gpu_twin_detach": (ctypes.c_int, [_vp]),
     "t2gpu_twin_copy": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_int]),

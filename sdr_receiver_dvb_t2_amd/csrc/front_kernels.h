@@ -56,6 +56,7 @@ constexpr int FRONT_CHAIN_MAX_GRID = 96, FRONT_CHAIN_RUNS = 24;
 struct FrontChainArgs {
     FrontParams p;
     unsigned long long *bar, target;
+    int *error;                                // set when a grid barrier of the chain gave up (t2gpu_front_state reports it)
     int fd_blocks;
     FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs, then Farrow runs
 };

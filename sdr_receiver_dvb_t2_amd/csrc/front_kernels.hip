@@ -540,14 +540,28 @@ __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p) { fron
 // grid in between; the grid is small (<= FRONT_CHAIN_MAX_GRID workgroups, all resident at once). Same values as the five launches:
 // the level-2 scan is evaluated by every workgroup for itself in front_dc_scan_kernel's order (one block per lane, the same shuffles).
 // The run tables travel in the kernel arguments.
-__device__ __forceinline__ void chain_barrier(unsigned long long *bar, unsigned long long target)
+// Grid barrier of the chain: every workgroup's stores of the phase before it are written back (agent-scope RELEASE ahead of its arrival),
+// every workgroup reads the next phase's inputs behind an agent-scope ACQUIRE (rounds 4: a full __threadfence() on either side, i.e.
+// a second L2 write-back and a second L1 invalidate per barrier, ~3.5 us each on gfx950). The wait is bounded: a counter that never
+// reaches its target (a launch that was refused after the host had advanced its count, workgroups that are not co-resident) ends in
+// the error word instead of a hung device.
+__device__ __forceinline__ void chain_barrier(unsigned long long *bar, unsigned long long target, int *error)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long t0 = 0;
+        for (unsigned spins = 1; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+            if ((spins & 0xfffu) == 0) {                       // the clock only now and then: reading it costs more than a poll
+                const long long now = wall_clock64();
+                if (!t0) t0 = now;
+                else if (now - t0 > 200000000LL) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(256) void front_chain_kernel(FrontChainArgs a)
     p.nco_runs = sh_runs; p.far_runs = sh_runs + p.n_nco_runs;
     __syncthreads();
     if (bid < p.n_blocks) front_dc_block_body(p, bid);
-    chain_barrier(a.bar, a.target + G);
+    chain_barrier(a.bar, a.target + G, a.error);
     {   // front_dc_scan_kernel with one block per lane (n_blocks <= 256): lane t composes the identity with block t's aggregate
         Lin l{1.0, 0.0, 0.0};
         if (tid < p.n_blocks) { const double4 v = *reinterpret_cast<const double4 *>(p.blk + 4 * dc_slot(tid, 1)); l = compose(l, Lin{v.x, v.y, v.z}); }
@@ -576,9 +590,9 @@ __global__ __launch_bounds__(256) void front_chain_kernel(FrontChainArgs a)
         __syncthreads();
     }
     if (bid < p.n_blocks) front_derotate_body(p, bid, sh_start);
-    chain_barrier(a.bar, a.target + 2 * G);
+    chain_barrier(a.bar, a.target + 2 * G, a.error);
     if (bid < a.fd_blocks) front_farrow_decimate_body(p, bid);
-    chain_barrier(a.bar, a.target + 3 * G);
+    chain_barrier(a.bar, a.target + 3 * G, a.error);
     if (bid == 0) {
         front_finish_body(p);
         if (tid == 0) { p.state->dc_re = sh_new_dc[0]; p.state->dc_im = sh_new_dc[1]; }

@@ -1,4 +1,5 @@
 #include "t2gpu_common.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -34,23 +35,32 @@ hipError_t ensure_dynamic_lds(const void *fn, int bytes)
 }
 
 namespace {
-struct Twin { const char *host; const char *dev; size_t bytes; int device; bool owned; bool pinned; };
+// guard: what the first and the last 64 bytes of the host range and its length hashed to when the entry was made (0 = not guarded:
+// page-locked buffers of the library's own that the DEVICE fills behind a sequence word)
+struct Twin { const char *host; const char *dev; size_t bytes; int device; bool owned; bool pinned; uint64_t guard; };
 std::mutex g_twin_m;
 std::vector<Twin> g_twins;
-bool twins_on()
+std::atomic<int> g_handoff{0};           // t2gpu_handoff_enable: implicit entries are consulted only when the caller has said its buffers travel unmodified
+
+uint64_t guard_of(const char *host, size_t bytes)
 {
-    static const bool on = [] { const char *e = std::getenv("T2GPU_HANDOFF"); return !(e && std::atoi(e) == 0); }();
-    return on;
+    uint64_t hsh = 1469598103934665603ull ^ (uint64_t)bytes;
+    auto mix = [&](const char *q, size_t n) { for (size_t i = 0; i < n; ++i) { hsh ^= (unsigned char)q[i]; hsh *= 1099511628211ull; } };
+    const size_t head = bytes < 64 ? bytes : 64;
+    mix(host, head);
+    if (bytes > 64) { const size_t tail = bytes - 64 < 64 ? bytes - 64 : 64; mix(host + bytes - tail, tail); }
+    return hsh | 1ull;                   // never 0
 }
 }  // namespace
 
-void twin_publish(const void *host, const void *dev, size_t bytes, int device)
+void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded)
 {
     if (!host || !dev || !bytes) return;
+    const uint64_t g = guarded ? guard_of(static_cast<const char *>(host), bytes) : 0;
     std::lock_guard<std::mutex> lk(g_twin_m);
     for (Twin &t : g_twins)
-        if (t.host == host && !t.owned) { t.dev = static_cast<const char *>(dev); t.bytes = bytes; t.device = device; return; }
-    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, false, false});
+        if (t.host == host && !t.owned) { t.dev = static_cast<const char *>(dev); t.bytes = bytes; t.device = device; t.guard = g; return; }
+    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, false, false, g});
 }
 void twin_retire(const void *host)
 {
@@ -69,14 +79,30 @@ void twin_retire_dev(const void *dev_lo, size_t bytes)
 }
 const void *twin_lookup(const void *host, size_t bytes, int device)
 {
-    if (!host || !twins_on()) return nullptr;
+    if (!host) return nullptr;
+    const bool implicit_ok = g_handoff.load(std::memory_order_relaxed) != 0;
     const char *h = static_cast<const char *>(host);
     std::lock_guard<std::mutex> lk(g_twin_m);
-    for (const Twin &t : g_twins)
-        if (t.device == device && h >= t.host && h + bytes <= t.host + t.bytes) return t.dev + (h - t.host);
+    for (size_t i = 0; i < g_twins.size(); ++i) {
+        const Twin &t = g_twins[i];
+        if (t.device != device || h < t.host || h + bytes > t.host + t.bytes) continue;
+        if (t.owned) return t.dev + (h - t.host);                 // attached by the caller, buffer by buffer: always honoured
+        if (!implicit_ok) return nullptr;
+        // an entry made on the way (a stage's output buffer): the address alone proves nothing -- the caller may have released the
+        // buffer and a new one may sit there. What was hashed when the entry was made must still be there, else the host bytes win
+        // and the entry is dropped.
+        if (t.guard && guard_of(t.host, t.bytes) != t.guard) { g_twins.erase(g_twins.begin() + (long)i); return nullptr; }
+        return t.dev + (h - t.host);
+    }
     return nullptr;
 }
 }  // namespace t2gpu
+
+// ---- the switch of the implicit hand-over (include/t2gpu.h): off unless the caller says its buffers travel unmodified
+extern "C" int t2gpu_handoff_enable(int on)
+{
+    return t2gpu::g_handoff.exchange(on ? 1 : 0);
+}
 
 // ---- caller-owned host buffers with a twin the library keeps for them (include/t2gpu.h)
 extern "C" int t2gpu_twin_attach(void *host, size_t bytes, int device)
@@ -89,7 +115,7 @@ extern "C" int t2gpu_twin_attach(void *host, size_t bytes, int device)
     const bool pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;   // faster copies; not essential
     if (!pinned) (void)hipGetLastError();
     std::lock_guard<std::mutex> lk(g_twin_m);
-    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, true, pinned});
+    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, true, pinned, 0});
     return 0;
 }
 extern "C" int t2gpu_twin_detach(void *host)

@@ -15,13 +15,28 @@ hipError_t ensure_dynamic_lds(const void *fn, int bytes);
 // ---- device twins of host buffers (include/t2gpu.h, "host-buffer hand-over"). The reference's slots carry host pointers from stage to
 // stage; every host-buffer entry point of this library leaves its result in the caller's buffer AND remembers where the same bytes
 // still are on the device. The next stage, handed that buffer unmodified (which is what the reference's signal / slot chain does),
-// finds the twin by address and skips its copy-in. All twins are written and read on the null stream (or ordered against it by events).
-// T2GPU_HANDOFF=0 disables every look-up (each stage then copies in, as in rounds 1-3).
-void twin_publish(const void *host, const void *dev, size_t bytes, int device);   // replaces an entry with the same host base
+// finds the twin by address and skips its copy-in -- but only once the caller has said so (t2gpu_handoff_enable; the stage classes of
+// t2gpu_stages.hpp do): by default a host-buffer entry point is a function of the bytes it is handed and nothing else. An entry made
+// on the way carries a hash of the buffer's first and last 64 bytes and its length; a look-up that finds them changed (a recycled
+// address) drops the entry. Buffers attached by the caller (t2gpu_twin_attach) are honoured always.
+// All twins are written and read on the null stream (or ordered against it by events).
+void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded = true);   // replaces an entry with the same host base
 void twin_retire(const void *host);                                               // the entry whose base is host, if any
 void twin_retire_dev(const void *dev_lo, size_t bytes);                           // every entry whose device range lies in [dev_lo, +bytes)
 const void *twin_lookup(const void *host, size_t bytes, int device);              // device address of [host, host + bytes) or nullptr
 }  // namespace t2gpu
+
+// one step of a host spin loop (the page-locked sequence words the device raises): the CPU's own hint where there is one
+static inline void t2_cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
 
 #define T2_HIP(call)                                   \
     do {                                               \

@@ -209,7 +209,7 @@ const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
         volatile unsigned *flag = h->h_flag;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; *flag != seq; ++spins) {
-            __builtin_ia32_pause();
+            t2_cpu_relax();
             if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;    // a failed launch shows here
                 if (*flag != seq) { set_error("t2gpu_demod: the symbol's results did not arrive"); return nullptr; }
@@ -430,7 +430,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) *h->h_flag = 0;
     if (const char *e = std::getenv("T2GPU_DEMOD_SPIN")) h->spin = std::atoi(e) != 0;
-    if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device);     // what the signals hand on is still on the device
+    if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device, false);     // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;

@@ -46,6 +46,7 @@ struct t2gpu_front {
     bool dev_runs_valid = false;
     // short calls in one launch (front_kernels.hip: front_chain_kernel); T2GPU_FRONT_CHAIN=0 at creation keeps the five launches
     unsigned long long *d_bar = nullptr, chain_count = 0;
+    int *d_chain_error = nullptr;      // raised by a grid barrier of the chain that gave up
     bool chain_on = true;
     int chain_cap = 0;                 // front_chain_capacity() of the handle's device
     // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
@@ -178,6 +179,7 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         *h->h_flag = 0;
     }
     bool ok = hipMalloc(&h->d_bar, 8) == hipSuccess && hipMemset(h->d_bar, 0, 8) == hipSuccess &&
+              hipMalloc(&h->d_chain_error, 4) == hipSuccess && hipMemset(h->d_chain_error, 0, 4) == hipSuccess &&
               hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
               hipMalloc(&h->d_derot, ((size_t)max_samples + 3) * sizeof(float2)) == hipSuccess &&
@@ -199,7 +201,7 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    hipFree(h->d_bar);
+    hipFree(h->d_bar); hipFree(h->d_chain_error);
     if (h->h_state) hipHostFree(h->h_state);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
@@ -327,8 +329,10 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
         a.p.nco_runs = nullptr; a.p.far_runs = nullptr; a.p.nco_index = nullptr; a.p.far_index = nullptr;
         if (nn) std::memcpy(a.runs, h->nco_runs.data(), nn * sizeof(FrontRun));
         if (nf) std::memcpy(a.runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
-        a.bar = h->d_bar; a.target = h->chain_count;
+        a.bar = h->d_bar; a.target = h->chain_count; a.error = h->d_chain_error;
         launch_front_chain(a, chain_grid, stream);
+        // the device's counter moves only if the launch was accepted: the host's copy follows it, not the attempt
+        T2_HIP(hipGetLastError());
         h->chain_count += 3ull * (unsigned long long)chain_grid;
     } else {
         if (stage_tables(h, (int)n, stream, p) != 0) return -1;
@@ -378,7 +382,7 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
         volatile unsigned *flag = h->h_flag;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; *flag != h->state_seq; ++spins) {
-            __builtin_ia32_pause();
+            t2_cpu_relax();
             if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
         }
         if (*flag == h->state_seq) { std::atomic_thread_fence(std::memory_order_acquire); s = *h->h_state; have = true; }
@@ -386,6 +390,9 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
     if (!have) {
         T2_HIP(hipStreamSynchronize(h->last_stream));
         T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
+        int err = 0;
+        T2_HIP(hipMemcpy(&err, h->d_chain_error, 4, hipMemcpyDeviceToHost));
+        if (err) { set_error("t2gpu_front: a grid barrier of the one-launch chain timed out"); return -1; }
     }
     out8[0] = (float)s.dc_re; out8[1] = (float)s.dc_im; out8[2] = s.c1; out8[3] = s.c2;
     out8[4] = h->phase_nco; out8[5] = h->frequency_nco; out8[6] = s.level_detect; out8[7] = h->x1;

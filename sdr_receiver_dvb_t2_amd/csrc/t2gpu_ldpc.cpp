@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace t2gpu;
@@ -42,6 +45,7 @@ struct t2gpu_ldpc {
     hipStream_t a_stream = nullptr;
     hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
+    bool a_ready = false;               // stream, event and pinned staging of the asynchronous form all exist
     bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
     bool plain_always = false;          // t2gpu_ldpc_set_plain_launch
     // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
@@ -63,6 +67,60 @@ static bool use_packed(const t2gpu_ldpc *h)
 }
 
 static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->blocks_per_cu; }
+
+// ---- what the plain launches of t2gpu_ldpc_submit may hold of a device at one time. The workgroups of a SIMD batch meet at
+// every sweep, so every workgroup of every decode in flight must be resident: a cooperative launch has the runtime's word for that, a
+// plain one has only this ledger. A submit books the CUs its grid needs (grid / workgroups per CU of its code) against the device's CUs
+// and waits -- for decodes already in flight to finish, which they do on their own -- when the device is booked out; a grid that could
+// never fit is launched cooperatively instead. Short kernels of other streams only delay a workgroup's start; they do not hold CUs.
+namespace {
+struct Booking { const t2gpu_ldpc *h; hipEvent_t done; int cus; bool armed; };   // armed: `done` has been recorded behind the decode
+std::mutex g_book_m;
+std::map<int, std::vector<Booking>> g_books;          // per device
+
+int booked_locked(std::vector<Booking> &b, bool query)
+{
+    int sum = 0;
+    for (size_t i = 0; i < b.size();) {
+        // (asking the runtime about every decode in flight on every submit cost the slot-shaped path a quarter of its rate: the events
+        // are only looked at when the ledger says the device is full; otherwise a booking goes with its handle's collect / next submit)
+        if (query && b[i].armed && hipEventQuery(b[i].done) == hipSuccess) b.erase(b.begin() + (long)i);   // that decode is through: its CUs are free
+        else { sum += b[i].cus; ++i; }
+    }
+    if (query) (void)hipGetLastError();                                                 // hipErrorNotReady is not an error
+    return sum;
+}
+// returns false when the grid cannot fit the device at all (the caller launches cooperatively then)
+bool book_cus(const t2gpu_ldpc *h, hipEvent_t done, int cus, int capacity)
+{
+    if (cus > capacity) return false;
+    for (;;) {
+        hipEvent_t oldest = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_book_m);
+            std::vector<Booking> &b = g_books[h->device];
+            for (size_t i = 0; i < b.size();) { if (b[i].h == h) b.erase(b.begin() + (long)i); else ++i; }   // a handle has one decode in flight
+            if (booked_locked(b, false) + cus <= capacity || booked_locked(b, true) + cus <= capacity) { b.push_back(Booking{h, done, cus, false}); return true; }
+            for (const Booking &x : b) if (x.armed) { oldest = x.done; break; }
+        }
+        if (oldest) hipEventSynchronize(oldest);     // booked out: until the oldest decode in flight is through
+        else std::this_thread::yield();              // (another thread is between its booking and its launch)
+    }
+}
+void arm_booking(const t2gpu_ldpc *h)
+{
+    std::lock_guard<std::mutex> lk(g_book_m);
+    for (Booking &x : g_books[h->device]) if (x.h == h) x.armed = true;
+}
+void unbook(const t2gpu_ldpc *h)
+{
+    std::lock_guard<std::mutex> lk(g_book_m);
+    auto it = g_books.find(h->device);
+    if (it == g_books.end()) return;
+    std::vector<Booking> &b = it->second;
+    for (size_t i = 0; i < b.size();) { if (b[i].h == h) b.erase(b.begin() + (long)i); else ++i; }
+}
+}  // namespace
 // the in-kernel profile is indexed by the workgroup id of whichever kernel runs: room for the larger of the two grids
 static size_t prof_blocks(const t2gpu_ldpc *h) { return std::max(h->state_blocks, h->state2_blocks); }
 
@@ -212,6 +270,7 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
+    unbook(h);
     if (h->a_done) hipEventDestroy(h->a_done);
     if (h->a_fence) hipEventDestroy(h->a_fence);
     if (h->d_out) twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);
@@ -413,7 +472,7 @@ extern "C" int t2gpu_ldpc_status(t2gpu_ldpc *h)
     int e = 0;
     T2_HIP(hipMemcpy(&e, h->d_error, 4, hipMemcpyDeviceToHost));
     h->last_status = e;
-    if (e) set_error("LDPC batch rendezvous timed out");
+    if (e) set_error(e == 2 ? "LDPC: entry table built for another LDS layout" : "LDPC batch rendezvous timed out");
     return e;
 }
 
@@ -450,23 +509,23 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     if (n_frames > h->max_frames) { set_error("t2gpu_ldpc_submit: more frames than max_frames"); return -1; }
     if (h->a_frames) { set_error("t2gpu_ldpc_submit: the previous submit has not been collected"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    if (!h->a_stream) {
+    if (!h->a_ready) {
+        // (a_ready only once everything is there: a call that failed half way starts over instead of running on null buffers)
         // lowest priority: the runtime keeps a separate set of hardware queues per priority, so these streams never share a queue with the
         // null stream -- a decode of milliseconds in the queue the per-symbol kernels of the caller go through would hold every one of
         // them up (seen in rocprofv3: the second batch's copy, on the null stream, waited for the first batch's kernel)
         int prio_least = 0, prio_greatest = 0;
         T2_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        T2_HIP(hipStreamCreateWithPriority(&h->a_stream, hipStreamNonBlocking, prio_least));
-        T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
-        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
-        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_out), (size_t)h->max_frames * h->g.k, hipHostMallocDefault));
-        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_trials), ((size_t)h->max_frames + 1) * sizeof(int), hipHostMallocDefault));
+        if (!h->a_stream) T2_HIP(hipStreamCreateWithPriority(&h->a_stream, hipStreamNonBlocking, prio_least));
+        if (!h->a_done) T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
+        if (!h->p_in) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
+        if (!h->p_out) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_out), (size_t)h->max_frames * h->g.k, hipHostMallocDefault));
+        if (!h->p_trials) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_trials), ((size_t)h->max_frames + 1) * sizeof(int), hipHostMallocDefault));
+        h->a_ready = true;
     }
-    if (!h->d_in) {
-        T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_frames * h->g.n));
-        T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_frames * h->g.k));
-        T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
-    }
+    if (!h->d_in) T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_frames * h->g.n));
+    if (!h->d_out) T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_frames * h->g.k));
+    if (!h->d_trials) T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
     const int nbatches = (n_frames + h->group - 1) / h->group;
     hipStream_t s = h->a_stream;
     twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
@@ -484,16 +543,21 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
         std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns
         T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));
     }
-    // several submits run side by side (cooperative launches would not); a submit is at most max_frames = a few SIMD batches, and
-    // the callers' rings (t2::ldpc_decoder: 8 handles of one batch) stay far below the device's resident workgroups
-    h->plain_launch = true;
+    // several submits run side by side (cooperative launches would not). What they hold of the device together is booked (above): this
+    // call waits while the decodes in flight leave no room for its grid, and a grid the device could never hold as a whole goes through
+    // the cooperative launch, which refuses rather than hangs
+    const int wgs = t2gpu_ldpc_launch_workgroups(h, n_frames);
+    const int per_cu = use_packed(h) ? h->p_blocks_per_cu : h->blocks_per_cu;
+    if (wgs < 1 || per_cu < 1) { set_error("t2gpu_ldpc_submit: the device cannot keep one batch resident"); return -1; }
+    h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu);
     const int rc = t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s);
     h->plain_launch = false;
-    if (rc) return -1;
+    if (rc) { unbook(h); return -1; }
     T2_HIP(hipMemcpyAsync(h->p_out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost, s));
     T2_HIP(hipMemcpyAsync(h->p_trials, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost, s));
     T2_HIP(hipMemcpyAsync(h->p_trials + h->max_frames, h->d_error, sizeof(int), hipMemcpyDeviceToHost, s));
     T2_HIP(hipEventRecord(h->a_done, s));
+    arm_booking(h);
     h->a_frames = n_frames;
     return 0;
 }
@@ -512,7 +576,8 @@ extern "C" int t2gpu_ldpc_collect(t2gpu_ldpc *h, int wait, const uint8_t **out, 
         T2_HIP(e);
     }
     *out = h->p_out; *trials_left = h->p_trials;
-    twin_publish(h->p_out, h->d_out, (size_t)h->a_frames * h->g.k, h->device);   // bch_decoder is handed these bits next
+    unbook(h);                                                       // the decode is through: its CUs are free
+    twin_publish(h->p_out, h->d_out, (size_t)h->a_frames * h->g.k, h->device, false);   // bch_decoder is handed these bits next
     if (n_frames) *n_frames = h->a_frames;
     h->a_frames = 0;
     h->last_status = h->p_trials[h->max_frames];

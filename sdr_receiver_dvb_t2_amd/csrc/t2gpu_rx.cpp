@@ -56,7 +56,7 @@ struct t2gpu_rx {
     // before. Three LLR buffers rotate (the demapper fills one, up to two decodes read the others; the frames behind a call's last
     // complete batch are copied to the head of the next buffer), two decode sets alternate (decoder handle with its state, stream,
     // output rows): decode k runs on set k % 2 from buffer k % 3.
-    bool overlap = false;
+    bool overlap = false, overlap_ready = false;   // overlap_ready: the second decode set, the streams and the events of the mode all exist
     int8_t *d_llr_ab[3] = {nullptr, nullptr, nullptr};
     int cur = 0;                              // LLR buffer the next back half fills
     int set = 0, last_set = 0;                // decode set of the next decode (when it is a small one) / of the last decode
@@ -515,6 +515,9 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
         T2_HIP(hipEventRecord(h->ev_demap, (hipStream_t)stream));                 // the call's stream may have put frames there itself (calls without a full batch)
         T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
         if (h->dec_done_set[1 - set]) T2_HIP(hipStreamWaitEvent(d, h->ev_dec_done[1 - set], 0));   // the end of a stream: nothing runs beside it
+        // the set's output rows may still be on their way to the host from an earlier decode (a last call that formed no batch puts the
+        // flushed rows at 0, over them): behind that copy, as the plain flush and the overlapped back half do
+        if (h->ts && h->ts->last_copy_s[set]) T2_HIP(hipStreamWaitEvent(d, h->ts->last_copy_s[set], 0));
         if (rx_decode(h, n, at, d, h->d_llr_ab[b]) != 0) return -1;
         T2_HIP(hipEventRecord(h->ev_llr_read[b], d));
         T2_HIP(hipEventRecord(h->ev_dec_done[set], d));
@@ -545,7 +548,8 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
     T2_HIP(hipSetDevice(h->device));
     T2_HIP(hipDeviceSynchronize());
     if (h->carry != 0) { set_error("t2gpu_rx_set_overlap: frames are waiting for a batch (flush or reset first)"); return -1; }
-    if (enable && !h->d_llr_ab[0]) {
+    if (enable && !h->overlap_ready) {
+        // (overlap_ready only once everything below exists: a call that failed half way starts over and frees nothing twice)
         const t2gpu_rx_config &c = h->cfg;
         const size_t rows = (size_t)c.max_frames * c.plp_num_blocks + h->row_pad;
         hipDeviceProp_t prop;
@@ -553,22 +557,24 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         h->num_cu = prop.multiProcessorCount;
         h->d_llr_ab[0] = h->d_llr; h->ldpc_s[0] = h->ldpc; h->d_bits_s[0] = h->d_bits; h->d_pack_s[0] = h->d_pack; h->d_trials_s[0] = h->d_trials;
         bool ok = true;
-        for (int b = 1; b < 3; ++b) ok = ok && hipMalloc(&h->d_llr_ab[b], rows * h->fec_size) == hipSuccess;
-        ok = ok && hipMalloc(&h->d_bits_s[1], rows * h->k_ldpc) == hipSuccess && hipMalloc(&h->d_pack_s[1], rows * (h->k_bch / 8)) == hipSuccess &&
-             hipMalloc(&h->d_trials_s[1], (rows / h->group + 2) * sizeof(int32_t)) == hipSuccess;
-        if (ok) {
+        for (int b = 1; b < 3; ++b) ok = ok && (h->d_llr_ab[b] || hipMalloc(&h->d_llr_ab[b], rows * h->fec_size) == hipSuccess);
+        ok = ok && (h->d_bits_s[1] || hipMalloc(&h->d_bits_s[1], rows * h->k_ldpc) == hipSuccess) &&
+             (h->d_pack_s[1] || hipMalloc(&h->d_pack_s[1], rows * (h->k_bch / 8)) == hipSuccess) &&
+             (h->d_trials_s[1] || hipMalloc(&h->d_trials_s[1], (rows / h->group + 2) * sizeof(int32_t)) == hipSuccess);
+        if (ok && !h->ldpc_s[1]) {
             h->ldpc_s[1] = t2gpu_ldpc_create(c.plp_fec_type, c.plp_cod, (int)rows, h->device);
             ok = h->ldpc_s[1] && t2gpu_ldpc_configure(h->ldpc_s[1], h->group, c.ldpc_trials > 0 ? c.ldpc_trials : 25) == 0;
         }
         // (default priority: at the lowest one the next call's front half, issued later, was dispatched ahead of the decode it is meant
         // to run beside -- 2- to 16-frame calls lost 2 - 7 %)
-        for (int k = 0; k < 2 && ok; ++k) ok = hipStreamCreateWithFlags(&h->dec_s[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) ok = h->dec_s[k] || hipStreamCreateWithFlags(&h->dec_s[k], hipStreamNonBlocking) == hipSuccess;
         for (hipEvent_t *e : {&h->ev_demap, &h->ev_l1_copied, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
                               &h->ev_carry[2], &h->ev_dec_done[0], &h->ev_dec_done[1]})
-            ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
-        if (!ok) { set_error("t2gpu_rx_set_overlap: allocation failed"); return -1; }
+            ok = ok && (*e || hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess);
+        if (!ok) { (void)hipGetLastError(); set_error("t2gpu_rx_set_overlap: allocation failed"); return -1; }
+        h->overlap_ready = true;
     }
-    if (h->d_llr_ab[0]) {
+    if (h->overlap_ready) {
         // from a known state either way: buffer 0, set 0, nothing in flight (the device is idle here)
         h->cur = 0; h->set = 0; h->last_set = 0;
         h->d_llr = h->d_llr_ab[0]; h->ldpc = h->ldpc_s[0]; h->d_bits = h->d_bits_s[0]; h->d_pack = h->d_pack_s[0]; h->d_trials = h->d_trials_s[0];

@@ -121,6 +121,8 @@ int main(int argc, char **argv)
             t2::ldpc_decoder ldpc(0, 8, threads);
             t2::bch_decoder bch;
             t2::bb_de_header deheader(need_plp);
+            // STAGE_HANDOFF=0: the hand-over of stage outputs by address, which the stage classes switch on, off again
+            if (std::getenv("STAGE_HANDOFF") && std::atoi(std::getenv("STAGE_HANDOFF")) == 0) t2::handoff(false);
             std::vector<uint8_t> out, ts;
             // STAGE_DUMP=<prefix>: what crosses the first two signals is also appended to <prefix>.ti.c64 / <prefix>.llr.i8
             const char *dump_to = std::getenv("STAGE_DUMP");

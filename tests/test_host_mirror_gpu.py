@@ -161,10 +161,10 @@ def test_fec_side_from_cells_two_plps(driver, tmp_path):
     ts = np.fromfile(tmp_path / "ts.u8", np.uint8)
     n_pkts = ((96 - n0) * ((k_bch - 80) // 8)) // 187 - 1
     assert np.array_equal(ts[:n_pkts * 188], ts1.reshape(-1)[:n_pkts * 188])
-    # the same chain with the device twins of the stage outputs switched off (every stage copies its input in, as in rounds 1-3):
-    # the hand-over by address changes where the bytes come from, not one of them
+    # the same chain with the hand-over of the stage outputs by address switched off again (t2::handoff(false): every stage copies its
+    # input in, which is what the plain C ABI does by default): it changes where the bytes come from, not one of them
     run(driver, "cells", tmp_path / "cells.c64", tmp_path / "out0.u8", 1, tmp_path / "ts0.u8", lps, code_rate, len(sizes), *sizes, 2, *plps,
-        env_extra={"T2GPU_HANDOFF": "0"})
+        env_extra={"STAGE_HANDOFF": "0"})
     assert np.array_equal(np.fromfile(tmp_path / "out0.u8", np.uint8), got.reshape(-1))
     assert np.array_equal(np.fromfile(tmp_path / "ts0.u8", np.uint8), ts)
     # ... and with the de-interleaver and the LDPC stage on threads of their own (t2::time_deinterleaver / t2::ldpc_decoder own_thread:

@@ -210,3 +210,30 @@ def test_noisy_full_grid_is_exact_and_repeatable(torch_cuda):
         t, wb, wl = ol.ora_decode(cid, llr[32 * b:32 * b + 32])
         assert t < 0
         assert np.array_equal(lo1[32 * b:32 * b + 32], wl)
+
+
+def test_submits_that_overbook_the_device_wait_for_each_other(torch_cuda):
+    """plain launches of t2gpu_ldpc_submit are booked against the device's CUs. Three handles whose grids (12 SIMD batches =
+    192 workgroups each, one per CU) cannot be resident together are submitted back to back from one thread: the second waits for the
+    first to finish instead of two half-resident grids spinning into the rendezvous time-out, and every result equals the plain call's."""
+    import ctypes
+    import sdr_receiver_dvb_t2_amd as pkg
+    l = pkg.lib()
+    cid = 9
+    n, k, _, _ = ol.ldpc_params(cid)
+    frames = 32 * 12
+    rng = np.random.Generator(np.random.PCG64(5))
+    llrs = [np.ascontiguousarray(rng.integers(-24, 25, size=(frames, n), dtype=np.int8)) for _ in range(3)]
+    decs = [pkg.ldpc_decoder(1, 3, max_frames=frames, trials=4) for _ in range(3)]
+    want = [d.execute_host(x) for d, x in zip(decs, llrs)]
+    for d, x in zip(decs, llrs):
+        assert l.t2gpu_ldpc_submit(d._h, x.ctypes.data, x.size) == 0, l.t2gpu_last_error()
+    for d, (wb, wt) in zip(decs, want):
+        out, tr, nf = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+        assert l.t2gpu_ldpc_collect(d._h, 1, ctypes.byref(out), ctypes.byref(tr), ctypes.byref(nf)) == 0, l.t2gpu_last_error()
+        assert nf.value == frames
+        bits = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint8)), shape=(frames, k))
+        trials = np.ctypeslib.as_array(ctypes.cast(tr, ctypes.POINTER(ctypes.c_int32)), shape=(frames // 32,))
+        assert np.array_equal(trials, wt) and np.array_equal(bits, wb)
+    for d in decs:
+        d.close()
