@@ -12,8 +12,11 @@ namespace t2gpu {
 struct FftLayout { long first, frame_stride; int per_frame, sym_stride; };
 
 // twiddle[m] = exp(-j*2*pi*m/N), m in [0, N); layout = nullptr: contiguous symbols
+// scratch (may be null): room for scratch_symbols x fft_size cells; calls of at most that many symbols then run as two launches spread
+// over many CUs (ofdm_kernels.hip: fft_stage_a_kernel / fft_stage_bc_kernel, bit-identical output) instead of one workgroup per symbol
 hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
-                      hipStream_t s, const FftLayout *layout = nullptr);
+                      hipStream_t s, const FftLayout *layout = nullptr, float2 *scratch = nullptr, int scratch_symbols = 0);
+constexpr int FFT_WIDE_SYMBOLS = 2;                         // calls of up to this many symbols take the two-launch form
 
 struct EqParams {
     int fft_size, l_nulls, k_total, c_data, n_p2, max_seg;   // c_data: cells out per symbol; n_p2: frame index of table row 0

@@ -180,10 +180,110 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
     }
 }
 
+// ---- the same transform of ONE symbol (or a few) on many CUs: the slot-shaped path hands the library one OFDM symbol at a time and
+// waits for it, and one workgroup on one CU took 19 us for a 32K symbol (load, three register stages, two exchanges, store -- all of
+// it latency of a single CU). After stage A the 32 values of k1 never meet again: the rest of the transform is 32 independent
+// 32 x T2 transforms. So: launch 1 = stage A, 64 lanes per workgroup (T / 64 workgroups per symbol), the first exchange through a
+// scratch array in memory (L2) instead of LDS; launch 2 = stages B and C, one workgroup per 8 values of k1 (8 * T2 lanes, 4
+// workgroups per symbol), the second exchange in its own LDS, and the lanes of a store instruction cover 8 consecutive bins (whole
+// 64-byte lines). Every value goes through the same operations in the same order as in fft_fwd_shift_kernel: bit-identical output
+// (tests/test_ofdm_gpu.py holds the two against each other).
+template <int T2>
+__global__ __launch_bounds__(64) void fft_stage_a_kernel(const float2 *__restrict__ in, float2 *__restrict__ scratch,
+                                                         const float2 *__restrict__ twiddle, FftLayout lay)
+{
+    constexpr int T = 32 * T2, N = 32 * T, WGS = T / 64;
+    const int sym = (int)blockIdx.x / WGS, tid = ((int)blockIdx.x % WGS) * 64 + (int)threadIdx.x;
+    const float2 *x = in + lay.first + (long)(sym / lay.per_frame) * lay.frame_stride + (long)(sym % lay.per_frame) * lay.sym_stride;
+    float2 *sc = scratch + (size_t)sym * N;
+    cf v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const float2 a = x[tid + T * j]; v[j] = {a.x, a.y}; }
+    fft_reg<32>(v);
+    {
+        cf pw[5];
+        cpow_table(twiddle + N, T, tid, pw);
+        twiddle_powers<32>(v, pw);
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sc[bitrev<32>(r) * T + tid] = make_float2(v[r].x, v[r].y);
+}
+
+template <int T2>
+__global__ __launch_bounds__(8 * T2) void fft_stage_bc_kernel(const float2 *__restrict__ scratch, float2 *__restrict__ out,
+                                                              const float2 *__restrict__ twiddle)
+{
+    constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
+    __shared__ float lds[32 * 8 * PITCH];                      // rows (q1, k1 of this workgroup) of T2 values over t1
+    const int sym = (int)blockIdx.x / 4, kb = ((int)blockIdx.x % 4) * 8;
+    const int l = (int)threadIdx.x, k1l = l / T2, t1n = l % T2, k1n = kb + k1l;
+    const float2 *sc = scratch + (size_t)sym * N;
+    float2 *y = out + (size_t)sym * N;
+    cf u[32];
+#pragma unroll
+    for (int t2 = 0; t2 < 32; ++t2) { const float2 a = sc[k1n * T + t1n + T2 * t2]; u[t2] = {a.x, a.y}; }
+    fft_reg<32>(u);
+    {
+        cf pw[5];
+        cpow_table(twiddle + N + 5 * T, T2, t1n, pw);
+        twiddle_powers<32>(u, pw);
+    }
+    cf w2[32];
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) lds[(bitrev<32>(r) * 8 + k1l) * PITCH + t1n] = plane ? u[r].y : u[r].x;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int pair = (T2 == 32) ? l : l + 8 * T2 * (e / T2);               // local (q1, k1) pair = q1 * 8 + k1l
+            const float f = lds[pair * PITCH + (e % T2)];
+            if (plane) w2[e].y = f; else w2[e].x = f;
+        }
+    }
+    // the lane's pair(s) in the numbering of fft_fwd_shift_kernel: id = q1 * 32 + k1
+    const int q1 = l / 8, k1 = kb + l % 8;
+    if (T2 == 32) {
+        fft_reg<32>(w2);
+        const int id = q1 * 32 + k1;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const int k = id + 1024 * bitrev<32>(r);
+            y[(k + N / 2) & (N - 1)] = make_float2(w2[r].x, w2[r].y);
+        }
+    } else {
+        cf a[32], b[32];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { a[e] = w2[e]; b[e] = w2[16 + e]; }
+        fft_reg<16>(a);
+        fft_reg<16>(b);
+        const int ida = q1 * 32 + k1, idb = (q1 + 16) * 32 + k1;                   // second pair: local index + 128 = q1 + 16
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q2 = bitrev<16>(r);
+            y[(ida + 1024 * q2 + N / 2) & (N - 1)] = make_float2(a[r].x, a[r].y);
+            y[(idb + 1024 * q2 + N / 2) & (N - 1)] = make_float2(b[r].x, b[r].y);
+        }
+    }
+}
+
 hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
-                      hipStream_t s, const FftLayout *layout)
+                      hipStream_t s, const FftLayout *layout, float2 *scratch, int scratch_symbols)
 {
     const FftLayout lay = layout ? *layout : FftLayout{0, 0, n_symbols > 0 ? n_symbols : 1, fft_size};
+    if (scratch && n_symbols >= 1 && n_symbols <= scratch_symbols) {
+        if (fft_size == 32768) {
+            hipLaunchKernelGGL(fft_stage_a_kernel<32>, dim3(16 * n_symbols), dim3(64), 0, s, in, scratch, twiddle, lay);
+            hipLaunchKernelGGL(fft_stage_bc_kernel<32>, dim3(4 * n_symbols), dim3(256), 0, s, scratch, out, twiddle);
+            return hipGetLastError();
+        }
+        if (fft_size == 16384) {
+            hipLaunchKernelGGL(fft_stage_a_kernel<16>, dim3(8 * n_symbols), dim3(64), 0, s, in, scratch, twiddle, lay);
+            hipLaunchKernelGGL(fft_stage_bc_kernel<16>, dim3(4 * n_symbols), dim3(128), 0, s, scratch, out, twiddle);
+            return hipGetLastError();
+        }
+    }
     const int blocks = (fft_size == 32768 || n_symbols < max_blocks) ? n_symbols : max_blocks;   // 32K: one workgroup per symbol
     if (fft_size == 32768) {
         const int lds_bytes = 32 * 1024 * 4 > 32 * 32 * 33 * 4 ? 32 * 1024 * 4 : 32 * 32 * 33 * 4;

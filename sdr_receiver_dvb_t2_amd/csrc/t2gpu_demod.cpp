@@ -80,6 +80,10 @@ struct t2gpu_demod {
     // the front end writes a symbol's chunk straight into the symbol buffer (T2GPU_DEMOD_DIRECT=0: into d_out, copied from there)
     bool direct = true;
     float *d_bounce = nullptr;
+    // A data symbol's `data` signal is emitted once the NEXT chunk's front-end launch is on its way (or at the end of the call): what the
+    // consumer does in it (the de-interleaver's push: ~9 us of host time and a launch) then runs beside the front-end kernel instead of
+    // in front of it. The cells stay where they are until the next equaliser launch, which comes later still.
+    int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
 };
 
 namespace {
@@ -227,6 +231,16 @@ const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
     return h->h_cells;
 }
 
+void flush_data_signal(t2gpu_demod *h)
+{
+    if (!h->pending_data) return;
+    const int n = h->pending_data;
+    h->pending_data = 0;
+    h->prof.start();
+    h->sig.data(h->sig.user, n, h->h_cells);
+    h->prof.stop(PF_SIGNAL);
+}
+
 // symbol_acquisition (:267-448). Returns 0, or -1 on an error of a stage.
 // src: the front end's output of this chunk -- h->d_out, or the symbol buffer itself from idx_buffer_sym on (t2gpu_demod_execute lets the
 // front end write there when the chunk continues a symbol: the copy below is then no copy at all).
@@ -312,10 +326,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             if (!c) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.stop(PF_SV);
-            if (carry) {
-                h->sig.data(h->sig.user, h->c_data, c);
-                h->prof.stop(PF_SIGNAL);
-            }
+            if (carry) { flush_data_signal(h); h->pending_data = h->c_data; (void)c; }   // emitted behind the next front-end launch
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
                 h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
@@ -327,10 +338,11 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, carry ? h->n_fc : 0);
             if (!c) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
-            if (carry) h->sig.data(h->sig.user, h->n_fc, c);
+            if (carry) { flush_data_signal(h); h->sig.data(h->sig.user, h->n_fc, c); }
             h->next_symbol_type = SYMBOL_TYPE_P1;
             ++h->frames;
         } else {                                                                    // SYMBOL_TYPE_P2
+            flush_data_signal(h);
             h->idx_symbol = 0;
             if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
             const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, h->c_p2);
@@ -526,8 +538,10 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
+        flush_data_signal(h);                                                       // (the front end is busy with the chunk just launched)
         if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
+    flush_data_signal(h);
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;

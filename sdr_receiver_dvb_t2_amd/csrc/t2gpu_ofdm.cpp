@@ -88,6 +88,7 @@ struct t2gpu_ofdm {
     int device = 0, max_symbols = 0, rows = 0, num_cu = 256;
     EqParams eq{}, eq_p2{}, eq_fc{};
     float2 *d_twiddle = nullptr;
+    float2 *d_fft_scratch = nullptr;   // the first exchange of the two-launch FFT of a one- or two-symbol call (ofdm_kernels.h)
     uint8_t *d_map = nullptr;
     uint16_t *d_dcar = nullptr, *d_dcar_p2 = nullptr, *d_dcar_fc = nullptr;   // carrier of every data cell, per table row
     float *d_refer = nullptr;
@@ -180,6 +181,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         ok = ok && hip_ok(hipMalloc((void **)dst, bytes), "hipMalloc") && hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy");
     };
     up(&h->d_twiddle, tw.data(), tw.size() * sizeof(float2));
+    ok = ok && hip_ok(hipMalloc((void **)&h->d_fft_scratch, (size_t)FFT_WIDE_SYMBOLS * m.fft_size * sizeof(float2)), "hipMalloc");
     up(&h->d_lut, lut.data(), lut.size() * sizeof(float2));
     up(&h->d_map, map.data(), map.size());
     up(&h->d_dcar, dcar.data(), dcar.size() * 2);
@@ -315,7 +317,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
 extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
 {
     if (!h) return;
-    hipFree(h->d_twiddle); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
+    hipFree(h->d_twiddle); hipFree(h->d_fft_scratch); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_pilot_scratch_p2); hipFree(h->d_pilot_scratch_fc); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
     hipFree(h->d_cellq); hipFree(h->d_cellq_p2); hipFree(h->d_cellq_fc); hipFree(h->d_sel); hipFree(h->d_sel_p2); hipFree(h->d_sel_fc);
@@ -330,7 +332,7 @@ extern "C" int t2gpu_fft_execute_dev(t2gpu_ofdm *h, const float *d_in, float *d_
 {
     if (!h || !d_in || !d_out || n_symbols < 1) { set_error("t2gpu_fft_execute_dev: bad arguments"); return -1; }
     T2_HIP(launch_fft(h->m.fft_size, reinterpret_cast<const float2 *>(d_in), reinterpret_cast<float2 *>(d_out), h->d_twiddle, n_symbols,
-                      h->num_cu, (hipStream_t)stream));
+                      h->num_cu, (hipStream_t)stream, nullptr, h->d_fft_scratch, FFT_WIDE_SYMBOLS));
     return 0;
 }
 
@@ -343,7 +345,7 @@ extern "C" int t2gpu_fft_execute_strided_dev(t2gpu_ofdm *h, const float *d_strea
     }
     const FftLayout lay{first, frame_stride, per_frame, sym_stride};
     T2_HIP(launch_fft(h->m.fft_size, reinterpret_cast<const float2 *>(d_stream), reinterpret_cast<float2 *>(d_out), h->d_twiddle, n_symbols,
-                      h->num_cu, (hipStream_t)stream, &lay));
+                      h->num_cu, (hipStream_t)stream, &lay, h->d_fft_scratch, FFT_WIDE_SYMBOLS));
     return 0;
 }
 

@@ -50,6 +50,28 @@ def test_fft_against_reference_fftw_and_dft(torch_cuda, fft_mode, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("fft_mode,n", [(5, 32768), (4, 16384)])
+def test_fft_of_one_symbol_on_many_cus_is_the_batch_kernels_output(torch_cuda, fft_mode, n):
+    """Calls of one or two symbols (the slot-shaped path) run as two launches over many CUs with the first exchange through memory
+    (fft_stage_a_kernel / fft_stage_bc_kernel); every value takes the same operations in the same order as in the one-workgroup kernel
+    a larger batch uses: the outputs are bit-identical."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    ctx = pkg.t2_ofdm(fft_mode, 1, 6, 4, 0, 59, max_symbols=8)
+    rng = np.random.Generator(np.random.PCG64(n + 1))
+    xb = (rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))).astype(np.complex64)
+    xb[4] = golden_input(n)
+    xd = torch_cuda.from_numpy(xb.view(np.float32).reshape(5, n, 2)).cuda()
+    batch = ctx.fft_dev(xd).cpu().numpy()                                    # five symbols: one workgroup each
+    for b in range(5):
+        one = ctx.fft_dev(xd[b:b + 1].contiguous()).cpu().numpy()            # one symbol: the two-launch form
+        assert np.array_equal(one[0].view(np.uint32), batch[b].view(np.uint32))
+    two = ctx.fft_dev(xd[3:5].contiguous()).cpu().numpy()
+    assert np.array_equal(two.view(np.uint32), batch[3:5].view(np.uint32))
+    y = two[1, :, 0] + 1j * two[1, :, 1]
+    assert rel_err(y, GOLD["fft_%d" % n]) < 2e-5
+    ctx.close()
+
+
 def test_fft_batch_properties_full_size(torch_cuda):
     """512 symbols of 32K (the batch size of the bench): Parseval and linearity hold for every symbol."""
     import sdr_receiver_dvb_t2_amd as pkg
