@@ -240,12 +240,13 @@ DROP_IN_EXE = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "bin", "t2gpu_rx_fil
 DROP_IN_BUF = 172032          # samples per execute() call: norm_blocks x 384 of the reference's SDRplay thread (rx_sdrplay.h:64, rx_sdrplay.cpp:199-261)
 
 
-def drop_in_leg(w, ui, uq, device, frames=26, warm_frames=10, sent=None, saturate=False, snr_db=None):
+def drop_in_leg(w, ui, uq, device, frames=72, warm_frames=12, sent=None, saturate=False, snr_db=None):
     """The slot-shaped path: int16 I/Q in device-buffer-sized calls through t2::dvbt2_demodulator::execute (t2gpu_demod_execute: closed
     tracking loops, the reference's own acquisition from P1 / guard search / L1-pre / L1-post) and the stage classes of
     include/t2gpu_stages.hpp wired as the reference wires its objects (time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder ->
     bb_de_header), in a plain C++ process (examples/t2gpu_rx_file.cpp, built by csrc/Makefile). The first warm_frames frames'
-    worth of buffers (acquisition) run before the program's clock starts. sent: the TS packets the frames carry -- every packet that
+    worth of buffers (acquisition) run before the program's clock starts; 60 frames (100 of config 4) are timed, more than half a second,
+    so that two rounds' figures can be compared (round 4 timed 15 frames, 0.18 s). sent: the TS packets the frames carry -- every packet that
     comes out is then looked up among them. saturate: the clamped-LLR extension (the reference's wrapping cast loses every 256-QAM
     SIMD batch, here as in the batch legs)."""
     import subprocess
@@ -391,7 +392,7 @@ def main():
     if args.only_drop_in:
         w = Workload(CONFIGS[args.config])
         ui, uq, sent = make_frames(w, 2, args.snr if args.snr is not None else CONFIGS[args.config]["snr"], seed=20250614)
-        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 26, sent=sent, saturate=args.saturate, snr_db=args.snr)))
+        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 72, sent=sent, saturate=args.saturate, snr_db=args.snr)))
         return
 
     def run_config(cfg_id, steps, warmup, extras, check_ts=False):
@@ -578,7 +579,7 @@ def main():
             if cfg_id != 4:
                 w4 = Workload(CONFIGS[4])
                 ui4, uq4, sent4 = make_frames(w4, 2, CONFIGS[4]["snr"], seed=20250614)
-                d_in["config_4"] = {k: v for k, v in drop_in_leg(w4, ui4, uq4, local_rank, frames=60, warm_frames=20, sent=sent4).items() if k != "entry"}
+                d_in["config_4"] = {k: v for k, v in drop_in_leg(w4, ui4, uq4, local_rank, frames=120, warm_frames=20, sent=sent4).items() if k != "entry"}
             extra["drop_in"] = d_in
 
         if rank != 0:

@@ -109,6 +109,7 @@ def p1_stream(seed=8):
 # the demapper / LDPC stage completes; cfg_a shows the 256-QAM wrap (every batch dropped), the others decode to TS.
 FEC_CASES = {
     "cfg_b": (2, 0, 0, 64, 16.0, 1),          # 64-QAM, 16200, r=1/2: two batches
+    "cfg_b_12": (2, 0, 0, 64, 12.0, 21),      # the same at 12 dB: BASELINE.md section 3's point for config 4, the one bench.py's config_4 legs run at
     "cfg_a": (3, 1, 3, 34, 21.0, 2),          # 256-QAM, 64800, r=3/4 at SURVEY 8d's 21 dB: the reference still drops every batch
     "cfg_c": (3, 1, 2, 33, 21.0, 3),          # 256-QAM, 64800, r=2/3 (demux_256_fec_size_normal_2_3), 21 dB
     "q16_n12": (1, 1, 0, 33, 10.0, 4),        # 16-QAM, 64800, r=1/2

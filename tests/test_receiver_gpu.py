@@ -372,3 +372,57 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
     sc, sr, sv, sts, scnt = run(True, pair=False)
     assert sc == pc and all(np.array_equal(a, b) for a, b in zip(pr, sr)) and all(np.array_equal(a, b) for a, b in zip(pv, sv))
     assert np.array_equal(pts, sts) and scnt["fec_frames"] == pcnt["fec_frames"]
+
+
+@pytest.mark.parametrize("pattern", [(1,) * 6, (2, 2, 2), (4, 4), (1, 4, 1, 16)])
+def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda, monkeypatch, pattern):
+    """bench.py's frames_sweep rows run CFG-A (32K / 256-QAM / 64800 r = 3/4, 202 FEC frames per T2 frame) at 1, 2, 4 ..
+    frames per call with t2gpu_rx_set_overlap; this is their correctness twin. Calls of the given sizes -- the last pattern changes size
+    from call to call, so the decode sets and the three LLR buffers rotate across the boundary where two decodes no longer fit the device
+    together -- with pairs allowed and not: the same row counts, packed rows, verdicts and TS bytes as the plain schedule (clamped LLRs,
+    so that batches decode and the rows carry BBFRAMEs)."""
+    torch = torch_cuda
+    import bench
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    w = bench.Workload(bench.CONFIGS[3])
+    ui, uq, _ = bench.make_frames(w, 2, 22.0, 4242)
+    total = sum(pattern)
+    reps = (total + 1) // 2
+    di = torch.from_numpy(np.concatenate([ui] * reps)[:total].reshape(-1)).cuda()
+    dq = torch.from_numpy(np.concatenate([uq] * reps)[:total].reshape(-1)).cuda()
+    flen = w.frame_samples
+
+    def run(overlap, pair=True):
+        rx = t2_rx(*w.mode, w.lps, w.plp[0], w.plp[1], w.plp[2], w.plp[3], w.nb, max_frames=max(pattern), saturate_llr=True)
+        rx.ts_enable(0, l1_check=True)
+        if overlap:
+            monkeypatch.setenv("T2GPU_RX_PAIR", "1" if pair else "0")
+            rx.set_overlap(True)
+        counts, rows, verdicts, at = [], [], [], 0
+        for c, nf in enumerate(pattern):
+            n = rx.execute_dev(di[at * flen:(at + nf) * flen], dq[at * flen:(at + nf) * flen], nf, first_call=(c == 0))
+            at += nf
+            counts.append(n)
+            if n:
+                r, t = rx.fetch_packed(n)
+                rows.append(r); verdicts.append(t)
+        n = rx.flush_dev()
+        counts.append(n)
+        if n:
+            r, t = rx.fetch_packed(counts[-2] + n)
+            rows.append(r[counts[-2]:]); verdicts.append(t)
+        ts_bytes = rx.ts_read(wait_all=True)
+        c = rx.ts_counters()
+        rx.close()
+        return counts, rows, verdicts, ts_bytes, c
+
+    pc, pr, pv, pts, pcnt = run(False)
+    assert sum(pc) == total * w.nb and pts.size > 0 and sum(int((v >= 0).sum()) for v in pv) > 0
+    for pair in (True, False):
+        oc, orr, ov, ots, ocnt = run(True, pair)
+        assert oc == pc, (pair, oc, pc)
+        assert len(orr) == len(pr) and all(np.array_equal(a, b) for a, b in zip(pr, orr)), pair
+        assert all(np.array_equal(a, b) for a, b in zip(pv, ov)), pair
+        assert np.array_equal(pts, ots), pair
+        for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
+            assert pcnt[k] == ocnt[k], (pair, k)
