@@ -408,6 +408,8 @@ int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2); /* c1 / c2 as a prev
  * to the sign statistics; t2gpu_front_commit_iq at the end of the execute() derives c1 / c2 / level_detect from all of them
  * (:227-235) for the NEXT execute(), as the reference does. hold = 0 (default): every call is an execute() of its own. */
 int t2gpu_front_hold_iq(t2gpu_front *h, int hold);
+/* a call of up to about two OFDM symbols' worth of samples runs as ONE launch (default); 0 keeps the five launches of longer calls: same values (tests) */
+int t2gpu_front_set_chain(t2gpu_front *h, int on);
 int t2gpu_front_commit_iq(t2gpu_front *h, void *stream);
 /* nominal resample = sample_rate / (SAMPLE_RATE * 2) and its limit (+100 ppm), as :54-55 computes them */
 int t2gpu_front_resample(const t2gpu_front *h, double *resample, double *max_resample);

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "t2gpu_front_set_frequency_nco": (ctypes.c_int, [_vp, ctypes.c_float]),
     "t2gpu_front_set_iq": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_front_hold_iq": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_front_set_chain": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_front_commit_iq": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_sync_reset": (None, [_vp, ctypes.c_float]),
     "t2gpu_sync_clear_frequency": (None, [_vp]),

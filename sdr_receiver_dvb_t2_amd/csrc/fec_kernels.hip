@@ -116,50 +116,9 @@ __device__ __forceinline__ float slice_axis(int mod, float x, float d)
     return pos ? amp : -amp;
 }
 
-// blockIdx.y = TI block of a batch: its cells at cells + y * cells_stride, its partial sums at partial + y * 2 * gridDim.x
-__global__ __launch_bounds__(256) void demap_stats_kernel(DemapParams p, const float2 *__restrict__ cells, int n_snr,
-                                                         double *__restrict__ partial, long cells_stride)
-{
-    cells += (long)blockIdx.y * cells_stride;
-    partial += (long)blockIdx.y * 2 * gridDim.x;
-    double ss = 0.0, se = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_snr; i += gridDim.x * blockDim.x) {
-        float2 v = cells[i];
-        if (p.rotate) v = derotate(v, p.rot_c, p.rot_s);
-        const float sr = slice_axis(p.mod, v.x, p.d), si = slice_axis(p.mod, v.y, p.d);
-        const float er = sub_r(v.x, sr), ei = sub_r(v.y, si);
-        ss += (double)add_r(mul_r(sr, sr), mul_r(si, si));      // std::norm(s), float as in the reference
-        se += (double)add_r(mul_r(er, er), mul_r(ei, ei));
-    }
-    __shared__ double sh[2][256];
-    sh[0][threadIdx.x] = ss; sh[1][threadIdx.x] = se;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
-}
-
-__global__ __launch_bounds__(64) void demap_stats_final_kernel(const double *__restrict__ partial, int blocks, float d,
-                                                               float precision_override, float *__restrict__ sums, int sums_stride)
-{
-    partial += (long)blockIdx.x * 2 * blocks;
-    sums += (long)blockIdx.x * sums_stride;
-    // one wavefront folds the per-block partial sums; lane-strided accumulation then a fixed butterfly: deterministic
-    double ss = 0.0, se = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += 64) { ss += partial[2 * b]; se += partial[2 * b + 1]; }
-    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_down(ss, o, 64); se += __shfl_down(se, o, 64); }
-    if (threadIdx.x != 0) return;
-    const float fs = (float)ss, fe = (float)se;
-    float precision = div_r(mul_r(mul_r(8.0f, d), fs), fe);        // 8.0f * NORM * sum_s / sum_e
-    if (precision_override > 0.0f) precision = precision_override;
-    sums[0] = fs; sums[1] = fe; sums[2] = precision;
-}
-
 // ---- K-snr, exact: the reference's statistics are two SEQUENTIAL float sums over the TI block (llr_demapper.cpp:564-676; in the
 // reference binary one vaddss per cell and sum, in cell order) -- float addition is not associative, and a tree or double-precision sum
-// (demap_stats_kernel above: the round 1-2 form, kept for comparison) differs from it by ~1e-4 relative, i.e. one LLR step on ~2 % of
+// (the round 1-2 form; removed in round 5) differs from it by ~1e-4 relative, i.e. one LLR step on ~2 % of
 // the positions, enough to flip a SIMD batch at the decoding threshold. This kernel reproduces the sequential sum bit for bit, in
 // parallel: while the running sum s stays inside one binade [2^E, 2^(E+1)), fl(s + x) = s + round(x / ulp) ulp with ulp = 2^(E-23) --
 // an INTEGER addition of the terms quantised at that ulp, which is associative -- except where x / ulp sits exactly on a half (the
@@ -479,8 +438,6 @@ __global__ void demap_scale_kernel(float d, float precision_override, float *__r
     q[2] = precision;
 }
 
-// T2GPU_DEMAP_TREE_STATS=1: the round 1-2 tree sums (for comparison with the exact form)
-static bool tree_stats() { const char *e = getenv("T2GPU_DEMAP_TREE_STATS"); return e && atoi(e) != 0; }
 
 long demap_terms_padded(int n_snr) { return ((long)n_snr + SEQ_CHUNK - 1) / SEQ_CHUNK * SEQ_CHUNK; }   // term pairs of scratch per TI block
 
@@ -499,7 +456,7 @@ static hipError_t launch_exact(const DemapParams &p, const float2 *cells, long c
     return hipGetLastError();
 }
 
-bool demap_stats_exact_form() { return !tree_stats(); }
+bool demap_stats_exact_form() { return true; }              // (rounds 1-2 summed as a tree in double: 2e-4 off the reference's sequential float sums)
 hipError_t launch_demap_stats_from_terms(const DemapParams &p, int n_snr, int n_batch, float2 *terms, float *sums, int sums_stride,
                                          float precision_override, hipStream_t s)
 {
@@ -510,20 +467,16 @@ hipError_t launch_demap_stats_from_terms(const DemapParams &p, int n_snr, int n_
 hipError_t launch_demap_stats(const DemapParams &p, const float2 *cells, int n_snr, double *partial, int blocks, float2 *terms, float *sums,
                               float precision_override, hipStream_t s)
 {
-    if (!tree_stats()) return launch_exact(p, cells, 0L, n_snr, 1, terms, sums, 0, precision_override, s);
-    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks), dim3(256), 0, s, p, cells, n_snr, partial, 0L);
-    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, 0);
-    return hipGetLastError();
+    (void)partial; (void)blocks;
+    return launch_exact(p, cells, 0L, n_snr, 1, terms, sums, 0, precision_override, s);
 }
 
 // n_batch TI blocks in one launch pair: every block summed on its own exactly as launch_demap_stats does (terms: n_batch * n_snr pairs)
 hipError_t launch_demap_stats_batch(const DemapParams &p, const float2 *cells, long cells_stride, int n_snr, int n_batch, double *partial,
                                     int blocks, float2 *terms, float *sums, int sums_stride, float precision_override, hipStream_t s)
 {
-    if (!tree_stats()) return launch_exact(p, cells, cells_stride, n_snr, n_batch, terms, sums, sums_stride, precision_override, s);
-    hipLaunchKernelGGL(demap_stats_kernel, dim3(blocks, n_batch), dim3(256), 0, s, p, cells, n_snr, partial, cells_stride);
-    hipLaunchKernelGGL(demap_stats_final_kernel, dim3(n_batch), dim3(64), 0, s, partial, blocks, p.d, precision_override, sums, sums_stride);
-    return hipGetLastError();
+    (void)partial; (void)blocks;
+    return launch_exact(p, cells, cells_stride, n_snr, n_batch, terms, sums, sums_stride, precision_override, s);
 }
 
 __device__ __forceinline__ int8_t cast_i8_trunc(float v)

@@ -1,12 +1,9 @@
-// ldpc_kernel.h -- launch interface between the C-ABI layer and ldpc_kernel.hip.
+// ldpc_kernel.h -- launch interface between the C-ABI layer and ldpc_kernel2.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef T2_LDPC_PAIRLANE
-#define T2_LDPC_PAIRLANE 1         // 1: one check node on two adjacent lanes (ldpc_cn2.h), 12 wavefronts; 0: one lane per node, 6 wavefronts
-#endif
-#define T2GPU_LDPC_THREADS (T2_LDPC_PAIRLANE ? 768 : 384)
+#define T2GPU_LDPC_THREADS 768      // one check node of a layer on two adjacent lanes (ldpc_cn3.h): 720 of 768 lanes, 12 wavefronts
 
 namespace t2gpu {
 
@@ -53,8 +50,5 @@ struct LdpcKernelParams {
 int ldpc_kernel2_record_dwords(int min_cnt, int max_cnt);
 hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes);
 hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream, bool allow_cooperative = true);
-
-hipError_t ldpc_kernel_attributes(int min_cnt, int max_cnt, int lds_bytes, int *blocks_per_cu, int *static_lds_bytes);
-hipError_t ldpc_kernel_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream);
 
 }  // namespace t2gpu

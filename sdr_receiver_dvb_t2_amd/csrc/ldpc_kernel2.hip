@@ -1,4 +1,4 @@
-// ldpc_kernel2.hip -- the decoder of ldpc_kernel.hip with TWO FEC frames per workgroup (ldpc_cn3.h): frames 2m and 2m + 1 of a
+// ldpc_kernel2.hip -- the LDPC decoder: TWO FEC frames per workgroup (ldpc_cn3.h): frames 2m and 2m + 1 of a
 // SIMD batch share a workgroup, their LLR bytes interleaved in LDS, every address / LDS access / DPP exchange serving both and the
 // int8 arithmetic running in the 16-bit halves of the registers. Same mapping otherwise: two lanes per check node (720 of 768
 // lanes), LLRs resident in LDS for the whole decode, per-link messages (one byte per link and frame, as in the reference) streaming
@@ -50,7 +50,7 @@ constexpr int kThreads2 = 768;
 
 __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- bit-parallel parity check of both frames (LDPCDecoder::bad, layered_decoder.hh:65-82; see ldpc_kernel.hip) -----------------
+// ---- bit-parallel parity check of both frames (LDPCDecoder::bad, layered_decoder.hh:65-82) -----------------
 // Sign words as there: 13 dwords per 360-bit group (bits 0..359 + a copy of bits 0..55), one array per frame. A dword of the
 // interleaved LLR bytes holds (A_k, B_k, A_k+1, B_k+1).
 __device__ __forceinline__ uint32_t has_zero_byte2(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }
@@ -171,7 +171,7 @@ __device__ __forceinline__ int frames_parity_bad(const int8_t *Lm, uint32_t *SA,
         if (tid == 0) { s_ctl[4 + 2 * ((trial + 1) & 1)] = 0; s_ctl[5 + 2 * ((trial + 1) & 1)] = 0; }
         if (fail_a && fail_b) return 3 | 4;
     }
-    // Probe (ldpc_kernel.hip): the 360 checks of layer 1 need the sign words of ~14 groups only, and a frame that has not converged
+    // Probe: the 360 checks of layer 1 need the sign words of ~14 groups only, and a frame that has not converged
     // almost always fails there. When BOTH frames fail the probe the workgroup is done; otherwise the full check runs for both.
     // The probe runs once per sweep for every frame pair that is still decoding: it reads nothing from memory (table entries from
     // their LDS copy) and ends in ONE barrier (the wavefronts' verdicts are OR-ed into an LDS word).
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
         return;
     }
     constexpr int RW = (HI + 2 + 1) / 2 > 8 ? 8 : 4;                 // record dwords per lane in memory: W <= 4 -> 4, else 8
-    const int group = p.group, wg_per_batch = group >> 1;
+    // an odd group (group = 1: independent frames) gives its last workgroup ONE frame: the B halves then carry a copy of frame A whose
+    // results are not stored (rounds 1-4 kept a second, one-frame-per-workgroup kernel for such groups)
+    const int group = p.group, wg_per_batch = (group + 1) >> 1;
     const int slot = blockIdx.x / wg_per_batch, member = blockIdx.x % wg_per_batch;
     const int nslots = gridDim.x / wg_per_batch;
     const int nbatches = (p.n_frames + group - 1) / group;
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
         }
         if (batch >= nbatches) break;
         const int frame_a = batch * group + 2 * member, frame_b = frame_a + 1;
-        const bool have_a = frame_a < p.n_frames, have_b = frame_b < p.n_frames;
+        const int batch_end = (batch + 1) * group < p.n_frames ? (batch + 1) * group : p.n_frames;
+        const bool have_a = frame_a < batch_end, have_b = frame_b < batch_end;
         const int nhave = (have_a ? 1 : 0) + (have_b ? 1 : 0);
         int members = p.n_frames - batch * group;
         members = members > group ? group : members;
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(kThreads2, 3) void ldpc_decode2_kernel(const LdpcLa
             int all_ok = clean == nhave;
             T2_PROF2_ADD(0, tp0);
             T2_PROF2_T(tp1);
-            if (group > 2 && have_a) {
+            if (wg_per_batch > 1 && have_a) {
                 // one word per (batch, trial): high half counts frames arrived, low half counts parity-clean frames
                 if (tid == 0) {
                     unsigned *w = p.sync + (size_t)batch * (p.max_trials + 1) + t;

@@ -734,24 +734,17 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         int range = 0;
         for (int k = 0; k < p.n_splits; ++k) range = std::max(range, eq_split_q(p.c_data, p.n_splits, k + 1) - eq_split_q(p.c_data, p.n_splits, k));
         const int bytes = (range + 1) * 8;
-        const char *th_env = getenv("T2GPU_EQ_THREADS");                  // 1024: one workgroup of twice the lanes per range (A/B, tests)
-        const int threads = (th_env && atoi(th_env) == 1024) ? 1024 : 512;
+        const int threads = 512;                                          // (1024-lane workgroups, one per CU, measured slower: profiles/HISTORY.md)
         const int it = (range + threads - 1) / threads;
         hipError_t e = hipErrorInvalidValue;
 #define T2_EQS(IT_, TH_) e = launch_eq_split<IT_, TH_>(p, symbols, symbol_index, n_symbols, out, pilot_scratch, bytes, s)
-        if (threads != 1024) {
-            if (it <= 8) T2_EQS(8, 512); else if (it <= 14) T2_EQS(14, 512); else if (it <= 18) T2_EQS(18, 512); else if (it <= 28) T2_EQS(28, 512);
-        } else {
-            if (it <= 4) T2_EQS(4, 1024); else if (it <= 7) T2_EQS(7, 1024); else if (it <= 9) T2_EQS(9, 1024); else if (it <= 11) T2_EQS(11, 1024);
-            else if (it <= 14) T2_EQS(14, 1024);
-        }
+        if (it <= 8) T2_EQS(8, 512); else if (it <= 14) T2_EQS(14, 512); else if (it <= 18) T2_EQS(18, 512); else if (it <= 28) T2_EQS(28, 512);
 #undef T2_EQS
         if (e != hipSuccess) return e;
     } else {
     int lds_bytes = 2 * (p.lds_span + 1) * 4 + p.lds_dspan * 8 + ((p.lds_dspan + 1) & ~1) * 2;
     const int lds_floor = 160 * 1024 / (T2_EQ_WGS_PER_CU + 1) + 1024;                     // at most T2_EQ_WGS_PER_CU workgroups per CU (see the kernel)
     lds_bytes = lds_bytes > lds_floor ? lds_bytes : lds_floor;
-    if (const char *pad = getenv("T2GPU_EQ_LDS_PAD")) lds_bytes += atoi(pad);             // experiments: fewer resident workgroups per CU
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(eq_data_kernel), lds_bytes)) return e;
     const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
     unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                         // linear id, see the kernel

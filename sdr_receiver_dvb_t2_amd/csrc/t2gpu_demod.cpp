@@ -73,12 +73,10 @@ struct t2gpu_demod {
     long out_cap = 0;
     float *h_cells = nullptr;          // pinned: the cells of the symbol just equalised, as the `data` / `l1_dyn_execute` signals carry them
     float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
-    // results by the device's own stores and a sequence word the host reads (symbol_results); T2GPU_DEMOD_SPIN=0: copies + stream wait
-    bool spin = true;
+    // results by the device's own stores and a sequence word the host reads (symbol_results)
     unsigned seq = 0;
     unsigned *h_flag = nullptr, *d_count = nullptr;
-    // the front end writes a symbol's chunk straight into the symbol buffer (T2GPU_DEMOD_DIRECT=0: into d_out, copied from there)
-    bool direct = true;
+    // (the front end writes a symbol's chunk straight into the symbol buffer; P1 searches read the chunk from d_out)
     float *d_bounce = nullptr;
     // A data symbol's `data` signal is emitted once the NEXT chunk's front-end launch is on its way (or at the end of the call): what the
     // consumer does in it (the de-interleaver's push: ~9 us of host time and a launch) then runs beside the front-end kernel instead of
@@ -203,7 +201,7 @@ int init_data(t2gpu_demod *h)
 // device) or nullptr on an error.
 const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
 {
-    if (h->spin) {
+    {
         // one launch stores cells and floats into the page-locked buffers and raises the sequence word behind them; the host reads that
         // word (three copies and the stream's completion signal cost the path some 40 us per symbol)
         const unsigned seq = ++h->seq;
@@ -220,11 +218,6 @@ const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-    } else {
-        if (cp && hipMemcpyAsync(h->h_small, h->d_cp, 16, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-        if (hipMemcpyAsync(h->h_small + 4, h->d_sync, 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-        if (n_cells > 0 && hipMemcpyAsync(h->h_cells, h->d_cells, (size_t)n_cells * 8, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return nullptr;
-        if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;
     }
     if (cp) std::memcpy(cp, h->h_small, 16);
     std::memcpy(sv, h->h_small + 4, 8);
@@ -430,7 +423,6 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_out, (size_t)h->out_cap * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_bounce, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
-    if (const char *e = std::getenv("T2GPU_DEMOD_DIRECT")) h->direct = std::atoi(e) != 0;
     ok = ok && hipMalloc(&h->d_spec, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
@@ -441,7 +433,6 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 64, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) *h->h_flag = 0;
-    if (const char *e = std::getenv("T2GPU_DEMOD_SPIN")) h->spin = std::atoi(e) != 0;
     if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device, false);     // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
@@ -529,7 +520,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         // end, if any, are moved by symbol_acquisition. P1 searches read the chunk from d_out.
         float *dst = h->d_out;
         long cap = h->out_cap;
-        if (h->direct && h->next_symbol_type != SYMBOL_TYPE_P1) {
+        if (h->next_symbol_type != SYMBOL_TYPE_P1) {
             dst = h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym;
             cap = SYM_BUF_CELLS - h->idx_buffer_sym;
         }

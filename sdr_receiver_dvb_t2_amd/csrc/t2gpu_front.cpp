@@ -44,7 +44,7 @@ struct t2gpu_front {
     std::vector<FrontRun> dev_runs;            // what d_runs holds (nco runs, then Farrow runs)
     size_t dev_nn = 0;
     bool dev_runs_valid = false;
-    // short calls in one launch (front_kernels.hip: front_chain_kernel); T2GPU_FRONT_CHAIN=0 at creation keeps the five launches
+    // short calls in one launch (front_kernels.hip: front_chain_kernel); t2gpu_front_set_chain(h, 0) keeps the five launches
     unsigned long long *d_bar = nullptr, chain_count = 0;
     int *d_chain_error = nullptr;      // raised by a grid barrier of the chain that gave up
     bool chain_on = true;
@@ -172,7 +172,6 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         const float rk = 1.0f / k_table;
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
-    if (const char *e = std::getenv("T2GPU_FRONT_CHAIN")) h->chain_on = std::atoi(e) != 0;
     h->chain_cap = front_chain_capacity();
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocCoherent) == hipSuccess) {
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
@@ -263,6 +262,14 @@ extern "C" int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2)
     s.c1 = c1; s.c2 = c2;
     T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
     h->state_published = false;
+    return 0;
+}
+
+// short calls (a symbol's worth of samples) as one launch (default) or as the five launches every longer call takes: same values
+extern "C" int t2gpu_front_set_chain(t2gpu_front *h, int on)
+{
+    if (!h) return -1;
+    h->chain_on = on != 0;
     return 0;
 }
 

@@ -1,5 +1,5 @@
 // t2gpu_ldpc.cpp -- C-ABI of the LDPC stage (include/t2gpu.h). Host side only: builds the graph, owns the device
-// buffers, sizes the persistent grid and launches ldpc_kernel.hip. There is no CPU decode path in this library.
+// buffers, sizes the persistent grid and launches ldpc_kernel2.hip. There is no CPU decode path in this library.
 #include "../../include/t2gpu.h"
 #include "ldpc_graph.h"
 #include "ldpc_kernel.h"
@@ -17,14 +17,11 @@ using namespace t2gpu;
 struct t2gpu_ldpc {
     LdpcGraph g;
     int device = 0, max_frames = 0, group = T2GPU_SIMD_BATCH, max_trials = T2GPU_LDPC_TRIALS;
-    int num_cu = 0, blocks_per_cu = 0, lds_bytes = 0, lds_ctl_offset = 0, lds_rec_offset = 0, lds_sign_offset = 0, lds_ent_offset = 0;
+    int num_cu = 0;
     LdpcLayerDev *d_layers = nullptr;
     uint32_t *d_layer_words = nullptr;   // the same, four packed dwords per layer (ldpc_kernel.h: LdpcKernelParams::layer_words)
-    uint32_t *d_entries = nullptr, *d_entries2 = nullptr;
-    int lds_base = 0;
+    uint32_t *d_entries = nullptr;
     uint32_t *d_cninfo = nullptr;
-    uint2 *d_state = nullptr;
-    size_t state_blocks = 0;
     unsigned *d_sync = nullptr;
     unsigned *d_ticket = nullptr;  // batch tickets of the two-frame kernel (ldpc_kernel.h)
     size_t ticket_words = 0;
@@ -48,8 +45,7 @@ struct t2gpu_ldpc {
     bool a_ready = false;               // stream, event and pinned staging of the asynchronous form all exist
     bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
     bool plain_always = false;          // t2gpu_ldpc_set_plain_launch
-    // two-frames-per-workgroup variant (ldpc_kernel2.hip); used when the group is even, see use_packed()
-    bool packed_ok = false;
+    // the kernel's geometry (ldpc_kernel2.hip: two frames per workgroup)
     int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
         p_rec_dwords = 0;
     uint32_t *d_entries2p = nullptr;
@@ -57,16 +53,9 @@ struct t2gpu_ldpc {
     size_t state2_blocks = 0;
 };
 
-// The packed variant decodes frames 2m, 2m + 1 of a batch in one workgroup: it needs an even group (the reference's SIMD batch is 32).
-// T2GPU_LDPC_PACKED=0 forces the one-frame kernel (A/B measurements).
-static bool use_packed(const t2gpu_ldpc *h)
-{
-    if (!h->packed_ok || (h->group & 1)) return false;
-    if (const char *e = std::getenv("T2GPU_LDPC_PACKED")) if (std::atoi(e) == 0) return false;
-    return h->p_blocks_per_cu * h->num_cu >= h->group / 2;
-}
-
-static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->blocks_per_cu; }
+// workgroups of one SIMD batch: two frames each, the last one a single frame when the group is odd (ldpc_kernel2.hip)
+static int wg_per_batch(const t2gpu_ldpc *h) { return (h->group + 1) / 2; }
+static int resident_blocks(const t2gpu_ldpc *h) { return h->num_cu * h->p_blocks_per_cu; }
 
 // ---- what the plain launches of t2gpu_ldpc_submit may hold of a device at one time. The workgroups of a SIMD batch meet at
 // every sweep, so every workgroup of every decode in flight must be resident: a cooperative launch has the runtime's word for that, a
@@ -121,8 +110,7 @@ void unbook(const t2gpu_ldpc *h)
     for (size_t i = 0; i < b.size();) { if (b[i].h == h) b.erase(b.begin() + (long)i); else ++i; }
 }
 }  // namespace
-// the in-kernel profile is indexed by the workgroup id of whichever kernel runs: room for the larger of the two grids
-static size_t prof_blocks(const t2gpu_ldpc *h) { return std::max(h->state_blocks, h->state2_blocks); }
+static size_t prof_blocks(const t2gpu_ldpc *h) { return h->state2_blocks; }
 
 extern "C" int t2gpu_ldpc_graph_stats(int fec_type, int code_rate, int *links_total, int *layers,
                                       int *levels_total, int *max_cnt)
@@ -160,30 +148,11 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     h->num_cu = prop.multiProcessorCount;
-    h->lds_ctl_offset = (h->g.n + 15) & ~15;
-    h->lds_rec_offset = h->lds_ctl_offset + 64;
-    h->lds_sign_offset = h->lds_rec_offset + 360 * 4;
-    h->lds_bytes = h->lds_sign_offset + (h->g.n / 360) * 13 * 4;
-#if T2_LDPC_PAIRLANE
-    h->lds_ent_offset = (h->lds_bytes + 7) & ~7;                  // the table entries as (base, shift) pairs: the two lanes of a node
-    h->lds_bytes = h->lds_ent_offset + (int)h->g.entries.size() * 8;   // read different entries, so the table cannot come through scalar loads
-#endif
-    if ((e = ldpc_kernel_attributes(h->g.min_cnt, h->g.max_cnt, h->lds_bytes, &h->blocks_per_cu, &h->lds_base)) != hipSuccess) return fail("kernel attributes", e);
-    if (h->blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
-    if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {          // experiments: fewer resident workgroups per CU
-        const int v = std::atoi(lim);
-        if (v >= 1 && v < h->blocks_per_cu) h->blocks_per_cu = v;
-    }
-
     std::vector<LdpcLayerDev> ld(h->g.q);
-    const char *band_env = std::getenv("T2GPU_LDPC_BAND");                     // experiments: 0 keeps the level schedule in GENERIC layers
-    const bool band_on = !(band_env && std::atoi(band_env) == 0);
-    const char *open_env = std::getenv("T2GPU_LDPC_OPEN_LAYERS");           // experiments: 0 closes every layer with a barrier
-    const bool open_on = !(open_env && std::atoi(open_env) == 0);
     for (int i = 0; i < h->g.q; ++i)
         ld[i] = LdpcLayerDev{h->g.layers[i].first_entry, h->g.layers[i].cnt, h->g.layers[i].lmax, h->g.layers[i].n_conflict,
-                             h->g.layers[i].kind, h->g.layers[i].step, band_on ? h->g.layers[i].band : 0,
-                             h->g.layers[i].band_prefetch | (open_on ? h->g.layers[i].no_close << 1 : 0)};
+                             h->g.layers[i].kind, h->g.layers[i].step, h->g.layers[i].band,
+                             h->g.layers[i].band_prefetch | (h->g.layers[i].no_close << 1)};
     if ((e = hipMalloc(&h->d_layers, ld.size() * sizeof(LdpcLayerDev))) != hipSuccess) return fail("hipMalloc", e);
     {   // the two-frame kernel's form of the same table: four dwords per layer, held in registers (one layer per lane) and read with
         // v_readlane -- no memory access and no wait at the head of a layer (ldpc_kernel2.hip)
@@ -209,20 +178,9 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
     if ((e = hipMalloc(&h->d_cninfo, h->g.cninfo.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemcpy(h->d_layers, ld.data(), ld.size() * sizeof(LdpcLayerDev), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
     if ((e = hipMemcpy(h->d_entries, h->g.entries.data(), h->g.entries.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
-    {   // the entries once more, unpacked and with the LDS address of the LLR array folded in (ldpc_cn.h, LayerDesc::ent2)
-        std::vector<uint32_t> e2(2 * h->g.entries.size());
-        for (size_t i = 0; i < h->g.entries.size(); ++i) {
-            e2[2 * i] = (h->g.entries[i] & 0xffffu) + (uint32_t)h->lds_base - (h->g.entries[i] >> 16);   // base - shift: the address is
-            e2[2 * i + 1] = h->g.entries[i] >> 16;                                                       // this + (j >= shift ? j : j + 360)
-        }
-        if ((e = hipMalloc(&h->d_entries2, e2.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
-        if ((e = hipMemcpy(h->d_entries2, e2.data(), e2.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
-    }
     if ((e = hipMemcpy(h->d_cninfo, h->g.cninfo.data(), h->g.cninfo.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
 
-    h->state_blocks = (size_t)resident_blocks(h);
-    if ((e = hipMalloc(&h->d_state, h->state_blocks * h->g.q * 360 * sizeof(uint2))) != hipSuccess) return fail("hipMalloc state", e);
-    {   // the two-frame variant: LDS = interleaved LLRs of both frames | control words | 2 x 360 chain records | sign words of both
+    {   // LDS = interleaved LLRs of both frames | control words | 2 x 360 chain records | sign words of both
         // frames | the table entries as (LDS address of bit 0 of the link's run, shift) pairs
         const int n2 = 2 * h->g.n;
         h->p_lds_ctl_offset = (n2 + 15) & ~15;
@@ -232,13 +190,11 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
         h->p_lds_ent_offset = (h->p_lds_sign_offset + std::max(2 * (h->g.n / 360) * 13 * 4, 2 * 360 * 8) + 7) & ~7;
         h->p_lds_bytes = h->p_lds_ent_offset + (int)h->g.entries.size() * 8;
         h->p_rec_dwords = ldpc_kernel2_record_dwords(h->g.min_cnt, h->g.max_cnt);
-        if (h->p_lds_bytes <= (int)prop.sharedMemPerBlock || h->p_lds_bytes <= 160 * 1024) {
-            hipError_t e2 = ldpc_kernel2_attributes(h->g.min_cnt, h->g.max_cnt, h->p_lds_bytes, &h->p_blocks_per_cu, &h->p_lds_base);
-            if (e2 == hipSuccess && h->p_blocks_per_cu >= 1) {
-                if (const char *lim = std::getenv("T2GPU_LDPC_BLOCKS_PER_CU")) {
-                    const int v = std::atoi(lim);
-                    if (v >= 1 && v < h->p_blocks_per_cu) h->p_blocks_per_cu = v;
-                }
+        if ((e = ldpc_kernel2_attributes(h->g.min_cnt, h->g.max_cnt, h->p_lds_bytes, &h->p_blocks_per_cu, &h->p_lds_base)) != hipSuccess)
+            return fail("kernel attributes", e);
+        if (h->p_blocks_per_cu < 1) { set_error("LDPC kernel does not fit a CU"); t2gpu_ldpc_destroy(h); return nullptr; }
+        {
+            {
                 std::vector<uint32_t> e2p(2 * h->g.entries.size());
                 for (size_t i = 0; i < h->g.entries.size(); ++i) {
                     const uint32_t base = h->g.entries[i] & 0xffffu, shift = h->g.entries[i] >> 16;
@@ -249,9 +205,6 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
                 if ((e = hipMalloc(&h->d_entries2p, e2p.size() * 4)) != hipSuccess) return fail("hipMalloc", e);
                 if ((e = hipMemcpy(h->d_entries2p, e2p.data(), e2p.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
                 if ((e = hipMalloc(&h->d_state2, h->state2_blocks * h->g.q * 720 * h->p_rec_dwords * 4)) != hipSuccess) return fail("hipMalloc state", e);
-                h->packed_ok = true;
-            } else {
-                (void)hipGetLastError();
             }
         }
     }
@@ -266,7 +219,7 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
-    hipFree(h->d_layers); hipFree(h->d_layer_words); hipFree(h->d_entries); hipFree(h->d_entries2); hipFree(h->d_cninfo); hipFree(h->d_state);
+    hipFree(h->d_layers); hipFree(h->d_layer_words); hipFree(h->d_entries); hipFree(h->d_cninfo);
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
     if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
@@ -281,7 +234,7 @@ extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 extern "C" int t2gpu_ldpc_configure(t2gpu_ldpc *h, int group, int max_trials)
 {
     if (!h || group < 1 || max_trials < 0 || max_trials > 63) { set_error("t2gpu_ldpc_configure: bad arguments"); return -1; }
-    if (group > 1 && resident_blocks(h) < group) { set_error("device cannot keep one batch resident"); return -1; }
+    if (resident_blocks(h) < (group + 1) / 2) { set_error("device cannot keep one batch resident"); return -1; }
     h->group = group; h->max_trials = max_trials;
     return 0;
 }
@@ -301,13 +254,12 @@ extern "C" int t2gpu_ldpc_info(const t2gpu_ldpc *h, int *fec_size, int *k_ldpc, 
 extern "C" int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6)
 {
     if (!h || !out6) { set_error("t2gpu_ldpc_occupancy: bad arguments"); return -1; }
-    const bool packed = use_packed(h);
-    out6[0] = packed ? h->p_blocks_per_cu : h->blocks_per_cu;
-    out6[1] = T2GPU_LDPC_THREADS / 64;                                                   // 768 lanes: two per check node of a layer (ldpc_cn2.h / ldpc_cn3.h)
-    out6[2] = packed ? h->p_lds_bytes : h->lds_bytes;
-    out6[3] = packed ? 2 : 1;
+    out6[0] = h->p_blocks_per_cu;
+    out6[1] = T2GPU_LDPC_THREADS / 64;                                                   // 768 lanes: two per check node of a layer (ldpc_cn3.h)
+    out6[2] = h->p_lds_bytes;
+    out6[3] = 2;
     out6[4] = h->num_cu;
-    out6[5] = (h->num_cu * out6[0]) / (packed ? std::max(h->group / 2, 1) : h->group);
+    out6[5] = resident_blocks(h) / wg_per_batch(h);
     return 0;
 }
 
@@ -316,14 +268,12 @@ extern "C" int t2gpu_ldpc_launch_workgroups(const t2gpu_ldpc *h, int n_frames)
 {
     if (!h || n_frames < 1) { set_error("t2gpu_ldpc_launch_workgroups: bad arguments"); return -1; }
     const int nbatches = (n_frames + h->group - 1) / h->group;
-    const bool packed = use_packed(h);
-    const int wg_per_batch = packed ? h->group / 2 : h->group;
-    const int maxslots = (packed ? h->num_cu * h->p_blocks_per_cu : resident_blocks(h)) / wg_per_batch;
+    const int maxslots = resident_blocks(h) / wg_per_batch(h);
     if (maxslots < 1) return -1;
-    return (nbatches < maxslots ? nbatches : maxslots) * wg_per_batch;
+    return (nbatches < maxslots ? nbatches : maxslots) * wg_per_batch(h);
 }
 
-// plain != 0: the packed kernel's decodes of this handle are ordinary launches, not cooperative ones. Cooperative launches of different
+// plain != 0: the decodes of this handle are ordinary launches, not cooperative ones. Cooperative launches of different
 // streams run one after the other; plain ones run side by side -- the caller then sees to it that what is in flight together fits the
 // device (t2gpu_ldpc_launch_workgroups; the frames of a batch meet at every sweep, so their workgroups must all be resident).
 extern "C" int t2gpu_ldpc_set_plain_launch(t2gpu_ldpc *h, int plain)
@@ -344,9 +294,8 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     hipStream_t s = (hipStream_t)stream;
     const int group = h->group;
     const int nbatches = (n_frames + group - 1) / group;
-    const bool packed = use_packed(h);
-    const int wg_per_batch = packed ? group / 2 : group;                      // two frames per workgroup in the packed variant
-    int maxslots = (packed ? h->num_cu * h->p_blocks_per_cu : resident_blocks(h)) / wg_per_batch;
+    const int wg_per_batch = ::wg_per_batch(h);                               // two frames per workgroup
+    int maxslots = resident_blocks(h) / wg_per_batch;
     if (maxslots < 1) { set_error("device cannot keep one batch resident"); return -1; }
     if (const char *lim = std::getenv("T2GPU_LDPC_MAX_SLOTS")) {              // experiments: leave part of the device to other streams
         const int v = std::atoi(lim);
@@ -360,60 +309,37 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
-    p.layers = h->d_layers; p.layer_words = reinterpret_cast<const uint4 *>(h->d_layer_words); p.entries = h->d_entries; p.entries2 = packed ? h->d_entries2p : h->d_entries2;
-    p.lds_base = packed ? h->p_lds_base : h->lds_base; p.cninfo = h->d_cninfo;
+    p.layers = h->d_layers; p.layer_words = reinterpret_cast<const uint4 *>(h->d_layer_words); p.entries = h->d_entries; p.entries2 = h->d_entries2p;
+    p.lds_base = h->p_lds_base; p.cninfo = h->d_cninfo;
     p.llr = d_llr; p.n_frames = n_frames; p.group = group; p.max_trials = h->max_trials;
     p.bits = d_bits; p.llr_out = d_llr_out; p.trials_left = d_trials_left;
-    p.state = packed ? reinterpret_cast<uint2 *>(h->d_state2) : h->d_state; p.sync = h->d_sync; p.error = h->d_error;
+    p.state = reinterpret_cast<uint2 *>(h->d_state2); p.sync = h->d_sync; p.error = h->d_error;
     p.spin_timeout_ticks = 200000000LL;   // 2 s at 100 MHz
     p.ticket = nullptr; p.ticket_rounds = 0;
-    p.lds_ctl_offset = packed ? h->p_lds_ctl_offset : h->lds_ctl_offset;
-    p.lds_rec_offset = packed ? h->p_lds_rec_offset : h->lds_rec_offset;
-    p.lds_sign_offset = packed ? h->p_lds_sign_offset : h->lds_sign_offset;
-    p.lds_ent_offset = packed ? h->p_lds_ent_offset : h->lds_ent_offset;
+    p.lds_ctl_offset = h->p_lds_ctl_offset;
+    p.lds_rec_offset = h->p_lds_rec_offset;
+    p.lds_sign_offset = h->p_lds_sign_offset;
+    p.lds_ent_offset = h->p_lds_ent_offset;
     p.n_entries = (int)h->g.entries.size();
     p.prof = h->d_prof;
     p.prof_blocks = (int)prof_blocks(h);
     p.resident = h->d_resident;
     if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, (prof_blocks(h) * 8 + 64) * sizeof(long long), s));
-    // One persistent launch walks all batches (best when batches take different numbers of sweeps). T2GPU_LDPC_ROUNDS_PER_LAUNCH=r
-    // cuts it into launches of r rounds of `nslots` batches: workgroups of other streams that need a whole CU's LDS (the 32K FFT)
-    // then get in at the launch boundaries instead of waiting for the whole decode.
-    int rounds = 0;
-    if (const char *r = std::getenv("T2GPU_LDPC_ROUNDS_PER_LAUNCH")) rounds = std::atoi(r);
-    if (rounds < 1 || (long)rounds * nslots >= nbatches) {
-        const char *tk = std::getenv("T2GPU_LDPC_TICKET");                    // experiments: 0 = static striding of the batches
-        if (packed && nbatches > nslots && !(tk && std::atoi(tk) == 0)) {
-            const size_t words = 1 + (size_t)nslots * nbatches;
-            if (words > h->ticket_words) {
-                T2_HIP(hipStreamSynchronize(s));
-                hipFree(h->d_ticket); h->d_ticket = nullptr; h->ticket_words = 0;
-                T2_HIP(hipMalloc(&h->d_ticket, words * 4));
-                h->ticket_words = words;
-            }
-            T2_HIP(hipMemsetAsync(h->d_ticket, 0, words * 4, s));
-            p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
+    // One persistent launch walks all batches; with more batches than resident slots they are handed out by ticket, so that slots whose
+    // batches stop early take more of them (best when batches take different numbers of sweeps).
+    if (nbatches > nslots) {
+        const size_t words = 1 + (size_t)nslots * nbatches;
+        if (words > h->ticket_words) {
+            T2_HIP(hipStreamSynchronize(s));
+            hipFree(h->d_ticket); h->d_ticket = nullptr; h->ticket_words = 0;
+            T2_HIP(hipMalloc(&h->d_ticket, words * 4));
+            h->ticket_words = words;
         }
-        h->resident_total += (unsigned)grid;
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
-        else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->lds_bytes, s));
-        return 0;
+        T2_HIP(hipMemsetAsync(h->d_ticket, 0, words * 4, s));
+        p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
     }
-    for (int b0 = 0; b0 < nbatches; b0 += rounds * nslots) {
-        const int nb = std::min(rounds * nslots, nbatches - b0);
-        const int f0 = b0 * group, nf = std::min(nb * group, n_frames - f0);
-        LdpcKernelParams q = p;
-        q.llr = d_llr + (size_t)f0 * h->g.n;
-        q.n_frames = nf;
-        q.bits = d_bits ? d_bits + (size_t)f0 * h->g.k : nullptr;
-        q.llr_out = d_llr_out ? d_llr_out + (size_t)f0 * h->g.n : nullptr;
-        q.trials_left = d_trials_left + b0;
-        q.sync = h->d_sync + (size_t)b0 * (h->max_trials + 1);
-        const int slots = std::min(nslots, nb);
-        h->resident_total += (unsigned)(slots * wg_per_batch);
-        if (packed) T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, q, slots * wg_per_batch, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
-        else T2_HIP(ldpc_kernel_launch(h->g.min_cnt, h->g.max_cnt, q, slots * group, h->lds_bytes, s));
-    }
+    h->resident_total += (unsigned)grid;
+    T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
     return 0;
 }
 
@@ -547,7 +473,7 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     // call waits while the decodes in flight leave no room for its grid, and a grid the device could never hold as a whole goes through
     // the cooperative launch, which refuses rather than hangs
     const int wgs = t2gpu_ldpc_launch_workgroups(h, n_frames);
-    const int per_cu = use_packed(h) ? h->p_blocks_per_cu : h->blocks_per_cu;
+    const int per_cu = h->p_blocks_per_cu;
     if (wgs < 1 || per_cu < 1) { set_error("t2gpu_ldpc_submit: the device cannot keep one batch resident"); return -1; }
     h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu);
     const int rc = t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s);

@@ -398,7 +398,6 @@ extern "C" int t2gpu_eq_data_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, 
     EqParams p = h->eq;
     p.per_frame = n_data_symbols; p.first = first_symbol; p.in_syms_per_frame = syms_per_frame;
     p.out_frame_stride = cells_frame_stride; p.out_offset = cells_offset;
-    if (const char *e = std::getenv("T2GPU_EQ_ROW_MAJOR")) p.row_major = std::atoi(e) != 0;   // A/B measurements: 0 = symbol order
     T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_spectrum), nullptr, (int)n, reinterpret_cast<float2 *>(d_cells),
                           h->d_pilot_scratch, reinterpret_cast<float2 *>(d_sync), (hipStream_t)stream));
     return h->m.c_data;

@@ -211,7 +211,7 @@ def test_statistics_are_the_references_sequential_float_sums(torch_cuda, mod, fe
     """sum_s / sum_e of whole TI blocks (up to 202 FEC blocks = 1.6 M cells: the sum passes through ~25 binades) against the oracle's
     sequential float loop (= the reference's, llr_demapper.cpp:564-676): bit for bit, for several TI blocks per launch with different
     signal levels (t2gpu_demap_stats_batch_dev), through t2gpu_ti_execute_blocks_stats_dev (de-interleaver + statistics in one call)
-    and for QPSK's 2048-cell window. T2GPU_DEMAP_TREE_STATS=1 (the round 1-2 tree sums) is NOT bit-equal on the large blocks."""
+    and for QPSK's 2048-cell window."""
     torch = torch_cuda
     import sdr_receiver_dvb_t2_amd as pkg
     frames = 3

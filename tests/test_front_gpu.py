@@ -146,14 +146,13 @@ def test_front_end_matches_oracle(torch_cuda, id_device, case):
 
 def test_short_calls_in_one_launch_equal_the_five_launches(torch_cuda, monkeypatch):
     """A call of up to a few OFDM symbols' worth of samples runs as ONE launch (front_chain_kernel: the same bodies phase after phase
-    with a barrier across its small grid, run tables in the kernel arguments); T2GPU_FRONT_CHAIN=0 at creation keeps the five
+    with a barrier across its small grid, run tables in the kernel arguments); t2gpu_front_set_chain(h, 0) keeps the five
     launches. Same cells, same carried state, bit for bit -- over calls of one symbol, of a few samples (what the slot-shaped path
     hands over when the chunk estimate was a sample short), and of a length that does not qualify."""
     from sdr_receiver_dvb_t2_amd import front
     n_max = 1 << 19
-    monkeypatch.setenv("T2GPU_FRONT_CHAIN", "0")
     five = front.front_end(max_samples=n_max)
-    monkeypatch.setenv("T2GPU_FRONT_CHAIN", "1")
+    assert five._l.t2gpu_front_set_chain(five.h, 0) == 0
     one = front.front_end(max_samples=n_max)
     rng = np.random.Generator(np.random.PCG64(77))
     for call, n in enumerate([70001, 3, 66050, 1, 2047, 4096, 4097, 90000, 300000, 5, 33024]):

@@ -59,13 +59,7 @@ def test_simd_batches_match_oracle(torch_cuda, cid, sigma):
 
 VARIANTS = {
     "default": {},
-    "one-frame kernel": {"T2GPU_LDPC_PACKED": "0"},                       # the fallback of odd groups / a failed LDS attribute
-    "one-frame kernel, one slot": {"T2GPU_LDPC_PACKED": "0", "T2GPU_LDPC_MAX_SLOTS": "1"},
     "tickets (batches > slots)": {"T2GPU_LDPC_MAX_SLOTS": "1"},
-    "static striding": {"T2GPU_LDPC_MAX_SLOTS": "1", "T2GPU_LDPC_TICKET": "0"},
-    "every layer closed": {"T2GPU_LDPC_OPEN_LAYERS": "0"},
-    "level schedule in GENERIC layers": {"T2GPU_LDPC_BAND": "0"},
-    "one round per launch": {"T2GPU_LDPC_MAX_SLOTS": "1", "T2GPU_LDPC_ROUNDS_PER_LAUNCH": "1"},
     "plain launch": {"T2GPU_LDPC_COOPERATIVE": "0"},
 }
 
@@ -73,8 +67,8 @@ VARIANTS = {
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("cid,sigma", [(9, 0.61), (0, 0.92)])
 def test_every_kernel_path_is_llr_exact(torch_cuda, cid, sigma, variant, monkeypatch):
-    """The experiment switches select real code paths (the one-frame kernel is the fallback whenever the packed one cannot run): each
-    of them against the oracle on three batches -- two whole, one of 9 frames (an odd count: the packed kernel's last workgroup holds a
+    """The two switches left select real code paths (batches handed out by ticket when there are more of them than resident slots; the
+    plain launch t2gpu_ldpc_submit uses): each of them against the oracle on three batches -- two whole, one of 9 frames (an odd count: the packed kernel's last workgroup holds a
     single frame) -- with one undecodable frame in batch 1. Per-batch trials-left, every final LLR, every hard bit."""
     for k, v in VARIANTS[variant].items():
         monkeypatch.setenv(k, v)

@@ -89,18 +89,14 @@ def test_fft_batch_properties_full_size(torch_cuda):
     ctx.close()
 
 
-@pytest.fixture(params=["default", "0", "3", "5", "2@1024", "4@1024"])
+@pytest.fixture(params=["default", "0", "3", "5"])
 def eq_form(request, monkeypatch):
     """Equaliser kernel form, read when the context is created: default = output ranges in LDS (eq_split_kernel, fewest ranges that
     fit), "3" / "5" = that kernel with three / five ranges per symbol, "0" = segment groups with scattered stores (eq_data_kernel)."""
-    monkeypatch.delenv("T2GPU_EQ_THREADS", raising=False)
     if request.param == "default":
         monkeypatch.delenv("T2GPU_EQ_SPLITS", raising=False)
     else:
-        splits, _, lanes = request.param.partition("@")          # "n@1024": n ranges, workgroups of 1024 lanes
-        monkeypatch.setenv("T2GPU_EQ_SPLITS", splits)
-        if lanes:
-            monkeypatch.setenv("T2GPU_EQ_THREADS", lanes)
+        monkeypatch.setenv("T2GPU_EQ_SPLITS", request.param)
     return request.param
 
 
