@@ -196,46 +196,30 @@ __device__ __forceinline__ void front_derotate_body(const FrontParams &p, const 
     const float c1 = p.state->c1, c2 = p.state->c2;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     int r = valid ? find_run(p.nco_runs, p.n_nco_runs, s0) : 0;
-    // two passes over the lane's samples: first everything up to the table index, then the FRONT_PER x 2 table reads together and the
-    // rotation. In one pass every sample waited for its own two reads (0.7 us each out of L2: 11 of the 38 us a symbol-sized call
-    // took); the operations and their order per sample are the same.
-    float re_c[FRONT_PER], im_c[FRONT_PER];
-    int li[FRONT_PER];
-    FrontRun run = p.nco_runs[r];
-    long next_i0 = r + 1 < p.n_nco_runs ? (long)p.nco_runs[r + 1].i0 : 0x7fffffffffffffffL;
-#pragma unroll
-    for (int k = 0; k < FRONT_PER; ++k) {
-        re_c[k] = 0.0f; im_c[k] = 0.0f; li[k] = 0;
-        if (k < valid) {
-            const long i = s0 + k;
-            dre = dre + DC_ALPHA * ((double)xr[k] - dre);                       // exponential_averager, loop_filters.hh:63-67
-            dim = dim + DC_ALPHA * ((double)xi[k] - dim);
-            float real = sub_r(xr[k], (float)dre), imag = sub_r(xi[k], (float)dim);
-            float sgn = real < 0 ? -1.0f : 1.0f;                                // est_1_bit_quantization, :256-265
-            t1 -= (double)mul_r(imag, sgn);
-            t2 += (double)mul_r(real, sgn);
-            sgn = imag < 0 ? -1.0f : 1.0f;
-            t3 += (double)mul_r(imag, sgn);
-            real = mul_r(real, c2);                                             // :184-185
-            imag = add_r(imag, mul_r(c1, real));
-            if (i >= next_i0) {                                                 // the run record stays in registers until the sample index leaves it
-                while (r + 1 < p.n_nco_runs && p.nco_runs[r + 1].i0 <= i) ++r;
-                run = p.nco_runs[r];
-                next_i0 = r + 1 < p.n_nco_runs ? (long)p.nco_runs[r + 1].i0 : 0x7fffffffffffffffL;
-            }
-            const float fnco = (float)(run.base + (double)(i - run.i0) * run.step); // frequency_nco for this sample (exact)
-            const float off = wrap_2pi(sub_r(fnco, run.aux));                   // :194-200
-            li[k] = (int)(off * K_TABLE + 32767) & 65535;                       // fast_math.h:47-58
-            re_c[k] = real; im_c[k] = imag;
-        }
+    // (one pass per sample. Round 4 split it in two -- everything up to the table index, then the 2 x FRONT_PER table reads together --
+    // for the one-launch chain of the slot-shaped path, where it bought nothing: an in-kernel clock showed the phase's time is the
+    // 16-step chain of double-precision operations per lane, not the reads; on 48-frame calls the arrays it kept in registers cost
+    // 357 -> 421 us. Back to the round-3 loop.)
+    for (int k = 0; k < valid; ++k) {
+        const long i = s0 + k;
+        dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
+        dim = dim + DC_ALPHA * ((double)xi[k] - dim);
+        float real = sub_r(xr[k], (float)dre), imag = sub_r(xi[k], (float)dim);
+        float sgn = real < 0 ? -1.0f : 1.0f;                                    // est_1_bit_quantization, :256-265
+        t1 -= (double)mul_r(imag, sgn);
+        t2 += (double)mul_r(real, sgn);
+        sgn = imag < 0 ? -1.0f : 1.0f;
+        t3 += (double)mul_r(imag, sgn);
+        real = mul_r(real, c2);                                                 // :184-185
+        imag = add_r(imag, mul_r(c1, real));
+        while (r + 1 < p.n_nco_runs && p.nco_runs[r + 1].i0 <= i) ++r;
+        const FrontRun run = p.nco_runs[r];
+        const float fnco = (float)(run.base + (double)(i - run.i0) * run.step); // frequency_nco for this sample (exact)
+        const float off = wrap_2pi(sub_r(fnco, run.aux));                       // :194-200
+        const int li = (int)(off * K_TABLE + 32767) & 65535;                    // fast_math.h:47-58
+        const float nr = p.lut_cos[li], ni = p.lut_sin[li];
+        sh_out[tid * (FRONT_PER + 1) + k] = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
     }
-    float nr[FRONT_PER], ni[FRONT_PER];
-#pragma unroll
-    for (int k = 0; k < FRONT_PER; ++k) { nr[k] = p.lut_cos[li[k]]; ni[k] = p.lut_sin[li[k]]; }
-#pragma unroll
-    for (int k = 0; k < FRONT_PER; ++k)
-        if (k < valid)
-            sh_out[tid * (FRONT_PER + 1) + k] = make_float2(sub_r(mul_r(re_c[k], nr[k]), mul_r(im_c[k], ni[k])), add_r(mul_r(im_c[k], nr[k]), mul_r(re_c[k], ni[k])));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { t1 += __shfl_down(t1, d, 64); t2 += __shfl_down(t2, d, 64); t3 += __shfl_down(t3, d, 64); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = t1; red[1][tid >> 6] = t2; red[2][tid >> 6] = t3; }
