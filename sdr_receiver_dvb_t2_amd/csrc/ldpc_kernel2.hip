@@ -651,6 +651,34 @@ hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int 
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads2, lds_bytes);
 }
 
+// The results of a decode into page-locked host memory by the device's own stores, in the decode's stream (t2gpu_ldpc_submit). A copy
+// engine would do the same -- but the runtime's copy queue is ONE in-order queue for all streams: a decode's copy-out waits in it for
+// its kernel, and the copy-in of the next handle's decode waits behind that copy-out, so decodes submitted on eight streams ran one
+// after the other (measured: 8 x 2.3 ms = 14 ms for what takes 4.6 ms side by side; profiles/HISTORY.md, round 5).
+__global__ __launch_bounds__(256) void ldpc_results_to_host_kernel(const uint4 *__restrict__ bits, size_t n16, const uint8_t *__restrict__ bits_tail, int n_tail,
+                                                                  const int *__restrict__ trials, int n_trials, const int *__restrict__ error,
+                                                                  uint4 *h_bits, uint8_t *h_bits_tail, int *h_trials, int *h_error)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) h_bits[i] = bits[i];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n_tail; i += blockDim.x) h_bits_tail[i] = bits_tail[i];
+        for (int i = threadIdx.x; i < n_trials; i += blockDim.x) h_trials[i] = trials[i];
+        if (threadIdx.x == 0) *h_error = *error;
+    }
+}
+
+hipError_t ldpc_results_to_host(const uint8_t *d_bits, size_t bytes, const int *d_trials, int n_trials, const int *d_error, uint8_t *h_bits, int *h_trials,
+                                int *h_error, hipStream_t stream)
+{
+    const size_t n16 = bytes / 16;
+    int grid = (int)((n16 + 255) / 256);
+    grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
+    hipLaunchKernelGGL(ldpc_results_to_host_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(d_bits), n16, d_bits + 16 * n16,
+                       (int)(bytes - 16 * n16), d_trials, n_trials, d_error, reinterpret_cast<uint4 *>(h_bits), h_bits + 16 * n16, h_trials, h_error);
+    return hipGetLastError();
+}
+
 hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream, bool allow_cooperative)
 {
     ldpc2_kernel_fn fn = pick_kernel2(min_cnt, max_cnt);

@@ -454,6 +454,7 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     if (!h->d_trials) T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
     const int nbatches = (n_frames + h->group - 1) / h->group;
     hipStream_t s = h->a_stream;
+    const int8_t *d_llr = h->d_in;
     twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
     if (const void *twin = twin_lookup(in, (size_t)len_in, h->device)) {
         // a SIMD batch assembled from the demapper's output (t2gpu_twin_copy) is on the device already: its twin is written on the
@@ -467,7 +468,7 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
         T2_HIP(hipStreamWaitEvent(s, h->a_fence, 0));
     } else {
         std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns
-        T2_HIP(hipMemcpyAsync(h->d_in, h->p_in, (size_t)len_in, hipMemcpyHostToDevice, s));
+        d_llr = h->p_in;                                            // the decoder reads every LLR once: straight from the page-locked copy
     }
     // several submits run side by side (cooperative launches would not). What they hold of the device together is booked (above): this
     // call waits while the decodes in flight leave no room for its grid, and a grid the device could never hold as a whole goes through
@@ -476,12 +477,12 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     const int per_cu = h->p_blocks_per_cu;
     if (wgs < 1 || per_cu < 1) { set_error("t2gpu_ldpc_submit: the device cannot keep one batch resident"); return -1; }
     h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu);
-    const int rc = t2gpu_ldpc_execute_dev(h, h->d_in, n_frames, h->d_out, nullptr, h->d_trials, s);
+    const int rc = t2gpu_ldpc_execute_dev(h, d_llr, n_frames, h->d_out, nullptr, h->d_trials, s);
     h->plain_launch = false;
     if (rc) { unbook(h); return -1; }
-    T2_HIP(hipMemcpyAsync(h->p_out, h->d_out, (size_t)n_frames * h->g.k, hipMemcpyDeviceToHost, s));
-    T2_HIP(hipMemcpyAsync(h->p_trials, h->d_trials, (size_t)nbatches * sizeof(int), hipMemcpyDeviceToHost, s));
-    T2_HIP(hipMemcpyAsync(h->p_trials + h->max_frames, h->d_error, sizeof(int), hipMemcpyDeviceToHost, s));
+    // results to the page-locked staging by a kernel of this stream, not by the copy engine (ldpc_kernel2.hip: one in-order copy queue
+    // for all streams made the decodes of different handles wait for each other)
+    T2_HIP(ldpc_results_to_host(h->d_out, (size_t)n_frames * h->g.k, h->d_trials, nbatches, h->d_error, h->p_out, h->p_trials, h->p_trials + h->max_frames, s));
     T2_HIP(hipEventRecord(h->a_done, s));
     arm_booking(h);
     h->a_frames = n_frames;

@@ -50,7 +50,19 @@ for a, b in zip(p1[-4:-1], p1[-3:]):
     break
 
 # ---- one data symbol in the middle of the last whole frame: everything between two FFT launches
-fft = [r for r in k if "fft_fwd" in r[0]]
+fft = [r for r in k if "fft_fwd" in r[0] or "fft_stage_a" in r[0]]
+if len(fft) > 200:
+    # how the symbol-to-symbol interval is distributed over the last frames (the one symbol printed below is a quiet one: intervals stretch
+    # while SIMD batches of the frame before are being decoded on the same device)
+    iv = sorted((b[1] - a[1]) / 1e3 for a, b in zip(fft[-181:-1], fft[-180:]))
+    print("symbol-to-symbol interval over the last 180 symbols: min %.1f  p25 %.1f  median %.1f  p75 %.1f  p90 %.1f  max %.1f us, mean %.1f" % (
+        iv[0], iv[len(iv) // 4], iv[len(iv) // 2], iv[3 * len(iv) // 4], iv[9 * len(iv) // 10], iv[-1], sum(iv) / len(iv)))
+    ld = [r for r in k if "ldpc_decode" in r[0]]
+    if ld:
+        lo, hi = fft[-181][1], fft[-1][1]
+        inside = [r for r in ld if r[2] > lo and r[1] < hi]
+        print("LDPC launches overlapping that span: %d, %.2f ms each on average, their sum %.1f %% of the span" % (
+            len(inside), sum(r[2] - r[1] for r in inside) / max(len(inside), 1) / 1e6, 100.0 * sum(min(r[2], hi) - max(r[1], lo) for r in inside) / (hi - lo)))
 if len(fft) > 40:
     a, b = fft[-30], fft[-29]
     print("one symbol: %.1f us between FFT launches" % ((b[1] - a[1]) / 1e3))

@@ -9,13 +9,15 @@ l.t2gpu_ldpc_collect.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(c
 l.t2gpu_ldpc_create.restype = ctypes.c_void_p
 hs = [l.t2gpu_ldpc_create(1, 3, 32, 0) for _ in range(8)]
 llr = np.random.default_rng(1).integers(-20, 21, size=(32, 64800), dtype=np.int8)
-for rnd in range(3):
+import os
+for cnt in (1, 2, 4, 8):
+  for rnd in range(2):
     ts = []
     t00 = time.perf_counter()
-    for h in hs:
+    for h in hs[:cnt]:
         t0 = time.perf_counter(); rc = l.t2gpu_ldpc_submit(h, llr.ctypes.data, llr.size); ts.append((time.perf_counter() - t0) * 1e6)
         assert rc == 0, l.t2gpu_last_error()
     o = ctypes.c_void_p(); tr = ctypes.c_void_p(); n = ctypes.c_int()
-    for h in hs:
+    for h in hs[:cnt]:
         assert l.t2gpu_ldpc_collect(h, 1, ctypes.byref(o), ctypes.byref(tr), ctypes.byref(n)) == 0
-    print("round", rnd, "submit us:", [round(x) for x in ts], "total ms %.2f" % ((time.perf_counter() - t00) * 1e3))
+    print("handles", cnt, "round", rnd, "submit us:", [round(x) for x in ts], "total ms %.2f" % ((time.perf_counter() - t00) * 1e3))
