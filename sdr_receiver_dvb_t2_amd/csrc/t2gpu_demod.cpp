@@ -82,6 +82,11 @@ struct t2gpu_demod {
     // consumer does in it (the de-interleaver's push: ~9 us of host time and a launch) then runs beside the front-end kernel instead of
     // in front of it. The cells stay where they are until the next equaliser launch, which comes later still.
     int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
+    // The IQ / level estimates of a buffer (c1, c2, level_detect: once per execute(), :227-235) are committed by a launch at the end of the
+    // call; nothing before the NEXT call reads them unless the caller asked for the gain decision (signal->gain_changed). So the call
+    // does not wait for that launch (59 us with the device idle, 14 times per 32K frame): the next call picks the state up first thing.
+    bool state_pending = false;        // a commit is on its way whose state has not been read back yet
+    bool saw_results = false;          // this call has read a symbol's results: everything enqueued before them -- the I/Q copies -- is through
 };
 
 namespace {
@@ -218,10 +223,22 @@ const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        h->saw_results = true;
     }
     if (cp) std::memcpy(cp, h->h_small, 16);
     std::memcpy(sv, h->h_small + 4, 8);
     return h->h_cells;
+}
+
+// the state the last commit left (level_detect for the P1 detector and the gain decision)
+int finish_state(t2gpu_demod *h)
+{
+    if (!h->state_pending) return 0;
+    float st[8];
+    if (t2gpu_front_state(h->front, st) != 0) return -1;
+    h->level_detect = st[6];
+    h->state_pending = false;
+    return 0;
 }
 
 void flush_data_signal(t2gpu_demod *h)
@@ -486,6 +503,8 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     if (!h || len_in < 0 || !i_in || !q_in || !signal_) { set_error("t2gpu_demod_execute: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     if (len_in == 0) return 0;
+    if (finish_state(h) != 0) return -1;                                            // the previous call's commit (long through by now)
+    h->saw_results = false;
     const size_t el = (size_t)len_in * h->stride;
     if (el > h->in_cap) {
         T2_HIP(hipDeviceSynchronize());
@@ -536,11 +555,14 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;
-    float st[8];
-    if (t2gpu_front_state(h->front, st) != 0) return -1;
+    h->state_pending = true;
+    // wait for the commit only when something of this call still needs it: the gain decision below, or the caller's I/Q buffers (their
+    // copies are in stream order ahead of every symbol's kernels: a call that has read a symbol's results knows they are through)
+    if (signal_->gain_changed || !h->saw_results) {
+        if (finish_state(h) != 0) return -1;
+    }
     h->prof.stop(PF_TAIL);
-    drain.armed = false;                                                            // t2gpu_front_state saw the end of the stream
-    h->level_detect = st[6];
+    drain.armed = false;                                                            // the I/Q copies are through either way
     if (signal_->gain_changed) {
         if (h->level_detect < h->level_min) { signal_->gain_offset = 1; signal_->change_gain = 1; }
         else if (h->level_detect > h->level_max) { signal_->gain_offset = -1; signal_->change_gain = 1; }
@@ -552,6 +574,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
 extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
 {
     if (!h || !out) { set_error("t2gpu_demod_status: bad arguments"); return -1; }
+    if (finish_state(const_cast<t2gpu_demod *>(h)) != 0) return -1;                // level_detect of the last call's commit
     double g[4];
     t2gpu_sync_get(h->sync, g);
     out->next_symbol_type = h->next_symbol_type;
