@@ -352,6 +352,17 @@ int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols
  * (src/DVB_T2/fc_symbol.h:31, fc_symbol.cpp:82-271) for the frame-closing symbols of n_symbols frames: [n][fft_size] in,
  * [n][n_fc] cells out (returned count). Fails when the mode has no frame-closing symbol (l_fc = 0). */
 int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols, float *d_cells, float *d_sync, void *stream);
+/* phase_offset / sample_rate_offset of ONE symbol -- the two by-reference outputs of data_symbol::execute (src/DVB_T2/data_symbol.cpp:108-109,
+ * 319-324), p2_symbol::execute (p2_symbol.cpp:89-262) and fc_symbol::execute (fc_symbol.cpp:82-271) -- from the symbol's pilots alone,
+ * without the equaliser's cell work (the reference's loop hands them to the tracking filters before the next chunk,
+ * dvbt2_demodulator.cpp:429-439), together with the guard-interval correlation of the symbol as buffered (dvbt2_demodulator.cpp:321-327).
+ * The same floats, bit for bit, as t2gpu_eq_*_execute_dev's d_sync and t2gpu_cp_correlate_dev's d_out4.
+ * kind: 0 data symbol idx_symbol, 1 P2, 2 frame closing. d_spectrum: fft_size cells (what the FFT wrote). d_buffered (may be null):
+ * guard + fft_size cells, guard first. d_cp4 (4 floats) / d_sync (2 floats): device, may be null. h_small (8 floats) / h_flag:
+ * page-locked host memory of the caller, may be null -- the kernel itself stores {sum.re, sum.im, frequency_est, 0} at h_small[0..3]
+ * (only with d_buffered) and {phase_offset, sample_rate_offset} at h_small[4..5], then seq at *h_flag (system scope, behind them). */
+int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_spectrum, const float *d_buffered, int guard,
+                       float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream);
 /* The same two for whole frames, in place like t2gpu_eq_data_frames_dev: the P2 (frame-closing) symbol of frame f is read at
  * d_spectrum + 2 * f * syms_per_frame * fft_size floats (+ the symbol's position in the frame); P2: the cells behind the first
  * skip_cells (the L1 cells, time_deinterleaver.cpp:296-300) go to d_cells + 2 * f * cells_frame_stride floats; frame closing: the

@@ -15,6 +15,7 @@
 // *_r helpers), so given the same de-rotated samples the Farrow and decimator outputs are bit-identical to the oracle.
 #include "front_kernels.h"
 #include "tables/dsp_tables_data.h"
+#include "cp_device.h"
 
 #pragma clang fp contract(off)
 
@@ -598,44 +599,14 @@ __global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, un
 }
 
 
-__device__ __forceinline__ float atan2_approx_dev(float y, float x)              // DSP/fast_math.h:61-81
-{
-    const float PI_2 = 1.57079637050628662109f;
-    if (x == 0.0f) return y > 0.0f ? PI_2 : -PI_2;
-    if (y == 0.0f) return x > 0.0f ? 0.0f : -PI_F;
-    const float abs_x = fabsf(x), abs_y = fabsf(y);
-    const bool min_x = abs_x < abs_y;
-    const float a = min_x ? abs_x / abs_y : abs_y / abs_x;
-    const float s = a * a;
-    float r = ((-4.6496475e-2f * s + 1.5931422e-1f) * s - 3.2762276e-1f) * s * a + a;
-    if (min_x) r = PI_2 - r;
-    if (x < 0.0f) r = PI_F - r;
-    if (y < 0.0f) r = -r;
-    return r;
-}
-
 __global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, long first, long frame_stride, int per_frame, int fft_size,
                                                            int guard, float4 *out)
 {
     __shared__ double red[2][256];
     const int i = blockIdx.x;
-    const float2 *s = sym + first + (long)(i / per_frame) * frame_stride + (long)(i % per_frame) * (fft_size + guard), *cp = s + fft_size;
-    double sr = 0.0, si = 0.0;
-    for (int i = 4 + threadIdx.x; i < guard - 4; i += 256) {
-        const float2 a = cp[i], b = s[i];
-        sr += (double)add_r(mul_r(a.x, b.x), mul_r(a.y, b.y));                  // cp[i] * conj(sym[i])
-        si += (double)sub_r(mul_r(a.y, b.x), mul_r(a.x, b.y));
-    }
-    red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
-    __syncthreads();
-    for (int t = 128; t > 0; t >>= 1) {
-        if (threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float re = (float)red[0][0], im = (float)red[1][0];
-        out[blockIdx.x] = make_float4(re, im, atan2_approx_dev(im, re) / (float)(fft_size << 1), 0.0f);
-    }
+    const float2 *s = sym + first + (long)(i / per_frame) * frame_stride + (long)(i % per_frame) * (fft_size + guard);
+    const float4 r = t2gpu::cp_correlate_body(s, fft_size, guard, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 bool g_taps_loaded[16] = {};

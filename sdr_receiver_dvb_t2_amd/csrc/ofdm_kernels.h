@@ -72,4 +72,11 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
 hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *cp4, const float *sync2, float2 *h_cells, float *h_small,
                                  unsigned *h_flag, unsigned seq, unsigned *d_count, hipStream_t s);
 
+// The synchronisation floats of ONE symbol straight from its spectrum, with the guard correlation of the buffered symbol (ofdm_kernels.hip:
+// sym_sync_kernel). symbol: the spectrum (fft_size cells); buffered (may be null): the symbol as collected, guard + fft_size cells;
+// cp_out / sync (device, may be null) receive {sum.re, sum.im, frequency_est, 0} / {phase_offset, sample_rate_offset}; h_small / h_flag
+// (page-locked, may be null): the same six floats at h_small[0..3] / [4..5] and *h_flag = seq behind them.
+hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,
+                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s);
+
 }  // namespace t2gpu

@@ -1,6 +1,7 @@
 // ofdm_kernels.hip -- OFDM-side kernels for gfx950: batched 32K / 16K forward FFT with fftshift, and the data-symbol
 // channel estimator / equaliser fused with the frequency de-interleaver. HBM-bound streaming work; no matrix cores.
 #include "ofdm_kernels.h"
+#include "cp_device.h"
 #include "t2gpu_common.h"
 #include <algorithm>
 
@@ -694,6 +695,90 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
     if (lane == 0) sync[b] = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
 }
 
+// ---- the synchronisation floats of ONE symbol straight from its spectrum (the slot-shaped path, t2gpu_demod.cpp) ----------------
+// phase_offset and sample_rate_offset (data_symbol.cpp:319-324, p2_symbol.cpp / fc_symbol.cpp likewise) depend on the symbol's pilots
+// only: nothing of the equaliser's cell work. In the reference's per-symbol loop they are what the NEXT chunk's NCO / resampler values
+// wait for, so here they are formed by a launch of their own right behind the FFT -- the per-pilot terms by pilot_estimate exactly as
+// eq_split_kernel / eq_data_kernel form them, folded in carrier order exactly as eq_sync_kernel folds them: the same floats, bit for
+// bit (tests/test_ofdm_gpu.py) -- while the equaliser runs beside the next chunk's front end. The same workgroup also forms the guard
+// correlation of the buffered symbol (symbol_acquisition, dvbt2_demodulator.cpp:321-327; cp_device.h: cp_correlate_kernel's body) and
+// stores all six floats to page-locked host memory with the sequence word behind them.
+__global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 *__restrict__ symbol, int idx_symbol,
+                                                       const float2 *__restrict__ buffered, int guard, float4 *cp_out,
+                                                       float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+{
+    extern __shared__ __attribute__((aligned(16))) float sy_lds[];             // [nseg + 1][4], then the correlation's 2 x 256 doubles
+    __shared__ int sh_lower;
+    const int tid = threadIdx.x;
+    const int row = idx_symbol - p.n_p2;
+    const int nseg = p.seg_count[row];
+    const float2 *cell = symbol + p.l_nulls;
+    const float *refer = p.refer + (size_t)row * p.k_total;
+    const int4 *segs = p.segs + (size_t)row * p.max_seg;
+    float4 *l4 = reinterpret_cast<float4 *>(sy_lds);
+    if (tid == 0) sh_lower = 0;
+    __syncthreads();
+    int lower = 0;
+    for (int k = tid; k <= nseg; k += 256) {
+        const int pc = k == 0 ? segs[0].x : segs[k - 1].y;                     // entry 0: the symbol's first pilot; entry k: segment k - 1's right pilot
+        const PilotEst e = pilot_estimate(cell[pc], refer[pc], 1.0f, 0);
+        const bool upper = pc > p.k_total / 2;
+        l4[k] = k == 0 ? make_float4(e.er, e.ei, 0.0f, 0.0f) : make_float4(e.er, e.ei, e.angle, upper ? 1.0f : 0.0f);
+        lower += (k >= 1 && !upper) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lower += __shfl_xor(lower, d, 64);
+    if ((tid & 63) == 0 && lower) atomicAdd(&sh_lower, lower);
+    float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (buffered) {
+        double (*red)[256] = reinterpret_cast<double (*)[256]>(sy_lds + 4 * (size_t)(p.max_seg + 2));
+        cp = cp_correlate_body(buffered, p.fft_size, guard, red);               // (its barriers also publish l4 / sh_lower)
+    } else {
+        __syncthreads();
+    }
+    lower = sh_lower;
+    const int lane = tid;
+    const int comp = lane % 3, second = lane / 3;                               // eq_sync_kernel's chains: lanes 0..2 first set, 3..5 second
+    float acc = 0.0f;
+    if (lane < 6) {
+        int k = second ? lower + 1 : (comp == 2 ? 1 : 0);
+        const int kend = second ? nseg : lower;
+        const float *q = sy_lds + comp;
+        for (; k + 8 <= kend + 1; k += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = q[4 * (k + u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; k <= kend; ++k) acc += q[4 * k];
+    }
+    if (tid >= 64) return;
+    const float s1r = __shfl(acc, 0, 64), s1i = __shfl(acc, 1, 64), a1 = __shfl(acc, 2, 64);
+    const float s2r = __shfl(acc, 3, 64), s2i = __shfl(acc, 4, 64), a2 = __shfl(acc, 5, 64);
+    if (lane == 0) {
+        const float2 sv = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
+        if (sync) *sync = sv;
+        if (cp_out && buffered) *cp_out = cp;
+        if (h_small) {
+            if (buffered) { h_small[0] = cp.x; h_small[1] = cp.y; h_small[2] = cp.z; h_small[3] = cp.w; }
+            h_small[4] = sv.x; h_small[5] = sv.y;
+            __threadfence_system();
+            __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,
+                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s)
+{
+    const int bytes = (p.max_seg + 2) * 16 + 2 * 256 * 8;
+    if (bytes > 64 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(sym_sync_kernel), bytes)) return e;
+    hipLaunchKernelGGL(sym_sync_kernel, dim3(1), dim3(256), bytes, s, p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void publish_symbol_kernel(const float2 *__restrict__ cells, int n_cells, const float *__restrict__ cp4,
                                                             const float *__restrict__ sync2, float2 *h_cells, float *h_small, unsigned *h_flag,
                                                             unsigned seq, unsigned *d_count)
@@ -711,7 +796,7 @@ __global__ __launch_bounds__(256) void publish_symbol_kernel(const float2 *__res
         if (before == gridDim.x - 1) {                      // the last workgroup: everything is over there
             __hip_atomic_store(d_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cp4) { h_small[0] = cp4[0]; h_small[1] = cp4[1]; h_small[2] = cp4[2]; h_small[3] = cp4[3]; }
-            h_small[4] = sync2[0]; h_small[5] = sync2[1];
+            if (sync2) { h_small[4] = sync2[0]; h_small[5] = sync2[1]; }
             __threadfence_system();
             __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -68,13 +68,21 @@ struct t2gpu_demod {
     // device buffers
     int16_t *d_i = nullptr, *d_q = nullptr;
     size_t in_cap = 0;
-    float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec = nullptr, *d_cells = nullptr, *d_sync = nullptr, *d_cp = nullptr;
+    // Spectrum, cells and the cells' page-locked copy exist twice and alternate symbol by symbol (the reference's demodulators alternate
+    // deinterleaved_buffer_a / _b the same way, data_symbol.cpp:140-147): a symbol's equaliser runs on eq_stream beside the NEXT chunk's
+    // front end -- what the next chunk waits for is the symbol's two synchronisation floats and its guard correlation, and those come
+    // from the pilots alone by a launch of their own right behind the FFT (t2gpu_sym_sync_dev).
+    float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec[2] = {nullptr, nullptr}, *d_cells[2] = {nullptr, nullptr};
     int32_t *d_symidx = nullptr;
     long out_cap = 0;
-    float *h_cells = nullptr;          // pinned: the cells of the symbol just equalised, as the `data` / `l1_dyn_execute` signals carry them
+    float *h_cells[2] = {nullptr, nullptr};   // pinned: the cells of a symbol, as the `data` / `l1_dyn_execute` signals carry them
     float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
-    // results by the device's own stores and a sequence word the host reads (symbol_results)
-    unsigned seq = 0;
+    int cur = 0;                       // which of the two buffer sets the symbol in hand uses
+    hipStream_t eq_stream = nullptr;
+    hipEvent_t ev_fft = nullptr, ev_eq[2] = {nullptr, nullptr};
+    bool eq_busy[2] = {false, false};  // ev_eq[k] has been recorded: buffer set k's last equaliser / publishing launches may still run
+    // results by the device's own stores and sequence words the host reads: h_flag[0] behind the floats (seq), h_flag[16] behind the cells (seq_b)
+    unsigned seq = 0, seq_b = 0;
     unsigned *h_flag = nullptr, *d_count = nullptr;
     // (the front end writes a symbol's chunk straight into the symbol buffer; P1 searches read the chunk from d_out)
     float *d_bounce = nullptr;
@@ -82,6 +90,8 @@ struct t2gpu_demod {
     // consumer does in it (the de-interleaver's push: ~9 us of host time and a launch) then runs beside the front-end kernel instead of
     // in front of it. The cells stay where they are until the next equaliser launch, which comes later still.
     int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
+    int pending_buf = 0;               // ... the buffer set they are in
+    unsigned pending_seq = 0;          // ... and the value h_flag[16] takes when they have arrived
     // The IQ / level estimates of a buffer (c1, c2, level_detect: once per execute(), :227-235) are committed by a launch at the end of the
     // call; nothing before the NEXT call reads them unless the caller asked for the gain decision (signal->gain_changed). So the call
     // does not wait for that launch (59 us with the device idle, 14 times per 32K frame): the next call picks the state up first thing.
@@ -102,10 +112,15 @@ void free_all(t2gpu_demod *h)
     if (h->sync) t2gpu_sync_destroy(h->sync);
     if (h->p2_ofdm) t2gpu_ofdm_destroy(h->p2_ofdm);
     if (h->data_ofdm) t2gpu_ofdm_destroy(h->data_ofdm);
-    hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out); hipFree(h->d_buffer_sym); hipFree(h->d_spec); hipFree(h->d_cells);
-    hipFree(h->d_sync); hipFree(h->d_cp); hipFree(h->d_symidx);
-    if (h->h_cells) twin_retire(h->h_cells);
-    hipHostFree(h->h_cells); hipHostFree(h->h_small);
+    hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out); hipFree(h->d_buffer_sym); hipFree(h->d_symidx);
+    for (int k = 0; k < 2; ++k) {
+        hipFree(h->d_spec[k]); hipFree(h->d_cells[k]);
+        if (h->h_cells[k]) { twin_retire(h->h_cells[k]); hipHostFree(h->h_cells[k]); }
+        if (h->ev_eq[k]) hipEventDestroy(h->ev_eq[k]);
+    }
+    if (h->ev_fft) hipEventDestroy(h->ev_fft);
+    if (h->eq_stream) hipStreamDestroy(h->eq_stream);
+    hipHostFree(h->h_small);
     if (h->h_flag) hipHostFree(h->h_flag);
     hipFree(h->d_count);
     hipFree(h->d_bounce);
@@ -200,34 +215,41 @@ int init_data(t2gpu_demod *h)
     return 0;
 }
 
-// One drain per symbol: the guard correlation, the two synchronisation floats and (when a signal carries them) the symbol's cells are
-// copied to page-locked memory behind the symbol's kernels, and the stream is waited for once (rounds 2-3: three blocking copies).
-// cp (may be null) / sv receive the floats; returns the cells' host address (the twin of d_cells: t2gpu_ti_push finds them on the
-// device) or nullptr on an error.
-const float *symbol_results(t2gpu_demod *h, float *cp, float *sv, int n_cells)
+// A sequence word the device raises behind its own stores into page-locked memory (publish_symbol_kernel, sym_sync_kernel): the host
+// reads it instead of waiting for copies and the stream (~40 us per symbol). Values only grow; false on an error.
+bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_t stream)
 {
-    {
-        // one launch stores cells and floats into the page-locked buffers and raises the sequence word behind them; the host reads that
-        // word (three copies and the stream's completion signal cost the path some 40 us per symbol)
-        const unsigned seq = ++h->seq;
-        if (!hip_ok(t2gpu::launch_publish_symbol(reinterpret_cast<const float2 *>(h->d_cells), n_cells, cp ? h->d_cp : nullptr, h->d_sync,
-                                                 reinterpret_cast<float2 *>(h->h_cells), h->h_small, h->h_flag, seq, h->d_count, nullptr),
-                    "publish_symbol_kernel")) return nullptr;
-        volatile unsigned *flag = h->h_flag;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spins = 0; *flag != seq; ++spins) {
-            t2_cpu_relax();
-            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return nullptr;    // a failed launch shows here
-                if (*flag != seq) { set_error("t2gpu_demod: the symbol's results did not arrive"); return nullptr; }
-            }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; (int)(*flag - seq) < 0; ++spins) {
+        t2_cpu_relax();
+        if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;            // a failed launch shows here
+            if ((int)(*flag - seq) < 0) { set_error("t2gpu_demod: the symbol's results did not arrive"); return false; }
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        h->saw_results = true;
     }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    h->saw_results = true;
+    return true;
+}
+
+// the symbol's two synchronisation floats and (cp != null) its guard correlation, stored by sym_sync_kernel; seq = the launch's word
+bool sync_results(t2gpu_demod *h, unsigned seq, float *cp, float *sv)
+{
+    if (!wait_word(h, h->h_flag, seq, nullptr)) return false;
     if (cp) std::memcpy(cp, h->h_small, 16);
     std::memcpy(sv, h->h_small + 4, 8);
-    return h->h_cells;
+    return true;
+}
+
+// n_cells cells of buffer set k to their page-locked copy by a launch on `stream`, h_flag[16] raised behind them; returns the word's value
+// (0 on an error: the words start at 1)
+unsigned publish_cells(t2gpu_demod *h, int k, int n_cells, hipStream_t stream)
+{
+    const unsigned seq = ++h->seq_b;
+    if (!hip_ok(t2gpu::launch_publish_symbol(reinterpret_cast<const float2 *>(h->d_cells[k]), n_cells, nullptr, nullptr,
+                                             reinterpret_cast<float2 *>(h->h_cells[k]), h->h_small, h->h_flag + 16, seq, h->d_count, stream),
+                "publish_symbol_kernel")) return 0;
+    return seq;
 }
 
 // the state the last commit left (level_detect for the P1 detector and the gain decision)
@@ -241,14 +263,17 @@ int finish_state(t2gpu_demod *h)
     return 0;
 }
 
-void flush_data_signal(t2gpu_demod *h)
+int flush_data_signal(t2gpu_demod *h)
 {
-    if (!h->pending_data) return;
+    if (!h->pending_data) return 0;
     const int n = h->pending_data;
     h->pending_data = 0;
     h->prof.start();
-    h->sig.data(h->sig.user, n, h->h_cells);
+    if (!wait_word(h, h->h_flag + 16, h->pending_seq, h->eq_stream)) return -1;
+    h->prof.stop(PF_CELLS);
+    h->sig.data(h->sig.user, n, h->h_cells[h->pending_buf]);
     h->prof.stop(PF_SIGNAL);
+    return 0;
 }
 
 // symbol_acquisition (:267-448). Returns 0, or -1 on an error of a stage.
@@ -320,43 +345,64 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         h->prof.start();
         const bool have_cp = h->crc32_l1_pre;                                       // :321-330; its result is read with the symbol's other results
         float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (have_cp && t2gpu_cp_correlate_dev(h->d_buffer_sym, 1, h->fft_size, h->guard_interval_size, h->d_cp, nullptr) != 0) return -1;
-        h->prof.stop(PF_CP);
-        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec, 1, nullptr) != 0)
+        // this symbol's buffer set; the launches that used it two symbols ago (equaliser, publishing: eq_stream) are through before the
+        // FFT writes into it -- long since, as a rule
+        const int k = h->cur ^= 1;
+        if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(nullptr, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
+        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec[k], 1, nullptr) != 0)
             return -1;
+        // guard correlation (:321-327) and the symbol's two synchronisation floats, from the pilots alone: one launch, stored to the host
+        const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
+        const unsigned seq_a = ++h->seq;
+        if (t2gpu_sym_sync_dev(kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_spec[k], have_cp ? h->d_buffer_sym : nullptr,
+                               h->guard_interval_size, nullptr, nullptr, h->h_small, h->h_flag, seq_a, nullptr) != 0) return -1;
+        h->prof.stop(PF_CP);
         h->est_chunk = 0;
         ++h->symbols;
         float sv[2] = {0.0f, 0.0f};                                                 // phase_est, sample_rate_est of this symbol
         // ---- the symbol demodulators (:343-427)
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
-            if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec, h->d_symidx + h->idx_symbol, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
-            h->prof.stop(PF_FFT_EQ);
+            // the equaliser beside whatever the null stream does next (the next chunk's front end): eq_stream, behind the FFT
+            T2_HIP(hipEventRecord(h->ev_fft, nullptr));
+            T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
+            if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[k], h->d_symidx + h->idx_symbol, 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
-            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, carry ? h->c_data : 0);
-            if (!c) return -1;
+            unsigned seq_cells = 0;
+            if (carry && !(seq_cells = publish_cells(h, k, h->c_data, h->eq_stream))) return -1;
+            T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
+            h->eq_busy[k] = true;
+            h->prof.stop(PF_FFT_EQ);
+            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.stop(PF_SV);
-            if (carry) { flush_data_signal(h); h->pending_data = h->c_data; (void)c; }   // emitted behind the next front-end launch
+            if (carry) {                                                            // emitted behind the next front-end launch
+                if (flush_data_signal(h) != 0) return -1;
+                h->pending_data = h->c_data; h->pending_buf = k; h->pending_seq = seq_cells;
+            }
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
                 h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
                 if (!h->frame_closing_symbol) ++h->frames;
             }
         } else if (h->next_symbol_type == SYMBOL_TYPE_FC) {
-            if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
+            if (flush_data_signal(h) != 0) return -1;
+            if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, nullptr) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
-            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, carry ? h->n_fc : 0);
-            if (!c) return -1;
+            const unsigned seq_cells = carry ? publish_cells(h, k, h->n_fc, nullptr) : 0;
+            if (carry && !seq_cells) return -1;
+            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
+            if (carry && !wait_word(h, h->h_flag + 16, seq_cells, nullptr)) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
-            if (carry) { flush_data_signal(h); h->sig.data(h->sig.user, h->n_fc, c); }
+            if (carry) h->sig.data(h->sig.user, h->n_fc, h->h_cells[k]);
             h->next_symbol_type = SYMBOL_TYPE_P1;
             ++h->frames;
         } else {                                                                    // SYMBOL_TYPE_P2
-            flush_data_signal(h);
+            if (flush_data_signal(h) != 0) return -1;
             h->idx_symbol = 0;
-            if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec, 1, h->d_cells, h->d_sync, nullptr) < 0) return -1;
-            const float *c = symbol_results(h, have_cp ? cp : nullptr, sv, h->c_p2);
-            if (!c) return -1;
+            if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, nullptr) < 0) return -1;
+            const unsigned seq_cells = publish_cells(h, k, h->c_p2, nullptr);
+            if (!seq_cells || !sync_results(h, seq_a, have_cp ? cp : nullptr, sv) || !wait_word(h, h->h_flag + 16, seq_cells, nullptr)) return -1;
+            const float *c = h->h_cells[k];
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.start();
             // p2_symbol::execute's tail (p2_symbol.cpp:281-296): L1-pre, then L1-post
@@ -440,17 +486,20 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_out, (size_t)h->out_cap * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_bounce, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_spec, (size_t)32768 * 8) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_cells, (size_t)32768 * 8) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_sync, 64) == hipSuccess && hipMalloc(&h->d_cp, 64) == hipSuccess;
+    for (int k = 0; k < 2; ++k) {
+        ok = ok && hipMalloc(&h->d_spec[k], (size_t)32768 * 8) == hipSuccess && hipMalloc(&h->d_cells[k], (size_t)32768 * 8) == hipSuccess;
+        // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the device stores into these while its kernels run and the host reads them then
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells[k]), (size_t)32768 * 8, hipHostMallocCoherent) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->ev_eq[k], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&h->ev_fft, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->eq_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
-    // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the device stores into these while its kernels run and the host reads them then
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells), (size_t)32768 * 8, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocCoherent) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 64, hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 128, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
-    if (ok) *h->h_flag = 0;
-    if (ok) twin_publish(h->h_cells, h->d_cells, (size_t)32768 * 8, device, false);     // what the signals hand on is still on the device
+    if (ok) h->h_flag[0] = h->h_flag[16] = 0;
+    for (int k = 0; ok && k < 2; ++k) twin_publish(h->h_cells[k], h->d_cells[k], (size_t)32768 * 8, device, false);   // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;
@@ -548,10 +597,10 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
-        flush_data_signal(h);                                                       // (the front end is busy with the chunk just launched)
+        if (flush_data_signal(h) != 0) return -1;                                   // (the front end is busy with the chunk just launched)
         if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
-    flush_data_signal(h);
+    if (flush_data_signal(h) != 0) return -1;
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;

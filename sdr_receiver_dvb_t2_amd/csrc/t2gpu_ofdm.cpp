@@ -478,6 +478,23 @@ extern "C" int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     return h->m.n_fc;
 }
 
+// phase_offset / sample_rate_offset of one symbol from its pilots alone, and the guard correlation of the buffered symbol, in one launch
+// (ofdm_kernels.hip: sym_sync_kernel). kind: 0 data symbol idx_symbol, 1 P2, 2 frame closing.
+extern "C" int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_spectrum, const float *d_buffered, int guard,
+                                  float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream)
+{
+    if (!h || !d_spectrum || kind < 0 || kind > 2 || (h_small && !h_flag) || (d_buffered && guard < 0)) { set_error("t2gpu_sym_sync_dev: bad arguments"); return -1; }
+    const EqParams &p = kind == 0 ? h->eq : kind == 1 ? h->eq_p2 : h->eq_fc;
+    if (kind == 1) idx_symbol = 0;
+    else if (kind == 2) {
+        if (!h->m.l_fc) { set_error("t2gpu_sym_sync_dev: this mode has no frame-closing symbol"); return -1; }
+        idx_symbol = h->m.len_frame - 1;
+    } else if (idx_symbol < h->m.n_p2 || idx_symbol >= h->m.n_p2 + h->rows) { set_error("t2gpu_sym_sync_dev: symbol index outside the frame's data symbols"); return -1; }
+    T2_HIP(launch_sym_sync(p, reinterpret_cast<const float2 *>(d_spectrum), idx_symbol, reinterpret_cast<const float2 *>(d_buffered), guard,
+                           reinterpret_cast<float4 *>(d_cp4), reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
                                      float *phase_offset)
 {

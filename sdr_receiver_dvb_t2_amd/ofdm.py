@@ -120,6 +120,23 @@ class t2_ofdm(object):
             check(rc, "t2gpu_eq_fc_execute_dev")
         return cells, sync
 
+    # ---- the by-reference outputs of {data,p2,fc}_symbol::execute from the pilots alone + the guard correlation, one symbol
+    def sym_sync_dev(self, kind, idx_symbol, spectrum, buffered=None, guard=0, host=None):
+        """spectrum: float32 device tensor [fft_size][2]; buffered (optional): float32 device tensor [guard + fft_size][2] (guard
+        first). Returns device tensors (cp4[4], sync[2]). host = (h_small, h_flag, seq): page-locked float32[8] / int32[1] tensors the
+        kernel itself stores into, the word last."""
+        import torch
+        assert spectrum.is_cuda and spectrum.dtype == torch.float32 and spectrum.is_contiguous()
+        cp4 = torch.zeros(4, dtype=torch.float32, device=spectrum.device)
+        sync = torch.zeros(2, dtype=torch.float32, device=spectrum.device)
+        hs, hf, seq = (host[0].data_ptr(), host[1].data_ptr(), host[2]) if host else (None, None, 0)
+        rc = self._l.t2gpu_sym_sync_dev(self._h, kind, idx_symbol, spectrum.data_ptr(), buffered.data_ptr() if buffered is not None else None,
+                                        guard, cp4.data_ptr(), sync.data_ptr(), hs, hf, seq,
+                                        torch.cuda.current_stream(spectrum.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_sym_sync_dev")
+        return cp4, sync
+
     def eq_data(self, idx_symbol, ofdm_cell):
         """Reference call shape: returns (cells complex64[c_data], sample_rate_offset, phase_offset)."""
         x = np.ascontiguousarray(ofdm_cell, np.complex64).reshape(self.fft_size)

@@ -178,3 +178,45 @@ def test_frame_closing_equaliser_matches_oracle(torch_cuda, mode, eq_form):
         assert np.array_equal(got, want)
         assert sync[b, 0] == np.float32(pho) and sync[b, 1] == np.float32(sro)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (4, 1, 1, 3, 0, 9), (4, 0, 4, 1, 2, 45), (5, 0, 3, 0, 0, 20)])
+def test_sync_floats_from_the_pilots_alone_equal_the_equalisers(torch_cuda, mode):
+    """t2gpu_sym_sync_dev (what the slot-shaped path waits for per symbol) against the equaliser launches' d_sync and
+    t2gpu_cp_correlate_dev's d_out4: the same floats bit for bit, data / P2 / frame-closing tables, and the copy the kernel itself
+    stores into page-locked memory with the sequence word behind it."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    from sdr_receiver_dvb_t2_amd import front
+    torch = torch_cuda
+    m = ol.ora_mode(*mode)
+    ctx = pkg.t2_ofdm(*mode, max_symbols=4)
+    rows = m.n_data - m.l_fc
+    guard = m.fft_size // 128 if mode[0] == 5 else m.fft_size // 16
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = [(0, 1), (0, 2), (0, rows), (0, 1 + rows // 2), (1, 0)] + ([(2, m.len_frame - 1)] if m.l_fc else [])
+    h_small = torch.zeros(8, dtype=torch.float32).pin_memory()
+    h_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    for n, (kind, idx) in enumerate(cases):
+        sym = make_symbol(m, idx, seed=n)
+        spec = torch.from_numpy(sym.view(np.float32).reshape(1, m.fft_size, 2)).cuda()
+        if kind == 0:
+            _, want = ctx.eq_data_dev(spec, torch.tensor([idx], dtype=torch.int32, device="cuda"))
+        elif kind == 1:
+            _, want = ctx.eq_p2_dev(spec)
+        else:
+            _, want = ctx.eq_fc_dev(spec)
+        buffered = (rng.standard_normal((1, guard + m.fft_size, 2)) * 0.25).astype(np.float32)
+        buffered[0, m.fft_size:, :] = buffered[0, :guard, :] * np.float32(0.9) + np.float32(0.01)
+        buf = torch.from_numpy(buffered).cuda()
+        want_cp = front.cp_correlate_dev(torch.view_as_complex(buf), m.fft_size, guard)
+        cp4, sync = ctx.sym_sync_dev(kind, idx, spec[0], buf[0], guard, host=(h_small, h_flag, n + 1))
+        torch.cuda.synchronize()
+        assert np.array_equal(sync.cpu().numpy().view(np.uint32), want.cpu().numpy()[0].view(np.uint32)), (kind, idx)
+        assert np.array_equal(cp4.cpu().numpy().view(np.uint32), want_cp.cpu().numpy()[0].view(np.uint32)), (kind, idx)
+        assert int(h_flag[0]) == n + 1
+        assert np.array_equal(h_small.numpy()[:4].view(np.uint32), cp4.cpu().numpy().view(np.uint32))
+        assert np.array_equal(h_small.numpy()[4:6].view(np.uint32), sync.cpu().numpy().view(np.uint32))
+        # without a buffered symbol: the floats alone
+        _, sync2 = ctx.sym_sync_dev(kind, idx, spec[0])
+        assert np.array_equal(sync2.cpu().numpy().view(np.uint32), sync.cpu().numpy().view(np.uint32))
+    ctx.close()
