@@ -175,6 +175,12 @@ int t2gpu_ti_cells_per_fec(const t2gpu_ti *h);
 int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks);
 int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells, float *d_out, void *stream);
 int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out);
+/* t2gpu_ti_push in two steps, for a caller whose thread must not stand still while a complete block comes down (13 MB for CFG-A; the
+ * reference's demodulator thread hands the block to the de-interleaver's own thread the same way, time_deinterleaver.cpp:30-36,313-353):
+ * _async returns 1 with the block's copy into `out` still on its way (page-lock `out`: t2gpu_host_pin); t2gpu_ti_wait, from any thread,
+ * returns when `out` holds the block -- call it before `out` is read or handed on. A push that finds the wait outstanding does it first. */
+int t2gpu_ti_push_async(t2gpu_ti *h, const float *cells, int n_cells, float *out);
+int t2gpu_ti_wait(t2gpu_ti *h);
 /* n_blocks complete TI blocks of the geometry set by t2gpu_ti_begin in one launch (e.g. the same TI block of every T2 frame of a
  * buffer): block f reads ti_block_size cells at d_cells + 2 * f * in_stride_cells floats and writes d_out + 2 * f *
  * out_stride_cells. Same result as t2gpu_ti_begin + one whole-block t2gpu_ti_push_dev per block. Returns n_blocks. */

@@ -472,7 +472,7 @@ private:
         std::vector<complex> out[2];
         int cur = 0;
     };
-    struct job { bool pending = false; int size = 0, plp = 0; complex *cells = nullptr; l1_postsignalling l1; };
+    struct job { bool pending = false; int size = 0, plp = 0; complex *cells = nullptr; t2gpu_ti *h = nullptr; l1_postsignalling l1; };
     void push(int n, complex *cells)
     {
         while (n > 0 && k_ < plan_.size()) {
@@ -484,24 +484,26 @@ private:
             int done;
             {
                 prof_scope ps(prof_table::TI_PUSH);
-                done = t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(l.out[l.cur].data()));
+                // with a thread of its own the complete block's copy down is waited for there (t2gpu_ti_wait), not here
+                done = threaded_ ? t2gpu_ti_push_async(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(l.out[l.cur].data()))
+                                 : t2gpu_ti_push(h, reinterpret_cast<const float *>(cells), take, reinterpret_cast<float *>(l.out[l.cur].data()));
             }
             if (done < 0) fail("t2gpu_ti_push");
             cells += take; n -= take; pos_ += take;
             if (done == 1) {
-                emit(b.size, l.out[l.cur].data(), b.plp);
+                emit(b.size, l.out[l.cur].data(), b.plp, h);
                 l.cur ^= 1;
                 ++k_;
             }
         }
     }
-    void emit(int size, complex *cells, int plp)
+    void emit(int size, complex *cells, int plp, t2gpu_ti *h)
     {
         if (!threaded_) { if (ti_block) ti_block(size, cells, plp, l1_post_); return; }
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !job_.pending; });          // the block before this one has been dealt with: its buffer is free again
         rethrow_locked();
-        job_.pending = true; job_.size = size; job_.plp = plp; job_.cells = cells; job_.l1 = l1_post_;
+        job_.pending = true; job_.size = size; job_.plp = plp; job_.cells = cells; job_.h = h; job_.l1 = l1_post_;
         cv_.notify_all();
     }
     void run()
@@ -512,6 +514,7 @@ private:
             if (stop_) return;
             lk.unlock();
             try {
+                if (t2gpu_ti_wait(job_.h) != 0) fail("t2gpu_ti_wait");                 // the block has come down
                 if (ti_block) ti_block(job_.size, job_.cells, job_.plp, job_.l1);
             } catch (...) {
                 std::lock_guard<std::mutex> g(m_);

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "t2gpu_ti_begin": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ti_push_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ti_push": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_ti_push_async": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_ti_wait": (ctypes.c_int, [_vp]),
     "t2gpu_demap_stats_batch_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "t2gpu_ti_execute_blocks_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_long, _vp, ctypes.c_long, ctypes.c_int, _vp]),
     "t2gpu_ti_execute_blocks_stats_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_long, _vp, ctypes.c_long, ctypes.c_int, ctypes.c_float, _vp, ctypes.c_int, _vp]),

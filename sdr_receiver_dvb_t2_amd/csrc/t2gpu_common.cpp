@@ -34,6 +34,23 @@ hipError_t ensure_dynamic_lds(const void *fn, int bytes)
     return e;
 }
 
+hipStream_t side_stream(int device)
+{
+    static std::mutex m;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) { set_error("t2gpu: device index outside the side-stream table"); return nullptr; }
+    std::lock_guard<std::mutex> lk(m);
+    if (!streams[device]) {
+        int cur = 0;
+        if (!hip_ok(hipGetDevice(&cur), "hipGetDevice")) return nullptr;
+        if (cur != device && !hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+        const bool ok = hip_ok(hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        if (cur != device) hipSetDevice(cur);
+        if (!ok) { streams[device] = nullptr; return nullptr; }
+    }
+    return streams[device];
+}
+
 namespace {
 // guard: what the first and the last 64 bytes of the host range and its length hashed to when the entry was made (0 = not guarded:
 // page-locked buffers of the library's own that the DEVICE fills behind a sequence word)
@@ -159,9 +176,11 @@ extern "C" int t2gpu_twin_copy(void *dst, const void *src, size_t bytes, int dev
     const void *d_dst = twin_lookup(dst, bytes, device);
     if (!d_dst) return 0;
     T2_HIP(hipSetDevice(device));
+    hipStream_t side = side_stream(device);                  // in order with the demapper's passes before it and the batch copy behind it
+    if (!side) return -1;
     const void *d_src = twin_lookup(src, bytes, device);
-    if (d_src) T2_HIP(hipMemcpyAsync(const_cast<void *>(d_dst), d_src, bytes, hipMemcpyDeviceToDevice, nullptr));
-    else T2_HIP(hipMemcpyAsync(const_cast<void *>(d_dst), dst, bytes, hipMemcpyHostToDevice, nullptr));
+    if (d_src) T2_HIP(hipMemcpyAsync(const_cast<void *>(d_dst), d_src, bytes, hipMemcpyDeviceToDevice, side));
+    else T2_HIP(hipMemcpyAsync(const_cast<void *>(d_dst), dst, bytes, hipMemcpyHostToDevice, side));
     return 0;
 }
 

@@ -19,11 +19,17 @@ hipError_t ensure_dynamic_lds(const void *fn, int bytes);
 // t2gpu_stages.hpp do): by default a host-buffer entry point is a function of the bytes it is handed and nothing else. An entry made
 // on the way carries a hash of the buffer's first and last 64 bytes and its length; a look-up that finds them changed (a recycled
 // address) drops the entry. Buffers attached by the caller (t2gpu_twin_attach) are honoured always.
-// All twins are written and read on the null stream (or ordered against it by events).
+// Twins are written and read on the null stream or on the device's side stream (below), one after the other by stream order, by an
+// event, or because the host has waited for the writer before it calls the reader.
 void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded = true);   // replaces an entry with the same host base
 void twin_retire(const void *host);                                               // the entry whose base is host, if any
 void twin_retire_dev(const void *dev_lo, size_t bytes);                           // every entry whose device range lies in [dev_lo, +bytes)
 const void *twin_lookup(const void *host, size_t bytes, int device);              // device address of [host, host + bytes) or nullptr
+// The device's SIDE STREAM (non-blocking, created on first use, lives as long as the process): where the host-buffer entry points of
+// the FEC side put their block-sized work -- a TI block's copy down, the demapper's passes, the SIMD batch copies, the descrambler --
+// so that a caller's per-symbol launches on the null stream (t2gpu_demod_execute) never queue behind a 13 MB copy or a statistics
+// walk. nullptr (and last_error set) when it cannot be created.
+hipStream_t side_stream(int device);
 }  // namespace t2gpu
 
 // one step of a host spin loop (the page-locked sequence words the device raises): the CPU's own hint where there is one

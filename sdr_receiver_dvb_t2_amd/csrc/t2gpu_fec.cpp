@@ -215,13 +215,17 @@ extern "C" int t2gpu_demap_execute(t2gpu_demap *h, const float *cells, int n_cel
     // its input in place (llr_demapper.cpp:555-557): it works on its own copy, the twin stays what the host buffer holds.
     const float *twin = static_cast<const float *>(twin_lookup(cells, (size_t)n_cells * 8, h->device));
     twin_retire_dev(h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell);       // the LLRs of the previous call are about to be overwritten
-    if (twin) T2_HIP(hipMemcpyAsync(h->d_cells, twin, (size_t)n_cells * 8, hipMemcpyDeviceToDevice, nullptr));
-    else T2_HIP(hipMemcpyAsync(h->d_cells, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
-    int nf = t2gpu_demap_execute_dev(h, h->d_cells, n_cells, 0.0f, h->d_llr, nullptr, nullptr);
+    // on the device's side stream (t2gpu_common.h): a TI block's worth of passes and 13 MB of LLRs coming down do not hold up whatever
+    // the caller's other threads have on the null stream
+    hipStream_t side = side_stream(h->device);
+    if (!side) return -1;
+    if (twin) T2_HIP(hipMemcpyAsync(h->d_cells, twin, (size_t)n_cells * 8, hipMemcpyDeviceToDevice, side));
+    else T2_HIP(hipMemcpyAsync(h->d_cells, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, side));
+    int nf = t2gpu_demap_execute_dev(h, h->d_cells, n_cells, 0.0f, h->d_llr, nullptr, side);
     if (nf < 0) return -1;
-    T2_HIP(hipMemcpyAsync(llr, h->d_llr, (size_t)nf * h->p.fec_size, hipMemcpyDeviceToHost, nullptr));
-    if (sums3) T2_HIP(hipMemcpyAsync(sums3, h->d_sums, 12, hipMemcpyDeviceToHost, nullptr));
-    T2_HIP(hipStreamSynchronize(nullptr));
+    T2_HIP(hipMemcpyAsync(llr, h->d_llr, (size_t)nf * h->p.fec_size, hipMemcpyDeviceToHost, side));
+    if (sums3) T2_HIP(hipMemcpyAsync(sums3, h->d_sums, 12, hipMemcpyDeviceToHost, side));
+    T2_HIP(hipStreamSynchronize(side));
     twin_publish(llr, h->d_llr, (size_t)nf * h->p.fec_size, h->device);
     return nf;
 }
@@ -235,6 +239,10 @@ struct t2gpu_ti {
     uint8_t *d_lost = nullptr, *d_lost_blk = nullptr;
     float *d_first_q = nullptr;
     float *d_in = nullptr, *d_out = nullptr;   // host-call staging
+    // t2gpu_ti_push_async: the complete block's copy down is on its way (side stream, behind `fixed`); t2gpu_ti_wait ends it
+    hipEvent_t fixed = nullptr, down = nullptr;
+    float *down_out = nullptr;
+    size_t down_bytes = 0;
     std::map<int, std::pair<std::vector<int32_t>, std::vector<uint8_t>>> geom;   // num_blocks -> (order, lost)
 };
 
@@ -265,6 +273,9 @@ extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, 
 extern "C" void t2gpu_ti_destroy(t2gpu_ti *h)
 {
     if (!h) return;
+    if (h->down_out) { hipEventSynchronize(h->down); h->down_out = nullptr; }  // a block's copy down still on its way: `out` is the caller's
+    if (h->fixed) hipEventDestroy(h->fixed);
+    if (h->down) hipEventDestroy(h->down);
     if (h->d_out) twin_retire_dev(h->d_out, (size_t)h->num_blocks_max * h->cells_per_fec * 8);
     hipFree(h->d_perm); hipFree(h->d_order); hipFree(h->d_lost); hipFree(h->d_lost_blk); hipFree(h->d_first_q); hipFree(h->d_in); hipFree(h->d_out);
     delete h;
@@ -410,7 +421,20 @@ extern "C" int t2gpu_ti_push_dev(t2gpu_ti *h, const float *d_cells, int n_cells,
     return 0;
 }
 
-extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out)
+// ends the copy down a t2gpu_ti_push_async left on its way: `out` then holds the block and has its twin
+extern "C" int t2gpu_ti_wait(t2gpu_ti *h)
+{
+    if (!h) { set_error("t2gpu_ti_wait: bad arguments"); return -1; }
+    if (!h->down_out) return 0;
+    T2_HIP(hipSetDevice(h->device));
+    float *out = h->down_out;
+    h->down_out = nullptr;
+    T2_HIP(hipEventSynchronize(h->down));
+    twin_publish(out, h->d_out, h->down_bytes, h->device);                      // the complete TI block: what llr_demapper is handed next
+    return 0;
+}
+
+extern "C" int t2gpu_ti_push_async(t2gpu_ti *h, const float *cells, int n_cells, float *out)
 {
     if (!h || !cells || !out || !h->num_blocks) { set_error("t2gpu_ti_push: bad arguments"); return -1; }
     if (n_cells < 0 || (long)h->pos + n_cells > (long)h->p.ti_block_size) {      // before anything is copied into the staging buffer
@@ -418,6 +442,7 @@ extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float
         return -1;
     }
     T2_HIP(hipSetDevice(h->device));
+    if (h->down_out && t2gpu_ti_wait(h) != 0) return -1;                        // (a caller that pushes on without having waited)
     const size_t cap = (size_t)h->num_blocks_max * h->cells_per_fec * 8;
     if (!h->d_in) { T2_HIP(hipMalloc(&h->d_in, cap)); T2_HIP(hipMalloc(&h->d_out, cap)); }
     const size_t blk = (size_t)h->p.ti_block_size * 8;
@@ -439,9 +464,26 @@ extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float
     int done = t2gpu_ti_push_dev(h, d_cells, n_cells, h->d_out, nullptr);
     if (done < 0) return -1;
     if (done == 1) {
-        T2_HIP(hipMemcpy(out, h->d_out, blk, hipMemcpyDeviceToHost));
-        twin_publish(out, h->d_out, blk, h->device);                            // the complete TI block: what llr_demapper is handed next
-    } else if (d_cells == h->d_in) T2_HIP(hipStreamSynchronize(nullptr));       // `cells` is the caller's again
+        // the block comes down on the device's side stream, behind the scatter / fix-up launches of the null stream: 13 MB at the link's
+        // rate (235 us) that the null stream -- the caller's next symbols -- does not wait for
+        hipStream_t side = side_stream(h->device);
+        if (!side) return -1;
+        if (!h->fixed) T2_HIP(hipEventCreateWithFlags(&h->fixed, hipEventDisableTiming));
+        if (!h->down) T2_HIP(hipEventCreateWithFlags(&h->down, hipEventDisableTiming));
+        T2_HIP(hipEventRecord(h->fixed, nullptr));
+        T2_HIP(hipStreamWaitEvent(side, h->fixed, 0));
+        T2_HIP(hipMemcpyAsync(out, h->d_out, blk, hipMemcpyDeviceToHost, side));
+        T2_HIP(hipEventRecord(h->down, side));
+        h->down_out = out; h->down_bytes = blk;
+    }
+    if (d_cells == h->d_in) T2_HIP(hipStreamSynchronize(nullptr));              // `cells` is the caller's again
+    return done;
+}
+
+extern "C" int t2gpu_ti_push(t2gpu_ti *h, const float *cells, int n_cells, float *out)
+{
+    const int done = t2gpu_ti_push_async(h, cells, n_cells, out);
+    if (done == 1 && t2gpu_ti_wait(h) != 0) return -1;
     return done;
 }
 
@@ -512,10 +554,13 @@ extern "C" int t2gpu_bch_descramble(int fec_type, int code_rate, const uint8_t *
     if (st.in_cap < in_b) { hipFree(st.in); st.in = nullptr; st.in_cap = 0; T2_HIP(hipMalloc(&st.in, in_b)); st.in_cap = in_b; }
     if (st.out_cap < out_b) { hipFree(st.out); st.out = nullptr; st.out_cap = 0; T2_HIP(hipMalloc(&st.out, out_b)); st.out_cap = out_b; }
     // bits straight from t2gpu_ldpc_collect / t2gpu_ldpc_execute are still on the device
+    hipStream_t side = side_stream(device);
+    if (!side) return -1;
     const uint8_t *d_in = static_cast<const uint8_t *>(twin_lookup(bits, in_b, device));
-    if (!d_in) { T2_HIP(hipMemcpyAsync(st.in, bits, in_b, hipMemcpyHostToDevice, nullptr)); d_in = st.in; }
-    const int kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, st.out, nullptr);
+    if (!d_in) { T2_HIP(hipMemcpyAsync(st.in, bits, in_b, hipMemcpyHostToDevice, side)); d_in = st.in; }
+    const int kb = t2gpu_bch_descramble_dev(fec_type, code_rate, d_in, n_frames, st.out, side);
     if (kb < 0) return -1;
-    T2_HIP(hipMemcpy(out, st.out, out_b, hipMemcpyDeviceToHost));
+    T2_HIP(hipMemcpyAsync(out, st.out, out_b, hipMemcpyDeviceToHost, side));
+    T2_HIP(hipStreamSynchronize(side));
     return kb;
 }

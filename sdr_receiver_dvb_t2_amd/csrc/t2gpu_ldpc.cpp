@@ -458,13 +458,15 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
     if (const void *twin = twin_lookup(in, (size_t)len_in, h->device)) {
         // a SIMD batch assembled from the demapper's output (t2gpu_twin_copy) is on the device already: its twin is written on the
-        // null stream, so the copy into this handle's input is put on the null stream too (in order with those writes, and the twin is
-        // free for the next batch when it is through) and this handle's stream starts behind it. Nothing on the null stream ever waits
-        // for this handle's stream: a wait the other way round held the caller's per-symbol kernels up behind whole decodes whenever two
-        // handles' streams shared a hardware queue.
+        // device's side stream, so the copy into this handle's input is put there too (in order with those writes, and the twin is
+        // free for the next batch when it is through) and this handle's stream starts behind it. Nothing on the side stream (or the
+        // null stream) ever waits for this handle's stream: a wait the other way round held the caller's per-symbol kernels up behind
+        // whole decodes whenever two handles' streams shared a hardware queue.
+        hipStream_t side = side_stream(h->device);
+        if (!side) return -1;
         if (!h->a_fence) T2_HIP(hipEventCreateWithFlags(&h->a_fence, hipEventDisableTiming));
-        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, nullptr));
-        T2_HIP(hipEventRecord(h->a_fence, nullptr));
+        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, side));
+        T2_HIP(hipEventRecord(h->a_fence, side));
         T2_HIP(hipStreamWaitEvent(s, h->a_fence, 0));
     } else {
         std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns

@@ -69,3 +69,17 @@ if len(fft) > 40:
     ops = [x for x in k if a[1] <= x[1] < b[1]] + [("copy " + x[0], x[1], x[2], -1) for x in copies if a[1] <= x[1] < b[1]]
     for r in sorted(ops, key=lambda x: x[1]):
         print("      +%8.1f us  %7.1f us  %s" % ((r[1] - a[1]) / 1e3, (r[2] - r[1]) / 1e3, r[0].split("(")[0][-60:] or "(unnamed kernel)"))
+
+# ---- every symbol of the last whole frame: interval to the next FFT launch, and what else started on the device inside it
+if len(p1) >= 3 and len(fft) > 130:
+    a, b = p1[-3], p1[-2]
+    fr = [r for r in fft if a[1] <= r[1] < b[1]]
+    print("symbols of one frame (interval to the next symbol's FFT; kernels / copies other than the symbol chain's that START inside it):")
+    chain = ("fft_stage", "fft_fwd", "sym_sync", "eq_split", "publish_symbol", "ti_scatter", "front_", "cp_correlate", "eq_sync")
+    for x, y in zip(fr[:-1], fr[1:]):
+        ins = [r for r in k if x[1] <= r[1] < y[1] and r[0] and not any(c in r[0] for c in chain)]
+        cps = [r for r in copies if x[1] <= r[1] < y[1]]
+        un = [r for r in k if x[1] <= r[1] < y[1] and not r[0]]
+        txt = ", ".join("%s %.0f" % (r[0].split("(")[0].split("::")[-1][:22], (r[2] - r[1]) / 1e3) for r in ins[:6])
+        txt += "".join(", copy %.0f (%.1f MB)" % ((r[2] - r[1]) / 1e3, (r[3] or 0) / 1e6) for r in cps[:4])
+        print("   %7.1f us  front %s  %s" % ((y[1] - x[1]) / 1e3, "+".join("%.0f" % ((r[2] - r[1]) / 1e3) for r in un), txt))
