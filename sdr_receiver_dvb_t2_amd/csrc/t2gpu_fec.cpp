@@ -441,6 +441,7 @@ extern "C" int t2gpu_ti_push_async(t2gpu_ti *h, const float *cells, int n_cells,
         set_error("t2gpu_ti_push: n_cells runs past the TI block");
         return -1;
     }
+    if (n_cells == 0) return 0;                                                 // (nothing arrives, nothing starts: a block begins with its first cell)
     T2_HIP(hipSetDevice(h->device));
     if (h->down_out && t2gpu_ti_wait(h) != 0) return -1;                        // (a caller that pushes on without having waited)
     const size_t cap = (size_t)h->num_blocks_max * h->cells_per_fec * 8;

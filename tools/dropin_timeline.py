@@ -83,3 +83,10 @@ if len(p1) >= 3 and len(fft) > 130:
         txt = ", ".join("%s %.0f" % (r[0].split("(")[0].split("::")[-1][:22], (r[2] - r[1]) / 1e3) for r in ins[:6])
         txt += "".join(", copy %.0f (%.1f MB)" % ((r[2] - r[1]) / 1e3, (r[3] or 0) / 1e6) for r in cps[:4])
         print("   %7.1f us  front %s  %s" % ((y[1] - x[1]) / 1e3, "+".join("%.0f" % ((r[2] - r[1]) / 1e3) for r in un), txt))
+    # the slowest symbols of that frame in full: every kernel / copy that starts inside, with its stream
+    slow = sorted(zip(fr[:-1], fr[1:]), key=lambda xy: xy[0][1] - xy[1][1])[:3]
+    for x, y in slow:
+        print("   --- a %.1f us symbol:" % ((y[1] - x[1]) / 1e3))
+        ops = [(r[0], r[1], r[2], r[3]) for r in k if x[1] <= r[1] < y[1]] + [("copy " + r[0], r[1], r[2], -1) for r in copies if x[1] <= r[1] < y[1]]
+        for r in sorted(ops, key=lambda q: q[1]):
+            print("      +%8.1f us  %7.1f us  stream %3s  %s" % ((r[1] - x[1]) / 1e3, (r[2] - r[1]) / 1e3, r[3], (r[0] or "(unnamed)").split("(")[0][-50:]))
