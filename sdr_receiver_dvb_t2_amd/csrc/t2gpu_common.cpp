@@ -44,7 +44,9 @@ hipStream_t side_stream(int device)
         int cur = 0;
         if (!hip_ok(hipGetDevice(&cur), "hipGetDevice")) return nullptr;
         if (cur != device && !hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
-        const bool ok = hip_ok(hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        int least = 0, greatest = 0;
+        const bool ok = hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange") &&
+                        hip_ok(hipStreamCreateWithPriority(&streams[device], hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
         if (cur != device) hipSetDevice(cur);
         if (!ok) { streams[device] = nullptr; return nullptr; }
     }
@@ -54,7 +56,7 @@ hipStream_t side_stream(int device)
 namespace {
 // guard: what the first and the last 64 bytes of the host range and its length hashed to when the entry was made (0 = not guarded:
 // page-locked buffers of the library's own that the DEVICE fills behind a sequence word)
-struct Twin { const char *host; const char *dev; size_t bytes; int device; bool owned; bool pinned; uint64_t guard; };
+struct Twin { const char *host; const char *dev; size_t bytes; int device; bool owned; bool pinned; uint64_t guard; hipStream_t home; };
 std::mutex g_twin_m;
 std::vector<Twin> g_twins;
 std::atomic<int> g_handoff{0};           // t2gpu_handoff_enable: implicit entries are consulted only when the caller has said its buffers travel unmodified
@@ -70,14 +72,16 @@ uint64_t guard_of(const char *host, size_t bytes)
 }
 }  // namespace
 
-void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded)
+bool handoff_on() { return g_handoff.load(std::memory_order_relaxed) != 0; }
+
+void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded, hipStream_t home)
 {
     if (!host || !dev || !bytes) return;
     const uint64_t g = guarded ? guard_of(static_cast<const char *>(host), bytes) : 0;
     std::lock_guard<std::mutex> lk(g_twin_m);
     for (Twin &t : g_twins)
-        if (t.host == host && !t.owned) { t.dev = static_cast<const char *>(dev); t.bytes = bytes; t.device = device; t.guard = g; return; }
-    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, false, false, g});
+        if (t.host == host && !t.owned) { t.dev = static_cast<const char *>(dev); t.bytes = bytes; t.device = device; t.guard = g; t.home = home; return; }
+    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, false, false, g, home});
 }
 void twin_retire(const void *host)
 {
@@ -94,8 +98,9 @@ void twin_retire_dev(const void *dev_lo, size_t bytes)
         else ++i;
     }
 }
-const void *twin_lookup(const void *host, size_t bytes, int device)
+const void *twin_lookup(const void *host, size_t bytes, int device, hipStream_t *home)
 {
+    if (home) *home = nullptr;
     if (!host) return nullptr;
     const bool implicit_ok = g_handoff.load(std::memory_order_relaxed) != 0;
     const char *h = static_cast<const char *>(host);
@@ -103,6 +108,7 @@ const void *twin_lookup(const void *host, size_t bytes, int device)
     for (size_t i = 0; i < g_twins.size(); ++i) {
         const Twin &t = g_twins[i];
         if (t.device != device || h < t.host || h + bytes > t.host + t.bytes) continue;
+        if (home) *home = t.home;
         if (t.owned) return t.dev + (h - t.host);                 // attached by the caller, buffer by buffer: always honoured
         if (!implicit_ok) return nullptr;
         // an entry made on the way (a stage's output buffer): the address alone proves nothing -- the caller may have released the
@@ -132,7 +138,7 @@ extern "C" int t2gpu_twin_attach(void *host, size_t bytes, int device)
     const bool pinned = hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess;   // faster copies; not essential
     if (!pinned) (void)hipGetLastError();
     std::lock_guard<std::mutex> lk(g_twin_m);
-    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, true, pinned, 0});
+    g_twins.push_back(Twin{static_cast<const char *>(host), static_cast<const char *>(dev), bytes, device, true, pinned, 0, nullptr});
     return 0;
 }
 extern "C" int t2gpu_twin_detach(void *host)

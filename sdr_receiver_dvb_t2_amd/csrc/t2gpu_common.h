@@ -21,11 +21,15 @@ hipError_t ensure_dynamic_lds(const void *fn, int bytes);
 // address) drops the entry. Buffers attached by the caller (t2gpu_twin_attach) are honoured always.
 // Twins are written and read on the null stream or on the device's side stream (below), one after the other by stream order, by an
 // event, or because the host has waited for the writer before it calls the reader.
-void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded = true);   // replaces an entry with the same host base
+// home: the stream the twin is written on -- a reader that goes on using the twin after its call has returned (t2gpu_ti_push's scatter)
+// puts that work there, so that the writer's next pass over the buffer comes behind it by stream order
+void twin_publish(const void *host, const void *dev, size_t bytes, int device, bool guarded = true, hipStream_t home = nullptr);   // replaces an entry with the same host base
 void twin_retire(const void *host);                                               // the entry whose base is host, if any
 void twin_retire_dev(const void *dev_lo, size_t bytes);                           // every entry whose device range lies in [dev_lo, +bytes)
-const void *twin_lookup(const void *host, size_t bytes, int device);              // device address of [host, host + bytes) or nullptr
-// The device's SIDE STREAM (non-blocking, created on first use, lives as long as the process): where the host-buffer entry points of
+bool handoff_on();                                                                // t2gpu_handoff_enable's state
+const void *twin_lookup(const void *host, size_t bytes, int device, hipStream_t *home = nullptr);   // device address of [host, host + bytes) or nullptr
+// The device's SIDE STREAM (non-blocking, highest priority -- a hardware queue no decode of t2gpu_ldpc_submit ever sits in --, created on
+// first use, lives as long as the process): where the host-buffer entry points of
 // the FEC side put their block-sized work -- a TI block's copy down, the demapper's passes, the SIMD batch copies, the descrambler --
 // so that a caller's per-symbol launches on the null stream (t2gpu_demod_execute) never queue behind a 13 MB copy or a statistics
 // walk. nullptr (and last_error set) when it cannot be created.

@@ -78,7 +78,11 @@ struct t2gpu_demod {
     float *h_cells[2] = {nullptr, nullptr};   // pinned: the cells of a symbol, as the `data` / `l1_dyn_execute` signals carry them
     float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
     int cur = 0;                       // which of the two buffer sets the symbol in hand uses
-    hipStream_t eq_stream = nullptr;
+    // Nothing of this object runs on the null stream. stream: the per-symbol chain (I/Q copies, front end, P1, FFT, synchronisation
+    // floats); eq_stream: a symbol's equaliser and the publishing of its cells, and -- as the home stream of the cells' twins -- what a
+    // consumer (t2gpu_ti_push) goes on doing with them. Both at the highest priority: the runtime keeps the hardware queues of a priority
+    // to itself, so no launch of theirs ever waits in a queue behind a decode of milliseconds (t2gpu_ldpc_submit: default priority).
+    hipStream_t stream = nullptr, eq_stream = nullptr;
     hipEvent_t ev_fft = nullptr, ev_eq[2] = {nullptr, nullptr};
     bool eq_busy[2] = {false, false};  // ev_eq[k] has been recorded: buffer set k's last equaliser / publishing launches may still run
     // results by the device's own stores and sequence words the host reads: h_flag[0] behind the floats (seq), h_flag[16] behind the cells (seq_b)
@@ -120,6 +124,7 @@ void free_all(t2gpu_demod *h)
     }
     if (h->ev_fft) hipEventDestroy(h->ev_fft);
     if (h->eq_stream) hipStreamDestroy(h->eq_stream);
+    if (h->stream) hipStreamDestroy(h->stream);
     hipHostFree(h->h_small);
     if (h->h_flag) hipHostFree(h->h_flag);
     hipFree(h->d_count);
@@ -235,7 +240,7 @@ bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_
 // the symbol's two synchronisation floats and (cp != null) its guard correlation, stored by sym_sync_kernel; seq = the launch's word
 bool sync_results(t2gpu_demod *h, unsigned seq, float *cp, float *sv)
 {
-    if (!wait_word(h, h->h_flag, seq, nullptr)) return false;
+    if (!wait_word(h, h->h_flag, seq, h->stream)) return false;
     if (cp) std::memcpy(cp, h->h_small, 16);
     std::memcpy(sv, h->h_small + 4, 8);
     return true;
@@ -284,10 +289,10 @@ int move_cells(t2gpu_demod *h, float *dst, const float *src, int n)
 {
     if (n <= 0 || dst == src) return 0;
     const bool overlap = src < dst + 2 * (size_t)n && dst < src + 2 * (size_t)n;
-    if (!overlap) { T2_HIP(hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr)); return 0; }
+    if (!overlap) { T2_HIP(hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream)); return 0; }
     float *tmp = h->d_bounce;
-    T2_HIP(hipMemcpyAsync(tmp, src, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr));
-    T2_HIP(hipMemcpyAsync(dst, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, nullptr));
+    T2_HIP(hipMemcpyAsync(tmp, src, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
+    T2_HIP(hipMemcpyAsync(dst, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
@@ -299,7 +304,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             t2gpu_p1_result r;
             h->prof.start();
             const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, src, &consume,
-                                                 signal_->p1_reset, &r, nullptr);
+                                                 signal_->p1_reset, &r, h->stream);
             h->prof.stop(PF_P1);
             if (det < 0) return -1;
             if (det == 1) {
@@ -348,23 +353,23 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // this symbol's buffer set; the launches that used it two symbols ago (equaliser, publishing: eq_stream) are through before the
         // FFT writes into it -- long since, as a rule
         const int k = h->cur ^= 1;
-        if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(nullptr, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
-        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec[k], 1, nullptr) != 0)
+        if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
+        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec[k], 1, h->stream) != 0)
             return -1;
+        T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         // guard correlation (:321-327) and the symbol's two synchronisation floats, from the pilots alone: one launch, stored to the host
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
         const unsigned seq_a = ++h->seq;
         if (t2gpu_sym_sync_dev(kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_spec[k], have_cp ? h->d_buffer_sym : nullptr,
-                               h->guard_interval_size, nullptr, nullptr, h->h_small, h->h_flag, seq_a, nullptr) != 0) return -1;
+                               h->guard_interval_size, nullptr, nullptr, h->h_small, h->h_flag, seq_a, h->stream) != 0) return -1;
         h->prof.stop(PF_CP);
         h->est_chunk = 0;
         ++h->symbols;
         float sv[2] = {0.0f, 0.0f};                                                 // phase_est, sample_rate_est of this symbol
-        // ---- the symbol demodulators (:343-427)
+        // ---- the symbol demodulators (:343-427): the equaliser on eq_stream, behind the FFT and beside whatever the chain does next (the
+        // next chunk's front end); the cells to the host by a launch behind it
+        T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
-            // the equaliser beside whatever the null stream does next (the next chunk's front end): eq_stream, behind the FFT
-            T2_HIP(hipEventRecord(h->ev_fft, nullptr));
-            T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[k], h->d_symidx + h->idx_symbol, 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
             unsigned seq_cells = 0;
@@ -386,12 +391,14 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             }
         } else if (h->next_symbol_type == SYMBOL_TYPE_FC) {
             if (flush_data_signal(h) != 0) return -1;
-            if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, nullptr) < 0) return -1;
+            if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
-            const unsigned seq_cells = carry ? publish_cells(h, k, h->n_fc, nullptr) : 0;
+            const unsigned seq_cells = carry ? publish_cells(h, k, h->n_fc, h->eq_stream) : 0;
             if (carry && !seq_cells) return -1;
+            T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
+            h->eq_busy[k] = true;
             if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
-            if (carry && !wait_word(h, h->h_flag + 16, seq_cells, nullptr)) return -1;
+            if (carry && !wait_word(h, h->h_flag + 16, seq_cells, h->eq_stream)) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             if (carry) h->sig.data(h->sig.user, h->n_fc, h->h_cells[k]);
             h->next_symbol_type = SYMBOL_TYPE_P1;
@@ -399,9 +406,12 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         } else {                                                                    // SYMBOL_TYPE_P2
             if (flush_data_signal(h) != 0) return -1;
             h->idx_symbol = 0;
-            if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, nullptr) < 0) return -1;
-            const unsigned seq_cells = publish_cells(h, k, h->c_p2, nullptr);
-            if (!seq_cells || !sync_results(h, seq_a, have_cp ? cp : nullptr, sv) || !wait_word(h, h->h_flag + 16, seq_cells, nullptr)) return -1;
+            if (t2gpu_eq_p2_execute_dev(h->p2_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
+            const unsigned seq_cells = publish_cells(h, k, h->c_p2, h->eq_stream);
+            if (!seq_cells) return -1;
+            T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
+            h->eq_busy[k] = true;
+            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv) || !wait_word(h, h->h_flag + 16, seq_cells, h->eq_stream)) return -1;
             const float *c = h->h_cells[k];
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.start();
@@ -493,13 +503,16 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
         ok = ok && hipEventCreateWithFlags(&h->ev_eq[k], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&h->ev_fft, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&h->eq_stream, hipStreamNonBlocking) == hipSuccess;
+    int prio_least = 0, prio_greatest = 0;
+    ok = ok && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&h->eq_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 128, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) h->h_flag[0] = h->h_flag[16] = 0;
-    for (int k = 0; ok && k < 2; ++k) twin_publish(h->h_cells[k], h->d_cells[k], (size_t)32768 * 8, device, false);   // what the signals hand on is still on the device
+    for (int k = 0; ok && k < 2; ++k) twin_publish(h->h_cells[k], h->d_cells[k], (size_t)32768 * 8, device, false, h->eq_stream);   // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;
@@ -566,9 +579,9 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     h->prof.start();
     // in stream order ahead of the kernels that read them; the caller's buffers are free when this call returns (it ends with
     // t2gpu_front_state, which waits for everything launched here). From page-locked buffers (t2gpu_host_pin) the copies do not block.
-    struct drain_on_error { bool armed = true; ~drain_on_error() { if (armed) hipStreamSynchronize(nullptr); } } drain;   // an early return leaves no copy in flight
-    T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, nullptr));
-    T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, nullptr));
+    struct drain_on_error { hipStream_t s; bool armed = true; ~drain_on_error() { if (armed) hipStreamSynchronize(s); } } drain{h->stream};   // an early return leaves no copy in flight
+    T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, h->stream));
+    T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, h->stream));
     h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {
@@ -593,7 +606,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             cap = SYM_BUF_CELLS - h->idx_buffer_sym;
         }
         const long n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
-                                                   h->d_q + (size_t)idx_in * h->stride, dst, cap, nullptr, nullptr);
+                                                   h->d_q + (size_t)idx_in * h->stride, dst, cap, nullptr, h->stream);
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
@@ -603,7 +616,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     if (flush_data_signal(h) != 0) return -1;
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
-    if (t2gpu_front_commit_iq(h->front, nullptr) != 0) return -1;
+    if (t2gpu_front_commit_iq(h->front, h->stream) != 0) return -1;
     h->state_pending = true;
     // wait for the commit only when something of this call still needs it: the gain decision below, or the caller's I/Q buffers (their
     // copies are in stream order ahead of every symbol's kernels: a call that has read a symbol's results knows they are through)

@@ -241,6 +241,11 @@ struct t2gpu_ti {
     float *d_in = nullptr, *d_out = nullptr;   // host-call staging
     // t2gpu_ti_push_async: the complete block's copy down is on its way (side stream, behind `fixed`); t2gpu_ti_wait ends it
     hipEvent_t fixed = nullptr, down = nullptr;
+    // d_out holds the image of this host buffer plus whatever an abandoned block (t2gpu_ti_begin in the middle of one: a block that does
+    // not complete inside its T2 frame) scattered over it -- which is what the reference's A / B buffer holds then
+    const float *res_host = nullptr;
+    bool abandoned = false;
+    hipStream_t blk_stream = nullptr;          // where the pushes of the block in the making put their launches (the cells' twin's home stream)
     float *down_out = nullptr;
     size_t down_bytes = 0;
     std::map<int, std::pair<std::vector<int32_t>, std::vector<uint8_t>>> geom;   // num_blocks -> (order, lost)
@@ -289,6 +294,7 @@ extern "C" int t2gpu_ti_begin(t2gpu_ti *h, int num_blocks)
     if (!h || num_blocks < 1 || num_blocks > h->num_blocks_max) { set_error("t2gpu_ti_begin: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     const bool loaded = h->num_blocks == num_blocks;       // the device tables of this geometry are already in place
+    if (h->pos != 0) h->abandoned = true;
     h->num_blocks = num_blocks; h->pos = 0;
     h->p.cols = 5 * num_blocks;
     h->p.ti_block_size = h->p.cols * h->p.rows;
@@ -452,32 +458,42 @@ extern "C" int t2gpu_ti_push_async(t2gpu_ti *h, const float *cells, int n_cells,
     // complete -- not with every OFDM symbol (60 round trips of 13 MB per 32K frame in rounds 1-3: 0.9 ms per symbol, three quarters of
     // the slot-shaped path's time). Between those two moments `out` is not touched.
     // (`out` handed back unmodified from the previous block of this handle: its twin IS d_out, nothing to bring up)
+    // cells straight from an equaliser's output (t2gpu_demod / t2gpu_eq_*_execute): they are still on the device. The scatter reads them
+    // there after this call has returned: it goes to the stream their producer writes them on (the twin's home stream), so that the
+    // producer's next pass over that buffer comes behind it. A block whose pushes change stream half way waits for what it has launched.
+    hipStream_t s = nullptr;
+    const float *d_cells = static_cast<const float *>(twin_lookup(cells, (size_t)n_cells * 8, h->device, &s));
+    if (!d_cells) s = nullptr;
+    if (h->pos != 0 && s != h->blk_stream) T2_HIP(hipStreamSynchronize(h->blk_stream));
+    h->blk_stream = s;
     if (h->pos == 0) {
-        if (twin_lookup(out, blk, h->device) != h->d_out) T2_HIP(hipMemcpyAsync(h->d_out, out, blk, hipMemcpyHostToDevice, nullptr));
+        // (a block abandoned half way -- CFG-A's 878 cells behind the frame's TI block start one that the next frame's start discards --
+        // leaves d_out as the reference's buffer is left: the old block with those cells scattered over it. It is not brought up again.)
+        const bool resident = twin_lookup(out, blk, h->device) == h->d_out || (h->abandoned && out == h->res_host && handoff_on());
+        if (!resident) T2_HIP(hipMemcpyAsync(h->d_out, out, blk, hipMemcpyHostToDevice, s));
         twin_retire_dev(h->d_out, cap);                                         // from here on d_out is a block in the making, nobody's twin
+        h->res_host = out; h->abandoned = false;
     }
-    // cells straight from an equaliser's output (t2gpu_demod / t2gpu_eq_*_execute): they are still on the device
-    const float *d_cells = static_cast<const float *>(twin_lookup(cells, (size_t)n_cells * 8, h->device));
     if (!d_cells) {
-        T2_HIP(hipMemcpyAsync(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, nullptr));
+        T2_HIP(hipMemcpyAsync(h->d_in, cells, (size_t)n_cells * 8, hipMemcpyHostToDevice, s));
         d_cells = h->d_in;
     }
-    int done = t2gpu_ti_push_dev(h, d_cells, n_cells, h->d_out, nullptr);
+    int done = t2gpu_ti_push_dev(h, d_cells, n_cells, h->d_out, s);
     if (done < 0) return -1;
     if (done == 1) {
-        // the block comes down on the device's side stream, behind the scatter / fix-up launches of the null stream: 13 MB at the link's
-        // rate (235 us) that the null stream -- the caller's next symbols -- does not wait for
+        // the block comes down on the device's side stream, behind the scatter / fix-up launches: 13 MB at the link's rate (235 us)
+        // that the pushes' stream -- the caller's next symbols -- does not wait for
         hipStream_t side = side_stream(h->device);
         if (!side) return -1;
         if (!h->fixed) T2_HIP(hipEventCreateWithFlags(&h->fixed, hipEventDisableTiming));
         if (!h->down) T2_HIP(hipEventCreateWithFlags(&h->down, hipEventDisableTiming));
-        T2_HIP(hipEventRecord(h->fixed, nullptr));
+        T2_HIP(hipEventRecord(h->fixed, s));
         T2_HIP(hipStreamWaitEvent(side, h->fixed, 0));
         T2_HIP(hipMemcpyAsync(out, h->d_out, blk, hipMemcpyDeviceToHost, side));
         T2_HIP(hipEventRecord(h->down, side));
         h->down_out = out; h->down_bytes = blk;
     }
-    if (d_cells == h->d_in) T2_HIP(hipStreamSynchronize(nullptr));              // `cells` is the caller's again
+    if (d_cells == h->d_in) T2_HIP(hipStreamSynchronize(s));                    // `cells` is the caller's again
     return done;
 }
 

@@ -437,12 +437,12 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     T2_HIP(hipSetDevice(h->device));
     if (!h->a_ready) {
         // (a_ready only once everything is there: a call that failed half way starts over instead of running on null buffers)
-        // lowest priority: the runtime keeps a separate set of hardware queues per priority, so these streams never share a queue with the
-        // null stream -- a decode of milliseconds in the queue the per-symbol kernels of the caller go through would hold every one of
-        // them up (seen in rocprofv3: the second batch's copy, on the null stream, waited for the first batch's kernel)
-        int prio_least = 0, prio_greatest = 0;
-        T2_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        if (!h->a_stream) T2_HIP(hipStreamCreateWithPriority(&h->a_stream, hipStreamNonBlocking, prio_least));
+        // Default priority, and everything short that must never sit behind a decode of milliseconds in a shared hardware queue -- the
+        // caller's per-symbol launches (t2gpu_demod's streams), the side stream -- at the HIGHEST: the runtime keeps a separate set of
+        // hardware queues per priority. (Rounds 4-5 had it the other way round, decodes at the lowest priority under a default-priority
+        // null stream: with waves of a lowest-priority queue resident, every launch of any other queue took ~45 us instead of ~6
+        // (tools/small_kernel_beside_submits.py) -- half of the slot-shaped path's time while a frame's batches were being decoded.)
+        if (!h->a_stream) T2_HIP(hipStreamCreateWithFlags(&h->a_stream, hipStreamNonBlocking));
         if (!h->a_done) T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
         if (!h->p_in) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
         if (!h->p_out) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_out), (size_t)h->max_frames * h->g.k, hipHostMallocDefault));

@@ -87,6 +87,6 @@ if len(p1) >= 3 and len(fft) > 130:
     slow = sorted(zip(fr[:-1], fr[1:]), key=lambda xy: xy[0][1] - xy[1][1])[:3]
     for x, y in slow:
         print("   --- a %.1f us symbol:" % ((y[1] - x[1]) / 1e3))
-        ops = [(r[0], r[1], r[2], r[3]) for r in k if x[1] <= r[1] < y[1]] + [("copy " + r[0], r[1], r[2], -1) for r in copies if x[1] <= r[1] < y[1]]
+        ops = [(r[0], r[1], r[2], r[3]) for r in k if r[1] < y[1] and r[2] > x[1]] + [("copy " + r[0], r[1], r[2], -1) for r in copies if r[1] < y[1] and r[2] > x[1]]
         for r in sorted(ops, key=lambda q: q[1]):
             print("      +%8.1f us  %7.1f us  stream %3s  %s" % ((r[1] - x[1]) / 1e3, (r[2] - r[1]) / 1e3, r[3], (r[0] or "(unnamed)").split("(")[0][-50:]))
