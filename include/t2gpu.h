@@ -425,7 +425,9 @@ int t2gpu_front_set_iq(t2gpu_front *h, float c1, float c2); /* c1 / c2 as a prev
  * to the sign statistics; t2gpu_front_commit_iq at the end of the execute() derives c1 / c2 / level_detect from all of them
  * (:227-235) for the NEXT execute(), as the reference does. hold = 0 (default): every call is an execute() of its own. */
 int t2gpu_front_hold_iq(t2gpu_front *h, int hold);
-/* a call of up to about two OFDM symbols' worth of samples runs as ONE launch (default); 0 keeps the five launches of longer calls: same values (tests) */
+/* a call of up to 98 304 samples (about three 32K symbols) whose resampling ratio gives one or two cells per sample runs as ONE launch
+ * with one pass per workgroup (default); 0 keeps the five launches of longer calls. Same NCO phases, Farrow positions and output counts
+ * bit for bit; the cells agree to the last bits of the dc averager's double-precision scan (1e-6; both within 2e-6 of the reference). */
 int t2gpu_front_set_chain(t2gpu_front *h, int on);
 int t2gpu_front_commit_iq(t2gpu_front *h, void *stream);
 /* nominal resample = sample_rate / (SAMPLE_RATE * 2) and its limit (+100 ppm), as :54-55 computes them */
@@ -442,7 +444,9 @@ int t2gpu_front_state(t2gpu_front *h, float *out8);
 /* intermediate streams of the last call, for tests: which 0 = de-rotated samples (n_in cells), 1 = resampled (before the
  * decimator). Synchronises. Returns the number of cells copied. Since t2gpu_front_execute runs the Farrow stage and the decimator
  * as one kernel, stream 1 holds real data in its last 63 cells only (what the next call starts from); its length is right, the
- * cells before are whatever the buffer held. t2gpu_farrow_execute is the way to look at resampled cells. */
+ * cells before are whatever the buffer held. t2gpu_farrow_execute is the way to look at resampled cells. Stream 0 exists behind a call
+ * of the five launches only (t2gpu_front_set_chain(h, 0), or a call too long for the one-launch form): in the one-launch form the
+ * de-rotated samples never leave the workgroups. */
 long t2gpu_front_debug_stream(t2gpu_front *h, int which, float *out, long cap_cells);
 
 /* Stand-alone stages with the call shape of the reference classes (host buffers; state kept in the handle):

@@ -49,20 +49,22 @@ void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_f
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 
-// One launch for a short call (front_kernels.hip: front_chain_kernel). front_chain_grid: the grid such a call needs, or 0 when the call
-// does not qualify (too long, too many runs, not the whole chain). bar: a device counter of the front end's own, zero at creation;
-// target: what it has been raised to by the launches before this one (each adds 3 x grid).
-constexpr int FRONT_CHAIN_MAX_GRID = 96, FRONT_CHAIN_RUNS = 24;
-struct FrontChainArgs {
+// One launch, one pass per workgroup for a short call (front_kernels.hip: front_one_kernel). front_one_grid: the grid such a call needs,
+// or 0 when the call does not qualify (too long, too many runs, not the whole chain, a resampling ratio outside [1/2, 1]).
+// flags / rec / done: device words of the front end's own, zero at creation; seq: this call's number (> 0, growing); done_target: what
+// `done` has been raised to by the launches before this one (each adds its grid). pre_out: 66 cells of scratch.
+constexpr int F1_B = 1024, F1_PER = 4, F1_H = 128, F1_MAX_GRID = 96, F1_WCAP = 2304, FRONT_CHAIN_RUNS = 24;
+struct FrontOneArgs {
     FrontParams p;
-    unsigned long long *bar, target;
-    int *error;                                // set when a grid barrier of the chain gave up (t2gpu_front_state reports it)
-    int fd_blocks;
+    unsigned long long seq, done_target;
+    unsigned long long *flags, *done;          // [F1_MAX_GRID], [1]
+    double *rec;                               // [F1_MAX_GRID][16]
+    float2 *pre_out;                           // [3 + 63]
+    int *error;                                // set when a look-back wait gave up (t2gpu_front_state reports it)
     FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs, then Farrow runs
 };
-int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs);
-int front_chain_capacity();                    // the largest grid the current device keeps resident for it (<= FRONT_CHAIN_MAX_GRID)
-void launch_front_chain(FrontChainArgs &a, int grid, hipStream_t stream);
+int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs);
+void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream);
 
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
 // sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).

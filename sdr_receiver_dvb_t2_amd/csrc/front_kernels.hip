@@ -519,68 +519,284 @@ __device__ __forceinline__ void front_finish_body(const FrontParams &p)
 }
 __global__ __launch_bounds__(256) void front_finish_kernel(FrontParams p) { front_finish_body(p); }
 
-// ---- the whole chain of one SHORT call in one launch (a symbol's worth of samples: the slot-shaped path hands the front end one
-// chunk per OFDM symbol and waits for its result, so the five launches above -- each a few microseconds of work -- and the copy of
-// the run tables were most of that path's time). The workgroups run the same bodies phase after phase with a barrier across the
-// grid in between; the grid is small (<= FRONT_CHAIN_MAX_GRID workgroups, all resident at once). Same values as the five launches:
-// the level-2 scan is evaluated by every workgroup for itself in front_dc_scan_kernel's order (one block per lane, the same shuffles).
-// The run tables travel in the kernel arguments.
-// Grid barrier of the chain: every workgroup's stores of the phase before it are written back (agent-scope RELEASE ahead of its arrival),
-// every workgroup reads the next phase's inputs behind an agent-scope ACQUIRE (rounds 4: a full __threadfence() on either side, i.e.
-// a second L2 write-back and a second L1 invalidate per barrier, ~3.5 us each on gfx950). The wait is bounded: a counter that never
-// reaches its target (a launch that was refused after the host had advanced its count, workgroups that are not co-resident) ends in
-// the error word instead of a hung device.
-__device__ __forceinline__ void chain_barrier(unsigned long long *bar, unsigned long long target, int *error)
+// ---- a SHORT call in ONE launch and ONE pass per workgroup (a symbol's worth of samples: the slot-shaped path hands the front end one
+// chunk per OFDM symbol and waits for what follows from it, so this kernel's duration is on that path's critical path once per symbol).
+// Round 4 ran the five kernels' bodies phase after phase with three barriers across the grid (36 us per 32K symbol: the barriers, a
+// 16-step chain of double-precision operations per lane in the de-rotation, the de-rotated stream through memory). Here a workgroup
+// takes F1_B = 1024 input samples (four per lane) and does everything for them: dc aggregate -> the averager's value at its first sample
+// from the workgroups before it (their aggregates arrive through agent-scope flags: a look-back, no barrier; a workgroup only ever waits
+// for LOWER-numbered ones, which were dispatched before it) -> de-rotation into LDS, with the F1_H samples before its own re-derived
+// (they feed the Farrow / decimator windows that reach back across the workgroup's border) -> Farrow into the decimator's window in LDS
+// -> the decimator's outputs that COMPLETE inside its samples. The last workgroup to finish sums the sign statistics and carries the
+// state. NCO phases, Farrow positions and every Farrow / decimator operation are those of the five launches (the same functions on the
+// same values); the dc averager's linear recurrence is composed in a different order (per 1024 samples here, per 4096 there), so the
+// de-rotated samples agree with the five launches to the last bits of a double -- and both with the reference's float IIR to 2e-6
+// (tests/test_front_gpu.py).
+__device__ __forceinline__ Lin lin_of(const float *xr, const float *xi, int valid)
 {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long t0 = 0;
-        for (unsigned spins = 1; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-            if ((spins & 0xfffu) == 0) {                       // the clock only now and then: reading it costs more than a poll
-                const long long now = wall_clock64();
-                if (!t0) t0 = now;
-                else if (now - t0 > 200000000LL) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
-            }
-            __builtin_amdgcn_s_sleep(1);
+    Lin l{1.0, 0.0, 0.0};
+    for (int k = 0; k < F1_PER; ++k)
+        if (k < valid) { l.a *= (1.0 - DC_ALPHA); l.re = (1.0 - DC_ALPHA) * l.re + DC_ALPHA * (double)xr[k]; l.im = (1.0 - DC_ALPHA) * l.im + DC_ALPHA * (double)xi[k]; }
+    return l;
+}
+__device__ __forceinline__ void load4(const FrontParams &p, long s, int valid, float *xr, float *xi)
+{
+    if (p.stride == 1 && valid == F1_PER && ((((uintptr_t)p.i_in | (uintptr_t)p.q_in) & 7) == 0)) {
+        const short4 vi = *reinterpret_cast<const short4 *>(p.i_in + s), vq = *reinterpret_cast<const short4 *>(p.q_in + s);
+        xr[0] = (float)vi.x * p.short_to_float; xr[1] = (float)vi.y * p.short_to_float; xr[2] = (float)vi.z * p.short_to_float; xr[3] = (float)vi.w * p.short_to_float;
+        xi[0] = (float)vq.x * p.short_to_float; xi[1] = (float)vq.y * p.short_to_float; xi[2] = (float)vq.z * p.short_to_float; xi[3] = (float)vq.w * p.short_to_float;
+    } else {
+        for (int k = 0; k < F1_PER; ++k) {
+            const long j = (s + k) * p.stride;
+            xr[k] = k < valid ? (float)p.i_in[j] * p.short_to_float : 0.0f;
+            xi[k] = k < valid ? (float)p.q_in[j] * p.short_to_float : 0.0f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __syncthreads();
+}
+// front_derotate_body's loop for a lane's (up to) four consecutive samples from sample s on; (dre, dim): the averager's value before s
+__device__ __forceinline__ void derot4(const FrontParams &p, float c1, float c2, long s, int valid, const float *xr, const float *xi, double dre, double dim,
+                                       float2 *dst, double *t, float2 *pre_out)
+{
+    int r = valid ? find_run(p.nco_runs, p.n_nco_runs, s) : 0;
+    for (int k = 0; k < valid; ++k) {
+        const long i = s + k;
+        dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
+        dim = dim + DC_ALPHA * ((double)xi[k] - dim);
+        float real = sub_r(xr[k], (float)dre), imag = sub_r(xi[k], (float)dim);
+        if (t) {
+            float sgn = real < 0 ? -1.0f : 1.0f;                                // est_1_bit_quantization, :256-265
+            t[0] -= (double)mul_r(imag, sgn);
+            t[1] += (double)mul_r(real, sgn);
+            sgn = imag < 0 ? -1.0f : 1.0f;
+            t[2] += (double)mul_r(imag, sgn);
+        }
+        real = mul_r(real, c2);                                                 // :184-185
+        imag = add_r(imag, mul_r(c1, real));
+        while (r + 1 < p.n_nco_runs && p.nco_runs[r + 1].i0 <= i) ++r;
+        const FrontRun run = p.nco_runs[r];
+        const float fnco = (float)(run.base + (double)(i - run.i0) * run.step); // frequency_nco for this sample (exact)
+        const float off = wrap_2pi(sub_r(fnco, run.aux));                       // :194-200
+        const int li = (int)(off * K_TABLE + 32767) & 65535;                    // fast_math.h:47-58
+        const float nr = p.lut_cos[li], ni = p.lut_sin[li];
+        const float2 v = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
+        dst[k] = v;
+        if (pre_out && i >= (long)p.n - 3) pre_out[i - ((long)p.n - 3)] = v;     // delay_data_3,2,1 of the next call
+    }
+}
+// index of the first resampled cell input sample i produces (i == n: one past the call's last)
+__device__ __forceinline__ long first_out_of(const FrontParams &p, long i)
+{
+    if (i >= p.n) return p.n_interp;
+    const FrontRun run = p.far_runs[p.n_far_runs == 1 ? 0 : find_run(p.far_runs, p.n_far_runs, i)];
+    return (long)run.o0 + (i - run.i0) * run.cnt;
 }
 
-__global__ __launch_bounds__(256) void front_chain_kernel(FrontChainArgs a)
+__global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
 {
     __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS];
     __shared__ Lin wave_tot[4];
-    __shared__ double sh_start[2], sh_new_dc[2];
-    const int tid = threadIdx.x, bid = (int)blockIdx.x;
-    const unsigned long long G = gridDim.x;
+    __shared__ Lin sh_a1;
+    __shared__ double sh_rec[F1_MAX_GRID][4];                  // the aggregates of the workgroups before this one: a, re, im
+    __shared__ double sh_v[8];                                 // S (re, im), M (re, im), c1, c2, the last workgroup's part of the new dc
+    __shared__ double red[3][4];
+    __shared__ int sh_last;
+    __shared__ float2 D[F1_H + F1_B];                          // de-rotated samples s0 - F1_H .. s0 + F1_B - 1
+    __shared__ float2 W[F1_WCAP + F1_WCAP / 8 + 8];            // the decimator's window, padded as front_farrow_decimate_body pads it
+    const int tid = threadIdx.x, b = (int)blockIdx.x, nb = (int)gridDim.x;
     FrontParams p = a.p;
     for (int t = tid; t < p.n_nco_runs + p.n_far_runs; t += 256) sh_runs[t] = a.runs[t];
     p.nco_runs = sh_runs; p.far_runs = sh_runs + p.n_nco_runs;
+    const long s0 = (long)b * F1_B;
+    // ---- own samples, their aggregate, the look-back
+    float xr[F1_PER], xi[F1_PER];
+    const long sl = s0 + (long)tid * F1_PER;
+    const int valid = (int)min((long)F1_PER, max(0L, (long)p.n - sl));
+    load4(p, sl, valid, xr, xi);
+    Lin total;
+    const Lin ex = block_scan_exclusive<4>(lin_of(xr, xi, valid), wave_tot, &total);
+    if (tid == (F1_B - F1_H) / F1_PER) sh_a1 = ex;             // the aggregate of the samples before the last F1_H: what the next workgroup starts its halo from
+    if (b == 0 && tid == 0) { sh_v[0] = p.state->dc_re; sh_v[1] = p.state->dc_im; sh_v[4] = (double)p.state->c1; sh_v[5] = (double)p.state->c2; }
     __syncthreads();
-    if (bid < p.n_blocks) front_dc_block_body(p, bid);
-    chain_barrier(a.bar, a.target + G, a.error);
-    {   // front_dc_scan_kernel with one block per lane (n_blocks <= 256): lane t composes the identity with block t's aggregate
-        Lin l{1.0, 0.0, 0.0};
-        if (tid < p.n_blocks) { const double4 v = *reinterpret_cast<const double4 *>(p.blk + 4 * dc_slot(tid, 1)); l = compose(l, Lin{v.x, v.y, v.z}); }
-        Lin total;
-        const Lin ex = block_scan_exclusive<4>(l, wave_tot, &total);
-        const double s_re = p.state->dc_re, s_im = p.state->dc_im;
-        if (tid == bid) { sh_start[0] = ex.a * s_re + ex.re; sh_start[1] = ex.a * s_im + ex.im; }
-        if (tid == 0) { sh_new_dc[0] = total.a * s_re + total.re; sh_new_dc[1] = total.a * s_im + total.im; }
+    if (tid == 0) {
+        double *rec = a.rec + 16 * (size_t)b;
+        rec[0] = total.a; rec[1] = total.re; rec[2] = total.im; rec[3] = sh_a1.a; rec[4] = sh_a1.re; rec[5] = sh_a1.im;
+        if (b == 0) { rec[6] = sh_v[0]; rec[7] = sh_v[1]; rec[8] = sh_v[4]; rec[9] = sh_v[5]; }   // the state as block 0 found it: nobody else reads it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(a.flags + b, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b > 0) {
+        if (tid < b) {
+            long long t0 = 0;
+            for (unsigned spins = 1; __hip_atomic_load(a.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq; ++spins) {
+                if ((spins & 0xfffu) == 0) {
+                    const long long now = wall_clock64();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > 200000000LL) { __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const double *rec = a.rec + 16 * (size_t)tid;
+            sh_rec[tid][0] = rec[0]; sh_rec[tid][1] = rec[1]; sh_rec[tid][2] = rec[2];
+            if (tid == b - 1) { sh_v[2] = rec[3]; sh_v[3] = rec[4]; sh_v[6] = rec[5]; }
+            if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double re = sh_v[0], im = sh_v[1];
+            for (int k = 0; k < b - 1; ++k) { re = sh_rec[k][0] * re + sh_rec[k][1]; im = sh_rec[k][0] * im + sh_rec[k][2]; }
+            const double a1 = sh_v[2], a1re = sh_v[3], a1im = sh_v[6];
+            sh_v[2] = a1 * re + a1re; sh_v[3] = a1 * im + a1im;                 // the averager before sample s0 - F1_H
+            sh_v[0] = sh_rec[b - 1][0] * re + sh_rec[b - 1][1]; sh_v[1] = sh_rec[b - 1][0] * im + sh_rec[b - 1][2];   // ... before sample s0
+        }
         __syncthreads();
     }
-    if (bid < p.n_blocks) front_derotate_body(p, bid, sh_start);
-    chain_barrier(a.bar, a.target + 2 * G, a.error);
-    if (bid < a.fd_blocks) front_farrow_decimate_body(p, bid);
-    chain_barrier(a.bar, a.target + 3 * G, a.error);
-    if (bid == 0) {
-        front_finish_body(p);
-        if (tid == 0) { p.state->dc_re = sh_new_dc[0]; p.state->dc_im = sh_new_dc[1]; }
+    const float c1 = (float)sh_v[4], c2 = (float)sh_v[5];
+    // ---- de-rotation: own samples (sign statistics, the next call's delay line), then the halo by the first half of wavefront 0
+    double t[3] = {0.0, 0.0, 0.0};
+    derot4(p, c1, c2, sl, valid, xr, xi, ex.a * sh_v[0] + ex.re, ex.a * sh_v[1] + ex.im, D + F1_H + tid * F1_PER, t, a.pre_out);
+    if (tid < 64) {
+        if (b > 0) {
+            const long hs = s0 - F1_H + (long)tid * F1_PER;
+            const int hv = tid < F1_H / F1_PER ? F1_PER : 0;
+            float hr[F1_PER], hi[F1_PER];
+            load4(p, hv ? hs : 0, hv, hr, hi);
+            Lin v = lin_of(hr, hi, hv);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const Lin o = shfl_up_lin(v, d);
+                if (tid >= d) v = compose(o, v);
+            }
+            Lin e = shfl_up_lin(v, 1);
+            if (tid == 0) e = Lin{1.0, 0.0, 0.0};
+            if (hv) derot4(p, c1, c2, hs, hv, hr, hi, e.a * sh_v[2] + e.re, e.a * sh_v[3] + e.im, D + tid * F1_PER, nullptr, nullptr);
+        } else if (tid < 3) {
+            D[F1_H - 3 + tid] = p.derot[tid];                                   // the delay line the call before left
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { t[0] += __shfl_down(t[0], d, 64); t[1] += __shfl_down(t[1], d, 64); t[2] += __shfl_down(t[2], d, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = t[0]; red[1][tid >> 6] = t[1]; red[2][tid >> 6] = t[2]; }
+    // ---- the decimator outputs this workgroup completes, their window
+    const long o_b = first_out_of(p, s0), o_e = first_out_of(p, min(s0 + (long)F1_B, (long)p.n));
+    const long k_lo = (o_b + p.decim_phase) >> 1, k_hi = (o_e + p.decim_phase) >> 1;
+    const int n_k = (int)(k_hi - k_lo);
+    const long m0 = 2 * k_lo + (1 - p.decim_phase);                             // buffer index (63-cell prefix included) of the window's first cell
+    for (int w = tid; w < 63 && m0 + w < 63; w += 256) W[fd_pad(w)] = p.interp[m0 + w];   // cells the call before left
+    __syncthreads();
+    if (tid == 0) {
+        double *o = p.theta_part + 4 * (long)b;
+        for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
+    }
+    // ---- Farrow (front_farrow_kernel's arithmetic) for the inputs from the owner of the window's first cell to the workgroup's last sample
+    {
+        const long oA = m0 > 63 ? m0 - 63 : 0;
+        const long i_end = min(s0 + (long)F1_B, (long)p.n);
+        long i_first = s0;
+        if (oA < o_b) {
+            const FrontRun ra = p.far_runs[p.n_far_runs == 1 ? 0 : find_run_out(p.far_runs, p.n_far_runs, oA)];
+            i_first = (long)ra.i0 + (uint32_t)(oA - ra.o0) / (uint32_t)ra.cnt;
+        }
+        const long tail_o = (long)p.n_interp - 63;
+        for (long i = i_first + tid; i < i_end; i += 256) {
+            const FrontRun run = p.far_runs[p.n_far_runs == 1 ? 0 : find_run(p.far_runs, p.n_far_runs, i)];
+            const long kk = i - run.i0;
+            float x1 = (float)(run.base + (double)kk * run.step);
+            long o = (long)run.o0 + kk * run.cnt;
+            const float delay_x = run.aux;
+            const float2 *dd = D + F1_H + (i - s0);
+            const float2 in = dd[0], d1 = dd[-1], d2 = dd[-2], d3 = dd[-3];
+            float a0[2], a1[2], a2[2], a3[2];
+            const float vin[2] = {in.x, in.y}, v1[2] = {d1.x, d1.y}, v2[2] = {d2.x, d2.y}, v3[2] = {d3.x, d3.y};
+            for (int c = 0; c < 2; ++c) {
+                const float even1 = add_r(v3[c], vin[c]), even2 = add_r(v2[c], v1[c]);
+                const float odd1 = sub_r(v3[c], vin[c]), odd2 = sub_r(v2[c], v1[c]);
+                a0[c] = sub_r(mul_r(9.0f / 16.0f, even2), mul_r(1.0f / 16.0f, even1));
+                a1[c] = sub_r(mul_r(1.0f / 8.0f, odd1), mul_r(11.0f / 8.0f, odd2));
+                a2[c] = mul_r(1.0f / 4.0f, sub_r(even1, even2));
+                a3[c] = sub_r(mul_r(3.0f / 2.0f, odd2), mul_r(1.0f / 2.0f, odd1));
+            }
+            while (x1 < 0.5f) {
+                const float x2 = mul_r(x1, x1), x3 = mul_r(x2, x1);
+                float v[2];
+                for (int c = 0; c < 2; ++c) v[c] = add_r(add_r(add_r(mul_r(a3[c], x3), mul_r(a2[c], x2)), mul_r(a1[c], x1)), a0[c]);
+                const long tw = 63 + o - m0;
+                if (tw >= 0 && tw < F1_WCAP) W[fd_pad((int)tw)] = make_float2(v[0], v[1]);
+                if (i >= s0 && o >= tail_o) a.pre_out[3 + (o - tail_o)] = make_float2(v[0], v[1]);   // the tail the next call starts from (its owner stores it)
+                ++o;
+                x1 = add_r(x1, delay_x);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- /2 decimator: front_farrow_decimate_body's stage, four consecutive outputs per lane
+    for (int g = tid; 4 * g < n_k; g += 256) {
+        const int ko = FD_R * g;
+        const long k = k_lo + ko;
+        const float2 *x = W + 2 * ko + (2 * ko >> 3);
+        float ar[FD_R][4], ai[FD_R][4];
+#pragma unroll
+        for (int r = 0; r < FD_R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ar[r][q] = 0.0f; ai[r][q] = 0.0f; }
+#pragma unroll 1
+        for (int blk = 0; blk < 4; ++blk) {
+            constexpr int NC = 16 + 2 * (FD_R - 1);
+            float2 c[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { const int m = 16 * blk + j; c[j] = x[m + (m >> 3)]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h0 = c_taps[16 * blk + q], h1 = c_taps[16 * blk + q + 4], h2 = c_taps[16 * blk + q + 8], h3 = c_taps[16 * blk + q + 12];
+#pragma unroll
+                for (int r = 0; r < FD_R; ++r) {
+                    const float2 x0 = c[q + 2 * r], x1 = c[q + 2 * r + 4], x2 = c[q + 2 * r + 8], x3 = c[q + 2 * r + 12];
+                    ar[r][q] = add_r(ar[r][q], add_r(add_r(mul_r(x0.x, h0), mul_r(x1.x, h1)), add_r(mul_r(x2.x, h2), mul_r(x3.x, h3))));
+                    ai[r][q] = add_r(ai[r][q], add_r(add_r(mul_r(x0.y, h0), mul_r(x1.y, h1)), add_r(mul_r(x2.y, h2), mul_r(x3.y, h3))));
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FD_R; ++r)
+            if (ko + r < n_k)
+                p.out[k + r] = make_float2(add_r(add_r(add_r(ar[r][0], ar[r][1]), ar[r][2]), ar[r][3]), add_r(add_r(add_r(ai[r][0], ai[r][1]), ai[r][2]), ai[r][3]));
+    }
+    // ---- the last workgroup to get here finishes the call (front_finish_kernel's work)
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned long long before = __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = before == a.done_target + (unsigned long long)nb - 1;
+        if (sh_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    // the delay lines: the last 3 de-rotated samples, the last 63 resampled cells -- from this call where it had that many, else moved up
+    float2 keep = make_float2(0.f, 0.f);
+    if (tid < 3) { const long i = (long)p.n - 3 + tid; keep = i >= 0 ? a.pre_out[tid] : p.derot[tid + p.n]; }
+    else if (tid >= 64 && tid < 64 + 63) { const long o = (long)p.n_interp - 63 + (tid - 64); keep = o >= 0 ? a.pre_out[3 + (tid - 64)] : p.interp[(tid - 64) + p.n_interp]; }
+    __syncthreads();
+    if (tid < 3) p.derot[tid] = keep;
+    else if (tid >= 64 && tid < 64 + 63) p.interp[tid - 64] = keep;
+    if (tid == 0) {
+        FrontState &s = *p.state;
+        double th[3] = {0.0, 0.0, 0.0};
+        const double *r0 = a.rec;
+        double re = r0[6], im = r0[7];
+        for (int k = 0; k < nb; ++k) {
+            const double *q = p.theta_part + 4 * (long)k, *rec = a.rec + 16 * (size_t)k;
+            th[0] += q[0]; th[1] += q[1]; th[2] += q[2];
+            re = rec[0] * re + rec[1]; im = rec[0] * im + rec[2];
+        }
+        s.dc_re = re; s.dc_im = im;
+        s.decim_phase = (int)((p.decim_phase + p.n_interp) & 1);
+        for (int c = 0; c < 3; ++c) s.theta[c] = th[c];
+        if (p.stages & FRONT_STAGE_HOLD_IQ) {
+            for (int c = 0; c < 3; ++c) s.theta_acc[c] += th[c];
+            s.n_acc += (double)p.n;
+        } else {
+            front_iq_estimate(s, th[0], th[1], th[2], (float)p.n);
+        }
     }
 }
 
@@ -634,31 +850,22 @@ static long fd_blocks_of(const FrontParams &p)
     return by_out > by_cells ? by_out : by_cells;
 }
 
-// workgroups of front_chain_kernel the current device keeps resident at once (its barrier needs the whole grid resident: a partitioned
-// device with 32 CUs holds fewer than FRONT_CHAIN_MAX_GRID)
-int front_chain_capacity()
-{
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_chain_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const long cap = (long)per_cu * prop.multiProcessorCount / 2;      // half of it: other streams' workgroups may hold the rest
-    return (int)(cap > FRONT_CHAIN_MAX_GRID ? FRONT_CHAIN_MAX_GRID : cap);
-}
-
-int front_chain_grid(const FrontParams &p, size_t n_nco_runs, size_t n_far_runs)
+// the grid of the one-launch form, or 0 when the call does not qualify: the whole chain, at most F1_MAX_GRID x F1_B samples, run tables
+// that fit the kernel's arguments, and between one and two resampled cells per input sample in every run (the window a workgroup keeps
+// in LDS and the F1_H samples of halo are sized for that: ratios up to ~1, the reference's devices)
+int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs)
 {
     const int all = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;
-    if (!T2_FRONT_FUSED || p.n <= 0 || (p.stages & all) != all || n_nco_runs + n_far_runs > (size_t)FRONT_CHAIN_RUNS) return 0;
-    const long fd = fd_blocks_of(p), g = fd > p.n_blocks ? fd : p.n_blocks;
-    return g <= FRONT_CHAIN_MAX_GRID && p.n_blocks <= 256 ? (int)g : 0;
+    if (!T2_FRONT_FUSED || p.n <= 0 || (p.stages & all) != all || n_nco_runs + n_far_runs > (size_t)FRONT_CHAIN_RUNS || n_far_runs < 1) return 0;
+    for (size_t r = 0; r < n_far_runs; ++r) if (far_runs[r].cnt < 1 || far_runs[r].cnt > 2) return 0;
+    const long g = ((long)p.n + F1_B - 1) / F1_B;
+    return g <= F1_MAX_GRID ? (int)g : 0;
 }
 
-void launch_front_chain(FrontChainArgs &a, int grid, hipStream_t stream)
+void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream)
 {
     load_taps();
-    a.fd_blocks = (int)fd_blocks_of(a.p);
-    hipLaunchKernelGGL(front_chain_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(front_one_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
 }
 
 void launch_front(const FrontParams &p, hipStream_t stream)

@@ -301,6 +301,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
     int consume = 0;
     while (consume < len_in) {
         if (h->next_symbol_type == SYMBOL_TYPE_P1) {
+            if (flush_data_signal(h) != 0) return -1;                               // (the frame's last symbol completes its TI block: not held back)
             t2gpu_p1_result r;
             h->prof.start();
             const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, src, &consume,
@@ -377,13 +378,14 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
             h->eq_busy[k] = true;
             h->prof.stop(PF_FFT_EQ);
+            // the symbol BEFORE this one hands its cells on now: everything of this symbol is on its way, the consumer's work (the
+            // de-interleaver's push: ~9 us of host time and a launch) runs beside it instead of in front of it
+            if (flush_data_signal(h) != 0) return -1;
+            h->prof.start();
             if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.stop(PF_SV);
-            if (carry) {                                                            // emitted behind the next front-end launch
-                if (flush_data_signal(h) != 0) return -1;
-                h->pending_data = h->c_data; h->pending_buf = k; h->pending_seq = seq_cells;
-            }
+            if (carry) { h->pending_data = h->c_data; h->pending_buf = k; h->pending_seq = seq_cells; }
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
                 h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
@@ -610,7 +612,6 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
-        if (flush_data_signal(h) != 0) return -1;                                   // (the front end is busy with the chunk just launched)
         if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
     if (flush_data_signal(h) != 0) return -1;

@@ -44,11 +44,11 @@ struct t2gpu_front {
     std::vector<FrontRun> dev_runs;            // what d_runs holds (nco runs, then Farrow runs)
     size_t dev_nn = 0;
     bool dev_runs_valid = false;
-    // short calls in one launch (front_kernels.hip: front_chain_kernel); t2gpu_front_set_chain(h, 0) keeps the five launches
-    unsigned long long *d_bar = nullptr, chain_count = 0;
-    int *d_chain_error = nullptr;      // raised by a grid barrier of the chain that gave up
+    // short calls in one launch (front_kernels.hip: front_one_kernel); t2gpu_front_set_chain(h, 0) keeps the five launches
+    char *d_one = nullptr;             // its flags [F1_MAX_GRID], done word, records [F1_MAX_GRID][16], scratch prefix [66]
+    unsigned long long one_seq = 0, one_done = 0;
+    int *d_chain_error = nullptr;      // raised by a look-back wait of that kernel that gave up
     bool chain_on = true;
-    int chain_cap = 0;                 // front_chain_capacity() of the handle's device
     // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
     FrontState *h_state = nullptr;
     unsigned *h_flag = nullptr, state_seq = 0;
@@ -172,12 +172,12 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         const float rk = 1.0f / k_table;
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
-    h->chain_cap = front_chain_capacity();
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocCoherent) == hipSuccess) {
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
         *h->h_flag = 0;
     }
-    bool ok = hipMalloc(&h->d_bar, 8) == hipSuccess && hipMemset(h->d_bar, 0, 8) == hipSuccess &&
+    constexpr size_t ONE_BYTES = 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID + 66 * sizeof(float2);
+    bool ok = hipMalloc(&h->d_one, ONE_BYTES) == hipSuccess && hipMemset(h->d_one, 0, ONE_BYTES) == hipSuccess &&
               hipMalloc(&h->d_chain_error, 4) == hipSuccess && hipMemset(h->d_chain_error, 0, 4) == hipSuccess &&
               hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
@@ -200,7 +200,7 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    hipFree(h->d_bar); hipFree(h->d_chain_error);
+    hipFree(h->d_one); hipFree(h->d_chain_error);
     if (h->h_state) hipHostFree(h->h_state);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
@@ -326,21 +326,25 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
     h->state_published = false;
     const size_t nn = h->nco_runs.size(), nf = h->far_runs.size();
-    int chain_grid = h->chain_on ? front_chain_grid(p, nn, nf) : 0;
-    if (chain_grid > h->chain_cap) chain_grid = 0;
-    if (chain_grid) {
-        // a symbol's worth of samples: one launch, the run tables in its arguments (no table copy, nothing to wait for)
-        FrontChainArgs a;
+    const int one_grid = h->chain_on ? front_one_grid(p, h->far_runs.data(), nn, nf) : 0;
+    if (one_grid) {
+        // a symbol's worth of samples: one launch, one pass per workgroup, the run tables in its arguments (no table copy, nothing to wait for)
+        FrontOneArgs a;
         a.p = p;
         a.p.n_nco_runs = (int)nn; a.p.n_far_runs = (int)nf;
         a.p.nco_runs = nullptr; a.p.far_runs = nullptr; a.p.nco_index = nullptr; a.p.far_index = nullptr;
         if (nn) std::memcpy(a.runs, h->nco_runs.data(), nn * sizeof(FrontRun));
         if (nf) std::memcpy(a.runs + nn, h->far_runs.data(), nf * sizeof(FrontRun));
-        a.bar = h->d_bar; a.target = h->chain_count; a.error = h->d_chain_error;
-        launch_front_chain(a, chain_grid, stream);
-        // the device's counter moves only if the launch was accepted: the host's copy follows it, not the attempt
+        a.flags = reinterpret_cast<unsigned long long *>(h->d_one);
+        a.done = reinterpret_cast<unsigned long long *>(h->d_one + 8 * (size_t)F1_MAX_GRID);
+        a.rec = reinterpret_cast<double *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64);
+        a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
+        a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
+        launch_front_one(a, one_grid, stream);
+        // the device's words move only if the launch was accepted: the host's copies follow it, not the attempt
         T2_HIP(hipGetLastError());
-        h->chain_count += 3ull * (unsigned long long)chain_grid;
+        h->one_seq += 1;
+        h->one_done += (unsigned long long)one_grid;
     } else {
         if (stage_tables(h, (int)n, stream, p) != 0) return -1;
         launch_front(p, stream);
@@ -399,7 +403,7 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
         T2_HIP(hipMemcpy(&s, h->d_state, sizeof s, hipMemcpyDeviceToHost));
         int err = 0;
         T2_HIP(hipMemcpy(&err, h->d_chain_error, 4, hipMemcpyDeviceToHost));
-        if (err) { set_error("t2gpu_front: a grid barrier of the one-launch chain timed out"); return -1; }
+        if (err) { set_error("t2gpu_front: a look-back wait of the one-launch form timed out"); return -1; }
     }
     out8[0] = (float)s.dc_re; out8[1] = (float)s.dc_im; out8[2] = s.c1; out8[3] = s.c2;
     out8[4] = h->phase_nco; out8[5] = h->frequency_nco; out8[6] = s.level_detect; out8[7] = h->x1;

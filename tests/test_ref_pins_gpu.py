@@ -355,17 +355,23 @@ def test_front_loop_against_the_reference(torch_cuda, grx):
     g = sub(grx, "front", "front")
     i16, q16, loops = rc.front_case()
     assert rc.sha(np.stack([i16, q16])) == str(g["in_sha"])
-    fe = front.front_end(max_samples=len(i16))
-    fe.set_iq(loops["c1"], loops["c2"])
-    got, _ = fe.execute(i16, q16, [len(i16)], [loops["phase_est_filtered"]], [loops["frequency_est_filtered"]])
-    der = fe.debug_stream(0, len(i16))
-    assert np.abs(der - g["derotated"]).max() < 2e-6
-    assert np.abs(got[:len(i16)] - g["decimated"][:len(got)]).max() < 3e-6
-    st, want = fe.state(), dict(zip(ol.RX_STATE, g["state"]))
-    assert np.float32(st["phase_nco"]) == np.float32(want["phase_nco"]) and np.float32(st["frequency_nco"]) == np.float32(want["frequency_nco"])
-    for k in ("c1", "c2", "level_detect"):
-        assert abs(st[k] - want[k]) <= 1e-4 * abs(want[k]), k
-    fe.close()
+    # both forms of the front end: the five launches (whose de-rotated stream is in memory to be looked at) and, for a chunk of this
+    # size, the one launch with one pass per workgroup that t2gpu_demod_execute's symbol-sized calls take (its de-rotated samples never
+    # leave the workgroups: pinned through the decimated stream behind them)
+    for one_launch in (0, 1):
+        fe = front.front_end(max_samples=len(i16))
+        assert fe._l.t2gpu_front_set_chain(fe.h, one_launch) == 0
+        fe.set_iq(loops["c1"], loops["c2"])
+        got, _ = fe.execute(i16, q16, [len(i16)], [loops["phase_est_filtered"]], [loops["frequency_est_filtered"]])
+        if not one_launch:
+            der = fe.debug_stream(0, len(i16))
+            assert np.abs(der - g["derotated"]).max() < 2e-6
+        assert np.abs(got[:len(i16)] - g["decimated"][:len(got)]).max() < 3e-6
+        st, want = fe.state(), dict(zip(ol.RX_STATE, g["state"]))
+        assert np.float32(st["phase_nco"]) == np.float32(want["phase_nco"]) and np.float32(st["frequency_nco"]) == np.float32(want["frequency_nco"])
+        for k in ("c1", "c2", "level_detect"):
+            assert abs(st[k] - want[k]) <= 1e-4 * abs(want[k]), k
+        fe.close()
 
 
 def test_whole_receiver_against_the_reference(built, grx, tmp_path):
