@@ -48,6 +48,8 @@ enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 
 void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
+// n int16 elements of I and of Q from page-locked host memory (device-visible addresses hi / hq) to di / dq, by a kernel
+void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int16_t *dq, size_t n, hipStream_t stream);
 
 // One launch, one pass per workgroup for a short call (front_kernels.hip: front_one_kernel). front_one_grid: the grid such a call needs,
 // or 0 when the call does not qualify (too long, too many runs, not the whole chain, a resampling ratio outside [1/2, 1]).

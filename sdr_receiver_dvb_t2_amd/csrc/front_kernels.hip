@@ -800,6 +800,24 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
     }
 }
 
+// ---- a buffer of int16 I and Q from PAGE-LOCKED host memory into the device's staging by a kernel of the caller's stream (the
+// slot-shaped path: two copy-engine transfers per execute() cost 12 us each and, worse, ~20 + 9 + 30 us of hand-over between the stream's
+// kernels and the copy engine on either side of them -- 85 us per 172 032-sample buffer, a whole OFDM symbol's worth)
+__global__ __launch_bounds__(256) void front_copy_in_kernel(const int16_t *__restrict__ hi, const int16_t *__restrict__ hq, int16_t *__restrict__ di,
+                                                            int16_t *__restrict__ dq, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((((uintptr_t)hi | (uintptr_t)hq | (uintptr_t)di | (uintptr_t)dq) & 15) == 0)) {
+        const size_t n8 = n / 8;
+        const uint4 *a = reinterpret_cast<const uint4 *>(hi), *b = reinterpret_cast<const uint4 *>(hq);
+        uint4 *da = reinterpret_cast<uint4 *>(di), *db = reinterpret_cast<uint4 *>(dq);
+        for (size_t i = t; i < n8; i += stride) { const uint4 x = a[i], y = b[i]; da[i] = x; db[i] = y; }
+        for (size_t i = 8 * n8 + t; i < n; i += stride) { di[i] = hi[i]; dq[i] = hq[i]; }
+    } else {
+        for (size_t i = t; i < n; i += stride) { di[i] = hi[i]; dq[i] = hq[i]; }
+    }
+}
+
 // end of an execute() whose chunks ran with FRONT_STAGE_HOLD_IQ (:227-235)
 __global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq)
 {
@@ -828,6 +846,13 @@ __global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, lo
 bool g_taps_loaded[16] = {};
 
 }  // namespace
+
+void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int16_t *dq, size_t n, hipStream_t stream)
+{
+    int grid = (int)((n / 8 + 255) / 256);
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    hipLaunchKernelGGL(front_copy_in_kernel, dim3(grid), dim3(256), 0, stream, hi, hq, di, dq, n);
+}
 
 void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream)
 {

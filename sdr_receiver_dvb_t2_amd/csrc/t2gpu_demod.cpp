@@ -10,6 +10,7 @@
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
 #include "ofdm_kernels.h"
+#include "front_kernels.h"
 
 #include <atomic>
 #include <chrono>
@@ -582,8 +583,18 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     // in stream order ahead of the kernels that read them; the caller's buffers are free when this call returns (it ends with
     // t2gpu_front_state, which waits for everything launched here). From page-locked buffers (t2gpu_host_pin) the copies do not block.
     struct drain_on_error { hipStream_t s; bool armed = true; ~drain_on_error() { if (armed) hipStreamSynchronize(s); } } drain{h->stream};   // an early return leaves no copy in flight
-    T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, h->stream));
-    T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, h->stream));
+    {
+        // page-locked buffers (t2gpu_host_pin) come over by a kernel of the chain's own stream; anything else through the copy engine
+        void *vi = nullptr, *vq = nullptr;
+        if (hipHostGetDevicePointer(&vi, const_cast<int16_t *>(i_in), 0) == hipSuccess && hipHostGetDevicePointer(&vq, const_cast<int16_t *>(q_in), 0) == hipSuccess) {
+            launch_front_copy_in(static_cast<const int16_t *>(vi), static_cast<const int16_t *>(vq), h->d_i, h->d_q, el, h->stream);
+            T2_HIP(hipGetLastError());
+        } else {
+            (void)hipGetLastError();
+            T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, h->stream));
+            T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, h->stream));
+        }
+    }
     h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {

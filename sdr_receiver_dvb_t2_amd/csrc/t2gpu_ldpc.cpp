@@ -305,8 +305,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     int grid = nslots * wg_per_batch;
     if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }
 
-    T2_HIP(hipMemsetAsync(h->d_sync, 0, (size_t)nbatches * (h->max_trials + 1) * 4, s));
-    T2_HIP(hipMemsetAsync(h->d_error, 0, 4, s));
+    T2_HIP(ldpc_clear(reinterpret_cast<unsigned *>(h->d_sync), (size_t)nbatches * (h->max_trials + 1), reinterpret_cast<unsigned *>(h->d_error), 1, s));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
     p.layers = h->d_layers; p.layer_words = reinterpret_cast<const uint4 *>(h->d_layer_words); p.entries = h->d_entries; p.entries2 = h->d_entries2p;
