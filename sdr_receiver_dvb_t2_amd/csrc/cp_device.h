@@ -22,18 +22,23 @@ __device__ __forceinline__ float atan2_approx_ref(float y, float x)             
     return r;
 }
 
-// s: the symbol's guard + fft_size cells (guard first). All 256 lanes of the workgroup call it; the value is valid in lane 0:
+// s: the symbol's guard + fft_size cells (guard first). All NL lanes of the workgroup call it (NL = 256, or 128 lanes that each stand for
+// two of the 256: the same per-lane sums and the same tree, so the same value); the value is valid in lane 0:
 // {sum.re, sum.im, frequency_est, 0}. Per-lane double sums of the float products (stride 256), folded by a tree over red[2][256].
+template <int NL = 256>
 __device__ __forceinline__ float4 cp_correlate_body(const float2 *__restrict__ s, int fft_size, int guard, double (*red)[256])
 {
+    static_assert(NL == 256 || NL == 128, "256 lanes, or 128 standing for 256");
     const float2 *cp = s + fft_size;
-    double sr = 0.0, si = 0.0;
-    for (int i = 4 + (int)threadIdx.x; i < guard - 4; i += 256) {
-        const float2 a = cp[i], b = s[i];
-        sr += (double)(a.x * b.x + a.y * b.y);                                  // cp[i] * conj(sym[i])
-        si += (double)(a.y * b.x - a.x * b.y);
+    for (int v = (int)threadIdx.x; v < 256; v += NL) {
+        double sr = 0.0, si = 0.0;
+        for (int i = 4 + v; i < guard - 4; i += 256) {
+            const float2 a = cp[i], b = s[i];
+            sr += (double)(a.x * b.x + a.y * b.y);                              // cp[i] * conj(sym[i])
+            si += (double)(a.y * b.x - a.x * b.y);
+        }
+        red[0][v] = sr; red[1][v] = si;
     }
-    red[0][threadIdx.x] = sr; red[1][threadIdx.x] = si;
     __syncthreads();
     for (int t = 128; t > 0; t >>= 1) {
         if ((int)threadIdx.x < t) { red[0][threadIdx.x] += red[0][threadIdx.x + t]; red[1][threadIdx.x] += red[1][threadIdx.x + t]; }

@@ -79,4 +79,12 @@ hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *
 hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,
                            float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s);
 
+// One symbol's FFT (the two-launch form) with launch_sym_sync's work done by the last workgroup of its second launch. count: a zeroed
+// device word of the caller's (left at zero). hipErrorInvalidValue when the pilot table of `p` does not fit the FFT's exchange buffer
+// ((max_seg + 2) x 16 + 4096 bytes of 33 792: P2 symbols, dense pilot patterns) -- the caller then takes the two entry points one after
+// the other.
+hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
+                               const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
+                               unsigned *h_flag, unsigned seq, hipStream_t s);
+
 }  // namespace t2gpu

@@ -210,12 +210,12 @@ __global__ __launch_bounds__(64) void fft_stage_a_kernel(const float2 *__restric
     for (int r = 0; r < 32; ++r) sc[bitrev<32>(r) * T + tid] = make_float2(v[r].x, v[r].y);
 }
 
+constexpr int FFT_BC_LDS_FLOATS = 32 * 8 * 33;
 template <int T2>
-__global__ __launch_bounds__(8 * T2) void fft_stage_bc_kernel(const float2 *__restrict__ scratch, float2 *__restrict__ out,
-                                                              const float2 *__restrict__ twiddle)
+__device__ __forceinline__ void fft_stage_bc_body(const float2 *__restrict__ scratch, float2 *__restrict__ out,
+                                                  const float2 *__restrict__ twiddle, float *lds /* [FFT_BC_LDS_FLOATS]: rows (q1, k1 of this workgroup) of T2 values over t1 */)
 {
     constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
-    __shared__ float lds[32 * 8 * PITCH];                      // rows (q1, k1 of this workgroup) of T2 values over t1
     const int sym = (int)blockIdx.x / 4, kb = ((int)blockIdx.x % 4) * 8;
     const int l = (int)threadIdx.x, k1l = l / T2, t1n = l % T2, k1n = kb + k1l;
     const float2 *sc = scratch + (size_t)sym * N;
@@ -267,6 +267,14 @@ __global__ __launch_bounds__(8 * T2) void fft_stage_bc_kernel(const float2 *__re
             y[(idb + 1024 * q2 + N / 2) & (N - 1)] = make_float2(b[r].x, b[r].y);
         }
     }
+}
+
+template <int T2>
+__global__ __launch_bounds__(8 * T2) void fft_stage_bc_kernel(const float2 *__restrict__ scratch, float2 *__restrict__ out,
+                                                              const float2 *__restrict__ twiddle)
+{
+    __shared__ float lds[FFT_BC_LDS_FLOATS];
+    fft_stage_bc_body<T2>(scratch, out, twiddle, lds);
 }
 
 hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, int n_symbols, int max_blocks,
@@ -703,11 +711,12 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
 // bit (tests/test_ofdm_gpu.py) -- while the equaliser runs beside the next chunk's front end. The same workgroup also forms the guard
 // correlation of the buffered symbol (symbol_acquisition, dvbt2_demodulator.cpp:321-327; cp_device.h: cp_correlate_kernel's body) and
 // stores all six floats to page-locked host memory with the sequence word behind them.
-__global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 *__restrict__ symbol, int idx_symbol,
-                                                       const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                                       float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+// NL lanes (256, or the 128 of fft_stage_bc_kernel<16>); sy_lds: (max_seg + 2) x 16 bytes, then the correlation's 2 x 256 doubles
+template <int NL>
+__device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *__restrict__ symbol, int idx_symbol,
+                                              const float2 *__restrict__ buffered, int guard, float4 *cp_out,
+                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, float *sy_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) float sy_lds[];             // [nseg + 1][4], then the correlation's 2 x 256 doubles
     __shared__ int sh_lower;
     const int tid = threadIdx.x;
     const int row = idx_symbol - p.n_p2;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 
     if (tid == 0) sh_lower = 0;
     __syncthreads();
     int lower = 0;
-    for (int k = tid; k <= nseg; k += 256) {
+    for (int k = tid; k <= nseg; k += NL) {
         const int pc = k == 0 ? segs[0].x : segs[k - 1].y;                     // entry 0: the symbol's first pilot; entry k: segment k - 1's right pilot
         const PilotEst e = pilot_estimate(cell[pc], refer[pc], 1.0f, 0);
         const bool upper = pc > p.k_total / 2;
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 
     float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (buffered) {
         double (*red)[256] = reinterpret_cast<double (*)[256]>(sy_lds + 4 * (size_t)(p.max_seg + 2));
-        cp = cp_correlate_body(buffered, p.fft_size, guard, red);               // (its barriers also publish l4 / sh_lower)
+        cp = cp_correlate_body<NL>(buffered, p.fft_size, guard, red);               // (its barriers also publish l4 / sh_lower)
     } else {
         __syncthreads();
     }
@@ -767,6 +776,58 @@ __global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 
             __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 *__restrict__ symbol, int idx_symbol,
+                                                       const float2 *__restrict__ buffered, int guard, float4 *cp_out,
+                                                       float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+{
+    extern __shared__ __attribute__((aligned(16))) float sy_lds_dyn[];
+    sym_sync_body<256>(p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, sy_lds_dyn);
+}
+
+// ---- the second launch of a ONE-symbol FFT with the symbol's synchronisation floats behind it in the same launch: the last of its four
+// workgroups to finish (a counter; its stores released, the others' acquired) runs sym_sync_body on the spectrum the four have just
+// written. One launch and one launch gap less on the slot-shaped path's per-symbol critical path. The body's LDS is the FFT's exchange
+// buffer (33 KB: pilot tables of up to FFT_SYNC_MAX_SEG segments; denser tables -- P2 -- take sym_sync_kernel).
+template <int T2>
+__global__ __launch_bounds__(8 * T2) void fft_stage_bc_sync_kernel(const float2 *__restrict__ scratch, float2 *__restrict__ out,
+                                                                   const float2 *__restrict__ twiddle, unsigned *count, EqParams p, int idx_symbol,
+                                                                   const float2 *__restrict__ buffered, int guard, float4 *cp_out,
+                                                                   float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+{
+    __shared__ __attribute__((aligned(16))) float lds[FFT_BC_LDS_FLOATS];
+    __shared__ int sh_last;
+    fft_stage_bc_body<T2>(scratch, out, twiddle, lds);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned before = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = before == gridDim.x - 1;
+        if (sh_last) { __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds);
+}
+
+hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
+                               const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
+                               unsigned *h_flag, unsigned seq, hipStream_t s)
+{
+    if ((p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_BC_LDS_FLOATS * 4 || !scratch || !count) return hipErrorInvalidValue;
+    if (fft_size == 32768) {
+        hipLaunchKernelGGL(fft_stage_a_kernel<32>, dim3(16), dim3(64), 0, s, in, scratch, twiddle, lay);
+        hipLaunchKernelGGL(fft_stage_bc_sync_kernel<32>, dim3(4), dim3(256), 0, s, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
+                           h_small, h_flag, seq);
+    } else if (fft_size == 16384) {
+        hipLaunchKernelGGL(fft_stage_a_kernel<16>, dim3(8), dim3(64), 0, s, in, scratch, twiddle, lay);
+        hipLaunchKernelGGL(fft_stage_bc_sync_kernel<16>, dim3(4), dim3(128), 0, s, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
+                           h_small, h_flag, seq);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,

@@ -356,14 +356,13 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // FFT writes into it -- long since, as a rule
         const int k = h->cur ^= 1;
         if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
-        if (t2gpu_fft_execute_strided_dev(h->p2_ofdm, h->d_buffer_sym, h->guard_interval_size, 0, 1, h->symbol_size, h->d_spec[k], 1, h->stream) != 0)
-            return -1;
-        T2_HIP(hipEventRecord(h->ev_fft, h->stream));
-        // guard correlation (:321-327) and the symbol's two synchronisation floats, from the pilots alone: one launch, stored to the host
+        // FFT (:332-334), and in its last launch the guard correlation (:321-327) and the symbol's two synchronisation floats, from the
+        // pilots alone, stored to the host with the sequence word behind them
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
         const unsigned seq_a = ++h->seq;
-        if (t2gpu_sym_sync_dev(kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_spec[k], have_cp ? h->d_buffer_sym : nullptr,
-                               h->guard_interval_size, nullptr, nullptr, h->h_small, h->h_flag, seq_a, h->stream) != 0) return -1;
+        if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
+                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small, h->h_flag, seq_a, h->stream) != 0) return -1;
+        T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         h->prof.stop(PF_CP);
         h->est_chunk = 0;
         ++h->symbols;

@@ -89,6 +89,7 @@ struct t2gpu_ofdm {
     EqParams eq{}, eq_p2{}, eq_fc{};
     float2 *d_twiddle = nullptr;
     float2 *d_fft_scratch = nullptr;   // the first exchange of the two-launch FFT of a one- or two-symbol call (ofdm_kernels.h)
+    unsigned *d_fft_count = nullptr;   // launch_fft_sym_sync's workgroup counter
     uint8_t *d_map = nullptr;
     uint16_t *d_dcar = nullptr, *d_dcar_p2 = nullptr, *d_dcar_fc = nullptr;   // carrier of every data cell, per table row
     float *d_refer = nullptr;
@@ -182,6 +183,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     };
     up(&h->d_twiddle, tw.data(), tw.size() * sizeof(float2));
     ok = ok && hip_ok(hipMalloc((void **)&h->d_fft_scratch, (size_t)FFT_WIDE_SYMBOLS * m.fft_size * sizeof(float2)), "hipMalloc");
+    ok = ok && hip_ok(hipMalloc((void **)&h->d_fft_count, 64), "hipMalloc") && hip_ok(hipMemset(h->d_fft_count, 0, 64), "hipMemset");
     up(&h->d_lut, lut.data(), lut.size() * sizeof(float2));
     up(&h->d_map, map.data(), map.size());
     up(&h->d_dcar, dcar.data(), dcar.size() * 2);
@@ -317,7 +319,7 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
 extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
 {
     if (!h) return;
-    hipFree(h->d_twiddle); hipFree(h->d_fft_scratch); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
+    hipFree(h->d_twiddle); hipFree(h->d_fft_scratch); hipFree(h->d_fft_count); hipFree(h->d_lut); hipFree(h->d_map); hipFree(h->d_refer); hipFree(h->d_segs); hipFree(h->d_seg_count);
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_pilot_scratch_p2); hipFree(h->d_pilot_scratch_fc); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
     hipFree(h->d_cellq); hipFree(h->d_cellq_p2); hipFree(h->d_cellq_fc); hipFree(h->d_sel); hipFree(h->d_sel_p2); hipFree(h->d_sel_fc);
@@ -493,6 +495,35 @@ extern "C" int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const
     T2_HIP(launch_sym_sync(p, reinterpret_cast<const float2 *>(d_spectrum), idx_symbol, reinterpret_cast<const float2 *>(d_buffered), guard,
                            reinterpret_cast<float4 *>(d_cp4), reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream));
     return 0;
+}
+
+// symbol_acquisition's guard removal + fft->execute() (dvbt2_demodulator.cpp:332-334) for ONE buffered symbol with t2gpu_sym_sync_dev's work
+// behind it: two launches where t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev are three (the synchronisation floats are formed by the
+// last workgroup of the FFT's second launch); pilot tables too large for that (P2, dense patterns) take the three. Same values either way.
+extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp,
+                                      float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream)
+{
+    if (!h || !tables || !d_buffered || !d_spectrum || kind < 0 || kind > 2 || guard < 0 || (h_small && !h_flag) || tables->m.fft_size != h->m.fft_size) {
+        set_error("t2gpu_fft_sym_sync_dev: bad arguments");
+        return -1;
+    }
+    const EqParams &p = kind == 0 ? tables->eq : kind == 1 ? tables->eq_p2 : tables->eq_fc;
+    int idx = idx_symbol;
+    if (kind == 1) idx = 0;
+    else if (kind == 2) {
+        if (!tables->m.l_fc) { set_error("t2gpu_fft_sym_sync_dev: this mode has no frame-closing symbol"); return -1; }
+        idx = tables->m.len_frame - 1;
+    } else if (idx < tables->m.n_p2 || idx >= tables->m.n_p2 + tables->rows) { set_error("t2gpu_fft_sym_sync_dev: symbol index outside the frame's data symbols"); return -1; }
+    const FftLayout lay{guard, 0, 1, h->m.fft_size + guard};
+    const float2 *buffered = with_cp ? reinterpret_cast<const float2 *>(d_buffered) : nullptr;
+    const hipError_t e = launch_fft_sym_sync(h->m.fft_size, reinterpret_cast<const float2 *>(d_buffered), reinterpret_cast<float2 *>(d_spectrum), h->d_twiddle, lay,
+                                             h->d_fft_scratch, h->d_fft_count, p, idx, buffered, guard, reinterpret_cast<float4 *>(d_cp4),
+                                             reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorInvalidValue) { T2_HIP(e); }
+    (void)hipGetLastError();
+    if (t2gpu_fft_execute_strided_dev(h, d_buffered, guard, 0, 1, h->m.fft_size + guard, d_spectrum, 1, stream) != 0) return -1;
+    return t2gpu_sym_sync_dev(tables, kind, idx_symbol, d_spectrum, with_cp ? d_buffered : nullptr, guard, d_cp4, d_sync, h_small, h_flag, seq, stream);
 }
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,

@@ -137,6 +137,23 @@ class t2_ofdm(object):
             check(rc, "t2gpu_sym_sync_dev")
         return cp4, sync
 
+    def fft_sym_sync_dev(self, kind, idx_symbol, buffered, guard, with_cp=True, tables=None, host=None):
+        """One buffered symbol (float32 device tensor [guard + fft_size][2], guard first): FFT of its useful part and, inside the FFT's
+        last launch, sym_sync_dev's outputs. Returns (spectrum [fft_size][2], cp4[4], sync[2]). tables: the t2_ofdm whose pilot tables
+        apply (default: this one)."""
+        import torch
+        assert buffered.is_cuda and buffered.dtype == torch.float32 and buffered.is_contiguous()
+        spec = torch.empty((self.fft_size, 2), dtype=torch.float32, device=buffered.device)
+        cp4 = torch.zeros(4, dtype=torch.float32, device=buffered.device)
+        sync = torch.zeros(2, dtype=torch.float32, device=buffered.device)
+        hs, hf, seq = (host[0].data_ptr(), host[1].data_ptr(), host[2]) if host else (None, None, 0)
+        rc = self._l.t2gpu_fft_sym_sync_dev(self._h, (tables or self)._h, kind, idx_symbol, buffered.data_ptr(), guard, 1 if with_cp else 0,
+                                            spec.data_ptr(), cp4.data_ptr(), sync.data_ptr(), hs, hf, seq,
+                                            torch.cuda.current_stream(buffered.device).cuda_stream)
+        if rc < 0:
+            check(rc, "t2gpu_fft_sym_sync_dev")
+        return spec, cp4, sync
+
     def eq_data(self, idx_symbol, ofdm_cell):
         """Reference call shape: returns (cells complex64[c_data], sample_rate_offset, phase_offset)."""
         x = np.ascontiguousarray(ofdm_cell, np.complex64).reshape(self.fft_size)

@@ -220,3 +220,37 @@ def test_sync_floats_from_the_pilots_alone_equal_the_equalisers(torch_cuda, mode
         _, sync2 = ctx.sym_sync_dev(kind, idx, spec[0])
         assert np.array_equal(sync2.cpu().numpy().view(np.uint32), sync.cpu().numpy().view(np.uint32))
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (4, 1, 1, 3, 0, 9), (4, 0, 4, 1, 2, 45), (4, 0, 0, 3, 0, 17), (5, 1, 1, 2, 2, 12)])
+def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode):
+    """t2gpu_fft_sym_sync_dev (what t2gpu_demod_execute launches per symbol) against t2gpu_fft_execute_dev + t2gpu_sym_sync_dev: spectrum,
+    guard correlation and synchronisation floats bit for bit -- 32K and 16K (whose 128-lane launch stands for the correlation's 256
+    lanes), data / frame-closing tables inside the launch, P2 and a dense pilot pattern (PP1) through the separate launches inside."""
+    import sdr_receiver_dvb_t2_amd as pkg
+    torch = torch_cuda
+    m = ol.ora_mode(*mode)
+    ctx = pkg.t2_ofdm(*mode, max_symbols=2)
+    rows = m.n_data - m.l_fc
+    guard = m.fft_size // 128 if mode[0] == 5 else m.fft_size // 16
+    rng = np.random.Generator(np.random.PCG64(23))
+    cases = [(0, 1), (0, rows), (0, 2), (1, 0)] + ([(2, m.len_frame - 1)] if m.l_fc else [])
+    h_small = torch.zeros(8, dtype=torch.float32).pin_memory()
+    h_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    for n, (kind, idx) in enumerate(cases * 2):                     # twice: the launch's counter is back at zero
+        buffered = (rng.standard_normal((guard + m.fft_size, 2)) * 0.25).astype(np.float32)
+        buffered[:guard] = buffered[m.fft_size:] * np.float32(0.95) + np.float32(0.003)
+        buf = torch.from_numpy(buffered).cuda()
+        want_spec = ctx.fft_dev(buf[guard:].contiguous().reshape(1, m.fft_size, 2))[0]
+        want_cp, want_sync = ctx.sym_sync_dev(kind, idx, want_spec, buf, guard)
+        with_cp = n % 3 != 2
+        spec, cp4, sync = ctx.fft_sym_sync_dev(kind, idx, buf, guard, with_cp=with_cp, host=(h_small, h_flag, 100 + n))
+        torch.cuda.synchronize()
+        assert torch.equal(spec.view(torch.int32), want_spec.view(torch.int32)), (kind, idx)
+        assert torch.equal(sync.view(torch.int32), want_sync.view(torch.int32)), (kind, idx)
+        if with_cp:
+            assert torch.equal(cp4.view(torch.int32), want_cp.view(torch.int32)), (kind, idx)
+            assert np.array_equal(h_small.numpy()[:4].view(np.uint32), cp4.cpu().numpy().view(np.uint32))
+        assert int(h_flag[0]) == 100 + n
+        assert np.array_equal(h_small.numpy()[4:6].view(np.uint32), sync.cpu().numpy().view(np.uint32))
+    ctx.close()
