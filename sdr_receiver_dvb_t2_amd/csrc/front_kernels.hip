@@ -557,8 +557,15 @@ __device__ __forceinline__ void load4(const FrontParams &p, long s, int valid, f
 __device__ __forceinline__ void derot4(const FrontParams &p, float c1, float c2, long s, int valid, const float *xr, const float *xi, double dre, double dim,
                                        float2 *dst, double *t, float2 *pre_out)
 {
+    // (in three steps, so that the lane's table reads are in flight together: with four samples per lane the arrays stay in registers, and a
+    // read per sample in the loop was four memory latencies in a row -- 3 of the kernel's 15 us)
     int r = valid ? find_run(p.nco_runs, p.n_nco_runs, s) : 0;
-    for (int k = 0; k < valid; ++k) {
+    float re_[F1_PER], im_[F1_PER];
+    int li_[F1_PER];
+#pragma unroll
+    for (int k = 0; k < F1_PER; ++k) {
+        re_[k] = 0.0f; im_[k] = 0.0f; li_[k] = 0;
+        if (k >= valid) continue;
         const long i = s + k;
         dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
         dim = dim + DC_ALPHA * ((double)xi[k] - dim);
@@ -576,9 +583,17 @@ __device__ __forceinline__ void derot4(const FrontParams &p, float c1, float c2,
         const FrontRun run = p.nco_runs[r];
         const float fnco = (float)(run.base + (double)(i - run.i0) * run.step); // frequency_nco for this sample (exact)
         const float off = wrap_2pi(sub_r(fnco, run.aux));                       // :194-200
-        const int li = (int)(off * K_TABLE + 32767) & 65535;                    // fast_math.h:47-58
-        const float nr = p.lut_cos[li], ni = p.lut_sin[li];
-        const float2 v = make_float2(sub_r(mul_r(real, nr), mul_r(imag, ni)), add_r(mul_r(imag, nr), mul_r(real, ni)));
+        li_[k] = (int)(off * K_TABLE + 32767) & 65535;                          // fast_math.h:47-58
+        re_[k] = real; im_[k] = imag;
+    }
+    float nr_[F1_PER], ni_[F1_PER];
+#pragma unroll
+    for (int k = 0; k < F1_PER; ++k) { nr_[k] = p.lut_cos[li_[k]]; ni_[k] = p.lut_sin[li_[k]]; }
+#pragma unroll
+    for (int k = 0; k < F1_PER; ++k) {
+        if (k >= valid) continue;
+        const long i = s + k;
+        const float2 v = make_float2(sub_r(mul_r(re_[k], nr_[k]), mul_r(im_[k], ni_[k])), add_r(mul_r(im_[k], nr_[k]), mul_r(re_[k], ni_[k])));
         dst[k] = v;
         if (pre_out && i >= (long)p.n - 3) pre_out[i - ((long)p.n - 3)] = v;     // delay_data_3,2,1 of the next call
     }
@@ -642,12 +657,18 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
             if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; }
         }
         __syncthreads();
-        if (tid == 0) {
-            double re = sh_v[0], im = sh_v[1];
-            for (int k = 0; k < b - 1; ++k) { re = sh_rec[k][0] * re + sh_rec[k][1]; im = sh_rec[k][0] * im + sh_rec[k][2]; }
-            const double a1 = sh_v[2], a1re = sh_v[3], a1im = sh_v[6];
-            sh_v[2] = a1 * re + a1re; sh_v[3] = a1 * im + a1im;                 // the averager before sample s0 - F1_H
-            sh_v[0] = sh_rec[b - 1][0] * re + sh_rec[b - 1][1]; sh_v[1] = sh_rec[b - 1][0] * im + sh_rec[b - 1][2];   // ... before sample s0
+        // the aggregates of the workgroups before this one composed by a scan over the lanes (workgroup t on lane t): lane b - 1 ends up
+        // with everything before workgroup b - 1 and finishes the two values this workgroup starts from
+        {
+            Lin l{1.0, 0.0, 0.0};
+            if (tid < b) l = Lin{sh_rec[tid][0], sh_rec[tid][1], sh_rec[tid][2]};
+            const Lin exb = block_scan_exclusive<4>(l, wave_tot, nullptr);
+            if (tid == b - 1) {
+                const double re = exb.a * sh_v[0] + exb.re, im = exb.a * sh_v[1] + exb.im;      // the averager before workgroup b - 1's first sample
+                const double a1 = sh_v[2], a1re = sh_v[3], a1im = sh_v[6];
+                sh_v[2] = a1 * re + a1re; sh_v[3] = a1 * im + a1im;             // ... before sample s0 - F1_H
+                sh_v[0] = l.a * re + l.re; sh_v[1] = l.a * im + l.im;           // ... before sample s0
+            }
         }
         __syncthreads();
     }
@@ -778,15 +799,24 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
     __syncthreads();
     if (tid < 3) p.derot[tid] = keep;
     else if (tid >= 64 && tid < 64 + 63) p.interp[tid - 64] = keep;
+    // every workgroup's aggregate and sign statistics into LDS by a lane each (one round of memory latency, not one per workgroup), then
+    // folded in workgroup order by one lane
+    double *fin = reinterpret_cast<double *>(W);                               // [nb][6]: a, re, im, theta 1..3 (the window is done with)
+    if (tid < nb) {
+        const double *q = p.theta_part + 4 * (long)tid, *rec = a.rec + 16 * (size_t)tid;
+        double *f = fin + 6 * tid;
+        f[0] = rec[0]; f[1] = rec[1]; f[2] = rec[2]; f[3] = q[0]; f[4] = q[1]; f[5] = q[2];
+    }
+    if (tid == 0) { sh_v[0] = a.rec[6]; sh_v[1] = a.rec[7]; }
+    __syncthreads();
     if (tid == 0) {
         FrontState &s = *p.state;
         double th[3] = {0.0, 0.0, 0.0};
-        const double *r0 = a.rec;
-        double re = r0[6], im = r0[7];
+        double re = sh_v[0], im = sh_v[1];
         for (int k = 0; k < nb; ++k) {
-            const double *q = p.theta_part + 4 * (long)k, *rec = a.rec + 16 * (size_t)k;
-            th[0] += q[0]; th[1] += q[1]; th[2] += q[2];
-            re = rec[0] * re + rec[1]; im = rec[0] * im + rec[2];
+            const double *f = fin + 6 * k;
+            th[0] += f[3]; th[1] += f[4]; th[2] += f[5];
+            re = f[0] * re + f[1]; im = f[0] * im + f[2];
         }
         s.dc_re = re; s.dc_im = im;
         s.decim_phase = (int)((p.decim_phase + p.n_interp) & 1);

@@ -375,8 +375,9 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             const bool carry = h->deint_start && h->sig.data;
             unsigned seq_cells = 0;
             if (carry && !(seq_cells = publish_cells(h, k, h->c_data, h->eq_stream))) return -1;
-            T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
-            h->eq_busy[k] = true;
+            // (with a consumer the host waits for these cells -- published behind the equaliser -- before the symbol after next is launched:
+            // buffer set k is free by then without an event)
+            if (!carry) { T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream)); h->eq_busy[k] = true; }
             h->prof.stop(PF_FFT_EQ);
             // the symbol BEFORE this one hands its cells on now: everything of this symbol is on its way, the consumer's work (the
             // de-interleaver's push: ~9 us of host time and a launch) runs beside it instead of in front of it
