@@ -16,7 +16,7 @@ struct FrontState {
     float c1, c2;                          // IQ-imbalance coefficients used by the NEXT call (:228-234)
     float level_detect;                    // :235
     int32_t decim_phase;                   // filter_decimator's d (filter_decimator.h:77)
-    int32_t pad_;
+    int32_t error_;                        // (in the page-locked copy a commit publishes: the one-launch form's error word)
     double theta_acc[3], n_acc;            // sign statistics / samples of the chunks of one execute() still open (FRONT_STAGE_HOLD_IQ)
 };
 
@@ -45,7 +45,7 @@ struct FrontParams {
 // c1 / c2 / level_detect stay as they are until launch_front_commit_iq (the reference derives them once per execute(), :227-235)
 enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4, FRONT_STAGE_HOLD_IQ = 8 };
 // h_copy / h_flag (may be null): the committed state is also stored to page-locked host memory and *h_flag = seq behind it
-void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream);
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 // n int16 elements of I and of Q from page-locked host memory (device-visible addresses hi / hq) to di / dq, by a kernel

@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void front_copy_in_kernel(const int16_t *__res
 }
 
 // end of an execute() whose chunks ran with FRONT_STAGE_HOLD_IQ (:227-235)
-__global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq)
+__global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error)
 {
     FrontState &s = *state;
     if (s.n_acc > 0.0) front_iq_estimate(s, s.theta_acc[0], s.theta_acc[1], s.theta_acc[2], (float)s.n_acc);
@@ -857,6 +857,7 @@ __global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, un
     s.n_acc = 0.0;
     if (h_copy) {                                           // the state as it stands now, to page-locked host memory, the sequence word behind it
         *h_copy = s;
+        h_copy->error_ = error ? *error : 0;                // a look-back wait of the one-launch form that gave up: reported with the state
         __threadfence_system();
         __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -884,9 +885,9 @@ void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int
     hipLaunchKernelGGL(front_copy_in_kernel, dim3(grid), dim3(256), 0, stream, hi, hq, di, dq, n);
 }
 
-void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, hipStream_t stream)
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream)
 {
-    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state, h_copy, h_flag, seq);
+    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state, h_copy, h_flag, seq, error);
 }
 
 static void load_taps()

@@ -285,7 +285,7 @@ extern "C" int t2gpu_front_commit_iq(t2gpu_front *h, void *stream)
     if (!h) return -1;
     T2_HIP(hipSetDevice(h->device));
     const unsigned seq = ++h->state_seq;
-    launch_front_commit_iq(h->d_state, h->h_state, h->h_state ? h->h_flag : nullptr, seq, (hipStream_t)stream);
+    launch_front_commit_iq(h->d_state, h->h_state, h->h_state ? h->h_flag : nullptr, seq, h->d_chain_error, (hipStream_t)stream);
     T2_HIP(hipGetLastError());
     h->last_stream = (hipStream_t)stream;
     h->state_published = h->h_state != nullptr;
@@ -396,7 +396,11 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
             t2_cpu_relax();
             if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
         }
-        if (*flag == h->state_seq) { std::atomic_thread_fence(std::memory_order_acquire); s = *h->h_state; have = true; }
+        if (*flag == h->state_seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            s = *h->h_state; have = true;
+            if (s.error_) { set_error("t2gpu_front: a look-back wait of the one-launch form timed out"); return -1; }
+        }
     }
     if (!have) {
         T2_HIP(hipStreamSynchronize(h->last_stream));
