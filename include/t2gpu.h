@@ -366,9 +366,12 @@ int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, int n_symbols
  * kind: 0 data symbol idx_symbol, 1 P2, 2 frame closing. d_spectrum: fft_size cells (what the FFT wrote). d_buffered (may be null):
  * guard + fft_size cells, guard first. d_cp4 (4 floats) / d_sync (2 floats): device, may be null. h_small (8 floats) / h_flag:
  * page-locked host memory of the caller, may be null -- the kernel itself stores {sum.re, sum.im, frequency_est, 0} at h_small[0..3]
- * (only with d_buffered) and {phase_offset, sample_rate_offset} at h_small[4..5], then seq at *h_flag (system scope, behind them). */
+ * (only with d_buffered) and {phase_offset, sample_rate_offset} at h_small[4..5], then seq at *h_flag (system scope, behind them).
+ * d_loop (may be null): the device's tracking-loop state (t2gpu_front_loop_dev): the launch's last lane then also advances the two loop
+ * filters with these floats as t2gpu_sync_frequency / t2gpu_sync_symbol do, and h_small[6..7] receive the new phase_est_filtered and
+ * frequency_est_filtered + tuner. */
 int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_spectrum, const float *d_buffered, int guard,
-                       float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream);
+                       float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
 /* symbol_acquisition's guard removal + fft->execute() (dvbt2_demodulator.cpp:332-334) for ONE buffered symbol (d_buffered: guard +
  * fft_size cells, guard first; spectrum to d_spectrum) with t2gpu_sym_sync_dev's outputs formed inside the FFT's last launch: what
  * t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev give, bit for bit, in two launches instead of three. h: the handle whose FFT
@@ -376,7 +379,7 @@ int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_s
  * guard correlation (h_small[0..3] untouched). Pilot tables that do not fit the FFT's exchange buffer (P2, dense pilot patterns) take
  * the separate launches inside. */
 int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp,
-                           float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream);
+                           float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
 /* The same two for whole frames, in place like t2gpu_eq_data_frames_dev: the P2 (frame-closing) symbol of frame f is read at
  * d_spectrum + 2 * f * syms_per_frame * fft_size floats (+ the symbol's position in the frame); P2: the cells behind the first
  * skip_cells (the L1 cells, time_deinterleaver.cpp:296-300) go to d_cells + 2 * f * cells_frame_stride floats; frame closing: the
@@ -449,6 +452,23 @@ long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len,
                          const int16_t *q_in, float *out, long out_cap_cells, int32_t *chunk_out_len);
 /* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
 int t2gpu_front_state(t2gpu_front *h, float *out8);
+/* ---- the loop on the device. The reference hands a symbol's two synchronisation floats and its guard correlation to the tracking filters
+ * and the filters' outputs to the next chunk's NCO (dvbt2_demodulator.cpp:165-171, 187-193, 328-330, 429-439): one host round trip per
+ * symbol for a caller that keeps the filters on the host. These entry points keep them on the device for as long as the caller likes (a
+ * T2 frame's data symbols in t2gpu_demod_execute): t2gpu_front_loop_begin sends the host's state up; t2gpu_sym_sync_dev /
+ * t2gpu_fft_sym_sync_dev with d_loop = t2gpu_front_loop_dev(h) advance the filters behind every symbol; t2gpu_front_execute_loop_dev runs a
+ * chunk whose NCO runs workgroup 0 plans from that state (the Farrow stage is planned by the host as always: its resampling value changes
+ * by -8e-9, 0 or +8e-9 per symbol, so the host knows it one symbol ahead whenever the three agree as floats). Nothing waits for the host;
+ * the host follows one symbol behind with the floats the launches publish (t2gpu_sync_*; t2gpu_front_loop_follow for the NCO accumulators,
+ * chunk by chunk, oldest first) and t2gpu_front_loop_read lets it check that it arrived where the device did. Returns: 0 / cells, -1 on
+ * an error; t2gpu_front_execute_loop_dev: -2 when the chunk does not qualify for the one-launch form (nothing has happened then). */
+void *t2gpu_front_loop_dev(t2gpu_front *h);
+int t2gpu_front_loop_begin(t2gpu_front *h, const float *state10, void *stream);   /* state10: t2gpu_sync_export's, [2] = the tuner (rad / sample) */
+long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, double arbitrary_resample, const int16_t *d_i, const int16_t *d_q, float *d_out,
+                                  long out_cap_cells, void *stream);
+int t2gpu_front_loop_follow(t2gpu_front *h, float phase_est_filtered, float frequency_est_filtered_plus_tuner);
+int t2gpu_front_loop_pending(const t2gpu_front *h);
+int t2gpu_front_loop_read(t2gpu_front *h, float *out8, void *stream);   /* {phase_nco, frequency_nco, pe, fe, frequency_est_filtered, f_int, p_int, error} */
 /* intermediate streams of the last call, for tests: which 0 = de-rotated samples (n_in cells), 1 = resampled (before the
  * decimator). Synchronises. Returns the number of cells copied. Since t2gpu_front_execute runs the Farrow stage and the decimator
  * as one kernel, stream 1 holds real data in its last 63 cells only (what the next call starts from); its length is right, the
@@ -480,6 +500,8 @@ void t2gpu_sync_frequency(t2gpu_sync *h, float frequency_est, int fft_size);
 void t2gpu_sync_symbol(t2gpu_sync *h, float phase_est, float sample_rate_est);
 /* out4 = {phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered, arbitrary_resample of the next chunk} */
 void t2gpu_sync_get(const t2gpu_sync *h, double *out4);
+/* {phase_est_filtered, frequency_est_filtered, 0, f_kp, f_ki, f_int, p_kp, p_ki, p_int, old_sample_rate_est}: the filters' state (t2gpu_front_loop_begin) */
+void t2gpu_sync_export(const t2gpu_sync *h, float *out10);
 /* dvbt2_demodulator::reset (:111-127); frequency_est_filtered = 0 (brute-force guard search, :486); resample -= correct_resample *
  * resample after a re-tune (:291) */
 void t2gpu_sync_reset(t2gpu_sync *h, float sample_rate);

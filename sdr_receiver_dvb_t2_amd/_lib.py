@@ -136,8 +136,15 @@ PROTOTYPES = {
                                                 ctypes.c_long, _vp, _vp]),
     "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_fc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
-    "t2gpu_fft_sym_sync_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp]),
-    "t2gpu_sym_sync_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp]),
+    "t2gpu_fft_sym_sync_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
+    "t2gpu_sym_sync_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
+    "t2gpu_front_loop_dev": (_vp, [_vp]),
+    "t2gpu_front_loop_begin": (ctypes.c_int, [_vp, _vp, _vp]),
+    "t2gpu_front_execute_loop_dev": (ctypes.c_long, [_vp, ctypes.c_int32, ctypes.c_double, _vp, _vp, _vp, ctypes.c_long, _vp]),
+    "t2gpu_front_loop_follow": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
+    "t2gpu_front_loop_pending": (ctypes.c_int, [_vp]),
+    "t2gpu_front_loop_read": (ctypes.c_int, [_vp, _vp, _vp]),
+    "t2gpu_sync_export": (None, [_vp, _vp]),
     "t2gpu_eq_data_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ofdm_mode_info": (ctypes.c_int, [ctypes.c_int] * 6 + [_vp]),
     "t2gpu_table_symbol_carriers": (ctypes.c_int, [ctypes.c_int] * 7 + [_vp, _vp]),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "front_plan.h"
+#include "loop_device.h"
 
 constexpr int FRONT_BLOCK = 4096;          // input samples per workgroup in the dc / de-rotation kernels (256 lanes x FRONT_PER)
 constexpr int FRONT_PER = FRONT_BLOCK / 256;
@@ -63,7 +64,9 @@ struct FrontOneArgs {
     double *rec;                               // [F1_MAX_GRID][16]
     float2 *pre_out;                           // [3 + 63]
     int *error;                                // set when a look-back wait gave up (t2gpu_front_state reports it)
-    FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs, then Farrow runs
+    T2DevLoop *loop;                           // non-null: the NCO runs of this (one-chunk) call are planned by workgroup 0 from the device's
+    FrontRun *loop_runs;                       // loop state into loop_runs[T2_LOOP_RUNS_CAP] and the accumulators are left advanced there
+    FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs (none with `loop`), then Farrow runs
 };
 int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs);
 void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream);

@@ -606,11 +606,74 @@ __device__ __forceinline__ long first_out_of(const FrontParams &p, long i)
     return (long)run.o0 + (i - run.i0) * run.cnt;
 }
 
+// ---- t2_plan_nco (front_plan.cpp) on the device: the same walk with the same float / double operations, one lane. Any decomposition
+// into exact runs gives the same sequence of float values; this one is the host's. Returns the number of runs, or -1 when `cap` is too small.
+__device__ __forceinline__ float nco_next_dev(float v, float fe, bool *wrapped)
+{
+    float t = sub_r(v, fe);
+    *wrapped = false;
+    while (t > PI_X_2) { t = sub_r(t, PI_X_2); *wrapped = true; }
+    while (t < -PI_X_2) { t = add_r(t, PI_X_2); *wrapped = true; }
+    return t;
+}
+__device__ __forceinline__ int expo_dev(double v) { return v == 0.0 ? -(1 << 30) : ilogb(v); }
+__device__ __forceinline__ long span_dev(double V, double D, double lo, double hi, long cap)
+{
+    if (!(V >= lo && V < hi)) return -1;
+    if (D == 0.0) return cap;
+    const double lim = D > 0.0 ? (hi - V) / D : (V - lo) / -D;
+    long t = lim >= (double)cap ? cap : (long)lim;
+    if (t > cap) t = cap;
+    while (t > 0 && !(V + (double)t * D >= lo && V + (double)t * D < hi)) --t;
+    return t;
+}
+__device__ __noinline__ int plan_nco_dev(float *acc, int n, float fe, float phase_nco, FrontRun *runs, int cap)
+{
+    constexpr int MAX_RUN = 1 << 24;
+    int i = 0, nr = 0;
+    float prev = *acc;
+    bool w;
+    while (i < n) {
+        const float v0 = nco_next_dev(prev, fe, &w);
+        long len = 1;
+        double step = 0.0;
+        bool w0;
+        if (nco_next_dev(v0, fe, &w0) == v0 && !w0) {
+            len = n - i;
+        } else if (n - i >= 3 && v0 != 0.0f) {
+            bool w1, w2;
+            const float v1 = nco_next_dev(v0, fe, &w1), v2 = nco_next_dev(v1, fe, &w2);
+            const double s1 = (double)v1 - (double)v0, s2 = (double)v2 - (double)v1;
+            const int e = expo_dev(v0);
+            const bool same = !w1 && !w2 && s1 == s2 && v1 != 0.0f && v2 != 0.0f && expo_dev(v1) == e && expo_dev(v2) == e &&
+                              signbit(v0) == signbit(v1) && signbit(v0) == signbit(v2);
+            if (same) {
+                const double u = ldexp(1.0, e - 23);
+                const double lo = ldexp(1.0, e) + u;
+                double hi = ldexp(1.0, e + 1) - u;
+                if (hi > (double)PI_X_2 - u) hi = (double)PI_X_2 - u;
+                const double mag = fabs((double)v0);
+                const double dmag = signbit(v0) ? -s1 : s1;
+                long t = span_dev(mag, dmag, lo, hi, MAX_RUN);
+                if (t > n - i - 1) t = n - i - 1;
+                if (t >= 2) { len = t + 1; step = s1; }
+            }
+        }
+        if (nr >= cap) return -1;
+        runs[nr++] = FrontRun{i, 0, (double)v0, step, 0, phase_nco};
+        prev = (float)((double)v0 + (double)(len - 1) * step);
+        i += (int)len;
+    }
+    *acc = prev;
+    return nr;
+}
+
 __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
 {
-    __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS];
+    __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS], sh_nco[FRONT_CHAIN_RUNS];
     __shared__ Lin wave_tot[4];
     __shared__ Lin sh_a1;
+    __shared__ int sh_nr;
     __shared__ double sh_rec[F1_MAX_GRID][4];                  // the aggregates of the workgroups before this one: a, re, im
     __shared__ double sh_v[8];                                 // S (re, im), M (re, im), c1, c2, the last workgroup's part of the new dc
     __shared__ double red[3][4];
@@ -636,6 +699,16 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
         double *rec = a.rec + 16 * (size_t)b;
         rec[0] = total.a; rec[1] = total.re; rec[2] = total.im; rec[3] = sh_a1.a; rec[4] = sh_a1.re; rec[5] = sh_a1.im;
         if (b == 0) { rec[6] = sh_v[0]; rec[7] = sh_v[1]; rec[8] = sh_v[4]; rec[9] = sh_v[5]; }   // the state as block 0 found it: nobody else reads it
+        if (b == 0 && a.loop) {
+            // the loop on the device: this chunk's NCO runs from the loop values the last sym_sync_kernel left (dvbt2_demodulator.cpp:165-171,
+            // 187-193), planned once, by this lane, into memory; the accumulators' new values travel with the record
+            const float phase_new = wrap_2pi(add_r(a.loop->phase_nco, a.loop->pe));
+            float acc = a.loop->frequency_nco;
+            int nr = plan_nco_dev(&acc, p.n, a.loop->fe, phase_new, a.loop_runs, T2_LOOP_RUNS_CAP);
+            if (nr < 0) { nr = 0; __hip_atomic_store(a.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            rec[10] = (double)nr; rec[11] = (double)phase_new; rec[12] = (double)acc;
+            sh_nr = nr;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(a.flags + b, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -654,7 +727,7 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
             const double *rec = a.rec + 16 * (size_t)tid;
             sh_rec[tid][0] = rec[0]; sh_rec[tid][1] = rec[1]; sh_rec[tid][2] = rec[2];
             if (tid == b - 1) { sh_v[2] = rec[3]; sh_v[3] = rec[4]; sh_v[6] = rec[5]; }
-            if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; }
+            if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; if (a.loop) sh_nr = (int)rec[10]; }
         }
         __syncthreads();
         // the aggregates of the workgroups before this one composed by a scan over the lanes (workgroup t on lane t): lane b - 1 ends up
@@ -671,6 +744,17 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
             }
         }
         __syncthreads();
+    }
+    if (a.loop) {
+        __syncthreads();                                       // (workgroup 0: sh_nr and the runs in memory are its own lane 0's)
+        p.n_nco_runs = sh_nr;
+        if (sh_nr <= FRONT_CHAIN_RUNS) {
+            for (int t = tid; t < sh_nr; t += 256) sh_nco[t] = a.loop_runs[t];
+            p.nco_runs = sh_nco;
+            __syncthreads();
+        } else {
+            p.nco_runs = a.loop_runs;                          // many runs (a large residual offset): searched where they lie
+        }
     }
     const float c1 = (float)sh_v[4], c2 = (float)sh_v[5];
     // ---- de-rotation: own samples (sign statistics, the next call's delay line), then the halo by the first half of wavefront 0
@@ -819,6 +903,7 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
             re = f[0] * re + f[1]; im = f[0] * im + f[2];
         }
         s.dc_re = re; s.dc_im = im;
+        if (a.loop) { a.loop->phase_nco = (float)a.rec[11]; a.loop->frequency_nco = (float)a.rec[12]; }
         s.decim_phase = (int)((p.decim_phase + p.n_interp) & 1);
         for (int c = 0; c < 3; ++c) s.theta[c] = th[c];
         if (p.stages & FRONT_STAGE_HOLD_IQ) {
@@ -907,13 +992,16 @@ static long fd_blocks_of(const FrontParams &p)
 }
 
 // the grid of the one-launch form, or 0 when the call does not qualify: the whole chain, at most F1_MAX_GRID x F1_B samples, run tables
-// that fit the kernel's arguments, and between one and two resampled cells per input sample in every run (the window a workgroup keeps
-// in LDS and the F1_H samples of halo are sized for that: ratios up to ~1, the reference's devices)
+// that fit the kernel's arguments, and between one and two resampled cells per input sample (the window a workgroup keeps in LDS and the
+// F1_H samples of halo are sized for that: ratios from 1/2 to ~1, the reference's devices)
 int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs)
 {
     const int all = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE;
     if (!T2_FRONT_FUSED || p.n <= 0 || (p.stages & all) != all || n_nco_runs + n_far_runs > (size_t)FRONT_CHAIN_RUNS || n_far_runs < 1) return 0;
-    for (size_t r = 0; r < n_far_runs; ++r) if (far_runs[r].cnt < 1 || far_runs[r].cnt > 2) return 0;
+    // (a ratio a hair under 1/2 -- the sample-rate tracker's first steps -- gives three cells for a sample now and then: the window has room
+    // for 128 of those per call)
+    for (size_t r = 0; r < n_far_runs; ++r) if (far_runs[r].cnt < 1 || far_runs[r].cnt > 3) return 0;
+    if (p.n_interp > 2 * (long)p.n + 128) return 0;
     const long g = ((long)p.n + F1_B - 1) / F1_B;
     return g <= F1_MAX_GRID ? (int)g : 0;
 }

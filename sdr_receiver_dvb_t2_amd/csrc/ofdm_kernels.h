@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ofdm_tables.h"
+#include "loop_device.h"
 
 namespace t2gpu {
 
@@ -76,8 +77,10 @@ hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *
 // sym_sync_kernel). symbol: the spectrum (fft_size cells); buffered (may be null): the symbol as collected, guard + fft_size cells;
 // cp_out / sync (device, may be null) receive {sum.re, sum.im, frequency_est, 0} / {phase_offset, sample_rate_offset}; h_small / h_flag
 // (page-locked, may be null): the same six floats at h_small[0..3] / [4..5] and *h_flag = seq behind them.
+// loop (device, may be null): the tracking loops' state the launch's last lane advances with the symbol's floats (loop_device.h); its new
+// phase_est_filtered / frequency input then also go to h_small[6..7].
 hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,
-                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s);
+                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr);
 
 // One symbol's FFT (the two-launch form) with launch_sym_sync's work done by the last workgroup of its second launch. count: a zeroed
 // device word of the caller's (left at zero). hipErrorInvalidValue when the pilot table of `p` does not fit the FFT's exchange buffer
@@ -85,6 +88,6 @@ hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symb
 // the other.
 hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
-                               unsigned *h_flag, unsigned seq, hipStream_t s);
+                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr);
 
 }  // namespace t2gpu

@@ -2,6 +2,7 @@
 // channel estimator / equaliser fused with the frequency de-interleaver. HBM-bound streaming work; no matrix cores.
 #include "ofdm_kernels.h"
 #include "cp_device.h"
+#include "loop_device.h"
 #include "t2gpu_common.h"
 #include <algorithm>
 
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(64) void eq_sync_kernel(EqParams p, const int32_t *
 template <int NL>
 __device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *__restrict__ symbol, int idx_symbol,
                                               const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, float *sy_lds)
+                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, float *sy_lds, T2DevLoop *loop)
 {
     __shared__ int sh_lower;
     const int tid = threadIdx.x;
@@ -769,9 +770,29 @@ __device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *_
         const float2 sv = make_float2(atan2_approx_dev(s2i, s2r) + atan2_approx_dev(s1i, s1r), a2 - a1);
         if (sync) *sync = sv;
         if (cp_out && buffered) *cp_out = cp;
+        if (loop) {
+            // the tracking loops on the device (loop_device.h): t2gpu_sync_frequency (dvbt2_demodulator.cpp:328-330) when the guard correlation
+            // was formed, then t2gpu_sync_symbol's phase filter (:429) -- PiFilter::step's operations in its order
+            if (buffered) {
+                float integral = loop->f_int + loop->f_ki * cp.z;
+                const float out = integral + loop->f_kp * cp.z;
+                const float mx = 1.0f / (float)p.fft_size;
+                if (integral > mx) integral = mx; else if (integral < -mx) integral = -mx;
+                loop->f_int = integral;
+                loop->frequency_est_filtered += out;
+            }
+            const float err = sv.x * 0.5f, mx2 = 3.14159274101257324219f * 2;
+            float integral = loop->p_int + loop->p_ki * err;
+            const float out = integral + loop->p_kp * err;
+            if (integral > mx2) integral = mx2; else if (integral < -mx2) integral = -mx2;
+            loop->p_int = integral;
+            loop->pe = out;
+            loop->fe = loop->frequency_est_filtered + loop->tuner;
+        }
         if (h_small) {
             if (buffered) { h_small[0] = cp.x; h_small[1] = cp.y; h_small[2] = cp.z; h_small[3] = cp.w; }
             h_small[4] = sv.x; h_small[5] = sv.y;
+            if (loop) { h_small[6] = loop->pe; h_small[7] = loop->fe; }
             __threadfence_system();
             __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -780,10 +801,10 @@ __device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *_
 
 __global__ __launch_bounds__(256) void sym_sync_kernel(EqParams p, const float2 *__restrict__ symbol, int idx_symbol,
                                                        const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                                       float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+                                                       float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, T2DevLoop *loop)
 {
     extern __shared__ __attribute__((aligned(16))) float sy_lds_dyn[];
-    sym_sync_body<256>(p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, sy_lds_dyn);
+    sym_sync_body<256>(p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, sy_lds_dyn, loop);
 }
 
 // ---- the second launch of a ONE-symbol FFT with the symbol's synchronisation floats behind it in the same launch: the last of its four
@@ -794,7 +815,7 @@ template <int T2>
 __global__ __launch_bounds__(8 * T2) void fft_stage_bc_sync_kernel(const float2 *__restrict__ scratch, float2 *__restrict__ out,
                                                                    const float2 *__restrict__ twiddle, unsigned *count, EqParams p, int idx_symbol,
                                                                    const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                                                   float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq)
+                                                                   float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, T2DevLoop *loop)
 {
     __shared__ __attribute__((aligned(16))) float lds[FFT_BC_LDS_FLOATS];
     __shared__ int sh_last;
@@ -808,22 +829,22 @@ __global__ __launch_bounds__(8 * T2) void fft_stage_bc_sync_kernel(const float2 
     }
     __syncthreads();
     if (!sh_last) return;
-    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds);
+    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds, loop);
 }
 
 hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
-                               unsigned *h_flag, unsigned seq, hipStream_t s)
+                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop)
 {
     if ((p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_BC_LDS_FLOATS * 4 || !scratch || !count) return hipErrorInvalidValue;
     if (fft_size == 32768) {
         hipLaunchKernelGGL(fft_stage_a_kernel<32>, dim3(16), dim3(64), 0, s, in, scratch, twiddle, lay);
         hipLaunchKernelGGL(fft_stage_bc_sync_kernel<32>, dim3(4), dim3(256), 0, s, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
-                           h_small, h_flag, seq);
+                           h_small, h_flag, seq, loop);
     } else if (fft_size == 16384) {
         hipLaunchKernelGGL(fft_stage_a_kernel<16>, dim3(8), dim3(64), 0, s, in, scratch, twiddle, lay);
         hipLaunchKernelGGL(fft_stage_bc_sync_kernel<16>, dim3(4), dim3(128), 0, s, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
-                           h_small, h_flag, seq);
+                           h_small, h_flag, seq, loop);
     } else {
         return hipErrorInvalidValue;
     }
@@ -831,12 +852,12 @@ hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, cons
 }
 
 hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out,
-                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s)
+                           float2 *sync, float *h_small, unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop)
 {
     const int bytes = (p.max_seg + 2) * 16 + 2 * 256 * 8;
     if (bytes > 64 * 1024)
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(sym_sync_kernel), bytes)) return e;
-    hipLaunchKernelGGL(sym_sync_kernel, dim3(1), dim3(256), bytes, s, p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq);
+    hipLaunchKernelGGL(sym_sync_kernel, dim3(1), dim3(256), bytes, s, p, symbol, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, loop);
     return hipGetLastError();
 }
 

@@ -361,7 +361,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
         const unsigned seq_a = ++h->seq;
         if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
-                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small, h->h_flag, seq_a, h->stream) != 0) return -1;
+                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small, h->h_flag, seq_a, nullptr, h->stream) != 0) return -1;
         T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         h->prof.stop(PF_CP);
         h->est_chunk = 0;

@@ -49,6 +49,11 @@ struct t2gpu_front {
     unsigned long long one_seq = 0, one_done = 0;
     int *d_chain_error = nullptr;      // raised by a look-back wait of that kernel that gave up
     bool chain_on = true;
+    // the tracking loops on the device (loop_device.h; t2gpu_front_loop_*): state, the NCO runs workgroup 0 plans, a page-locked staging
+    // slot for the state going up, and the chunks launched in that mode whose NCO the host has not followed yet
+    T2DevLoop *d_loop = nullptr, *h_loop = nullptr;
+    FrontRun *d_loop_runs = nullptr;
+    std::vector<int32_t> loop_pending;
     // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
     FrontState *h_state = nullptr;
     unsigned *h_flag = nullptr, state_seq = 0;
@@ -177,7 +182,10 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         *h->h_flag = 0;
     }
     constexpr size_t ONE_BYTES = 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID + 66 * sizeof(float2);
-    bool ok = hipMalloc(&h->d_one, ONE_BYTES) == hipSuccess && hipMemset(h->d_one, 0, ONE_BYTES) == hipSuccess &&
+    bool ok = hipMalloc(&h->d_loop, sizeof(T2DevLoop)) == hipSuccess && hipMemset(h->d_loop, 0, sizeof(T2DevLoop)) == hipSuccess &&
+              hipMalloc(&h->d_loop_runs, (size_t)T2_LOOP_RUNS_CAP * sizeof(FrontRun)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void **>(&h->h_loop), sizeof(T2DevLoop), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc(&h->d_one, ONE_BYTES) == hipSuccess && hipMemset(h->d_one, 0, ONE_BYTES) == hipSuccess &&
               hipMalloc(&h->d_chain_error, 4) == hipSuccess && hipMemset(h->d_chain_error, 0, 4) == hipSuccess &&
               hipMalloc(&h->d_state, sizeof(FrontState)) == hipSuccess && hipMalloc(&h->d_blk, ((nb + 1023) / 1024 * 1024) * 4 * sizeof(double)) == hipSuccess &&      // lane-interleaved slots (front_kernels.hip: dc_slot)
               hipMalloc(&h->d_theta, nb * 4 * sizeof(double)) == hipSuccess && hipMalloc(&h->d_lut, lut.size() * 4) == hipSuccess &&
@@ -200,7 +208,8 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    hipFree(h->d_one); hipFree(h->d_chain_error);
+    hipFree(h->d_one); hipFree(h->d_chain_error); hipFree(h->d_loop); hipFree(h->d_loop_runs);
+    if (h->h_loop) hipHostFree(h->h_loop);
     if (h->h_state) hipHostFree(h->h_state);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
@@ -340,6 +349,7 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
         a.rec = reinterpret_cast<double *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64);
         a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
         a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
+        a.loop = nullptr; a.loop_runs = nullptr;
         launch_front_one(a, one_grid, stream);
         // the device's words move only if the launch was accepted: the host's copies follow it, not the attempt
         T2_HIP(hipGetLastError());
@@ -353,6 +363,96 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
     h->decim_phase = (int)((h->decim_phase + n_interp) & 1);
     h->last_stream = stream; h->last_n = n; h->last_n_interp = n_interp;
     return n_out;
+}
+
+// ---- the tracking loops on the device (include/t2gpu.h, "the loop on the device")
+extern "C" void *t2gpu_front_loop_dev(t2gpu_front *h) { return h ? h->d_loop : nullptr; }
+
+// state10 = {phase_est_filtered, frequency_est_filtered, tuner, f_kp, f_ki, f_int, p_kp, p_ki, p_int, -}: with the handle's own two NCO
+// accumulators, the device's loop state from here on (stream order)
+extern "C" int t2gpu_front_loop_begin(t2gpu_front *h, const float *state10, void *stream)
+{
+    if (!h || !state10) { set_error("t2gpu_front_loop_begin: bad arguments"); return -1; }
+    if (!h->loop_pending.empty()) { set_error("t2gpu_front_loop_begin: chunks of the mode before are still to be followed"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize((hipStream_t)stream));         // (the staging slot of the begin before; once per T2 frame)
+    T2DevLoop &l = *h->h_loop;
+    l = T2DevLoop{};
+    l.phase_nco = h->phase_nco; l.frequency_nco = h->frequency_nco;
+    l.pe = state10[0]; l.frequency_est_filtered = state10[1]; l.tuner = state10[2]; l.fe = state10[1] + state10[2];
+    l.f_kp = state10[3]; l.f_ki = state10[4]; l.f_int = state10[5]; l.p_kp = state10[6]; l.p_ki = state10[7]; l.p_int = state10[8];
+    T2_HIP(hipMemcpyAsync(h->d_loop, h->h_loop, sizeof(T2DevLoop), hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// One chunk whose NCO runs the device plans itself from its loop state (front_one_kernel with `loop`): the host plans the Farrow stage
+// only. Returns the decimated cells, -1 on an error, -2 when the call does not qualify for the one-launch form (nothing has happened
+// then: the caller follows the loops on the host for this chunk).
+extern "C" long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out,
+                                             long out_cap_cells, void *stream_)
+{
+    if (!h || chunk < 1 || !d_i || !d_q || !d_out) { set_error("t2gpu_front_execute_loop_dev: bad arguments"); return -1; }
+    if (chunk > h->max_samples) { set_error("t2gpu_front_execute: more samples than max_samples"); return -1; }
+    hipStream_t stream = (hipStream_t)stream_;
+    T2_HIP(hipSetDevice(h->device));
+    const float s_x1 = h->x1;
+    long n_out = 0;
+    const long n_interp = plan_call(h, 1, &chunk, nullptr, nullptr, &rs, false, true, nullptr, &n_out);
+    FrontParams p = base_params(h);
+    p.i_in = d_i; p.q_in = d_q; p.n = chunk; p.n_blocks = (chunk + FRONT_BLOCK - 1) / FRONT_BLOCK;
+    p.n_interp = n_interp; p.out = reinterpret_cast<float2 *>(d_out); p.n_out = n_out;
+    p.stages = FRONT_STAGE_DEROTATE | FRONT_STAGE_FARROW | FRONT_STAGE_DECIMATE | (h->hold_iq ? FRONT_STAGE_HOLD_IQ : 0);
+    const size_t nf = h->far_runs.size();
+    const int one_grid = (n_interp >= 0 && n_interp <= h->interp_cap && n_out <= out_cap_cells && h->chain_on) ? front_one_grid(p, h->far_runs.data(), 0, nf) : 0;
+    if (!one_grid) { h->x1 = s_x1; return n_interp < 0 ? -1 : -2; }
+    h->state_published = false;
+    FrontOneArgs a;
+    a.p = p;
+    a.p.n_nco_runs = 0; a.p.n_far_runs = (int)nf;
+    a.p.nco_runs = nullptr; a.p.far_runs = nullptr; a.p.nco_index = nullptr; a.p.far_index = nullptr;
+    std::memcpy(a.runs, h->far_runs.data(), nf * sizeof(FrontRun));
+    a.flags = reinterpret_cast<unsigned long long *>(h->d_one);
+    a.done = reinterpret_cast<unsigned long long *>(h->d_one + 8 * (size_t)F1_MAX_GRID);
+    a.rec = reinterpret_cast<double *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64);
+    a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
+    a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
+    a.loop = h->d_loop; a.loop_runs = h->d_loop_runs;
+    launch_front_one(a, one_grid, stream);
+    T2_HIP(hipGetLastError());
+    h->one_seq += 1;
+    h->one_done += (unsigned long long)one_grid;
+    h->decim_phase = (int)((h->decim_phase + n_interp) & 1);
+    h->last_stream = stream; h->last_n = chunk; h->last_n_interp = n_interp;
+    h->loop_pending.push_back(chunk);
+    return n_out;
+}
+
+// the host follows the NCO of the OLDEST chunk launched by t2gpu_front_execute_loop_dev with the loop values that chunk ran on
+// (dvbt2_demodulator.cpp:165-171, 187-193 through t2_plan_nco): its accumulators are then where the device's are behind that chunk
+extern "C" int t2gpu_front_loop_follow(t2gpu_front *h, float pe, float fe)
+{
+    if (!h || h->loop_pending.empty()) { set_error("t2gpu_front_loop_follow: no chunk to follow"); return -1; }
+    const int32_t len = h->loop_pending.front();
+    h->loop_pending.erase(h->loop_pending.begin());
+    h->phase_nco = t2_wrap_2pi(h->phase_nco + pe);
+    h->nco_runs.clear();
+    t2_plan_nco(h->frequency_nco, 0, len, fe, h->phase_nco, h->nco_runs);
+    return 0;
+}
+extern "C" int t2gpu_front_loop_pending(const t2gpu_front *h) { return h ? (int)h->loop_pending.size() : -1; }
+
+// waits for `stream` and brings the device's loop state down: out8 = {phase_nco, frequency_nco, pe, fe, frequency_est_filtered, f_int,
+// p_int, error} -- what the host's own copies must equal when every chunk has been followed
+extern "C" int t2gpu_front_loop_read(t2gpu_front *h, float *out8, void *stream)
+{
+    if (!h || !out8) { set_error("t2gpu_front_loop_read: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    T2_HIP(hipStreamSynchronize((hipStream_t)stream));
+    T2DevLoop l;
+    T2_HIP(hipMemcpy(&l, h->d_loop, sizeof l, hipMemcpyDeviceToHost));
+    out8[0] = l.phase_nco; out8[1] = l.frequency_nco; out8[2] = l.pe; out8[3] = l.fe; out8[4] = l.frequency_est_filtered; out8[5] = l.f_int;
+    out8[6] = l.p_int; out8[7] = (float)l.error;
+    return 0;
 }
 
 extern "C" long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len, const float *pe, const float *fe,
@@ -572,6 +672,16 @@ extern "C" void t2gpu_sync_reset(t2gpu_sync *s, float sample_rate)
 extern "C" void t2gpu_sync_clear_frequency(t2gpu_sync *s) { if (s) s->frequency_est_filtered = 0.0f; }
 // symbol_acquisition after a re-tune (:291): resample -= correct_resample * resample
 extern "C" void t2gpu_sync_correct_resample(t2gpu_sync *s, double correct_resample) { if (s) s->resample -= correct_resample * s->resample; }
+
+// {phase_est_filtered, frequency_est_filtered, -, f_kp, f_ki, f_int, p_kp, p_ki, p_int, old_sample_rate_est}: t2gpu_front_loop_begin's state10 (the
+// caller fills in [2], its tuner)
+extern "C" void t2gpu_sync_export(const t2gpu_sync *s, float *out10)
+{
+    if (!s || !out10) return;
+    out10[0] = s->phase_est_filtered; out10[1] = s->frequency_est_filtered; out10[2] = 0.0f;
+    out10[3] = s->freq.k_p; out10[4] = s->freq.k_i; out10[5] = s->freq.old_integral;
+    out10[6] = s->phase.k_p; out10[7] = s->phase.k_i; out10[8] = s->phase.old_integral; out10[9] = s->old_sample_rate_est;
+}
 
 extern "C" void t2gpu_sync_get(const t2gpu_sync *s, double *out4)
 {

@@ -483,7 +483,7 @@ extern "C" int t2gpu_eq_fc_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
 // phase_offset / sample_rate_offset of one symbol from its pilots alone, and the guard correlation of the buffered symbol, in one launch
 // (ofdm_kernels.hip: sym_sync_kernel). kind: 0 data symbol idx_symbol, 1 P2, 2 frame closing.
 extern "C" int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_spectrum, const float *d_buffered, int guard,
-                                  float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream)
+                                  float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream)
 {
     if (!h || !d_spectrum || kind < 0 || kind > 2 || (h_small && !h_flag) || (d_buffered && guard < 0)) { set_error("t2gpu_sym_sync_dev: bad arguments"); return -1; }
     const EqParams &p = kind == 0 ? h->eq : kind == 1 ? h->eq_p2 : h->eq_fc;
@@ -493,7 +493,8 @@ extern "C" int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const
         idx_symbol = h->m.len_frame - 1;
     } else if (idx_symbol < h->m.n_p2 || idx_symbol >= h->m.n_p2 + h->rows) { set_error("t2gpu_sym_sync_dev: symbol index outside the frame's data symbols"); return -1; }
     T2_HIP(launch_sym_sync(p, reinterpret_cast<const float2 *>(d_spectrum), idx_symbol, reinterpret_cast<const float2 *>(d_buffered), guard,
-                           reinterpret_cast<float4 *>(d_cp4), reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream));
+                           reinterpret_cast<float4 *>(d_cp4), reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream,
+                           static_cast<T2DevLoop *>(d_loop)));
     return 0;
 }
 
@@ -501,7 +502,7 @@ extern "C" int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const
 // behind it: two launches where t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev are three (the synchronisation floats are formed by the
 // last workgroup of the FFT's second launch); pilot tables too large for that (P2, dense patterns) take the three. Same values either way.
 extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp,
-                                      float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *stream)
+                                      float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream)
 {
     if (!h || !tables || !d_buffered || !d_spectrum || kind < 0 || kind > 2 || guard < 0 || (h_small && !h_flag) || tables->m.fft_size != h->m.fft_size) {
         set_error("t2gpu_fft_sym_sync_dev: bad arguments");
@@ -518,12 +519,12 @@ extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kin
     const float2 *buffered = with_cp ? reinterpret_cast<const float2 *>(d_buffered) : nullptr;
     const hipError_t e = launch_fft_sym_sync(h->m.fft_size, reinterpret_cast<const float2 *>(d_buffered), reinterpret_cast<float2 *>(d_spectrum), h->d_twiddle, lay,
                                              h->d_fft_scratch, h->d_fft_count, p, idx, buffered, guard, reinterpret_cast<float4 *>(d_cp4),
-                                             reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream);
+                                             reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream, static_cast<T2DevLoop *>(d_loop));
     if (e == hipSuccess) return 0;
     if (e != hipErrorInvalidValue) { T2_HIP(e); }
     (void)hipGetLastError();
     if (t2gpu_fft_execute_strided_dev(h, d_buffered, guard, 0, 1, h->m.fft_size + guard, d_spectrum, 1, stream) != 0) return -1;
-    return t2gpu_sym_sync_dev(tables, kind, idx_symbol, d_spectrum, with_cp ? d_buffered : nullptr, guard, d_cp4, d_sync, h_small, h_flag, seq, stream);
+    return t2gpu_sym_sync_dev(tables, kind, idx_symbol, d_spectrum, with_cp ? d_buffered : nullptr, guard, d_cp4, d_sync, h_small, h_flag, seq, d_loop, stream);
 }
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,

@@ -83,6 +83,38 @@ class front_end(object):
             _err("t2gpu_front_execute_dev")
         return n, col
 
+    # ---- the loop on the device (include/t2gpu.h)
+    def loop_dev(self):
+        return self._l.t2gpu_front_loop_dev(self.h)
+
+    def loop_begin(self, state10, stream=None):
+        import torch
+        v = np.ascontiguousarray(state10, np.float32)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if self._l.t2gpu_front_loop_begin(self.h, v.ctypes.data, s) != 0:
+            _err("t2gpu_front_loop_begin")
+
+    def execute_loop_dev(self, d_i, d_q, chunk, out, arbitrary_resample, stream=None):
+        import torch
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        n = self._l.t2gpu_front_execute_loop_dev(self.h, int(chunk), float(arbitrary_resample), d_i.data_ptr(), d_q.data_ptr(), out.data_ptr(),
+                                                 out.numel(), s)
+        if n == -1:
+            _err("t2gpu_front_execute_loop_dev")
+        return n
+
+    def loop_follow(self, pe, fe):
+        if self._l.t2gpu_front_loop_follow(self.h, float(pe), float(fe)) != 0:
+            _err("t2gpu_front_loop_follow")
+
+    def loop_read(self, stream=None):
+        import torch
+        v = np.zeros(8, np.float32)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if self._l.t2gpu_front_loop_read(self.h, v.ctypes.data, s) != 0:
+            _err("t2gpu_front_loop_read")
+        return dict(phase_nco=v[0], frequency_nco=v[1], pe=v[2], fe=v[3], frequency_est_filtered=v[4], f_int=v[5], p_int=v[6], error=int(v[7]))
+
     def state(self):
         v = np.zeros(8, np.float32)
         if self._l.t2gpu_front_state(self.h, v.ctypes.data) != 0:
@@ -144,6 +176,12 @@ class sync_loops(object):
 
     def symbol(self, phase_est, sample_rate_est):
         self._l.t2gpu_sync_symbol(self.h, phase_est, sample_rate_est)
+
+    def export(self):
+        """The filters' state as t2gpu_front_loop_begin takes it (float32[10]; [2] is the caller's tuner)."""
+        v = np.zeros(10, np.float32)
+        self._l.t2gpu_sync_export(self.h, v.ctypes.data)
+        return v
 
     def get(self):
         v = np.zeros(4, np.float64)

@@ -121,7 +121,7 @@ class t2_ofdm(object):
         return cells, sync
 
     # ---- the by-reference outputs of {data,p2,fc}_symbol::execute from the pilots alone + the guard correlation, one symbol
-    def sym_sync_dev(self, kind, idx_symbol, spectrum, buffered=None, guard=0, host=None):
+    def sym_sync_dev(self, kind, idx_symbol, spectrum, buffered=None, guard=0, host=None, loop=None):
         """spectrum: float32 device tensor [fft_size][2]; buffered (optional): float32 device tensor [guard + fft_size][2] (guard
         first). Returns device tensors (cp4[4], sync[2]). host = (h_small, h_flag, seq): page-locked float32[8] / int32[1] tensors the
         kernel itself stores into, the word last."""
@@ -131,13 +131,13 @@ class t2_ofdm(object):
         sync = torch.zeros(2, dtype=torch.float32, device=spectrum.device)
         hs, hf, seq = (host[0].data_ptr(), host[1].data_ptr(), host[2]) if host else (None, None, 0)
         rc = self._l.t2gpu_sym_sync_dev(self._h, kind, idx_symbol, spectrum.data_ptr(), buffered.data_ptr() if buffered is not None else None,
-                                        guard, cp4.data_ptr(), sync.data_ptr(), hs, hf, seq,
+                                        guard, cp4.data_ptr(), sync.data_ptr(), hs, hf, seq, loop,
                                         torch.cuda.current_stream(spectrum.device).cuda_stream)
         if rc < 0:
             check(rc, "t2gpu_sym_sync_dev")
         return cp4, sync
 
-    def fft_sym_sync_dev(self, kind, idx_symbol, buffered, guard, with_cp=True, tables=None, host=None):
+    def fft_sym_sync_dev(self, kind, idx_symbol, buffered, guard, with_cp=True, tables=None, host=None, loop=None):
         """One buffered symbol (float32 device tensor [guard + fft_size][2], guard first): FFT of its useful part and, inside the FFT's
         last launch, sym_sync_dev's outputs. Returns (spectrum [fft_size][2], cp4[4], sync[2]). tables: the t2_ofdm whose pilot tables
         apply (default: this one)."""
@@ -148,7 +148,7 @@ class t2_ofdm(object):
         sync = torch.zeros(2, dtype=torch.float32, device=buffered.device)
         hs, hf, seq = (host[0].data_ptr(), host[1].data_ptr(), host[2]) if host else (None, None, 0)
         rc = self._l.t2gpu_fft_sym_sync_dev(self._h, (tables or self)._h, kind, idx_symbol, buffered.data_ptr(), guard, 1 if with_cp else 0,
-                                            spec.data_ptr(), cp4.data_ptr(), sync.data_ptr(), hs, hf, seq,
+                                            spec.data_ptr(), cp4.data_ptr(), sync.data_ptr(), hs, hf, seq, loop,
                                             torch.cuda.current_stream(buffered.device).cuda_stream)
         if rc < 0:
             check(rc, "t2gpu_fft_sym_sync_dev")

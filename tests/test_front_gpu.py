@@ -271,3 +271,74 @@ def test_decimator_and_farrow_against_reference_vectors(torch_cuda):
         f = front.front_end(sample_rate=front.SAMPLE_RATE * 2 * min(float(r), 0.5), max_samples=1 << 14)
         y = np.concatenate([f.farrow(x[:3000], float(r)), f.farrow(x[3000:], float(r))])
         assert np.array_equal(bits(y), bits(g["farrow%d_strict" % k]))
+
+
+def test_the_loop_on_the_device_plans_the_nco_as_the_host_does(torch_cuda):
+    """t2gpu_front_execute_loop_dev (the chunk's NCO runs planned by workgroup 0 from the device's loop state) against
+    t2gpu_front_execute_dev with the same loop values planned on the host: every cell bit for bit, and the device's accumulators where the
+    host's are after t2gpu_front_loop_follow -- residual offsets from none to one that takes hundreds of runs per chunk (searched in memory),
+    symbol-sized chunks and the few-sample ones that complete a symbol."""
+    import torch
+    from sdr_receiver_dvb_t2_amd import front
+    host = front.front_end(max_samples=1 << 17)
+    dev = front.front_end(max_samples=1 << 17)
+    rng = np.random.Generator(np.random.PCG64(41))
+    fes = [0.0, 2e-5, -3e-4, 7e-4, 0.0123, -6.9e-5, 1e-6]
+    for call, n in enumerate([33024, 2, 33022, 35072, 1, 33023, 8000]):
+        i_in, q_in = iq16(n, 700 + call)
+        pe, fe = np.float32(rng.standard_normal() * 0.05), np.float32(fes[call])
+        rs = host.resample - rng.integers(-2, 3) * 8.0e-9
+        di, dq = torch.from_numpy(i_in).cuda(), torch.from_numpy(q_in).cuda()
+        oa = torch.zeros(n + 64, dtype=torch.complex64, device="cuda")
+        ob = torch.zeros(n + 64, dtype=torch.complex64, device="cuda")
+        na, _ = host.execute_dev(di, dq, [n], oa, [pe], [fe], [rs])
+        st = np.zeros(10, np.float32); st[0] = pe; st[1] = fe                 # phase_est_filtered, frequency_est_filtered (tuner 0)
+        dev.loop_begin(st)
+        nb = dev.execute_loop_dev(di, dq, n, ob, rs)
+        assert nb == na, (call, na, nb)
+        dev.loop_follow(pe, fe)
+        got = dev.loop_read()
+        torch.cuda.synchronize()
+        assert torch.equal(oa[:na].view(torch.int32) if False else torch.view_as_real(oa[:na]).view(torch.int32), torch.view_as_real(ob[:nb]).view(torch.int32)), call
+        sa, sb = host.state(), dev.state()
+        for k in ("phase_nco", "frequency_nco", "x1", "dc_re", "dc_im"):
+            assert bits(np.float32(sa[k])) == bits(np.float32(sb[k])), (call, k, sa[k], sb[k])
+        assert got["error"] == 0
+        assert bits(np.float32(got["phase_nco"])) == bits(np.float32(sb["phase_nco"])), (call, got, sb)
+        assert bits(np.float32(got["frequency_nco"])) == bits(np.float32(sb["frequency_nco"])), (call, got, sb)
+    host.close(); dev.close()
+
+
+def test_the_loop_filters_on_the_device_are_the_hosts(torch_cuda):
+    """sym_sync_kernel with the device's loop state advances the two PI loop filters as t2gpu_sync_frequency / t2gpu_sync_symbol do: after
+    every symbol phase_est_filtered and frequency_est_filtered + tuner (published at h_small[6..7]) equal the host's, bit for bit."""
+    import torch
+    import sdr_receiver_dvb_t2_amd as pkg
+    from sdr_receiver_dvb_t2_amd import front
+    mode = (5, 1, 6, 4, 0, 59)
+    ctx = pkg.t2_ofdm(*mode, max_symbols=2)
+    fe_obj = front.front_end(max_samples=1 << 16)
+    loops = front.sync_loops()
+    st = loops.export(); st[2] = np.float32(1.25e-5)                          # an emulated tuner offset
+    fe_obj.loop_begin(st)
+    rng = np.random.Generator(np.random.PCG64(9))
+    guard, n = 256, 32768
+    h_small = torch.zeros(8, dtype=torch.float32).pin_memory()
+    h_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    for k in range(12):
+        spec = torch.from_numpy((rng.standard_normal((n, 2)) * 0.3).astype(np.float32)).cuda()
+        buffered = (rng.standard_normal((guard + n, 2)) * 0.25).astype(np.float32)
+        buffered[n:] = buffered[:guard] * np.float32(0.9) + np.float32(0.02 * (k - 5))
+        buf = torch.from_numpy(buffered).cuda()
+        with_cp = k % 4 != 3
+        cp4, sync = ctx.sym_sync_dev(0, 1 + k, spec, buf if with_cp else None, guard, host=(h_small, h_flag, k + 1), loop=fe_obj.loop_dev())
+        torch.cuda.synchronize()
+        cp4, sync = cp4.cpu().numpy(), sync.cpu().numpy()
+        if with_cp:
+            loops.frequency(float(cp4[2]), n)
+        loops.symbol(float(sync[0]), float(sync[1]))
+        g = loops.get()
+        want_pe, want_fe = np.float32(g["phase_est_filtered"]), np.float32(np.float32(g["frequency_est_filtered"]) + st[2])
+        assert bits(h_small.numpy()[6:7])[0] == bits(want_pe), (k, h_small[6], want_pe)
+        assert bits(h_small.numpy()[7:8])[0] == bits(want_fe), (k, h_small[7], want_fe)
+    ctx.close(); fe_obj.close(); loops.close()
