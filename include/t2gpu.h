@@ -468,6 +468,7 @@ long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, double arbitrar
                                   long out_cap_cells, void *stream);
 int t2gpu_front_loop_follow(t2gpu_front *h, float phase_est_filtered, float frequency_est_filtered_plus_tuner);
 int t2gpu_front_loop_pending(const t2gpu_front *h);
+int t2gpu_front_nco(const t2gpu_front *h, float *out2);   /* the host's {phase_nco, frequency_nco}, no device access */
 int t2gpu_front_loop_read(t2gpu_front *h, float *out8, void *stream);   /* {phase_nco, frequency_nco, pe, fe, frequency_est_filtered, f_int, p_int, error} */
 /* intermediate streams of the last call, for tests: which 0 = de-rotated samples (n_in cells), 1 = resampled (before the
  * decimator). Synchronises. Returns the number of cells copied. Since t2gpu_front_execute runs the Farrow stage and the decimator
@@ -502,6 +503,8 @@ void t2gpu_sync_symbol(t2gpu_sync *h, float phase_est, float sample_rate_est);
 void t2gpu_sync_get(const t2gpu_sync *h, double *out4);
 /* {phase_est_filtered, frequency_est_filtered, 0, f_kp, f_ki, f_int, p_kp, p_ki, p_int, old_sample_rate_est}: the filters' state (t2gpu_front_loop_begin) */
 void t2gpu_sync_export(const t2gpu_sync *h, float *out10);
+/* the three values t2gpu_sync_get's arbitrary_resample can take after the next t2gpu_sync_symbol (the tracker steps by -8e-9, 0 or +8e-9, :430-439) */
+void t2gpu_sync_candidates(const t2gpu_sync *h, double *out3);
 /* dvbt2_demodulator::reset (:111-127); frequency_est_filtered = 0 (brute-force guard search, :486); resample -= correct_resample *
  * resample after a re-tune (:291) */
 void t2gpu_sync_reset(t2gpu_sync *h, float sample_rate);
@@ -609,6 +612,11 @@ void t2gpu_demod_destroy(t2gpu_demod *h);
 int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *signals);
 int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const int16_t *q_in, t2gpu_signal_estimate *signal_);
 int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
+/* The tracking loops of a frame's data symbols on the device (on = 1: a symbol's launches are followed by the next chunk's without waiting
+ * for its results, the host reads them one symbol behind -- "the loop on the device" above) or on the host for every symbol (0, the
+ * default: measured 3 % faster as long as the caller's thread also makes the equaliser's launches and emits the signals, DESIGN.md
+ * section 6). Same cells, same TS either way. */
+int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on);
 int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
 
 /* ---------------------------------------------------------------- batch receiver: buffers of whole T2 frames --------------

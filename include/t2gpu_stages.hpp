@@ -706,6 +706,8 @@ public:
     }
     // a recorded buffer has no tuner to move: see t2gpu_demod_set_tuner
     void set_tuner(double offset_hz) { if (t2gpu_demod_set_tuner(h_, offset_hz) != 0) fail("t2gpu_demod_set_tuner"); }
+    // the tracking loops of a frame's data symbols on the device (t2gpu_demod_set_device_loop); off unless asked for
+    void set_device_loop(bool on) { if (t2gpu_demod_set_device_loop(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_device_loop"); }
     t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
 private:
     static l1_postsignalling pack(const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn)

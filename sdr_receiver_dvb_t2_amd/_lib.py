@@ -88,6 +88,7 @@ PROTOTYPES = {
     "t2gpu_demod_connect": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "t2gpu_demod_set_device_loop": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_eq_p2_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp]),
     "t2gpu_eq_fc_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_long, _vp, _vp]),
@@ -143,8 +144,10 @@ PROTOTYPES = {
     "t2gpu_front_execute_loop_dev": (ctypes.c_long, [_vp, ctypes.c_int32, ctypes.c_double, _vp, _vp, _vp, ctypes.c_long, _vp]),
     "t2gpu_front_loop_follow": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_front_loop_pending": (ctypes.c_int, [_vp]),
+    "t2gpu_front_nco": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_front_loop_read": (ctypes.c_int, [_vp, _vp, _vp]),
     "t2gpu_sync_export": (None, [_vp, _vp]),
+    "t2gpu_sync_candidates": (None, [_vp, _vp]),
     "t2gpu_eq_data_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ofdm_mode_info": (ctypes.c_int, [ctypes.c_int] * 6 + [_vp]),
     "t2gpu_table_symbol_carriers": (ctypes.c_int, [ctypes.c_int] * 7 + [_vp, _vp]),

@@ -94,6 +94,13 @@ struct t2gpu_demod {
     // A data symbol's `data` signal is emitted once the NEXT chunk's front-end launch is on its way (or at the end of the call): what the
     // consumer does in it (the de-interleaver's push: ~9 us of host time and a launch) then runs beside the front-end kernel instead of
     // in front of it. The cells stay where they are until the next equaliser launch, which comes later still.
+    // The loop on the device (include/t2gpu.h): between a frame's P2 and its last data symbol the tracking filters and the NCO's accumulators
+    // live on the device, a data symbol's launches are followed by the next chunk's without waiting for its results, and the host reads
+    // them one symbol behind (pend), recomputing the same floats for its own copies. Checked when the mode is left, once per frame.
+    bool dev_loop = false;             // t2gpu_demod_set_device_loop
+    bool dev_mode = false;
+    struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0; } pend;
+    long dev_symbols = 0, dev_speculated = 0, dev_waited = 0;
     int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
     int pending_buf = 0;               // ... the buffer set they are in
     unsigned pending_seq = 0;          // ... and the value h_flag[16] takes when they have arrived
@@ -140,6 +147,7 @@ int reset(t2gpu_demod *h)
     h->p2_init = false;
     h->demodulator_init = false;
     h->next_symbol_type = SYMBOL_TYPE_P1;
+    h->dev_mode = false; h->pend.valid = false;
     ++h->resets;
     return 0;
 }
@@ -239,11 +247,11 @@ bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_
 }
 
 // the symbol's two synchronisation floats and (cp != null) its guard correlation, stored by sym_sync_kernel; seq = the launch's word
-bool sync_results(t2gpu_demod *h, unsigned seq, float *cp, float *sv)
+bool sync_results(t2gpu_demod *h, unsigned seq, int k, float *cp, float *sv)
 {
     if (!wait_word(h, h->h_flag, seq, h->stream)) return false;
-    if (cp) std::memcpy(cp, h->h_small, 16);
-    std::memcpy(sv, h->h_small + 4, 8);
+    if (cp) std::memcpy(cp, h->h_small + 8 * k, 16);
+    std::memcpy(sv, h->h_small + 8 * k + 4, 8);
     return true;
 }
 
@@ -297,10 +305,90 @@ int move_cells(t2gpu_demod *h, float *dst, const float *src, int n)
     return 0;
 }
 
+// the tracking loops with a symbol's floats (:328-330, 429-439) and the readout the GUI gets (:441-444)
+void loops_after_symbol(t2gpu_demod *h, bool have_cp, const float *cp, const float *sv)
+{
+    if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
+    t2gpu_sync_symbol(h->sync, sv[0], sv[1]);
+    if (h->sig.replace_null_indicator) {
+        double g[4];
+        t2gpu_sync_get(h->sync, g);
+        const float PI_X_2 = 3.14159274101257324219f * 2.0f;
+        h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
+    }
+}
+
+// the chunks the device has run on its own loop values and the host has not followed yet: with the host's values as they stand
+int follow_chunks(t2gpu_demod *h)
+{
+    double g[4];
+    t2gpu_sync_get(h->sync, g);
+    const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+    while (t2gpu_front_loop_pending(h->front) > 0)
+        if (t2gpu_front_loop_follow(h->front, pe, fe) != 0) return -1;
+    return 0;
+}
+
+// the data symbol whose launches went out without waiting: its floats, the loops, the chunks launched behind it, its `data` signal in turn
+int consume_pending(t2gpu_demod *h)
+{
+    if (!h->pend.valid) return 0;
+    h->pend.valid = false;
+    float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sv[2] = {0.0f, 0.0f};
+    h->prof.start();
+    if (!sync_results(h, h->pend.seq_a, h->pend.k, h->pend.have_cp ? cp : nullptr, sv)) return -1;
+    h->prof.stop(PF_SV);
+    loops_after_symbol(h, h->pend.have_cp, cp, sv);
+    // what the device's filters made of the same floats travels with them: the host's copies must be the same numbers
+    {
+        double g[4];
+        t2gpu_sync_get(h->sync, g);
+        const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+        if (std::memcmp(&pe, h->h_small + 8 * h->pend.k + 6, 4) != 0 || std::memcmp(&fe, h->h_small + 8 * h->pend.k + 7, 4) != 0) {
+            set_error("t2gpu_demod: the tracking loops on the device and on the host disagree");
+            return -1;
+        }
+    }
+    if (follow_chunks(h) != 0) return -1;
+    if (flush_data_signal(h) != 0) return -1;
+    if (h->pend.carry) { h->pending_data = h->c_data; h->pending_buf = h->pend.k; h->pending_seq = h->pend.seq_cells; }
+    return 0;
+}
+
+int enter_dev_mode(t2gpu_demod *h)
+{
+    float st[10];
+    t2gpu_sync_export(h->sync, st);
+    st[2] = (float)h->tuner;
+    if (t2gpu_front_loop_begin(h->front, st, h->stream) != 0) return -1;
+    h->dev_mode = true;
+    return 0;
+}
+
+// back to the loops on the host: everything outstanding is read, and the device's state must be where the host's copies are
+int leave_dev_mode(t2gpu_demod *h)
+{
+    if (!h->dev_mode) return 0;
+    if (consume_pending(h) != 0) return -1;
+    h->dev_mode = false;
+    float d[8], st[8] = {};
+    if (t2gpu_front_loop_read(h->front, d, h->stream) != 0 || t2gpu_front_nco(h->front, st + 4) != 0) return -1;
+    double g[4];
+    t2gpu_sync_get(h->sync, g);
+    const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+    if (d[7] != 0.0f) { set_error("t2gpu_demod: the NCO planner on the device ran out of room"); return -1; }
+    if (std::memcmp(&d[0], &st[4], 4) != 0 || std::memcmp(&d[1], &st[5], 4) != 0 || std::memcmp(&d[2], &pe, 4) != 0 || std::memcmp(&d[3], &fe, 4) != 0) {
+        set_error("t2gpu_demod: the device's loop state is not where the host's copy is");
+        return -1;
+    }
+    return 0;
+}
+
 int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal_, const float *src)
 {
     int consume = 0;
     while (consume < len_in) {
+        if (h->next_symbol_type != SYMBOL_TYPE_DATA && leave_dev_mode(h) != 0) return -1;   // (the loop on the device is for a frame's data symbols)
         if (h->next_symbol_type == SYMBOL_TYPE_P1) {
             if (flush_data_signal(h) != 0) return -1;                               // (the frame's last symbol completes its TI block: not held back)
             t2gpu_p1_result r;
@@ -361,7 +449,8 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
         const unsigned seq_a = ++h->seq;
         if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
-                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small, h->h_flag, seq_a, nullptr, h->stream) != 0) return -1;
+                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small + 8 * k, h->h_flag, seq_a,
+                                   h->dev_mode ? t2gpu_front_loop_dev(h->front) : nullptr, h->stream) != 0) return -1;
         T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         h->prof.stop(PF_CP);
         h->est_chunk = 0;
@@ -371,27 +460,37 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // next chunk's front end); the cells to the host by a launch behind it
         T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
+            // the loop on the device: this symbol's filters run behind its floats in the launch just made; the symbol BEFORE it is read now (its
+            // floats, the loops' host copies, its chunks' NCO) and the one before THAT hands its cells on -- ahead of this symbol's equaliser
+            // in the cells' stream, whose buffer set is the one those cells are in
+            if (h->dev_mode && consume_pending(h) != 0) return -1;
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[k], h->d_symidx + h->idx_symbol, 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
             unsigned seq_cells = 0;
             if (carry && !(seq_cells = publish_cells(h, k, h->c_data, h->eq_stream))) return -1;
             // (with a consumer the host waits for these cells -- published behind the equaliser -- before the symbol after next is launched:
             // buffer set k is free by then without an event)
-            if (!carry) { T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream)); h->eq_busy[k] = true; }
+            // (with the loop on the device the next symbol but one is launched before this one's cells have been waited for: the event then too)
+            if (!carry || h->dev_mode) { T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream)); h->eq_busy[k] = true; }
             h->prof.stop(PF_FFT_EQ);
-            // the symbol BEFORE this one hands its cells on now: everything of this symbol is on its way, the consumer's work (the
-            // de-interleaver's push: ~9 us of host time and a launch) runs beside it instead of in front of it
-            if (flush_data_signal(h) != 0) return -1;
-            h->prof.start();
-            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
-            if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
-            h->prof.stop(PF_SV);
-            if (carry) { h->pending_data = h->c_data; h->pending_buf = k; h->pending_seq = seq_cells; }
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
                 h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
                 if (!h->frame_closing_symbol) ++h->frames;
             }
+            if (h->dev_mode) {
+                h->pend.valid = true; h->pend.seq_a = seq_a; h->pend.have_cp = have_cp; h->pend.carry = carry; h->pend.k = k; h->pend.seq_cells = seq_cells;
+                ++h->dev_symbols;
+                continue;
+            }
+            // the symbol BEFORE this one hands its cells on now: everything of this symbol is on its way, the consumer's work (the
+            // de-interleaver's push: ~9 us of host time and a launch) runs beside it instead of in front of it
+            if (flush_data_signal(h) != 0) return -1;
+            h->prof.start();
+            if (!sync_results(h, seq_a, k, have_cp ? cp : nullptr, sv)) return -1;
+            if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
+            h->prof.stop(PF_SV);
+            if (carry) { h->pending_data = h->c_data; h->pending_buf = k; h->pending_seq = seq_cells; }
         } else if (h->next_symbol_type == SYMBOL_TYPE_FC) {
             if (flush_data_signal(h) != 0) return -1;
             if (t2gpu_eq_fc_execute_dev(h->data_ofdm, h->d_spec[k], 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
@@ -400,7 +499,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             if (carry && !seq_cells) return -1;
             T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
             h->eq_busy[k] = true;
-            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv)) return -1;
+            if (!sync_results(h, seq_a, k, have_cp ? cp : nullptr, sv)) return -1;
             if (carry && !wait_word(h, h->h_flag + 16, seq_cells, h->eq_stream)) return -1;
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             if (carry) h->sig.data(h->sig.user, h->n_fc, h->h_cells[k]);
@@ -414,7 +513,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             if (!seq_cells) return -1;
             T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream));
             h->eq_busy[k] = true;
-            if (!sync_results(h, seq_a, have_cp ? cp : nullptr, sv) || !wait_word(h, h->h_flag + 16, seq_cells, h->eq_stream)) return -1;
+            if (!sync_results(h, seq_a, k, have_cp ? cp : nullptr, sv) || !wait_word(h, h->h_flag + 16, seq_cells, h->eq_stream)) return -1;
             const float *c = h->h_cells[k];
             if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
             h->prof.start();
@@ -473,6 +572,9 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
             const float PI_X_2 = 3.14159274101257324219f * 2.0f;
             h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
         }
+        // behind a frame's P2 symbol the loops go to the device for its data symbols
+        if (h->dev_loop && !h->dev_mode && h->next_symbol_type == SYMBOL_TYPE_DATA && h->crc32_l1_pre && h->demodulator_init && h->data_ofdm &&
+            enter_dev_mode(h) != 0) return -1;
     }
     return 0;
 }
@@ -511,7 +613,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     ok = ok && hipStreamCreateWithPriority(&h->eq_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 64, hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 128, hipHostMallocCoherent) == hipSuccess;   // two slots of 8 floats: a symbol's floats are read while the next symbol's launch may already store its own
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 128, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) h->h_flag[0] = h->h_flag[16] = 0;
@@ -541,6 +643,8 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
         double tot = 0;
         for (int k = 0; k < PF_N; ++k) tot += h->prof.t[k];
         std::fprintf(stderr, "t2gpu_demod profile (host wall time inside execute(), %ld symbols):\n", h->symbols);
+        std::fprintf(stderr, "  loop on the device: %ld data symbols; chunks launched ahead of a symbol's results %ld, chunks that waited for them %ld\n",
+                     h->dev_symbols, h->dev_speculated, h->dev_waited);
         for (int k = 0; k < PF_N; ++k)
             std::fprintf(stderr, "  %-46s %9.3f ms  %5.1f %%  %7ld calls  %8.1f us each\n", PF_NAME[k], h->prof.t[k] * 1e3, 100.0 * h->prof.t[k] / (tot > 0 ? tot : 1),
                          h->prof.n[k], h->prof.n[k] ? h->prof.t[k] * 1e6 / h->prof.n[k] : 0.0);
@@ -559,7 +663,23 @@ extern "C" int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *si
 extern "C" int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz)
 {
     if (!h) { set_error("t2gpu_demod_set_tuner: bad arguments"); return -1; }
+    if (h->dev_mode) {                                          // (the device's copy of the loops holds the tuner it was sent up with)
+        T2_HIP(hipSetDevice(h->device));
+        if (leave_dev_mode(h) != 0) return -1;
+    }
     h->tuner = 2.0 * 3.14159265358979323846 * offset_hz / (double)SAMPLE_RATE_HZ;
+    return 0;
+}
+
+// on = 0 (default): the tracking loops stay on the host for every symbol (one round trip per symbol); 1: on the device for a frame's data symbols
+extern "C" int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on)
+{
+    if (!h) { set_error("t2gpu_demod_set_device_loop: bad arguments"); return -1; }
+    if (!on && h->dev_mode) {
+        T2_HIP(hipSetDevice(h->device));
+        if (leave_dev_mode(h) != 0) return -1;
+    }
+    h->dev_loop = on != 0;
     return 0;
 }
 
@@ -604,11 +724,27 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         }
         double g[4];
         t2gpu_sync_get(h->sync, g);
-        const double arbitrary_resample = g[3];                                     // :157-158
-        int32_t chunk = (int32_t)std::nearbyint(h->est_chunk * arbitrary_resample * 2.0);   // :160
-        if (chunk > len_in - idx_in) chunk = len_in - idx_in;
+        double arbitrary_resample = g[3];                                           // :157-158
+        auto chunk_for = [&](double r) {
+            int32_t c = (int32_t)std::nearbyint(h->est_chunk * r * 2.0);            // :160
+            return c > len_in - idx_in ? (int32_t)(len_in - idx_in) : c;
+        };
+        if (h->dev_mode && h->pend.valid) {
+            // the loop on the device: the symbol whose results are still out moves the resampling value by -8e-9, 0 or +8e-9 (:430-439). When
+            // all three mean the same float for the Farrow stage and the same chunk, this chunk does not wait for it.
+            double c3[3];
+            t2gpu_sync_candidates(h->sync, c3);
+            const bool same = (float)c3[0] == (float)c3[1] && (float)c3[2] == (float)c3[1] && chunk_for(c3[0]) == chunk_for(c3[1]) && chunk_for(c3[2]) == chunk_for(c3[1]);
+            if (same) ++h->dev_speculated;
+            else {
+                ++h->dev_waited;
+                if (consume_pending(h) != 0) return -1;
+                t2gpu_sync_get(h->sync, g);
+                arbitrary_resample = g[3];
+            }
+        }
+        int32_t chunk = chunk_for(arbitrary_resample);
         if (chunk > CHUNK_MAX) { set_error("t2gpu_demod_execute: chunk larger than the work buffers"); return -1; }
-        const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
         h->prof.start();
         // a chunk that continues (or starts) an OFDM symbol is written where the symbol is collected; its few cells beyond the symbol's
         // end, if any, are moved by symbol_acquisition. P1 searches read the chunk from d_out.
@@ -618,14 +754,26 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             dst = h->d_buffer_sym + 2 * (size_t)h->idx_buffer_sym;
             cap = SYM_BUF_CELLS - h->idx_buffer_sym;
         }
-        const long n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
-                                                   h->d_q + (size_t)idx_in * h->stride, dst, cap, nullptr, h->stream);
+        long n_out = -2;
+        if (h->dev_mode) {
+            n_out = t2gpu_front_execute_loop_dev(h->front, chunk, arbitrary_resample, h->d_i + (size_t)idx_in * h->stride, h->d_q + (size_t)idx_in * h->stride,
+                                                 dst, cap, h->stream);
+            if (n_out == -1) return -1;
+            if (n_out == -2) { if (leave_dev_mode(h) != 0) return -1; }             // (a chunk the one-launch form does not take: this frame goes on with the loops on the host)
+            else if (!h->pend.valid && follow_chunks(h) != 0) return -1;            // nothing out: the device ran on the values the host holds
+        }
+        if (n_out == -2) {
+            t2gpu_sync_get(h->sync, g);
+            const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
+            n_out = t2gpu_front_execute_dev(h->front, 1, &chunk, &pe, &fe, &arbitrary_resample, h->d_i + (size_t)idx_in * h->stride,
+                                            h->d_q + (size_t)idx_in * h->stride, dst, cap, nullptr, h->stream);
+        }
         h->prof.stop(PF_FRONT);
         if (n_out < 0) return -1;
         idx_in += chunk;
         if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
-    if (flush_data_signal(h) != 0) return -1;
+    if (consume_pending(h) != 0 || flush_data_signal(h) != 0) return -1;           // everything this buffer completed has been handed on
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, h->stream) != 0) return -1;

@@ -439,6 +439,13 @@ extern "C" int t2gpu_front_loop_follow(t2gpu_front *h, float pe, float fe)
     t2_plan_nco(h->frequency_nco, 0, len, fe, h->phase_nco, h->nco_runs);
     return 0;
 }
+// the host's two NCO accumulators as they stand (no device access): {phase_nco, frequency_nco}
+extern "C" int t2gpu_front_nco(const t2gpu_front *h, float *out2)
+{
+    if (!h || !out2) return -1;
+    out2[0] = h->phase_nco; out2[1] = h->frequency_nco;
+    return 0;
+}
 extern "C" int t2gpu_front_loop_pending(const t2gpu_front *h) { return h ? (int)h->loop_pending.size() : -1; }
 
 // waits for `stream` and brings the device's loop state down: out8 = {phase_nco, frequency_nco, pe, fe, frequency_est_filtered, f_int,
@@ -689,6 +696,22 @@ extern "C" void t2gpu_sync_get(const t2gpu_sync *s, double *out4)
     double r = s->resample - s->sample_rate_est_filtered;                                  // :157-158
     if (r > s->max_resample) r = s->max_resample;
     out4[0] = s->phase_est_filtered; out4[1] = s->frequency_est_filtered; out4[2] = s->sample_rate_est_filtered; out4[3] = r;
+}
+
+// the three values arbitrary_resample (t2gpu_sync_get's [3]) can take after the NEXT t2gpu_sync_symbol: the tracker steps by -8e-9, 0 or
+// +8e-9 on the sign of a difference of two floats (dvbt2_demodulator.cpp:430-439), whatever they are
+extern "C" void t2gpu_sync_candidates(const t2gpu_sync *s, double *out3)
+{
+    if (!s || !out3) return;
+    const double step = 8.0e-9;
+    for (int d = -1; d <= 1; ++d) {
+        double f = s->sample_rate_est_filtered;
+        if (d < 0) { f -= step; if (s->resample - f < -s->max_resample) f += step; }
+        else if (d > 0) { f += step; if (s->resample - f > s->max_resample) f -= step; }
+        double r = s->resample - f;
+        if (r > s->max_resample) r = s->max_resample;
+        out3[d + 1] = r;
+    }
 }
 
 // ---- planner expansion for tests (host only) -----------------------------------------------------------------------------

@@ -157,6 +157,8 @@ int main(int argc, char **argv)
             const int buf_len = std::atoi(argv[5]), need_plp = std::atoi(argv[6]);
             std::FILE *log = std::fopen(argv[7], "w");
             t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f);
+            // STAGE_DEVICE_LOOP=1: the tracking loops of a frame's data symbols on the device (same cells, same TS)
+            if (std::getenv("STAGE_DEVICE_LOOP") && std::atoi(std::getenv("STAGE_DEVICE_LOOP")) != 0) demodulator.set_device_loop(true);
             t2::llr_demapper qam;
             t2::ldpc_decoder ldpc;
             t2::bch_decoder bch;

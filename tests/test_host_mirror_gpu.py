@@ -209,6 +209,15 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     # there; the last frames' FEC blocks wait in an unfinished SIMD batch
     assert len(found) >= 3 and found == list(range(found[0], found[0] + len(found))) and found[0] <= 8, (found, log)
     assert found[-1] >= n_frames - 2, (found, log)
+    # the same stream with the tracking loops of every frame's data symbols ON THE DEVICE (t2gpu_demod_set_device_loop: sym_sync_kernel's
+    # last lane runs the two loop filters, front_one_kernel's workgroup 0 plans the chunk's NCO, the next chunk is launched ahead of the
+    # symbol's results and the host follows one symbol behind, comparing as it goes): the same transport stream, byte for byte, and the
+    # same loop values at the end
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_dev.ts", buf, 0, tmp_path / "log_dev.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1"})
+    assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
+    log_dev = open(tmp_path / "log_dev.txt").read()
+    assert [ln for ln in log_dev.splitlines() if ln.startswith("buf ")] == lines
 
 
 def test_demodulator_class_resets_and_recovers(driver, tmp_path):
@@ -228,6 +237,10 @@ def test_demodulator_class_resets_and_recovers(driver, tmp_path):
     found = [f for f in range(n_frames) if got.find(marks[f]) >= 0]
     assert any(f < spoil for f in found) and any(f > spoil + 1 for f in found), (found, log)
     assert spoil not in found, found
+    # ... and with the loops on the device: a reset in the middle of it, the same bytes
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_dev.ts", buf, 0, tmp_path / "log_dev.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1"})
+    assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
 
 
 def test_example_rx_file_program(driver, tmp_path):
