@@ -265,7 +265,7 @@ def drop_in_leg(w, ui, uq, device, frames=72, warm_frames=12, sent=None, saturat
         wrap = os.environ.get("T2GPU_DROPIN_WRAPPER", "").split()          # e.g. "rocprofv3 --kernel-trace --stats -d gpurun_out/x --"
         ts_path = os.path.join(d, "out.ts")
         p = subprocess.run(wrap + [DROP_IN_EXE, os.path.join(d, "i.s16"), os.path.join(d, "q.s16"), "--out", ts_path, "--buf", str(DROP_IN_BUF),
-                            "--warm", str(warm), "--json", "1", "--device", str(device), "--saturate", "1" if saturate else "0"],
+                            "--warm", str(warm), "--json", "1", "--device", str(device), "--saturate", "1" if saturate else "0"] + os.environ.get("T2GPU_DROPIN_ARGS", "").split(),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
         wall = time.perf_counter() - t0
         ts = np.fromfile(ts_path, np.uint8) if p.returncode == 0 and os.path.exists(ts_path) else np.zeros(0, np.uint8)

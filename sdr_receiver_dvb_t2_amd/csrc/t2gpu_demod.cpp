@@ -14,6 +14,10 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +105,22 @@ struct t2gpu_demod {
     bool dev_mode = false;
     struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0; } pend;
     long dev_symbols = 0, dev_speculated = 0, dev_waited = 0;
+    // ... and in that mode a data symbol's equaliser, the publishing of its cells and its `data` signal are the business of a thread of
+    // the object's own (cells_run): the caller's thread then makes three launches per symbol and reads six floats, which is what lets the
+    // device's chain, not the host's runtime calls, set the pace. Jobs go through a ring; `done` counts the symbols whose signal has
+    // been emitted (their buffer set is free again); the caller's thread drains the ring before it emits a signal itself (P2, FC).
+    struct CellsJob { int k = 0, idx_symbol = 0, n_cells = 0; bool carry = false; };
+    std::thread cells_thread;
+    std::mutex cells_m;
+    std::condition_variable cells_cv;
+    CellsJob cells_q[4];
+    unsigned cells_head = 0, cells_tail = 0;
+    bool cells_stop = false, cells_drain = false;
+    std::atomic<unsigned> cells_done{0};
+    unsigned cells_submitted = 0;
+    std::atomic<int> cells_failed{0};
+    std::string cells_error;
+    hipEvent_t ev_fft2[2] = {nullptr, nullptr};
     int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
     int pending_buf = 0;               // ... the buffer set they are in
     unsigned pending_seq = 0;          // ... and the value h_flag[16] takes when they have arrived
@@ -119,6 +139,12 @@ constexpr int CHUNK_MAX = 2 * (MAX_SYMBOL + P1_LEN) + 4096;                     
 
 void free_all(t2gpu_demod *h)
 {
+    if (h->cells_thread.joinable()) {
+        { std::lock_guard<std::mutex> lk(h->cells_m); h->cells_stop = true; }
+        h->cells_cv.notify_one();
+        h->cells_thread.join();
+    }
+    for (int k = 0; k < 2; ++k) if (h->ev_fft2[k]) hipEventDestroy(h->ev_fft2[k]);
     if (h->front) t2gpu_front_destroy(h->front);
     if (h->p1) t2gpu_p1_destroy(h->p1);
     if (h->sync) t2gpu_sync_destroy(h->sync);
@@ -231,7 +257,7 @@ int init_data(t2gpu_demod *h)
 
 // A sequence word the device raises behind its own stores into page-locked memory (publish_symbol_kernel, sym_sync_kernel): the host
 // reads it instead of waiting for copies and the stream (~40 us per symbol). Values only grow; false on an error.
-bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_t stream)
+bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_t stream, bool callers_thread = true)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; (int)(*flag - seq) < 0; ++spins) {
@@ -242,7 +268,7 @@ bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    h->saw_results = true;
+    if (callers_thread) h->saw_results = true;
     return true;
 }
 
@@ -305,6 +331,71 @@ int move_cells(t2gpu_demod *h, float *dst, const float *src, int n)
     return 0;
 }
 
+// ---- the cells' thread (the loop on the device): equaliser + publishing of symbol j, then the `data` signal of symbol j - 1
+void cells_run(t2gpu_demod *h)
+{
+    hipSetDevice(h->device);
+    bool have_prev = false;
+    t2gpu_demod::CellsJob prev;
+    unsigned prev_seq = 0;
+    auto emit_prev = [&]() {
+        if (prev.carry) {
+            if (!wait_word(h, h->h_flag + 16, prev_seq, h->eq_stream, false)) { h->cells_error = last_error(); h->cells_failed.store(1); }
+            else h->sig.data(h->sig.user, prev.n_cells, h->h_cells[prev.k]);
+        } else if (hipStreamSynchronize(h->eq_stream) != hipSuccess) { h->cells_error = "hipStreamSynchronize (cells' stream)"; h->cells_failed.store(1); }
+        have_prev = false;
+        h->cells_done.fetch_add(1, std::memory_order_release);
+    };
+    for (;;) {
+        std::unique_lock<std::mutex> lk(h->cells_m);
+        h->cells_cv.wait(lk, [&] { return h->cells_stop || h->cells_head != h->cells_tail || (h->cells_drain && have_prev); });
+        if (h->cells_stop) return;
+        if (h->cells_head != h->cells_tail) {
+            const t2gpu_demod::CellsJob job = h->cells_q[h->cells_head % 4];
+            ++h->cells_head;
+            lk.unlock();
+            unsigned seq = 0;
+            bool ok = hipStreamWaitEvent(h->eq_stream, h->ev_fft2[job.k], 0) == hipSuccess &&
+                      t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[job.k], h->d_symidx + job.idx_symbol, 1, h->d_cells[job.k], nullptr, h->eq_stream) >= 0;
+            if (ok && job.carry) ok = (seq = publish_cells(h, job.k, job.n_cells, h->eq_stream)) != 0;
+            if (!ok) { h->cells_error = last_error(); h->cells_failed.store(1); }
+            if (have_prev) emit_prev();
+            prev = job; prev_seq = seq; have_prev = true;
+        } else {
+            lk.unlock();
+            emit_prev();
+        }
+    }
+}
+
+// the caller's thread: hands a symbol to the cells' thread / waits until the symbols up to number `upto` have been handed on / all of them
+void cells_submit(t2gpu_demod *h, const t2gpu_demod::CellsJob &job)
+{
+    { std::lock_guard<std::mutex> lk(h->cells_m); h->cells_q[h->cells_tail % 4] = job; ++h->cells_tail; }
+    ++h->cells_submitted;
+    h->cells_cv.notify_one();
+}
+int cells_wait(t2gpu_demod *h, unsigned upto)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; (int)(h->cells_done.load(std::memory_order_acquire) - upto) < 0; ++spins) {
+        t2_cpu_relax();
+        if (h->cells_failed.load()) break;
+        if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { set_error("t2gpu_demod: the cells' thread does not answer"); return -1; }
+    }
+    if (h->cells_failed.load()) { set_error("t2gpu_demod (cells' thread): " + h->cells_error); return -1; }
+    return 0;
+}
+int cells_drain(t2gpu_demod *h)
+{
+    if (h->cells_done.load(std::memory_order_acquire) == h->cells_submitted) return h->cells_failed.load() ? cells_wait(h, h->cells_submitted) : 0;
+    { std::lock_guard<std::mutex> lk(h->cells_m); h->cells_drain = true; }
+    h->cells_cv.notify_one();
+    const int rc = cells_wait(h, h->cells_submitted);
+    { std::lock_guard<std::mutex> lk(h->cells_m); h->cells_drain = false; }
+    return rc;
+}
+
 // the tracking loops with a symbol's floats (:328-330, 429-439) and the readout the GUI gets (:441-444)
 void loops_after_symbol(t2gpu_demod *h, bool have_cp, const float *cp, const float *sv)
 {
@@ -349,18 +440,20 @@ int consume_pending(t2gpu_demod *h)
             return -1;
         }
     }
-    if (follow_chunks(h) != 0) return -1;
-    if (flush_data_signal(h) != 0) return -1;
-    if (h->pend.carry) { h->pending_data = h->c_data; h->pending_buf = h->pend.k; h->pending_seq = h->pend.seq_cells; }
-    return 0;
+    return follow_chunks(h);                                   // (its cells are the cells' thread's business)
 }
 
 int enter_dev_mode(t2gpu_demod *h)
 {
+    if (flush_data_signal(h) != 0) return -1;                  // (a symbol read on the host hands its cells on before the cells' thread's first)
     float st[10];
     t2gpu_sync_export(h->sync, st);
     st[2] = (float)h->tuner;
     if (t2gpu_front_loop_begin(h->front, st, h->stream) != 0) return -1;
+    if (!h->cells_thread.joinable()) {
+        for (int k = 0; k < 2; ++k) if (!h->ev_fft2[k]) T2_HIP(hipEventCreateWithFlags(&h->ev_fft2[k], hipEventDisableTiming));
+        h->cells_thread = std::thread(cells_run, h);
+    }
     h->dev_mode = true;
     return 0;
 }
@@ -369,7 +462,7 @@ int enter_dev_mode(t2gpu_demod *h)
 int leave_dev_mode(t2gpu_demod *h)
 {
     if (!h->dev_mode) return 0;
-    if (consume_pending(h) != 0) return -1;
+    if (consume_pending(h) != 0 || cells_drain(h) != 0) return -1;
     h->dev_mode = false;
     float d[8], st[8] = {};
     if (t2gpu_front_loop_read(h->front, d, h->stream) != 0 || t2gpu_front_nco(h->front, st + 4) != 0) return -1;
@@ -378,7 +471,10 @@ int leave_dev_mode(t2gpu_demod *h)
     const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
     if (d[7] != 0.0f) { set_error("t2gpu_demod: the NCO planner on the device ran out of room"); return -1; }
     if (std::memcmp(&d[0], &st[4], 4) != 0 || std::memcmp(&d[1], &st[5], 4) != 0 || std::memcmp(&d[2], &pe, 4) != 0 || std::memcmp(&d[3], &fe, 4) != 0) {
-        set_error("t2gpu_demod: the device's loop state is not where the host's copy is");
+        char msg[320];
+        std::snprintf(msg, sizeof msg, "t2gpu_demod: the device's loop state is not where the host's copy is (phase_nco %.9g / %.9g, frequency_nco %.9g / %.9g, "
+                      "phase_est_filtered %.9g / %.9g, frequency input %.9g / %.9g)", d[0], st[4], d[1], st[5], d[2], pe, d[3], fe);
+        set_error(msg);
         return -1;
     }
     return 0;
@@ -444,6 +540,8 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         // FFT writes into it -- long since, as a rule
         const int k = h->cur ^= 1;
         if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
+        // (the loop on the device: set k was the symbol's before last, which the cells' thread has handed on by now -- as a rule)
+        if (h->dev_mode && h->cells_submitted >= 2 && cells_wait(h, h->cells_submitted - 1) != 0) return -1;
         // FFT (:332-334), and in its last launch the guard correlation (:321-327) and the symbol's two synchronisation floats, from the
         // pilots alone, stored to the host with the sequence word behind them
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
@@ -451,37 +549,46 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
                                    have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small + 8 * k, h->h_flag, seq_a,
                                    h->dev_mode ? t2gpu_front_loop_dev(h->front) : nullptr, h->stream) != 0) return -1;
-        T2_HIP(hipEventRecord(h->ev_fft, h->stream));
+        if (!h->dev_mode) T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         h->prof.stop(PF_CP);
         h->est_chunk = 0;
         ++h->symbols;
         float sv[2] = {0.0f, 0.0f};                                                 // phase_est, sample_rate_est of this symbol
         // ---- the symbol demodulators (:343-427): the equaliser on eq_stream, behind the FFT and beside whatever the chain does next (the
         // next chunk's front end); the cells to the host by a launch behind it
-        T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
+        if (!h->dev_mode) T2_HIP(hipStreamWaitEvent(h->eq_stream, h->ev_fft, 0));
         if (h->next_symbol_type == SYMBOL_TYPE_DATA) {
-            // the loop on the device: this symbol's filters run behind its floats in the launch just made; the symbol BEFORE it is read now (its
-            // floats, the loops' host copies, its chunks' NCO) and the one before THAT hands its cells on -- ahead of this symbol's equaliser
-            // in the cells' stream, whose buffer set is the one those cells are in
-            if (h->dev_mode && consume_pending(h) != 0) return -1;
+            if (h->dev_mode) {
+                // the loop on the device: this symbol's filters run behind its floats in the launch just made and nobody waits for them here. Its
+                // equaliser, its cells and its `data` signal go to the cells' thread; the symbol BEFORE it is read now (its floats, the loops'
+                // host copies, its chunks' NCO).
+                T2_HIP(hipEventRecord(h->ev_fft2[k], h->stream));
+                t2gpu_demod::CellsJob job;
+                job.k = k; job.idx_symbol = h->idx_symbol; job.n_cells = h->c_data; job.carry = h->deint_start && h->sig.data;
+                cells_submit(h, job);
+                h->prof.stop(PF_FFT_EQ);
+                if (consume_pending(h) != 0) return -1;
+                h->pend.valid = true; h->pend.seq_a = seq_a; h->pend.have_cp = have_cp; h->pend.k = k;
+                ++h->dev_symbols;
+                ++h->idx_symbol;
+                if (h->idx_symbol == h->end_data_symbol) {
+                    h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
+                    if (!h->frame_closing_symbol) ++h->frames;
+                }
+                continue;
+            }
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[k], h->d_symidx + h->idx_symbol, 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
             const bool carry = h->deint_start && h->sig.data;
             unsigned seq_cells = 0;
             if (carry && !(seq_cells = publish_cells(h, k, h->c_data, h->eq_stream))) return -1;
             // (with a consumer the host waits for these cells -- published behind the equaliser -- before the symbol after next is launched:
             // buffer set k is free by then without an event)
-            // (with the loop on the device the next symbol but one is launched before this one's cells have been waited for: the event then too)
-            if (!carry || h->dev_mode) { T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream)); h->eq_busy[k] = true; }
+            if (!carry) { T2_HIP(hipEventRecord(h->ev_eq[k], h->eq_stream)); h->eq_busy[k] = true; }
             h->prof.stop(PF_FFT_EQ);
             ++h->idx_symbol;
             if (h->idx_symbol == h->end_data_symbol) {
                 h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
                 if (!h->frame_closing_symbol) ++h->frames;
-            }
-            if (h->dev_mode) {
-                h->pend.valid = true; h->pend.seq_a = seq_a; h->pend.have_cp = have_cp; h->pend.carry = carry; h->pend.k = k; h->pend.seq_cells = seq_cells;
-                ++h->dev_symbols;
-                continue;
             }
             // the symbol BEFORE this one hands its cells on now: everything of this symbol is on its way, the consumer's work (the
             // de-interleaver's push: ~9 us of host time and a launch) runs beside it instead of in front of it
@@ -638,6 +745,7 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->dev_mode) (void)cells_drain(h);                     // (the last symbols' cells are handed on before the thread goes)
     hipDeviceSynchronize();
     if (h->prof.on) {
         double tot = 0;
@@ -759,7 +867,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             n_out = t2gpu_front_execute_loop_dev(h->front, chunk, arbitrary_resample, h->d_i + (size_t)idx_in * h->stride, h->d_q + (size_t)idx_in * h->stride,
                                                  dst, cap, h->stream);
             if (n_out == -1) return -1;
-            if (n_out == -2) { if (leave_dev_mode(h) != 0) return -1; }             // (a chunk the one-launch form does not take: this frame goes on with the loops on the host)
+            if (n_out == -2) { if (leave_dev_mode(h) != 0) return -1; }             // (a chunk the one-launch form does not take: this symbol goes on with the loops on the host)
             else if (!h->pend.valid && follow_chunks(h) != 0) return -1;            // nothing out: the device ran on the values the host holds
         }
         if (n_out == -2) {
@@ -796,6 +904,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
 extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
 {
     if (!h || !out) { set_error("t2gpu_demod_status: bad arguments"); return -1; }
+    if (h->dev_mode && cells_drain(const_cast<t2gpu_demod *>(h)) != 0) return -1;    // (every symbol launched has been handed on when this returns)
     if (finish_state(const_cast<t2gpu_demod *>(h)) != 0) return -1;                // level_detect of the last call's commit
     double g[4];
     t2gpu_sync_get(h->sync, g);
