@@ -278,7 +278,8 @@ def drop_in_leg(w, ui, uq, device, frames=72, warm_frames=12, sent=None, saturat
     out = {"value": round(r["msamples_per_s"], 1), "unit": "Msamples/s", "real_time_factor": round(r["msamples_per_s"] / (64.0 / 7.0), 1),
            "samples_per_call": DROP_IN_BUF, "calls_timed": r["buffers"], "t2_frames_timed": r["t2_frames"], "seconds": round(r["seconds"], 4),
            "bbframes": r["bbframes"], "ts_bytes": r["ts_bytes"], "simd_batches_dropped_by_ldpc": dropped, "resets": r["resets"],
-           "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2), "llr_cast": "clamped (extension)" if saturate else "reference (wraps)"}
+           "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2), "llr_cast": "clamped (extension)" if saturate else "reference (wraps)",
+           "device_loop": "--device-loop 0" not in os.environ.get("T2GPU_DROPIN_ARGS", "")}
     if sent is not None:
         # whole packets of the program's output (from the start of the file: the first BBFRAME's SYNCD puts it on a packet boundary) among those sent
         pk = ts[:ts.size // 188 * 188].reshape(-1, 188)

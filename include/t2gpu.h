@@ -341,6 +341,11 @@ int t2gpu_fft_execute_strided_dev(t2gpu_ofdm *h, const float *d_stream, long fir
                                   float *d_out, int n_symbols, void *stream);
 int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, const int32_t *d_symbol_index, int n_symbols,
                               float *d_cells, float *d_sync, void *stream);
+/* t2gpu_eq_data_execute_dev for ONE symbol whose cells the equaliser's own workgroups also store to page-locked host memory (h_cells: c_data
+ * cells), *h_flag = seq behind them (system scope): the `data` signal's buffer without a copy or a launch of its own. d_count: a zeroed
+ * device word of the caller's (left at zero). */
+int t2gpu_eq_data_publish_dev(t2gpu_ofdm *h, const float *d_symbol, const int32_t *d_symbol_index, float *d_cells, float *h_cells,
+                              unsigned *h_flag, unsigned seq, unsigned *d_count, void *stream);
 /* The same for the data symbols of whole frames, read in place from the frames' spectra (n_frames x syms_per_frame x fft_size
  * cells, what t2gpu_fft_execute_strided_dev wrote) and written in place into the frames' cell streams: data symbol first_symbol + l
  * of frame f is read at d_spectrum + 2 * (f * syms_per_frame + first_symbol + l) * fft_size floats and its c_data cells go to

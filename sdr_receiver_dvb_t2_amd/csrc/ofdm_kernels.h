@@ -55,6 +55,11 @@ struct EqParams {
     int cq_steps = 0;                 // steps stored per row: the longest segment of the table, rounded up to EQS_PU
     const uint32_t *sel = nullptr;    // [rows][c_data] (carrier << 16 | output position) of the data cells, range by range, cell order inside a range
     int n_splits = 0;
+    // ONE symbol (n_symbols = 1, per_frame = 0, output-range form): the cells also go to page-locked host memory by the workgroups' own stores
+    // and the last workgroup raises *pub_flag = pub_seq behind them (system scope) -- what a publishing launch of its own did before
+    float2 *pub_cells = nullptr;
+    unsigned *pub_flag = nullptr, *pub_count = nullptr;    // pub_count: a zeroed device word of the caller's (left at zero)
+    unsigned pub_seq = 0;
 };
 // first output position of range s (even, so that a range starts on a 16-byte boundary of the symbol's cells)
 __host__ __device__ inline int eq_split_q(int c_data, int n_splits, int s) { return s >= n_splits ? c_data : (int)(((long)c_data * s / n_splits) & ~1L); }

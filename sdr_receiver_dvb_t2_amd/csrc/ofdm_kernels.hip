@@ -637,6 +637,19 @@ __global__ __launch_bounds__(THREADS) void eq_split_kernel(EqParams p, const flo
         const float2 eq = eqs_buf[k];
         if (at >= 0) o[at] = eq;
         else if (p.skip_out) p.skip_out[(size_t)fr * p.out_skip + q] = eq;
+        if (p.pub_cells) p.pub_cells[q] = eq;
+    }
+    if (p.pub_cells) {                                      // (one symbol: NS workgroups get here)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned before = __hip_atomic_fetch_add(p.pub_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == (unsigned)NS - 1) {
+                __hip_atomic_store(p.pub_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(p.pub_flag, p.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 

@@ -77,10 +77,11 @@ struct t2gpu_demod {
     // deinterleaved_buffer_a / _b the same way, data_symbol.cpp:140-147): a symbol's equaliser runs on eq_stream beside the NEXT chunk's
     // front end -- what the next chunk waits for is the symbol's two synchronisation floats and its guard correlation, and those come
     // from the pilots alone by a launch of their own right behind the FFT (t2gpu_sym_sync_dev).
-    float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec[2] = {nullptr, nullptr}, *d_cells[2] = {nullptr, nullptr};
+    static constexpr int NSETS = 4;
+    float *d_out = nullptr, *d_buffer_sym = nullptr, *d_spec[NSETS] = {}, *d_cells[NSETS] = {};
     int32_t *d_symidx = nullptr;
     long out_cap = 0;
-    float *h_cells[2] = {nullptr, nullptr};   // pinned: the cells of a symbol, as the `data` / `l1_dyn_execute` signals carry them
+    float *h_cells[NSETS] = {};               // pinned: the cells of a symbol, as the `data` / `l1_dyn_execute` signals carry them
     float *h_small = nullptr;          // pinned: guard correlation (4 floats) + the two synchronisation floats of a symbol
     int cur = 0;                       // which of the two buffer sets the symbol in hand uses
     // Nothing of this object runs on the null stream. stream: the per-symbol chain (I/Q copies, front end, P1, FFT, synchronisation
@@ -88,8 +89,8 @@ struct t2gpu_demod {
     // consumer (t2gpu_ti_push) goes on doing with them. Both at the highest priority: the runtime keeps the hardware queues of a priority
     // to itself, so no launch of theirs ever waits in a queue behind a decode of milliseconds (t2gpu_ldpc_submit: default priority).
     hipStream_t stream = nullptr, eq_stream = nullptr;
-    hipEvent_t ev_fft = nullptr, ev_eq[2] = {nullptr, nullptr};
-    bool eq_busy[2] = {false, false};  // ev_eq[k] has been recorded: buffer set k's last equaliser / publishing launches may still run
+    hipEvent_t ev_fft = nullptr, ev_eq[NSETS] = {};
+    bool eq_busy[NSETS] = {};           // ev_eq[k] has been recorded: buffer set k's last equaliser / publishing launches may still run
     // results by the device's own stores and sequence words the host reads: h_flag[0] behind the floats (seq), h_flag[16] behind the cells (seq_b)
     unsigned seq = 0, seq_b = 0;
     unsigned *h_flag = nullptr, *d_count = nullptr;
@@ -120,7 +121,9 @@ struct t2gpu_demod {
     unsigned cells_submitted = 0;
     std::atomic<int> cells_failed{0};
     std::string cells_error;
-    hipEvent_t ev_fft2[2] = {nullptr, nullptr};
+    double cells_t[4] = {0, 0, 0, 0};     // T2GPU_DEMOD_PROF: the thread's time in launches / waiting for cells / the signal / idle
+    long cells_n = 0;
+    hipEvent_t ev_fft2[NSETS] = {};
     int pending_data = 0;              // cells of the symbol whose `data` signal is still to be emitted (0: none)
     int pending_buf = 0;               // ... the buffer set they are in
     unsigned pending_seq = 0;          // ... and the value h_flag[16] takes when they have arrived
@@ -144,14 +147,14 @@ void free_all(t2gpu_demod *h)
         h->cells_cv.notify_one();
         h->cells_thread.join();
     }
-    for (int k = 0; k < 2; ++k) if (h->ev_fft2[k]) hipEventDestroy(h->ev_fft2[k]);
+    for (int k = 0; k < t2gpu_demod::NSETS; ++k) if (h->ev_fft2[k]) hipEventDestroy(h->ev_fft2[k]);
     if (h->front) t2gpu_front_destroy(h->front);
     if (h->p1) t2gpu_p1_destroy(h->p1);
     if (h->sync) t2gpu_sync_destroy(h->sync);
     if (h->p2_ofdm) t2gpu_ofdm_destroy(h->p2_ofdm);
     if (h->data_ofdm) t2gpu_ofdm_destroy(h->data_ofdm);
     hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out); hipFree(h->d_buffer_sym); hipFree(h->d_symidx);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < t2gpu_demod::NSETS; ++k) {
         hipFree(h->d_spec[k]); hipFree(h->d_cells[k]);
         if (h->h_cells[k]) { twin_retire(h->h_cells[k]); hipHostFree(h->h_cells[k]); }
         if (h->ev_eq[k]) hipEventDestroy(h->ev_eq[k]);
@@ -335,35 +338,56 @@ int move_cells(t2gpu_demod *h, float *dst, const float *src, int n)
 void cells_run(t2gpu_demod *h)
 {
     hipSetDevice(h->device);
-    bool have_prev = false;
-    t2gpu_demod::CellsJob prev;
-    unsigned prev_seq = 0;
-    auto emit_prev = [&]() {
+    // launched, not yet handed on: at most two -- a symbol's cells are on the host a good symbol's time after its equaliser was launched (the
+    // launch waits for the FFT, which waits for the chunk's front end), so the thread hands on the symbol before last, never waiting
+    t2gpu_demod::CellsJob held[2];
+    unsigned held_seq[2] = {0, 0};
+    int n_held = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto emit_oldest = [&]() {
+        const t2gpu_demod::CellsJob prev = held[0];
+        const unsigned prev_seq = held_seq[0];
+        held[0] = held[1]; held_seq[0] = held_seq[1]; --n_held;
         if (prev.carry) {
+            const auto t0 = now();
             if (!wait_word(h, h->h_flag + 16, prev_seq, h->eq_stream, false)) { h->cells_error = last_error(); h->cells_failed.store(1); }
-            else h->sig.data(h->sig.user, prev.n_cells, h->h_cells[prev.k]);
+            else {
+                const auto t1 = now();
+                h->sig.data(h->sig.user, prev.n_cells, h->h_cells[prev.k]);
+                if (h->prof.on) { h->cells_t[1] += secs(t0, t1); h->cells_t[2] += secs(t1, now()); }
+            }
         } else if (hipStreamSynchronize(h->eq_stream) != hipSuccess) { h->cells_error = "hipStreamSynchronize (cells' stream)"; h->cells_failed.store(1); }
-        have_prev = false;
         h->cells_done.fetch_add(1, std::memory_order_release);
     };
     for (;;) {
+        const auto t_idle = now();
         std::unique_lock<std::mutex> lk(h->cells_m);
-        h->cells_cv.wait(lk, [&] { return h->cells_stop || h->cells_head != h->cells_tail || (h->cells_drain && have_prev); });
+        h->cells_cv.wait(lk, [&] { return h->cells_stop || h->cells_head != h->cells_tail || (h->cells_drain && n_held > 0); });
         if (h->cells_stop) return;
+        if (h->prof.on) h->cells_t[3] += secs(t_idle, now());
         if (h->cells_head != h->cells_tail) {
             const t2gpu_demod::CellsJob job = h->cells_q[h->cells_head % 4];
             ++h->cells_head;
             lk.unlock();
+            const auto t_l = now();
             unsigned seq = 0;
-            bool ok = hipStreamWaitEvent(h->eq_stream, h->ev_fft2[job.k], 0) == hipSuccess &&
-                      t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[job.k], h->d_symidx + job.idx_symbol, 1, h->d_cells[job.k], nullptr, h->eq_stream) >= 0;
-            if (ok && job.carry) ok = (seq = publish_cells(h, job.k, job.n_cells, h->eq_stream)) != 0;
+            // (with a consumer the equaliser's workgroups store the cells to the host themselves: no publishing launch)
+            bool ok = hipStreamWaitEvent(h->eq_stream, h->ev_fft2[job.k], 0) == hipSuccess;
+            if (ok && job.carry) {
+                seq = ++h->seq_b;
+                ok = t2gpu_eq_data_publish_dev(h->data_ofdm, h->d_spec[job.k], h->d_symidx + job.idx_symbol, h->d_cells[job.k], h->h_cells[job.k], h->h_flag + 16, seq,
+                                               h->d_count, h->eq_stream) >= 0;
+            } else if (ok) {
+                ok = t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[job.k], h->d_symidx + job.idx_symbol, 1, h->d_cells[job.k], nullptr, h->eq_stream) >= 0;
+            }
             if (!ok) { h->cells_error = last_error(); h->cells_failed.store(1); }
-            if (have_prev) emit_prev();
-            prev = job; prev_seq = seq; have_prev = true;
+            if (h->prof.on) { h->cells_t[0] += secs(t_l, now()); ++h->cells_n; }
+            if (n_held == 2) emit_oldest();
+            held[n_held] = job; held_seq[n_held] = seq; ++n_held;
         } else {
             lk.unlock();
-            emit_prev();
+            while (n_held > 0) emit_oldest();
         }
     }
 }
@@ -451,7 +475,7 @@ int enter_dev_mode(t2gpu_demod *h)
     st[2] = (float)h->tuner;
     if (t2gpu_front_loop_begin(h->front, st, h->stream) != 0) return -1;
     if (!h->cells_thread.joinable()) {
-        for (int k = 0; k < 2; ++k) if (!h->ev_fft2[k]) T2_HIP(hipEventCreateWithFlags(&h->ev_fft2[k], hipEventDisableTiming));
+        for (int k = 0; k < t2gpu_demod::NSETS; ++k) if (!h->ev_fft2[k]) T2_HIP(hipEventCreateWithFlags(&h->ev_fft2[k], hipEventDisableTiming));
         h->cells_thread = std::thread(cells_run, h);
     }
     h->dev_mode = true;
@@ -538,10 +562,10 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         // this symbol's buffer set; the launches that used it two symbols ago (equaliser, publishing: eq_stream) are through before the
         // FFT writes into it -- long since, as a rule
-        const int k = h->cur ^= 1;
+        const int k = h->cur = (h->cur + 1) % t2gpu_demod::NSETS;
         if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
-        // (the loop on the device: set k was the symbol's before last, which the cells' thread has handed on by now -- as a rule)
-        if (h->dev_mode && h->cells_submitted >= 2 && cells_wait(h, h->cells_submitted - 1) != 0) return -1;
+        // (the loop on the device: set k was the symbol's four back, which the cells' thread has handed on by now -- as a rule)
+        if (h->dev_mode && h->cells_submitted >= (unsigned)t2gpu_demod::NSETS && cells_wait(h, h->cells_submitted - (t2gpu_demod::NSETS - 1)) != 0) return -1;
         // FFT (:332-334), and in its last launch the guard correlation (:321-327) and the symbol's two synchronisation floats, from the
         // pilots alone, stored to the host with the sequence word behind them
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
@@ -708,7 +732,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipMalloc(&h->d_out, (size_t)h->out_cap * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_buffer_sym, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_bounce, (size_t)SYM_BUF_CELLS * 8) == hipSuccess;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < t2gpu_demod::NSETS; ++k) {
         ok = ok && hipMalloc(&h->d_spec[k], (size_t)32768 * 8) == hipSuccess && hipMalloc(&h->d_cells[k], (size_t)32768 * 8) == hipSuccess;
         // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the device stores into these while its kernels run and the host reads them then
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_cells[k]), (size_t)32768 * 8, hipHostMallocCoherent) == hipSuccess;
@@ -720,11 +744,11 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     ok = ok && hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     ok = ok && hipStreamCreateWithPriority(&h->eq_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
     ok = ok && hipMalloc(&h->d_symidx, 4096 * 4) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 128, hipHostMallocCoherent) == hipSuccess;   // two slots of 8 floats: a symbol's floats are read while the next symbol's launch may already store its own
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_small), 32 * t2gpu_demod::NSETS, hipHostMallocCoherent) == hipSuccess;   // a slot of 8 floats per buffer set: a symbol's floats are read while the next symbol's launch may already store its own
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&h->h_flag), 128, hipHostMallocCoherent) == hipSuccess;
     ok = ok && hipMalloc(&h->d_count, 4) == hipSuccess && hipMemset(h->d_count, 0, 4) == hipSuccess;
     if (ok) h->h_flag[0] = h->h_flag[16] = 0;
-    for (int k = 0; ok && k < 2; ++k) twin_publish(h->h_cells[k], h->d_cells[k], (size_t)32768 * 8, device, false, h->eq_stream);   // what the signals hand on is still on the device
+    for (int k = 0; ok && k < t2gpu_demod::NSETS; ++k) twin_publish(h->h_cells[k], h->d_cells[k], (size_t)32768 * 8, device, false, h->eq_stream);   // what the signals hand on is still on the device
     if (ok) {
         std::vector<int32_t> idx(4096);
         for (int i = 0; i < 4096; ++i) idx[i] = i;
@@ -751,6 +775,8 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
         double tot = 0;
         for (int k = 0; k < PF_N; ++k) tot += h->prof.t[k];
         std::fprintf(stderr, "t2gpu_demod profile (host wall time inside execute(), %ld symbols):\n", h->symbols);
+        if (h->cells_n) std::fprintf(stderr, "  cells' thread, per symbol: launches %.1f us, waiting for the cells %.1f us, the signal %.1f us, idle %.1f us\n", h->cells_t[0] * 1e6 / h->cells_n,
+                                     h->cells_t[1] * 1e6 / h->cells_n, h->cells_t[2] * 1e6 / h->cells_n, h->cells_t[3] * 1e6 / h->cells_n);
         std::fprintf(stderr, "  loop on the device: %ld data symbols; chunks launched ahead of a symbol's results %ld, chunks that waited for them %ld\n",
                      h->dev_symbols, h->dev_speculated, h->dev_waited);
         for (int k = 0; k < PF_N; ++k)

@@ -386,6 +386,20 @@ extern "C" int t2gpu_eq_data_execute_dev(t2gpu_ofdm *h, const float *d_symbols, 
     return h->m.c_data;
 }
 
+// ONE data symbol with its cells also stored to page-locked host memory by the equaliser's own workgroups, *h_flag = seq behind them
+// (the slot-shaped path: no publishing launch). d_count: a zeroed device word of the caller's. Needs the output-range form (default).
+extern "C" int t2gpu_eq_data_publish_dev(t2gpu_ofdm *h, const float *d_symbol, const int32_t *d_symbol_index, float *d_cells, float *h_cells,
+                                         unsigned *h_flag, unsigned seq, unsigned *d_count, void *stream)
+{
+    if (!h || !d_symbol || !d_symbol_index || !d_cells || !h_cells || !h_flag || !d_count) { set_error("t2gpu_eq_data_publish_dev: bad arguments"); return -1; }
+    if (h->eq.n_splits < 1) { set_error("t2gpu_eq_data_publish_dev: needs the output-range form of the equaliser"); return -1; }
+    EqParams p = h->eq;
+    p.pub_cells = reinterpret_cast<float2 *>(h_cells); p.pub_flag = h_flag; p.pub_seq = seq; p.pub_count = d_count;
+    T2_HIP(launch_eq_data(p, reinterpret_cast<const float2 *>(d_symbol), d_symbol_index, 1, reinterpret_cast<float2 *>(d_cells), h->d_pilot_scratch,
+                          nullptr, (hipStream_t)stream));
+    return h->m.c_data;
+}
+
 // Data symbols of whole frames straight from the frames' spectra into the frames' cell streams (no gather / scatter copies)
 extern "C" int t2gpu_eq_data_frames_dev(t2gpu_ofdm *h, const float *d_spectrum, int n_frames, int syms_per_frame, int first_symbol,
                                         int n_data_symbols, float *d_cells, long cells_frame_stride, long cells_offset, float *d_sync,
