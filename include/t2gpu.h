@@ -457,6 +457,8 @@ long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len,
                          const int16_t *q_in, float *out, long out_cap_cells, int32_t *chunk_out_len);
 /* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
 int t2gpu_front_state(t2gpu_front *h, float *out8);
+/* the same eight as the LAST t2gpu_front_commit_iq left them, whatever has been launched on the handle since (waits for that commit's launch only) */
+int t2gpu_front_committed_state(t2gpu_front *h, float *out8);
 /* ---- the loop on the device. The reference hands a symbol's two synchronisation floats and its guard correlation to the tracking filters
  * and the filters' outputs to the next chunk's NCO (dvbt2_demodulator.cpp:165-171, 187-193, 328-330, 429-439): one host round trip per
  * symbol for a caller that keeps the filters on the host. These entry points keep them on the device for as long as the caller likes (a

@@ -163,6 +163,7 @@ PROTOTYPES = {
     "t2gpu_front_execute_dev": (ctypes.c_long, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp, _vp]),
     "t2gpu_front_execute": (ctypes.c_long, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     "t2gpu_front_state": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_front_committed_state": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_front_debug_stream": (ctypes.c_long, [_vp, ctypes.c_int, _vp, ctypes.c_long]),
     "t2gpu_decim_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_farrow_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_double, _vp, ctypes.c_int]),

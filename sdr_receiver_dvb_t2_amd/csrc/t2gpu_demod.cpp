@@ -300,7 +300,7 @@ int finish_state(t2gpu_demod *h)
 {
     if (!h->state_pending) return 0;
     float st[8];
-    if (t2gpu_front_state(h->front, st) != 0) return -1;
+    if (t2gpu_front_committed_state(h->front, st) != 0) return -1;
     h->level_detect = st[6];
     h->state_pending = false;
     return 0;
@@ -511,6 +511,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         if (h->next_symbol_type != SYMBOL_TYPE_DATA && leave_dev_mode(h) != 0) return -1;   // (the loop on the device is for a frame's data symbols)
         if (h->next_symbol_type == SYMBOL_TYPE_P1) {
             if (flush_data_signal(h) != 0) return -1;                               // (the frame's last symbol completes its TI block: not held back)
+            if (finish_state(h) != 0) return -1;                                    // level_detect as the execute() before left it (:227-235)
             t2gpu_p1_result r;
             h->prof.start();
             const int det = t2gpu_p1_execute_dev(h->p1, signal_->gain_changed, h->level_detect, len_in, src, &consume,
@@ -822,7 +823,6 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     if (!h || len_in < 0 || !i_in || !q_in || !signal_) { set_error("t2gpu_demod_execute: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     if (len_in == 0) return 0;
-    if (finish_state(h) != 0) return -1;                                            // the previous call's commit (long through by now)
     h->saw_results = false;
     const size_t el = (size_t)len_in * h->stride;
     if (el > h->in_cap) {
@@ -907,7 +907,10 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         idx_in += chunk;
         if (symbol_acquisition(h, (int)n_out, signal_, dst) != 0) return -1;
     }
-    if (consume_pending(h) != 0 || flush_data_signal(h) != 0) return -1;           // everything this buffer completed has been handed on
+    // (the loop on the device: a symbol whose results are still out stays out across the call's end -- the next call's first chunk goes ahead of
+    // them as any other -- unless nothing of this call has been read yet, which is what says that its I/Q has come over)
+    if (!(h->dev_mode && h->saw_results) && consume_pending(h) != 0) return -1;
+    if (flush_data_signal(h) != 0) return -1;
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, h->stream) != 0) return -1;
@@ -930,7 +933,8 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
 extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
 {
     if (!h || !out) { set_error("t2gpu_demod_status: bad arguments"); return -1; }
-    if (h->dev_mode && cells_drain(const_cast<t2gpu_demod *>(h)) != 0) return -1;    // (every symbol launched has been handed on when this returns)
+    // (the loop on the device: every symbol launched has been read and handed on when this returns -- the values below are then the device's)
+    if (h->dev_mode && (consume_pending(const_cast<t2gpu_demod *>(h)) != 0 || cells_drain(const_cast<t2gpu_demod *>(h)) != 0)) return -1;
     if (finish_state(const_cast<t2gpu_demod *>(h)) != 0) return -1;                // level_detect of the last call's commit
     double g[4];
     t2gpu_sync_get(h->sync, g);

@@ -521,6 +521,26 @@ extern "C" int t2gpu_front_state(t2gpu_front *h, float *out8)
     return 0;
 }
 
+// the state the LAST t2gpu_front_commit_iq left (c1 / c2 / level_detect as the reference derives them at the end of an execute(), :227-235),
+// whatever has been launched on the front end since: the commit's launch stored it to page-locked memory. Waits for that launch only.
+extern "C" int t2gpu_front_committed_state(t2gpu_front *h, float *out8)
+{
+    if (!h || !out8) return -1;
+    if (!h->h_state || h->state_seq == 0) return t2gpu_front_state(h, out8);
+    volatile unsigned *flag = h->h_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; (int)(*flag - h->state_seq) < 0; ++spins) {
+        t2_cpu_relax();
+        if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return t2gpu_front_state(h, out8);
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const FrontState s = *h->h_state;
+    if (s.error_) { set_error("t2gpu_front: a look-back wait of the one-launch form timed out"); return -1; }
+    out8[0] = (float)s.dc_re; out8[1] = (float)s.dc_im; out8[2] = s.c1; out8[3] = s.c2;
+    out8[4] = h->phase_nco; out8[5] = h->frequency_nco; out8[6] = s.level_detect; out8[7] = h->x1;
+    return 0;
+}
+
 extern "C" long t2gpu_front_debug_stream(t2gpu_front *h, int which, float *out, long cap_cells)
 {
     if (!h || !out || which < 0 || which > 1) return -1;
