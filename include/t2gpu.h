@@ -86,6 +86,10 @@ int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_frames, uin
  * batch meet at every sweep, so kernels of another stream that grab the CUs first stall whole batches; with this wait they
  * start once the decoder is placed and use what it leaves. */
 int t2gpu_ldpc_wait_resident(t2gpu_ldpc *h, void *stream);
+/* The decodes of t2gpu_ldpc_submit run on a stream whose CU mask leaves the device's first n_cus CUs to everybody else (default 32 of
+ * 256; 0: no mask): short launches of other streams beside resident decodes otherwise take ~45 us longer each.
+ * Before the handle's first submit. */
+int t2gpu_ldpc_set_submit_cu_reserve(t2gpu_ldpc *h, int n_cus);
 /* What a decode occupies: out6 = {workgroups resident per CU, wavefronts per workgroup, dynamic LDS bytes per workgroup, FEC frames per
  * workgroup, CUs of the device, SIMD batches resident at once} for the kernel variant the handle's configuration selects. */
 int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6);

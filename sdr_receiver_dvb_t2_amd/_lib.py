@@ -40,6 +40,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_collect": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_ldpc_set_submit_cu_reserve": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_occupancy": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_launch_workgroups": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_set_plain_launch": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -40,6 +40,7 @@ struct t2gpu_ldpc {
     uint8_t *p_out = nullptr;
     int *p_trials = nullptr;            // [max_frames] verdicts, then the error word
     hipStream_t a_stream = nullptr;
+    int a_cu_reserve = 32;              // CUs the submit stream's mask leaves to everybody else (t2gpu_ldpc_set_submit_cu_reserve)
     hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
     bool a_ready = false;               // stream, event and pinned staging of the asynchronous form all exist
@@ -427,6 +428,14 @@ extern "C" int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, u
 // ---- the host-buffer slot, split in two (include/t2gpu.h): submit enqueues copy-in, decode and copy-out on the handle's own stream
 // and returns; collect waits for (or polls) the result. Several handles in flight keep several SIMD batches on the device at once --
 // a caller with the reference's call shape (ldpc_decoder::execute, one batch of 32 per call) otherwise leaves 15/16 of the CUs idle.
+// CUs of the device the decodes of t2gpu_ldpc_submit keep off (default 32; 0: none). Before the handle's first submit.
+extern "C" int t2gpu_ldpc_set_submit_cu_reserve(t2gpu_ldpc *h, int n_cus)
+{
+    if (!h || n_cus < 0 || h->a_stream) { set_error("t2gpu_ldpc_set_submit_cu_reserve: bad arguments (or the handle has submitted already)"); return -1; }
+    h->a_cu_reserve = n_cus;
+    return 0;
+}
+
 extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
 {
     if (!h || !in || len_in < h->g.n || len_in % h->g.n) { set_error("t2gpu_ldpc_submit: bad arguments"); return -1; }
@@ -441,6 +450,18 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
         // hardware queues per priority. (Rounds 4-5 had it the other way round, decodes at the lowest priority under a default-priority
         // null stream: with waves of a lowest-priority queue resident, every launch of any other queue took ~45 us instead of ~6
         // (tools/small_kernel_beside_submits.py) -- half of the slot-shaped path's time while a frame's batches were being decoded.)
+        // ... and on a CU mask that leaves the device's first a_cu_reserve CUs alone (t2gpu_ldpc_set_submit_cu_reserve; 32 of 256 by default):
+        // with the decodes' workgroups -- twelve wavefronts and 155 KB of LDS for a millisecond each -- free to settle on every CU, EVERY
+        // launch of every other stream of the process took ~45 us longer while three or more decodes were resident (a 4 us scatter: 45 us;
+        // the slot-shaped path's symbols 110 - 380 us instead of 55 for a third of each frame; profiles/HISTORY.md, round 5). With a few CUs
+        // the decodes never touch, the short launches are short again.
+        if (!h->a_stream && h->a_cu_reserve > 0 && h->num_cu - h->a_cu_reserve >= 16 && h->num_cu <= 1024) {
+            uint32_t mask[32] = {};
+            for (int c = h->a_cu_reserve; c < h->num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
+            if (hipExtStreamCreateWithCUMask(&h->a_stream, (uint32_t)((h->num_cu + 31) / 32), mask) != hipSuccess) { (void)hipGetLastError(); h->a_stream = nullptr; h->a_cu_reserve = 0; }
+        } else if (!h->a_stream) {
+            h->a_cu_reserve = 0;
+        }
         if (!h->a_stream) T2_HIP(hipStreamCreateWithFlags(&h->a_stream, hipStreamNonBlocking));
         if (!h->a_done) T2_HIP(hipEventCreateWithFlags(&h->a_done, hipEventDisableTiming));
         if (!h->p_in) T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->p_in), (size_t)h->max_frames * h->g.n, hipHostMallocDefault));
@@ -477,7 +498,7 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     const int wgs = t2gpu_ldpc_launch_workgroups(h, n_frames);
     const int per_cu = h->p_blocks_per_cu;
     if (wgs < 1 || per_cu < 1) { set_error("t2gpu_ldpc_submit: the device cannot keep one batch resident"); return -1; }
-    h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu);
+    h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu - h->a_cu_reserve);
     const int rc = t2gpu_ldpc_execute_dev(h, d_llr, n_frames, h->d_out, nullptr, h->d_trials, s);
     h->plain_launch = false;
     if (rc) { unbook(h); return -1; }
