@@ -383,12 +383,15 @@ int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_s
                        float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
 /* symbol_acquisition's guard removal + fft->execute() (dvbt2_demodulator.cpp:332-334) for ONE buffered symbol (d_buffered: guard +
  * fft_size cells, guard first; spectrum to d_spectrum) with t2gpu_sym_sync_dev's outputs formed inside the FFT's last launch: what
- * t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev give, bit for bit, in two launches instead of three. h: the handle whose FFT
+ * t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev give, bit for bit, in one launch (t2gpu_fft_set_one_launch) instead of three. h: the handle whose FFT
  * runs; tables: the handle whose pilot tables apply (the same FFT size; kind / idx_symbol as in t2gpu_sym_sync_dev). with_cp = 0: no
  * guard correlation (h_small[0..3] untouched). Pilot tables that do not fit the FFT's exchange buffer (P2, dense pilot patterns) take
  * the separate launches inside. */
 int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp,
                            float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
+/* on = 1 (default): t2gpu_fft_sym_sync_dev is ONE launch (stage A in its first four workgroups, stages B + C and the synchronisation
+ * floats in the other four, which wait for them); 0: the two launches. Process-wide; same values bit for bit. */
+void t2gpu_fft_set_one_launch(int on);
 /* The same two for whole frames, in place like t2gpu_eq_data_frames_dev: the P2 (frame-closing) symbol of frame f is read at
  * d_spectrum + 2 * f * syms_per_frame * fft_size floats (+ the symbol's position in the frame); P2: the cells behind the first
  * skip_cells (the L1 cells, time_deinterleaver.cpp:296-300) go to d_cells + 2 * f * cells_frame_stride floats; frame closing: the

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_data_publish_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_eq_fc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "t2gpu_fft_set_one_launch": (None, [ctypes.c_int]),
     "t2gpu_fft_sym_sync_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_sym_sync_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_front_loop_dev": (_vp, [_vp]),

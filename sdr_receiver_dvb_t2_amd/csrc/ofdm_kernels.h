@@ -95,4 +95,6 @@ hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, cons
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
                                unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr);
 
+void set_fft_one_launch(int on);   // launch_fft_sym_sync as one launch (default) or two
+
 }  // namespace t2gpu

@@ -190,14 +190,11 @@ __global__ __launch_bounds__(32 * T2) void fft_fwd_shift_kernel(const float2 *__
 // workgroups per symbol), the second exchange in its own LDS, and the lanes of a store instruction cover 8 consecutive bins (whole
 // 64-byte lines). Every value goes through the same operations in the same order as in fft_fwd_shift_kernel: bit-identical output
 // (tests/test_ofdm_gpu.py holds the two against each other).
+// (one lane's share of stage A: tid = the lane's number among the T of a symbol)
 template <int T2>
-__global__ __launch_bounds__(64) void fft_stage_a_kernel(const float2 *__restrict__ in, float2 *__restrict__ scratch,
-                                                         const float2 *__restrict__ twiddle, FftLayout lay)
+__device__ __forceinline__ void fft_stage_a_body(const float2 *__restrict__ x, float2 *__restrict__ sc, const float2 *__restrict__ twiddle, int tid)
 {
-    constexpr int T = 32 * T2, N = 32 * T, WGS = T / 64;
-    const int sym = (int)blockIdx.x / WGS, tid = ((int)blockIdx.x % WGS) * 64 + (int)threadIdx.x;
-    const float2 *x = in + lay.first + (long)(sym / lay.per_frame) * lay.frame_stride + (long)(sym % lay.per_frame) * lay.sym_stride;
-    float2 *sc = scratch + (size_t)sym * N;
+    constexpr int T = 32 * T2, N = 32 * T;
     cf v[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) { const float2 a = x[tid + T * j]; v[j] = {a.x, a.y}; }
@@ -211,13 +208,25 @@ __global__ __launch_bounds__(64) void fft_stage_a_kernel(const float2 *__restric
     for (int r = 0; r < 32; ++r) sc[bitrev<32>(r) * T + tid] = make_float2(v[r].x, v[r].y);
 }
 
+template <int T2>
+__global__ __launch_bounds__(64) void fft_stage_a_kernel(const float2 *__restrict__ in, float2 *__restrict__ scratch,
+                                                         const float2 *__restrict__ twiddle, FftLayout lay)
+{
+    constexpr int T = 32 * T2, N = 32 * T, WGS = T / 64;
+    const int sym = (int)blockIdx.x / WGS, tid = ((int)blockIdx.x % WGS) * 64 + (int)threadIdx.x;
+    const float2 *x = in + lay.first + (long)(sym / lay.per_frame) * lay.frame_stride + (long)(sym % lay.per_frame) * lay.sym_stride;
+    fft_stage_a_body<T2>(x, scratch + (size_t)sym * N, twiddle, tid);
+}
+
 constexpr int FFT_BC_LDS_FLOATS = 32 * 8 * 33;
 template <int T2>
 __device__ __forceinline__ void fft_stage_bc_body(const float2 *__restrict__ scratch, float2 *__restrict__ out,
-                                                  const float2 *__restrict__ twiddle, float *lds /* [FFT_BC_LDS_FLOATS]: rows (q1, k1 of this workgroup) of T2 values over t1 */)
+                                                  const float2 *__restrict__ twiddle, float *lds /* [FFT_BC_LDS_FLOATS]: rows (q1, k1 of this workgroup) of T2 values over t1 */,
+                                                  int block = -1)
 {
     constexpr int T = 32 * T2, N = 32 * T, PITCH = 33;
-    const int sym = (int)blockIdx.x / 4, kb = ((int)blockIdx.x % 4) * 8;
+    if (block < 0) block = (int)blockIdx.x;
+    const int sym = block / 4, kb = (block % 4) * 8;
     const int l = (int)threadIdx.x, k1l = l / T2, t1n = l % T2, k1n = kb + k1l;
     const float2 *sc = scratch + (size_t)sym * N;
     float2 *y = out + (size_t)sym * N;
@@ -845,12 +854,69 @@ __global__ __launch_bounds__(8 * T2) void fft_stage_bc_sync_kernel(const float2 
     sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds, loop);
 }
 
+// ---- ... and the FIRST launch in it as well (round 5): ONE launch per symbol's transform. Workgroups 0-3 run stage A (the T lanes of the
+// symbol, 8 * T2 of them each; no LDS, no barrier), raise a counter behind their stores; workgroups 4-7 wait for the four (a workgroup
+// only ever waits for lower-numbered ones, which were dispatched before it; bounded), run stages B and C, and the last of them runs
+// sym_sync_body as above. Every value goes through the operations of the two launches in their order: bit-identical spectrum and floats.
+// While decodes are resident every launch of the chain costs tens of microseconds more than its body (profiles/HISTORY.md, round 5):
+// the per-symbol critical path has one launch less.
+template <int T2>
+__global__ __launch_bounds__(8 * T2) void fft_one_sync_kernel(const float2 *__restrict__ in, float2 *__restrict__ scratch, float2 *__restrict__ out,
+                                                              const float2 *__restrict__ twiddle, unsigned *count, EqParams p, int idx_symbol,
+                                                              const float2 *__restrict__ buffered, int guard, float4 *cp_out,
+                                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, T2DevLoop *loop)
+{
+    __shared__ __attribute__((aligned(16))) float lds[FFT_BC_LDS_FLOATS];
+    __shared__ int sh_last;
+    const int b = (int)blockIdx.x;
+    if (b < 4) {
+        fft_stage_a_body<T2>(in, scratch, twiddle, b * (8 * T2) + (int)threadIdx.x);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        for (unsigned spins = 0; __hip_atomic_load(count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u && spins < (1u << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    fft_stage_bc_body<T2>(scratch, out, twiddle, lds, b - 4);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned before = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = before == 3u;
+        if (sh_last) {
+            __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (all four have passed their wait)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds, loop);
+}
+
+static int g_fft_one_launch = 1;
+void set_fft_one_launch(int on) { g_fft_one_launch = on != 0; }
+
 hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
                                unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop)
 {
     if ((p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_BC_LDS_FLOATS * 4 || !scratch || !count) return hipErrorInvalidValue;
-    if (fft_size == 32768) {
+    if (g_fft_one_launch && (fft_size == 32768 || fft_size == 16384)) {
+        const float2 *x = in + lay.first;                     // (one symbol: symbol 0 of the layout)
+        if (fft_size == 32768)
+            hipLaunchKernelGGL(fft_one_sync_kernel<32>, dim3(8), dim3(256), 0, s, x, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
+                               h_small, h_flag, seq, loop);
+        else
+            hipLaunchKernelGGL(fft_one_sync_kernel<16>, dim3(8), dim3(128), 0, s, x, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
+                               h_small, h_flag, seq, loop);
+    } else if (fft_size == 32768) {
         hipLaunchKernelGGL(fft_stage_a_kernel<32>, dim3(16), dim3(64), 0, s, in, scratch, twiddle, lay);
         hipLaunchKernelGGL(fft_stage_bc_sync_kernel<32>, dim3(4), dim3(256), 0, s, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
                            h_small, h_flag, seq, loop);

@@ -541,6 +541,8 @@ extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kin
     return t2gpu_sym_sync_dev(tables, kind, idx_symbol, d_spectrum, with_cp ? d_buffered : nullptr, guard, d_cp4, d_sync, h_small, h_flag, seq, d_loop, stream);
 }
 
+extern "C" void t2gpu_fft_set_one_launch(int on) { t2gpu::set_fft_one_launch(on); }
+
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
                                      float *phase_offset)
 {

@@ -222,13 +222,16 @@ def test_sync_floats_from_the_pilots_alone_equal_the_equalisers(torch_cuda, mode
     ctx.close()
 
 
+@pytest.mark.parametrize("one_launch", [1, 0])
 @pytest.mark.parametrize("mode", [(5, 1, 6, 4, 0, 59), (4, 1, 1, 3, 0, 9), (4, 0, 4, 1, 2, 45), (4, 0, 0, 3, 0, 17), (5, 1, 1, 2, 2, 12)])
-def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode):
+def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode, one_launch):
     """t2gpu_fft_sym_sync_dev (what t2gpu_demod_execute launches per symbol) against t2gpu_fft_execute_dev + t2gpu_sym_sync_dev: spectrum,
     guard correlation and synchronisation floats bit for bit -- 32K and 16K (whose 128-lane launch stands for the correlation's 256
-    lanes), data / frame-closing tables inside the launch, P2 and a dense pilot pattern (PP1) through the separate launches inside."""
+    lanes), data / frame-closing tables inside the launch, P2 and a dense pilot pattern (PP1) through the separate launches inside. Both forms:
+    the whole transform in ONE launch (default: stage A's workgroups in front of the others, which wait for them) and the two launches."""
     import sdr_receiver_dvb_t2_amd as pkg
     torch = torch_cuda
+    pkg.lib().t2gpu_fft_set_one_launch(one_launch)
     m = ol.ora_mode(*mode)
     ctx = pkg.t2_ofdm(*mode, max_symbols=2)
     rows = m.n_data - m.l_fc
@@ -253,4 +256,5 @@ def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode):
             assert np.array_equal(h_small.numpy()[:4].view(np.uint32), cp4.cpu().numpy().view(np.uint32))
         assert int(h_flag[0]) == 100 + n
         assert np.array_equal(h_small.numpy()[4:6].view(np.uint32), sync.cpu().numpy().view(np.uint32))
+    pkg.lib().t2gpu_fft_set_one_launch(1)
     ctx.close()
