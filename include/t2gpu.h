@@ -464,6 +464,17 @@ long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len,
                          const int16_t *q_in, float *out, long out_cap_cells, int32_t *chunk_out_len);
 /* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
 int t2gpu_front_state(t2gpu_front *h, float *out8);
+/* The sign statistics of an execute() AHEAD of its chunks (held-IQ mode). c1 / c2 / level_detect of a call (dvbt2_demodulator.cpp:227-235)
+ * depend on its samples and the dc averagers only, not on anything the symbols decide: t2gpu_front_call_begin launches one pass over the
+ * call's n samples of device I/Q (d_i / d_q: the buffer the chunks will be cut from, the front end's stride) with its own copy of the
+ * averagers, t2gpu_front_call_level hands out what it formed (out3 = c1, c2, level_detect; waits for that launch only -- the gain decision
+ * at the end of an execute() then does not wait for the chunks), and the call's t2gpu_front_commit_iq leaves those values. call_begin
+ * returns 1 when the look-ahead is on its way, 0 when this call goes without (longer than 1 048 576 samples, the first call, a call
+ * behind a reset: t2gpu_front_commit_iq then derives the values from the chunks' sums as before and carries the averagers over), -1 on
+ * an error. A t2gpu_front_reset_loops between call_begin and the commit cancels the look-ahead (call_level then returns 1). The two routes agree to the last bits of
+ * the double-precision sums (the recurrence is composed per 4096 samples from the call's start instead of per chunk). */
+int t2gpu_front_call_begin(t2gpu_front *h, const int16_t *d_i, const int16_t *d_q, int n, void *stream);
+int t2gpu_front_call_level(t2gpu_front *h, float *out3);
 /* the same eight as the LAST t2gpu_front_commit_iq left them, whatever has been launched on the handle since (waits for that commit's launch only) */
 int t2gpu_front_committed_state(t2gpu_front *h, float *out8);
 /* ---- the loop on the device. The reference hands a symbol's two synchronisation floats and its guard correlation to the tracking filters
@@ -631,6 +642,12 @@ int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
  * default: measured 3 % faster as long as the caller's thread also makes the equaliser's launches and emits the signals, DESIGN.md
  * section 6). Same cells, same TS either way. */
 int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on);
+/* level_detect / c1 / c2 of an execute() from one pass over its buffer at its head (on = 1: t2gpu_front_call_begin -- the call's gain
+ * decision and its return do not wait for its chunks, the next call's launches follow the last chunk's directly) or from the chunks'
+ * own sums (0, the default: the end of every call waits for them). The same values to the last bits of a double-precision sum. Off by
+ * default because it measured 2.5 % SLOWER on the slot-shaped path: the device's chain bounds that path, not the
+ * host's wait, and the look-ahead is one more launch per call in the chain's stream. */
+int t2gpu_demod_set_call_stats(t2gpu_demod *h, int on);
 int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
 
 /* ---------------------------------------------------------------- batch receiver: buffers of whole T2 frames --------------

@@ -708,6 +708,8 @@ public:
     void set_tuner(double offset_hz) { if (t2gpu_demod_set_tuner(h_, offset_hz) != 0) fail("t2gpu_demod_set_tuner"); }
     // the tracking loops of a frame's data symbols on the device (t2gpu_demod_set_device_loop); off unless asked for
     void set_device_loop(bool on) { if (t2gpu_demod_set_device_loop(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_device_loop"); }
+    // a call's level / IQ estimates from one pass at its head (default) or from its chunks' sums (t2gpu_demod_set_call_stats)
+    void set_call_stats(bool on) { if (t2gpu_demod_set_call_stats(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_call_stats"); }
     t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
 private:
     static l1_postsignalling pack(const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn)

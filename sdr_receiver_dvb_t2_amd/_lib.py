@@ -79,6 +79,8 @@ PROTOTYPES = {
     "t2gpu_front_set_frequency_nco": (ctypes.c_int, [_vp, ctypes.c_float]),
     "t2gpu_front_set_iq": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_front_hold_iq": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_front_call_begin": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
+    "t2gpu_front_call_level": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_front_set_chain": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_front_commit_iq": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_sync_reset": (None, [_vp, ctypes.c_float]),
@@ -89,6 +91,7 @@ PROTOTYPES = {
     "t2gpu_demod_connect": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
+    "t2gpu_demod_set_call_stats": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_set_device_loop": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_eq_p2_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp]),

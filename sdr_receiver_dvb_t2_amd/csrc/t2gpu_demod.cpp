@@ -103,6 +103,7 @@ struct t2gpu_demod {
     // live on the device, a data symbol's launches are followed by the next chunk's without waiting for its results, and the host reads
     // them one symbol behind (pend), recomputing the same floats for its own copies. Checked when the mode is left, once per frame.
     bool dev_loop = false;             // t2gpu_demod_set_device_loop
+    bool call_stats = false;           // a call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats)
     bool dev_mode = false;
     struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0; } pend;
     long dev_symbols = 0, dev_speculated = 0, dev_waited = 0;
@@ -806,6 +807,17 @@ extern "C" int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz)
     return 0;
 }
 
+// on = 1: level_detect / c1 / c2 of an execute() are formed by one pass over its buffer at its head (t2gpu_front_call_begin) and the call's end
+// does not wait for its chunks; 0 (default): from the chunks' own sums, the end of the call waits for them. Measured on the slot-shaped path
+// (tools/ab_dropin_args.sh "--call-stats 1" "--call-stats 0", same box): 309 against 318 Msamples/s -- the chain on the device is what
+// bounds that path, not the host's wait at the end of a call, and the look-ahead is one more launch in the chain's stream per call.
+extern "C" int t2gpu_demod_set_call_stats(t2gpu_demod *h, int on)
+{
+    if (!h) { set_error("t2gpu_demod_set_call_stats: bad arguments"); return -1; }
+    h->call_stats = on != 0;
+    return 0;
+}
+
 // on = 0 (default): the tracking loops stay on the host for every symbol (one round trip per symbol); 1: on the device for a frame's data symbols
 extern "C" int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on)
 {
@@ -849,6 +861,10 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, h->stream));
         }
     }
+    // the call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats): the gain decision below then reads them without waiting
+    // for the chain, and their arrival says the I/Q has come over
+    const int look_ahead = h->call_stats ? t2gpu_front_call_begin(h->front, h->d_i, h->d_q, len_in, h->stream) : 0;
+    if (look_ahead < 0) return -1;
     h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {
@@ -909,12 +925,15 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     }
     // (the loop on the device: a symbol whose results are still out stays out across the call's end -- the next call's first chunk goes ahead of
     // them as any other -- unless nothing of this call has been read yet, which is what says that its I/Q has come over)
-    if (!(h->dev_mode && h->saw_results) && consume_pending(h) != 0) return -1;
+    float ahead[3] = {0.0f, 0.0f, 0.0f};
+    const bool have_ahead = look_ahead == 1 && t2gpu_front_call_level(h->front, ahead) == 0;   // (1: a reset on the way cancelled it)
+    if (!(h->dev_mode && (h->saw_results || have_ahead)) && consume_pending(h) != 0) return -1;
     if (flush_data_signal(h) != 0) return -1;
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, h->stream) != 0) return -1;
     h->state_pending = true;
+    if (have_ahead) { h->level_detect = ahead[2]; h->state_pending = false; h->saw_results = true; }   // what the commit leaves, known already
     // wait for the commit only when something of this call still needs it: the gain decision below, or the caller's I/Q buffers (their
     // copies are in stream order ahead of every symbol's kernels: a call that has read a symbol's results knows they are through)
     if (signal_->gain_changed || !h->saw_results) {

@@ -159,6 +159,8 @@ int main(int argc, char **argv)
             t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f);
             // STAGE_DEVICE_LOOP=1: the tracking loops of a frame's data symbols on the device (same cells, same TS)
             if (std::getenv("STAGE_DEVICE_LOOP") && std::atoi(std::getenv("STAGE_DEVICE_LOOP")) != 0) demodulator.set_device_loop(true);
+            // STAGE_CALL_STATS=1: a call's level / IQ estimates from one pass over its buffer at its head (t2gpu_demod_set_call_stats)
+            if (std::getenv("STAGE_CALL_STATS") && std::atoi(std::getenv("STAGE_CALL_STATS")) != 0) demodulator.set_call_stats(true);
             t2::llr_demapper qam;
             t2::ldpc_decoder ldpc;
             t2::bch_decoder bch;

@@ -218,6 +218,14 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
     log_dev = open(tmp_path / "log_dev.txt").read()
     assert [ln for ln in log_dev.splitlines() if ln.startswith("buf ")] == lines
+    # ... and with every call's level / IQ estimates formed ahead of its chunks (t2gpu_demod_set_call_stats: the end of an execute() does
+    # not wait for the chain; the estimates agree with the chunks' sums to the last bits of a double-precision sum, which the stream's
+    # acquisition -- P1 thresholds from level_detect, the re-tunes -- and every byte of the transport stream bear out)
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_cs.ts", buf, 0, tmp_path / "log_cs.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_CALL_STATS": "1"})
+    assert np.fromfile(tmp_path / "out_cs.ts", np.uint8).tobytes() == got
+    log_cs = open(tmp_path / "log_cs.txt").read()
+    assert [ln for ln in log_cs.splitlines() if ln.startswith("buf ")] == lines
 
 
 def test_demodulator_class_resets_and_recovers(driver, tmp_path):
@@ -241,6 +249,10 @@ def test_demodulator_class_resets_and_recovers(driver, tmp_path):
     run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_dev.ts", buf, 0, tmp_path / "log_dev.txt",
         env_extra={"STAGE_DEVICE_LOOP": "1"})
     assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
+    # ... and with the calls' statistics ahead of their chunks: the reset cancels the look-ahead of the call it falls into
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_cs.ts", buf, 0, tmp_path / "log_cs.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_CALL_STATS": "1"})
+    assert np.fromfile(tmp_path / "out_cs.ts", np.uint8).tobytes() == got
 
 
 def test_example_rx_file_program(driver, tmp_path):
