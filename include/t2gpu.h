@@ -110,6 +110,16 @@ int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out
  * pending per handle; several handles in flight run their batches side by side (t2::ldpc_decoder keeps a ring of them and emits
  * bit_bch in submission order, include/t2gpu_stages.hpp). */
 int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in);
+/* t2gpu_ldpc_submit in two steps, for a caller that is handed SIMD batches one by one but wants several of them decoded by ONE launch:
+ * t2gpu_ldpc_submit_add puts one more batch (len_in = fec_size * frames, whole SIMD batches except for the last addition) behind what has
+ * been added to the handle's input (the caller's buffer is free again, nothing is launched), t2gpu_ldpc_submit_go launches the decode of
+ * everything added; t2gpu_ldpc_collect then hands out the bits of all of them and one verdict per SIMD batch. Up to the handle's
+ * max_frames. Why: with TWO OR MORE decodes resident on the device at once (launches of different streams, milliseconds each), every
+ * launch of every other stream takes tens of microseconds longer to get its workgroups started; with ONE it does not (DESIGN.md section 6,
+ * profiles/HISTORY.md round 5) -- t2::ldpc_decoder therefore decodes the batches a TI block gives rise to in one launch. Batches with a
+ * device twin and batches without cannot share a decode (-1: launch what has been added first). */
+int t2gpu_ldpc_submit_add(t2gpu_ldpc *h, const int8_t *in, int len_in);
+int t2gpu_ldpc_submit_go(t2gpu_ldpc *h);
 int t2gpu_ldpc_collect(t2gpu_ldpc *h, int wait, const uint8_t **out, const int **trials_left, int *n_frames);
 /* diagnostics: the first call arms per-phase cycle counters inside the kernel (off by default); later calls return the
  * sums over all workgroups of the last launch: [0] parity check, [1] batch rendezvous, [2] PLAIN, [3] PAIR, [4] GENERIC

@@ -111,11 +111,19 @@ public:
     // submission order and emits bit_bch -- and with it whatever the consumer wires behind (bch_decoder, bb_de_header, the sink) -- there,
     // beside the caller. flush() returns when everything submitted has been emitted; an exception thrown on that thread is rethrown by
     // the next execute() / flush().
-    explicit ldpc_decoder(int device = 0, int in_flight = 8, bool own_thread = false)
-        : device_(device), depth_(in_flight < 1 ? 1 : in_flight), threaded_(own_thread && in_flight > 1)
+    // merge (own_thread only; default on): the batches handed over in a burst -- the 6 - 7 a TI block gives rise to come within a few
+    // hundred microseconds -- are decoded by ONE launch (t2gpu_ldpc_submit_add / _go), and the next launch waits for the one in flight:
+    // with two or more decodes resident at once (launches of different streams) every launch of every other stream of the process -- the
+    // demodulator's per-symbol chain first of all -- takes tens of microseconds longer to get its workgroups started, with one it does not
+    // (DESIGN.md section 6). A batch waits at most `merge_linger_us` for the burst to end while nothing is in flight. Same bits, same
+    // verdicts, bit_bch in the order of execute() as before.
+    explicit ldpc_decoder(int device = 0, int in_flight = 8, bool own_thread = false, bool merge = true, int merge_linger_us = 250)
+        : device_(device), depth_(in_flight < 1 ? 1 : in_flight), threaded_(own_thread && in_flight > 1), merged_(own_thread && in_flight > 1 && merge),
+          linger_(merge_linger_us < 0 ? 0 : merge_linger_us)
     {
         handoff_default();
-        if (threaded_) worker_ = std::thread([this] { run(); });
+        if (merged_) groups_.resize(3);
+        if (threaded_) worker_ = std::thread([this] { if (merged_) run_merged(); else run(); });
     }
     ~ldpc_decoder()
     {
@@ -126,6 +134,7 @@ public:
             worker_.join();
         }
         for (auto &ring : gpu_) for (auto &code : ring) for (slot &s : code) if (s.h) t2gpu_ldpc_destroy(s.h);
+        for (group &g : groups_) for (auto &ft : g.h) for (t2gpu_ldpc *h : ft) if (h) t2gpu_ldpc_destroy(h);
     }
     ldpc_decoder(const ldpc_decoder &) = delete;
     ldpc_decoder &operator=(const ldpc_decoder &) = delete;
@@ -138,6 +147,7 @@ public:
         const t2gpu_l1_plp &p = l1_post.plp.at((size_t)idx_plp_simd[0]);
         if (p.plp_cod < 0 || p.plp_cod > 5 || p.plp_fec_type < 0 || p.plp_fec_type > 1)    // T2-Lite codes 6, 7: not in the reference's switch (:173-246)
             fail("ldpc_decoder: PLP_COD / PLP_FEC_TYPE outside the reference's twelve codes");
+        if (merged_) { execute_merged(idx_plp_simd, l1_post, p, len_in, in); return; }
         // a free handle of this code's ring; when all are busy, the oldest batch in flight is awaited (and emitted) first
         slot *s = nullptr;
         {
@@ -169,7 +179,14 @@ public:
     // everything still inside the stage comes out (end of stream; a caller that needs the synchronous behaviour calls it after execute)
     void flush()
     {
-        if (threaded_) {
+        if (merged_) {
+            std::unique_lock<std::mutex> lk(m_);
+            flush_req_ = true;
+            cv_work_.notify_all();
+            cv_free_.wait(lk, [this] { return (gfifo_.empty() && !forming_) || error_; });
+            flush_req_ = false;
+            rethrow_locked();
+        } else if (threaded_) {
             std::unique_lock<std::mutex> lk(m_);
             cv_free_.wait(lk, [this] { return fifo_.empty() || error_; });
             rethrow_locked();
@@ -177,7 +194,13 @@ public:
             while (emit_front(true)) {}
         }
     }
-    int in_flight() const { std::lock_guard<std::mutex> lk(m_); return (int)fifo_.size(); }
+    int in_flight() const
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        int n = (int)fifo_.size() + (forming_ ? forming_->count : 0);
+        for (const group *g : gfifo_) n += g->count;
+        return n;
+    }
 private:
     struct slot {
         t2gpu_ldpc *h = nullptr;
@@ -240,8 +263,134 @@ private:
             }
         }
     }
+    // ---- the merged form: a group = one handle of 8 SIMD batches' capacity per code, the batches added to it and their headers
+    static constexpr int MERGE_MAX = 8;
+    struct group {
+        t2gpu_ldpc *h[2][6] = {};
+        int fec_type = -1, cod = -1, k_ldpc = 0, count = 0;
+        enum { FREE, FORMING, FLYING } state = FREE;
+        std::chrono::steady_clock::time_point last_add;
+        int idx[MERGE_MAX][SIZEOF_SIMD] = {};
+        l1_postsignalling l1[MERGE_MAX];
+    };
+    // (m_ held) the forming group becomes the newest decode in flight
+    void launch_locked(group *g)
+    {
+        g->state = group::FLYING;
+        forming_ = nullptr;
+        int rc;
+        {
+            prof_scope ps(prof_table::LDPC_SUBMIT);
+            rc = t2gpu_ldpc_submit_go(g->h[g->fec_type][g->cod]);
+        }
+        if (rc != 0) { g->state = group::FREE; g->count = 0; cv_free_.notify_all(); fail("t2gpu_ldpc_submit_go"); }
+        gfifo_.push_back(g);
+        cv_work_.notify_all();
+    }
+    void execute_merged(int *idx_plp_simd, const l1_postsignalling &l1_post, const t2gpu_l1_plp &p, int len_in, int8_t *in)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        rethrow_locked();
+        group *g = forming_;
+        if (g && (g->fec_type != p.plp_fec_type || g->cod != p.plp_cod)) { launch_locked(g); g = nullptr; }   // another code: what is forming goes first (order kept)
+        if (!g) {
+            for (;;) {
+                for (group &c : groups_) if (c.state == group::FREE) { g = &c; break; }
+                if (g) break;
+                cv_free_.wait(lk);
+                rethrow_locked();
+            }
+            g->fec_type = p.plp_fec_type; g->cod = p.plp_cod; g->count = 0;
+            t2gpu_ldpc *&h = g->h[g->fec_type][g->cod];
+            if (!h && !(h = t2gpu_ldpc_create(g->fec_type, g->cod, SIZEOF_SIMD * MERGE_MAX, device_))) fail("t2gpu_ldpc_create");
+            t2gpu_ldpc_info(h, nullptr, &g->k_ldpc, nullptr, nullptr);
+            g->state = group::FORMING;
+            forming_ = g;
+        }
+        {
+            prof_scope ps(prof_table::LDPC_SUBMIT);
+            if (t2gpu_ldpc_submit_add(g->h[g->fec_type][g->cod], in, len_in) != 0) {
+                if (g->count == 0) { g->state = group::FREE; forming_ = nullptr; }
+                fail("t2gpu_ldpc_submit_add");
+            }
+        }
+        std::copy(idx_plp_simd, idx_plp_simd + SIZEOF_SIMD, g->idx[g->count]);
+        g->l1[g->count] = l1_post;
+        ++g->count;
+        g->last_add = std::chrono::steady_clock::now();
+        if (g->count == MERGE_MAX) launch_locked(g);
+        cv_work_.notify_all();
+    }
+    // the oldest decode in flight: waits for it, launches what has formed meanwhile (the device is free again), emits its batches in order
+    void emit_group_front()
+    {
+        group *g = nullptr;
+        { std::lock_guard<std::mutex> lk(m_); if (gfifo_.empty()) return; g = gfifo_.front(); }
+        const uint8_t *out = nullptr;
+        const int *trials = nullptr;
+        int rc;
+        {
+            prof_scope ps(prof_table::LDPC_WAIT);
+            rc = t2gpu_ldpc_collect(g->h[g->fec_type][g->cod], 1, &out, &trials, nullptr);
+        }
+        if (rc != 0) fail("t2gpu_ldpc_collect");
+        struct done_guard {
+            ldpc_decoder *d; group *g;
+            ~done_guard()
+            {
+                { std::lock_guard<std::mutex> lk(d->m_); d->gfifo_.erase(d->gfifo_.begin()); g->state = group::FREE; g->count = 0; }
+                d->cv_free_.notify_all();
+            }
+        } guard{this, g};
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (gfifo_.size() == 1 && forming_ && (flush_req_ || std::chrono::steady_clock::now() - forming_->last_add >= linger_)) launch_locked(forming_);
+        }
+        for (int b = 0; b < g->count; ++b) {
+            if (trials[b] < 0) std::fprintf(stderr, "LDPC decoder could not recover the codeword! %d\n", trials[b]);
+            else if (bit_bch) bit_bch(g->idx[b], g->l1[b], g->k_ldpc * SIZEOF_SIMD, const_cast<uint8_t *>(out) + (size_t)b * g->k_ldpc * SIZEOF_SIMD);
+        }
+    }
+    void run_merged()                                            // the stage's own thread, merged form
+    {
+        for (;;) {
+            bool emit = false;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [this] { return stop_ || ((!gfifo_.empty() || forming_) && !error_); });
+                if (stop_) return;
+                if (!gfifo_.empty()) emit = true;
+                else {
+                    // nothing in flight and a group forming: launched when the burst is over (no addition for linger_), or at once in a flush
+                    const auto ripe_at = forming_->last_add + linger_;
+                    if (flush_req_ || std::chrono::steady_clock::now() >= ripe_at) {
+                        try { launch_locked(forming_); } catch (...) { error_ = std::current_exception(); cv_free_.notify_all(); }
+                    } else cv_work_.wait_until(lk, ripe_at);
+                    continue;
+                }
+            }
+            if (!emit) continue;
+            try {
+                emit_group_front();
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                error_ = std::current_exception();
+                for (group *q : gfifo_) {                        // what was in flight is lost with the error; its handles are made reusable
+                    const uint8_t *o = nullptr; const int *t = nullptr;
+                    (void)t2gpu_ldpc_collect(q->h[q->fec_type][q->cod], 1, &o, &t, nullptr);
+                    q->state = group::FREE; q->count = 0;
+                }
+                gfifo_.clear();
+                cv_free_.notify_all();
+            }
+        }
+    }
     int device_, depth_;
-    bool threaded_, stop_ = false;
+    bool threaded_, merged_ = false, flush_req_ = false, stop_ = false;
+    std::chrono::microseconds linger_{250};
+    std::vector<group> groups_;
+    group *forming_ = nullptr;
+    std::vector<group *> gfifo_;
     mutable std::mutex m_;
     std::condition_variable cv_work_, cv_free_;
     std::exception_ptr error_;

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "t2gpu_ldpc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "t2gpu_ldpc_execute": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "t2gpu_ldpc_submit": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "t2gpu_ldpc_submit_add": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "t2gpu_ldpc_submit_go": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_collect": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_ldpc_status": (ctypes.c_int, [_vp]),
     "t2gpu_ldpc_wait_resident": (ctypes.c_int, [_vp, _vp]),

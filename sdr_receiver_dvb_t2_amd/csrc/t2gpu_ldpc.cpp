@@ -43,6 +43,8 @@ struct t2gpu_ldpc {
     int a_cu_reserve = 32;              // CUs the submit stream's mask leaves to everybody else (t2gpu_ldpc_set_submit_cu_reserve)
     hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
+    int s_frames = 0;                   // frames added to the decode being put together (t2gpu_ldpc_submit_add)
+    bool s_side = false, s_host = false; // ... of which some came from twins on the device / from host buffers
     bool a_ready = false;               // stream, event and pinned staging of the asynchronous form all exist
     bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
     bool plain_always = false;          // t2gpu_ldpc_set_plain_launch
@@ -436,11 +438,14 @@ extern "C" int t2gpu_ldpc_set_submit_cu_reserve(t2gpu_ldpc *h, int n_cus)
     return 0;
 }
 
-extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
+// One more SIMD batch (or several) into the decode the handle is putting together: its LLRs are on their way into the handle's input behind
+// what has been added before; nothing is launched.
+extern "C" int t2gpu_ldpc_submit_add(t2gpu_ldpc *h, const int8_t *in, int len_in)
 {
     if (!h || !in || len_in < h->g.n || len_in % h->g.n) { set_error("t2gpu_ldpc_submit: bad arguments"); return -1; }
     const int n_frames = len_in / h->g.n;
-    if (n_frames > h->max_frames) { set_error("t2gpu_ldpc_submit: more frames than max_frames"); return -1; }
+    if (h->s_frames % h->group) { set_error("t2gpu_ldpc_submit_add: only the last addition may end in a partial SIMD batch"); return -1; }
+    if (h->s_frames + n_frames > h->max_frames) { set_error("t2gpu_ldpc_submit: more frames than max_frames"); return -1; }
     if (h->a_frames) { set_error("t2gpu_ldpc_submit: the previous submit has not been collected"); return -1; }
     T2_HIP(hipSetDevice(h->device));
     if (!h->a_ready) {
@@ -472,11 +477,17 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     if (!h->d_in) T2_HIP(hipMalloc(&h->d_in, (size_t)h->max_frames * h->g.n));
     if (!h->d_out) T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_frames * h->g.k));
     if (!h->d_trials) T2_HIP(hipMalloc(&h->d_trials, (size_t)h->max_frames * sizeof(int)));
-    const int nbatches = (n_frames + h->group - 1) / h->group;
-    hipStream_t s = h->a_stream;
-    const int8_t *d_llr = h->d_in;
-    twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);      // the previous result's bits are about to be overwritten
-    if (const void *twin = twin_lookup(in, (size_t)len_in, h->device)) {
+    if (h->s_frames == 0) {
+        twin_retire_dev(h->d_out, (size_t)h->max_frames * h->g.k);  // the previous result's bits are about to be overwritten
+        h->s_side = false; h->s_host = false;
+    }
+    const size_t at = (size_t)h->s_frames * h->g.n;
+    const void *twin = twin_lookup(in, (size_t)len_in, h->device);
+    if (h->s_frames && (twin ? h->s_host : h->s_side)) {
+        set_error("t2gpu_ldpc_submit_add: batches with and without a device twin in one decode (launch what has been added first)");
+        return -1;
+    }
+    if (twin) {
         // a SIMD batch assembled from the demapper's output (t2gpu_twin_copy) is on the device already: its twin is written on the
         // device's side stream, so the copy into this handle's input is put there too (in order with those writes, and the twin is
         // free for the next batch when it is through) and this handle's stream starts behind it. Nothing on the side stream (or the
@@ -484,14 +495,34 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
         // whole decodes whenever two handles' streams shared a hardware queue.
         hipStream_t side = side_stream(h->device);
         if (!side) return -1;
+        T2_HIP(hipMemcpyAsync(h->d_in + at, twin, (size_t)len_in, hipMemcpyDeviceToDevice, side));
+        h->s_side = true;
+    } else {
+        std::memcpy(h->p_in + at, in, (size_t)len_in);              // the caller's buffer is free again when this returns
+        h->s_host = true;
+    }
+    h->s_frames += n_frames;
+    return 0;
+}
+
+// ... and the decode of everything added, as ONE launch
+extern "C" int t2gpu_ldpc_submit_go(t2gpu_ldpc *h)
+{
+    if (!h || !h->s_frames || !h->a_ready) { set_error("t2gpu_ldpc_submit_go: nothing has been added"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    const int n_frames = h->s_frames;
+    const int nbatches = (n_frames + h->group - 1) / h->group;
+    hipStream_t s = h->a_stream;
+    const int8_t *d_llr = h->d_in;
+    if (h->s_host) d_llr = h->p_in;                                 // the decoder reads every LLR once: straight from the page-locked copy
+    if (h->s_side) {
+        hipStream_t side = side_stream(h->device);
+        if (!side) return -1;
         if (!h->a_fence) T2_HIP(hipEventCreateWithFlags(&h->a_fence, hipEventDisableTiming));
-        T2_HIP(hipMemcpyAsync(h->d_in, twin, (size_t)len_in, hipMemcpyDeviceToDevice, side));
         T2_HIP(hipEventRecord(h->a_fence, side));
         T2_HIP(hipStreamWaitEvent(s, h->a_fence, 0));
-    } else {
-        std::memcpy(h->p_in, in, (size_t)len_in);                   // the caller's buffer is free again when this returns
-        d_llr = h->p_in;                                            // the decoder reads every LLR once: straight from the page-locked copy
     }
+    h->s_frames = 0;
     // several submits run side by side (cooperative launches would not). What they hold of the device together is booked (above): this
     // call waits while the decodes in flight leave no room for its grid, and a grid the device could never hold as a whole goes through
     // the cooperative launch, which refuses rather than hangs
@@ -509,6 +540,13 @@ extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
     arm_booking(h);
     h->a_frames = n_frames;
     return 0;
+}
+
+extern "C" int t2gpu_ldpc_submit(t2gpu_ldpc *h, const int8_t *in, int len_in)
+{
+    if (h && h->s_frames) { set_error("t2gpu_ldpc_submit: a decode is being put together (t2gpu_ldpc_submit_add)"); return -1; }
+    if (t2gpu_ldpc_submit_add(h, in, len_in) != 0) return -1;
+    return t2gpu_ldpc_submit_go(h);
 }
 
 // wait != 0: blocks until the pending submit is through; wait == 0: returns 1 at once when it is not. On 0, *out points at

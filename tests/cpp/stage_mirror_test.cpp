@@ -60,7 +60,8 @@ int main(int argc, char **argv)
             t2::l1_postsignalling l1;
             l1.plp.resize(1);
             l1.plp[0].plp_fec_type = fec_type; l1.plp[0].plp_cod = cod;
-            t2::ldpc_decoder ldpc(0, 8, std::getenv("STAGE_THREADS") && std::atoi(std::getenv("STAGE_THREADS")) != 0);
+            t2::ldpc_decoder ldpc(0, 8, std::getenv("STAGE_THREADS") && std::atoi(std::getenv("STAGE_THREADS")) != 0,
+                                  !(std::getenv("STAGE_MERGE") && std::atoi(std::getenv("STAGE_MERGE")) == 0));   // STAGE_MERGE=0: one launch per SIMD batch
             t2::bch_decoder bch;
             bch.outer_code = argc > 6 && std::string(argv[6]) == "outer";       // the library's opt-in BCH correction in front
             std::vector<uint8_t> out;
@@ -118,7 +119,7 @@ int main(int argc, char **argv)
             const bool threads = std::getenv("STAGE_THREADS") && std::atoi(std::getenv("STAGE_THREADS")) != 0;
             t2::time_deinterleaver ti(0, threads);
             t2::llr_demapper qam;
-            t2::ldpc_decoder ldpc(0, 8, threads);
+            t2::ldpc_decoder ldpc(0, 8, threads, !(std::getenv("STAGE_MERGE") && std::atoi(std::getenv("STAGE_MERGE")) == 0));
             t2::bch_decoder bch;
             t2::bb_de_header deheader(need_plp);
             // STAGE_HANDOFF=0: the hand-over of stage outputs by address, which the stage classes switch on, off again

@@ -55,17 +55,20 @@ def test_decimator_and_farrow_classes(driver, tmp_path):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("fec_type,cod,threads", [(0, 0, 0), (1, 3, 0), (1, 3, 1)])
+@pytest.mark.parametrize("fec_type,cod,threads", [(0, 0, 0), (1, 3, 0), (1, 3, 1), (1, 3, 2), (0, 0, 1)])
 def test_ldpc_bch_chain_with_drop(driver, tmp_path, fec_type, cod, threads):
     """ldpc_decoder.bit_bch -> bch_decoder.execute -> bit_descramble, three SIMD batches, the middle one undecodable: the
-    reference prints its message and drops that batch; the other two come out descrambled, frame by frame."""
+    reference prints its message and drops that batch; the other two come out descrambled, frame by frame. threads 1: the stage on a
+    thread of its own, the three batches decoded by ONE launch (t2gpu_ldpc_submit_add / _go: one verdict per batch); 2: that thread with
+    one launch per batch (STAGE_MERGE=0)."""
     cid = ol.code_id(fec_type, cod)
     n, k, _, _ = ol.ldpc_params(cid)
     info, llr = ol.make_llr(cid, 96, 0.55 if fec_type else 0.7, 5)
     rng = np.random.Generator(np.random.PCG64(6))
     llr[32:64] = rng.integers(-20, 21, size=(32, n), dtype=np.int8)              # noise only: never converges
     llr.tofile(tmp_path / "llr.i8")
-    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod, env_extra={"STAGE_THREADS": str(threads)})
+    err = run(driver, "fec", tmp_path / "llr.i8", tmp_path / "out.u8", fec_type, cod,
+              env_extra={"STAGE_THREADS": str(min(threads, 1)), "STAGE_MERGE": "0" if threads == 2 else "1"})
     assert err.count("LDPC decoder could not recover the codeword!") == 1
     k_bch = t2_tx.K_BCH[cid]
     got = np.fromfile(tmp_path / "out.u8", np.uint8).reshape(-1, 1 + k_bch)
