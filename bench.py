@@ -240,7 +240,7 @@ DROP_IN_EXE = os.path.join(ROOT, "sdr_receiver_dvb_t2_amd", "bin", "t2gpu_rx_fil
 DROP_IN_BUF = 172032          # samples per execute() call: norm_blocks x 384 of the reference's SDRplay thread (rx_sdrplay.h:64, rx_sdrplay.cpp:199-261)
 
 
-def drop_in_leg(w, ui, uq, device, frames=72, warm_frames=12, sent=None, saturate=False, snr_db=None):
+def drop_in_leg(w, ui, uq, device, frames=132, warm_frames=12, sent=None, saturate=False, snr_db=None):
     """The slot-shaped path: int16 I/Q in device-buffer-sized calls through t2::dvbt2_demodulator::execute (t2gpu_demod_execute: closed
     tracking loops, the reference's own acquisition from P1 / guard search / L1-pre / L1-post) and the stage classes of
     include/t2gpu_stages.hpp wired as the reference wires its objects (time_deinterleaver -> llr_demapper -> ldpc_decoder -> bch_decoder ->
@@ -279,7 +279,8 @@ def drop_in_leg(w, ui, uq, device, frames=72, warm_frames=12, sent=None, saturat
            "samples_per_call": DROP_IN_BUF, "calls_timed": r["buffers"], "t2_frames_timed": r["t2_frames"], "seconds": round(r["seconds"], 4),
            "bbframes": r["bbframes"], "ts_bytes": r["ts_bytes"], "simd_batches_dropped_by_ldpc": dropped, "resets": r["resets"],
            "acquired": bool(r["deint_start"]), "process_wall_s": round(wall, 2), "llr_cast": "clamped (extension)" if saturate else "reference (wraps)",
-           "device_loop": "--device-loop 0" not in os.environ.get("T2GPU_DROPIN_ARGS", "")}
+           "device_loop": "--device-loop 0" not in os.environ.get("T2GPU_DROPIN_ARGS", ""),
+           "ldpc_batches_of_a_burst_in_one_launch": "--ldpc-merge 0" not in os.environ.get("T2GPU_DROPIN_ARGS", "")}
     if sent is not None:
         # whole packets of the program's output (from the start of the file: the first BBFRAME's SYNCD puts it on a packet boundary) among those sent
         pk = ts[:ts.size // 188 * 188].reshape(-1, 188)
@@ -393,7 +394,7 @@ def main():
     if args.only_drop_in:
         w = Workload(CONFIGS[args.config])
         ui, uq, sent = make_frames(w, 2, args.snr if args.snr is not None else CONFIGS[args.config]["snr"], seed=20250614)
-        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 72, sent=sent, saturate=args.saturate, snr_db=args.snr)))
+        print(json.dumps(drop_in_leg(w, ui, uq, local_rank, frames=args.frames or 132, sent=sent, saturate=args.saturate, snr_db=args.snr)))
         return
 
     def run_config(cfg_id, steps, warmup, extras, check_ts=False):
@@ -580,7 +581,7 @@ def main():
             if cfg_id != 4:
                 w4 = Workload(CONFIGS[4])
                 ui4, uq4, sent4 = make_frames(w4, 2, CONFIGS[4]["snr"], seed=20250614)
-                d_in["config_4"] = {k: v for k, v in drop_in_leg(w4, ui4, uq4, local_rank, frames=120, warm_frames=20, sent=sent4).items() if k != "entry"}
+                d_in["config_4"] = {k: v for k, v in drop_in_leg(w4, ui4, uq4, local_rank, frames=240, warm_frames=20, sent=sent4).items() if k != "entry"}
             extra["drop_in"] = d_in
 
         if rank != 0:
