@@ -231,3 +231,56 @@ def test_submits_that_overbook_the_device_wait_for_each_other(torch_cuda):
         assert np.array_equal(trials, wt) and np.array_equal(bits, wb)
     for d in decs:
         d.close()
+
+
+def test_batches_added_one_by_one_and_decoded_by_one_launch(torch_cuda):
+    """t2gpu_ldpc_submit_add / t2gpu_ldpc_submit_go (what t2::ldpc_decoder's own thread does with the burst of SIMD batches a TI block gives
+    rise to): five batches handed over one by one -- decodable, all noise, decodable, a short last one of 9 frames, from host buffers -- and
+    decoded by ONE launch give the bits and the per-batch verdicts of five separate t2gpu_ldpc_submit calls; a whole batch behind a partial
+    one, more frames than max_frames, go / collect with nothing added are refused; the handle goes on afterwards (add + go again)."""
+    import ctypes
+    import sdr_receiver_dvb_t2_amd as pkg
+    l = pkg.lib()
+    cid = ol.code_id(1, 3)
+    n, k, _, _ = ol.ldpc_params(cid)
+    rng = np.random.Generator(np.random.PCG64(11))
+    parts = []
+    for b, frames in enumerate((32, 32, 32, 32, 9)):
+        if b == 1:
+            parts.append(np.ascontiguousarray(rng.integers(-20, 21, size=(frames, n), dtype=np.int8)))       # never converges
+        else:
+            parts.append(np.ascontiguousarray(ol.make_llr(cid, frames, 0.55, 40 + b)[1]))
+    total = sum(p.shape[0] for p in parts)
+
+    def collect(d, frames):
+        out, tr, nf = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+        assert l.t2gpu_ldpc_collect(d._h, 1, ctypes.byref(out), ctypes.byref(tr), ctypes.byref(nf)) == 0, l.t2gpu_last_error()
+        assert nf.value == frames
+        bits = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_uint8)), shape=(frames, k)).copy()
+        trials = np.ctypeslib.as_array(ctypes.cast(tr, ctypes.POINTER(ctypes.c_int32)), shape=((frames + 31) // 32,)).copy()
+        return bits, trials
+
+    one = pkg.ldpc_decoder(1, 3, max_frames=32)
+    want_bits, want_trials = [], []
+    for p in parts:
+        assert l.t2gpu_ldpc_submit(one._h, p.ctypes.data, p.size) == 0, l.t2gpu_last_error()
+        b, t = collect(one, p.shape[0])
+        want_bits.append(b); want_trials.append(t)
+    one.close()
+    assert want_trials[1][0] < 0 and all(t[0] >= 0 for i, t in enumerate(want_trials) if i != 1)
+
+    d = pkg.ldpc_decoder(1, 3, max_frames=160)
+    assert l.t2gpu_ldpc_submit_go(d._h) == -1                                   # nothing added
+    for rep in range(2):                                                        # twice: the handle goes on
+        for p in parts:
+            assert l.t2gpu_ldpc_submit_add(d._h, p.ctypes.data, p.size) == 0, l.t2gpu_last_error()
+        assert l.t2gpu_ldpc_submit_add(d._h, parts[0].ctypes.data, parts[0].size) == -1      # behind a partial batch (and over max_frames)
+        assert l.t2gpu_ldpc_submit(d._h, parts[0].ctypes.data, parts[0].size) == -1          # a decode is being put together
+        assert l.t2gpu_ldpc_submit_go(d._h) == 0, l.t2gpu_last_error()
+        assert l.t2gpu_ldpc_submit_add(d._h, parts[0].ctypes.data, parts[0].size) == -1      # the previous one has not been collected
+        bits, trials = collect(d, total)
+        assert np.array_equal(trials, np.concatenate(want_trials))
+        assert np.array_equal(bits, np.concatenate(want_bits))
+    big = np.zeros((161, n), np.int8)
+    assert l.t2gpu_ldpc_submit_add(d._h, big.ctypes.data, big.size) == -1       # more frames than max_frames
+    d.close()
