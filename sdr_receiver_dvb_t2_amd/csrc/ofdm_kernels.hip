@@ -879,7 +879,9 @@ __global__ __launch_bounds__(8 * T2) void fft_one_sync_kernel(const float2 *__re
         return;
     }
     if (threadIdx.x == 0) {
-        for (unsigned spins = 0; __hip_atomic_load(count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u && spins < (1u << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        unsigned spins = 0;
+        for (; __hip_atomic_load(count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u && spins < (1u << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        if (spins == (1u << 24)) __builtin_trap();            // (~0.5 s: stage A's workgroups never arrived -- the launch fails loudly rather than hand on a spectrum of leftovers)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
