@@ -858,6 +858,8 @@ public:
     // the tracking loops of a frame's data symbols on the device (t2gpu_demod_set_device_loop); off unless asked for
     void set_device_loop(bool on) { if (t2gpu_demod_set_device_loop(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_device_loop"); }
     // a call's level / IQ estimates from one pass at its head (default) or from its chunks' sums (t2gpu_demod_set_call_stats)
+    // the chunk that completes a 32K data symbol and the symbol's transform as one launch (default) or two (t2gpu_demod_set_chain_one)
+    void set_chain_one(bool on) { if (t2gpu_demod_set_chain_one(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_chain_one"); }
     void set_call_stats(bool on) { if (t2gpu_demod_set_call_stats(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_call_stats"); }
     t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
 private:

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include "front_plan.h"
 #include "loop_device.h"
+#include "ofdm_kernels.h"
 
 constexpr int FRONT_BLOCK = 4096;          // input samples per workgroup in the dc / de-rotation kernels (256 lanes x FRONT_PER)
 constexpr int FRONT_PER = FRONT_BLOCK / 256;
@@ -94,6 +95,14 @@ struct FrontOneArgs {
 };
 int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs);
 void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream);
+// ... and with the transform + synchronisation floats of the 32K symbol the chunk completes in the same launch (front_fft_one_kernel)
+void launch_front_fft_one(FrontOneArgs &a, int grid, const t2gpu::FftOneArgs &f, hipStream_t stream);
+
+// (internal, C++ linkage: t2gpu_demod.cpp) t2gpu_front_execute_loop_dev; when `fft` is given and the chunk gives exactly need_out cells, the
+// launch also runs *fft (the symbol those cells complete) and *fused is set to 1
+struct t2gpu_front;
+long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out, long out_cap_cells,
+                          void *stream, long need_out, const t2gpu::FftOneArgs *fft, int *fused);
 
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
 // sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).

@@ -16,6 +16,7 @@
 #include "front_kernels.h"
 #include "tables/dsp_tables_data.h"
 #include "cp_device.h"
+#include "ofdm_device.h"
 
 #pragma clang fp contract(off)
 
@@ -668,7 +669,7 @@ __device__ __noinline__ int plan_nco_dev(float *acc, int n, float fe, float phas
     return nr;
 }
 
-__global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
+__device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, const int nb)
 {
     __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS], sh_nco[FRONT_CHAIN_RUNS];
     __shared__ Lin wave_tot[4];
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
     __shared__ int sh_last;
     __shared__ float2 D[F1_H + F1_B];                          // de-rotated samples s0 - F1_H .. s0 + F1_B - 1
     __shared__ float2 W[F1_WCAP + F1_WCAP / 8 + 8];            // the decimator's window, padded as front_farrow_decimate_body pads it
-    const int tid = threadIdx.x, b = (int)blockIdx.x, nb = (int)gridDim.x;
+    const int tid = threadIdx.x;
     FrontParams p = a.p;
     for (int t = tid; t < p.n_nco_runs + p.n_far_runs; t += 256) sh_runs[t] = a.runs[t];
     p.nco_runs = sh_runs; p.far_runs = sh_runs + p.n_nco_runs;
@@ -915,6 +916,39 @@ __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a) { front_one_body(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// ---- a chunk's front end AND the transform + synchronisation floats of the 32K symbol it completes, in ONE launch (round 5): workgroups
+// 0 .. nb_front - 1 are front_one_kernel's, the eight behind them fft_one_sync_kernel<32>'s (ofdm_device.h) -- stage A's four wait until every
+// front-end workgroup has counted itself done (its cells stored and released; a workgroup only ever waits for lower-numbered ones, which were
+// dispatched before it), the other four wait for stage A as before. The per-symbol critical path of the slot-shaped path is then one launch
+// and no launch gap; every value goes through the operations of the two launches in their order.
+__global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gpu::FftOneArgs f, int nb_front)
+{
+    __shared__ __attribute__((aligned(16))) float fft_lds[t2gpu::FFT_BC_LDS_FLOATS];
+    const int b = (int)blockIdx.x;
+    if (b < nb_front) { front_one_body(a, b, nb_front); return; }
+    const int fb = b - nb_front;
+    if (fb < 4) {
+        if (threadIdx.x == 0) {
+            const unsigned long long want = a.done_target + (unsigned long long)nb_front;
+            long long t0 = 0;
+            for (unsigned spins = 1; __hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spins) {
+                if ((spins & 0xfffu) == 0) {
+                    const long long now = wall_clock64();
+                    if (!t0) t0 = now;
+                    else if (now - t0 > 200000000LL) __builtin_trap();          // 2 s at 100 MHz: the front end never finished -- fail loudly
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    t2gpu::fft_one_sync_body<32>(f.in, f.scratch, f.out, f.twiddle, f.count, f.p, f.idx_symbol, f.buffered, f.guard, f.cp_out, f.sync, f.h_small, f.h_flag, f.seq,
+                                 f.loop, fb, fft_lds);
+}
+
 // ---- a buffer of int16 I and Q from PAGE-LOCKED host memory into the device's staging by a kernel of the caller's stream (the
 // slot-shaped path: two copy-engine transfers per execute() cost 12 us each and, worse, ~20 + 9 + 30 us of hand-over between the stream's
 // kernels and the copy engine on either side of them -- 85 us per 172 032-sample buffer, a whole OFDM symbol's worth)
@@ -1138,6 +1172,12 @@ void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream)
 {
     load_taps();
     hipLaunchKernelGGL(front_one_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+}
+
+void launch_front_fft_one(FrontOneArgs &a, int grid, const t2gpu::FftOneArgs &f, hipStream_t stream)
+{
+    load_taps();
+    hipLaunchKernelGGL(front_fft_one_kernel, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
 }
 
 void launch_front(const FrontParams &p, hipStream_t stream)

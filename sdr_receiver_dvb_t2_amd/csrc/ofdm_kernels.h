@@ -95,6 +95,21 @@ hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, cons
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
                                unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr);
 
+// what fft_one_sync_kernel takes, for the launch that runs a chunk's front end AND the symbol's transform (front_kernels.hip:
+// front_fft_one_kernel; 32K symbols -- the front end's workgroups have 256 lanes, as stages B + C of a 32K transform)
+struct FftOneArgs {
+    const float2 *in; float2 *scratch, *out; const float2 *twiddle; unsigned *count;
+    EqParams p; int idx_symbol; const float2 *buffered; int guard; float4 *cp_out; float2 *sync; float *h_small; unsigned *h_flag; unsigned seq;
+    T2DevLoop *loop; int fft_size;
+};
+constexpr int FFT_ONE_LDS_FLOATS = 32 * 8 * 33;   // (= ofdm_device.h's FFT_BC_LDS_FLOATS)
 void set_fft_one_launch(int on);   // launch_fft_sym_sync as one launch (default) or two
 
 }  // namespace t2gpu
+
+// (internal, C++ linkage: t2gpu_demod.cpp) the arguments t2gpu_fft_sym_sync_dev would launch with, for the launch that also runs the chunk's
+// front end: 0 = filled in, 1 = this symbol does not take the one-launch form (pilot tables too large for the exchange buffer, not 32K), -1 = error
+struct t2gpu_ofdm;
+int t2gpu_fft_one_args(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp, float *d_spectrum,
+                       float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, t2gpu::FftOneArgs *out);
+

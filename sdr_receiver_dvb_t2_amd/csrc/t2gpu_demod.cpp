@@ -104,6 +104,12 @@ struct t2gpu_demod {
     // them one symbol behind (pend), recomputing the same floats for its own copies. Checked when the mode is left, once per frame.
     bool dev_loop = false;             // t2gpu_demod_set_device_loop
     bool call_stats = false;           // a call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats)
+    // the chunk that completes a 32K data symbol and the symbol's transform + floats as ONE launch (t2gpu_demod_set_chain_one): what the symbol's
+    // launches need -- its buffer set (with the waits for the set's last users), its sequence word -- is then settled ahead of the chunk
+    bool chain_one = true;
+    struct { bool valid = false, have_cp = false; int k = 0; unsigned seq_a = 0; } prep;
+    bool fft_fused = false;            // the chunk just launched took the symbol's transform with it
+    long fused_symbols = 0;
     bool dev_mode = false;
     struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0; } pend;
     long dev_symbols = 0, dev_speculated = 0, dev_waited = 0;
@@ -505,6 +511,24 @@ int leave_dev_mode(t2gpu_demod *h)
     return 0;
 }
 
+// the buffer set and the sequence word of the symbol being collected (symbol_acquisition's first steps at a complete symbol, :321-330): settled
+// once per symbol, either here ahead of the chunk that will complete it (the one-launch chain) or when the symbol is complete
+int prepare_symbol(t2gpu_demod *h)
+{
+    if (h->prep.valid) return 0;
+    h->prep.have_cp = h->crc32_l1_pre;                                              // :321-330; its result is read with the symbol's other results
+    // this symbol's buffer set; the launches that used it two symbols ago (equaliser, publishing: eq_stream) are through before the
+    // FFT writes into it -- long since, as a rule
+    const int k = h->cur = (h->cur + 1) % t2gpu_demod::NSETS;
+    if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
+    // (the loop on the device: set k was the symbol's four back, which the cells' thread has handed on by now -- as a rule)
+    if (h->dev_mode && h->cells_submitted >= (unsigned)t2gpu_demod::NSETS && cells_wait(h, h->cells_submitted - (t2gpu_demod::NSETS - 1)) != 0) return -1;
+    h->prep.k = k;
+    h->prep.seq_a = ++h->seq;
+    h->prep.valid = true;
+    return 0;
+}
+
 int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal_, const float *src)
 {
     int consume = 0;
@@ -560,21 +584,19 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         }
         h->idx_buffer_sym = 0;
         h->prof.start();
-        const bool have_cp = h->crc32_l1_pre;                                       // :321-330; its result is read with the symbol's other results
         float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        // this symbol's buffer set; the launches that used it two symbols ago (equaliser, publishing: eq_stream) are through before the
-        // FFT writes into it -- long since, as a rule
-        const int k = h->cur = (h->cur + 1) % t2gpu_demod::NSETS;
-        if (h->eq_busy[k]) { T2_HIP(hipStreamWaitEvent(h->stream, h->ev_eq[k], 0)); h->eq_busy[k] = false; }
-        // (the loop on the device: set k was the symbol's four back, which the cells' thread has handed on by now -- as a rule)
-        if (h->dev_mode && h->cells_submitted >= (unsigned)t2gpu_demod::NSETS && cells_wait(h, h->cells_submitted - (t2gpu_demod::NSETS - 1)) != 0) return -1;
+        if (prepare_symbol(h) != 0) return -1;
+        const bool have_cp = h->prep.have_cp;
+        const int k = h->prep.k;
+        const unsigned seq_a = h->prep.seq_a;
+        h->prep.valid = false;
         // FFT (:332-334), and in its last launch the guard correlation (:321-327) and the symbol's two synchronisation floats, from the
-        // pilots alone, stored to the host with the sequence word behind them
+        // pilots alone, stored to the host with the sequence word behind them -- unless the chunk's launch has run them already
         const int kind = h->next_symbol_type == SYMBOL_TYPE_DATA ? 0 : h->next_symbol_type == SYMBOL_TYPE_P2 ? 1 : 2;
-        const unsigned seq_a = ++h->seq;
-        if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
-                                   have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small + 8 * k, h->h_flag, seq_a,
-                                   h->dev_mode ? t2gpu_front_loop_dev(h->front) : nullptr, h->stream) != 0) return -1;
+        if (h->fft_fused) { h->fft_fused = false; ++h->fused_symbols; }
+        else if (t2gpu_fft_sym_sync_dev(h->p2_ofdm, kind == 1 ? h->p2_ofdm : h->data_ofdm, kind, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size,
+                                        have_cp ? 1 : 0, h->d_spec[k], nullptr, nullptr, h->h_small + 8 * k, h->h_flag, seq_a,
+                                        h->dev_mode ? t2gpu_front_loop_dev(h->front) : nullptr, h->stream) != 0) return -1;
         if (!h->dev_mode) T2_HIP(hipEventRecord(h->ev_fft, h->stream));
         h->prof.stop(PF_CP);
         h->est_chunk = 0;
@@ -779,8 +801,8 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
         std::fprintf(stderr, "t2gpu_demod profile (host wall time inside execute(), %ld symbols):\n", h->symbols);
         if (h->cells_n) std::fprintf(stderr, "  cells' thread, per symbol: launches %.1f us, waiting for the cells %.1f us, the signal %.1f us, idle %.1f us\n", h->cells_t[0] * 1e6 / h->cells_n,
                                      h->cells_t[1] * 1e6 / h->cells_n, h->cells_t[2] * 1e6 / h->cells_n, h->cells_t[3] * 1e6 / h->cells_n);
-        std::fprintf(stderr, "  loop on the device: %ld data symbols; chunks launched ahead of a symbol's results %ld, chunks that waited for them %ld\n",
-                     h->dev_symbols, h->dev_speculated, h->dev_waited);
+        std::fprintf(stderr, "  loop on the device: %ld data symbols (%ld with their transform in the chunk's launch); chunks launched ahead of a symbol's results %ld, chunks that waited for them %ld\n",
+                     h->dev_symbols, h->fused_symbols, h->dev_speculated, h->dev_waited);
         for (int k = 0; k < PF_N; ++k)
             std::fprintf(stderr, "  %-46s %9.3f ms  %5.1f %%  %7ld calls  %8.1f us each\n", PF_NAME[k], h->prof.t[k] * 1e3, 100.0 * h->prof.t[k] / (tot > 0 ? tot : 1),
                          h->prof.n[k], h->prof.n[k] ? h->prof.t[k] * 1e6 / h->prof.n[k] : 0.0);
@@ -804,6 +826,15 @@ extern "C" int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz)
         if (leave_dev_mode(h) != 0) return -1;
     }
     h->tuner = 2.0 * 3.14159265358979323846 * offset_hz / (double)SAMPLE_RATE_HZ;
+    return 0;
+}
+
+// on = 1 (default): with the loop on the device, the chunk that completes a 32K data symbol and the symbol's transform + synchronisation floats are
+// ONE launch (front_fft_one_kernel); 0: two. Same values.
+extern "C" int t2gpu_demod_set_chain_one(t2gpu_demod *h, int on)
+{
+    if (!h) { set_error("t2gpu_demod_set_chain_one: bad arguments"); return -1; }
+    h->chain_one = on != 0;
     return 0;
 }
 
@@ -906,8 +937,21 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         }
         long n_out = -2;
         if (h->dev_mode) {
-            n_out = t2gpu_front_execute_loop_dev(h->front, chunk, arbitrary_resample, h->d_i + (size_t)idx_in * h->stride, h->d_q + (size_t)idx_in * h->stride,
-                                                 dst, cap, h->stream);
+            // the chunk that completes a 32K data symbol takes the symbol's transform and floats with it (one launch; t2gpu_demod_set_chain_one)
+            t2gpu::FftOneArgs fa;
+            const t2gpu::FftOneArgs *fft = nullptr;
+            const long need = (long)h->symbol_size - h->idx_buffer_sym;
+            if (h->chain_one && h->next_symbol_type == SYMBOL_TYPE_DATA && h->fft_size == 32768 && h->data_ofdm) {
+                if (prepare_symbol(h) != 0) return -1;
+                const int rc = t2gpu_fft_one_args(h->p2_ofdm, h->data_ofdm, 0, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size, h->prep.have_cp ? 1 : 0,
+                                                  h->d_spec[h->prep.k], h->h_small + 8 * h->prep.k, h->h_flag, h->prep.seq_a, t2gpu_front_loop_dev(h->front), &fa);
+                if (rc < 0) return -1;
+                if (rc == 0) fft = &fa;
+            }
+            int fused = 0;
+            n_out = t2gpu_front_loop_fft(h->front, chunk, arbitrary_resample, h->d_i + (size_t)idx_in * h->stride, h->d_q + (size_t)idx_in * h->stride,
+                                         dst, cap, h->stream, need, fft, &fused);
+            h->fft_fused = fused != 0;
             if (n_out == -1) return -1;
             if (n_out == -2) { if (leave_dev_mode(h) != 0) return -1; }             // (a chunk the one-launch form does not take: this symbol goes on with the loops on the host)
             else if (!h->pend.valid && follow_chunks(h) != 0) return -1;            // nothing out: the device ran on the values the host holds

@@ -456,6 +456,13 @@ extern "C" int t2gpu_front_loop_begin(t2gpu_front *h, const float *state10, void
 extern "C" long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out,
                                              long out_cap_cells, void *stream_)
 {
+    return t2gpu_front_loop_fft(h, chunk, rs, d_i, d_q, d_out, out_cap_cells, stream_, -1, nullptr, nullptr);
+}
+
+long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out, long out_cap_cells,
+                          void *stream_, long need_out, const t2gpu::FftOneArgs *fft, int *fused)
+{
+    if (fused) *fused = 0;
     if (!h || chunk < 1 || !d_i || !d_q || !d_out) { set_error("t2gpu_front_execute_loop_dev: bad arguments"); return -1; }
     if (chunk > h->max_samples) { set_error("t2gpu_front_execute: more samples than max_samples"); return -1; }
     hipStream_t stream = (hipStream_t)stream_;
@@ -482,7 +489,8 @@ extern "C" long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, doub
     a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
     a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
     a.loop = h->d_loop; a.loop_runs = h->d_loop_runs;
-    launch_front_one(a, one_grid, stream);
+    if (fft && fused && n_out == need_out && fft->fft_size == 32768) { launch_front_fft_one(a, one_grid, *fft, stream); *fused = 1; }
+    else launch_front_one(a, one_grid, stream);
     T2_HIP(hipGetLastError());
     h->one_seq += 1;
     h->one_done += (unsigned long long)one_grid;

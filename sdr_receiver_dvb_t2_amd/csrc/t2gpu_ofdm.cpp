@@ -541,6 +541,24 @@ extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kin
     return t2gpu_sym_sync_dev(tables, kind, idx_symbol, d_spectrum, with_cp ? d_buffered : nullptr, guard, d_cp4, d_sync, h_small, h_flag, seq, d_loop, stream);
 }
 
+int t2gpu_fft_one_args(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symbol, const float *d_buffered, int guard, int with_cp, float *d_spectrum,
+                       float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, t2gpu::FftOneArgs *out)
+{
+    if (!h || !tables || !d_buffered || !d_spectrum || !out || kind != 0 || guard < 0 || (h_small && !h_flag) || tables->m.fft_size != h->m.fft_size) {
+        set_error("t2gpu_fft_one_args: bad arguments");
+        return -1;
+    }
+    if (idx_symbol < tables->m.n_p2 || idx_symbol >= tables->m.n_p2 + tables->rows) { set_error("t2gpu_fft_one_args: symbol index outside the frame's data symbols"); return -1; }
+    const EqParams &p = tables->eq;
+    if (h->m.fft_size != 32768 || (p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_ONE_LDS_FLOATS * 4 || !h->d_fft_scratch || !h->d_fft_count) return 1;
+    out->in = reinterpret_cast<const float2 *>(d_buffered) + guard;
+    out->scratch = h->d_fft_scratch; out->out = reinterpret_cast<float2 *>(d_spectrum); out->twiddle = h->d_twiddle; out->count = h->d_fft_count;
+    out->p = p; out->idx_symbol = idx_symbol; out->buffered = with_cp ? reinterpret_cast<const float2 *>(d_buffered) : nullptr; out->guard = guard;
+    out->cp_out = nullptr; out->sync = nullptr; out->h_small = h_small; out->h_flag = h_flag; out->seq = seq; out->loop = static_cast<T2DevLoop *>(d_loop);
+    out->fft_size = h->m.fft_size;
+    return 0;
+}
+
 extern "C" void t2gpu_fft_set_one_launch(int on) { t2gpu::set_fft_one_launch(on); }
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,

@@ -162,6 +162,8 @@ int main(int argc, char **argv)
             if (std::getenv("STAGE_DEVICE_LOOP") && std::atoi(std::getenv("STAGE_DEVICE_LOOP")) != 0) demodulator.set_device_loop(true);
             // STAGE_CALL_STATS=1: a call's level / IQ estimates from one pass over its buffer at its head (t2gpu_demod_set_call_stats)
             if (std::getenv("STAGE_CALL_STATS") && std::atoi(std::getenv("STAGE_CALL_STATS")) != 0) demodulator.set_call_stats(true);
+            // STAGE_CHAIN_ONE=0: the completing chunk and the symbol's transform as two launches (t2gpu_demod_set_chain_one)
+            if (std::getenv("STAGE_CHAIN_ONE") && std::atoi(std::getenv("STAGE_CHAIN_ONE")) == 0) demodulator.set_chain_one(false);
             t2::llr_demapper qam;
             t2::ldpc_decoder ldpc;
             t2::bch_decoder bch;

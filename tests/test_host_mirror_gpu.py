@@ -221,6 +221,11 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
     assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
     log_dev = open(tmp_path / "log_dev.txt").read()
     assert [ln for ln in log_dev.splitlines() if ln.startswith("buf ")] == lines
+    # ... (that run had the chunk that completes a symbol and the symbol's transform in ONE launch, the default; here as two)
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_two.ts", buf, 0, tmp_path / "log_two.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_CHAIN_ONE": "0"})
+    assert np.fromfile(tmp_path / "out_two.ts", np.uint8).tobytes() == got
+    assert [ln for ln in open(tmp_path / "log_two.txt").read().splitlines() if ln.startswith("buf ")] == lines
     # ... and with every call's level / IQ estimates formed ahead of its chunks (t2gpu_demod_set_call_stats: the end of an execute() does
     # not wait for the chain; the estimates agree with the chunks' sums to the last bits of a double-precision sum, which the stream's
     # acquisition -- P1 thresholds from level_detect, the re-tunes -- and every byte of the transport stream bear out)
