@@ -50,7 +50,7 @@ for a, b in zip(p1[-4:-1], p1[-3:]):
     break
 
 # ---- one data symbol in the middle of the last whole frame: everything between two FFT launches
-fft = [r for r in k if "fft_fwd" in r[0] or "fft_stage_a" in r[0] or "fft_one_sync" in r[0]]   # a symbol's transform: its first (or only) launch
+fft = [r for r in k if "fft_fwd" in r[0] or "fft_stage_a" in r[0] or "fft_one_sync" in r[0] or "front_fft_one" in r[0]]   # a symbol's transform: its first (or only) launch
 if len(fft) > 200:
     # how the symbol-to-symbol interval is distributed over the last frames (the one symbol printed below is a quiet one: intervals stretch
     # while SIMD batches of the frame before are being decoded on the same device)
@@ -75,7 +75,7 @@ if len(p1) >= 3 and len(fft) > 130:
     a, b = p1[-3], p1[-2]
     fr = [r for r in fft if a[1] <= r[1] < b[1]]
     print("symbols of one frame (interval to the next symbol's FFT; kernels / copies other than the symbol chain's that START inside it):")
-    chain = ("fft_stage", "fft_fwd", "fft_one_sync", "sym_sync", "eq_split", "publish_symbol", "ti_scatter", "front_", "cp_correlate", "eq_sync")
+    chain = ("fft_stage", "fft_fwd", "fft_one_sync", "front_fft_one", "sym_sync", "eq_split", "publish_symbol", "ti_scatter", "front_", "cp_correlate", "eq_sync")
     for x, y in zip(fr[:-1], fr[1:]):
         ins = [r for r in k if x[1] <= r[1] < y[1] and r[0] and not any(c in r[0] for c in chain)]
         cps = [r for r in copies if x[1] <= r[1] < y[1]]
