@@ -652,9 +652,9 @@ int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
  * default: measured 3 % faster as long as the caller's thread also makes the equaliser's launches and emits the signals, DESIGN.md
  * section 6). Same cells, same TS either way. */
 int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on);
-/* With the loop on the device: the chunk that completes a 32K data symbol and the symbol's transform + synchronisation floats as ONE launch
+/* With the loop on the device: the chunk that completes a data symbol and the symbol's transform + synchronisation floats as ONE launch
  * (on = 1, the default: front_fft_one_kernel -- the front end's workgroups, then the eight of the transform, which wait for them) or as two
- * (0). Same cells, same floats, same TS. 16K symbols and symbols whose pilot tables do not fit the transform's exchange buffer take the two. */
+ * (0). Same cells, same floats, same TS. Symbols whose pilot tables do not fit the transform's exchange buffer (dense patterns) take the two. */
 int t2gpu_demod_set_chain_one(t2gpu_demod *h, int on);
 /* level_detect / c1 / c2 of an execute() from one pass over its buffer at its head (on = 1: t2gpu_front_call_begin -- the call's gain
  * decision and its return do not wait for its chunks, the next call's launches follow the last chunk's directly) or from the chunks'

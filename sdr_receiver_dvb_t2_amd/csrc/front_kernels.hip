@@ -918,11 +918,12 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
 
 __global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a) { front_one_body(a, (int)blockIdx.x, (int)gridDim.x); }
 
-// ---- a chunk's front end AND the transform + synchronisation floats of the 32K symbol it completes, in ONE launch (round 5): workgroups
-// 0 .. nb_front - 1 are front_one_kernel's, the eight behind them fft_one_sync_kernel<32>'s (ofdm_device.h) -- stage A's four wait until every
+// ---- a chunk's front end AND the transform + synchronisation floats of the 32K / 16K symbol it completes, in ONE launch (round 5): workgroups
+// 0 .. nb_front - 1 are front_one_kernel's, the eight behind them fft_one_sync_kernel<T2>'s (ofdm_device.h) -- stage A's four wait until every
 // front-end workgroup has counted itself done (its cells stored and released; a workgroup only ever waits for lower-numbered ones, which were
 // dispatched before it), the other four wait for stage A as before. The per-symbol critical path of the slot-shaped path is then one launch
 // and no launch gap; every value goes through the operations of the two launches in their order.
+template <int T2>
 __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gpu::FftOneArgs f, int nb_front)
 {
     __shared__ __attribute__((aligned(16))) float fft_lds[t2gpu::FFT_BC_LDS_FLOATS];
@@ -945,7 +946,10 @@ __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gp
         }
         __syncthreads();
     }
-    t2gpu::fft_one_sync_body<32>(f.in, f.scratch, f.out, f.twiddle, f.count, f.p, f.idx_symbol, f.buffered, f.guard, f.cp_out, f.sync, f.h_small, f.h_flag, f.seq,
+    // (a 16K transform's workgroups have 128 lanes: the upper two wavefronts of these leave here -- a workgroup's barriers count the
+    // wavefronts that have not ended)
+    if constexpr (T2 == 16) { if (threadIdx.x >= 128) return; }
+    t2gpu::fft_one_sync_body<T2>(f.in, f.scratch, f.out, f.twiddle, f.count, f.p, f.idx_symbol, f.buffered, f.guard, f.cp_out, f.sync, f.h_small, f.h_flag, f.seq,
                                  f.loop, fb, fft_lds);
 }
 
@@ -1177,7 +1181,8 @@ void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream)
 void launch_front_fft_one(FrontOneArgs &a, int grid, const t2gpu::FftOneArgs &f, hipStream_t stream)
 {
     load_taps();
-    hipLaunchKernelGGL(front_fft_one_kernel, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
+    if (f.fft_size == 32768) hipLaunchKernelGGL(front_fft_one_kernel<32>, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
+    else hipLaunchKernelGGL(front_fft_one_kernel<16>, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
 }
 
 void launch_front(const FrontParams &p, hipStream_t stream)

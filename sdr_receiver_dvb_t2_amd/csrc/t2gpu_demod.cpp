@@ -104,7 +104,7 @@ struct t2gpu_demod {
     // them one symbol behind (pend), recomputing the same floats for its own copies. Checked when the mode is left, once per frame.
     bool dev_loop = false;             // t2gpu_demod_set_device_loop
     bool call_stats = false;           // a call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats)
-    // the chunk that completes a 32K data symbol and the symbol's transform + floats as ONE launch (t2gpu_demod_set_chain_one): what the symbol's
+    // the chunk that completes a data symbol and the symbol's transform + floats as ONE launch (t2gpu_demod_set_chain_one): what the symbol's
     // launches need -- its buffer set (with the waits for the set's last users), its sequence word -- is then settled ahead of the chunk
     bool chain_one = true;
     struct { bool valid = false, have_cp = false; int k = 0; unsigned seq_a = 0; } prep;
@@ -941,7 +941,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             t2gpu::FftOneArgs fa;
             const t2gpu::FftOneArgs *fft = nullptr;
             const long need = (long)h->symbol_size - h->idx_buffer_sym;
-            if (h->chain_one && h->next_symbol_type == SYMBOL_TYPE_DATA && h->fft_size == 32768 && h->data_ofdm) {
+            if (h->chain_one && h->next_symbol_type == SYMBOL_TYPE_DATA && (h->fft_size == 32768 || h->fft_size == 16384) && h->data_ofdm) {
                 if (prepare_symbol(h) != 0) return -1;
                 const int rc = t2gpu_fft_one_args(h->p2_ofdm, h->data_ofdm, 0, h->idx_symbol, h->d_buffer_sym, h->guard_interval_size, h->prep.have_cp ? 1 : 0,
                                                   h->d_spec[h->prep.k], h->h_small + 8 * h->prep.k, h->h_flag, h->prep.seq_a, t2gpu_front_loop_dev(h->front), &fa);

@@ -489,7 +489,7 @@ long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_
     a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
     a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
     a.loop = h->d_loop; a.loop_runs = h->d_loop_runs;
-    if (fft && fused && n_out == need_out && fft->fft_size == 32768) { launch_front_fft_one(a, one_grid, *fft, stream); *fused = 1; }
+    if (fft && fused && n_out == need_out && (fft->fft_size == 32768 || fft->fft_size == 16384)) { launch_front_fft_one(a, one_grid, *fft, stream); *fused = 1; }
     else launch_front_one(a, one_grid, stream);
     T2_HIP(hipGetLastError());
     h->one_seq += 1;

@@ -550,7 +550,7 @@ int t2gpu_fft_one_args(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symb
     }
     if (idx_symbol < tables->m.n_p2 || idx_symbol >= tables->m.n_p2 + tables->rows) { set_error("t2gpu_fft_one_args: symbol index outside the frame's data symbols"); return -1; }
     const EqParams &p = tables->eq;
-    if (h->m.fft_size != 32768 || (p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_ONE_LDS_FLOATS * 4 || !h->d_fft_scratch || !h->d_fft_count) return 1;
+    if ((h->m.fft_size != 32768 && h->m.fft_size != 16384) || (p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_ONE_LDS_FLOATS * 4 || !h->d_fft_scratch || !h->d_fft_count) return 1;
     out->in = reinterpret_cast<const float2 *>(d_buffered) + guard;
     out->scratch = h->d_fft_scratch; out->out = reinterpret_cast<float2 *>(d_spectrum); out->twiddle = h->d_twiddle; out->count = h->d_fft_count;
     out->p = p; out->idx_symbol = idx_symbol; out->buffered = with_cp ? reinterpret_cast<const float2 *>(d_buffered) : nullptr; out->guard = guard;
