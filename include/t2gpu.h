@@ -656,6 +656,10 @@ int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on);
  * (on = 1, the default: front_fft_one_kernel -- the front end's workgroups, then the eight of the transform, which wait for them) or as two
  * (0). Same cells, same floats, same TS. Symbols whose pilot tables do not fit the transform's exchange buffer (dense patterns) take the two. */
 int t2gpu_demod_set_chain_one(t2gpu_demod *h, int on);
+/* Page-locked I/Q of an execute() (t2gpu_host_pin) comes over chunk by chunk (on = 1, the default): the call's first chunk's samples by a
+ * launch in front of it, every later chunk's inside the launch of the chunk before it -- instead of the whole buffer by one launch in front
+ * of the call's first chunk (0). The buffers must stay untouched until the call returns (they must anyway). Same samples, same TS. */
+int t2gpu_demod_set_copy_ahead(t2gpu_demod *h, int on);
 /* level_detect / c1 / c2 of an execute() from one pass over its buffer at its head (on = 1: t2gpu_front_call_begin -- the call's gain
  * decision and its return do not wait for its chunks, the next call's launches follow the last chunk's directly) or from the chunks'
  * own sums (0, the default: the end of every call waits for them). The same values to the last bits of a double-precision sum. Off by

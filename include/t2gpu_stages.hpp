@@ -860,6 +860,7 @@ public:
     // a call's level / IQ estimates from one pass at its head (default) or from its chunks' sums (t2gpu_demod_set_call_stats)
     // the chunk that completes a 32K data symbol and the symbol's transform as one launch (default) or two (t2gpu_demod_set_chain_one)
     void set_chain_one(bool on) { if (t2gpu_demod_set_chain_one(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_chain_one"); }
+    void set_copy_ahead(bool on) { if (t2gpu_demod_set_copy_ahead(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_copy_ahead"); }
     void set_call_stats(bool on) { if (t2gpu_demod_set_call_stats(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_call_stats"); }
     t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
 private:

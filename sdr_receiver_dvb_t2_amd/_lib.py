@@ -94,6 +94,7 @@ PROTOTYPES = {
     "t2gpu_demod_execute": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
     "t2gpu_demod_set_chain_one": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_demod_set_copy_ahead": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_set_call_stats": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_set_device_loop": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),

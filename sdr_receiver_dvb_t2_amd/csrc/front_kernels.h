@@ -91,8 +91,13 @@ struct FrontOneArgs {
     int *error;                                // set when a look-back wait gave up (t2gpu_front_state reports it)
     T2DevLoop *loop;                           // non-null: the NCO runs of this (one-chunk) call are planned by workgroup 0 from the device's
     FrontRun *loop_runs;                       // loop state into loop_runs[T2_LOOP_RUNS_CAP] and the accumulators are left advanced there
+    // cp_wgs > 0: that many extra workgroups at the END of the grid bring cp_n int16 elements of I and of Q over from page-locked host memory
+    // (device-visible addresses cp_si / cp_sq) to cp_di / cp_dq -- the samples of the call's NEXT chunk, beside this chunk's work
+    const int16_t *cp_si, *cp_sq; int16_t *cp_di, *cp_dq; long cp_n; int cp_wgs;
     FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs (none with `loop`), then Farrow runs
 };
+// the I/Q a launch of the one-launch form brings over for the chunk behind it (t2gpu_front_loop_fft)
+struct FrontCopyAhead { const int16_t *si, *sq; int16_t *di, *dq; long n; };
 int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_runs, size_t n_far_runs);
 void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream);
 // ... and with the transform + synchronisation floats of the 32K symbol the chunk completes in the same launch (front_fft_one_kernel)
@@ -101,8 +106,9 @@ void launch_front_fft_one(FrontOneArgs &a, int grid, const t2gpu::FftOneArgs &f,
 // (internal, C++ linkage: t2gpu_demod.cpp) t2gpu_front_execute_loop_dev; when `fft` is given and the chunk gives exactly need_out cells, the
 // launch also runs *fft (the symbol those cells complete) and *fused is set to 1
 struct t2gpu_front;
+// ahead (may be null): I/Q the launch brings over from page-locked memory beside its own work
 long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out, long out_cap_cells,
-                          void *stream, long need_out, const t2gpu::FftOneArgs *fft, int *fused);
+                          void *stream, long need_out, const t2gpu::FftOneArgs *fft, int *fused, const FrontCopyAhead *ahead = nullptr);
 
 // Guard-interval correlation of symbol_acquisition (dvbt2_demodulator.cpp:321-327): one workgroup per buffered symbol.
 // sym: n_symbols x symbol_size cells (guard first); out[s] = (sum.re, sum.im, frequency_est, 0).

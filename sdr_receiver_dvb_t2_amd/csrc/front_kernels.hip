@@ -916,7 +916,19 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
     }
 }
 
-__global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a) { front_one_body(a, (int)blockIdx.x, (int)gridDim.x); }
+__device__ __forceinline__ void front_copy_body(const int16_t *__restrict__ hi, const int16_t *__restrict__ hq, int16_t *__restrict__ di,
+                                                int16_t *__restrict__ dq, size_t n, const size_t t, const size_t stride);
+// (the workgroups behind the chunk's own bring the next chunk's I/Q over: FrontOneArgs::cp_*)
+__device__ __forceinline__ void front_copy_ahead(const FrontOneArgs &a, int wg)
+{
+    front_copy_body(a.cp_si, a.cp_sq, a.cp_di, a.cp_dq, (size_t)a.cp_n, (size_t)wg * 256 + threadIdx.x, (size_t)a.cp_wgs * 256);
+}
+__global__ __launch_bounds__(256) void front_one_kernel(FrontOneArgs a)
+{
+    const int nb = (int)gridDim.x - a.cp_wgs, b = (int)blockIdx.x;
+    if (b >= nb) { front_copy_ahead(a, b - nb); return; }
+    front_one_body(a, b, nb);
+}
 
 // ---- a chunk's front end AND the transform + synchronisation floats of the 32K / 16K symbol it completes, in ONE launch (round 5): workgroups
 // 0 .. nb_front - 1 are front_one_kernel's, the eight behind them fft_one_sync_kernel<T2>'s (ofdm_device.h) -- stage A's four wait until every
@@ -929,6 +941,7 @@ __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gp
     __shared__ __attribute__((aligned(16))) float fft_lds[t2gpu::FFT_BC_LDS_FLOATS];
     const int b = (int)blockIdx.x;
     if (b < nb_front) { front_one_body(a, b, nb_front); return; }
+    if (b >= nb_front + 8) { front_copy_ahead(a, b - nb_front - 8); return; }
     const int fb = b - nb_front;
     if (fb < 4) {
         if (threadIdx.x == 0) {
@@ -956,10 +969,16 @@ __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gp
 // ---- a buffer of int16 I and Q from PAGE-LOCKED host memory into the device's staging by a kernel of the caller's stream (the
 // slot-shaped path: two copy-engine transfers per execute() cost 12 us each and, worse, ~20 + 9 + 30 us of hand-over between the stream's
 // kernels and the copy engine on either side of them -- 85 us per 172 032-sample buffer, a whole OFDM symbol's worth)
+__device__ __forceinline__ void front_copy_body(const int16_t *__restrict__ hi, const int16_t *__restrict__ hq, int16_t *__restrict__ di,
+                                                int16_t *__restrict__ dq, size_t n, const size_t t, const size_t stride);
 __global__ __launch_bounds__(256) void front_copy_in_kernel(const int16_t *__restrict__ hi, const int16_t *__restrict__ hq, int16_t *__restrict__ di,
                                                             int16_t *__restrict__ dq, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    front_copy_body(hi, hq, di, dq, n, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+__device__ __forceinline__ void front_copy_body(const int16_t *__restrict__ hi, const int16_t *__restrict__ hq, int16_t *__restrict__ di,
+                                                int16_t *__restrict__ dq, size_t n, const size_t t, const size_t stride)
+{
     if (((((uintptr_t)hi | (uintptr_t)hq | (uintptr_t)di | (uintptr_t)dq) & 15) == 0)) {
         const size_t n8 = n / 8;
         const uint4 *a = reinterpret_cast<const uint4 *>(hi), *b = reinterpret_cast<const uint4 *>(hq);
@@ -1175,14 +1194,14 @@ int front_one_grid(const FrontParams &p, const FrontRun *far_runs, size_t n_nco_
 void launch_front_one(FrontOneArgs &a, int grid, hipStream_t stream)
 {
     load_taps();
-    hipLaunchKernelGGL(front_one_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(front_one_kernel, dim3((unsigned)(grid + a.cp_wgs)), dim3(256), 0, stream, a);
 }
 
 void launch_front_fft_one(FrontOneArgs &a, int grid, const t2gpu::FftOneArgs &f, hipStream_t stream)
 {
     load_taps();
-    if (f.fft_size == 32768) hipLaunchKernelGGL(front_fft_one_kernel<32>, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
-    else hipLaunchKernelGGL(front_fft_one_kernel<16>, dim3((unsigned)grid + 8u), dim3(256), 0, stream, a, f, grid);
+    if (f.fft_size == 32768) hipLaunchKernelGGL(front_fft_one_kernel<32>, dim3((unsigned)(grid + 8 + a.cp_wgs)), dim3(256), 0, stream, a, f, grid);
+    else hipLaunchKernelGGL(front_fft_one_kernel<16>, dim3((unsigned)(grid + 8 + a.cp_wgs)), dim3(256), 0, stream, a, f, grid);
 }
 
 void launch_front(const FrontParams &p, hipStream_t stream)

@@ -12,6 +12,7 @@
 #include "ofdm_kernels.h"
 #include "front_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -107,6 +108,7 @@ struct t2gpu_demod {
     // the chunk that completes a data symbol and the symbol's transform + floats as ONE launch (t2gpu_demod_set_chain_one): what the symbol's
     // launches need -- its buffer set (with the waits for the set's last users), its sequence word -- is then settled ahead of the chunk
     bool chain_one = true;
+    bool copy_ahead = true;            // page-locked I/Q comes over chunk by chunk, a chunk's samples inside the launch of the chunk before (t2gpu_demod_set_copy_ahead)
     struct { bool valid = false, have_cp = false; int k = 0; unsigned seq_a = 0; } prep;
     bool fft_fused = false;            // the chunk just launched took the symbol's transform with it
     long fused_symbols = 0;
@@ -838,6 +840,16 @@ extern "C" int t2gpu_demod_set_chain_one(t2gpu_demod *h, int on)
     return 0;
 }
 
+// on = 1 (default): page-locked I/Q of an execute() comes over chunk by chunk -- the first chunk's samples by a launch in front of it, every
+// later chunk's inside the launch of the chunk before it (extra workgroups of front_one_kernel / front_fft_one_kernel) -- instead of the whole
+// buffer by one launch in front of the call's first chunk; 0: the whole buffer at once. Same samples either way.
+extern "C" int t2gpu_demod_set_copy_ahead(t2gpu_demod *h, int on)
+{
+    if (!h) { set_error("t2gpu_demod_set_copy_ahead: bad arguments"); return -1; }
+    h->copy_ahead = on != 0;
+    return 0;
+}
+
 // on = 1: level_detect / c1 / c2 of an execute() are formed by one pass over its buffer at its head (t2gpu_front_call_begin) and the call's end
 // does not wait for its chunks; 0 (default): from the chunks' own sums, the end of the call waits for them. Measured on the slot-shaped path
 // (tools/ab_dropin_args.sh "--call-stats 1" "--call-stats 0", same box): 309 against 318 Msamples/s -- the chain on the device is what
@@ -876,6 +888,17 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         T2_HIP(hipMalloc(&h->d_q, el * 2));
         h->in_cap = el;
     }
+    const int16_t *src_i = nullptr, *src_q = nullptr;          // page-locked I/Q coming over chunk by chunk (copy_ahead)
+    size_t copied = 0;                                         // ... elements of each that are on the device or on their way
+    // [copied, upto) by a launch of its own (the call's first chunk; a chunk larger than the one before it had announced)
+    auto ensure_copied = [&](size_t upto) -> int {
+        if (!src_i || upto <= copied) return 0;
+        const size_t from = copied & ~size_t(7);              // (16-byte steps; the few elements copied twice are the same)
+        launch_front_copy_in(src_i + from, src_q + from, h->d_i + from, h->d_q + from, upto - from, h->stream);
+        T2_HIP(hipGetLastError());
+        copied = upto;
+        return 0;
+    };
     h->prof.start();
     // in stream order ahead of the kernels that read them; the caller's buffers are free when this call returns (it ends with
     // t2gpu_front_state, which waits for everything launched here). From page-locked buffers (t2gpu_host_pin) the copies do not block.
@@ -884,8 +907,14 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         // page-locked buffers (t2gpu_host_pin) come over by a kernel of the chain's own stream; anything else through the copy engine
         void *vi = nullptr, *vq = nullptr;
         if (hipHostGetDevicePointer(&vi, const_cast<int16_t *>(i_in), 0) == hipSuccess && hipHostGetDevicePointer(&vq, const_cast<int16_t *>(q_in), 0) == hipSuccess) {
-            launch_front_copy_in(static_cast<const int16_t *>(vi), static_cast<const int16_t *>(vq), h->d_i, h->d_q, el, h->stream);
-            T2_HIP(hipGetLastError());
+            if (h->copy_ahead && !h->call_stats) {
+                // (t2gpu_demod_set_copy_ahead) nothing comes over here: a chunk's samples are brought over by the launch of the chunk before it, the
+                // call's first chunk's by a launch of their own in front of it (ensure_copied)
+                src_i = static_cast<const int16_t *>(vi); src_q = static_cast<const int16_t *>(vq);
+            } else {
+                launch_front_copy_in(static_cast<const int16_t *>(vi), static_cast<const int16_t *>(vq), h->d_i, h->d_q, el, h->stream);
+                T2_HIP(hipGetLastError());
+            }
         } else {
             (void)hipGetLastError();
             T2_HIP(hipMemcpyAsync(h->d_i, i_in, el * 2, hipMemcpyHostToDevice, h->stream));
@@ -936,6 +965,13 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             cap = SYM_BUF_CELLS - h->idx_buffer_sym;
         }
         long n_out = -2;
+        if (ensure_copied(((size_t)idx_in + (size_t)chunk) * h->stride) != 0) return -1;
+        FrontCopyAhead ahead{nullptr, nullptr, nullptr, nullptr, 0};
+        if (src_i && copied < el) {
+            // the chunk behind this one is about as long: its samples (and a margin) come over inside this chunk's launch
+            const size_t from = copied & ~size_t(7), upto = std::min(el, copied + ((size_t)chunk + 4096) * h->stride);
+            ahead = FrontCopyAhead{src_i + from, src_q + from, h->d_i + from, h->d_q + from, (long)(upto - from)};
+        }
         if (h->dev_mode) {
             // the chunk that completes a 32K data symbol takes the symbol's transform and floats with it (one launch; t2gpu_demod_set_chain_one)
             t2gpu::FftOneArgs fa;
@@ -950,8 +986,9 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             }
             int fused = 0;
             n_out = t2gpu_front_loop_fft(h->front, chunk, arbitrary_resample, h->d_i + (size_t)idx_in * h->stride, h->d_q + (size_t)idx_in * h->stride,
-                                         dst, cap, h->stream, need, fft, &fused);
+                                         dst, cap, h->stream, need, fft, &fused, ahead.n > 0 ? &ahead : nullptr);
             h->fft_fused = fused != 0;
+            if (n_out >= 0 && ahead.n > 0) copied = std::min(el, copied + ((size_t)chunk + 4096) * h->stride);
             if (n_out == -1) return -1;
             if (n_out == -2) { if (leave_dev_mode(h) != 0) return -1; }             // (a chunk the one-launch form does not take: this symbol goes on with the loops on the host)
             else if (!h->pend.valid && follow_chunks(h) != 0) return -1;            // nothing out: the device ran on the values the host holds

@@ -415,6 +415,7 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
         a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
         a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
         a.loop = nullptr; a.loop_runs = nullptr;
+        a.cp_si = a.cp_sq = nullptr; a.cp_di = a.cp_dq = nullptr; a.cp_n = 0; a.cp_wgs = 0;
         launch_front_one(a, one_grid, stream);
         // the device's words move only if the launch was accepted: the host's copies follow it, not the attempt
         T2_HIP(hipGetLastError());
@@ -456,11 +457,11 @@ extern "C" int t2gpu_front_loop_begin(t2gpu_front *h, const float *state10, void
 extern "C" long t2gpu_front_execute_loop_dev(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out,
                                              long out_cap_cells, void *stream_)
 {
-    return t2gpu_front_loop_fft(h, chunk, rs, d_i, d_q, d_out, out_cap_cells, stream_, -1, nullptr, nullptr);
+    return t2gpu_front_loop_fft(h, chunk, rs, d_i, d_q, d_out, out_cap_cells, stream_, -1, nullptr, nullptr, nullptr);
 }
 
 long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_t *d_i, const int16_t *d_q, float *d_out, long out_cap_cells,
-                          void *stream_, long need_out, const t2gpu::FftOneArgs *fft, int *fused)
+                          void *stream_, long need_out, const t2gpu::FftOneArgs *fft, int *fused, const FrontCopyAhead *ahead)
 {
     if (fused) *fused = 0;
     if (!h || chunk < 1 || !d_i || !d_q || !d_out) { set_error("t2gpu_front_execute_loop_dev: bad arguments"); return -1; }
@@ -489,6 +490,12 @@ long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_
     a.pre_out = reinterpret_cast<float2 *>(h->d_one + 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID);
     a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
     a.loop = h->d_loop; a.loop_runs = h->d_loop_runs;
+    a.cp_si = a.cp_sq = nullptr; a.cp_di = a.cp_dq = nullptr; a.cp_n = 0; a.cp_wgs = 0;
+    if (ahead && ahead->n > 0) {                                  // the next chunk's I/Q comes over beside this chunk's work: 8 KB per workgroup and pass
+        a.cp_si = ahead->si; a.cp_sq = ahead->sq; a.cp_di = ahead->di; a.cp_dq = ahead->dq; a.cp_n = ahead->n;
+        a.cp_wgs = (int)std::min<long>(16, (ahead->n / 8 + 255) / 256);
+        if (a.cp_wgs < 1) a.cp_wgs = 1;
+    }
     if (fft && fused && n_out == need_out && (fft->fft_size == 32768 || fft->fft_size == 16384)) { launch_front_fft_one(a, one_grid, *fft, stream); *fused = 1; }
     else launch_front_one(a, one_grid, stream);
     T2_HIP(hipGetLastError());

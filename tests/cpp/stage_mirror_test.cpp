@@ -164,6 +164,10 @@ int main(int argc, char **argv)
             if (std::getenv("STAGE_CALL_STATS") && std::atoi(std::getenv("STAGE_CALL_STATS")) != 0) demodulator.set_call_stats(true);
             // STAGE_CHAIN_ONE=0: the completing chunk and the symbol's transform as two launches (t2gpu_demod_set_chain_one)
             if (std::getenv("STAGE_CHAIN_ONE") && std::atoi(std::getenv("STAGE_CHAIN_ONE")) == 0) demodulator.set_chain_one(false);
+            // STAGE_PIN=1: the I/Q buffers page-locked (t2gpu_host_pin) -- they then come over chunk by chunk inside the chunks' launches
+            // (t2gpu_demod_set_copy_ahead; STAGE_COPY_AHEAD=0: the whole buffer by one launch at the head of each call)
+            if (std::getenv("STAGE_PIN") && std::atoi(std::getenv("STAGE_PIN")) != 0) { t2gpu_host_pin(vi.data(), vi.size() * 2); t2gpu_host_pin(vq.data(), vq.size() * 2); }
+            if (std::getenv("STAGE_COPY_AHEAD") && std::atoi(std::getenv("STAGE_COPY_AHEAD")) == 0) demodulator.set_copy_ahead(false);
             t2::llr_demapper qam;
             t2::ldpc_decoder ldpc;
             t2::bch_decoder bch;

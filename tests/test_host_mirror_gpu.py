@@ -226,6 +226,13 @@ def test_demodulator_class_acquires_and_decodes(driver, tmp_path):
         env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_CHAIN_ONE": "0"})
     assert np.fromfile(tmp_path / "out_two.ts", np.uint8).tobytes() == got
     assert [ln for ln in open(tmp_path / "log_two.txt").read().splitlines() if ln.startswith("buf ")] == lines
+    # ... with page-locked I/Q buffers, which come over chunk by chunk inside the chunks' launches (t2gpu_demod_set_copy_ahead), and as one
+    # copy per call
+    for ahead in ("1", "0"):
+        run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_pin.ts", buf, 0, tmp_path / "log_pin.txt",
+            env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_PIN": "1", "STAGE_COPY_AHEAD": ahead})
+        assert np.fromfile(tmp_path / "out_pin.ts", np.uint8).tobytes() == got, ahead
+        assert [ln for ln in open(tmp_path / "log_pin.txt").read().splitlines() if ln.startswith("buf ")] == lines, ahead
     # ... and with every call's level / IQ estimates formed ahead of its chunks (t2gpu_demod_set_call_stats: the end of an execute() does
     # not wait for the chain; the estimates agree with the chunks' sums to the last bits of a double-precision sum, which the stream's
     # acquisition -- P1 thresholds from level_detect, the re-tunes -- and every byte of the transport stream bear out)
@@ -257,6 +264,10 @@ def test_demodulator_class_resets_and_recovers(driver, tmp_path):
     run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_dev.ts", buf, 0, tmp_path / "log_dev.txt",
         env_extra={"STAGE_DEVICE_LOOP": "1"})
     assert np.fromfile(tmp_path / "out_dev.ts", np.uint8).tobytes() == got
+    # ... page-locked I/Q coming over chunk by chunk, a reset in the middle of it
+    run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_pin.ts", buf, 0, tmp_path / "log_pin.txt",
+        env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_PIN": "1"})
+    assert np.fromfile(tmp_path / "out_pin.ts", np.uint8).tobytes() == got
     # ... and with the calls' statistics ahead of their chunks: the reset cancels the look-ahead of the call it falls into
     run(driver, "rx", tmp_path / "i.s16", tmp_path / "q.s16", tmp_path / "out_cs.ts", buf, 0, tmp_path / "log_cs.txt",
         env_extra={"STAGE_DEVICE_LOOP": "1", "STAGE_CALL_STATS": "1"})
