@@ -74,6 +74,9 @@ int front_call_stats_grid(int n);              // 0: the call is too long for th
 void launch_front_call_stats(const FrontCallStatsArgs &a, int grid, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
+// the device's loop state set / read by launches (no copy engine): h_out / h_flag page-locked, *h_flag = seq behind the state
+void launch_front_loop_set(T2DevLoop *d, const T2DevLoop &v, hipStream_t stream);
+void launch_front_loop_get(const T2DevLoop *d, T2DevLoop *h_out, unsigned *h_flag, unsigned seq, hipStream_t stream);
 // n int16 elements of I and of Q from page-locked host memory (device-visible addresses hi / hq) to di / dq, by a kernel
 void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int16_t *dq, size_t n, hipStream_t stream);
 

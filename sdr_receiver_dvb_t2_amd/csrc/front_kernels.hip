@@ -1137,9 +1137,25 @@ __global__ __launch_bounds__(256) void cp_correlate_kernel(const float2 *sym, lo
     if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
+// ---- the loop state up and down by launches of the chain's own stream (a 64-byte copy through the copy engine stands in its queue behind
+// whatever else is there -- the 13 MB of a TI block coming down: 250 us per T2 frame -- and costs a hand-over on either side in the stream)
+__global__ void front_loop_set_kernel(T2DevLoop *d, T2DevLoop v) { *d = v; }
+__global__ void front_loop_get_kernel(const T2DevLoop *d, T2DevLoop *h_out, unsigned *h_flag, unsigned seq)
+{
+    *h_out = *d;
+    __threadfence_system();
+    __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 bool g_taps_loaded[16] = {};
 
 }  // namespace
+
+void launch_front_loop_set(T2DevLoop *d, const T2DevLoop &v, hipStream_t stream) { hipLaunchKernelGGL(front_loop_set_kernel, dim3(1), dim3(1), 0, stream, d, v); }
+void launch_front_loop_get(const T2DevLoop *d, T2DevLoop *h_out, unsigned *h_flag, unsigned seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(front_loop_get_kernel, dim3(1), dim3(1), 0, stream, d, h_out, h_flag, seq);
+}
 
 void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int16_t *dq, size_t n, hipStream_t stream)
 {

@@ -51,7 +51,8 @@ struct t2gpu_front {
     bool chain_on = true;
     // the tracking loops on the device (loop_device.h; t2gpu_front_loop_*): state, the NCO runs workgroup 0 plans, a page-locked staging
     // slot for the state going up, and the chunks launched in that mode whose NCO the host has not followed yet
-    T2DevLoop *d_loop = nullptr, *h_loop = nullptr;
+    T2DevLoop *d_loop = nullptr, *h_loop = nullptr, *h_loop_out = nullptr;
+    unsigned *h_loop_flag = nullptr, loop_read_seq = 0;
     FrontRun *d_loop_runs = nullptr;
     std::vector<int32_t> loop_pending;
     // the state a commit leaves, stored to page-locked memory by the commit's own launch (t2gpu_front_state then reads it there)
@@ -224,6 +225,7 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     hipDeviceSynchronize();
     hipFree(h->d_one); hipFree(h->d_chain_error); hipFree(h->d_loop); hipFree(h->d_loop_runs);
     if (h->h_loop) hipHostFree(h->h_loop);
+    if (h->h_loop_out) hipHostFree(h->h_loop_out);
     if (h->h_state) hipHostFree(h->h_state);
     if (h->h_call) hipHostFree(h->h_call);
     hipFree(h->d_call); hipFree(h->d_call_work);
@@ -441,13 +443,12 @@ extern "C" int t2gpu_front_loop_begin(t2gpu_front *h, const float *state10, void
     if (!h || !state10) { set_error("t2gpu_front_loop_begin: bad arguments"); return -1; }
     if (!h->loop_pending.empty()) { set_error("t2gpu_front_loop_begin: chunks of the mode before are still to be followed"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    T2_HIP(hipStreamSynchronize((hipStream_t)stream));         // (the staging slot of the begin before; once per T2 frame)
-    T2DevLoop &l = *h->h_loop;
-    l = T2DevLoop{};
+    T2DevLoop l{};                                             // (travels in the launch's arguments: nothing to stage, nothing to wait for)
     l.phase_nco = h->phase_nco; l.frequency_nco = h->frequency_nco;
     l.pe = state10[0]; l.frequency_est_filtered = state10[1]; l.tuner = state10[2]; l.fe = state10[1] + state10[2];
     l.f_kp = state10[3]; l.f_ki = state10[4]; l.f_int = state10[5]; l.p_kp = state10[6]; l.p_ki = state10[7]; l.p_int = state10[8];
-    T2_HIP(hipMemcpyAsync(h->d_loop, h->h_loop, sizeof(T2DevLoop), hipMemcpyHostToDevice, (hipStream_t)stream));
+    launch_front_loop_set(h->d_loop, l, (hipStream_t)stream);
+    T2_HIP(hipGetLastError());
     return 0;
 }
 
@@ -534,9 +535,29 @@ extern "C" int t2gpu_front_loop_read(t2gpu_front *h, float *out8, void *stream)
 {
     if (!h || !out8) { set_error("t2gpu_front_loop_read: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
-    T2_HIP(hipStreamSynchronize((hipStream_t)stream));
-    T2DevLoop l;
-    T2_HIP(hipMemcpy(&l, h->d_loop, sizeof l, hipMemcpyDeviceToHost));
+    // by a launch of `stream` into page-locked memory, the sequence word behind it (a blocking 64-byte copy stood in the copy engine's queue
+    // behind the TI block coming down: ~250 us per T2 frame on the slot-shaped path)
+    if (!h->h_loop_out) {
+        T2_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->h_loop_out), sizeof(T2DevLoop) + 64, hipHostMallocCoherent));
+        h->h_loop_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_loop_out) + sizeof(T2DevLoop));
+        *h->h_loop_flag = 0;
+    }
+    const unsigned seq = ++h->loop_read_seq;
+    launch_front_loop_get(h->d_loop, h->h_loop_out, h->h_loop_flag, seq, (hipStream_t)stream);
+    T2_HIP(hipGetLastError());
+    {
+        volatile unsigned *flag = h->h_loop_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; *flag != seq; ++spins) {
+            t2_cpu_relax();
+            if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                T2_HIP(hipStreamSynchronize((hipStream_t)stream));                 // a failed launch shows here
+                if (*flag != seq) { set_error("t2gpu_front_loop_read: the loop state did not arrive"); return -1; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const T2DevLoop l = *h->h_loop_out;
     out8[0] = l.phase_nco; out8[1] = l.frequency_nco; out8[2] = l.pe; out8[3] = l.fe; out8[4] = l.frequency_est_filtered; out8[5] = l.f_int;
     out8[6] = l.p_int; out8[7] = (float)l.error;
     return 0;
