@@ -10,7 +10,7 @@
 //           reference's constructors wire them (include/t2gpu_stages.hpp), every stage a call into libt2gpu.so.
 //
 // build:  g++ -O2 -std=c++17 -I../include t2gpu_rx_file.cpp -L../sdr_receiver_dvb_t2_amd -lt2gpu -Wl,-rpath,$PWD/../sdr_receiver_dvb_t2_amd -o t2gpu_rx_file
-// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1] [--saturate 0] [--threads 1] [--device-loop 1] [--fft-one-launch 1] [--call-stats 0] [--ldpc-in-flight 8] [--ldpc-merge 1] [--chain-one 1] [--copy-ahead 1]
+// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1] [--saturate 0] [--threads 1] [--device-loop 1] [--fft-one-launch 1] [--ldpc-in-flight 8] [--ldpc-merge 1] [--chain-one 1] [--copy-ahead 1]
 //         --buf: samples per execute() call (the reference's SDRplay thread hands over norm_blocks x 384 = 172 032, rx_sdrplay.h:64)
 //         --warm n: the first n buffers (acquisition: P1, guard search, L1) run before the clock starts; --json 1: one JSON line on
 //         stdout with the throughput of the timed buffers (bench.py's drop_in leg reads it); --saturate 1: LLRs clamped to int8
@@ -49,7 +49,7 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *out_path = nullptr;
-    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0, saturate = 0, threads = 1, device_loop = 1, fft_one = 1, call_stats = 0, in_flight = 8, ldpc_merge = 1, chain_one = 1, copy_ahead = 1;
+    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0, saturate = 0, threads = 1, device_loop = 1, fft_one = 1, in_flight = 8, ldpc_merge = 1, chain_one = 1, copy_ahead = 1;
     for (int a = 3; a + 1 < argc; a += 2) {
         if (!std::strcmp(argv[a], "--out")) out_path = argv[a + 1];
         else if (!std::strcmp(argv[a], "--udp")) udp_port = std::atoi(argv[a + 1]);
@@ -62,7 +62,6 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[a], "--threads")) threads = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--device-loop")) device_loop = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--fft-one-launch")) fft_one = std::atoi(argv[a + 1]);
-        else if (!std::strcmp(argv[a], "--call-stats")) call_stats = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--ldpc-in-flight")) in_flight = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--ldpc-merge")) ldpc_merge = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--chain-one")) chain_one = std::atoi(argv[a + 1]);
@@ -88,7 +87,6 @@ int main(int argc, char **argv)
         demodulator.set_device_loop(device_loop != 0);
         demodulator.set_chain_one(chain_one != 0);                        // (A/B: the completing chunk and the symbol's transform as one launch or two)
         demodulator.set_copy_ahead(copy_ahead != 0);                      // (A/B: the I/Q chunk by chunk inside the chunks' launches, or the whole buffer at the head of a call)
-        demodulator.set_call_stats(call_stats != 0);                      // (A/B: a call's level estimate ahead of its chunks, or from them)
         t2gpu_fft_set_one_launch(fft_one);                                // (A/B: a symbol's transform as one launch or two)
         t2::llr_demapper qam(device);
         qam.saturate_llr = saturate != 0;
@@ -144,6 +142,7 @@ int main(int argc, char **argv)
         long frames0 = 0, bb0 = 0, ts0 = 0, n_buf = 0;
         for (; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len, ++n_buf) {
             if (n_buf == warm) {                                          // acquisition is behind us: the clock starts here
+                demodulator.flush();
                 demodulator.deinterleaver->flush();
                 ldpc.flush();
                 const t2gpu_demod_info w = demodulator.status();
@@ -157,6 +156,7 @@ int main(int argc, char **argv)
             set_gain();
             demodulator.execute(buf_len, const_cast<int16_t *>(vi.data()) + pos, const_cast<int16_t *>(vq.data()) + pos, &signal);
         }
+        demodulator.flush();                                              // the last symbols' cells reach the de-interleaver before it is flushed
         demodulator.deinterleaver->flush();
         ldpc.flush();                                                     // batches still in the decoder come out (and through BCH / de-framer) inside the clock
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -474,17 +474,6 @@ long t2gpu_front_execute(t2gpu_front *h, int n_chunks, const int32_t *chunk_len,
                          const int16_t *q_in, float *out, long out_cap_cells, int32_t *chunk_out_len);
 /* synchronises; out8 = {dc_real, dc_imag, c1, c2, phase_nco, frequency_nco, level_detect, farrow position x1} */
 int t2gpu_front_state(t2gpu_front *h, float *out8);
-/* The sign statistics of an execute() AHEAD of its chunks (held-IQ mode). c1 / c2 / level_detect of a call (dvbt2_demodulator.cpp:227-235)
- * depend on its samples and the dc averagers only, not on anything the symbols decide: t2gpu_front_call_begin launches one pass over the
- * call's n samples of device I/Q (d_i / d_q: the buffer the chunks will be cut from, the front end's stride) with its own copy of the
- * averagers, t2gpu_front_call_level hands out what it formed (out3 = c1, c2, level_detect; waits for that launch only -- the gain decision
- * at the end of an execute() then does not wait for the chunks), and the call's t2gpu_front_commit_iq leaves those values. call_begin
- * returns 1 when the look-ahead is on its way, 0 when this call goes without (longer than 1 048 576 samples, the first call, a call
- * behind a reset: t2gpu_front_commit_iq then derives the values from the chunks' sums as before and carries the averagers over), -1 on
- * an error. A t2gpu_front_reset_loops between call_begin and the commit cancels the look-ahead (call_level then returns 1). The two routes agree to the last bits of
- * the double-precision sums (the recurrence is composed per 4096 samples from the call's start instead of per chunk). */
-int t2gpu_front_call_begin(t2gpu_front *h, const int16_t *d_i, const int16_t *d_q, int n, void *stream);
-int t2gpu_front_call_level(t2gpu_front *h, float *out3);
 /* the same eight as the LAST t2gpu_front_commit_iq left them, whatever has been launched on the handle since (waits for that commit's launch only) */
 int t2gpu_front_committed_state(t2gpu_front *h, float *out8);
 /* ---- the loop on the device. The reference hands a symbol's two synchronisation floats and its guard correlation to the tracking filters
@@ -609,7 +598,7 @@ int t2gpu_p1_debug(t2gpu_p1 *h, float *corr, int n_corr, float *p1_fft1024);
  * Signals of the class (dvbt2_demodulator.h:70-75) are C callbacks; cell pointers are host memory valid during the call:
  *   start            time_deinterleaver::start(dvbt2, l1_pre, l1_post) -- the direct call at :386
  *   l1_dyn_execute   emit l1_dyn_execute(l1_post, c_p2, cells)          :391
- *   data             emit data(c_data | n_fc, cells)                    :346,361
+ *   data             emit data(c_data | n_fc, cells)                    :346,361  (from the handle's own thread while the loop is on the device, below)
  *   amount_plp       emit amount_plp(num_plp)                           :388
  *   replace_null_indicator(sample_rate_offset_hz, frequency_offset_hz)  :444
  * t2gpu_demod_execute returns 0, or -1 when a stage failed (t2gpu_last_error; e.g. P1 announces an FFT size outside 16K / 32K).
@@ -640,6 +629,7 @@ typedef struct {
     int64_t symbols, frames, resets; /* OFDM symbols demodulated, T2 frames completed, reset() calls */
     float level_detect;
     double phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered, arbitrary_resample;
+    int64_t loop_resyncs;            /* the host's copies of the loops re-set from the device's state (0 by construction; T2GPU_DEMOD_STRICT_LOOPS=1: an error instead) */
 } t2gpu_demod_info;
 typedef struct t2gpu_demod t2gpu_demod;
 t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int device);
@@ -647,25 +637,38 @@ void t2gpu_demod_destroy(t2gpu_demod *h);
 int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *signals);
 int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const int16_t *q_in, t2gpu_signal_estimate *signal_);
 int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
-/* The tracking loops of a frame's data symbols on the device (on = 1: a symbol's launches are followed by the next chunk's without waiting
- * for its results, the host reads them one symbol behind -- "the loop on the device" above) or on the host for every symbol (0, the
- * default: measured 3 % faster as long as the caller's thread also makes the equaliser's launches and emits the signals, DESIGN.md
- * section 6). Same cells, same TS either way. */
+/* The tracking loops of a frame's data symbols on the device (on = 1, the DEFAULT: a symbol's launches are followed by the next chunk's
+ * without waiting for its results, the host reads them one symbol behind, and a thread of the handle's own makes the equaliser's launches
+ * and emits the `data` signal -- "the loop on the device" above; DESIGN.md section 6: the base of 270 -> 478 Msamples/s on the slot-shaped
+ * path) or on the host for every symbol (0: one round trip per symbol, every signal on the caller's thread). Same cells, same loop
+ * values, same TS either way (tests/test_ref_pins_gpu.py holds both to the reference's own trajectory).
+ * THREADS: with the loop on the device the `data` callback is called from the handle's own thread, concurrently with the caller's
+ * thread (which calls `start`, `l1_dyn_execute`, `amount_plp`, `replace_null_indicator` and the frame-closing symbol's `data`); the
+ * order of the calls is the reference's (a P2 / frame-closing symbol waits until the data symbols before it have been handed on). What
+ * the callback throws (C++ callers) is caught on that thread and comes back as -1 from the next t2gpu_demod_execute / _flush / _status.
+ * t2gpu_demod_execute may return with up to three symbols still to be handed on; they follow within a symbol's time, or at once with
+ * t2gpu_demod_flush: everything launched so far read and handed on -- to be called at the end of a stream BEFORE the stages behind the
+ * demodulator are flushed or destroyed. */
 int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on);
+int t2gpu_demod_flush(t2gpu_demod *h);
 /* With the loop on the device: the chunk that completes a data symbol and the symbol's transform + synchronisation floats as ONE launch
  * (on = 1, the default: front_fft_one_kernel -- the front end's workgroups, then the eight of the transform, which wait for them) or as two
  * (0). Same cells, same floats, same TS. Symbols whose pilot tables do not fit the transform's exchange buffer (dense patterns) take the two. */
 int t2gpu_demod_set_chain_one(t2gpu_demod *h, int on);
 /* Page-locked I/Q of an execute() (t2gpu_host_pin) comes over chunk by chunk (on = 1, the default): the call's first chunk's samples by a
  * launch in front of it, every later chunk's inside the launch of the chunk before it -- instead of the whole buffer by one launch in front
- * of the call's first chunk (0). The buffers must stay untouched until the call returns (they must anyway). Same samples, same TS. */
+ * of the call's first chunk (0). Either way the caller's buffers are free when the call returns. Same samples, same TS. */
 int t2gpu_demod_set_copy_ahead(t2gpu_demod *h, int on);
-/* level_detect / c1 / c2 of an execute() from one pass over its buffer at its head (on = 1: t2gpu_front_call_begin -- the call's gain
- * decision and its return do not wait for its chunks, the next call's launches follow the last chunk's directly) or from the chunks'
- * own sums (0, the default: the end of every call waits for them). The same values to the last bits of a double-precision sum. Off by
- * default because it measured 2.5 % SLOWER on the slot-shaped path: the device's chain bounds that path, not the
- * host's wait, and the look-ahead is one more launch per call in the chain's stream. */
-int t2gpu_demod_set_call_stats(t2gpu_demod *h, int on);
+/* The loop trajectory (telemetry; what the reference's private members hold when it emits replace_null_indicator, dvbt2_demodulator.cpp:
+ * 429-444): one record of T2GPU_DEMOD_TRACE_W doubles per P2 / data / frame-closing symbol that reaches the tracking loops, written on the
+ * caller's thread when the loops have taken the symbol's floats -- {ordinal of the symbol (t2gpu_demod_info::symbols), next_symbol_type and
+ * idx_symbol behind it, input samples of the chunk that completed it, phase_est_filtered, frequency_est_filtered,
+ * sample_rate_est_filtered, arbitrary_resample, and the symbol's raw estimates: phase_est, sample_rate_est (the equaliser's two floats) and
+ * frequency_est (the guard correlation's angle / (2 fft_size); 0 before the first good L1-pre)}. records: caller's memory for cap_records records (NULL / 0: off);
+ * t2gpu_demod_trace_count: records written so far (counts on beyond cap_records without writing). */
+#define T2GPU_DEMOD_TRACE_W 11
+int t2gpu_demod_set_trace(t2gpu_demod *h, double *records, long cap_records);
+long t2gpu_demod_trace_count(const t2gpu_demod *h);
 int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out);
 
 /* ---------------------------------------------------------------- batch receiver: buffers of whole T2 frames --------------

@@ -855,13 +855,16 @@ public:
     }
     // a recorded buffer has no tuner to move: see t2gpu_demod_set_tuner
     void set_tuner(double offset_hz) { if (t2gpu_demod_set_tuner(h_, offset_hz) != 0) fail("t2gpu_demod_set_tuner"); }
-    // the tracking loops of a frame's data symbols on the device (t2gpu_demod_set_device_loop); off unless asked for
+    // the tracking loops of a frame's data symbols on the device (t2gpu_demod_set_device_loop: the default) or on the host
     void set_device_loop(bool on) { if (t2gpu_demod_set_device_loop(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_device_loop"); }
-    // a call's level / IQ estimates from one pass at its head (default) or from its chunks' sums (t2gpu_demod_set_call_stats)
     // the chunk that completes a 32K data symbol and the symbol's transform as one launch (default) or two (t2gpu_demod_set_chain_one)
     void set_chain_one(bool on) { if (t2gpu_demod_set_chain_one(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_chain_one"); }
     void set_copy_ahead(bool on) { if (t2gpu_demod_set_copy_ahead(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_copy_ahead"); }
-    void set_call_stats(bool on) { if (t2gpu_demod_set_call_stats(h_, on ? 1 : 0) != 0) fail("t2gpu_demod_set_call_stats"); }
+    // end of a stream: every symbol launched so far is read and handed on (t2gpu_demod_flush) -- before the stages behind are flushed
+    void flush() { if (t2gpu_demod_flush(h_) != 0) fail("t2gpu_demod_flush"); }
+    // the loop trajectory, one record of T2GPU_DEMOD_TRACE_W doubles per tracked symbol (t2gpu_demod_set_trace)
+    void set_trace(double *records, long cap_records) { if (t2gpu_demod_set_trace(h_, records, cap_records) != 0) fail("t2gpu_demod_set_trace"); }
+    long trace_count() const { return t2gpu_demod_trace_count(h_); }
     t2gpu_demod_info status() const { t2gpu_demod_info i{}; t2gpu_demod_status(h_, &i); return i; }
 private:
     static l1_postsignalling pack(const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn)

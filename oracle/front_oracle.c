@@ -296,7 +296,7 @@ ora_sync *ora_sync_create(float sample_rate)
     const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);                              /* SAMPLE_RATE, dvbt2_definition.h:29-30 */
     ora_pi_init(&s->phase, 0.3f, 1000000, (int)fs);                               /* .h:106-110 */
     ora_pi_init(&s->freq, 0.7f, 4000000, (int)fs);                                /* .h:112-116 */
-    s->resample = sample_rate / (fs * 2);                                         /* :54, float arithmetic stored to double */
+    s->resample = sample_rate * (1.0f / (fs * 2));     /* :54, float arithmetic stored to double; as the -Ofast reference binary evaluates the division (by a constant: times its float reciprocal) */
     s->max_resample = s->resample + s->resample * 1.0e-4;
     return s;
 }

@@ -143,7 +143,9 @@ struct ref_rx {
     dvbt2_demodulator *dem = nullptr;
     taps t;
     signal_estimate sig;
+    std::vector<double> traj;          /* per symbol that reaches the tracking loops (dvbt2_demodulator.cpp:429-444): TRAJ_W doubles */
 };
+constexpr int TRAJ_W = 16;
 
 int tap_get(taps &t, int which, int *meta, void *out, int cap)
 {
@@ -275,8 +277,33 @@ void *ref_rx_new(int id_device, float sample_rate, const char *ts_path, int need
     QObject::connect(h->dem, &dvbt2_demodulator::l1_dyn_execute, h->dem,
                      [h](l1_postsignalling, int len, complex *c) { h->t.push(4, len, 0, 1, 0, c, sizeof(complex) * len); },
                      Qt::DirectConnection);
+    /* the loop trajectory: replace_null_indicator is emitted at the end of every pass through the tracking loops (:444), i.e. once per
+     * P2 / data / frame-closing symbol of a tracked frame, behind the filters' update. Private members read, nothing written:
+     * next_symbol_type, idx_symbol (both already advanced), chunk (the chunk that completed the symbol), phase_est_filtered,
+     * frequency_est_filtered, sample_rate_est_filtered, resample, phase_nco, frequency_nco, old_sample_rate_est, and the signal's two
+     * arguments (sample-rate and frequency offsets in Hz as the GUI gets them), the loop filters' integrators and gains */
+    QObject::connect(h->dem, &dvbt2_demodulator::replace_null_indicator, h->dem,
+                     [h](const float b1, const float b2) {
+                         dvbt2_demodulator *d = h->dem;
+                         const double v[TRAJ_W] = { double(d->next_symbol_type), double(d->idx_symbol), double(d->chunk), double(d->phase_est_filtered),
+                                                    double(d->frequency_est_filtered), d->sample_rate_est_filtered, d->resample, double(d->phase_nco),
+                                                    double(d->frequency_nco), double(d->old_sample_rate_est), double(b1), double(b2),
+                                                    /* the two PI filters' integrators and proportional gains (DSP/loop_filters.hh:28-33): a symbol's raw
+                                                     * phase_est follows from them as 2 (phase_est_filtered - integral) / k_p while the integrator is inside its clamp */
+                                                    double(d->loop_filter_phase_offset.old_integral_error), double(d->loop_filter_phase_offset.k_p),
+                                                    double(d->loop_filter_frequency_offset.old_integral_error), double(d->loop_filter_frequency_offset.k_p) };
+                         h->traj.insert(h->traj.end(), v, v + TRAJ_W);
+                     }, Qt::DirectConnection);
     set_ts_file(h->dem->deinterleaver->qam->decoder->decoder->deheader, ts_path, need_plp);
     return h;
+}
+/* the trajectory so far: returns the number of records (TRAJ_W doubles each); out may be NULL (count only) */
+int ref_rx_traj(void *hv, double *out, int cap_records)
+{
+    ref_rx *h = static_cast<ref_rx *>(hv);
+    const int n = static_cast<int>(h->traj.size() / TRAJ_W);
+    if (out) std::memcpy(out, h->traj.data(), sizeof(double) * TRAJ_W * (n < cap_records ? n : cap_records));
+    return n;
 }
 void ref_rx_keep(void *hv, int which, int keep) { static_cast<ref_rx *>(hv)->t.keep[which] = keep != 0; }
 

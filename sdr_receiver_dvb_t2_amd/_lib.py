@@ -81,8 +81,6 @@ PROTOTYPES = {
     "t2gpu_front_set_frequency_nco": (ctypes.c_int, [_vp, ctypes.c_float]),
     "t2gpu_front_set_iq": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float]),
     "t2gpu_front_hold_iq": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "t2gpu_front_call_begin": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
-    "t2gpu_front_call_level": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_front_set_chain": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_front_commit_iq": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_sync_reset": (None, [_vp, ctypes.c_float]),
@@ -95,7 +93,9 @@ PROTOTYPES = {
     "t2gpu_demod_set_tuner": (ctypes.c_int, [_vp, ctypes.c_double]),
     "t2gpu_demod_set_chain_one": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_set_copy_ahead": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "t2gpu_demod_set_call_stats": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_demod_flush": (ctypes.c_int, [_vp]),
+    "t2gpu_demod_set_trace": (ctypes.c_int, [_vp, _vp, ctypes.c_long]),
+    "t2gpu_demod_trace_count": (ctypes.c_long, [_vp]),
     "t2gpu_demod_set_device_loop": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_demod_status": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_eq_p2_frames_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_long, ctypes.c_int, _vp, _vp]),

@@ -47,31 +47,7 @@ struct FrontParams {
 // c1 / c2 / level_detect stay as they are until launch_front_commit_iq (the reference derives them once per execute(), :227-235)
 enum { FRONT_STAGE_DEROTATE = 1, FRONT_STAGE_FARROW = 2, FRONT_STAGE_DECIMATE = 4, FRONT_STAGE_HOLD_IQ = 8 };
 // h_copy / h_flag (may be null): the committed state is also stored to page-locked host memory and *h_flag = seq behind it
-// call / use_call: see front_call_stats_kernel (null: the chunks' own sums, as before)
-struct FrontCallStats;
-void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream,
-                            FrontCallStats *call = nullptr, int use_call = 0);
-
-// The sign statistics of a whole execute() ahead of its chunks (front_kernels.hip: front_call_stats_kernel): its own dc averagers (carried
-// from call to call), the call's sums and what :227-235 derive from them. A page-locked copy + sequence word receive the same.
-struct FrontCallStats {
-    double dc_re, dc_im;
-    double theta[3];
-    float c1, c2, level_detect;
-    int32_t error_;
-};
-constexpr int FCS_MAX_GRID = 256;              // workgroups of 4096 samples: calls of up to 1 048 576 samples
-struct FrontCallStatsArgs {
-    const int16_t *i_in, *q_in; int stride; float short_to_float; int n;
-    FrontCallStats *st, *h_copy;
-    unsigned *h_flag; unsigned h_seq;
-    unsigned long long seq, done_target;
-    unsigned long long *flags, *done;          // [FCS_MAX_GRID], [1]
-    double *rec;                               // [FCS_MAX_GRID][8]: aggregate a, re, im; (workgroup 0: the averagers as it found them); the sums
-    int *error;
-};
-int front_call_stats_grid(int n);              // 0: the call is too long for the look-ahead
-void launch_front_call_stats(const FrontCallStatsArgs &a, int grid, hipStream_t stream);
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream);
 
 void launch_front(const FrontParams &p, hipStream_t stream);
 // the device's loop state set / read by launches (no copy engine): h_out / h_flag page-locked, *h_flag = seq behind the state

@@ -990,132 +990,11 @@ __device__ __forceinline__ void front_copy_body(const int16_t *__restrict__ hi, 
     }
 }
 
-// ---- the sign statistics of a WHOLE execute() ahead of its chunks (round 5; the slot-shaped path). theta1..3 / c1 / c2 / level_detect of a
-// call (dvbt2_demodulator.cpp:227-235) depend on its samples and on the dc averagers only -- not on the tracking loops, the chunk sizes or
-// anything a symbol's results decide -- so one launch at the head of the call forms them from the call's I/Q (its own copy of the dc
-// recurrence, carried from call to call in FrontCallStats; the same linear recurrence composed per 4096 samples from the call's start
-// instead of per chunk: equal to the chunks' sums to the last bits of a double) and stores them to page-locked memory: the gain
-// decision at the END of the call reads them there and does not wait for the chain to drain. One workgroup per 4096 samples, the
-// averager's value at a workgroup's first sample by a look-back over the aggregates of the lower-numbered ones (front_one_kernel's
-// scheme), the last workgroup to finish folds the sums in workgroup order.
-__global__ __launch_bounds__(256) void front_call_stats_kernel(FrontCallStatsArgs a)
-{
-    __shared__ Lin wave_tot[4];
-    __shared__ double sh_rec[FCS_MAX_GRID][3];
-    __shared__ double sh_v[2];
-    __shared__ double red[3][4];
-    __shared__ int sh_last;
-    const int tid = threadIdx.x, b = (int)blockIdx.x, nb = (int)gridDim.x;
-    FrontParams p{};
-    p.i_in = a.i_in; p.q_in = a.q_in; p.stride = a.stride; p.short_to_float = a.short_to_float; p.n = a.n;
-    float xr[FRONT_PER], xi[FRONT_PER]; int valid;
-    const long sl = (long)b * FRONT_BLOCK + (long)tid * FRONT_PER;
-    load_samples(p, sl, xr, xi, valid);
-    Lin total;
-    const Lin ex = block_scan_exclusive<4>(thread_lin(xr, xi, valid), wave_tot, &total);
-    if (b == 0 && tid == 0) { sh_v[0] = a.st->dc_re; sh_v[1] = a.st->dc_im; }
-    __syncthreads();
-    if (tid == 0) {
-        double *rec = a.rec + 8 * (size_t)b;
-        rec[0] = total.a; rec[1] = total.re; rec[2] = total.im;
-        if (b == 0) { rec[3] = sh_v[0]; rec[4] = sh_v[1]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(a.flags + b, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (b > 0) {
-        if (tid < b) {
-            long long t0 = 0;
-            for (unsigned spins = 1; __hip_atomic_load(a.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.seq; ++spins) {
-                if ((spins & 0xfffu) == 0) {
-                    const long long now = wall_clock64();
-                    if (!t0) t0 = now;
-                    else if (now - t0 > 200000000LL) { __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const double *rec = a.rec + 8 * (size_t)tid;
-            sh_rec[tid][0] = rec[0]; sh_rec[tid][1] = rec[1]; sh_rec[tid][2] = rec[2];
-            if (tid == 0) { sh_v[0] = rec[3]; sh_v[1] = rec[4]; }
-        }
-        __syncthreads();
-        Lin l{1.0, 0.0, 0.0};
-        if (tid < b) l = Lin{sh_rec[tid][0], sh_rec[tid][1], sh_rec[tid][2]};
-        const Lin exb = block_scan_exclusive<4>(l, wave_tot, nullptr);
-        __syncthreads();
-        if (tid == b - 1) {                                    // everything before workgroup b - 1, then that workgroup: the averager before sample s0
-            const double re = exb.a * sh_v[0] + exb.re, im = exb.a * sh_v[1] + exb.im;
-            sh_v[0] = l.a * re + l.re; sh_v[1] = l.a * im + l.im;
-        }
-        __syncthreads();
-    }
-    double dre = ex.a * sh_v[0] + ex.re, dim = ex.a * sh_v[1] + ex.im;
-    double t[3] = {0.0, 0.0, 0.0};
-    for (int k = 0; k < valid; ++k) {
-        dre = dre + DC_ALPHA * ((double)xr[k] - dre);                           // exponential_averager, loop_filters.hh:63-67
-        dim = dim + DC_ALPHA * ((double)xi[k] - dim);
-        const float real = sub_r(xr[k], (float)dre), imag = sub_r(xi[k], (float)dim);
-        float sgn = real < 0 ? -1.0f : 1.0f;                                    // est_1_bit_quantization, :256-265
-        t[0] -= (double)mul_r(imag, sgn);
-        t[1] += (double)mul_r(real, sgn);
-        sgn = imag < 0 ? -1.0f : 1.0f;
-        t[2] += (double)mul_r(imag, sgn);
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { t[0] += __shfl_down(t[0], d, 64); t[1] += __shfl_down(t[1], d, 64); t[2] += __shfl_down(t[2], d, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = t[0]; red[1][tid >> 6] = t[1]; red[2][tid >> 6] = t[2]; }
-    __syncthreads();
-    if (tid == 0) {
-        double *o = a.rec + 8 * (size_t)b + 5;
-        for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned long long before = __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_last = before == a.done_target + (unsigned long long)nb - 1;
-        if (sh_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    // every workgroup's aggregate and sums by a lane each, folded in workgroup order by one lane
-    __shared__ double fin[FCS_MAX_GRID][6];
-    if (tid < nb) {
-        const double *rec = a.rec + 8 * (size_t)tid;
-        fin[tid][0] = rec[0]; fin[tid][1] = rec[1]; fin[tid][2] = rec[2]; fin[tid][3] = rec[5]; fin[tid][4] = rec[6]; fin[tid][5] = rec[7];
-    }
-    if (tid == 0) { sh_v[0] = a.rec[3]; sh_v[1] = a.rec[4]; }
-    __syncthreads();
-    if (tid == 0) {
-        double th[3] = {0.0, 0.0, 0.0}, re = sh_v[0], im = sh_v[1];
-        for (int k = 0; k < nb; ++k) {
-            th[0] += fin[k][3]; th[1] += fin[k][4]; th[2] += fin[k][5];
-            re = fin[k][0] * re + fin[k][1]; im = fin[k][0] * im + fin[k][2];
-        }
-        FrontCallStats &st = *a.st;
-        st.dc_re = re; st.dc_im = im;
-        FrontState tmp{};
-        front_iq_estimate(tmp, th[0], th[1], th[2], (float)a.n);
-        st.c1 = tmp.c1; st.c2 = tmp.c2; st.level_detect = tmp.level_detect;
-        st.theta[0] = th[0]; st.theta[1] = th[1]; st.theta[2] = th[2];
-        st.error_ = *a.error;
-        if (a.h_copy) {
-            *a.h_copy = st;
-            __threadfence_system();
-            __hip_atomic_store(a.h_flag, a.h_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
 // end of an execute() whose chunks ran with FRONT_STAGE_HOLD_IQ (:227-235)
-// call: the call's statistics as front_call_stats_kernel formed them ahead of the chunks (use_call != 0: they are what the call leaves; 0: the
-// chunks' own sums are -- a call the look-ahead did not cover, or one whose dc averagers were reset on the way -- and the look-ahead's
-// averagers go on from the chunks')
-__global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, FrontCallStats *call, int use_call)
+__global__ void front_commit_iq_kernel(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error)
 {
     FrontState &s = *state;
-    if (call && use_call) {
-        s.c1 = call->c1; s.c2 = call->c2; s.level_detect = call->level_detect;
-        s.theta[0] = call->theta[0]; s.theta[1] = call->theta[1]; s.theta[2] = call->theta[2];
-    } else if (s.n_acc > 0.0) front_iq_estimate(s, s.theta_acc[0], s.theta_acc[1], s.theta_acc[2], (float)s.n_acc);
-    if (call && !use_call) { call->dc_re = s.dc_re; call->dc_im = s.dc_im; }
+    if (s.n_acc > 0.0) front_iq_estimate(s, s.theta_acc[0], s.theta_acc[1], s.theta_acc[2], (float)s.n_acc);
     s.theta_acc[0] = s.theta_acc[1] = s.theta_acc[2] = 0.0;
     s.n_acc = 0.0;
     if (h_copy) {                                           // the state as it stands now, to page-locked host memory, the sequence word behind it
@@ -1164,16 +1043,9 @@ void launch_front_copy_in(const int16_t *hi, const int16_t *hq, int16_t *di, int
     hipLaunchKernelGGL(front_copy_in_kernel, dim3(grid), dim3(256), 0, stream, hi, hq, di, dq, n);
 }
 
-void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream,
-                            FrontCallStats *call, int use_call)
+void launch_front_commit_iq(FrontState *state, FrontState *h_copy, unsigned *h_flag, unsigned seq, const int *error, hipStream_t stream)
 {
-    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state, h_copy, h_flag, seq, error, call, use_call);
-}
-
-int front_call_stats_grid(int n) { const long g = ((long)n + FRONT_BLOCK - 1) / FRONT_BLOCK; return n > 0 && g <= FCS_MAX_GRID ? (int)g : 0; }
-void launch_front_call_stats(const FrontCallStatsArgs &a, int grid, hipStream_t stream)
-{
-    hipLaunchKernelGGL(front_call_stats_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(front_commit_iq_kernel, dim3(1), dim3(1), 0, stream, state, h_copy, h_flag, seq, error);
 }
 
 static void load_taps()

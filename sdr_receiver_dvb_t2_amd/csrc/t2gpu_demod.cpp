@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 using namespace t2gpu;
@@ -103,8 +104,7 @@ struct t2gpu_demod {
     // The loop on the device (include/t2gpu.h): between a frame's P2 and its last data symbol the tracking filters and the NCO's accumulators
     // live on the device, a data symbol's launches are followed by the next chunk's without waiting for its results, and the host reads
     // them one symbol behind (pend), recomputing the same floats for its own copies. Checked when the mode is left, once per frame.
-    bool dev_loop = false;             // t2gpu_demod_set_device_loop
-    bool call_stats = false;           // a call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats)
+    bool dev_loop = true;              // t2gpu_demod_set_device_loop
     // the chunk that completes a data symbol and the symbol's transform + floats as ONE launch (t2gpu_demod_set_chain_one): what the symbol's
     // launches need -- its buffer set (with the waits for the set's last users), its sequence word -- is then settled ahead of the chunk
     bool chain_one = true;
@@ -113,7 +113,7 @@ struct t2gpu_demod {
     bool fft_fused = false;            // the chunk just launched took the symbol's transform with it
     long fused_symbols = 0;
     bool dev_mode = false;
-    struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0; } pend;
+    struct { bool valid = false, have_cp = false, carry = false; unsigned seq_a = 0, seq_cells = 0; int k = 0, chunk = 0, next_type = 0, idx_symbol = 0; long ordinal = 0; } pend;
     long dev_symbols = 0, dev_speculated = 0, dev_waited = 0;
     // ... and in that mode a data symbol's equaliser, the publishing of its cells and its `data` signal are the business of a thread of
     // the object's own (cells_run): the caller's thread then makes three launches per symbol and reads six floats, which is what lets the
@@ -141,7 +141,17 @@ struct t2gpu_demod {
     // does not wait for that launch (59 us with the device idle, 14 times per 32K frame): the next call picks the state up first thing.
     bool state_pending = false;        // a commit is on its way whose state has not been read back yet
     bool saw_results = false;          // this call has read a symbol's results: everything enqueued before them -- the I/Q copies -- is through
+    // t2gpu_demod_set_trace: one record per symbol that reaches the tracking loops, written on the caller's thread when the loops have its floats
+    double *trace = nullptr;
+    long trace_cap = 0, trace_n = 0;
+    int last_chunk = 0;                // input samples of the chunk launched last (dvbt2_demodulator.h:86 `chunk`)
+    long loop_resyncs = 0;             // the host's copies of the loops set from the device's after a disagreement (never, by construction)
+    bool strict_loops = false;         // T2GPU_DEMOD_STRICT_LOOPS=1 (the tests): such a disagreement is an error instead
 };
+
+// internal to the library (t2gpu_front.cpp), not part of the ABI: the host's copies of the loops take the device's values
+extern "C" void t2gpu_sync_adopt(t2gpu_sync *s, float phase_est_filtered, float frequency_est_filtered, float f_int, float p_int);
+extern "C" int t2gpu_front_adopt_nco(t2gpu_front *h, float phase_nco, float frequency_nco);
 
 namespace {
 
@@ -363,7 +373,11 @@ void cells_run(t2gpu_demod *h)
             if (!wait_word(h, h->h_flag + 16, prev_seq, h->eq_stream, false)) { h->cells_error = last_error(); h->cells_failed.store(1); }
             else {
                 const auto t1 = now();
-                h->sig.data(h->sig.user, prev.n_cells, h->h_cells[prev.k]);
+                // the consumer's callback runs on THIS thread (include/t2gpu.h says so); what it throws -- the stage classes' fail() does --
+                // is kept for the caller's thread, whose next execute() / status() / flush() returns -1 with the message
+                try { h->sig.data(h->sig.user, prev.n_cells, h->h_cells[prev.k]); }
+                catch (const std::exception &e) { h->cells_error = std::string("the `data` callback threw: ") + e.what(); h->cells_failed.store(1); }
+                catch (...) { h->cells_error = "the `data` callback threw"; h->cells_failed.store(1); }
                 if (h->prof.on) { h->cells_t[1] += secs(t0, t1); h->cells_t[2] += secs(t1, now()); }
             }
         } else if (hipStreamSynchronize(h->eq_stream) != hipSuccess) { h->cells_error = "hipStreamSynchronize (cells' stream)"; h->cells_failed.store(1); }
@@ -429,17 +443,33 @@ int cells_drain(t2gpu_demod *h)
     return rc;
 }
 
-// the tracking loops with a symbol's floats (:328-330, 429-439) and the readout the GUI gets (:441-444)
+// t2gpu_demod_set_trace: the loops as they stand behind a symbol's update (what dvbt2_demodulator holds at :444)
+void trace_symbol(t2gpu_demod *h, long ordinal, int next_type, int idx_symbol, int chunk, const float *sv, bool have_cp, const float *cp)
+{
+    if (!h->trace || h->trace_n >= h->trace_cap) { if (h->trace) ++h->trace_n; return; }
+    double g[4];
+    t2gpu_sync_get(h->sync, g);
+    double *r = h->trace + T2GPU_DEMOD_TRACE_W * h->trace_n++;
+    r[0] = (double)ordinal; r[1] = next_type; r[2] = idx_symbol; r[3] = chunk;
+    r[4] = g[0]; r[5] = g[1]; r[6] = g[2]; r[7] = g[3];
+    r[8] = sv[0]; r[9] = sv[1]; r[10] = have_cp ? cp[2] : 0.0;
+}
+
+// the readout the GUI gets (:441-444)
+void emit_null_indicator(t2gpu_demod *h)
+{
+    if (!h->sig.replace_null_indicator) return;
+    double g[4];
+    t2gpu_sync_get(h->sync, g);
+    const float PI_X_2 = 3.14159274101257324219f * 2.0f;
+    h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
+}
+
+// the tracking loops with a symbol's floats (:328-330, 429-439)
 void loops_after_symbol(t2gpu_demod *h, bool have_cp, const float *cp, const float *sv)
 {
     if (have_cp) t2gpu_sync_frequency(h->sync, cp[2], h->fft_size);
     t2gpu_sync_symbol(h->sync, sv[0], sv[1]);
-    if (h->sig.replace_null_indicator) {
-        double g[4];
-        t2gpu_sync_get(h->sync, g);
-        const float PI_X_2 = 3.14159274101257324219f * 2.0f;
-        h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
-    }
 }
 
 // the chunks the device has run on its own loop values and the host has not followed yet: with the host's values as they stand
@@ -469,10 +499,15 @@ int consume_pending(t2gpu_demod *h)
         t2gpu_sync_get(h->sync, g);
         const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
         if (std::memcmp(&pe, h->h_small + 8 * h->pend.k + 6, 4) != 0 || std::memcmp(&fe, h->h_small + 8 * h->pend.k + 7, 4) != 0) {
-            set_error("t2gpu_demod: the tracking loops on the device and on the host disagree");
-            return -1;
+            // bit-equal by construction (same operations, -ffp-contract=off on both sides). Should a build ever break that, reception
+            // must not: T2GPU_DEMOD_STRICT_LOOPS=1 (the tests) makes it an error, otherwise this frame's remaining symbols run with the
+            // loops on the host, starting from the host's values, and the event is counted (t2gpu_demod_info::loop_resyncs)
+            if (h->strict_loops) { set_error("t2gpu_demod: the tracking loops on the device and on the host disagree"); return -1; }
+            ++h->loop_resyncs;                                 // (leave_dev_mode adopts the device's state: the device's values are what the samples saw)
         }
     }
+    trace_symbol(h, h->pend.ordinal, h->pend.next_type, h->pend.idx_symbol, h->pend.chunk, sv, h->pend.have_cp, cp);
+    emit_null_indicator(h);
     return follow_chunks(h);                                   // (its cells are the cells' thread's business)
 }
 
@@ -495,7 +530,7 @@ int enter_dev_mode(t2gpu_demod *h)
 int leave_dev_mode(t2gpu_demod *h)
 {
     if (!h->dev_mode) return 0;
-    if (consume_pending(h) != 0 || cells_drain(h) != 0) return -1;
+    if (consume_pending(h) != 0 || cells_drain(h) != 0) { h->dev_mode = false; h->pend.valid = false; return -1; }
     h->dev_mode = false;
     float d[8], st[8] = {};
     if (t2gpu_front_loop_read(h->front, d, h->stream) != 0 || t2gpu_front_nco(h->front, st + 4) != 0) return -1;
@@ -504,6 +539,12 @@ int leave_dev_mode(t2gpu_demod *h)
     const float pe = (float)g[0], fe = (float)g[1] + (float)h->tuner;
     if (d[7] != 0.0f) { set_error("t2gpu_demod: the NCO planner on the device ran out of room"); return -1; }
     if (std::memcmp(&d[0], &st[4], 4) != 0 || std::memcmp(&d[1], &st[5], 4) != 0 || std::memcmp(&d[2], &pe, 4) != 0 || std::memcmp(&d[3], &fe, 4) != 0) {
+        if (!h->strict_loops) {
+            // never, by construction; if a build breaks the construction, reception goes on from what the device did to the samples
+            ++h->loop_resyncs;
+            t2gpu_sync_adopt(h->sync, d[2], d[4], d[5], d[6]);
+            return t2gpu_front_adopt_nco(h->front, d[0], d[1]);
+        }
         char msg[320];
         std::snprintf(msg, sizeof msg, "t2gpu_demod: the device's loop state is not where the host's copy is (phase_nco %.9g / %.9g, frequency_nco %.9g / %.9g, "
                       "phase_est_filtered %.9g / %.9g, frequency input %.9g / %.9g)", d[0], st[4], d[1], st[5], d[2], pe, d[3], fe);
@@ -625,6 +666,7 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
                     h->next_symbol_type = h->frame_closing_symbol ? SYMBOL_TYPE_FC : SYMBOL_TYPE_P1;
                     if (!h->frame_closing_symbol) ++h->frames;
                 }
+                h->pend.ordinal = h->symbols; h->pend.chunk = h->last_chunk; h->pend.next_type = h->next_symbol_type; h->pend.idx_symbol = h->idx_symbol;
                 continue;
             }
             if (t2gpu_eq_data_execute_dev(h->data_ofdm, h->d_spec[k], h->d_symidx + h->idx_symbol, 1, h->d_cells[k], nullptr, h->eq_stream) < 0) return -1;
@@ -723,12 +765,8 @@ int symbol_acquisition(t2gpu_demod *h, int len_in, t2gpu_signal_estimate *signal
         }
         // ---- tracking loops (:429-439) and the readout the GUI gets (:441-444)
         t2gpu_sync_symbol(h->sync, sv[0], sv[1]);
-        if (h->sig.replace_null_indicator) {
-            double g[4];
-            t2gpu_sync_get(h->sync, g);
-            const float PI_X_2 = 3.14159274101257324219f * 2.0f;
-            h->sig.replace_null_indicator(h->sig.user, (float)(g[2] * SAMPLE_RATE_HZ) / PI_X_2, ((float)g[1] * SAMPLE_RATE_HZ) / PI_X_2);
-        }
+        trace_symbol(h, h->symbols, h->next_symbol_type, h->idx_symbol, h->last_chunk, sv, have_cp, cp);
+        emit_null_indicator(h);
         // behind a frame's P2 symbol the loops go to the device for its data symbols
         if (h->dev_loop && !h->dev_mode && h->next_symbol_type == SYMBOL_TYPE_DATA && h->crc32_l1_pre && h->demodulator_init && h->data_ofdm &&
             enter_dev_mode(h) != 0) return -1;
@@ -748,6 +786,7 @@ extern "C" t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int
     }
     t2gpu_demod *h = new t2gpu_demod();
     if (const char *e = std::getenv("T2GPU_DEMOD_PROF")) h->prof.on = std::atoi(e) != 0;
+    if (const char *e = std::getenv("T2GPU_DEMOD_STRICT_LOOPS")) h->strict_loops = std::atoi(e) != 0;
     h->device = device; h->id_device = id_device; h->sample_rate = sample_rate;
     h->stride = id_device == 1 ? 2 : 1;                                             // convert_input, :31-50
     h->front = t2gpu_front_create(id_device, sample_rate, CHUNK_MAX, device);
@@ -850,18 +889,7 @@ extern "C" int t2gpu_demod_set_copy_ahead(t2gpu_demod *h, int on)
     return 0;
 }
 
-// on = 1: level_detect / c1 / c2 of an execute() are formed by one pass over its buffer at its head (t2gpu_front_call_begin) and the call's end
-// does not wait for its chunks; 0 (default): from the chunks' own sums, the end of the call waits for them. Measured on the slot-shaped path
-// (tools/ab_dropin_args.sh "--call-stats 1" "--call-stats 0", same box): 309 against 318 Msamples/s -- the chain on the device is what
-// bounds that path, not the host's wait at the end of a call, and the look-ahead is one more launch in the chain's stream per call.
-extern "C" int t2gpu_demod_set_call_stats(t2gpu_demod *h, int on)
-{
-    if (!h) { set_error("t2gpu_demod_set_call_stats: bad arguments"); return -1; }
-    h->call_stats = on != 0;
-    return 0;
-}
-
-// on = 0 (default): the tracking loops stay on the host for every symbol (one round trip per symbol); 1: on the device for a frame's data symbols
+// on = 1 (default): the tracking loops on the device for a frame's data symbols; 0: on the host for every symbol (one round trip per symbol)
 extern "C" int t2gpu_demod_set_device_loop(t2gpu_demod *h, int on)
 {
     if (!h) { set_error("t2gpu_demod_set_device_loop: bad arguments"); return -1; }
@@ -907,7 +935,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         // page-locked buffers (t2gpu_host_pin) come over by a kernel of the chain's own stream; anything else through the copy engine
         void *vi = nullptr, *vq = nullptr;
         if (hipHostGetDevicePointer(&vi, const_cast<int16_t *>(i_in), 0) == hipSuccess && hipHostGetDevicePointer(&vq, const_cast<int16_t *>(q_in), 0) == hipSuccess) {
-            if (h->copy_ahead && !h->call_stats) {
+            if (h->copy_ahead) {
                 // (t2gpu_demod_set_copy_ahead) nothing comes over here: a chunk's samples are brought over by the launch of the chunk before it, the
                 // call's first chunk's by a launch of their own in front of it (ensure_copied)
                 src_i = static_cast<const int16_t *>(vi); src_q = static_cast<const int16_t *>(vq);
@@ -921,10 +949,6 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
             T2_HIP(hipMemcpyAsync(h->d_q, q_in, el * 2, hipMemcpyHostToDevice, h->stream));
         }
     }
-    // the call's sign statistics ahead of its chunks (t2gpu_demod_set_call_stats): the gain decision below then reads them without waiting
-    // for the chain, and their arrival says the I/Q has come over
-    const int look_ahead = h->call_stats ? t2gpu_front_call_begin(h->front, h->d_i, h->d_q, len_in, h->stream) : 0;
-    if (look_ahead < 0) return -1;
     h->prof.stop(PF_COPY_IN);
     int idx_in = 0;
     while (idx_in < len_in) {
@@ -955,6 +979,7 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
         }
         int32_t chunk = chunk_for(arbitrary_resample);
         if (chunk > CHUNK_MAX) { set_error("t2gpu_demod_execute: chunk larger than the work buffers"); return -1; }
+        h->last_chunk = chunk;
         h->prof.start();
         // a chunk that continues (or starts) an OFDM symbol is written where the symbol is collected; its few cells beyond the symbol's
         // end, if any, are moved by symbol_acquisition. P1 searches read the chunk from d_out.
@@ -1006,18 +1031,18 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     }
     // (the loop on the device: a symbol whose results are still out stays out across the call's end -- the next call's first chunk goes ahead of
     // them as any other -- unless nothing of this call has been read yet, which is what says that its I/Q has come over)
-    float ahead[3] = {0.0f, 0.0f, 0.0f};
-    const bool have_ahead = look_ahead == 1 && t2gpu_front_call_level(h->front, ahead) == 0;   // (1: a reset on the way cancelled it)
-    if (!(h->dev_mode && (h->saw_results || have_ahead)) && consume_pending(h) != 0) return -1;
+    if (!(h->dev_mode && h->saw_results) && consume_pending(h) != 0) return -1;
     if (flush_data_signal(h) != 0) return -1;
     // ---- IQ-imbalance and level estimates of this buffer (:227-235), gain request (:236-249)
     h->prof.start();
     if (t2gpu_front_commit_iq(h->front, h->stream) != 0) return -1;
     h->state_pending = true;
-    if (have_ahead) { h->level_detect = ahead[2]; h->state_pending = false; h->saw_results = true; }   // what the commit leaves, known already
     // wait for the commit only when something of this call still needs it: the gain decision below, or the caller's I/Q buffers (their
     // copies are in stream order ahead of every symbol's kernels: a call that has read a symbol's results knows they are through)
-    if (signal_->gain_changed || !h->saw_results) {
+    // ... which holds for I/Q that came over at the head of the call. Page-locked I/Q that came over chunk by chunk (copy_ahead) is read by
+    // the call's later launches too -- the last chunks' own copy-in, the copy-ahead workgroups inside chunk launches, whose sequence word
+    // does not cover them -- and the symbol results read so far say nothing about those: the commit, launched behind all of them, does.
+    if (signal_->gain_changed || !h->saw_results || src_i) {
         if (finish_state(h) != 0) return -1;
     }
     h->prof.stop(PF_TAIL);
@@ -1029,6 +1054,28 @@ extern "C" int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_
     }
     return 0;
 }
+
+// Everything of the symbols launched so far is read and handed on: the symbol whose results are still out (the loop on the device), the
+// symbols the cells' thread still holds, a `data` signal held back for the next launch. To be called before the stages behind the
+// demodulator are flushed or destroyed at the end of a stream.
+extern "C" int t2gpu_demod_flush(t2gpu_demod *h)
+{
+    if (!h) { set_error("t2gpu_demod_flush: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    if (h->dev_mode && (consume_pending(h) != 0 || cells_drain(h) != 0)) return -1;
+    if (h->cells_failed.load()) { set_error("t2gpu_demod (cells' thread): " + h->cells_error); return -1; }
+    return flush_data_signal(h);
+}
+
+extern "C" int t2gpu_demod_set_trace(t2gpu_demod *h, double *records, long cap_records)
+{
+    if (!h || cap_records < 0 || (cap_records > 0 && !records)) { set_error("t2gpu_demod_set_trace: bad arguments"); return -1; }
+    h->trace = cap_records > 0 ? records : nullptr;
+    h->trace_cap = cap_records;
+    h->trace_n = 0;
+    return 0;
+}
+extern "C" long t2gpu_demod_trace_count(const t2gpu_demod *h) { return h ? h->trace_n : -1; }
 
 extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
 {
@@ -1048,5 +1095,6 @@ extern "C" int t2gpu_demod_status(const t2gpu_demod *h, t2gpu_demod_info *out)
     out->level_detect = h->level_detect;
     out->phase_est_filtered = g[0]; out->frequency_est_filtered = g[1]; out->sample_rate_est_filtered = g[2];
     out->arbitrary_resample = g[3];
+    out->loop_resyncs = h->loop_resyncs;
     return 0;
 }

@@ -59,13 +59,6 @@ struct t2gpu_front {
     FrontState *h_state = nullptr;
     unsigned *h_flag = nullptr, state_seq = 0;
     bool state_published = false;      // nothing has touched the device state since the last commit
-    // the sign statistics of a whole execute() ahead of its chunks (t2gpu_front_call_begin; front_kernels.hip: front_call_stats_kernel)
-    FrontCallStats *d_call = nullptr, *h_call = nullptr;
-    unsigned *h_call_flag = nullptr, call_hseq = 0;
-    char *d_call_work = nullptr;       // flags [FCS_MAX_GRID], done word, records [FCS_MAX_GRID][8]
-    unsigned long long call_seq = 0, call_done = 0;
-    bool call_open = false;            // a look-ahead has been launched for the execute() in hand and nothing has invalidated it
-    bool call_synced = false;          // the look-ahead's dc averagers are where the chunks' are (false until a commit has carried them over)
 };
 
 namespace {
@@ -174,7 +167,10 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
     h->stride = id_device == 1 ? 2 : 1;                                                    // dvbt2_demodulator.cpp:31-50
     h->short_to_float = 1.0f / (float)(1 << (id_device == 0 ? 14 : id_device == 1 ? 12 : 11));
     const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);                                      // SAMPLE_RATE
-    h->resample = sample_rate / (fs * 2);                                                  // :54 (float arithmetic)
+    // :54 `sample_rate / (SAMPLE_RATE * upsample)` in float arithmetic as the reference's own build (-Ofast, sdr_receiver_dvb_t2.pro:33-39)
+    // evaluates it: a division by a constant becomes a multiplication by the constant's float reciprocal -- one float ulp (6e-8) apart
+    // from the true quotient for some sample rates (9 142 875 Hz: tests/test_ref_pins_gpu.py, rxoff/rx32k)
+    h->resample = sample_rate * (1.0f / (fs * 2));
     h->max_resample = h->resample + h->resample * 1.0e-4;                                  // :55
     h->interp_cap = (long)((double)max_samples / std::min(h->resample, 1.0) * 1.001) + 64;
     const size_t nb = (size_t)(max_samples + FRONT_BLOCK - 1) / FRONT_BLOCK;
@@ -189,15 +185,8 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
         *h->h_flag = 0;
     }
-    constexpr size_t CALL_BYTES = 8 * (size_t)FCS_MAX_GRID + 64 + 64 * (size_t)FCS_MAX_GRID;
-    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_call), sizeof(FrontCallStats) + 64, hipHostMallocCoherent) == hipSuccess) {
-        h->h_call_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_call) + ((sizeof(FrontCallStats) + 15) & ~size_t(15)));
-        *h->h_call_flag = 0;
-    }
     constexpr size_t ONE_BYTES = 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID + 66 * sizeof(float2);
-    bool ok = hipMalloc(&h->d_call, sizeof(FrontCallStats)) == hipSuccess && hipMemset(h->d_call, 0, sizeof(FrontCallStats)) == hipSuccess &&
-              hipMalloc(&h->d_call_work, CALL_BYTES) == hipSuccess && hipMemset(h->d_call_work, 0, CALL_BYTES) == hipSuccess &&
-              hipMalloc(&h->d_loop, sizeof(T2DevLoop)) == hipSuccess && hipMemset(h->d_loop, 0, sizeof(T2DevLoop)) == hipSuccess &&
+    bool ok = hipMalloc(&h->d_loop, sizeof(T2DevLoop)) == hipSuccess && hipMemset(h->d_loop, 0, sizeof(T2DevLoop)) == hipSuccess &&
               hipMalloc(&h->d_loop_runs, (size_t)T2_LOOP_RUNS_CAP * sizeof(FrontRun)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void **>(&h->h_loop), sizeof(T2DevLoop), hipHostMallocDefault) == hipSuccess &&
               hipMalloc(&h->d_one, ONE_BYTES) == hipSuccess && hipMemset(h->d_one, 0, ONE_BYTES) == hipSuccess &&
@@ -227,8 +216,6 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (h->h_loop) hipHostFree(h->h_loop);
     if (h->h_loop_out) hipHostFree(h->h_loop_out);
     if (h->h_state) hipHostFree(h->h_state);
-    if (h->h_call) hipHostFree(h->h_call);
-    hipFree(h->d_call); hipFree(h->d_call_work);
     hipFree(h->d_state); hipFree(h->d_blk); hipFree(h->d_theta); hipFree(h->d_lut); hipFree(h->d_derot); hipFree(h->d_interp);
     hipFree(h->d_runs); hipFree(h->d_index); hipFree(h->d_i); hipFree(h->d_q); hipFree(h->d_out);
     if (h->h_runs) hipHostFree(h->h_runs);
@@ -251,7 +238,6 @@ extern "C" int t2gpu_front_reset(t2gpu_front *h)
     T2_HIP(hipMemset(h->d_interp, 0, 63 * sizeof(float2)));
     h->phase_nco = 0.0f; h->frequency_nco = 0.0f; h->x1 = -0.5f; h->decim_phase = 0;
     h->last_n = 0; h->last_n_interp = 0;
-    h->call_open = false; h->call_synced = false;
     return 0;
 }
 
@@ -268,7 +254,6 @@ extern "C" int t2gpu_front_reset_loops(t2gpu_front *h)
     T2_HIP(hipMemcpy(h->d_state, &s, sizeof s, hipMemcpyHostToDevice));
     h->state_published = false;
     h->phase_nco = 0.0f; h->frequency_nco = 0.0f;
-    h->call_open = false; h->call_synced = false;             // (the look-ahead of the call in hand ran on the averagers as they were)
     return 0;
 }
 
@@ -314,57 +299,10 @@ extern "C" int t2gpu_front_commit_iq(t2gpu_front *h, void *stream)
     if (!h) return -1;
     T2_HIP(hipSetDevice(h->device));
     const unsigned seq = ++h->state_seq;
-    launch_front_commit_iq(h->d_state, h->h_state, h->h_state ? h->h_flag : nullptr, seq, h->d_chain_error, (hipStream_t)stream, h->d_call, h->call_open ? 1 : 0);
+    launch_front_commit_iq(h->d_state, h->h_state, h->h_state ? h->h_flag : nullptr, seq, h->d_chain_error, (hipStream_t)stream);
     T2_HIP(hipGetLastError());
-    h->call_open = false;
-    h->call_synced = true;                                     // (either the call's look-ahead was what it left, or its averagers have been carried over)
     h->last_stream = (hipStream_t)stream;
     h->state_published = h->h_state != nullptr;
-    return 0;
-}
-
-// The sign statistics of the execute() in hand ahead of its chunks: n samples of device I/Q (the call's whole buffer, the front end's
-// stride). Returns 1 when the look-ahead is on its way (t2gpu_front_call_level then has the call's level_detect long before the chunks
-// are through, and t2gpu_front_commit_iq leaves what it formed), 0 when this call goes without (too long, or the look-ahead's averagers
-// have not been carried over from the chunks' yet: the first call, a call behind a reset), -1 on an error.
-extern "C" int t2gpu_front_call_begin(t2gpu_front *h, const int16_t *d_i, const int16_t *d_q, int n, void *stream)
-{
-    if (!h || !d_i || !d_q || n < 0) { set_error("t2gpu_front_call_begin: bad arguments"); return -1; }
-    if (h->call_open) h->call_synced = false;                 // (the call before never committed: its look-ahead's averagers ran ahead of the chunks')
-    h->call_open = false;
-    const int grid = front_call_stats_grid(n);
-    if (!grid || !h->call_synced || !h->h_call || !h->hold_iq) return 0;
-    T2_HIP(hipSetDevice(h->device));
-    FrontCallStatsArgs a{};
-    a.i_in = d_i; a.q_in = d_q; a.stride = h->stride; a.short_to_float = h->short_to_float; a.n = n;
-    a.st = h->d_call; a.h_copy = h->h_call; a.h_flag = h->h_call_flag; a.h_seq = ++h->call_hseq;
-    a.seq = ++h->call_seq; a.done_target = h->call_done;
-    a.flags = reinterpret_cast<unsigned long long *>(h->d_call_work);
-    a.done = reinterpret_cast<unsigned long long *>(h->d_call_work + 8 * (size_t)FCS_MAX_GRID);
-    a.rec = reinterpret_cast<double *>(h->d_call_work + 8 * (size_t)FCS_MAX_GRID + 64);
-    a.error = h->d_chain_error;
-    launch_front_call_stats(a, grid, (hipStream_t)stream);
-    T2_HIP(hipGetLastError());
-    h->call_done += (unsigned long long)grid;
-    h->call_open = true;
-    return 1;
-}
-
-// level_detect (and c1 / c2: out3 = c1, c2, level_detect) of the call whose look-ahead t2gpu_front_call_begin launched: waits for that launch only
-extern "C" int t2gpu_front_call_level(t2gpu_front *h, float *out3)
-{
-    if (!h || !out3) { set_error("t2gpu_front_call_level: bad arguments"); return -1; }
-    if (!h->call_open) return 1;                               // none in hand (a reset on the way cancelled it)
-    volatile unsigned *flag = h->h_call_flag;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0; (int)(*flag - h->call_hseq) < 0; ++spins) {
-        t2_cpu_relax();
-        if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { set_error("t2gpu_front_call_level: the look-ahead did not arrive"); return -1; }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const FrontCallStats s = *h->h_call;
-    if (s.error_) { set_error("t2gpu_front: a look-back wait of the one-launch form timed out"); return -1; }
-    out3[0] = s.c1; out3[1] = s.c2; out3[2] = s.level_detect;
     return 0;
 }
 
@@ -763,7 +701,7 @@ extern "C" t2gpu_sync *t2gpu_sync_create(float sample_rate)
     const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);
     s->phase.init(0.3f, 1000000, (int)fs);                                                 // dvbt2_demodulator.h:106-110
     s->freq.init(0.7f, 4000000, (int)fs);                                                  // .h:112-116
-    s->resample = sample_rate / (fs * 2);
+    s->resample = sample_rate * (1.0f / (fs * 2));                          // (the reference binary's form of `/`: t2gpu_front_create)
     s->max_resample = s->resample + s->resample * 1.0e-4;
     return s;
 }
@@ -794,7 +732,7 @@ extern "C" void t2gpu_sync_reset(t2gpu_sync *s, float sample_rate)
     s->frequency_est_filtered = 0.0f; s->old_sample_rate_est = 0.0f;            // phase_est_filtered is not touched there
     s->sample_rate_est_filtered = 0.0;
     const float fs = 1.0f / (1.0e-6f * 7.0f / 64.0f);
-    s->resample = sample_rate / (fs * 2);
+    s->resample = sample_rate * (1.0f / (fs * 2));                          // (the reference binary's form of `/`: t2gpu_front_create)
 }
 // set_guard_interval_by_brute_force, first attempt of a guard length (:484-487): the frequency estimate starts from zero
 extern "C" void t2gpu_sync_clear_frequency(t2gpu_sync *s) { if (s) s->frequency_est_filtered = 0.0f; }
@@ -817,6 +755,20 @@ extern "C" void t2gpu_sync_get(const t2gpu_sync *s, double *out4)
     double r = s->resample - s->sample_rate_est_filtered;                                  // :157-158
     if (r > s->max_resample) r = s->max_resample;
     out4[0] = s->phase_est_filtered; out4[1] = s->frequency_est_filtered; out4[2] = s->sample_rate_est_filtered; out4[3] = r;
+}
+
+// internal (t2gpu_demod.cpp, after a disagreement between the host's copies and the device's loop state): the device's values win
+extern "C" void t2gpu_sync_adopt(t2gpu_sync *s, float phase_est_filtered, float frequency_est_filtered, float f_int, float p_int)
+{
+    if (!s) return;
+    s->phase_est_filtered = phase_est_filtered; s->frequency_est_filtered = frequency_est_filtered;
+    s->freq.old_integral = f_int; s->phase.old_integral = p_int;
+}
+extern "C" int t2gpu_front_adopt_nco(t2gpu_front *h, float phase_nco, float frequency_nco)
+{
+    if (!h) return -1;
+    h->phase_nco = phase_nco; h->frequency_nco = frequency_nco;
+    return 0;
 }
 
 // the three values arbitrary_resample (t2gpu_sync_get's [3]) can take after the NEXT t2gpu_sync_symbol: the tracker steps by -8e-9, 0 or

@@ -157,11 +157,32 @@ int main(int argc, char **argv)
             const char *ts_path = argv[4];
             const int buf_len = std::atoi(argv[5]), need_plp = std::atoi(argv[6]);
             std::FILE *log = std::fopen(argv[7], "w");
-            t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f);
-            // STAGE_DEVICE_LOOP=1: the tracking loops of a frame's data symbols on the device (same cells, same TS)
-            if (std::getenv("STAGE_DEVICE_LOOP") && std::atoi(std::getenv("STAGE_DEVICE_LOOP")) != 0) demodulator.set_device_loop(true);
-            // STAGE_CALL_STATS=1: a call's level / IQ estimates from one pass over its buffer at its head (t2gpu_demod_set_call_stats)
-            if (std::getenv("STAGE_CALL_STATS") && std::atoi(std::getenv("STAGE_CALL_STATS")) != 0) demodulator.set_call_stats(true);
+            // STAGE_SAMPLE_RATE_OFF=<Hz>: the sample rate the demodulator is TOLD, minus the recording's true 64e6 / 7 (a receiver clock that is
+            // off: what the sample-rate tracker has to find, dvbt2_demodulator.cpp:430-439)
+            const float rate_off = std::getenv("STAGE_SAMPLE_RATE_OFF") ? (float)std::atof(std::getenv("STAGE_SAMPLE_RATE_OFF")) : 0.0f;
+            t2::dvbt2_demodulator demodulator(t2::id_sdrplay, 64.0e6f / 7.0f + rate_off);
+            // STAGE_TRACE=<path>: the loop trajectory (t2gpu_demod_set_trace), raw doubles
+            std::vector<double> trace;
+            if (std::getenv("STAGE_TRACE")) { trace.resize((size_t)T2GPU_DEMOD_TRACE_W * 65536); demodulator.set_trace(trace.data(), 65536); }
+            // STAGE_TUNER_MOVES="k:hz,k:hz": the recording sits behind an EXTERNAL emulated tuner (tests/ref_cases.py RX_OFFSET_CASES): it has been
+            // rotated already by the moves the reference asked for, from buffer k on. A re-tune request must then come at one of those buffers;
+            // the SDR thread's bookkeeping runs with the listed value (what the tuner was told) and set_tuner is not used.
+            std::vector<std::pair<long, double>> ext_moves;
+            const bool ext_tuner = std::getenv("STAGE_TUNER_MOVES") != nullptr;
+            if (ext_tuner) {
+                const char *q = std::getenv("STAGE_TUNER_MOVES");
+                while (*q) {
+                    char *e = nullptr;
+                    const long k = std::strtol(q, &e, 10);
+                    if (*e != ':') break;
+                    const double hz = std::strtod(e + 1, &e);
+                    ext_moves.emplace_back(k, hz);
+                    q = *e == ',' ? e + 1 : e;
+                }
+            }
+            long buf_no = 0;
+            // STAGE_DEVICE_LOOP=0 / 1: the tracking loops of a frame's data symbols on the host / on the device (the library's default; same cells, same TS)
+            if (std::getenv("STAGE_DEVICE_LOOP")) demodulator.set_device_loop(std::atoi(std::getenv("STAGE_DEVICE_LOOP")) != 0);
             // STAGE_CHAIN_ONE=0: the completing chunk and the symbol's transform as two launches (t2gpu_demod_set_chain_one)
             if (std::getenv("STAGE_CHAIN_ONE") && std::atoi(std::getenv("STAGE_CHAIN_ONE")) == 0) demodulator.set_chain_one(false);
             // STAGE_PIN=1: the I/Q buffers page-locked (t2gpu_host_pin) -- they then come over chunk by chunk inside the chunks' launches
@@ -215,10 +236,17 @@ int main(int argc, char **argv)
                     signal.change_frequency = false;
                     frequency_changed = false;
                     signal.frequency_changed = false;
+                    if (ext_tuner && signal.coarse_freq_offset != 0.0) {
+                        double listed = 0.0;
+                        bool found = false;
+                        for (const auto &mv : ext_moves) if (mv.first == buf_no) { listed = mv.second; found = true; }
+                        std::fprintf(log, "set_rf_ext %ld %.6f %s\n", buf_no, signal.coarse_freq_offset, found ? "listed" : "UNLISTED");
+                        if (found) signal.coarse_freq_offset = listed;
+                    }
                     signal.correct_resample = signal.coarse_freq_offset / rf_frequency;
                     rf_frequency += signal.coarse_freq_offset;
                     tuner_hz += signal.coarse_freq_offset;                   // mir_sdr_SetRf: the recording cannot be re-tuned, the demodulator's
-                    demodulator.set_tuner(tuner_hz);                         // extra NCO term stands in for the local oscillator
+                    if (!ext_tuner) demodulator.set_tuner(tuner_hz);         // extra NCO term stands in for the local oscillator
                     std::fprintf(log, "set_rf %.3f\n", tuner_hz);
                 }
             };
@@ -229,7 +257,7 @@ int main(int argc, char **argv)
                 signal.reset = false;
                 rf_frequency = ch_frequency;
                 tuner_hz = 0;
-                demodulator.set_tuner(0.0);
+                if (!ext_tuner) demodulator.set_tuner(0.0);
                 signal.coarse_freq_offset = 0.0;
                 signal.change_frequency = true;
                 signal.correct_resample = 0.0;
@@ -242,6 +270,7 @@ int main(int argc, char **argv)
             reset();
             const auto t_begin = std::chrono::steady_clock::now();
             for (size_t pos = 0; pos + (size_t)buf_len <= vi.size(); pos += (size_t)buf_len) {
+                buf_no = (long)(pos / (size_t)buf_len);
                 frequency_changed = true;                                    // rf_changed / gr_changed arrive with the next packets (:216-223)
                 gain_changed = true;
                 if (signal.reset) { reset(); continue; }                     // :229-235 (the buffer is dropped)
@@ -254,7 +283,15 @@ int main(int argc, char **argv)
                              st.guard_interval_size, (long)st.symbols, (long)st.frames, (long)st.resets, st.level_detect, signal.coarse_freq_offset,
                              st.frequency_est_filtered, st.arbitrary_resample);
             }
+            demodulator.flush();
             ldpc.flush();
+            if (const char *tp = std::getenv("STAGE_TRACE")) {
+                long n = demodulator.trace_count();
+                if (n > 65536) n = 65536;
+                std::FILE *f = std::fopen(tp, "wb");
+                if (f) { std::fwrite(trace.data(), sizeof(double), (size_t)n * T2GPU_DEMOD_TRACE_W, f); std::fclose(f); }
+                demodulator.set_trace(nullptr, 0);
+            }
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             std::fprintf(log, "bbframes %ld ts %zu\n", bbframes, ts.size());
             std::fprintf(log, "wall %.3f s for %zu samples = %.2f Msamples/s (real time: 9.14)\n", secs, vi.size(), vi.size() / secs / 1e6);

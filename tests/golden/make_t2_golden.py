@@ -245,10 +245,42 @@ def case_rx(_):
             "state_log": np.array([[s[k] for k in ol.RX_STATE] for s in log], np.float64)}
 
 
+def case_rxoff(name):
+    """The reference's whole receiver, every loop closed, on a recording with a carrier offset behind an emulated tuner and with a receiver
+    clock that is off (tests/ref_cases.py, RX_OFFSET_CASES): the tuner moves it asked for, the loop trajectory symbol by symbol (private
+    members read when replace_null_indicator is emitted, dvbt2_demodulator.cpp:429-444), the state after every execute(), a sample of
+    every TI block's cells, the BBFRAMEs and the TS."""
+    c, m, bi, bq, sent = rc.rx_offset_case(name)
+    tmp = tempfile.mkdtemp()
+    r = ol.RefRx(os.path.join(tmp, "rx.ts"), sample_rate=rc.rx_offset_sample_rate(c))
+    for w in (1, 2, 4):
+        r.keep(w, False)
+    log, moves = r.run_recording_tuned(bi, bq, c["buf"], c["cfo_hz"], c["tuner_step"])
+    traj = r.traj()
+    ti = r.taps(0)
+    bb = r.taps(3)
+    msgs = [bytes(b).decode() for _, b in r.taps(5)]
+    ts = r.ts()
+    pk = ts[:ts.size // 188 * 188].reshape(-1, 188)
+    want = {bytes(p) for f in sent for p in f}
+    sent_ok = np.array([bytes(p) in want for p in pk])
+    step = rc.RX_OFFSET_TI_STEP
+    states = np.array([[s[k] for k in ol.RX_STATE] for s in log], np.float64)
+    col = {k: i for i, k in enumerate(ol.RX_STATE)}
+    # dvbt2.fft_size / guard_interval_size are uninitialised memory in the reference until the first decoded P1 (init_dvbt2): not data
+    states[states[:, col["p2_init"]] == 0, col["guard_interval_size"]] = 0
+    states[states[:, col["p2_init"]] == 0, col["fft_size"]] = 0
+    return {"base_sha": np.array(rc.sha(np.stack([bi, bq]))), "moves": np.array(moves, np.float64).reshape(-1, 3), "traj": traj,
+            "state_log": states,
+            "ti_meta": np.array([meta[:2] for meta, _ in ti], np.int32).reshape(-1, 2), "ti_sample": np.stack([cells[::step] for _, cells in ti]),
+            "bbframes": np.int32(len(bb)), "bb_crc": rc.crc_rows(np.stack([x[1] for x in bb])), "messages": np.array(msgs),
+            "ts_len": np.int64(ts.size), "ts_packet_crc": rc.crc_rows(pk), "ts_packets_sent": np.int64(sent_ok.sum())}
+
+
 KINDS = {"sym": (case_sym, list(rc.SYM_MODES)), "p1": (case_p1, ["p1"]), "fec": (case_fec, list(rc.FEC_CASES)), "bbdh": (case_bbdh, ["bbdh"]),
          "ldpc_in": (case_ldpc_in, list(rc.LDPC_IN_CASES)), "carry": (case_carry, list(rc.CARRY_CASES)),
-         "front": (case_front, ["front"]), "rx": (case_rx, ["rx"])}
-FILES = {"t2sym_golden.npz": ("sym", "p1"), "t2fec_golden.npz": ("fec", "bbdh"), "t2rx_golden.npz": ("front", "rx"),
+         "front": (case_front, ["front"]), "rx": (case_rx, ["rx"]), "rxoff": (case_rxoff, list(rc.RX_OFFSET_CASES))}
+FILES = {"t2sym_golden.npz": ("sym", "p1"), "t2fec_golden.npz": ("fec", "bbdh"), "t2rx_golden.npz": ("front", "rx", "rxoff"),
          "t2batch_golden.npz": ("ldpc_in", "carry")}
 
 

@@ -820,6 +820,58 @@ class RefRx(_Taps):
         self.L.ref_rx_close(self.h)
         return np.fromfile(self.ts_path, np.uint8)
 
+    TRAJ = ("next_symbol_type", "idx_symbol", "chunk", "phase_est_filtered", "frequency_est_filtered", "sample_rate_est_filtered", "resample",
+            "phase_nco", "frequency_nco", "old_sample_rate_est", "sample_rate_offset_hz", "frequency_offset_hz", "phase_integral", "phase_k_p",
+            "frequency_integral", "frequency_k_p")
+
+    def traj(self):
+        """Per symbol that reached the tracking loops (dvbt2_demodulator.cpp:429-444), behind their update: [n][len(TRAJ)] float64."""
+        self.L.ref_rx_traj.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        n = self.L.ref_rx_traj(self.h, None, 0)
+        out = np.zeros((n, len(self.TRAJ)), np.float64)
+        if n:
+            self.L.ref_rx_traj(self.h, out.ctypes.data, n)
+        return out
+
+    def run_recording_tuned(self, base_i, base_q, buf, cfo_hz, tuner_step):
+        """rx_sdrplay::start's loop over a recording behind an EMULATED TUNER (tests/ref_cases.py, RX_OFFSET_CASES): when the demodulator
+        asks for a move of the local oscillator (change_frequency, coarse_freq_offset) the SDR thread's bookkeeping runs as in
+        rx_sdrplay.cpp:158-176 and from that buffer on the recording is rotated by the move, rounded to a multiple of tuner_step.
+        Returns (per-buffer states, moves = [(buffer index, requested Hz, tuner total Hz)])."""
+        import t2_tx
+        s = self.sig
+        rf = [626.0e6]
+        tuned = [0.0]
+        moves = []
+
+        def reset():
+            s[7] = 0; s[1] = 0.0; s[0] = 1; s[6] = 0.0; s[4] = 0; s[3] = 1
+            rf[0] = 626.0e6
+
+        def set_rf(k):
+            if not s[2]:
+                s[2] = 1
+            if s[0]:
+                s[0] = 0; s[2] = 0
+                s[6] = s[1] / rf[0]
+                rf[0] += s[1]
+                if s[1] != 0.0:
+                    tuned[0] += tuner_step * np.rint(s[1] / tuner_step)
+                    moves.append((k, float(s[1]), tuned[0]))
+        reset()
+        set_rf(0)
+        log = []
+        for k in range(len(base_i) // buf):
+            if s[7]:
+                reset(); set_rf(k)
+                continue
+            set_rf(k)
+            s[5] = 1
+            i16, q16 = t2_tx.rx_offset_rotate(base_i[k * buf:(k + 1) * buf], base_q[k * buf:(k + 1) * buf], k * buf, cfo_hz - tuned[0])
+            self.execute(i16, q16)
+            log.append(self.state())
+        return log, moves
+
     def run_recording(self, i16, q16, buf):
         """rx_sdrplay::start's loop (rx_sdrplay.cpp:135-261) over a recording: reset(), then per buffer set_rf_frequency /
         set_gain bookkeeping and execute(). A recording cannot be re-tuned, so it must carry no carrier offset worth a re-tune

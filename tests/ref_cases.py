@@ -186,6 +186,40 @@ def rx_stream():
                                 RX_STREAM["plp"])
 
 
+# ------------------------------------------------------------------------------------------------ whole receiver, loops closed under offsets
+# What VERDICT r5 found missing: the path `drop_in` times -- 32K, every loop closed -- held to the reference's own dvbt2_demodulator on the
+# same samples, under a carrier offset and a sample-rate offset. name: OFDM mode (ora_mode arguments), L1-post size, P1 S2 field, PLP
+# (modulation, FEC type, code rate, SNR dB: modes that DECODE in the reference's arithmetic), T2 frames, seed, carrier offset of the
+# recording in Hz, sample_rate handed to the demodulator's constructor minus the true 64e6 / 7 in Hz (a receiver clock that is off: what
+# the sample-rate tracker must find, dvbt2_demodulator.cpp:430-439; float32 sample rates are 1 Hz = 0.11 ppm apart), samples per
+# execute() call, frequency step of the emulated tuner in Hz.
+# The tuner: the reference asks the SDR thread to move the local oscillator by P1's coarse estimate whenever it is 10 Hz or more
+# (dvbt2_demodulator.cpp:291-305, rx_sdrplay.cpp:158-176) and goes no further until it is less. A recording has no tuner, so the harness
+# emulates one: the move is applied to the recording itself (t2_tx.rx_offset_rotate) from the next buffer on, rounded to a multiple of
+# `tuner_step` -- a synthesizer of finite resolution -- which leaves a residual of a few Hz for the frequency loop to pull in (with a perfect
+# tuner the loops would idle). The fixture records the moves the REFERENCE asked for; the product is fed the very same samples.
+RX_OFFSET_CASES = {
+    "rx32k": dict(mode=(5, 1, 6, 4, 0, 59), lps=350, s2=10, plp=(2, 1, 2, 20.0), n_frames=17, seed=3201, cfo_hz=77.0, rate_off_hz=18.0,
+                  buf=172032, tuner_step=12.0),
+    "rx16k": dict(mode=(4, 1, 6, 0, 0, 24), lps=400, s2=8, plp=(2, 0, 0, 18.0), n_frames=16, seed=1601, cfo_hz=-64.0, rate_off_hz=-9.0,
+                  buf=172032, tuner_step=12.0),
+}
+
+
+RX_OFFSET_TI_STEP = 4099          # every 4099th cell of a TI block goes into the fixture (a prime: walks through all symbols / FEC blocks)
+
+
+def rx_offset_case(name):
+    """(case dict, mode object, base I, base Q, TS packets sent per frame) -- the recording before the tuner (t2_tx.rx_offset_tuned)."""
+    c = RX_OFFSET_CASES[name]
+    m, i16, q16, sent = t2_tx.rx_offset_base(c["mode"], c["lps"], c["s2"], c["plp"], c["n_frames"], c["seed"])
+    return c, m, i16, q16, sent
+
+
+def rx_offset_sample_rate(c):
+    return float(np.float32(64.0e6 / 7.0) + np.float32(c["rate_off_hz"]))
+
+
 # ------------------------------------------------------------------------------------------------ LDPC stage input (256-QAM payload pin)
 # The reference's own 256-QAM demapper never hands a decodable batch to its LDPC stage: the hard-decision SNR estimate saturates and
 # the truncating int8 cast wraps the outer constellation points (llr_demapper.cpp:564-737; DESIGN.md section 3 has the command that

@@ -455,3 +455,51 @@ def rx_test_stream(n_frames, seed, cfo_hz, spoil_frame=None, l1_post_mod=0, plp=
     per_frame = (nb * dfl_bytes) // 187 - 1
     marks = [ts[f * per:f * per + per_frame - 1].tobytes() for f in range(n_frames)]
     return m, i16, q16, buf, marks
+
+
+# ------------------------------------------------------------------------------------------------ closed-loop streams with offsets
+FS = 64.0e6 / 7.0
+
+
+def rx_offset_base(mode, lps, s2, plp, n_frames, seed):
+    """int16 I/Q of n_frames T2 frames of `mode` (ora_mode arguments) with one PLP plp = (modulation, fec type, code rate, SNR dB), real L1
+    signalling (QPSK L1-post), a different TS payload in every frame, AWGN -- WITHOUT carrier offset (rx_offset_rotate adds it, together
+    with what an emulated tuner has taken off again). Returns (mode object, I, Q, TS packets per frame [n_frames][per][188])."""
+    mod, fec_type, code_rate, snr = plp
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    cpf = (64800 if fec_type else 16200) // (2 * (mod + 1))
+    nb = plp_blocks_per_frame(m, lps, cpf)
+    k_bch = K_BCH[cid]
+    per = nb * (k_bch // 1496 + 1)
+    guard = {0: m.fft_size // 32, 1: m.fft_size // 16, 2: m.fft_size // 8, 3: m.fft_size // 4, 4: m.fft_size // 128}[mode[3]]
+    frames, sent = [], []
+    for f in range(n_frames):
+        ts = ts_packets(per, seed + 1000 * (f + 1))
+        cells, _, _ = build_plp_frame_cells(cid, mod, fec_type, code_rate, ts, nb)
+        frames.append(build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0,
+                                  l1_cells=l1_cells(mode, lps, mod, fec_type, code_rate, nb, frame_idx=f)))
+        sent.append(ts)
+    i16, q16, _ = iq_stream(frames, guard, s2, snr, seed)
+    return m, i16, q16, np.stack(sent)
+
+
+def rx_offset_rotate(base_i, base_q, start, hz, phase0=0.7):
+    """Samples [start, start + len) of the recording as a tuner that is `hz` away from the carrier delivers them: base * exp(j (2 pi hz n / fs
+    + phase0)) with the absolute sample index n, rounded to int16. Deterministic given (base, start, hz)."""
+    n = np.arange(start, start + len(base_i), dtype=np.float64)
+    x = (base_i.astype(np.float64) + 1j * base_q.astype(np.float64)) * np.exp(1j * (2 * np.pi * hz / FS * n + phase0))
+    return (np.clip(np.rint(x.real), -32768, 32767).astype(np.int16), np.clip(np.rint(x.imag), -32768, 32767).astype(np.int16))
+
+
+def rx_offset_tuned(base_i, base_q, buf, cfo_hz, moves):
+    """The whole recording as buffers of `buf` samples behind an emulated tuner: carrier offset cfo_hz, and from buffer k on the tuner has
+    moved by hz_total (moves = [(k, hz_total), ...], ascending k). The tail that does not fill a buffer is dropped."""
+    n_buf = len(base_i) // buf
+    out_i, out_q = np.empty(n_buf * buf, np.int16), np.empty(n_buf * buf, np.int16)
+    edges = [0] + [k for k, _ in moves] + [n_buf]
+    tuned = [0.0] + [hz for _, hz in moves]
+    for a, b, t in zip(edges[:-1], edges[1:], tuned):
+        if b > a:
+            out_i[a * buf:b * buf], out_q[a * buf:b * buf] = rx_offset_rotate(base_i[a * buf:b * buf], base_q[a * buf:b * buf], a * buf, cfo_hz - t)
+    return out_i, out_q

@@ -342,56 +342,3 @@ def test_the_loop_filters_on_the_device_are_the_hosts(torch_cuda):
         assert bits(h_small.numpy()[6:7])[0] == bits(want_pe), (k, h_small[6], want_pe)
         assert bits(h_small.numpy()[7:8])[0] == bits(want_fe), (k, h_small[7], want_fe)
     ctx.close(); fe_obj.close(); loops.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("id_device", [0, 1])
-def test_call_statistics_ahead_of_the_chunks(torch_cuda, id_device):
-    """t2gpu_front_call_begin / _call_level: c1 / c2 / level_detect of an execute() (dvbt2_demodulator.cpp:227-235) from ONE pass over its
-    buffer at its head against the chunks' own sums (held-IQ mode, t2gpu_front_commit_iq) -- the same recurrence and the same
-    double-precision sums composed per 4096 samples from the call's start instead of per chunk: equal to 1e-7 relative (a last bit of the
-    float quotient at most); the commit of a call with a look-ahead leaves exactly the look-ahead's values; the first call and a call with
-    a reset of the loops on the way go without (0 / cancelled) and the call behind them is covered again."""
-    import ctypes
-    from sdr_receiver_dvb_t2_amd import front
-    torch = torch_cuda
-    chunks = [33024, 33024, 17000, 1, 40000, 2047, 33024, 13912]
-    n = sum(chunks)
-    assert n == 172032
-    a, b = front.front_end(id_device=id_device, max_samples=n), front.front_end(id_device=id_device, max_samples=n)
-    s = torch.cuda.current_stream().cuda_stream
-    for f in (a, b):
-        assert f._l.t2gpu_front_hold_iq(f.h, 1) == 0
-    out = torch.zeros(n + 64, dtype=torch.complex64, device="cuda")
-    took = []
-    for call in range(5):
-        i_in, q_in = iq16(n * a.stride, 900 + call)
-        i_in = (i_in.astype(np.int32) + 37).clip(-32768, 32767).astype(np.int16)      # a dc offset for the averagers to find
-        d_i, d_q = torch.from_numpy(i_in).cuda(), torch.from_numpy(q_in).cuda()
-        rc = a._l.t2gpu_front_call_begin(a.h, d_i.data_ptr(), d_q.data_ptr(), n, s)
-        assert rc in (0, 1)
-        took.append(rc)
-        ahead = np.zeros(3, np.float32)
-        if rc == 1 and call != 3:
-            assert a._l.t2gpu_front_call_level(a.h, ahead.ctypes.data) == 0          # long before the chunks: nothing of them has been launched
-        pos = 0
-        for k, c in enumerate(chunks):
-            for f in (a, b):
-                f.execute_dev(d_i[pos * f.stride:], d_q[pos * f.stride:], [c], out, None, np.float32([1e-4]), None)
-            if call == 3 and k == 2:                                                   # dvbt2_demodulator::reset on the way: the averagers start again
-                for f in (a, b):
-                    assert f._l.t2gpu_front_reset_loops(f.h) == 0
-                assert a._l.t2gpu_front_call_level(a.h, ahead.ctypes.data) == 1       # cancelled
-            pos += c
-        for f in (a, b):
-            assert f._l.t2gpu_front_commit_iq(f.h, s) == 0
-        sa, sb = a.state(), b.state()
-        for key in ("c1", "c2", "level_detect"):
-            assert abs(sa[key] - sb[key]) <= 1e-7 * max(abs(sb[key]), 1e-3), (call, key, sa[key], sb[key])
-        assert abs(sa["dc_re"] - sb["dc_re"]) < 1e-9 and abs(sa["dc_im"] - sb["dc_im"]) < 1e-9
-        if rc == 1 and call != 3:
-            assert bits(np.float32(sa["c1"])) == bits(ahead[0]) and bits(np.float32(sa["c2"])) == bits(ahead[1])
-            assert bits(np.float32(sa["level_detect"])) == bits(ahead[2])
-    assert took == [0, 1, 1, 1, 1]
-    assert b._l.t2gpu_front_call_begin(b.h, d_i.data_ptr(), d_q.data_ptr(), 1 << 21, s) == 0      # longer than the look-ahead takes: goes without
-    a.close(); b.close()

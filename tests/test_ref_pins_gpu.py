@@ -408,3 +408,152 @@ def test_whole_receiver_against_the_reference(built, grx, tmp_path):
     # and frame for frame: every frame the reference recovered after frame 5 is recovered here
     found = [f for f in range(len(marks)) if ts.tobytes().find(marks[f]) >= 0]
     assert set(int(f) for f in g["frames_found"] if f >= 6) <= set(found), (found, g["frames_found"])
+
+
+# ------------------------------------------------------------------------------------------------ whole receiver, loops closed under offsets
+def _build_stage_driver(tmp_path):
+    exe = str(tmp_path / "stage_mirror_test")
+    pkg = os.path.join(ol.ROOT, "sdr_receiver_dvb_t2_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ol.ROOT, "include"),
+                           os.path.join(ol.ROOT, "tests", "cpp", "stage_mirror_test.cpp"), "-L" + pkg, "-lt2gpu", "-Wl,-rpath," + pkg, "-o", exe])
+    return exe
+
+
+# What the product may differ by from the reference's trajectory, and why (measured on an MI355X in round 6, `pytest -s` prints them):
+#   The loop FILTERS are the reference's float operations bit for bit (tests/test_front_gpu.py); what enters them is not: the guard
+#   correlation is a double-precision tree sum here and a sequential float sum there (2e-5 relative), the spectrum comes from a different FFT
+#   (2e-5 rms against FFTW), the dc averager is a scan in double (2e-6). A symbol's raw estimates therefore agree with the reference's to
+#   float precision at the start (|d phase_est| 2e-7 rad on the first symbols) and drift apart slowly: a difference of 1e-9 rad / sample in
+#   frequency_est_filtered is 3e-5 rad of phase per 32K symbol. Two parts of the reference turn such last-digit differences into discrete
+#   ones: the sample-rate tracker steps by 8e-9 on the SIGN of the difference of two successive noisy estimates (dvbt2_demodulator.cpp:
+#   430-439) and never corrects -- it walks -- and the equaliser's phase unwrapping (data_symbol.cpp:189-191) is discontinuous at pi. So the
+#   two receivers are held to each other TIGHTLY over the first RXOFF_HEAD tracked symbols (same chunk lengths, same tracker steps, loop
+#   values to 1e-4) -- which is what shows they are the same function of the samples -- and LOOSELY afterwards (both stay locked on the same
+#   carrier and clock; the tracker's walk may end tens of steps apart), and exactly again behind the FEC: the BBFRAMEs and the transport
+#   stream are the reference's, packet for packet.
+RXOFF_HEAD = 100
+RXOFF_TOL = dict(
+    head=dict(chunk=0, rate_steps=0, phase=2.0e-4, freq_rel=1.0e-3, phase_est=3.0e-3),     # measured: 0, 0, 5.0e-5, 1.9e-4, 6.0e-4 (rx32k)
+    chunk=4,               # input samples of a whole-symbol chunk (nearbyint of est_chunk * arbitrary_resample * 2: moves with the tracker's value); measured 2
+    p1_samples=8,          # ... of the chunk that completes a frame's P2 symbol: it starts where the P1 detector put the frame, and the
+                           # detector's correlation peak is flat-topped (recursive float running sums there, sliding sums here); measured 0
+    phase=1.0,             # |phase_est_filtered - reference| in rad over the whole stream; measured 0.32 (rx32k), 0.039 (rx16k)
+    freq_rel=0.1,          # |frequency_est_filtered - reference| relative to the tracked value (41 Hz / -40 Hz); measured 0.031, 0.012
+    rate_steps=150,        # |sample_rate_est_filtered - reference| in the tracker's steps of 8e-9; measured 68, 8
+    ti_cells=5.0e-2,       # de-interleaved cells against the reference's (unit-power constellation; the noise at 18 - 20 dB is 1e-1)
+)
+
+
+@pytest.mark.parametrize("name", list(rc.RX_OFFSET_CASES))
+def test_closed_loop_trajectory_against_the_reference(built, grx, tmp_path, name):
+    """VERDICT r5's parity hole: the slot-shaped path with every loop closed -- 32K (and a 16K twin), the loops on the device and on the host
+    -- against what the REFERENCE's dvbt2_demodulator::execute did on the same samples (fixture rxoff/*, made by tests/golden/
+    make_t2_golden.py from the compiled reference): a recording with a 77 Hz (-64 Hz) carrier offset behind an emulated tuner, a
+    receiver clock that is 2 ppm (-1 ppm) off, 172 032-sample buffers, nothing configured. Held to the reference: the re-tune requests
+    (same buffers, the estimate within 1 Hz), the acquisition state after every execute(), the loop trajectory symbol by symbol (chunk
+    lengths, phase_est_filtered, frequency_est_filtered, sample_rate_est_filtered), the de-interleaved cells of every TI block, the
+    BBFRAMEs and the transport stream packet for packet. The two forms of the product (loops on the device / on the host) must agree
+    with each other bit for bit."""
+    g = sub(grx, "rxoff", name)
+    c, m, bi, bq, sent = rc.rx_offset_case(name)
+    same_input = rc.sha(np.stack([bi, bq])) == str(g["base_sha"])
+    moves = g["moves"]
+    i16, q16 = t2_tx.rx_offset_tuned(bi, bq, c["buf"], c["cfo_hz"], [(int(k), float(t)) for k, _, t in moves])
+    i16.tofile(tmp_path / "i.s16")
+    q16.tofile(tmp_path / "q.s16")
+    exe = _build_stage_driver(tmp_path)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    env.update(STAGE_SAMPLE_RATE_OFF=repr(float(c["rate_off_hz"])), STAGE_TUNER_MOVES=",".join("%d:%.17g" % (int(k), r) for k, r, _ in moves),
+               T2GPU_DEMOD_STRICT_LOOPS="1", STAGE_THREADS="1")
+    runs = {}
+    for loop in ("1", "0"):
+        tag = "dev" if loop == "1" else "host"
+        e = dict(env, STAGE_DEVICE_LOOP=loop, STAGE_TRACE=str(tmp_path / ("trace_%s.f64" % tag)), STAGE_DUMP=str(tmp_path / ("dump_%s" % tag)))
+        p = subprocess.run([exe, "rx", str(tmp_path / "i.s16"), str(tmp_path / "q.s16"), str(tmp_path / ("out_%s.ts" % tag)), str(c["buf"]), "0",
+                            str(tmp_path / ("log_%s.txt" % tag))], env=e, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr
+        runs[tag] = dict(trace=np.fromfile(tmp_path / ("trace_%s.f64" % tag), np.float64).reshape(-1, 11), ts=np.fromfile(tmp_path / ("out_%s.ts" % tag), np.uint8),
+                         log=open(tmp_path / ("log_%s.txt" % tag)).read())
+    if os.environ.get("RXOFF_SAVE"):                                            # (development: keep what the runs wrote for a look on another machine)
+        import shutil
+        os.makedirs(os.environ["RXOFF_SAVE"], exist_ok=True)
+        for tag in runs:
+            for fn in ("trace_%s.f64" % tag, "log_%s.txt" % tag, "out_%s.ts" % tag):
+                shutil.copy(tmp_path / fn, os.path.join(os.environ["RXOFF_SAVE"], name + "_" + fn))
+        ti_all = np.fromfile(str(tmp_path / "dump_dev") + ".ti.c64", np.complex64)
+        np.save(os.path.join(os.environ["RXOFF_SAVE"], name + "_ti_sample.npy"), ti_all[::rc.RX_OFFSET_TI_STEP])
+    # ---- the product's two forms: the same trajectory, the same bytes
+    assert np.array_equal(runs["dev"]["trace"].view(np.uint64), runs["host"]["trace"].view(np.uint64)), "loops on the device / on the host: different trajectories"
+    assert np.array_equal(runs["dev"]["ts"], runs["host"]["ts"])
+    r = runs["dev"]
+    # ---- the tuner: asked to move at the buffers the reference asked at, by what the reference asked for (its P1 estimate) within 1 Hz
+    asks = [ln.split() for ln in r["log"].splitlines() if ln.startswith("set_rf_ext")]
+    assert [int(a[1]) for a in asks] == [int(k) for k, _, _ in moves] and all(a[3] == "listed" for a in asks), (asks, moves)
+    worst_ask = max(abs(float(a[2]) - req) for a, (_, req, _) in zip(asks, moves))
+    assert worst_ask < 1.0, (asks, moves)
+    # ---- acquisition, execute() by execute()
+    lines = [dict(zip(ln.split()[2::2], ln.split()[3::2])) for ln in r["log"].splitlines() if ln.startswith("buf ")]
+    ref_state = [dict(zip(ol.RX_STATE, row)) for row in g["state_log"]]
+    assert len(lines) == len(ref_state)
+    for k, (a, b) in enumerate(zip(lines, ref_state)):
+        mine = (int(a["next"]), int(a["p2_init"]), int(a["init"]), int(a["deint"]), int(a["crc"]))
+        want = (int(b["next_symbol_type"]), int(b["p2_init"]), int(b["demodulator_init"]), int(b["deint_start"]), int(b["crc32_l1_pre"]))
+        assert mine == want, (k, mine, want)
+        if want[1]:
+            assert int(a["gi"]) == int(b["guard_interval_size"]), (k, a["gi"], b["guard_interval_size"])
+    # ---- the trajectory, symbol by symbol
+    t, w = r["trace"], g["traj"]
+    col = {n: i for i, n in enumerate(ol.RefRx.TRAJ)}
+    assert t.shape[0] == w.shape[0], (t.shape, w.shape)
+    assert np.array_equal(t[:, 1], w[:, col["next_symbol_type"]]) and np.array_equal(t[:, 2], w[:, col["idx_symbol"]])
+    # chunks: a chunk cut short by the end of an execute() buffer says where the BUFFER ended relative to the symbol, which moves with the
+    # P1 position by a few samples from frame to frame; whole-symbol chunks are compared (all but the ~1 in 5 that straddle two buffers)
+    nominal = np.median(t[:, 3])
+    whole = (t[:, 3] > nominal - 64) & (w[:, col["chunk"]] > nominal - 64)
+    is_p2 = t[:, 2] == 1
+    d_chunk = np.where(whole & ~is_p2, np.abs(t[:, 3] - w[:, col["chunk"]]), 0.0)
+    d_p1 = np.where(whole & is_p2, np.abs(t[:, 3] - w[:, col["chunk"]]), 0.0)
+    assert whole.mean() > 0.7, whole.mean()
+    # a symbol's raw phase estimate follows from the reference's filter state: 2 (phase_est_filtered - integral) / k_p (DSP/loop_filters.hh:36-44)
+    ref_phase_est = 2.0 * (w[:, col["phase_est_filtered"]] - w[:, col["phase_integral"]]) / w[:, col["phase_k_p"]]
+    d_phase = np.abs(t[:, 4] - w[:, col["phase_est_filtered"]])
+    d_freq = np.abs(t[:, 5] - w[:, col["frequency_est_filtered"]])
+    d_rate = np.abs(t[:, 6] - w[:, col["sample_rate_est_filtered"]]) / 8.0e-9
+    f_ref = np.abs(w[:, col["frequency_est_filtered"]]).max()
+    exact = dict(chunk=float((d_chunk == 0).mean()), phase=float((d_phase == 0).mean()), freq=float((d_freq == 0).mean()), rate=float((d_rate < 0.5).mean()))
+    print("closed loop %s: input %s; %d tracked symbols (%d whole-symbol chunks); re-tune estimates within %.3f Hz; max |d chunk| %d (P2: %d), |d phase_est_filtered| %.3e rad, "
+          "|d frequency_est_filtered| %.3e (%.3e of the tracked %.3e), |d sample_rate_est_filtered| %.1f steps; equal to the last bit: %s"
+          % (name, "identical to the fixture's" if same_input else "NOT the fixture's bits (this host's libm / FFT round differently)", t.shape[0], int(whole.sum()),
+             worst_ask, int(d_chunk.max()), int(d_p1.max()), d_phase.max(), d_freq.max(), d_freq.max() / f_ref, f_ref, d_rate.max(), exact))
+    H, tol_h = RXOFF_HEAD, RXOFF_TOL["head"]
+    head = dict(chunk=float(np.abs(t[:H, 3] - w[:H, col["chunk"]]).max()), rate_steps=float(d_rate[:H].max()), phase=float(d_phase[:H].max()),
+                freq_rel=float(d_freq[:H].max() / f_ref), phase_est=float(np.abs(t[:H, 8] - ref_phase_est[:H]).max()))
+    print("closed loop %s: the first %d tracked symbols against the reference: %s" % (name, H, head))
+    for k, v in head.items():
+        assert v <= tol_h[k], (k, v, tol_h[k])
+    assert np.array_equal(t[:H, 9].astype(np.float32) != 0, w[:H, col["old_sample_rate_est"]] != 0)
+    assert np.abs(t[:H, 9] - w[:H, col["old_sample_rate_est"]]).max() <= 2e-6 * np.abs(w[:H, col["old_sample_rate_est"]]).max()   # the symbols' sample-rate estimates
+    assert d_chunk.max() <= RXOFF_TOL["chunk"], d_chunk.max()
+    assert d_p1.max() <= RXOFF_TOL["p1_samples"], d_p1.max()
+    assert d_phase.max() <= RXOFF_TOL["phase"], d_phase.max()
+    assert d_freq.max() <= RXOFF_TOL["freq_rel"] * f_ref, (d_freq.max(), f_ref)
+    assert d_rate.max() <= RXOFF_TOL["rate_steps"], d_rate.max()
+    # the derived resampling value the reference holds (resample - sample_rate_est_filtered, :157): same nominal value, to a float's last bits
+    assert abs((t[-1, 7] + t[-1, 6]) - w[-1, col["resample"]]) < 1e-12
+    # ---- the de-interleaved cells of every TI block
+    ti = np.fromfile(str(tmp_path / "dump_dev") + ".ti.c64", np.complex64)
+    sizes = [int(s) for s, _ in g["ti_meta"]]
+    assert ti.size == sum(sizes), (ti.size, sizes)
+    pos, worst = 0, 0.0
+    for b, n in enumerate(sizes):
+        worst = max(worst, float(np.abs(ti[pos:pos + n][::rc.RX_OFFSET_TI_STEP] - g["ti_sample"][b][:len(ti[pos:pos + n][::rc.RX_OFFSET_TI_STEP])]).max()))
+        pos += n
+    print("closed loop %s: %d TI blocks, sampled cells within %.3e of the reference's" % (name, len(sizes), worst))
+    assert worst < RXOFF_TOL["ti_cells"], worst
+    # ---- behind the FEC: the reference's BBFRAMEs and its transport stream, packet for packet
+    ts = r["ts"]
+    assert ts.size == int(g["ts_len"]), (ts.size, int(g["ts_len"]))
+    assert np.array_equal(rc.crc_rows(ts[:ts.size // 188 * 188].reshape(-1, 188)), g["ts_packet_crc"])
+    last = [ln for ln in r["log"].splitlines() if ln.startswith("bbframes ")][-1].split()
+    assert int(last[1]) == int(g["bbframes"]), (last, int(g["bbframes"]))
