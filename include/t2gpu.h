@@ -634,7 +634,7 @@ typedef struct {
 typedef struct t2gpu_demod t2gpu_demod;
 t2gpu_demod *t2gpu_demod_create(int id_device, float sample_rate, int device);
 void t2gpu_demod_destroy(t2gpu_demod *h);
-int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *signals);
+int t2gpu_demod_connect(t2gpu_demod *h, const t2gpu_demod_signals *callbacks);   /* (not `signals`: a macro wherever Qt headers are included) */
 int t2gpu_demod_execute(t2gpu_demod *h, int len_in, const int16_t *i_in, const int16_t *q_in, t2gpu_signal_estimate *signal_);
 int t2gpu_demod_set_tuner(t2gpu_demod *h, double offset_hz);
 /* The tracking loops of a frame's data symbols on the device (on = 1, the DEFAULT: a symbol's launches are followed by the next chunk's

@@ -354,12 +354,12 @@ private:
     void run_merged()                                            // the stage's own thread, merged form
     {
         for (;;) {
-            bool emit = false;
+            bool hand_on = false;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_work_.wait(lk, [this] { return stop_ || ((!gfifo_.empty() || forming_) && !error_); });
                 if (stop_) return;
-                if (!gfifo_.empty()) emit = true;
+                if (!gfifo_.empty()) hand_on = true;
                 else {
                     // nothing in flight and a group forming: launched when the burst is over (no addition for linger_), or at once in a flush
                     const auto ripe_at = forming_->last_add + linger_;
@@ -369,7 +369,7 @@ private:
                     continue;
                 }
             }
-            if (!emit) continue;
+            if (!hand_on) continue;
             try {
                 emit_group_front();
             } catch (...) {
@@ -640,13 +640,13 @@ private:
             if (done < 0) fail("t2gpu_ti_push");
             cells += take; n -= take; pos_ += take;
             if (done == 1) {
-                emit(b.size, l.out[l.cur].data(), b.plp, h);
+                hand_over(b.size, l.out[l.cur].data(), b.plp, h);
                 l.cur ^= 1;
                 ++k_;
             }
         }
     }
-    void emit(int size, complex *cells, int plp, t2gpu_ti *h)
+    void hand_over(int size, complex *cells, int plp, t2gpu_ti *h)
     {
         if (!threaded_) { if (ti_block) ti_block(size, cells, plp, l1_post_); return; }
         std::unique_lock<std::mutex> lk(m_);

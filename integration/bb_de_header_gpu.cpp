@@ -5,6 +5,11 @@
 // need_plp); what comes back is the run of transport-stream bytes the reference would have written for this BBFRAME, and it goes out the
 // way the reference sends it: one UDP datagram or one write to the file (:433-443). Messages as the reference words them.
 // (The text block set_info builds for the GUI once per PLP, :452-498, is not produced by this body.)
+#include <QDataStream>
+#include <QFile>
+#include <QHostAddress>
+#include <QUdpSocket>
+
 #include "bb_de_header.h"          // the reference's
 #include "t2gpu_ref_glue.h"
 

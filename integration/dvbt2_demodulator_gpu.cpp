@@ -23,8 +23,8 @@ std::vector<dynamic_plp> post_dyn[2];
 int post_cur = 0;
 }
 
-// a struct that is a friend of nothing: the callbacks are static member-like free functions that reach the private members through a
-// local derived accessor -- in the reference's tree they would simply be private static members of dvbt2_demodulator
+// the ABI's plain L1-post structs back into the reference's (the callbacks below are lambdas inside the member function, so they reach the
+// class's private members as any member does; in the reference's tree they would be private static members)
 struct dvbt2_demodulator_gpu_access {
     static l1_postsignalling unpack(const t2gpu_l1_post *post, const t2gpu_l1_plp *plp, const t2gpu_l1_dyn_plp *dyn)
     {

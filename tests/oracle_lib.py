@@ -776,8 +776,12 @@ class RefRx(_Taps):
     def available(strict=False):
         return _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx") is not None
 
-    def __init__(self, ts_path, id_device=0, sample_rate=64.0e6 / 7.0, need_plp=0, strict=False):
-        L = _ref_lib("ref_t2rx_strict" if strict else "ref_t2rx")
+    def __init__(self, ts_path, id_device=0, sample_rate=64.0e6 / 7.0, need_plp=0, strict=False, lib=None):
+        """lib: another build of the same driver -- "ref_t2rx_gpufec" / "ref_t2rx_gpu": the reference's objects with the slot bodies of
+        integration/*_gpu.cpp (libt2gpu.so behind the reference's own signal flow; oracle/Makefile, target `binding`)."""
+        L = _ref_lib(lib or ("ref_t2rx_strict" if strict else "ref_t2rx"))
+        if L is None:
+            raise OSError("oracle/_ref/lib%s.so does not load here" % (lib or "ref_t2rx"))
         L.ref_rx_new.restype = ctypes.c_void_p
         L.ref_rx_new.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_char_p, ctypes.c_int]
         L.ref_rx_keep.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]

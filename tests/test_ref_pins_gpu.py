@@ -440,7 +440,10 @@ RXOFF_TOL = dict(
     phase=1.0,             # |phase_est_filtered - reference| in rad over the whole stream; measured 0.32 (rx32k), 0.039 (rx16k)
     freq_rel=0.1,          # |frequency_est_filtered - reference| relative to the tracked value (41 Hz / -40 Hz); measured 0.031, 0.012
     rate_steps=150,        # |sample_rate_est_filtered - reference| in the tracker's steps of 8e-9; measured 68, 8
-    ti_cells=5.0e-2,       # de-interleaved cells against the reference's (unit-power constellation; the noise at 18 - 20 dB is 1e-1)
+    ti_cells_first=2.0e-3, # de-interleaved cells of the FIRST TI block against the reference's (unit-power constellation): measured 3.1e-4, 2.3e-4
+    ti_cells=0.25,         # ... of every TI block: once the trackers have walked apart (68 steps = 5e-7 = one sample by the end of a 32K frame)
+                           # the FFT windows sit a sample apart and the pilot interpolation leaves different residues; measured 7.6e-2, at a
+                           # noise of 1e-1 (20 dB) -- what counts there is the LDPC's output, which is identical
 )
 
 
@@ -545,12 +548,13 @@ def test_closed_loop_trajectory_against_the_reference(built, grx, tmp_path, name
     ti = np.fromfile(str(tmp_path / "dump_dev") + ".ti.c64", np.complex64)
     sizes = [int(s) for s, _ in g["ti_meta"]]
     assert ti.size == sum(sizes), (ti.size, sizes)
-    pos, worst = 0, 0.0
+    pos, per_block = 0, []
     for b, n in enumerate(sizes):
-        worst = max(worst, float(np.abs(ti[pos:pos + n][::rc.RX_OFFSET_TI_STEP] - g["ti_sample"][b][:len(ti[pos:pos + n][::rc.RX_OFFSET_TI_STEP])]).max()))
+        mine = ti[pos:pos + n][::rc.RX_OFFSET_TI_STEP]
+        per_block.append(float(np.abs(mine - g["ti_sample"][b][:len(mine)]).max()))
         pos += n
-    print("closed loop %s: %d TI blocks, sampled cells within %.3e of the reference's" % (name, len(sizes), worst))
-    assert worst < RXOFF_TOL["ti_cells"], worst
+    print("closed loop %s: %d TI blocks, sampled cells within %s of the reference's" % (name, len(sizes), " ".join("%.1e" % v for v in per_block)))
+    assert per_block[0] < RXOFF_TOL["ti_cells_first"] and max(per_block) < RXOFF_TOL["ti_cells"], per_block
     # ---- behind the FEC: the reference's BBFRAMEs and its transport stream, packet for packet
     ts = r["ts"]
     assert ts.size == int(g["ts_len"]), (ts.size, int(g["ts_len"]))
