@@ -375,8 +375,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    # dry run of the N > 1 control flow on a one-GPU box: T2GPU_BENCH_ONE_DEVICE=1 puts every rank on device 0 and uses gloo (RCCL
-    # refuses two ranks on one device); the driver's runs use one GPU per rank and RCCL
+    # dry run of the N > 1 control flow on a one-GPU box: T2GPU_BENCH_ONE_DEVICE=1 puts every rank on device 0; the driver's runs use
+    # one GPU per rank. The path has no cross-GPU dependency (north_star: "no RCCL"): what the ranks exchange is the
+    # barrier around the timed region and two scalars (max seconds, sum of frames) -- over gloo, on CPU tensors, whatever the launcher;
+    # nothing of RCCL is initialised.
     one_device = os.environ.get("T2GPU_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local_rank = 0
@@ -384,10 +386,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: the loopback interface (the container's hostname may not resolve)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from sdr_receiver_dvb_t2_amd.receiver import t2_rx
 
@@ -515,7 +515,7 @@ def main():
         elapsed, stage_acc, ldpc_ms, ts_bytes, ts_kept = timed_leg(rx, steps, warmup, level, keep_ts=check_ts)
         ref_trials = rx.fetch_packed(count)[1] if full else None
         counters = rx.ts_counters() if full and not args.no_ts_end else None
-        max_s, units = aggregate_timing(elapsed, F * steps, dist if world > 1 else None, None if one_device else dev)
+        max_s, units = aggregate_timing(elapsed, F * steps, dist if world > 1 else None, None)
         rx.close()
 
         extra = {}

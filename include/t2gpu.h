@@ -769,6 +769,30 @@ int t2gpu_rx_sync_sums(t2gpu_rx *h, int n_frames, float *sync2);
 int t2gpu_rx_set_outer_code(t2gpu_rx *h, int enable);
 int t2gpu_rx_outer_code_status(t2gpu_rx *h, int n_fec_frames, int32_t *status);
 
+/* ---------------------------------------------------------------- several devices, one transport stream ---------------------------
+ * The reference is one process (rx_sdrplay.cpp:199-261 -> dvbt2_demodulator::execute): what it binds on a node with several GPUs is one
+ * object. A pool owns one t2gpu_rx per listed device (a device may be listed more than once) and one thread per member. t2gpu_rx_pool_execute
+ * takes HOST int16 I/Q of n_frames whole T2 frames (frame after frame, each starting at its P1 symbol: what t2gpu_rx_execute_dev takes in
+ * device memory; page-lock it with t2gpu_host_pin for the link's rate) and gives member k the contiguous frames t2gpu_rx_pool_share reports.
+ * Share boundaries are multiples of t2gpu_rx_pool_frame_alignment -- the smallest number of T2 frames that is a whole number of the
+ * reference's SIMD batches (llr_demapper.cpp:742-764) -- and n_frames must be a multiple of it (-3 otherwise): every batch of 32 FEC frames is
+ * then formed, decoded or dropped (ldpc_decoder.cpp:264-268) exactly as ONE sequential receiver would, whichever device it lands on. Nothing
+ * crosses between devices (no collective, no RCCL); the packed BBFRAMEs of the shares go, in member order = frame order,
+ * through ONE bb_de_header state machine (a TS packet straddles BBFRAMEs, bb_de_header.cpp:166-322), and t2gpu_rx_pool_ts_read hands out
+ * the transport stream: byte for byte what a single t2gpu_rx with t2gpu_rx_ts_enable(need_plp, 0) writes for the same frames.
+ * cfg->max_frames bounds a member's share per call. Returns: execute the FEC frames decoded by the call; -1 a stage failed on a member
+ * (t2gpu_last_error names the device), -2 as t2gpu_rx_execute_dev, -3 n_frames not aligned. counters: rows de-framed, rows dropped by the
+ * LDPC rule, BBHEADER CRC errors, frames skipped, TS packets flagged, resynchronisations; the seconds the last call's de-framing took. */
+typedef struct t2gpu_rx_pool t2gpu_rx_pool;
+t2gpu_rx_pool *t2gpu_rx_pool_create(const t2gpu_rx_config *cfg, const int *devices, int n_devices, int need_plp);
+void t2gpu_rx_pool_destroy(t2gpu_rx_pool *p);
+int t2gpu_rx_pool_frame_alignment(const t2gpu_rx_pool *p);
+int t2gpu_rx_pool_info(const t2gpu_rx_pool *p, t2gpu_rx_geometry *out);
+int t2gpu_rx_pool_share(const t2gpu_rx_pool *p, int n_frames, int k, int *lo, int *hi);
+long t2gpu_rx_pool_execute(t2gpu_rx_pool *p, const int16_t *i_in, const int16_t *q_in, int n_frames);
+long t2gpu_rx_pool_ts_read(t2gpu_rx_pool *p, uint8_t *out, long cap);
+int t2gpu_rx_pool_counters(const t2gpu_rx_pool *p, int64_t *out6, double *merge_seconds);
+
 /* ---------------------------------------------------------------- mode tables (host only, no GPU needed) -----------
  * The permutations the kernels gather/scatter through, as this library builds them (for inspection and for tests):
  * bit de-interleaver address per LLR of an FEC frame (llr_demapper::address_generator, llr_demapper.cpp:110-130),

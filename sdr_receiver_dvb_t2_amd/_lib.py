@@ -112,6 +112,14 @@ PROTOTYPES = {
     "t2gpu_rx_ts_read": (ctypes.c_long, [_vp, _vp, ctypes.c_long, ctypes.c_int]),
     "t2gpu_rx_ts_counters_get": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "t2gpu_rx_create": (_vp, [_vp, ctypes.c_int]),
+    "t2gpu_rx_pool_create": (_vp, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "t2gpu_rx_pool_destroy": (None, [_vp]),
+    "t2gpu_rx_pool_frame_alignment": (ctypes.c_int, [_vp]),
+    "t2gpu_rx_pool_info": (ctypes.c_int, [_vp, _vp]),
+    "t2gpu_rx_pool_share": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "t2gpu_rx_pool_execute": (ctypes.c_long, [_vp, _vp, _vp, ctypes.c_int]),
+    "t2gpu_rx_pool_ts_read": (ctypes.c_long, [_vp, _vp, ctypes.c_long]),
+    "t2gpu_rx_pool_counters": (ctypes.c_int, [_vp, _vp, _vp]),
     "t2gpu_rx_destroy": (None, [_vp]),
     "t2gpu_rx_info": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_rx_set_overlap": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -1,6 +1,7 @@
 """Frame-batch sharding across the GPUs of one node: every FEC frame / SIMD batch is independent
 given the mode tables, so ranks take disjoint, contiguous, batch-aligned ranges and never exchange data on the data
-path. The only collectives are the bench's barrier and the max-over-ranks of the timed region."""
+path. The only collectives are the bench's barrier and the max-over-ranks of the timed region -- CPU tensors over gloo; RCCL is not
+used anywhere. The same sharding inside ONE process, over the devices of a node, is the C ABI's t2gpu_rx_pool_* (csrc/t2gpu_rx_pool.cpp)."""
 
 
 def shard_frames(total_frames, world_size, rank, align=32):
@@ -53,6 +54,11 @@ class ordered_receiver(object):
         self._bbdh = None
         self._out = None
 
+    def _cpu_group(self):
+        if getattr(self, "_grp", None) is None:
+            self._grp = self.dist.group.WORLD if self.dist.get_backend() == "gloo" else self.dist.new_group(backend="gloo")
+        return self._grp
+
     def close(self):
         if self._bbdh is not None:
             from ._lib import lib
@@ -86,9 +92,11 @@ class ordered_receiver(object):
             import torch
             # every rank needs the row width to shape its tensors: the ranks that decoded something know it
             kb = torch.tensor([k_bch or 0], dtype=torch.int64)
-            dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
-            kb = kb.to(dev)
-            self.dist.all_reduce(kb, op=self.dist.ReduceOp.MAX)
+            # The rows are RESULTS on their way to the one de-framer, host memory to host memory: CPU tensors over gloo whatever the
+            # default backend is (SURVEY.md 8e / north_star: no RCCL on this path; a process group that only has nccl gets a gloo group
+            # of the same ranks beside it, made once).
+            grp = self._cpu_group()
+            self.dist.all_reduce(kb, op=self.dist.ReduceOp.MAX, group=grp)
             k_bch = int(kb.item())
             row_bytes = (k_bch + 7) // 8
             max_rows = max(n_rows)
@@ -98,14 +106,13 @@ class ordered_receiver(object):
             if rows.shape[0]:
                 t_rows[:rows.shape[0]] = torch.from_numpy(rows)
                 t_tr[:trials.shape[0]] = torch.from_numpy(trials)
-            t_rows, t_tr = t_rows.to(dev), t_tr.to(dev)
             g_rows = [torch.empty_like(t_rows) for _ in range(self.world)] if self.rank == 0 else None
             g_tr = [torch.empty_like(t_tr) for _ in range(self.world)] if self.rank == 0 else None
-            self.dist.gather(t_rows, g_rows, dst=0)                  # rank order = frame order; k_bch / 8 bytes per FEC frame
-            self.dist.gather(t_tr, g_tr, dst=0)
+            self.dist.gather(t_rows, g_rows, dst=0, group=grp)       # rank order = frame order; k_bch / 8 bytes per FEC frame
+            self.dist.gather(t_tr, g_tr, dst=0, group=grp)
             if self.rank != 0:
                 return None
-            parts = [(g_rows[r].cpu().numpy()[:n_rows[r]], g_tr[r].cpu().numpy()) for r in range(self.world)]
+            parts = [(g_rows[r].numpy()[:n_rows[r]], g_tr[r].numpy()) for r in range(self.world)]
         else:
             parts = [(rows, trials)]
         from ._lib import lib
