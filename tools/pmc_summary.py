@@ -50,7 +50,9 @@ try:
     line = [l for l in open(os.path.join(root, "gpurun_out", "pmc_%s_sq.json" % tag)) if l.startswith("{")][-1]
     d = json.loads(line)
     frames = int(re.search(r"(\d+) FEC frames", d["config"]["workload"]).group(1))
-    out = {"config": 3, "frames": frames, "sweeps": 25, "source": "tools/pmc_passes.sh %s: separate rocprofv3 --pmc passes of bench.py --no-cpu-baseline --no-extra-legs, "
+    sys.path.insert(0, root)
+    import bench
+    out = {"config": 3, "frames": frames, "sweeps": 25, "kernel": "ldpc_decode2_kernel", "kernel_sources_sha16": bench.ldpc_kernel_hash(), "source": "tools/pmc_passes.sh %s: separate rocprofv3 --pmc passes of bench.py --no-cpu-baseline --no-extra-legs, "
            "ldpc_decode2_kernel averaged over its launches" % tag,
            "SQ_INSTS_VALU": ldpc_avg["SQ_INSTS_VALU"], "FETCH_SIZE_KiB": ldpc_avg["FETCH_SIZE"], "WRITE_SIZE_KiB": ldpc_avg["WRITE_SIZE"],
            "SQ_LDS_IDX_ACTIVE": ldpc_avg["SQ_LDS_IDX_ACTIVE"], "SQ_LDS_BANK_CONFLICT": ldpc_avg["SQ_LDS_BANK_CONFLICT"], "SQ_WAIT_ANY": ldpc_avg["SQ_WAIT_ANY"],
