@@ -10,7 +10,7 @@
 //           reference's constructors wire them (include/t2gpu_stages.hpp), every stage a call into libt2gpu.so.
 //
 // build:  g++ -O2 -std=c++17 -I../include t2gpu_rx_file.cpp -L../sdr_receiver_dvb_t2_amd -lt2gpu -Wl,-rpath,$PWD/../sdr_receiver_dvb_t2_amd -o t2gpu_rx_file
-// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1] [--saturate 0] [--threads 1] [--device-loop 1] [--fft-one-launch 1] [--ldpc-in-flight 8] [--ldpc-merge 1] [--chain-one 1] [--copy-ahead 1]
+// usage:  t2gpu_rx_file i.s16 q.s16 (--out ts.bin | --udp 7654) [--plp 0] [--buf 172032] [--device 0] [--warm 0] [--json 1] [--saturate 0] [--threads 1] [--device-loop 1] [--ldpc-in-flight 8] [--ldpc-merge 1] [--chain-one 1] [--copy-ahead 1]
 //         --buf: samples per execute() call (the reference's SDRplay thread hands over norm_blocks x 384 = 172 032, rx_sdrplay.h:64)
 //         --warm n: the first n buffers (acquisition: P1, guard search, L1) run before the clock starts; --json 1: one JSON line on
 //         stdout with the throughput of the timed buffers (bench.py's drop_in leg reads it); --saturate 1: LLRs clamped to int8
@@ -49,7 +49,7 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *out_path = nullptr;
-    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0, saturate = 0, threads = 1, device_loop = 1, fft_one = 1, in_flight = 8, ldpc_merge = 1, chain_one = 1, copy_ahead = 1;
+    int udp_port = 0, need_plp = 0, buf_len = 172032, device = 0, warm = 0, json = 0, saturate = 0, threads = 1, device_loop = 1, in_flight = 8, ldpc_merge = 1, chain_one = 1, copy_ahead = 1;
     for (int a = 3; a + 1 < argc; a += 2) {
         if (!std::strcmp(argv[a], "--out")) out_path = argv[a + 1];
         else if (!std::strcmp(argv[a], "--udp")) udp_port = std::atoi(argv[a + 1]);
@@ -61,7 +61,6 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[a], "--saturate")) saturate = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--threads")) threads = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--device-loop")) device_loop = std::atoi(argv[a + 1]);
-        else if (!std::strcmp(argv[a], "--fft-one-launch")) fft_one = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--ldpc-in-flight")) in_flight = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--ldpc-merge")) ldpc_merge = std::atoi(argv[a + 1]);
         else if (!std::strcmp(argv[a], "--chain-one")) chain_one = std::atoi(argv[a + 1]);
@@ -87,7 +86,6 @@ int main(int argc, char **argv)
         demodulator.set_device_loop(device_loop != 0);
         demodulator.set_chain_one(chain_one != 0);                        // (A/B: the completing chunk and the symbol's transform as one launch or two)
         demodulator.set_copy_ahead(copy_ahead != 0);                      // (A/B: the I/Q chunk by chunk inside the chunks' launches, or the whole buffer at the head of a call)
-        t2gpu_fft_set_one_launch(fft_one);                                // (A/B: a symbol's transform as one launch or two)
         t2::llr_demapper qam(device);
         qam.saturate_llr = saturate != 0;
         t2::ldpc_decoder ldpc(device, in_flight, threads != 0, ldpc_merge != 0, ldpc_merge > 1 ? ldpc_merge : 250);   // --ldpc-merge 0: one launch per SIMD batch; n > 1: the linger in us                   // --threads 1: the LDPC stage and what is wired behind it on a thread of their own

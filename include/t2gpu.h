@@ -99,6 +99,9 @@ int t2gpu_ldpc_occupancy(const t2gpu_ldpc *h, int *out6);
  * device's CUs (t2gpu_rx with t2gpu_rx_set_overlap does). */
 int t2gpu_ldpc_launch_workgroups(const t2gpu_ldpc *h, int n_frames);
 int t2gpu_ldpc_set_plain_launch(t2gpu_ldpc *h, int plain);
+/* n >= 1: a decode of this handle keeps at most n SIMD batches resident and hands the others out by ticket as slots come free (the CUs it
+ * leaves alone are where other streams' kernels run beside it: a resident decode workgroup fills its CU's LDS); 0 (default): all the device holds. */
+int t2gpu_ldpc_set_max_slots(t2gpu_ldpc *h, int n);
 /* reference-shaped call: len_in = fec_size * n_frames (the reference always passes 32 frames) */
 int t2gpu_ldpc_execute(t2gpu_ldpc *h, const int8_t *in, int len_in, uint8_t *out,
                        int *trials_left /* [ceil(n_frames/group)] */);
@@ -393,7 +396,7 @@ int t2gpu_sym_sync_dev(t2gpu_ofdm *h, int kind, int idx_symbol, const float *d_s
                        float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
 /* symbol_acquisition's guard removal + fft->execute() (dvbt2_demodulator.cpp:332-334) for ONE buffered symbol (d_buffered: guard +
  * fft_size cells, guard first; spectrum to d_spectrum) with t2gpu_sym_sync_dev's outputs formed inside the FFT's last launch: what
- * t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev give, bit for bit, in one launch (t2gpu_fft_set_one_launch) instead of three. h: the handle whose FFT
+ * t2gpu_fft_execute_strided_dev + t2gpu_sym_sync_dev give, bit for bit, in one launch (per handle: t2gpu_ofdm_set_one_launch(h, 0) = the two launches of before, same values) instead of three. h: the handle whose FFT
  * runs; tables: the handle whose pilot tables apply (the same FFT size; kind / idx_symbol as in t2gpu_sym_sync_dev). with_cp = 0: no
  * guard correlation (h_small[0..3] untouched). Pilot tables that do not fit the FFT's exchange buffer (P2, dense pilot patterns) take
  * the separate launches inside. */
@@ -401,7 +404,7 @@ int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_
                            float *d_spectrum, float *d_cp4, float *d_sync, float *h_small, unsigned *h_flag, unsigned seq, void *d_loop, void *stream);
 /* on = 1 (default): t2gpu_fft_sym_sync_dev is ONE launch (stage A in its first four workgroups, stages B + C and the synchronisation
  * floats in the other four, which wait for them); 0: the two launches. Process-wide; same values bit for bit. */
-void t2gpu_fft_set_one_launch(int on);
+int t2gpu_ofdm_set_one_launch(t2gpu_ofdm *h, int on);
 /* The same two for whole frames, in place like t2gpu_eq_data_frames_dev: the P2 (frame-closing) symbol of frame f is read at
  * d_spectrum + 2 * f * syms_per_frame * fft_size floats (+ the symbol's position in the frame); P2: the cells behind the first
  * skip_cells (the L1 cells, time_deinterleaver.cpp:296-300) go to d_cells + 2 * f * cells_frame_stride floats; frame closing: the
@@ -729,6 +732,11 @@ int t2gpu_rx_carry(const t2gpu_rx *h);
  * demapper run beside it where the decoder leaves CUs free: calls of one or two T2 frames are 6 - 13 SIMD batches = 96 - 208 of the 256
  * workgroups the device keeps resident. Decodes of at most half the device (one-frame calls) also run beside EACH OTHER, two at a time:
  * three LLR buffers rotate, two decode sets (decoder state, stream, output rows) alternate; larger ones follow one another on one set.
+ * Calls of fewer than 2 x 14 SIMD batches (up to four CFG-A frames) do not get a decode each: their LLR frames collect in the handle until 14
+ * batches are there, and every decode is then a whole number of rounds of 14 resident batches (t2gpu_ldpc_set_max_slots) -- ONE decode
+ * resident at a time, all of its slots busy for all of its time, and 32 CUs left to the front halves of the calls that run beside it
+ * (two or more dispatches of other queues resident at once slow every launch of a latency-bound chain down). A call
+ * then returns the FEC frames whose decode IT launched -- 0 for a call that only collected (as for a call that completes no SIMD batch).
  * Same results, same batch formation, same TS. With it on, a call's stream no longer covers the decode:
  * d_bytes_out / d_trials_out (the rows of THIS call's decode) are complete after t2gpu_rx_wait (or any fetch / results / stage_ms /
  * TS read, which wait themselves). To be switched on a drained handle with no frames waiting for a batch. */

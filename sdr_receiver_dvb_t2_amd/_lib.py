@@ -45,6 +45,7 @@ PROTOTYPES = {
     "t2gpu_ldpc_set_submit_cu_reserve": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_occupancy": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_launch_workgroups": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "t2gpu_ldpc_set_max_slots": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_set_plain_launch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_ldpc_profile": (ctypes.c_int, [_vp, _vp]),
     "t2gpu_ldpc_profile_layers": (ctypes.c_int, [_vp, _vp]),
@@ -154,7 +155,7 @@ PROTOTYPES = {
     "t2gpu_eq_p2_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "t2gpu_eq_data_publish_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_eq_fc_execute_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
-    "t2gpu_fft_set_one_launch": (None, [ctypes.c_int]),
+    "t2gpu_ofdm_set_one_launch": (ctypes.c_int, [_vp, ctypes.c_int]),
     "t2gpu_fft_sym_sync_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_sym_sync_dev": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp]),
     "t2gpu_front_loop_dev": (_vp, [_vp]),

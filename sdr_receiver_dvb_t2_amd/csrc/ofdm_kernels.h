@@ -38,9 +38,6 @@ struct EqParams {
     int out_skip = 0;          // frame layout: the first out_skip cells of the symbol are not stored (the L1 cells of P2), the rest move up
     float2 *skip_out = nullptr;       // frame layout, out_skip > 0: where the skipped cells go instead (frame f at skip_out + f * out_skip) --
                                       // the L1-pre / L1-post cells of every P2 symbol, for the host's per-frame L1 parse
-    // LDS staging of the equaliser (EQ_GROUP consecutive segments per workgroup): the widest carrier span / data-cell span any
-    // group of this table covers (host-computed, sizes the dynamic LDS)
-    int lds_span = 0, lds_dspan = 0;
     // P2 and frame-closing tables: the pilot amplitude never changes inside p2_symbol::execute / fc_symbol::execute, and the
     // reference binary (-Ofast, sdr_receiver_dvb_t2.pro:33-39) evaluates sqrt(norm(cell)) / amp_pilot as a product with
     // 1 / amp_pilot there; data_symbol::execute, whose amplitude alternates, keeps the division. Pinned by tests/golden/t2sym_golden.npz.
@@ -63,11 +60,7 @@ struct EqParams {
 };
 // first output position of range s (even, so that a range starts on a 16-byte boundary of the symbol's cells)
 __host__ __device__ inline int eq_split_q(int c_data, int n_splits, int s) { return s >= n_splits ? c_data : (int)(((long)c_data * s / n_splits) & ~1L); }
-#ifndef T2_EQ_GROUP
-#define T2_EQ_GROUP 32
-#endif
-constexpr int EQ_GROUP = T2_EQ_GROUP;
-constexpr int EQS_PU = 8;                   // eq_split_kernel reads its destinations EQS_PU steps ahead of the recurrence      // segments per equaliser workgroup (ofdm_kernels.hip)
+constexpr int EQS_PU = 8;                   // eq_split_kernel reads its destinations EQS_PU steps ahead of the recurrence
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s);
 
@@ -93,7 +86,7 @@ hipError_t launch_sym_sync(const EqParams &p, const float2 *symbol, int idx_symb
 // the other.
 hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
-                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr);
+                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop = nullptr, bool one_launch = true);
 
 // what fft_one_sync_kernel takes, for the launch that runs a chunk's front end AND the symbol's transform (front_kernels.hip:
 // front_fft_one_kernel; 32K symbols -- the front end's workgroups have 256 lanes, as stages B + C of a 32K transform)
@@ -103,7 +96,6 @@ struct FftOneArgs {
     T2DevLoop *loop; int fft_size;
 };
 constexpr int FFT_ONE_LDS_FLOATS = 32 * 8 * 33;   // (= ofdm_device.h's FFT_BC_LDS_FLOATS)
-void set_fft_one_launch(int on);   // launch_fft_sym_sync as one launch (default) or two
 
 }  // namespace t2gpu
 

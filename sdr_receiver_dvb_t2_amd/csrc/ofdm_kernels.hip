@@ -175,174 +175,10 @@ hipError_t launch_fft(int fft_size, const float2 *in, float2 *out, const float2 
 // LUT cos/sin divided by the amplitude; segments between pilots are independent, so one lane walks one segment with
 // exactly the reference's sequence of float operations. The frequency de-interleaver (out[h[d]]) is fused in.
 
-// One workgroup = EQ_GROUP consecutive segments of one symbol, in two phases over LDS.
-//   load:    the group's carriers (one contiguous run), their types and the de-interleaver indices of its data cells, coalesced
-//            (in global memory neighbouring segments are a whole pilot spacing -- up to 96 carriers = 768 B -- apart).
-//   phase 1: one lane per segment estimates its two pilots and runs the reference's angle / amplitude recurrences -- repeated
-//            float additions, a serial chain per segment -- leaving (angle, amplitude) of every data cell in LDS.
-//   phase 2: all lanes, one data cell each: table reads, the two divisions, the rotation and the de-interleaved store -- the
-//            reference's per-cell operations on the values phase 1 produced in the reference's order.
-// Every cell is an 8-byte store somewhere in the symbol's 219 KB of output; a 128-byte line is complete only when all groups of the
-// symbol have run, and it reaches HBM once only if it stays in L2 until then. What decides that is how many symbols are in flight per
-// XCD (each XCD has its own 4 MB L2, shared with the incoming spectra): resident workgroups per XCD / groups per symbol. Measured
-// (tools/eq_write_probe.sh, 32K PP7, WRITE_SIZE over algorithmic bytes): 12 symbols in flight 4.3x, 8 -> 2.2x, 4 -> 1.07x. Hence
-// small groups (32 segments: 15 to 145 workgroups per symbol) of many lanes (512) and at most two workgroups per CU (launch_eq_data
-// asks for LDS accordingly), dealt to the XCDs so that all groups of a symbol write through the same L2.
-#ifndef T2_EQ_THREADS
-#define T2_EQ_THREADS 1024
-#endif
-#ifndef T2_EQ_WGS_PER_CU
-#define T2_EQ_WGS_PER_CU 2
-#endif
-constexpr int EQ_THREADS = T2_EQ_THREADS;
-
-__global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const float2 *__restrict__ symbols,
-                                                          const int32_t *__restrict__ symbol_index, float2 *__restrict__ out,
-                                                          float4 *__restrict__ pilot_scratch, int n_symbols, int groups)
-{
-    extern __shared__ __attribute__((aligned(16))) float eq_lds[];
-    const float K_TABLE = 32767.0f / (2.0f * 3.14159274101257324219f);
-    const float PI = 3.14159274101257324219f;
-    // Workgroups are dealt round-robin to the 8 XCDs: linear id w -> XCD w % 8; symbol = 8 * (w / 8 / groups) + w % 8,
-    // group = (w / 8) % groups.
-    const int wg = (int)blockIdx.x;
-    int b, grp;
-    if (p.per_frame > 1 && p.row_major) {
-        // Frame layout with several symbols per frame (the data symbols): the tables (pilot references, carrier map, segments, the
-        // de-interleaver and carrier indices: ~340 KB per symbol ROW, 20 MB for the 59 rows of CFG-A) are the same for that row of every
-        // frame. Symbol after symbol, every workgroup pulled its row's tables through an L2 that had seen 58 other rows since (reads
-        // 1.7x the algorithmic bytes). Row-major instead: all XCDs work on the same row at the same time, XCD x on frames x, x + 8, ...;
-        // a row's tables enter each L2 once per launch. All groups of a symbol still share one XCD, back to back (see above).
-        const int xcd = wg & 7, i = wg >> 3;
-        const int frames = n_symbols / p.per_frame, fx = (frames + 7) >> 3;
-        const int row = i / (fx * groups), rem = i - row * fx * groups;
-        const int fr_x = rem / groups;
-        grp = rem - fr_x * groups;
-        const int frame = fr_x * 8 + xcd;
-        if (row >= p.per_frame || frame >= frames) return;
-        b = frame * p.per_frame + row;
-    } else {
-        b = 8 * ((wg >> 3) / groups) + (wg & 7);                                // symbol of the batch
-        grp = (wg >> 3) % groups;
-    }
-    if (b >= n_symbols) return;
-    const int fr = p.per_frame ? b / p.per_frame : 0, lo = p.per_frame ? b - fr * p.per_frame : 0;
-    const int idx_symbol = p.per_frame ? p.first + lo : symbol_index[b];        // position in the T2 frame (P2 = 0)
-    const int row = idx_symbol - p.n_p2;                                        // data-symbol table row
-    const int nseg = p.seg_count[row];
-    const int seg0 = grp * EQ_GROUP;
-    if (seg0 >= nseg) return;
-    const int seg1 = min(nseg, seg0 + EQ_GROUP) - 1;
-    const float2 *cell = symbols + (p.per_frame ? (size_t)(fr * p.in_syms_per_frame + idx_symbol) : (size_t)b) * p.fft_size + p.l_nulls;
-    const uint8_t *map = p.map + (size_t)row * p.k_total;
-    const float *refer = p.refer + (size_t)row * p.k_total;
-    const int32_t *h = (idx_symbol & 1) ? p.h_even : p.h_odd;                   // data_symbol.cpp:148-149
-    float2 *o = p.per_frame ? out + (size_t)fr * p.out_frame_stride + p.out_offset + (size_t)lo * p.c_data : out + (size_t)b * p.c_data;
-    const int4 *segs = p.segs + (size_t)row * p.max_seg;
-    const int4 sgf = segs[seg0], sgl = segs[seg1];
-    const int c0 = sgf.x, span = sgl.y - sgf.x + 1, d0 = sgf.z, dspan = sgl.z + sgl.w - sgf.z;
-    // LDS: carriers (re, im planes), (angle, amplitude) per data cell, the 16-bit de-interleaver indices
-    float *l_re = eq_lds, *l_im = l_re + p.lds_span;
-    float2 *l_aa = reinterpret_cast<float2 *>(l_im + p.lds_span + (p.lds_span & 1));
-    uint16_t *l_h = reinterpret_cast<uint16_t *>(l_aa + p.lds_dspan);
-    static_assert(EQ_GROUP <= 64 && EQ_THREADS > 64, "phase 1 is wavefront 0, the other wavefronts stage");
-    if (threadIdx.x < 64) {
-        // ---- phase 1 (wavefront 0, beside the staging of the others: it needs its own two pilots only, read straight from memory)
-        const int seg = seg0 + (int)threadIdx.x;
-        if (seg <= seg1) {
-            const int4 sg = segs[seg];                                          // left pilot, right pilot, d start, data count
-            const int pl = sg.x, pr = sg.y, n = sg.w, d = sg.z - d0;
-            const float2 cl = cell[pl], cr = cell[pr];
-            const float refer_l = refer[pl], refer_r = refer[pr];
-            // amp_pilot: scattered amplitude unless the pilot is a continual one (the edge pilots are mapped SCATTERED); every
-            // pilot of a P2 symbol has the P2 amplitude (p2_symbol.cpp:49-55,127)
-            const uint8_t tl = map[pl], tr = map[pr];
-            const PilotEst L = pilot_estimate(cl, refer_l, tl == T2_P2PILOT ? p.amp_p2 : (tl == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
-            const PilotEst R = pilot_estimate(cr, refer_r, tr == T2_P2PILOT ? p.amp_p2 : (tr == T2_CONTINUAL ? p.amp_cp : p.amp_sp), p.recip_amp);
-            float dif_angle = R.angle - L.angle;
-            if (dif_angle > PI) dif_angle = PI * 2.0f - dif_angle;              // as written in the reference (:189-191)
-            else if (dif_angle < -PI) dif_angle = PI * 2.0f + dif_angle;
-            const float delta_angle = dif_angle / (float)(n + 1);
-            const float delta_amp = (R.amp - L.amp) / (float)(n + 1);
-            float angle_est = L.angle, amp_est = L.amp;
-            float2 *aa = l_aa + d;
-#pragma unroll 4
-            for (int k = 0; k < n; ++k) {                                       // one step per DATA cell: reserved tones / the unused
-                angle_est += delta_angle; amp_est += delta_amp;                 // centre pilot between the pilots take none (:198)
-                aa[k] = make_float2(angle_est, amp_est);
-            }
-            // per-pilot terms of the synchronisation sums, folded in carrier order by eq_sync_kernel
-            float4 *ps = pilot_scratch + (size_t)b * (p.max_seg + 1);
-            if (seg == 0) ps[0] = make_float4(L.er, L.ei, 0.0f, 0.0f);          // first pilot: no angle term (:153-162)
-            ps[seg + 1] = make_float4(R.er, R.ei, R.angle, pr > p.k_total / 2 ? 1.0f : 0.0f);
-        }
-    } else {
-        // ---- staging: all global reads of a pass are issued before the first LDS store waits for one (a loop of load -> store
-        // pays the memory latency once per trip, and a workgroup has nothing else to do meanwhile)
-        constexpr int LU = 4, ST = EQ_THREADS - 64;
-        const int t0 = (int)threadIdx.x - 64;
-        for (int i0 = t0; i0 < span; i0 += LU * ST) {
-            float2 v[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = i0 + u * ST;
-                v[u] = i < span ? cell[c0 + i] : make_float2(0.0f, 0.0f);
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = i0 + u * ST;
-                if (i < span) { l_re[i] = v[u].x; l_im[i] = v[u].y; }
-            }
-        }
-        for (int i0 = t0; i0 < dspan; i0 += LU * ST) {
-            int32_t hv[LU];
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = i0 + u * ST;
-                hv[u] = i < dspan ? h[d0 + i] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = i0 + u * ST;
-                if (i < dspan) l_h[i] = (uint16_t)hv[u];
-            }
-        }
-    }
-    __syncthreads();
-    const float2 *__restrict__ lut = p.lut_cs;
-    const uint16_t *dcar = p.dcar + (size_t)row * p.dcar_stride + d0;
-    constexpr int U = 4;                                                        // cells per lane in flight: the table reads of all of
-    for (int dl0 = threadIdx.x; dl0 < dspan; dl0 += U * EQ_THREADS) {           // them are issued before the first is used
-        float cr[U], sr[U];
-        int car[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int dl = dl0 + u * EQ_THREADS;
-            const bool in = dl < dspan;
-            const int li = in ? ((int)(l_aa[dl].x * K_TABLE + 32767) & 65535) : 0;
-            const float2 cs = lut[li];
-            cr[u] = cs.x; sr[u] = cs.y;
-            car[u] = in ? (int)dcar[dl] - c0 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int dl = dl0 + u * EQ_THREADS;
-            if (dl >= dspan) continue;
-            const float amp = l_aa[dl].y;
-            const float dr = cr[u] / amp, di = sr[u] / amp;
-            const float2 v = make_float2(l_re[car[u]], l_im[car[u]]);
-            const int at = (int)l_h[dl] - p.out_skip;
-            const float2 eq = make_float2(v.x * dr + v.y * di, v.y * dr - v.x * di);     // buffer_cell[j] * conj(derotate)
-            if (at >= 0) o[at] = eq;
-            else if (p.skip_out) p.skip_out[(size_t)fr * p.out_skip + l_h[dl]] = eq;
-        }
-    }
-}
-
-// ---- output-range form (default) ----------------------------------------------------------------------------------------------
-// eq_data_kernel stores every cell with an 8-byte write somewhere in the symbol's 219 KB of output and depends on L2 to merge them
-// into lines before they leave for HBM, which caps the symbols in flight (above) and with them the loads in flight: 1.2 TB/s.
-// Here the de-interleaver's scatter lands in LDS instead. One workgroup = one symbol x one RANGE of output positions
+// ---- output-range form ----------------------------------------------------------------------------------------------------------
+// (Round 2's kernel walked groups of segments and stored every cell with an 8-byte write somewhere in the symbol's 219 KB of output,
+// depending on L2 to merge them into lines: 1.2 TB/s. Retired in round 6 -- its A/B against this form is settled, profiles/HISTORY.md.)
+// The de-interleaver's scatter lands in LDS. One workgroup = one symbol x one RANGE of output positions
 // [q0, q1) (a third of a 32K symbol: 73 KB as (re, im) pairs, two workgroups of 512 lanes per CU):
 //   phase 1: one lane per pilot-to-pilot segment of the WHOLE symbol runs the reference's angle / amplitude recurrences (serial
 //            float additions, in the reference's order) and leaves (angle, amplitude) of the cells that land in the range AT THEIR
@@ -351,9 +187,9 @@ __global__ __launch_bounds__(EQ_THREADS) void eq_data_kernel(EqParams p, const f
 //            half-dense runs): table read, two divisions, rotation -- the reference's per-cell operations -- result back to the
 //            same LDS slot.
 //   phase 3: the range leaves LDS as one contiguous run.
-// Same float operations on the same values as eq_data_kernel: bit-identical output (tests/test_ofdm_gpu.py runs both).
+// Bit-identical for every number of ranges (tests/test_ofdm_gpu.py runs three against the oracle).
 // Measured (config 3, 2832 data symbols; skipping phases one at a time): reads 0.18 ms, phase 1 0.12, phase 2 0.11, phase 3 0.12 --
-// they add up, two workgroups per CU overlap little of it: 0.52 ms against 0.90 ms of the segment-group kernel. More, smaller ranges
+// they add up, two workgroups per CU overlap little of it: 0.52 ms (0.90 ms for the retired segment-group kernel). More, smaller ranges
 // repeat phase 1 more often (+0.09 ms per range); a half symbol per workgroup of 1024 lanes leaves one workgroup per CU (0.55 ms).
 // IT = cells per lane (range <= IT * THREADS): every global input of phase 2 (list entry, spectrum cell) is in registers before
 // phase 1 starts, so the recurrences run under their latency and phase 2 waits for LDS and the cos / sin table only.
@@ -607,15 +443,12 @@ __global__ __launch_bounds__(8 * T2) void fft_one_sync_kernel(const float2 *__re
     fft_one_sync_body<T2>(in, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, loop, (int)blockIdx.x, lds);
 }
 
-static int g_fft_one_launch = 1;
-void set_fft_one_launch(int on) { g_fft_one_launch = on != 0; }
-
 hipError_t launch_fft_sym_sync(int fft_size, const float2 *in, float2 *out, const float2 *twiddle, const FftLayout &lay, float2 *scratch, unsigned *count,
                                const EqParams &p, int idx_symbol, const float2 *buffered, int guard, float4 *cp_out, float2 *sync, float *h_small,
-                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop)
+                               unsigned *h_flag, unsigned seq, hipStream_t s, T2DevLoop *loop, bool one_launch)
 {
     if ((p.max_seg + 2) * 16 + 2 * 256 * 8 > FFT_BC_LDS_FLOATS * 4 || !scratch || !count) return hipErrorInvalidValue;
-    if (g_fft_one_launch && (fft_size == 32768 || fft_size == 16384)) {
+    if (one_launch && (fft_size == 32768 || fft_size == 16384)) {
         const float2 *x = in + lay.first;                     // (one symbol: symbol 0 of the layout)
         if (fft_size == 32768)
             hipLaunchKernelGGL(fft_one_sync_kernel<32>, dim3(8), dim3(256), 0, s, x, scratch, out, twiddle, count, p, idx_symbol, buffered, guard, cp_out, sync,
@@ -683,7 +516,8 @@ hipError_t launch_publish_symbol(const float2 *cells, int n_cells, const float *
 hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_t *symbol_index, int n_symbols, float2 *out,
                           float4 *pilot_scratch, float2 *sync, hipStream_t s)
 {
-    if (p.n_splits > 0) {
+    if (p.n_splits < 1) return hipErrorInvalidValue;
+    {
         int range = 0;
         for (int k = 0; k < p.n_splits; ++k) range = std::max(range, eq_split_q(p.c_data, p.n_splits, k + 1) - eq_split_q(p.c_data, p.n_splits, k));
         const int bytes = (range + 1) * 8;
@@ -694,16 +528,6 @@ hipError_t launch_eq_data(const EqParams &p, const float2 *symbols, const int32_
         if (it <= 8) T2_EQS(8, 512); else if (it <= 14) T2_EQS(14, 512); else if (it <= 18) T2_EQS(18, 512); else if (it <= 28) T2_EQS(28, 512);
 #undef T2_EQS
         if (e != hipSuccess) return e;
-    } else {
-    int lds_bytes = 2 * (p.lds_span + 1) * 4 + p.lds_dspan * 8 + ((p.lds_dspan + 1) & ~1) * 2;
-    const int lds_floor = 160 * 1024 / (T2_EQ_WGS_PER_CU + 1) + 1024;                     // at most T2_EQ_WGS_PER_CU workgroups per CU (see the kernel)
-    lds_bytes = lds_bytes > lds_floor ? lds_bytes : lds_floor;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(eq_data_kernel), lds_bytes)) return e;
-    const int groups = (p.max_seg + EQ_GROUP - 1) / EQ_GROUP;
-    unsigned grid = (unsigned)(((n_symbols + 7) / 8) * 8 * groups);                         // linear id, see the kernel
-    if (p.per_frame > 1 && p.row_major) grid = (unsigned)(8 * p.per_frame * ((n_symbols / p.per_frame + 7) / 8) * groups);
-    hipLaunchKernelGGL(eq_data_kernel, dim3(grid), dim3(EQ_THREADS), lds_bytes, s, p, symbols, symbol_index, out, pilot_scratch, n_symbols,
-                       groups);
     }
     if (sync) {
         const int sy_bytes = (p.max_seg + 1) * 16;

@@ -48,6 +48,7 @@ struct t2gpu_ldpc {
     bool a_ready = false;               // stream, event and pinned staging of the asynchronous form all exist
     bool plain_launch = false;          // set around the launches of a submit (ldpc_kernel2_launch)
     bool plain_always = false;          // t2gpu_ldpc_set_plain_launch
+    int slot_cap = 0;                   // t2gpu_ldpc_set_max_slots: resident batch slots a decode of this handle takes at most (0: all the device holds)
     // the kernel's geometry (ldpc_kernel2.hip: two frames per workgroup)
     int p_blocks_per_cu = 0, p_lds_bytes = 0, p_lds_ctl_offset = 0, p_lds_rec_offset = 0, p_lds_sign_offset = 0, p_lds_ent_offset = 0, p_lds_base = 0,
         p_rec_dwords = 0;
@@ -271,9 +272,20 @@ extern "C" int t2gpu_ldpc_launch_workgroups(const t2gpu_ldpc *h, int n_frames)
 {
     if (!h || n_frames < 1) { set_error("t2gpu_ldpc_launch_workgroups: bad arguments"); return -1; }
     const int nbatches = (n_frames + h->group - 1) / h->group;
-    const int maxslots = resident_blocks(h) / wg_per_batch(h);
+    int maxslots = resident_blocks(h) / wg_per_batch(h);
     if (maxslots < 1) return -1;
+    if (h->slot_cap >= 1 && h->slot_cap < maxslots) maxslots = h->slot_cap;
     return (nbatches < maxslots ? nbatches : maxslots) * wg_per_batch(h);
+}
+
+// n >= 1: a decode of this handle keeps at most n SIMD batches resident (16 workgroups = 16 CUs each for the 64800-bit codes) and hands the
+// rest out by ticket as slots come free -- the CUs it leaves alone are where other streams' kernels run beside it (a resident decode workgroup
+// fills its CU's LDS); 0: as many as the device holds.
+extern "C" int t2gpu_ldpc_set_max_slots(t2gpu_ldpc *h, int n)
+{
+    if (!h || n < 0) { set_error("t2gpu_ldpc_set_max_slots: bad arguments"); return -1; }
+    h->slot_cap = n;
+    return 0;
 }
 
 // plain != 0: the decodes of this handle are ordinary launches, not cooperative ones. Cooperative launches of different
@@ -304,6 +316,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
         const int v = std::atoi(lim);
         if (v >= 1 && v < maxslots) maxslots = v;
     }
+    if (h->slot_cap >= 1 && h->slot_cap < maxslots) maxslots = h->slot_cap;
     int nslots = nbatches < maxslots ? nbatches : maxslots;
     int grid = nslots * wg_per_batch;
     if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }

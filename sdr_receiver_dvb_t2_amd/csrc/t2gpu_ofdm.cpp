@@ -90,6 +90,7 @@ struct t2gpu_ofdm {
     float2 *d_twiddle = nullptr;
     float2 *d_fft_scratch = nullptr;   // the first exchange of the two-launch FFT of a one- or two-symbol call (ofdm_kernels.h)
     unsigned *d_fft_count = nullptr;   // launch_fft_sym_sync's workgroup counter
+    bool one_launch = true;            // t2gpu_ofdm_set_one_launch: a symbol's transform + floats as one launch or two
     uint8_t *d_map = nullptr;
     uint16_t *d_dcar = nullptr, *d_dcar_p2 = nullptr, *d_dcar_fc = nullptr;   // carrier of every data cell, per table row
     float *d_refer = nullptr;
@@ -263,15 +264,16 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
     h->eq_fc.recip_amp = 1;
     // Output-range form (eq_split_kernel): per table row the output position of every data cell (the de-interleaver of the row's
     // parity, data_symbol.cpp:148-149) and, range by range, the (carrier, output position) list of the cells that land in it.
-    // Ranges: the fewest that fit 75 KB of LDS each -- two workgroups per CU (T2GPU_EQ_SPLITS=n forces n; 0 = the segment-group kernel eq_data_kernel).
+    // Ranges: the fewest that fit 75 KB of LDS each -- two workgroups per CU (T2GPU_EQ_SPLITS=n forces n >= 1: tests).
     {
         int forced = -1;
-        if (const char *e = getenv("T2GPU_EQ_SPLITS")) forced = atoi(e);
+        if (const char *e = getenv("T2GPU_EQ_SPLITS")) forced = atoi(e) >= 1 ? atoi(e) : -1;
         auto build = [&](EqParams &q, int n_rows, int first_idx, const std::vector<int32_t> &hev, const std::vector<int32_t> &hod,
                          const std::vector<uint16_t> &dc, const std::vector<int4> *sg_rows, uint16_t **d_cq, uint32_t **d_sl) {
             const int C = q.c_data;
             int ns = forced >= 0 ? forced : (C * 8 + 75 * 1024 - 1) / (75 * 1024);
-            if (ns <= 0 || C / ns + 2 > 14 * 1024 || C >= 65535) { q.n_splits = 0; return; }   // a range is at most 14 cells per lane of 1024 (28 of 512)
+            while (C / ns + 2 > 14 * 1024) ++ns;                                // a range is at most 28 cells per lane of 512
+            if (C >= 65535) { q.n_splits = 0; return; }                         // (16-bit output positions; no supported mode comes near)
             int steps = 0;
             for (int r = 0; r < n_rows; ++r)
                 for (const int4 &g : sg_rows[r]) steps = std::max(steps, g.w);
@@ -302,17 +304,6 @@ extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pil
         if (m.l_fc) build(h->eq_fc, 1, m.len_frame - 1, he3_keep, ho3_keep, dcar3_keep, &seg3_keep, &h->d_cellq_fc, &h->d_sel_fc);
         if (!ok) { t2gpu_ofdm_destroy(h); return nullptr; }
     }
-    // widest carrier / data-cell span of any EQ_GROUP consecutive segments, per table (sizes the equaliser's LDS staging)
-    auto spans = [](const std::vector<int4> &sg, int &span, int &dspan) {
-        for (size_t g0 = 0; g0 < sg.size(); g0 += EQ_GROUP) {
-            const size_t g1 = std::min(sg.size(), g0 + EQ_GROUP) - 1;
-            span = std::max(span, sg[g1].y - sg[g0].x + 1);
-            dspan = std::max(dspan, sg[g1].z + sg[g1].w - sg[g0].z);
-        }
-    };
-    for (int r = 0; r < rows; ++r) spans(segs[r], h->eq.lds_span, h->eq.lds_dspan);
-    spans(seg2, h->eq_p2.lds_span, h->eq_p2.lds_dspan);
-    if (m.l_fc) spans(seg3_keep, h->eq_fc.lds_span, h->eq_fc.lds_dspan);
     return h;
 }
 
@@ -533,7 +524,7 @@ extern "C" int t2gpu_fft_sym_sync_dev(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kin
     const float2 *buffered = with_cp ? reinterpret_cast<const float2 *>(d_buffered) : nullptr;
     const hipError_t e = launch_fft_sym_sync(h->m.fft_size, reinterpret_cast<const float2 *>(d_buffered), reinterpret_cast<float2 *>(d_spectrum), h->d_twiddle, lay,
                                              h->d_fft_scratch, h->d_fft_count, p, idx, buffered, guard, reinterpret_cast<float4 *>(d_cp4),
-                                             reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream, static_cast<T2DevLoop *>(d_loop));
+                                             reinterpret_cast<float2 *>(d_sync), h_small, h_flag, seq, (hipStream_t)stream, static_cast<T2DevLoop *>(d_loop), h->one_launch);
     if (e == hipSuccess) return 0;
     if (e != hipErrorInvalidValue) { T2_HIP(e); }
     (void)hipGetLastError();
@@ -559,7 +550,12 @@ int t2gpu_fft_one_args(t2gpu_ofdm *h, t2gpu_ofdm *tables, int kind, int idx_symb
     return 0;
 }
 
-extern "C" void t2gpu_fft_set_one_launch(int on) { t2gpu::set_fft_one_launch(on); }
+extern "C" int t2gpu_ofdm_set_one_launch(t2gpu_ofdm *h, int on)
+{
+    if (!h) { set_error("t2gpu_ofdm_set_one_launch: bad arguments"); return -1; }
+    h->one_launch = on != 0;
+    return 0;
+}
 
 extern "C" int t2gpu_eq_data_execute(t2gpu_ofdm *h, int idx_symbol, const float *ofdm_cell, float *cells, float *sample_rate_offset,
                                      float *phase_offset)

@@ -32,6 +32,7 @@ using namespace t2gpu;
 
 namespace {
 constexpr int P1_LEN = 2048, L1_PRE_CELL = 1840;
+constexpr int ACC_BATCHES = 14;             // overlap mode, small calls: see t2gpu_rx_back_dev (14 of the 16 batch slots a 64800-bit decode can keep resident)
 }
 
 struct t2gpu_rx {
@@ -70,6 +71,7 @@ struct t2gpu_rx {
     hipEvent_t ev_dec_done[2] = {nullptr, nullptr};             // the last decode of set s is through
     bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false}, l1_copied_set = false;
     int in_flight_wg[2] = {0, 0};             // workgroups of the last decode of each set (what may still be resident)
+    int acc_batches = ACC_BATCHES;            // overlap mode, small calls: SIMD batches that collect before a decode is launched = its resident slots (0: off)
     bool pair_allowed = true;                 // T2GPU_RX_PAIR=0 (read by t2gpu_rx_set_overlap): every decode on set 0, one after the other
     int num_cu = 0;
     uint8_t *d_bits = nullptr, *d_out = nullptr;
@@ -114,7 +116,9 @@ struct TsSlot {
     bool busy = false;
 };
 struct TsEnd {
-    static constexpr int SLOTS = 4;           // two decodes in flight, one being de-framed, one being filled
+    static constexpr int SLOTS = 12;          // jobs between a call and the worker. Large calls use 4 (two decodes in flight, one being de-framed, one
+                                              // being filled); small calls collect for a decode that ends milliseconds -- several calls -- later: all 12
+    int n_slots = 4;
     t2gpu_rx *rx = nullptr;
     t2gpu_bbdh *bbdh = nullptr;
     int need_plp = 0, l1_check = 0;
@@ -242,7 +246,10 @@ extern "C" t2gpu_rx *t2gpu_rx_create(const t2gpu_rx_config *c, int device)
     h->ti = t2gpu_ti_create(c->plp_mod, c->plp_fec_type, c->plp_num_blocks, device);
     h->demap = t2gpu_demap_create(c->plp_mod, c->plp_fec_type, c->plp_cod, c->plp_rotation, h->n_ti, device);
     const int group = c->ldpc_group > 0 ? c->ldpc_group : T2GPU_SIMD_BATCH;
-    const int pad = std::max(64, group);                         // carry < group rows (a group above 64 ran past nb + 64)
+    // rows beyond a call's own: the frames carried between calls. Plain mode: fewer than one group. Overlap mode with small calls: up to
+    // ACC_BATCHES batches collect before a decode is launched, a decode takes at most two rounds of them, and a flush appends what is left
+    // behind the last decode's rows: 3 x ACC_BATCHES x group + one group.
+    const int pad = std::max(64, group) + 3 * ACC_BATCHES * group;
     h->group = group;
     h->row_pad = pad;
     h->ldpc = t2gpu_ldpc_create(c->plp_fec_type, c->plp_cod, nb + pad, device);
@@ -420,14 +427,24 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
     const int total = h->carry + F * nb;
-    const int ready = (total / h->group) * h->group, rest = total - ready;
+    int ready = (total / h->group) * h->group, rest = total - ready;
+    // Overlap mode, calls of fewer than 2 K batches (K = acc_batches): the frames collect until K batches are there, and a decode is a whole
+    // number of rounds of K resident batches -- one dispatch at a time with every slot busy, 16 - K slots' CUs left to the front halves
+    // that run beside it. (Larger calls: as before, every complete batch at once on all the device holds.)
+    const bool collect = h->overlap && h->acc_batches > 0 && !h->outer_code && F * nb < 2 * h->acc_batches * h->group;
+    if (collect) {
+        const int k_rows = h->acc_batches * h->group;
+        ready = (total / k_rows) * k_rows;
+        rest = total - ready;
+    }
     if (h->overlap) {
         // ---- the decode on a stream of the handle's own (t2gpu_rx_set_overlap)
         const int b = h->cur, nb_ = (h->cur + 1) % 3;
         // a decode that could not run beside another one like it (more than half the device) stays on set 0 and is launched
         // cooperatively, as the one-stream schedule of round 4's first form did; smaller ones alternate between the sets, plain launches
+        for (t2gpu_ldpc *l : h->ldpc_s) if (l) t2gpu_ldpc_set_max_slots(l, collect ? h->acc_batches : 0);
         const int wg_est = ready > 0 ? (h->outer_code ? h->num_cu : t2gpu_ldpc_launch_workgroups(h->ldpc_s[0], ready)) : 0;
-        const bool pair_ok = ready > 0 && h->pair_allowed && 2 * wg_est <= h->num_cu;
+        const bool pair_ok = ready > 0 && !collect && h->pair_allowed && 2 * wg_est <= h->num_cu;
         const int set = pair_ok ? h->set : 0;
         int8_t *llr = h->d_llr_ab[b];
         // this buffer was last read by the decode of three calls ago; d_l1 is read by the host end's copy of the previous call
@@ -587,6 +604,13 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
     }
     h->overlap = enable != 0;
     if (const char *e = std::getenv("T2GPU_RX_PAIR")) h->pair_allowed = std::atoi(e) != 0;
+    {
+        // the slots a collected decode keeps resident: what the device holds less 32 CUs' worth, at most ACC_BATCHES (the rows were sized for that)
+        int occ[6] = {0, 0, 0, 0, 0, 0};
+        if (t2gpu_ldpc_occupancy(h->ldpc_s[0] ? h->ldpc_s[0] : h->ldpc, occ) == 0 && occ[4] > 32 && occ[5] > 0)
+            h->acc_batches = std::max(1, std::min(ACC_BATCHES, occ[5] * (occ[4] - 32) / occ[4]));
+        if (const char *e = std::getenv("T2GPU_RX_COLLECT")) { const int v = std::atoi(e); if (v >= 0 && v <= ACC_BATCHES) h->acc_batches = v; }   // 0: a decode per call, as round 5
+    }
     return 0;
 }
 extern "C" int t2gpu_rx_wait(t2gpu_rx *h)
@@ -753,7 +777,7 @@ int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s,
         k = t->next_slot;
         t->cv_done.wait(lk, [&] { return !t->slot[k].busy; });
         t->slot[k].busy = true;
-        t->next_slot = (k + 1) % TsEnd::SLOTS;
+        t->next_slot = (k + 1) % t->n_slots;
         ++t->in_flight;
     }
     TsSlot &sl = t->slot[k];
@@ -806,7 +830,9 @@ extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
     t->bbdh = t2gpu_bbdh_create(need_plp);
     const size_t frames = (size_t)h->cfg.max_frames * h->cfg.plp_num_blocks + h->row_pad;
     bool ok = t->bbdh != nullptr;
-    for (TsSlot &sl : t->slot) {
+    t->n_slots = h->cfg.max_frames * h->cfg.plp_num_blocks < 2 * ACC_BATCHES * h->group ? TsEnd::SLOTS : 4;
+    for (int q = 0; q < t->n_slots; ++q) {
+        TsSlot &sl = t->slot[q];
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&sl.pack), frames * (h->k_bch / 8), hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&sl.trials), (frames / h->group + 2) * 4, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc(reinterpret_cast<void **>(&sl.l1), (size_t)h->cfg.max_frames * std::max(h->p2_skip, 1) * 8, hipHostMallocDefault) == hipSuccess &&

@@ -366,7 +366,7 @@ def test_example_program_on_the_benchmark_mode(tmp_path):
         # (front_fft_one_kernel), the SIMD batches of a TI block decoded by ONE launch (t2gpu_ldpc_submit_add / _go). The forms of before --
         # two launches per symbol's transform behind the chunk's, one decode per batch on streams of their own -- give the same file, byte
         # for byte
-        for extra in (["--chain-one", "0"], ["--chain-one", "0", "--fft-one-launch", "0", "--ldpc-merge", "0"], ["--device-loop", "0"]):
+        for extra in (["--chain-one", "0"], ["--chain-one", "0", "--ldpc-merge", "0"], ["--device-loop", "0"]):
             subprocess.run([exe, str(tmp_path / "i.s16"), str(tmp_path / "q.s16"), "--out", str(tmp_path / "out2.ts"), "--json", "1", "--saturate", "1"] + extra,
                            check=True, env=env, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             assert np.array_equal(np.fromfile(tmp_path / "out2.ts", np.uint8), got), extra

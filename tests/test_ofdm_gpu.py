@@ -89,10 +89,10 @@ def test_fft_batch_properties_full_size(torch_cuda):
     ctx.close()
 
 
-@pytest.fixture(params=["default", "0", "3", "5"])
+@pytest.fixture(params=["default", "3", "5"])
 def eq_form(request, monkeypatch):
     """Equaliser kernel form, read when the context is created: default = output ranges in LDS (eq_split_kernel, fewest ranges that
-    fit), "3" / "5" = that kernel with three / five ranges per symbol, "0" = segment groups with scattered stores (eq_data_kernel)."""
+    fit), "3" / "5" = that kernel with three / five ranges per symbol (the segment-group kernel of round 2 was retired in round 6)."""
     if request.param == "default":
         monkeypatch.delenv("T2GPU_EQ_SPLITS", raising=False)
     else:
@@ -231,9 +231,9 @@ def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode, one_launc
     the whole transform in ONE launch (default: stage A's workgroups in front of the others, which wait for them) and the two launches."""
     import sdr_receiver_dvb_t2_amd as pkg
     torch = torch_cuda
-    pkg.lib().t2gpu_fft_set_one_launch(one_launch)
     m = ol.ora_mode(*mode)
     ctx = pkg.t2_ofdm(*mode, max_symbols=2)
+    assert pkg.lib().t2gpu_ofdm_set_one_launch(ctx._h, one_launch) == 0        # a property of the handle
     rows = m.n_data - m.l_fc
     guard = m.fft_size // 128 if mode[0] == 5 else m.fft_size // 16
     rng = np.random.Generator(np.random.PCG64(23))
@@ -256,5 +256,4 @@ def test_fft_with_the_sync_floats_in_its_last_launch(torch_cuda, mode, one_launc
             assert np.array_equal(h_small.numpy()[:4].view(np.uint32), cp4.cpu().numpy().view(np.uint32))
         assert int(h_flag[0]) == 100 + n
         assert np.array_equal(h_small.numpy()[4:6].view(np.uint32), sync.cpu().numpy().view(np.uint32))
-    pkg.lib().t2gpu_fft_set_one_launch(1)
     ctx.close()

@@ -336,11 +336,12 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
     probe.close()
     di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
 
-    def run(overlap, pair=True):
+    def run(overlap, pair=True, collect=0):
         rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
         rx.ts_enable(0, l1_check=True)
         if overlap:
             monkeypatch.setenv("T2GPU_RX_PAIR", "1" if pair else "0")
+            monkeypatch.setenv("T2GPU_RX_COLLECT", str(collect))         # 0: a decode per call (round 5's form); n: collect n batches per decode
             rx.set_overlap(True)
         rows, verdicts, counts = [], [], []
         for f in range(n_frames):
@@ -354,7 +355,7 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
         counts.append(n)
         if n:
             r, t = rx.fetch_packed(counts[-2] + n)                  # the rows of the flush follow the last back half's
-            rows.append(r[counts[-2]:]); verdicts.append(t)
+            rows.append(r[counts[-2]:]); verdicts.append(t[counts[-2] // 32:])
         ts_bytes = rx.ts_read(wait_all=True)
         c = rx.ts_counters()
         rx.close()
@@ -372,6 +373,15 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
     sc, sr, sv, sts, scnt = run(True, pair=False)
     assert sc == pc and all(np.array_equal(a, b) for a, b in zip(pr, sr)) and all(np.array_equal(a, b) for a, b in zip(pv, sv))
     assert np.array_equal(pts, sts) and scnt["fec_frames"] == pcnt["fec_frames"]
+    # round 6: small calls COLLECT -- their LLR frames wait in the handle until 3 (here) SIMD batches are there, every decode is a whole
+    # number of rounds of that many resident batches, a call returns the rows whose decode it launched (0 while collecting). The same rows,
+    # verdicts and TS bytes in the same order; only the calls they come back from differ
+    cc, cr, cv, cts, ccnt = run(True, collect=3)
+    assert sum(cc) == sum(pc) and all(x % (3 * 32) == 0 for x in cc[:-1]) and 0 in cc[:-1], cc
+    assert np.array_equal(np.concatenate(cr), np.concatenate(pr)) and np.array_equal(np.concatenate(cv), np.concatenate(pv))
+    assert np.array_equal(pts, cts)
+    for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
+        assert pcnt[k] == ccnt[k], k
 
 
 @pytest.mark.parametrize("pattern", [(1,) * 6, (2, 2, 2), (4, 4), (1, 4, 1, 16)])
@@ -392,11 +402,12 @@ def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda,
     dq = torch.from_numpy(np.concatenate([uq] * reps)[:total].reshape(-1)).cuda()
     flen = w.frame_samples
 
-    def run(overlap, pair=True):
+    def run(overlap, pair=True, collect=0):
         rx = t2_rx(*w.mode, w.lps, w.plp[0], w.plp[1], w.plp[2], w.plp[3], w.nb, max_frames=max(pattern), saturate_llr=True)
         rx.ts_enable(0, l1_check=True)
         if overlap:
             monkeypatch.setenv("T2GPU_RX_PAIR", "1" if pair else "0")
+            monkeypatch.setenv("T2GPU_RX_COLLECT", str(collect))
             rx.set_overlap(True)
         counts, rows, verdicts, at = [], [], [], 0
         for c, nf in enumerate(pattern):
@@ -410,7 +421,7 @@ def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda,
         counts.append(n)
         if n:
             r, t = rx.fetch_packed(counts[-2] + n)
-            rows.append(r[counts[-2]:]); verdicts.append(t)
+            rows.append(r[counts[-2]:]); verdicts.append(t[counts[-2] // 32:])
         ts_bytes = rx.ts_read(wait_all=True)
         c = rx.ts_counters()
         rx.close()
@@ -426,3 +437,14 @@ def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda,
         assert np.array_equal(pts, ots), pair
         for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
             assert pcnt[k] == ocnt[k], (pair, k)
+    # the library's default since round 6: calls of fewer than 28 batches collect until 14 are there (one decode resident at a time, whole
+    # rounds of 14 slots); larger calls (the 16-frame one of the last pattern) decode at once as before. Same rows in the same order, same TS
+    monkeypatch.delenv("T2GPU_RX_COLLECT", raising=False)
+    cc, cr, cv, cts, ccnt = run(True, collect=14)
+    assert sum(cc) == sum(pc), (cc, pc)
+    assert np.array_equal(np.concatenate(cr), np.concatenate(pr)) and np.array_equal(np.concatenate(cv), np.concatenate(pv))
+    assert np.array_equal(pts, cts)
+    for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
+        assert pcnt[k] == ccnt[k], k
+    if max(pattern) <= 4:
+        assert all(x % (14 * 32) == 0 for x in cc[:-1]), cc

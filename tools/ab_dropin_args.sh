@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of the slot-shaped path on argument sets of examples/t2gpu_rx_file (T2GPU_DROPIN_ARGS), alternating:
-#   tools/ab_dropin_args.sh "--fft-one-launch 1" "--fft-one-launch 0"            (add --saturate as $SAT=1)
+#   tools/ab_dropin_args.sh "--chain-one 1" "--chain-one 0"            (add --saturate as $SAT=1)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 for r in 1 2 3; do
