@@ -53,7 +53,9 @@ hipError_t launch_ti_fixup(const TiParams &p, const int32_t *order, const uint8_
 // Returns hipErrorInvalidValue when the FEC block does not fit LDS (QPSK with 64800-bit frames): use the scatter kernels.
 // terms (optional): the demapper's per-cell statistics terms of the first n_snr de-interleaved cells of every TI block, formed while
 // the cells are on their way out (two planes of demap_terms_padded(n_snr) floats per TI block, as demap_terms_kernel writes them)
-struct TiTerms { const DemapParams *dp = nullptr; float2 *terms = nullptr; int n_snr = 0; };
+// pad_key (may be null): what the zeros behind every plane's terms were last written for (geometry key); launch_ti_blocks skips the fill when it is
+// unchanged -- nothing else writes there as long as the owner resets the key whenever the scratch is used otherwise
+struct TiTerms { const DemapParams *dp = nullptr; float2 *terms = nullptr; int n_snr = 0; long *pad_key = nullptr; };
 hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int num_blocks, const float2 *cells, long in_stride,
                             float2 *out, long out_stride, int frames, hipStream_t s, const TiTerms *tt = nullptr);
 // the walk + scale of launch_demap_stats_batch's exact form on terms that are already there (launch_ti_blocks with TiTerms)

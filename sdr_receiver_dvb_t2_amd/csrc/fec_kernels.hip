@@ -664,7 +664,9 @@ hipError_t launch_ti_blocks(const TiParams &p, const uint8_t *lost_by_block, int
     const dim3 grid((unsigned)(8 * ((num_blocks + 7) / 8) * frames));
     if (tt && tt->terms) {
         const long plane = demap_terms_padded(tt->n_snr);
-        if (plane > tt->n_snr) {                                         // zeros behind every plane's n_snr terms: the walk reads whole chunks
+        const long key = ((long)tt->n_snr * 4099 + plane) * 8191 + frames;
+        if (plane > tt->n_snr && !(tt->pad_key && *tt->pad_key == key)) {   // zeros behind every plane's n_snr terms: the walk reads whole chunks
+            if (tt->pad_key) *tt->pad_key = key;                         // (written once per geometry: the kernel below never touches them)
             hipError_t e = hipMemset2DAsync(reinterpret_cast<float *>(tt->terms) + tt->n_snr, (size_t)plane * 4, 0, (size_t)(plane - tt->n_snr) * 4,
                                             (size_t)2 * frames, s);
             if (e != hipSuccess) return e;

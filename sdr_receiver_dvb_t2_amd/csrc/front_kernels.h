@@ -69,10 +69,12 @@ struct FrontOneArgs {
     float2 *pre_out;                           // [3 + 63]
     int *error;                                // set when a look-back wait gave up (t2gpu_front_state reports it)
     T2DevLoop *loop;                           // non-null: the NCO runs of this (one-chunk) call are planned by workgroup 0 from the device's
-    FrontRun *loop_runs;                       // loop state into loop_runs[T2_LOOP_RUNS_CAP] and the accumulators are left advanced there
+    FrontRun *loop_runs;                       // loop state (every workgroup for itself; long plans into loop_runs[workgroup][T2_LOOP_RUNS_CAP]) and the accumulators are left advanced there
     // cp_wgs > 0: that many extra workgroups at the END of the grid bring cp_n int16 elements of I and of Q over from page-locked host memory
     // (device-visible addresses cp_si / cp_sq) to cp_di / cp_dq -- the samples of the call's NEXT chunk, beside this chunk's work
     const int16_t *cp_si, *cp_sq; int16_t *cp_di, *cp_dq; long cp_n; int cp_wgs;
+    // development (T2GPU_FRONT_STAMPS=1): page-locked [64 workgroups][16] wall-clock stamps (100 MHz) of the phases of the launch, else null
+    long long *stamps;
     FrontRun runs[FRONT_CHAIN_RUNS];           // NCO runs (none with `loop`), then Farrow runs
 };
 // the I/Q a launch of the one-launch form brings over for the chunk behind it (t2gpu_front_loop_fft)

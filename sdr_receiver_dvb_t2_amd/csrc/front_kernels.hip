@@ -669,12 +669,15 @@ __device__ __noinline__ int plan_nco_dev(float *acc, int n, float fe, float phas
     return nr;
 }
 
+// (development) phase stamps of a launch: workgroup w, phase k, by one lane
+#define T2_STAMP(a_, w_, k_) do { if ((a_).stamps && threadIdx.x == 0 && (w_) < 64) (a_).stamps[16 * (w_) + (k_)] = wall_clock64(); } while (0)
+
 __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, const int nb)
 {
     __shared__ FrontRun sh_runs[FRONT_CHAIN_RUNS], sh_nco[FRONT_CHAIN_RUNS];
     __shared__ Lin wave_tot[4];
     __shared__ Lin sh_a1;
-    __shared__ int sh_nr;
+    __shared__ int sh_nr, sh_nco_far;
     __shared__ double sh_rec[F1_MAX_GRID][4];                  // the aggregates of the workgroups before this one: a, re, im
     __shared__ double sh_v[8];                                 // S (re, im), M (re, im), c1, c2, the last workgroup's part of the new dc
     __shared__ double red[3][4];
@@ -682,6 +685,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
     __shared__ float2 D[F1_H + F1_B];                          // de-rotated samples s0 - F1_H .. s0 + F1_B - 1
     __shared__ float2 W[F1_WCAP + F1_WCAP / 8 + 8];            // the decimator's window, padded as front_farrow_decimate_body pads it
     const int tid = threadIdx.x;
+    T2_STAMP(a, b, 0);
     FrontParams p = a.p;
     for (int t = tid; t < p.n_nco_runs + p.n_far_runs; t += 256) sh_runs[t] = a.runs[t];
     p.nco_runs = sh_runs; p.far_runs = sh_runs + p.n_nco_runs;
@@ -696,22 +700,33 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
     if (tid == (F1_B - F1_H) / F1_PER) sh_a1 = ex;             // the aggregate of the samples before the last F1_H: what the next workgroup starts its halo from
     if (b == 0 && tid == 0) { sh_v[0] = p.state->dc_re; sh_v[1] = p.state->dc_im; sh_v[4] = (double)p.state->c1; sh_v[5] = (double)p.state->c2; }
     __syncthreads();
+    T2_STAMP(a, b, 1);
     if (tid == 0) {
         double *rec = a.rec + 16 * (size_t)b;
         rec[0] = total.a; rec[1] = total.re; rec[2] = total.im; rec[3] = sh_a1.a; rec[4] = sh_a1.re; rec[5] = sh_a1.im;
         if (b == 0) { rec[6] = sh_v[0]; rec[7] = sh_v[1]; rec[8] = sh_v[4]; rec[9] = sh_v[5]; }   // the state as block 0 found it: nobody else reads it
-        if (b == 0 && a.loop) {
-            // the loop on the device: this chunk's NCO runs from the loop values the last sym_sync_kernel left (dvbt2_demodulator.cpp:165-171,
-            // 187-193), planned once, by this lane, into memory; the accumulators' new values travel with the record
-            const float phase_new = wrap_2pi(add_r(a.loop->phase_nco, a.loop->pe));
-            float acc = a.loop->frequency_nco;
-            int nr = plan_nco_dev(&acc, p.n, a.loop->fe, phase_new, a.loop_runs, T2_LOOP_RUNS_CAP);
-            if (nr < 0) { nr = 0; __hip_atomic_store(a.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            rec[10] = (double)nr; rec[11] = (double)phase_new; rec[12] = (double)acc;
-            sh_nr = nr;
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(a.flags + b, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    T2_STAMP(a, b, 2);
+    if (a.loop && tid == 255) {
+        // The loop on the device: this chunk's NCO runs from the loop values the last sym_sync_kernel left (dvbt2_demodulator.cpp:165-171,
+        // 187-193). EVERY workgroup plans them for itself, by a lane that polls no flag, while the look-back below waits for the other
+        // workgroups' aggregates (round 6; before, workgroup 0 planned ahead of its flag and all the others waited for it: ~5 us of every
+        // symbol's chain). The plan is a function of four floats and the chunk's length: the same runs everywhere. Into LDS; a chunk of
+        // more than FRONT_CHAIN_RUNS runs (a residual offset of hundreds of Hz) into the workgroup's own slice of loop_runs.
+        const float phase_new = wrap_2pi(add_r(a.loop->phase_nco, a.loop->pe));
+        float acc = a.loop->frequency_nco;
+        int far = 0;
+        int nr = plan_nco_dev(&acc, p.n, a.loop->fe, phase_new, sh_nco, FRONT_CHAIN_RUNS);
+        if (nr < 0) {
+            far = 1;
+            acc = a.loop->frequency_nco;
+            nr = plan_nco_dev(&acc, p.n, a.loop->fe, phase_new, a.loop_runs + (size_t)b * T2_LOOP_RUNS_CAP, T2_LOOP_RUNS_CAP);
+            if (nr < 0) { nr = 0; __hip_atomic_store(a.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        sh_nr = nr; sh_nco_far = far;
+        if (b == 0) { double *rec = a.rec; rec[11] = (double)phase_new; rec[12] = (double)acc; }   // the accumulators' new values: the last workgroup leaves them in the loop state
     }
     if (b > 0) {
         if (tid < b) {
@@ -728,7 +743,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
             const double *rec = a.rec + 16 * (size_t)tid;
             sh_rec[tid][0] = rec[0]; sh_rec[tid][1] = rec[1]; sh_rec[tid][2] = rec[2];
             if (tid == b - 1) { sh_v[2] = rec[3]; sh_v[3] = rec[4]; sh_v[6] = rec[5]; }
-            if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; if (a.loop) sh_nr = (int)rec[10]; }
+            if (tid == 0) { sh_v[0] = rec[6]; sh_v[1] = rec[7]; sh_v[4] = rec[8]; sh_v[5] = rec[9]; }
         }
         __syncthreads();
         // the aggregates of the workgroups before this one composed by a scan over the lanes (workgroup t on lane t): lane b - 1 ends up
@@ -746,18 +761,14 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
         }
         __syncthreads();
     }
+    T2_STAMP(a, b, 3);
     if (a.loop) {
-        __syncthreads();                                       // (workgroup 0: sh_nr and the runs in memory are its own lane 0's)
+        __syncthreads();                                       // (the planning lane's runs and their count)
         p.n_nco_runs = sh_nr;
-        if (sh_nr <= FRONT_CHAIN_RUNS) {
-            for (int t = tid; t < sh_nr; t += 256) sh_nco[t] = a.loop_runs[t];
-            p.nco_runs = sh_nco;
-            __syncthreads();
-        } else {
-            p.nco_runs = a.loop_runs;                          // many runs (a large residual offset): searched where they lie
-        }
+        p.nco_runs = sh_nco_far ? a.loop_runs + (size_t)b * T2_LOOP_RUNS_CAP : sh_nco;
     }
     const float c1 = (float)sh_v[4], c2 = (float)sh_v[5];
+    T2_STAMP(a, b, 4);
     // ---- de-rotation: own samples (sign statistics, the next call's delay line), then the halo by the first half of wavefront 0
     double t[3] = {0.0, 0.0, 0.0};
     derot4(p, c1, c2, sl, valid, xr, xi, ex.a * sh_v[0] + ex.re, ex.a * sh_v[1] + ex.im, D + F1_H + tid * F1_PER, t, a.pre_out);
@@ -790,6 +801,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
     const long m0 = 2 * k_lo + (1 - p.decim_phase);                             // buffer index (63-cell prefix included) of the window's first cell
     for (int w = tid; w < 63 && m0 + w < 63; w += 256) W[fd_pad(w)] = p.interp[m0 + w];   // cells the call before left
     __syncthreads();
+    T2_STAMP(a, b, 5);
     if (tid == 0) {
         double *o = p.theta_part + 4 * (long)b;
         for (int c = 0; c < 3; ++c) o[c] = (red[c][0] + red[c][1]) + (red[c][2] + red[c][3]);
@@ -835,6 +847,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
         }
     }
     __syncthreads();
+    T2_STAMP(a, b, 6);
     // ---- /2 decimator: front_farrow_decimate_body's stage, four consecutive outputs per lane
     for (int g = tid; 4 * g < n_k; g += 256) {
         const int ko = FD_R * g;
@@ -869,6 +882,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
     }
     // ---- the last workgroup to get here finishes the call (front_finish_kernel's work)
     __syncthreads();
+    T2_STAMP(a, b, 7);
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned long long before = __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -876,6 +890,7 @@ __device__ __forceinline__ void front_one_body(FrontOneArgs &a, const int b, con
         if (sh_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    T2_STAMP(a, b, 8);
     if (!sh_last) return;
     // the delay lines: the last 3 de-rotated samples, the last 63 resampled cells -- from this call where it had that many, else moved up
     float2 keep = make_float2(0.f, 0.f);
@@ -943,7 +958,8 @@ __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gp
     if (b < nb_front) { front_one_body(a, b, nb_front); return; }
     if (b >= nb_front + 8) { front_copy_ahead(a, b - nb_front - 8); return; }
     const int fb = b - nb_front;
-    if (fb < 4) {
+    T2_STAMP(a, 48 + fb, 0);
+    if (fb <= 4) {                                                // stage A's four, and the workgroup that forms the guard correlation beside them: the buffered symbol must be complete
         if (threadIdx.x == 0) {
             const unsigned long long want = a.done_target + (unsigned long long)nb_front;
             long long t0 = 0;
@@ -961,9 +977,11 @@ __global__ __launch_bounds__(256) void front_fft_one_kernel(FrontOneArgs a, t2gp
     }
     // (a 16K transform's workgroups have 128 lanes: the upper two wavefronts of these leave here -- a workgroup's barriers count the
     // wavefronts that have not ended)
+    T2_STAMP(a, 48 + fb, 1);
     if constexpr (T2 == 16) { if (threadIdx.x >= 128) return; }
     t2gpu::fft_one_sync_body<T2>(f.in, f.scratch, f.out, f.twiddle, f.count, f.p, f.idx_symbol, f.buffered, f.guard, f.cp_out, f.sync, f.h_small, f.h_flag, f.seq,
-                                 f.loop, fb, fft_lds);
+                                 f.loop, fb, fft_lds, a.stamps ? a.stamps + 16 * (48 + fb) : nullptr);
+    T2_STAMP(a, 48 + fb, 9);
 }
 
 // ---- a buffer of int16 I and Q from PAGE-LOCKED host memory into the device's staging by a kernel of the caller's stream (the

@@ -52,7 +52,7 @@ hipError_t ldpc_kernel2_attributes(int min_cnt, int max_cnt, int lds_bytes, int 
 hipError_t ldpc_kernel2_launch(int min_cnt, int max_cnt, const LdpcKernelParams &p, int grid, int lds_bytes, hipStream_t stream, bool allow_cooperative = true);
 
 // bits / verdicts / error word of a decode into page-locked host memory by a kernel of the decode's own stream (no copy engine)
-hipError_t ldpc_clear(unsigned *a, size_t na, unsigned *b, size_t nb, hipStream_t stream);
+hipError_t ldpc_clear(unsigned *a, size_t na, unsigned *b, size_t nb, hipStream_t stream, unsigned *c = nullptr, size_t nc = 0);
 hipError_t ldpc_results_to_host(const uint8_t *d_bits, size_t bytes, const int *d_trials, int n_trials, const int *d_error, uint8_t *h_bits, int *h_trials,
                                 int *h_error, hipStream_t stream);
 

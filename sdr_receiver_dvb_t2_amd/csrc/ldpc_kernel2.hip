@@ -670,18 +670,20 @@ __global__ __launch_bounds__(256) void ldpc_results_to_host_kernel(const uint4 *
 
 // zeroes the rendezvous words and the error word of a decode in the decode's own stream (two hipMemsetAsync before: the runtime's fill
 // kernels -- see t2gpu_ldpc_execute_dev)
-__global__ __launch_bounds__(256) void ldpc_clear_kernel(unsigned *a, size_t na, unsigned *b, size_t nb)
+__global__ __launch_bounds__(256) void ldpc_clear_kernel(unsigned *a, size_t na, unsigned *b, size_t nb, unsigned *c, size_t nc)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = 0u;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += stride) c[i] = 0u;
 }
-hipError_t ldpc_clear(unsigned *a, size_t na, unsigned *b, size_t nb, hipStream_t stream)
+hipError_t ldpc_clear(unsigned *a, size_t na, unsigned *b, size_t nb, hipStream_t stream, unsigned *c, size_t nc)
 {
     size_t n = na > nb ? na : nb;
+    n = n > nc ? n : nc;
     int grid = (int)((n + 255) / 256);
     grid = grid < 1 ? 1 : (grid > 64 ? 64 : grid);
-    hipLaunchKernelGGL(ldpc_clear_kernel, dim3(grid), dim3(256), 0, stream, a, na, b, nb);
+    hipLaunchKernelGGL(ldpc_clear_kernel, dim3(grid), dim3(256), 0, stream, a, na, b, nb, c, nc);
     return hipGetLastError();
 }
 

@@ -198,7 +198,8 @@ __device__ __forceinline__ PilotEst pilot_estimate(float2 cell, float refer, flo
 template <int NL>
 __device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *__restrict__ symbol, int idx_symbol,
                                               const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, float *sy_lds, T2DevLoop *loop)
+                                              float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, float *sy_lds, T2DevLoop *loop,
+                                              const float4 *cp_ready = nullptr /* the guard correlation, formed already (fft_one_sync_body) */)
 {
     __shared__ int sh_lower;
     const int tid = threadIdx.x;
@@ -222,10 +223,11 @@ __device__ __forceinline__ void sym_sync_body(const EqParams &p, const float2 *_
     for (int d = 32; d > 0; d >>= 1) lower += __shfl_xor(lower, d, 64);
     if ((tid & 63) == 0 && lower) atomicAdd(&sh_lower, lower);
     float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (buffered) {
+    if (buffered && !cp_ready) {
         double (*red)[256] = reinterpret_cast<double (*)[256]>(sy_lds + 4 * (size_t)(p.max_seg + 2));
         cp = cp_correlate_body<NL>(buffered, p.fft_size, guard, red);               // (its barriers also publish l4 / sh_lower)
     } else {
+        if (buffered && tid == 0) cp = *cp_ready;                                   // (lane 0 is the one that uses it)
         __syncthreads();
     }
     lower = sh_lower;
@@ -287,17 +289,28 @@ template <int T2>
 __device__ __forceinline__ void fft_one_sync_body(const float2 *__restrict__ in, float2 *__restrict__ scratch, float2 *__restrict__ out,
                                                   const float2 *__restrict__ twiddle, unsigned *count, const EqParams &p, int idx_symbol,
                                                   const float2 *__restrict__ buffered, int guard, float4 *cp_out,
-                                                  float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, T2DevLoop *loop, const int b, float *lds)
+                                                  float2 *__restrict__ sync, float *h_small, unsigned *h_flag, unsigned seq, T2DevLoop *loop, const int b, float *lds,
+                                                  long long *stamps = nullptr /* development: 16 wall-clock stamps of this workgroup */)
 {
     __shared__ int sh_last;
     if (b < 4) {
         fft_stage_a_body<T2>(in, scratch, twiddle, b * (8 * T2) + (int)threadIdx.x);
         __syncthreads();
+        if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
+    }
+    // The guard correlation needs the buffered symbol only, not its transform: the first of these four workgroups forms it NOW, while stage A
+    // runs (round 6; the last workgroup formed it behind the transform before: ~2.5 us of every symbol's chain). Same function, same lanes,
+    // same tree: the same floats. It reaches the last workgroup through memory, behind this workgroup's release below.
+    float4 *cp_slot = reinterpret_cast<float4 *>(count + 8);
+    if (b == 4 && buffered) {
+        const float4 cp = cp_correlate_body<8 * T2>(buffered, p.fft_size, guard, reinterpret_cast<double (*)[256]>(lds));
+        if (threadIdx.x == 0) *cp_slot = cp;
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         unsigned spins = 0;
@@ -306,8 +319,10 @@ __device__ __forceinline__ void fft_one_sync_body(const float2 *__restrict__ in,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
     fft_stage_bc_body<T2>(scratch, out, twiddle, lds, b - 4);
     __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[4] = wall_clock64();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned before = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,7 +335,9 @@ __device__ __forceinline__ void fft_one_sync_body(const float2 *__restrict__ in,
     }
     __syncthreads();
     if (!sh_last) return;
-    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds, loop);
+    if (stamps && threadIdx.x == 0) stamps[5] = wall_clock64();
+    sym_sync_body<8 * T2>(p, out, idx_symbol, buffered, guard, cp_out, sync, h_small, h_flag, seq, lds, loop, cp_slot);
+    if (stamps && threadIdx.x == 0) stamps[6] = wall_clock64();
 }
 
 }  // namespace t2gpu

@@ -57,6 +57,7 @@ struct t2gpu_demap {
     uint16_t *d_address = nullptr;
     double *d_partial = nullptr;
     float2 *d_terms = nullptr;         // the statistics' per-cell terms (|s|^2, |e|^2): scratch of the exact sequential sums
+    long terms_pad_key = 0;            // TiTerms::pad_key: 0 whenever anything but launch_ti_blocks has written the scratch
     size_t terms_cells = 0;
     float *d_sums = nullptr;
     float *d_cells = nullptr;      // host-call staging
@@ -121,7 +122,7 @@ static bool ensure_terms(t2gpu_demap *h, size_t cells, hipStream_t s)
     if (!hip_ok(hipMalloc(&p, cells * sizeof(float2)), "hipMalloc")) return false;
     if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) { hipFree(p); return false; }
     hipFree(h->d_terms);
-    h->d_terms = p; h->terms_cells = cells;
+    h->d_terms = p; h->terms_cells = cells; h->terms_pad_key = 0;
     return true;
 }
 
@@ -135,6 +136,7 @@ extern "C" int t2gpu_demap_execute_dev(t2gpu_demap *h, const float *d_cells, int
     const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;       // llr_demapper.cpp:184 (QPSK: first 2048 cells)
     int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
     if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr), s)) return -1;
+    h->terms_pad_key = 0;
     T2_HIP(launch_demap_stats(h->p, cells, n_snr, h->d_partial, blocks, h->d_terms, sums, precision_override, s));
     const int n_frames = n_cells / h->p.cells_per_fec;
     if (n_frames > 0) T2_HIP(launch_demap_llr(h->p, cells, n_frames, sums, d_llr, s));
@@ -150,6 +152,7 @@ extern "C" int t2gpu_demap_stats_dev(t2gpu_demap *h, const float *d_cells, int n
     const int n_snr = h->p.mod == 0 ? std::min(n_cells, 2048) : n_cells;
     const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
     if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr), (hipStream_t)stream)) return -1;
+    h->terms_pad_key = 0;
     T2_HIP(launch_demap_stats(h->p, reinterpret_cast<const float2 *>(d_cells), n_snr, h->d_partial, blocks, h->d_terms, d_sums3, precision_override,
                               (hipStream_t)stream));
     return 0;
@@ -176,6 +179,7 @@ extern "C" int t2gpu_demap_stats_batch_dev(t2gpu_demap *h, const float *d_cells,
     const int n_snr = h->p.mod == 0 ? std::min(cells_per_block, 2048) : cells_per_block;
     const int blocks = std::min(h->stats_blocks, (n_snr + 255) / 256);
     if (!ensure_terms(h, (size_t)demap_terms_padded(n_snr) * n_blocks, (hipStream_t)stream)) return -1;
+    h->terms_pad_key = 0;
     T2_HIP(launch_demap_stats_batch(h->p, reinterpret_cast<const float2 *>(d_cells), cells_stride, n_snr, n_blocks, h->d_partial, blocks,
                                     h->d_terms, d_sums, sums_stride, precision_override, (hipStream_t)stream));
     return 0;
@@ -371,7 +375,7 @@ extern "C" int t2gpu_ti_execute_blocks_terms_dev(t2gpu_ti *h, t2gpu_demap *dm, c
     if (!fused) return t2gpu_ti_execute_blocks_dev(h, d_cells, in_stride_cells, d_out, out_stride_cells, n_blocks, stream) < 0 ? -1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (!ensure_terms(dm, (size_t)demap_terms_padded(n_snr) * n_blocks, s)) return -1;
-    const TiTerms tt{&dm->p, dm->d_terms, n_snr};
+    const TiTerms tt{&dm->p, dm->d_terms, n_snr, &dm->terms_pad_key};
     T2_HIP(launch_ti_blocks(h->p, h->d_lost_blk, h->num_blocks, reinterpret_cast<const float2 *>(d_cells), in_stride_cells,
                             reinterpret_cast<float2 *>(d_out), out_stride_cells, n_blocks, s, &tt));
     return 1;

@@ -45,6 +45,8 @@ struct t2gpu_front {
     size_t dev_nn = 0;
     bool dev_runs_valid = false;
     // short calls in one launch (front_kernels.hip: front_one_kernel); t2gpu_front_set_chain(h, 0) keeps the five launches
+    long long *h_stamps = nullptr;     // T2GPU_FRONT_STAMPS=1: phase stamps of the one-launch form's last launch (printed when the handle goes)
+    long stamps_fused = 0;
     char *d_one = nullptr;             // its flags [F1_MAX_GRID], done word, records [F1_MAX_GRID][16], scratch prefix [66]
     unsigned long long one_seq = 0, one_done = 0;
     int *d_chain_error = nullptr;      // raised by a look-back wait of that kernel that gave up
@@ -181,13 +183,16 @@ extern "C" t2gpu_front *t2gpu_front_create(int id_device, float sample_rate, int
         const float rk = 1.0f / k_table;
         for (int i = -32767; i < 32768; ++i) sincosf((float)i * rk, &lut[i + 32767], &lut[65536 + i + 32767]);
     }
+    if (const char *e = std::getenv("T2GPU_FRONT_STAMPS"))
+        if (std::atoi(e) != 0 && hipHostMalloc(reinterpret_cast<void **>(&h->h_stamps), 64 * 16 * sizeof(long long), hipHostMallocCoherent) == hipSuccess)
+            std::memset(h->h_stamps, 0, 64 * 16 * sizeof(long long));
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_state), sizeof(FrontState) + 64, hipHostMallocCoherent) == hipSuccess) {
         h->h_flag = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(h->h_state) + ((sizeof(FrontState) + 15) & ~size_t(15)));
         *h->h_flag = 0;
     }
     constexpr size_t ONE_BYTES = 8 * (size_t)F1_MAX_GRID + 64 + 128 * (size_t)F1_MAX_GRID + 66 * sizeof(float2);
     bool ok = hipMalloc(&h->d_loop, sizeof(T2DevLoop)) == hipSuccess && hipMemset(h->d_loop, 0, sizeof(T2DevLoop)) == hipSuccess &&
-              hipMalloc(&h->d_loop_runs, (size_t)T2_LOOP_RUNS_CAP * sizeof(FrontRun)) == hipSuccess &&
+              hipMalloc(&h->d_loop_runs, (size_t)F1_MAX_GRID * T2_LOOP_RUNS_CAP * sizeof(FrontRun)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void **>(&h->h_loop), sizeof(T2DevLoop), hipHostMallocDefault) == hipSuccess &&
               hipMalloc(&h->d_one, ONE_BYTES) == hipSuccess && hipMemset(h->d_one, 0, ONE_BYTES) == hipSuccess &&
               hipMalloc(&h->d_chain_error, 4) == hipSuccess && hipMemset(h->d_chain_error, 0, 4) == hipSuccess &&
@@ -212,6 +217,22 @@ extern "C" void t2gpu_front_destroy(t2gpu_front *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    if (h->h_stamps) {
+        // development: the phases of the LAST one-launch form launched (front_kernels.hip T2_STAMP), microseconds from the launch's first stamp
+        hipDeviceSynchronize();
+        long long t0 = 0;
+        for (int i = 0; i < 64 * 16; ++i) if (h->h_stamps[i] && (!t0 || h->h_stamps[i] < t0)) t0 = h->h_stamps[i];
+        std::fprintf(stderr, "t2gpu_front stamps (us from the first; rows: workgroup -- 0.. front end, 48..51 FFT stage A, 52..55 stages B + C):\n");
+        for (int w = 0; w < 64; ++w) {
+            bool any = false;
+            for (int k = 0; k < 16; ++k) any = any || h->h_stamps[16 * w + k];
+            if (!any) continue;
+            std::fprintf(stderr, "  wg %2d:", w);
+            for (int k = 0; k < 10; ++k) { if (h->h_stamps[16 * w + k]) std::fprintf(stderr, " %6.2f", (h->h_stamps[16 * w + k] - t0) * 0.01); else std::fprintf(stderr, "      -"); }
+            std::fprintf(stderr, "\n");
+        }
+        hipHostFree(h->h_stamps);
+    }
     hipFree(h->d_one); hipFree(h->d_chain_error); hipFree(h->d_loop); hipFree(h->d_loop_runs);
     if (h->h_loop) hipHostFree(h->h_loop);
     if (h->h_loop_out) hipHostFree(h->h_loop_out);
@@ -356,6 +377,7 @@ extern "C" long t2gpu_front_execute_dev(t2gpu_front *h, int n_chunks, const int3
         a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
         a.loop = nullptr; a.loop_runs = nullptr;
         a.cp_si = a.cp_sq = nullptr; a.cp_di = a.cp_dq = nullptr; a.cp_n = 0; a.cp_wgs = 0;
+        a.stamps = nullptr;
         launch_front_one(a, one_grid, stream);
         // the device's words move only if the launch was accepted: the host's copies follow it, not the attempt
         T2_HIP(hipGetLastError());
@@ -430,6 +452,7 @@ long t2gpu_front_loop_fft(t2gpu_front *h, int32_t chunk, double rs, const int16_
     a.seq = h->one_seq + 1; a.done_target = h->one_done; a.error = h->d_chain_error;
     a.loop = h->d_loop; a.loop_runs = h->d_loop_runs;
     a.cp_si = a.cp_sq = nullptr; a.cp_di = a.cp_dq = nullptr; a.cp_n = 0; a.cp_wgs = 0;
+    a.stamps = h->h_stamps;
     if (ahead && ahead->n > 0) {                                  // the next chunk's I/Q comes over beside this chunk's work: 8 KB per workgroup and pass
         a.cp_si = ahead->si; a.cp_sq = ahead->sq; a.cp_di = ahead->di; a.cp_dq = ahead->dq; a.cp_n = ahead->n;
         a.cp_wgs = (int)std::min<long>(16, (ahead->n / 8 + 255) / 256);

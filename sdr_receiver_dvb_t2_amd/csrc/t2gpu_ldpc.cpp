@@ -321,7 +321,21 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     int grid = nslots * wg_per_batch;
     if ((size_t)nbatches * (h->max_trials + 1) > h->sync_words) { set_error("sync scratch too small"); return -1; }
 
-    T2_HIP(ldpc_clear(reinterpret_cast<unsigned *>(h->d_sync), (size_t)nbatches * (h->max_trials + 1), reinterpret_cast<unsigned *>(h->d_error), 1, s));
+    // One persistent launch walks all batches; with more batches than resident slots they are handed out by ticket, so that slots whose
+    // batches stop early take more of them (best when batches take different numbers of sweeps). The ticket words are zeroed with the
+    // rendezvous words, by the one clear launch (a hipMemsetAsync is a runtime fill kernel of its own: ~20 us in the decode's stream).
+    size_t ticket_words = 0;
+    if (nbatches > nslots) {
+        ticket_words = 1 + (size_t)nslots * nbatches;
+        if (ticket_words > h->ticket_words) {
+            T2_HIP(hipStreamSynchronize(s));
+            hipFree(h->d_ticket); h->d_ticket = nullptr; h->ticket_words = 0;
+            T2_HIP(hipMalloc(&h->d_ticket, ticket_words * 4));
+            h->ticket_words = ticket_words;
+        }
+    }
+    T2_HIP(ldpc_clear(reinterpret_cast<unsigned *>(h->d_sync), (size_t)nbatches * (h->max_trials + 1), reinterpret_cast<unsigned *>(h->d_error), 1, s,
+                      reinterpret_cast<unsigned *>(h->d_ticket), ticket_words));
     LdpcKernelParams p;
     p.n = h->g.n; p.k = h->g.k; p.q = h->g.q;
     p.layers = h->d_layers; p.layer_words = reinterpret_cast<const uint4 *>(h->d_layer_words); p.entries = h->d_entries; p.entries2 = h->d_entries2p;
@@ -340,19 +354,7 @@ extern "C" int t2gpu_ldpc_execute_dev(t2gpu_ldpc *h, const int8_t *d_llr, int n_
     p.prof_blocks = (int)prof_blocks(h);
     p.resident = h->d_resident;
     if (h->d_prof) T2_HIP(hipMemsetAsync(h->d_prof, 0, (prof_blocks(h) * 8 + 64) * sizeof(long long), s));
-    // One persistent launch walks all batches; with more batches than resident slots they are handed out by ticket, so that slots whose
-    // batches stop early take more of them (best when batches take different numbers of sweeps).
-    if (nbatches > nslots) {
-        const size_t words = 1 + (size_t)nslots * nbatches;
-        if (words > h->ticket_words) {
-            T2_HIP(hipStreamSynchronize(s));
-            hipFree(h->d_ticket); h->d_ticket = nullptr; h->ticket_words = 0;
-            T2_HIP(hipMalloc(&h->d_ticket, words * 4));
-            h->ticket_words = words;
-        }
-        T2_HIP(hipMemsetAsync(h->d_ticket, 0, words * 4, s));
-        p.ticket = h->d_ticket; p.ticket_rounds = nbatches;
-    }
+    if (nbatches > nslots) { p.ticket = h->d_ticket; p.ticket_rounds = nbatches; }
     h->resident_total += (unsigned)grid;
     T2_HIP(ldpc_kernel2_launch(h->g.min_cnt, h->g.max_cnt, p, grid, h->p_lds_bytes, s, !(h->plain_launch || h->plain_always)));
     return 0;

@@ -109,7 +109,7 @@ struct t2gpu_ofdm {
     uint32_t *d_sel = nullptr, *d_sel_p2 = nullptr, *d_sel_fc = nullptr;
     // host-call staging
     float2 *d_in = nullptr, *d_out = nullptr, *d_sync = nullptr;
-    int32_t *d_index = nullptr;
+    int32_t *d_index = nullptr, *d_index_zero = nullptr;   // d_index_zero: max_symbols zeros (every P2 symbol of a batch is frame symbol 0)
 };
 
 extern "C" t2gpu_ofdm *t2gpu_ofdm_create(int fft_mode, int carrier_mode, int pilot_pattern, int guard_interval_mode, int papr_mode,
@@ -314,7 +314,7 @@ extern "C" void t2gpu_ofdm_destroy(t2gpu_ofdm *h)
     hipFree(h->d_h_even); hipFree(h->d_h_odd); hipFree(h->d_pilot_scratch); hipFree(h->d_pilot_scratch_p2); hipFree(h->d_pilot_scratch_fc); hipFree(h->d_in); hipFree(h->d_out);
     hipFree(h->d_dcar); hipFree(h->d_dcar_p2); hipFree(h->d_dcar_fc);
     hipFree(h->d_cellq); hipFree(h->d_cellq_p2); hipFree(h->d_cellq_fc); hipFree(h->d_sel); hipFree(h->d_sel_p2); hipFree(h->d_sel_fc);
-    hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
+    hipFree(h->d_sync); hipFree(h->d_index); hipFree(h->d_index_zero); hipFree(h->d_map_p2); hipFree(h->d_refer_p2); hipFree(h->d_segs_p2);
     hipFree(h->d_seg_count_p2); hipFree(h->d_h_even_p2); hipFree(h->d_h_odd_p2);
     hipFree(h->d_map_fc); hipFree(h->d_refer_fc); hipFree(h->d_segs_fc); hipFree(h->d_seg_count_fc); hipFree(h->d_h_even_fc);
     hipFree(h->d_h_odd_fc); hipFree(h->d_index_fc);
@@ -350,6 +350,8 @@ static int ensure_staging(t2gpu_ofdm *h)
     T2_HIP(hipMalloc(&h->d_out, (size_t)h->max_symbols * h->m.fft_size * sizeof(float2)));
     T2_HIP(hipMalloc(&h->d_sync, (size_t)h->max_symbols * sizeof(float2)));
     T2_HIP(hipMalloc(&h->d_index, (size_t)h->max_symbols * 4));
+    T2_HIP(hipMalloc(&h->d_index_zero, (size_t)h->max_symbols * 4));
+    T2_HIP(hipMemset(h->d_index_zero, 0, (size_t)h->max_symbols * 4));
     return 0;
 }
 
@@ -416,8 +418,7 @@ extern "C" int t2gpu_eq_p2_execute_dev(t2gpu_ofdm *h, const float *d_symbols, in
     if (!h || !d_symbols || !d_cells || n_symbols < 1 || n_symbols > h->max_symbols) { set_error("t2gpu_eq_p2_execute_dev: bad arguments"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     if (ensure_staging(h)) return -1;
-    T2_HIP(hipMemsetAsync(h->d_index, 0, (size_t)n_symbols * 4, s));           // every symbol is frame symbol 0
-    T2_HIP(launch_eq_data(h->eq_p2, reinterpret_cast<const float2 *>(d_symbols), h->d_index, n_symbols, reinterpret_cast<float2 *>(d_cells),
+    T2_HIP(launch_eq_data(h->eq_p2, reinterpret_cast<const float2 *>(d_symbols), h->d_index_zero, n_symbols, reinterpret_cast<float2 *>(d_cells),
                           h->d_pilot_scratch_p2, reinterpret_cast<float2 *>(d_sync), s));
     return h->m.c_p2;
 }
