@@ -539,14 +539,26 @@ extern "C" int t2gpu_ldpc_submit_go(t2gpu_ldpc *h)
     }
     h->s_frames = 0;
     // several submits run side by side (cooperative launches would not). What they hold of the device together is booked (above): this
-    // call waits while the decodes in flight leave no room for its grid, and a grid the device could never hold as a whole goes through
-    // the cooperative launch, which refuses rather than hangs
-    const int wgs = t2gpu_ldpc_launch_workgroups(h, n_frames);
+    // call waits while the decodes in flight leave no room for its grid. The grid itself is sized for the CUs this stream can reach: its
+    // CU mask leaves a_cu_reserve CUs out, and a ticketed persistent grid larger than what fits there would have workgroups that are
+    // never dispatched while the resident ones wait for them at the batch rendezvous (the cooperative launch's occupancy check
+    // counts the whole device, not the mask). So the resident slots are capped to whole batches inside the mask -- the other batches are
+    // handed out by ticket as slots come free -- and the launch is always a plain one.
     const int per_cu = h->p_blocks_per_cu;
-    if (wgs < 1 || per_cu < 1) { set_error("t2gpu_ldpc_submit: the device cannot keep one batch resident"); return -1; }
-    h->plain_launch = book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu - h->a_cu_reserve);
-    const int rc = t2gpu_ldpc_execute_dev(h, d_llr, n_frames, h->d_out, nullptr, h->d_trials, s);
-    h->plain_launch = false;
+    const int reach = (h->num_cu - h->a_cu_reserve) * per_cu / wg_per_batch(h);
+    if (per_cu < 1 || reach < 1) { set_error("t2gpu_ldpc_submit: the CUs this stream can reach cannot keep one batch resident"); return -1; }
+    const int cap_was = h->slot_cap;
+    h->slot_cap = cap_was >= 1 && cap_was < reach ? cap_was : reach;
+    const int wgs = t2gpu_ldpc_launch_workgroups(h, n_frames);
+    int rc = -1;
+    if (wgs >= 1 && book_cus(h, h->a_done, (wgs + per_cu - 1) / per_cu, h->num_cu - h->a_cu_reserve)) {
+        h->plain_launch = true;
+        rc = t2gpu_ldpc_execute_dev(h, d_llr, n_frames, h->d_out, nullptr, h->d_trials, s);
+        h->plain_launch = false;
+    } else {
+        set_error("t2gpu_ldpc_submit: the decode's grid does not fit the CUs of its stream");
+    }
+    h->slot_cap = cap_was;
     if (rc) { unbook(h); return -1; }
     // results to the page-locked staging by a kernel of this stream, not by the copy engine (ldpc_kernel2.hip: one in-order copy queue
     // for all streams made the decodes of different handles wait for each other)

@@ -33,16 +33,16 @@ def run_binding(lib, case, tmp_path, env_extra=None):
         return {k: z[k] for k in z.files}, p.stderr
 
 
-@pytest.mark.parametrize("lib", ["ref_t2rx_gpufec", "ref_t2rx_gpu"])
-def test_the_reference_runs_on_the_library(built, tmp_path, lib):
+@pytest.mark.parametrize("lib,case", [("ref_t2rx_gpufec", "rx16k"), ("ref_t2rx_gpu", "rx16k"), ("ref_t2rx_gpu", "rx32k")])
+def test_the_reference_runs_on_the_library(built, tmp_path, lib, case):
     if not _have(lib):
         pytest.skip("oracle/_ref/lib%s.so (built where /root/reference and the Qt SDK are) is not here" % lib)
-    g = sub(_load("t2rx_golden.npz"), "rxoff", "rx16k")
-    got, err = run_binding(lib, "rx16k", tmp_path)
+    g = sub(_load("t2rx_golden.npz"), "rxoff", case)
+    got, err = run_binding(lib, case, tmp_path)
     want = g["ts_packet_crc"]
     mine = got["ts_packet_crc"]
-    print("%s: %d BBFRAMEs (reference %d), %d TS packets (reference %d), re-tune requests %s" %
-          (lib, int(got["bbframes"]), int(g["bbframes"]), len(mine), len(want), got["asked"].tolist()))
+    print("%s on %s: %d BBFRAMEs (reference %d), %d TS packets (reference %d), re-tune requests %s" %
+          (lib, case, int(got["bbframes"]), int(g["bbframes"]), len(mine), len(want), got["asked"].tolist()))
     assert [int(k) for k, _ in got["asked"]] == [int(k) for k, _, _ in g["moves"]]
     assert np.abs(got["asked"][:, 1] - g["moves"][:, 1]).max() < 1.0
     assert int(got["bbframes"]) == int(g["bbframes"])

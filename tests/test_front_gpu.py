@@ -274,7 +274,7 @@ def test_decimator_and_farrow_against_reference_vectors(torch_cuda):
 
 
 def test_the_loop_on_the_device_plans_the_nco_as_the_host_does(torch_cuda):
-    """t2gpu_front_execute_loop_dev (the chunk's NCO runs planned by workgroup 0 from the device's loop state) against
+    """t2gpu_front_execute_loop_dev (the chunk's NCO runs planned from the device's loop state, by every workgroup for itself since round 6) against
     t2gpu_front_execute_dev with the same loop values planned on the host: every cell bit for bit, and the device's accumulators where the
     host's are after t2gpu_front_loop_follow -- residual offsets from none to one that takes hundreds of runs per chunk (searched in memory),
     symbol-sized chunks and the few-sample ones that complete a symbol."""
