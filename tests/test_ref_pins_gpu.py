@@ -61,7 +61,7 @@ def close_cells(got, want, what):
 
 @pytest.mark.parametrize("name", list(rc.SYM_MODES))
 def test_equalisers_against_the_reference(torch_cuda, gsym, name):
-    """eq_data_kernel with the data / P2 / frame-closing tables on the spectra the reference equalised: data symbols bit-exact
+    """The equaliser (eq_split_kernel) with the data / P2 / frame-closing tables on the spectra the reference equalised: data symbols bit-exact
     (cells and both sync outputs); P2 and FC cells bit-exact except <= 0.05 % within 3e-4, phase within 1e-6, sample-rate offset
     within 2.5e-4 (see tests/test_ref_pins.py::test_equalisers_equal_the_reference). The P2 symbol is read with the extended-carrier
     tables whatever the mode, as the reference reads it."""

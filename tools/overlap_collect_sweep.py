@@ -21,15 +21,16 @@ F = 48
 di = torch.from_numpy(np.concatenate([ui] * (F // 2)).reshape(-1)).cuda()
 dq = torch.from_numpy(np.concatenate([uq] * (F // 2)).reshape(-1)).cuda()
 FS = w.frame_samples
-TS = len(sys.argv) > 1 and sys.argv[1] == "--ts"             # with the library's host end (L1 parse, drop rule, de-framer) on
-print("host end", "on" if TS else "off")
+TS = len(sys.argv) > 1 and sys.argv[1].startswith("--ts")
+L1 = not (len(sys.argv) > 1 and sys.argv[1] == "--ts-nol1")             # with the library's host end (L1 parse, drop rule, de-framer) on
+print("host end", ("on" if L1 else "on, without the per-frame L1 check") if TS else "off")
 for nf in (1, 2, 4):
     row = []
     for K in (0, 12, 13, 14):
         os.environ["T2GPU_RX_COLLECT"] = str(K)
         rx = t2_rx(*w.mode, w.lps, *w.plp, w.nb, max_frames=nf)
         if TS:
-            rx.ts_enable(0, l1_check=True)
+            rx.ts_enable(0, l1_check=L1)
         rx.execute_dev(di, dq, nf, first_call=True)
         torch.cuda.synchronize()
         if rx.carry:
