@@ -433,6 +433,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Every library call below goes on a stream of this process's own, not the legacy NULL stream: a launch on the NULL stream waits for
+    # every blocking stream of the process, and the receiver's helper streams (decode sets, host end's copies: hardware queues of their
+    # own, t2gpu.h) are blocking streams in that sense -- small overlapped calls would run behind the decodes they are meant to run beside.
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: the loopback interface (the container's hostname may not resolve)

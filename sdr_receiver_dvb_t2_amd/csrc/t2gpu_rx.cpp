@@ -31,6 +31,38 @@
 using namespace t2gpu;
 
 namespace {
+// A stream with a hardware queue of its own, for the handle's helper streams (decode sets, the host end's copies): each of them spends
+// most of its life waiting for a decode to finish, and the runtime deals plain streams round-robin onto a pool of FOUR hardware queues
+// per device -- a fifth stream shares a queue with the first, and a queue is served in order: with the host end on, the decode set's
+// stream landed in the caller's queue and every call ran BEHIND the decode it was meant to run beside (profiles/HISTORY.md, round 6:
+// one-frame calls 1016 -> 1465 Msamples/s). A stream created with a CU mask (here: all CUs) gets a queue that is never shared. It is a
+// blocking stream in the legacy null stream's sense: a caller that works on the NULL stream serialises with the decodes (t2gpu.h).
+// Streams a destroyed handle gives back are kept (per device) for the next one: making and destroying hardware queues again and again
+// left later handles of a process ~10 % slower than its first.
+std::mutex g_private_m;
+std::vector<std::pair<int, hipStream_t>> g_private_free;
+hipError_t private_queue_stream(hipStream_t *s, int device, int num_cu)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_private_m);
+        for (size_t k = 0; k < g_private_free.size(); ++k)
+            if (g_private_free[k].first == device) { *s = g_private_free[k].second; g_private_free.erase(g_private_free.begin() + (long)k); return hipSuccess; }
+    }
+    if (num_cu > 0 && num_cu <= 1024) {
+        uint32_t mask[32] = {0};
+        for (int c = 0; c < num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
+        if (hipExtStreamCreateWithCUMask(s, (uint32_t)((num_cu + 31) / 32), mask) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+void private_queue_stream_release(hipStream_t s, int device)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_private_m);
+    g_private_free.emplace_back(device, s);
+}
 constexpr int P1_LEN = 2048, L1_PRE_CELL = 1840;
 constexpr int ACC_BATCHES = 14;             // overlap mode, small calls: see t2gpu_rx_back_dev (14 of the 16 batch slots a 64800-bit decode can keep resident)
 }
@@ -169,7 +201,7 @@ void free_all(t2gpu_rx *h)
     for (int b = 1; b < 3; ++b) hipFree(h->d_llr_ab[b]);
     if (h->ldpc_s[1]) t2gpu_ldpc_destroy(h->ldpc_s[1]);
     hipFree(h->d_bits_s[1]); hipFree(h->d_pack_s[1]); hipFree(h->d_trials_s[1]);
-    for (hipStream_t st : h->dec_s) if (st) hipStreamDestroy(st);
+    for (hipStream_t st : h->dec_s) private_queue_stream_release(st, h->device);
     for (hipEvent_t e : {h->ev_demap, h->ev_l1_copied, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
                          h->ev_dec_done[0], h->ev_dec_done[1]}) if (e) hipEventDestroy(e);
 }
@@ -192,8 +224,8 @@ void ts_stop(t2gpu_rx *h)
         if (sl.l1_ready) hipEventDestroy(sl.l1_ready);
     }
     if (t->bbdh) t2gpu_bbdh_destroy(t->bbdh);
-    if (t->copy_stream) hipStreamDestroy(t->copy_stream);
-    if (t->l1_stream) hipStreamDestroy(t->l1_stream);
+    private_queue_stream_release(t->copy_stream, h->device);
+    private_queue_stream_release(t->l1_stream, h->device);
     if (t->decoded) hipEventDestroy(t->decoded);
     delete t;
     h->ts = nullptr;
@@ -584,7 +616,7 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         }
         // (default priority: at the lowest one the next call's front half, issued later, was dispatched ahead of the decode it is meant
         // to run beside -- 2- to 16-frame calls lost 2 - 7 %)
-        for (int k = 0; k < 2 && ok; ++k) ok = h->dec_s[k] || hipStreamCreateWithFlags(&h->dec_s[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) ok = h->dec_s[k] || private_queue_stream(&h->dec_s[k], h->device, h->num_cu) == hipSuccess;
         for (hipEvent_t *e : {&h->ev_demap, &h->ev_l1_copied, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
                               &h->ev_carry[2], &h->ev_dec_done[0], &h->ev_dec_done[1]})
             ok = ok && (*e || hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess);
@@ -839,8 +871,8 @@ extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
              hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sl.l1_ready, hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&t->l1_stream, hipStreamNonBlocking) == hipSuccess &&
+    ok = ok && private_queue_stream(&t->copy_stream, h->device, h->num_cu) == hipSuccess &&
+         private_queue_stream(&t->l1_stream, h->device, h->num_cu) == hipSuccess &&
          hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming) == hipSuccess;
     h->ts = t;
     if (!ok) { ts_stop(h); set_error("t2gpu_rx_ts_enable: pinned host memory allocation failed"); return -1; }

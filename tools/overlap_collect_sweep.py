@@ -21,12 +21,14 @@ F = 48
 di = torch.from_numpy(np.concatenate([ui] * (F // 2)).reshape(-1)).cuda()
 dq = torch.from_numpy(np.concatenate([uq] * (F // 2)).reshape(-1)).cuda()
 FS = w.frame_samples
+if not os.environ.get("PROBE_NULL_STREAM"):
+    torch.cuda.set_stream(torch.cuda.Stream())          # not the legacy null stream (PROBE_NULL_STREAM=1: on it)
 TS = len(sys.argv) > 1 and sys.argv[1].startswith("--ts")
 L1 = not (len(sys.argv) > 1 and sys.argv[1] == "--ts-nol1")             # with the library's host end (L1 parse, drop rule, de-framer) on
 print("host end", ("on" if L1 else "on, without the per-frame L1 check") if TS else "off")
 for nf in (1, 2, 4):
     row = []
-    for K in (0, 12, 13, 14):
+    for K in [int(x) for x in os.environ.get("SWEEP_K", "0,12,13,14").split(",")]:
         os.environ["T2GPU_RX_COLLECT"] = str(K)
         rx = t2_rx(*w.mode, w.lps, *w.plp, w.nb, max_frames=nf)
         if TS:
