@@ -406,6 +406,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informative legs: 50-trial point, clamped-LLR variant, config 5 (profiling runs)")
     ap.add_argument("--no-clamped-variant", action="store_true", help="(kept for old command lines) same as --no-extra-legs")
+    ap.add_argument("--only-frames-sweep", action="store_true", help="of the informative legs run the frames-per-call sweep alone (no 50-trial / clamped / drop-in / other-config legs)")
     ap.add_argument("--only-drop-in", action="store_true", help="run the drop_in leg alone (the slot-shaped path) and print its JSON")
     ap.add_argument("--saturate", action="store_true", help="with --only-drop-in: the clamped-LLR extension instead of the reference's wrapping cast")
     ap.add_argument("--no-ts-end", action="store_true", help="leave the library's host end (L1 parse + de-framing worker) off")
@@ -433,9 +434,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # Every library call below goes on a stream of this process's own, not the legacy NULL stream: a launch on the NULL stream waits for
-    # every blocking stream of the process, and the receiver's helper streams (decode sets, host end's copies: hardware queues of their
-    # own, t2gpu.h) are blocking streams in that sense -- small overlapped calls would run behind the decodes they are meant to run beside.
+    # Every library call below goes on a stream of this process's own, not the legacy NULL stream (whose every launch checks all the
+    # process's blocking streams). The receiver's overlap mode does not depend on it: there a call runs on the handle's own streams.
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -518,12 +518,16 @@ def main():
                     got[0] += n
                     if n == 0:
                         break
-            consumer = threading.Thread(target=consume) if ts_on else None
+            consumer = threading.Thread(target=consume) if ts_on and not os.environ.get("T2GPU_BENCH_NO_CONSUMER") else None
             t0 = time.perf_counter()
             if consumer:
                 consumer.start()
+            call_s = [] if os.environ.get("T2GPU_BENCH_CALL_TIMES") else None
             for it in range(steps):
+                tc = time.perf_counter()
                 step(rx, level, nf)
+                if call_s is not None:
+                    call_s.append(time.perf_counter() - tc)
                 if not drain and it + 1 < steps:       # calls follow each other without the host waiting for the device in between
                     continue
                 for k, v in rx.stage_ms().items():     # HIP events between the stages on the call's stream; also drains the step
@@ -538,6 +542,9 @@ def main():
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
+            if call_s:                                 # T2GPU_BENCH_CALL_TIMES=1: host time inside each call of the leg
+                print("  calls of %d frame(s), host ms: %s ... sum %.2f of %.2f" % (nf, " ".join("%.2f" % (x * 1e3) for x in call_s[:24]), sum(call_s) * 1e3,
+                                                                               (time.perf_counter() - t0) * 1e3), file=sys.stderr)
             return time.perf_counter() - t0, acc, ldpc, ts_bytes, (sink[:ts_bytes] if ts_on and keep_ts else None)
 
         def ts_check(ts, tsb, secs, n_steps, counters=None):
@@ -573,26 +580,27 @@ def main():
 
         extra = {}
         if rank == 0 and world == 1 and full and extras:     # N = 1 only: timed_leg's barriers are collective
-            # (i) the BASELINE config's "50 iters" point beside the reference's own TRIALS = 25
-            r50 = make_rx(False, F, 50)
-            r50.execute_dev(d_i, d_q, F, first_call=True)
-            e50, _, l50, _, _ = timed_leg(r50, 2, 1, level)
-            r50.close()
-            extra["trials_50"] = {"msamples_per_s": round(2 * F * FS / e50 / 1e6, 1), "ldpc_ms": round(sum(l50) / len(l50), 3),
-                                  "note": "same workload with the LDPC trial limit at 50 (BASELINE.json config text); the reference itself stops at 25"}
-            # (ii) clamped LLRs (extension) -> the same frames decode; demod -> TS with every byte checked
-            c3 = make_rx(True, F, args.trials)
-            c3.execute_dev(d_i, d_q, F, first_call=True)
-            e3, _, _, tsb, ts = timed_leg(c3, 3, 2, level, keep_ts=True)
-            t3 = c3.fetch_packed(F * nb)[1]
-            k3 = c3.ts_counters() if not args.no_ts_end else None
-            c3.close()
-            var = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "avg_ldpc_updates": round(float((args.trials - t3).mean()), 2),
-                   "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
-            if ts is not None:
-                var.update(ts_check(ts, tsb, e3, 3, k3))
-                var.update({"bytes_d2h_per_fec_frame": w.k_bch // 8, "host_end_counters": k3})
-            extra["clamped_llr_variant"] = var
+            if not args.only_frames_sweep:
+                # (i) the BASELINE config's "50 iters" point beside the reference's own TRIALS = 25
+                r50 = make_rx(False, F, 50)
+                r50.execute_dev(d_i, d_q, F, first_call=True)
+                e50, _, l50, _, _ = timed_leg(r50, 2, 1, level)
+                r50.close()
+                extra["trials_50"] = {"msamples_per_s": round(2 * F * FS / e50 / 1e6, 1), "ldpc_ms": round(sum(l50) / len(l50), 3),
+                                      "note": "same workload with the LDPC trial limit at 50 (BASELINE.json config text); the reference itself stops at 25"}
+                # (ii) clamped LLRs (extension) -> the same frames decode; demod -> TS with every byte checked
+                c3 = make_rx(True, F, args.trials)
+                c3.execute_dev(d_i, d_q, F, first_call=True)
+                e3, _, _, tsb, ts = timed_leg(c3, 3, 2, level, keep_ts=True)
+                t3 = c3.fetch_packed(F * nb)[1]
+                k3 = c3.ts_counters() if not args.no_ts_end else None
+                c3.close()
+                var = {"msamples_per_s": round(3 * F * FS / e3 / 1e6, 1), "avg_ldpc_updates": round(float((args.trials - t3).mean()), 2),
+                       "note": "extension (t2gpu_demap_configure saturate=1): not the reference's arithmetic"}
+                if ts is not None:
+                    var.update(ts_check(ts, tsb, e3, 3, k3))
+                    var.update({"bytes_d2h_per_fec_frame": w.k_bch // 8, "host_end_counters": k3})
+                extra["clamped_llr_variant"] = var
             # (iii) throughput against T2 frames per call of the batch receiver (the headline's 48 fill 18.9 rounds of the decoder's
             # resident batch slots; one frame = 202 FEC frames = 6.3 SIMD batches, formed across calls exactly as the reference forms them)
             # Calls are made back to back (the host waits for the device once, behind the last); `overlapped` = the same with the decode of a
@@ -611,8 +619,20 @@ def main():
                             rs.flush_dev()
                             torch.cuda.synchronize(dev)
                         rs.set_overlap(True)
-                    k = max(4, min(32, 128 // nf))
-                    es, accs, ls, _, _ = timed_leg(rs, k, 2, level, nf=nf, drain=False)
+                    # a burst of ~0.2 s per row (rounds 4-6a: at most 32 calls, where the last decode behind the last one-frame call was
+                    # 8 % of the burst); the warm-up long enough for the collecting handle to have a decode resident when the clock starts
+                    k = max(4, min(160, 192 // nf))
+                    if os.environ.get("T2GPU_BENCH_SWEEP_SIMPLE") and mode == "overlapped":
+                        for _ in range(9):
+                            rs.execute_dev(d_i, d_q, nf, level)
+                        rs.wait(); torch.cuda.synchronize(dev)
+                        tq = time.perf_counter()
+                        for c in range(k):
+                            rs.execute_dev(d_i, d_q, nf, level)
+                        rs.wait(); torch.cuda.synchronize(dev)
+                        rs.ts_read(wait_all=True)
+                        print("  simple loop nf=%d: %.0f Msamples/s" % (nf, k * nf * FS / (time.perf_counter() - tq) / 1e6), file=sys.stderr)
+                    es, accs, ls, _, _ = timed_leg(rs, k, 2 if nf >= 8 else 6, level, nf=nf, drain=False)
                     rs.close()
                     if mode == "plain":
                         row.update({"msamples_per_s": round(k * nf * FS / es / 1e6, 1), "ms_per_call": round(es / k * 1e3, 3),
@@ -626,31 +646,32 @@ def main():
                 r["of_full_batch_rate"] = round(r["msamples_per_s"] / top, 3)
                 r["overlapped_of_full_batch_rate"] = round(r["overlapped_msamples_per_s"] / top, 3)
             extra["frames_sweep"] = sweep
-            # (iv) the same input through the reference's own call shape (slot by slot, device-buffer-sized calls, loops closed)
-            # -- with the reference's cast (all 256-QAM batches dropped by the LDPC stage, as in the headline leg), then with clamped LLRs so
-            # that the transport stream comes out and is checked; config 4 (64-QAM: the cast does not wrap) through the same program
-            # (each leg is a process of 2 - 3 s whose rate moves by several per cent with whatever else the box does in that moment: it is run
-            # three times and the MEDIAN run reported, all three rates listed in "runs")
-            def best_of_two(*a, **kw):
-                rs = [drop_in_leg(*a, **kw) for _ in range(3)]
-                bad = [r for r in rs if "error" in r]
-                if bad:
-                    return bad[0]
-                rs.sort(key=lambda r: r["value"])
-                rs[1]["runs"] = [r["value"] for r in rs]
-                rs[1]["reported"] = "median of 3 runs"
-                return rs[1]
-            d_in = best_of_two(w, ui, uq, local_rank, sent=sent)
-            d_in["clamped_llr_variant"] = {k: v for k, v in best_of_two(w, ui, uq, local_rank, sent=sent, saturate=True).items() if k not in ("entry", "workload", "unit")}
-            if cfg_id != 4:
-                w4 = Workload(CONFIGS[4])
-                ui4, uq4, sent4 = make_frames(w4, 2, CONFIGS[4]["snr"], seed=20250614)
-                d_in["config_4"] = {k: v for k, v in best_of_two(w4, ui4, uq4, local_rank, frames=240, warm_frames=20, sent=sent4).items() if k != "entry"}
-                # ... and the 32K mode with a constellation the reference's arithmetic decodes: the slot-shaped path at 32K with its TS checked
-                w6 = Workload(CONFIGS[6])
-                ui6, uq6, sent6 = make_frames(w6, 2, CONFIGS[6]["snr"], seed=20250614)
-                d_in["config_32k_64qam"] = {k: v for k, v in best_of_two(w6, ui6, uq6, local_rank, sent=sent6).items() if k != "entry"}
-            extra["drop_in"] = d_in
+            if not args.only_frames_sweep:
+                # (iv) the same input through the reference's own call shape (slot by slot, device-buffer-sized calls, loops closed)
+                # -- with the reference's cast (all 256-QAM batches dropped by the LDPC stage, as in the headline leg), then with clamped LLRs so
+                # that the transport stream comes out and is checked; config 4 (64-QAM: the cast does not wrap) through the same program
+                # (each leg is a process of 2 - 3 s whose rate moves by several per cent with whatever else the box does in that moment: it is run
+                # three times and the MEDIAN run reported, all three rates listed in "runs")
+                def best_of_two(*a, **kw):
+                    rs = [drop_in_leg(*a, **kw) for _ in range(3)]
+                    bad = [r for r in rs if "error" in r]
+                    if bad:
+                        return bad[0]
+                    rs.sort(key=lambda r: r["value"])
+                    rs[1]["runs"] = [r["value"] for r in rs]
+                    rs[1]["reported"] = "median of 3 runs"
+                    return rs[1]
+                d_in = best_of_two(w, ui, uq, local_rank, sent=sent)
+                d_in["clamped_llr_variant"] = {k: v for k, v in best_of_two(w, ui, uq, local_rank, sent=sent, saturate=True).items() if k not in ("entry", "workload", "unit")}
+                if cfg_id != 4:
+                    w4 = Workload(CONFIGS[4])
+                    ui4, uq4, sent4 = make_frames(w4, 2, CONFIGS[4]["snr"], seed=20250614)
+                    d_in["config_4"] = {k: v for k, v in best_of_two(w4, ui4, uq4, local_rank, frames=240, warm_frames=20, sent=sent4).items() if k != "entry"}
+                    # ... and the 32K mode with a constellation the reference's arithmetic decodes: the slot-shaped path at 32K with its TS checked
+                    w6 = Workload(CONFIGS[6])
+                    ui6, uq6, sent6 = make_frames(w6, 2, CONFIGS[6]["snr"], seed=20250614)
+                    d_in["config_32k_64qam"] = {k: v for k, v in best_of_two(w6, ui6, uq6, local_rank, sent=sent6).items() if k != "entry"}
+                extra["drop_in"] = d_in
 
         if rank != 0:
             return None
@@ -723,7 +744,7 @@ def main():
     if rank == 0:
         cpu_args = out.pop("_cpu_args")
         ui_all, uq_all = out.pop("_frames")
-    if args.config == 3 and not args.no_extra_legs:
+    if args.config == 3 and not args.no_extra_legs and not args.only_frames_sweep:
         # BASELINE.json configs[4] (r = 2/3) as an extra key of the same line: with N > 1 the scaling run then reports both codes
         c5 = run_config(5, 2, 1, extras=False)
         if rank == 0:

@@ -737,9 +737,20 @@ int t2gpu_rx_carry(const t2gpu_rx *h);
  * resident at a time, all of its slots busy for all of its time, and 32 CUs left to the front halves of the calls that run beside it
  * (two or more dispatches of other queues resident at once slow every launch of a latency-bound chain down). A call
  * then returns the FEC frames whose decode IT launched -- 0 for a call that only collected (as for a call that completes no SIMD batch).
- * Same results, same batch formation, same TS. With it on, a call's stream no longer covers the decode:
+ * Larger calls decode whole rounds of ALL the resident slots (16 for a 64800-bit code); the batches of a last, mostly empty round wait for
+ * the next call's (8-frame calls: 50.5 batches = three rounds and 2.5 batches in 16 slots otherwise; 1622 -> 1850 Msamples/s). The end of
+ * a stream: t2gpu_rx_flush_dev, which decodes what waits -- complete batches as the reference forms them, then the incomplete one.
+ * Same results, same batch formation, same TS. With it on, a call's stream no longer covers the call (see STREAMS):
  * d_bytes_out / d_trials_out (the rows of THIS call's decode) are complete after t2gpu_rx_wait (or any fetch / results / stage_ms /
- * TS read, which wait themselves). To be switched on a drained handle with no frames waiting for a batch. */
+ * TS read, which wait themselves). To be switched on a drained handle with no frames waiting for a batch.
+ * STREAMS: with it on, a call's work runs on FOUR STREAMS OF THE HANDLE'S OWN -- the call's chain (front end .. demapper), the side
+ * stream of the P2 / frame-closing equalisers, the two decode sets -- each with a hardware queue of its own, made one after the other so
+ * that they sit on four different pipes of the command processor (a chain of short launches whose queue shares a hardware queue, or only
+ * a pipe, with a queue that holds a decode of milliseconds is 20 % and more slower; which queues a process's streams get depends on the
+ * order it made them in: csrc/t2gpu_rx.cpp, StreamBundle). The chain waits for `stream` at entry (the inputs); NOTHING is enqueued on
+ * `stream` behind the call: d_i / d_q have been read when the call returns, and everything the call produces is complete after
+ * t2gpu_rx_wait (or any fetch / results / stage_ms / TS read). Whatever `stream` is -- the legacy NULL stream included -- the rate is
+ * the same (one-frame calls 1.45 - 1.5 Gsamples/s with the host end on; 0.9 - 1.2 before, depending on the caller's stream). */
 int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable);
 int t2gpu_rx_wait(t2gpu_rx *h);
 int t2gpu_rx_ldpc_occupancy(const t2gpu_rx *h, int *out6);          /* t2gpu_ldpc_occupancy of the handle's decoder */

@@ -14,6 +14,9 @@ hipError_t launch_bch_descramble(const uint8_t *bits, int n_frames, int k_ldpc, 
 hipError_t launch_bch_descramble_pack(const uint8_t *bits, int n_frames, int k_ldpc, int k_bch, const uint8_t *prbs_packed, uint8_t *out,
                                       hipStream_t s);
 
+// K-rows-to-host: bytes from device memory to (page-locked, device-visible) host memory by a kernel on stream s
+hipError_t launch_copy_bytes(const void *src, void *dst, long bytes, hipStream_t s);
+
 long demap_terms_padded(int n_snr);      // term pairs of scratch launch_demap_stats* need per TI block (n_snr rounded up to whole chunks)
 
 struct DemapParams {

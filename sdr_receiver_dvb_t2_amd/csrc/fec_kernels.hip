@@ -87,6 +87,30 @@ hipError_t launch_bch_descramble_pack(const uint8_t *bits, int n_frames, int k_l
     return hipGetLastError();
 }
 
+// K-rows-to-host: a plain copy, 16 bytes per lane, for results that leave for page-locked host memory ON THE STREAM THAT MADE THEM
+// (t2gpu_rx's host end in the overlap mode: a copy on a stream of its own is one more queue with work that waits for a decode, and
+// whatever shares that hardware queue waits with it). The tail and unaligned buffers go byte by byte.
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, long n16, long bytes)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    for (long i = t; i < n16; i += stride) d4[i] = s4[i];
+    for (long i = 16 * n16 + t; i < bytes; i += stride) dst[i] = src[i];
+}
+hipError_t launch_copy_bytes(const void *src, void *dst, long bytes, hipStream_t s)
+{
+    if (bytes <= 0) return hipSuccess;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+    const long n16 = aligned ? bytes / 16 : 0;
+    long blocks = ((aligned ? n16 : bytes) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n16, bytes);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------- demapper
 // Replaces llr_demapper::execute and qpsk/qam16/qam64/qam256 (/root/reference/src/DVB_T2/llr_demapper.cpp:132-158,
 // 160-228, 230-364, 366-535, 537-768). Floating-point products and sums are written with the non-contracting

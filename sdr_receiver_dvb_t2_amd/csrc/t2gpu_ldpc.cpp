@@ -475,6 +475,12 @@ extern "C" int t2gpu_ldpc_submit_add(t2gpu_ldpc *h, const int8_t *in, int len_in
         // launch of every other stream of the process took ~45 us longer while three or more decodes were resident (a 4 us scatter: 45 us;
         // the slot-shaped path's symbols 110 - 380 us instead of 55 for a third of each frame; profiles/HISTORY.md, round 5). With a few CUs
         // the decodes never touch, the short launches are short again.
+        if (const char *e = std::getenv("T2GPU_LDPC_QUEUE_SKIP"))        // EXPERIMENT: hardware queues made (and left idle) ahead of the submit stream's
+            for (int k = 0; k < std::atoi(e) && !h->a_stream; ++k) {
+                hipStream_t dummy = nullptr;
+                uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+                if (hipExtStreamCreateWithCUMask(&dummy, 8, all) != hipSuccess) (void)hipGetLastError();
+            }
         if (!h->a_stream && h->a_cu_reserve > 0 && h->num_cu - h->a_cu_reserve >= 16 && h->num_cu <= 1024) {
             uint32_t mask[32] = {};
             for (int c = h->a_cu_reserve; c < h->num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);

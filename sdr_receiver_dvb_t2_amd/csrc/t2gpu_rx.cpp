@@ -14,6 +14,7 @@
 // stream; the reference has no such thing and simply never decodes the tail) decodes the remainder as one short batch.
 #include "../../include/t2gpu.h"
 #include "t2gpu_common.h"
+#include "fec_kernels.h"
 
 #include <algorithm>
 #include <atomic>
@@ -31,37 +32,50 @@
 using namespace t2gpu;
 
 namespace {
-// A stream with a hardware queue of its own, for the handle's helper streams (decode sets, the host end's copies): each of them spends
-// most of its life waiting for a decode to finish, and the runtime deals plain streams round-robin onto a pool of FOUR hardware queues
-// per device -- a fifth stream shares a queue with the first, and a queue is served in order: with the host end on, the decode set's
-// stream landed in the caller's queue and every call ran BEHIND the decode it was meant to run beside (profiles/HISTORY.md, round 6:
-// one-frame calls 1016 -> 1465 Msamples/s). A stream created with a CU mask (here: all CUs) gets a queue that is never shared. It is a
-// blocking stream in the legacy null stream's sense: a caller that works on the NULL stream serialises with the decodes (t2gpu.h).
-// Streams a destroyed handle gives back are kept (per device) for the next one: making and destroying hardware queues again and again
+// The overlap mode's four streams -- the call's chain (front end .. demapper), the side stream of the P2 / frame-closing equalisers, the two
+// decode sets -- each with a hardware queue of its own, made ONE AFTER THE OTHER. What that buys (profiles/HISTORY.md, round 6, measured with
+// idle queues made ahead of the caller's / the decode's to shift them): the runtime deals plain streams round-robin onto a pool of FOUR
+// hardware queues per device (a fifth stream shares a queue with the first, and a queue is served in order: a decode set's stream in the
+// caller's queue put every call BEHIND the decode it was meant to run beside), and the hardware queues themselves go round-robin onto
+// four pipes of the command processor in the order they were made: a latency-bound chain of short launches whose queue shares a PIPE with a
+// queue that holds a decode of milliseconds (or the launches that wait for it) is ~20 % slower (one-frame calls 1.2 against 1.45
+// Gsamples/s; the slot-shaped path 390 - 490 Msamples/s over the four positions of its decode queue). Streams made with a CU mask (here:
+// all CUs) get queues outside the pool, one each, and four made in a row sit on four different pipes whatever the process made before.
+// They are blocking streams in the legacy NULL stream's sense: a caller that works on the NULL stream serialises with the decodes
+// (t2gpu.h). A destroyed handle's four are kept (per device) for the next one: making and destroying hardware queues again and again
 // left later handles of a process ~10 % slower than its first.
-std::mutex g_private_m;
-std::vector<std::pair<int, hipStream_t>> g_private_free;
-hipError_t private_queue_stream(hipStream_t *s, int device, int num_cu)
+struct StreamBundle { hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; };    // chain, side, decode set 0, decode set 1
+std::mutex g_bundle_m;
+std::vector<std::pair<int, StreamBundle>> g_bundle_free;
+bool stream_bundle_acquire(StreamBundle *b, int device, int num_cu)
 {
     {
-        std::lock_guard<std::mutex> lk(g_private_m);
-        for (size_t k = 0; k < g_private_free.size(); ++k)
-            if (g_private_free[k].first == device) { *s = g_private_free[k].second; g_private_free.erase(g_private_free.begin() + (long)k); return hipSuccess; }
+        std::lock_guard<std::mutex> lk(g_bundle_m);
+        for (size_t k = 0; k < g_bundle_free.size(); ++k)
+            if (g_bundle_free[k].first == device) { *b = g_bundle_free[k].second; g_bundle_free.erase(g_bundle_free.begin() + (long)k); return true; }
     }
-    if (num_cu > 0 && num_cu <= 1024) {
-        uint32_t mask[32] = {0};
-        for (int c = 0; c < num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
-        if (hipExtStreamCreateWithCUMask(s, (uint32_t)((num_cu + 31) / 32), mask) == hipSuccess) return hipSuccess;
+    uint32_t mask[32] = {0};
+    const bool masked = num_cu > 0 && num_cu <= 1024;
+    for (int c = 0; masked && c < num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
+    for (int k = 0; k < 4; ++k) {
+        if (masked && hipExtStreamCreateWithCUMask(&b->s[k], (uint32_t)((num_cu + 31) / 32), mask) == hipSuccess) continue;
         (void)hipGetLastError();
+        if (hipStreamCreateWithFlags(&b->s[k], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int q = 0; q < k; ++q) hipStreamDestroy(b->s[q]);
+            *b = StreamBundle();
+            return false;
+        }
     }
-    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return true;
 }
-void private_queue_stream_release(hipStream_t s, int device)
+void stream_bundle_release(StreamBundle *b, int device)
 {
-    if (!s) return;
-    (void)hipStreamSynchronize(s);
-    std::lock_guard<std::mutex> lk(g_private_m);
-    g_private_free.emplace_back(device, s);
+    if (!b->s[0]) return;
+    for (hipStream_t st : b->s) (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_bundle_m);
+    g_bundle_free.emplace_back(device, *b);
+    *b = StreamBundle();
 }
 constexpr int P1_LEN = 2048, L1_PRE_CELL = 1840;
 constexpr int ACC_BATCHES = 14;             // overlap mode, small calls: see t2gpu_rx_back_dev (14 of the 16 batch slots a 64800-bit decode can keep resident)
@@ -94,15 +108,19 @@ struct t2gpu_rx {
     int cur = 0;                              // LLR buffer the next back half fills
     int set = 0, last_set = 0;                // decode set of the next decode (when it is a small one) / of the last decode
     t2gpu_ldpc *ldpc_s[2] = {nullptr, nullptr};
+    StreamBundle bundle;                      // overlap mode's streams (see StreamBundle): [0] the call's chain, [1] the side stream, [2], [3] = dec_s
     hipStream_t dec_s[2] = {nullptr, nullptr};
+    hipEvent_t ev_enter = nullptr;                              // the caller's stream -> the chain (ChainScope)
     uint8_t *d_bits_s[2] = {nullptr, nullptr}, *d_pack_s[2] = {nullptr, nullptr};
     int32_t *d_trials_s[2] = {nullptr, nullptr};
-    hipEvent_t ev_demap = nullptr, ev_l1_copied = nullptr;
+    hipEvent_t ev_demap = nullptr;
     hipEvent_t ev_llr_read[3] = {nullptr, nullptr, nullptr};    // the decode that read buffer b is through
     hipEvent_t ev_carry[3] = {nullptr, nullptr, nullptr};       // the waiting frames have been copied to the head of buffer b
     hipEvent_t ev_dec_done[2] = {nullptr, nullptr};             // the last decode of set s is through
-    bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false}, l1_copied_set = false;
+    bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false};
     int in_flight_wg[2] = {0, 0};             // workgroups of the last decode of each set (what may still be resident)
+    int all_slots = 0;                        // overlap mode: SIMD batches a decode of this handle's code keeps resident on the whole device
+    bool whole_rounds = true;                 // overlap mode, larger calls: decodes of whole rounds of all_slots batches (T2GPU_RX_ROUNDS=0: every complete batch)
     int acc_batches = ACC_BATCHES;            // overlap mode, small calls: SIMD batches that collect before a decode is launched = its resident slots (0: off)
     bool pair_allowed = true;                 // T2GPU_RX_PAIR=0 (read by t2gpu_rx_set_overlap): every decode on set 0, one after the other
     int num_cu = 0;
@@ -139,6 +157,7 @@ struct t2gpu_rx {
 struct TsJob {
     int slot = 0, fec_frames = 0, t2_frames = 0;
     long fec_first = 0, t2_first = 0;
+    bool l1_event = false;                    // the slot's L1 cells have an event of their own (they left on another stream than the rows)
 };
 struct TsSlot {
     uint8_t *pack = nullptr;                  // pinned: [frames][k_bch / 8]
@@ -161,9 +180,7 @@ struct TsEnd {
     std::deque<TsJob> jobs;
     int next_slot = 0, in_flight = 0;
     bool stop = false;
-    hipStream_t copy_stream = nullptr;        // the device -> host copies run beside the next call's kernels
-    hipStream_t l1_stream = nullptr;          // overlap mode: the L1 cells' copy on a stream of its own -- behind the rows of earlier decodes
-                                              // on copy_stream it would wait for those decodes, and the next call's P2 equaliser for it
+    hipStream_t copy_stream = nullptr;        // plain mode: the device -> host copies run beside the next call's kernels (overlap mode: ts_submit)
     hipEvent_t decoded = nullptr;             // recorded on the call's stream behind K-descramble-pack
     hipEvent_t last_copy = nullptr;           // `ready` of the newest job: the next back half waits for it before it overwrites the rows
     hipEvent_t last_copy_s[2] = {nullptr, nullptr};   // overlap mode: the same per decode set (a decode overwrites its own set's rows only)
@@ -201,8 +218,9 @@ void free_all(t2gpu_rx *h)
     for (int b = 1; b < 3; ++b) hipFree(h->d_llr_ab[b]);
     if (h->ldpc_s[1]) t2gpu_ldpc_destroy(h->ldpc_s[1]);
     hipFree(h->d_bits_s[1]); hipFree(h->d_pack_s[1]); hipFree(h->d_trials_s[1]);
-    for (hipStream_t st : h->dec_s) private_queue_stream_release(st, h->device);
-    for (hipEvent_t e : {h->ev_demap, h->ev_l1_copied, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
+    stream_bundle_release(&h->bundle, h->device);
+    if (h->ev_enter) hipEventDestroy(h->ev_enter);
+    for (hipEvent_t e : {h->ev_demap, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
                          h->ev_dec_done[0], h->ev_dec_done[1]}) if (e) hipEventDestroy(e);
 }
 
@@ -224,8 +242,7 @@ void ts_stop(t2gpu_rx *h)
         if (sl.l1_ready) hipEventDestroy(sl.l1_ready);
     }
     if (t->bbdh) t2gpu_bbdh_destroy(t->bbdh);
-    private_queue_stream_release(t->copy_stream, h->device);
-    private_queue_stream_release(t->l1_stream, h->device);
+    if (t->copy_stream) hipStreamDestroy(t->copy_stream);
     if (t->decoded) hipEventDestroy(t->decoded);
     delete t;
     h->ts = nullptr;
@@ -334,12 +351,43 @@ extern "C" int t2gpu_rx_info(const t2gpu_rx *h, t2gpu_rx_geometry *g)
     return 0;
 }
 
+namespace {
+// Overlap mode: a call's work goes on the handle's own chain stream (StreamBundle), which waits for the caller's stream at entry (the
+// inputs). Nothing is put on the caller's stream behind the call: a wait there for the call's end is a queue with a blocked packet in it
+// for most of every call, and on the wrong pipe that alone cost 12 % (1278 against 1450 Msamples/s). The inputs have been read when the
+// call returns (the front end runs ahead of the call's one host round trip); everything else is complete after t2gpu_rx_wait (or any
+// fetch / results / stage_ms / TS read), as the decode's rows have been since round 5.
+struct ChainScope {
+    t2gpu_rx *h;
+    hipStream_t caller, s;
+    bool on = false;
+    ChainScope(t2gpu_rx *h_, void *stream) : h(h_), caller((hipStream_t)stream), s((hipStream_t)stream)
+    {
+        if (!h || !h->overlap || !h->bundle.s[0]) return;
+        // (the legacy NULL stream: the chain, a blocking stream in its sense, is ordered behind it by the runtime already -- and an event
+        // recorded THERE would wait for every decode in flight)
+        if (caller == nullptr || (hipEventRecord(h->ev_enter, caller) == hipSuccess && hipStreamWaitEvent(h->bundle.s[0], h->ev_enter, 0) == hipSuccess)) { s = h->bundle.s[0]; on = true; }
+        else (void)hipGetLastError();
+    }
+    ChainScope(const ChainScope &) = delete;
+    ChainScope &operator=(const ChainScope &) = delete;
+};
+int rx_front(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call, void *stream);
+int rx_back(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream);
+}  // namespace
+
 // front half: front end, P1 windows, guard correlation, FFT of n_frames frames. Synchronises once (the P1 decisions are host data).
 extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call,
                                   void *stream)
 {
     if (!h || !d_i || !d_q || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_front_dev: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
+    ChainScope sc(h, stream);
+    return rx_front(h, d_i, d_q, n_frames, level_detect, first_call, sc.s);
+}
+namespace {
+int rx_front(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call, void *stream)
+{
     const int32_t n_in = (int32_t)((long)n_frames * h->frame_len);
     for (bool &b : h->ev_set) b = false;
     if (!mark(h, 0, (hipStream_t)stream)) return -1;
@@ -378,6 +426,7 @@ extern "C" int t2gpu_rx_front_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t
     if (!mark(h, 4, (hipStream_t)stream)) return -1;                                    // FFT
     return 0;
 }
+}  // namespace
 
 namespace {
 // equalisers -> time de-interleaver -> demapper on the spectra in d_spec (stages 4..6); the LLR frames land behind the `llr_at`
@@ -392,13 +441,14 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
     float *sy = h->d_sync;
     // The P2 launch (one symbol per frame: fewer workgroups than CUs, its synchronisation sums a chain of 4640 pilots per symbol) and
     // the frame-closing one run on a side stream beside the data symbols' launch: disjoint symbols, cells and scratch.
+    hipStream_t side = h->overlap && h->bundle.s[1] ? h->bundle.s[1] : h->side;
     T2_HIP(hipEventRecord(h->ev_fork, s));
-    T2_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    if (t2gpu_eq_p2_frames_l1_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, h->d_l1, sy, h->side) < 0) return -1;
+    T2_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
+    if (t2gpu_eq_p2_frames_l1_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, h->p2_skip, h->d_l1, sy, side) < 0) return -1;
     if (h->l_fc && t2gpu_eq_fc_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, h->d_cells, h->frame_cells, a + (long)h->n_dat * h->c_data,
-                                          sy + 2 * (size_t)F * (1 + h->n_dat), h->side) < 0)
+                                          sy + 2 * (size_t)F * (1 + h->n_dat), side) < 0)
         return -1;
-    T2_HIP(hipEventRecord(h->ev_join, h->side));
+    T2_HIP(hipEventRecord(h->ev_join, side));
     if (h->n_dat > 0 && t2gpu_eq_data_frames_dev(h->ofdm, h->d_spec, F, h->n_sym, 1, h->n_dat, h->d_cells, h->frame_cells, a, sy + 2 * (size_t)F, s) < 0) return -1;
     T2_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     if (!mark(h, 5, s)) return -1;                                                      // equalisers
@@ -431,7 +481,7 @@ int rx_decode(t2gpu_rx *h, int count, int at, hipStream_t s, const int8_t *llr =
     return 0;
 }
 
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after = nullptr, int set = -1);
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipStream_t call_s = nullptr, int set = -1);
 }  // namespace
 
 // BASELINE config 2: FFT (guard dropped) + equalisers / frequency de-interleave + time de-interleave + demap of the frames the last
@@ -441,6 +491,8 @@ extern "C" int t2gpu_rx_fft_eq_demap_dev(t2gpu_rx *h, int n_frames, void *stream
 {
     if (!h || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_fft_eq_demap_dev: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
+    ChainScope sc(h, stream);
+    stream = sc.s;
     for (bool &b : h->ev_set) b = false;
     if (!mark(h, 3, (hipStream_t)stream)) return -1;
     if (t2gpu_fft_execute_strided_dev(h->ofdm, h->d_stream, h->p2_start[0] + h->guard, h->frame_len, h->n_sym, h->sym_size, h->d_spec,
@@ -456,6 +508,12 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
 {
     if (!h || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_back_dev: bad arguments"); return -1; }
     T2_HIP(hipSetDevice(h->device));
+    ChainScope sc(h, stream);
+    return rx_back(h, n_frames, d_bytes_out, d_trials_out, sc.s);
+}
+namespace {
+int rx_back(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream)
+{
     hipStream_t s = (hipStream_t)stream;
     const int F = n_frames, nb = h->cfg.plp_num_blocks;
     const int total = h->carry + F * nb;
@@ -468,6 +526,11 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
         const int k_rows = h->acc_batches * h->group;
         ready = (total / k_rows) * k_rows;
         rest = total - ready;
+    } else if (h->overlap && h->acc_batches > 0 && h->whole_rounds && !h->outer_code && h->all_slots > 0 && h->all_slots <= 3 * ACC_BATCHES) {
+        // larger calls: whole rounds of ALL the slots -- the batches of a round that would run with most slots empty wait for the next call's
+        // (8-frame calls end on a round of 2.5 batches in 16 slots otherwise)
+        const int k_rows = h->all_slots * h->group;
+        if (total >= k_rows) { ready = (total / k_rows) * k_rows; rest = total - ready; }
     }
     if (h->overlap) {
         // ---- the decode on a stream of the handle's own (t2gpu_rx_set_overlap)
@@ -479,9 +542,8 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
         const bool pair_ok = ready > 0 && !collect && h->pair_allowed && 2 * wg_est <= h->num_cu;
         const int set = pair_ok ? h->set : 0;
         int8_t *llr = h->d_llr_ab[b];
-        // this buffer was last read by the decode of three calls ago; d_l1 is read by the host end's copy of the previous call
+        // this buffer was last read by the decode of three calls ago (d_l1: copied out on this stream by the previous call's ts_submit)
         if (h->llr_read_set[b]) T2_HIP(hipStreamWaitEvent(s, h->ev_llr_read[b], 0));
-        if (h->l1_copied_set) T2_HIP(hipStreamWaitEvent(s, h->ev_l1_copied, 0));
         if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
         T2_HIP(hipEventRecord(h->ev_demap, s));
         if (ready > 0) {
@@ -497,7 +559,7 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
             // (the opt-in outer code keeps its per-frame status in one buffer for both sets: its decodes go one after the other)
             const int wg = wg_est;
             if (wg < 0) return -1;
-            t2gpu_ldpc_set_plain_launch(h->ldpc, pair_ok ? 1 : 0);
+            t2gpu_ldpc_set_plain_launch(h->ldpc, 1);
             if (h->dec_done_set[1 - set] && wg + h->in_flight_wg[1 - set] > h->num_cu) T2_HIP(hipStreamWaitEvent(d, h->ev_dec_done[1 - set], 0));
             if (rest > 0) {
                 // the frames behind the last complete batch go to the head of the next buffer (its last reader: the decode of two calls ago)
@@ -516,12 +578,12 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
             h->last_set = set;
             h->carry = rest;
             h->last_ready = ready;
-            if (h->ts && ts_submit(h, ready, 0, F, d, h->ev_demap, set) != 0) return -1;
+            if (h->ts && ts_submit(h, ready, 0, F, d, s, set) != 0) return -1;
         } else {
             // nothing to decode yet: the frames stay where they are; the host end still gets the call's L1 cells
             h->carry = rest;
             h->last_ready = 0;
-            if (h->ts && ts_submit(h, 0, 0, F, s, h->ev_demap, -1) != 0) return -1;
+            if (h->ts && ts_submit(h, 0, 0, F, s, s, -1) != 0) return -1;
         }
         h->fec_seq += ready;
         h->t2_seq += F;
@@ -545,6 +607,8 @@ extern "C" int t2gpu_rx_back_dev(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_ou
     return ready;
 }
 
+}  // namespace
+
 // End of stream: the frames still waiting for a full batch are decoded as one short batch (an addition: the reference never decodes
 // them). Their rows follow those of the last back half in the output buffers. Returns the number of FEC frames flushed.
 extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
@@ -553,6 +617,8 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
     T2_HIP(hipSetDevice(h->device));
     const int n = h->carry;
     if (n == 0) return 0;
+    ChainScope sc(h, stream);
+    stream = sc.s;
     if (h->overlap) {
         // the waiting frames sit at the head of buffer `cur` (copied there on a decode stream). They are decoded on the set of the last
         // decode, on its stream and so behind it, and their rows follow that decode's rows, as in the plain schedule
@@ -573,7 +639,7 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
         h->llr_read_set[b] = true; h->dec_done_set[set] = true; h->in_flight_wg[set] = h->num_cu;
         h->carry = 0;
         h->last_ready = at + n;
-        if (h->ts && ts_submit(h, n, at, 0, d, nullptr, set) != 0) return -1;
+        if (h->ts && ts_submit(h, n, at, 0, d, d, set) != 0) return -1;
         h->fec_seq += n;
         return n;
     }
@@ -616,8 +682,10 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         }
         // (default priority: at the lowest one the next call's front half, issued later, was dispatched ahead of the decode it is meant
         // to run beside -- 2- to 16-frame calls lost 2 - 7 %)
-        for (int k = 0; k < 2 && ok; ++k) ok = h->dec_s[k] || private_queue_stream(&h->dec_s[k], h->device, h->num_cu) == hipSuccess;
-        for (hipEvent_t *e : {&h->ev_demap, &h->ev_l1_copied, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
+        ok = ok && (h->bundle.s[0] || stream_bundle_acquire(&h->bundle, h->device, h->num_cu));
+        if (ok) { h->dec_s[0] = h->bundle.s[2]; h->dec_s[1] = h->bundle.s[3]; }
+        ok = ok && (h->ev_enter || hipEventCreateWithFlags(&h->ev_enter, hipEventDisableTiming) == hipSuccess);
+        for (hipEvent_t *e : {&h->ev_demap, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
                               &h->ev_carry[2], &h->ev_dec_done[0], &h->ev_dec_done[1]})
             ok = ok && (*e || hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess);
         if (!ok) { (void)hipGetLastError(); set_error("t2gpu_rx_set_overlap: allocation failed"); return -1; }
@@ -629,7 +697,7 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         h->d_llr = h->d_llr_ab[0]; h->ldpc = h->ldpc_s[0]; h->d_bits = h->d_bits_s[0]; h->d_pack = h->d_pack_s[0]; h->d_trials = h->d_trials_s[0];
         for (bool &v : h->llr_read_set) v = false;
         for (bool &v : h->carry_set) v = false;
-        h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false;
+        h->dec_done_set[0] = h->dec_done_set[1] = false;
         h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
         if (h->ts) h->ts->last_copy_s[0] = h->ts->last_copy_s[1] = nullptr;
         for (t2gpu_ldpc *l : h->ldpc_s) if (l) t2gpu_ldpc_set_plain_launch(l, 0);    // (decided per decode in overlap mode)
@@ -641,6 +709,8 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         int occ[6] = {0, 0, 0, 0, 0, 0};
         if (t2gpu_ldpc_occupancy(h->ldpc_s[0] ? h->ldpc_s[0] : h->ldpc, occ) == 0 && occ[4] > 32 && occ[5] > 0)
             h->acc_batches = std::max(1, std::min(ACC_BATCHES, occ[5] * (occ[4] - 32) / occ[4]));
+        h->all_slots = occ[5];
+        if (const char *e = std::getenv("T2GPU_RX_ROUNDS")) h->whole_rounds = std::atoi(e) != 0;
         if (const char *e = std::getenv("T2GPU_RX_COLLECT")) { const int v = std::atoi(e); if (v >= 0 && v <= ACC_BATCHES) h->acc_batches = v; }   // 0: a decode per call, as round 5
     }
     return 0;
@@ -649,6 +719,7 @@ extern "C" int t2gpu_rx_wait(t2gpu_rx *h)
 {
     if (!h) { set_error("t2gpu_rx_wait: null handle"); return -1; }
     T2_HIP(hipSetDevice(h->device));
+    if (h->bundle.s[0]) { T2_HIP(hipStreamSynchronize(h->bundle.s[0])); T2_HIP(hipStreamSynchronize(h->bundle.s[1])); }
     for (hipStream_t st : h->dec_s) if (st) T2_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -670,7 +741,7 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
     h->set = 0; h->last_set = 0;
     for (bool &v : h->llr_read_set) v = false;
     for (bool &v : h->carry_set) v = false;
-    h->dec_done_set[0] = h->dec_done_set[1] = false; h->l1_copied_set = false;
+    h->dec_done_set[0] = h->dec_done_set[1] = false;
     h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
     return 0;
 }
@@ -678,9 +749,12 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
 extern "C" int t2gpu_rx_execute_dev(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, float level_detect, int first_call,
                                     uint8_t **d_bytes_out, int32_t **d_trials_out, void *stream)
 {
-    const int rc = t2gpu_rx_front_dev(h, d_i, d_q, n_frames, level_detect, first_call, stream);
+    if (!h || !d_i || !d_q || n_frames < 1 || n_frames > h->cfg.max_frames) { set_error("t2gpu_rx_execute_dev: bad arguments"); return -1; }
+    T2_HIP(hipSetDevice(h->device));
+    ChainScope sc(h, stream);
+    const int rc = rx_front(h, d_i, d_q, n_frames, level_detect, first_call, sc.s);
     if (rc != 0) return rc;
-    return t2gpu_rx_back_dev(h, n_frames, d_bytes_out, d_trials_out, stream);
+    return rx_back(h, n_frames, d_bytes_out, d_trials_out, sc.s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host end
@@ -725,7 +799,7 @@ void ts_worker(TsEnd *t)
             t->jobs.pop_front();
         }
         TsSlot &sl = t->slot[j.slot];
-        const bool ok = hipEventSynchronize(sl.ready) == hipSuccess;
+        const bool ok = hipEventSynchronize(sl.ready) == hipSuccess && (!j.l1_event || hipEventSynchronize(sl.l1_ready) == hipSuccess);
         t2gpu_rx_ts_counters d{};
         const size_t per = (size_t)row + 2 * 188 + 64;           // the de-framer's out_cap contract: len_in / 8 + 376
         const size_t need = (size_t)j.fec_frames * per + per;
@@ -796,10 +870,15 @@ void ts_worker(TsEnd *t)
 }
 
 // queue the device -> host copies of one decode (packed BBFRAME rows at.., their trials, the L1 cells of the call's T2 frames) behind it
-// on the stream and hand the job to the worker. Blocks only when all slots are still in use (the host end is SLOTS calls behind).
-// l1_after (overlap mode): the L1 cells are complete at that event already -- their copy is queued behind it and in front of the decode's
-// (the next call's P2 equaliser, which overwrites them, waits for ev_l1_copied, not for this call's decode)
-int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipEvent_t l1_after, int set)
+// and hand the job to the worker. Blocks only when all slots are still in use (the host end is SLOTS calls behind).
+// Plain mode (call_s == nullptr): copy-engine copies on the host end's own stream behind the decode, so that they run beside the next
+// call's front half. Overlap mode (call_s = the call's stream, s = the decode's): NO stream of the host end's own -- the rows and trials
+// leave by a kernel on the decode's stream, the L1 cells by a kernel on the call's stream (complete there already; the next call's P2
+// equaliser, which overwrites them, follows in stream order). A copy stream spends its life waiting for decodes; the runtime deals
+// streams onto a handful of hardware queues, a queue is served in order, and whatever shared the copy stream's queue waited with it:
+// the L1 copy of the NEXT call behind the rows of a decode still running, and the call after that behind the L1 copy
+// (profiles/HISTORY.md, round 6).
+int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s, hipStream_t call_s, int set)
 {
     TsEnd *t = h->ts;
     if (fec_frames == 0 && t2_frames == 0) return 0;
@@ -814,35 +893,41 @@ int ts_submit(t2gpu_rx *h, int fec_frames, int at, int t2_frames, hipStream_t s,
     }
     TsSlot &sl = t->slot[k];
     const int row = h->k_bch / 8;
-    hipStream_t cs = t->copy_stream;
     bool ok = true;
     const bool l1_now = t2_frames > 0 && t->l1_check;
-    if (l1_now && l1_after) {
-        hipStream_t ls = t->l1_stream;
-        ok = hipStreamWaitEvent(ls, l1_after, 0) == hipSuccess &&
-             hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, ls) == hipSuccess &&
-             hipEventRecord(h->ev_l1_copied, ls) == hipSuccess && hipEventRecord(sl.l1_ready, ls) == hipSuccess &&
-             hipStreamWaitEvent(cs, sl.l1_ready, 0) == hipSuccess;          // the slot's `ready` (recorded on cs below) covers it
-        h->l1_copied_set = ok;
+    bool l1_event = false;
+    if (call_s) {
+        if (l1_now) {
+            ok = launch_copy_bytes(h->d_l1, sl.l1, (long)t2_frames * h->p2_skip * 8, call_s) == hipSuccess &&
+                 hipEventRecord(sl.l1_ready, call_s) == hipSuccess;
+            l1_event = ok && call_s != s;                            // (the same stream: `ready` below covers it)
+        }
+        if (ok && fec_frames > 0)
+            ok = launch_copy_bytes(h->d_trials + at / h->group, sl.trials, (long)((fec_frames + h->group - 1) / h->group) * 4, s) == hipSuccess &&
+                 launch_copy_bytes(h->d_pack + (size_t)at * row, sl.pack, (long)fec_frames * row, s) == hipSuccess;
+        ok = ok && hipEventRecord(sl.ready, fec_frames > 0 ? s : call_s) == hipSuccess;
+    } else {
+        hipStream_t cs = t->copy_stream;
+        ok = hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
+        if (ok && fec_frames > 0) {
+            ok = hipMemcpyAsync(sl.trials, h->d_trials + at / h->group, (size_t)((fec_frames + h->group - 1) / h->group) * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+                 hipMemcpyAsync(sl.pack, h->d_pack + (size_t)at * row, (size_t)fec_frames * row, hipMemcpyDeviceToHost, cs) == hipSuccess;
+        }
+        if (ok && l1_now)
+            ok = hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
+        ok = ok && hipEventRecord(sl.ready, cs) == hipSuccess;
     }
-    ok = ok && hipEventRecord(t->decoded, s) == hipSuccess && hipStreamWaitEvent(cs, t->decoded, 0) == hipSuccess;
-    if (ok && fec_frames > 0) {
-        ok = hipMemcpyAsync(sl.trials, h->d_trials + at / h->group, (size_t)((fec_frames + h->group - 1) / h->group) * 4, hipMemcpyDeviceToHost, cs) == hipSuccess &&
-             hipMemcpyAsync(sl.pack, h->d_pack + (size_t)at * row, (size_t)fec_frames * row, hipMemcpyDeviceToHost, cs) == hipSuccess;
-    }
-    if (ok && l1_now && !l1_after)
-        ok = hipMemcpyAsync(sl.l1, h->d_l1, (size_t)t2_frames * h->p2_skip * 8, hipMemcpyDeviceToHost, cs) == hipSuccess;
-    ok = ok && hipEventRecord(sl.ready, cs) == hipSuccess;
     t->last_copy = ok ? sl.ready : nullptr;
     if (set >= 0) t->last_copy_s[set] = t->last_copy;
     TsJob j;
     j.slot = k; j.fec_frames = ok ? fec_frames : 0; j.t2_frames = ok ? t2_frames : 0; j.fec_first = h->fec_seq; j.t2_first = h->t2_seq;
+    j.l1_event = l1_event;
     {
         std::lock_guard<std::mutex> lk(t->m);
         t->jobs.push_back(j);
     }
     t->cv_job.notify_one();
-    if (!ok) { set_error("t2gpu_rx: device -> host copy of the decoded frames failed"); return -1; }
+    if (!ok) { (void)hipGetLastError(); set_error("t2gpu_rx: device -> host copy of the decoded frames failed"); return -1; }
     return 0;
 }
 }  // namespace
@@ -871,8 +956,7 @@ extern "C" int t2gpu_rx_ts_enable(t2gpu_rx *h, int need_plp, int l1_check)
              hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sl.l1_ready, hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && private_queue_stream(&t->copy_stream, h->device, h->num_cu) == hipSuccess &&
-         private_queue_stream(&t->l1_stream, h->device, h->num_cu) == hipSuccess &&
+    ok = ok && hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&t->decoded, hipEventDisableTiming) == hipSuccess;
     h->ts = t;
     if (!ok) { ts_stop(h); set_error("t2gpu_rx_ts_enable: pinned host memory allocation failed"); return -1; }
@@ -931,7 +1015,10 @@ extern "C" int t2gpu_rx_results(t2gpu_rx *h, int n_frames, t2gpu_p1_result *p1, 
         if (p1) p1[f] = h->p1_res[f];
         if (p2_start) p2_start[f] = h->p2_start[f];
     }
-    if (cp4) T2_HIP(hipMemcpy(cp4, h->d_cp, (size_t)n_frames * h->n_sym * 16, hipMemcpyDeviceToHost));
+    if (cp4) {
+        T2_HIP(hipDeviceSynchronize());                     // (the call may have been made on a non-blocking stream: a blocking copy alone does not wait for it)
+        T2_HIP(hipMemcpy(cp4, h->d_cp, (size_t)n_frames * h->n_sym * 16, hipMemcpyDeviceToHost));
+    }
     if (level_detect) {
         float st[8];
         if (t2gpu_front_state(h->front, st) != 0) return -1;

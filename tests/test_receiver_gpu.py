@@ -438,7 +438,7 @@ def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda,
         for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
             assert pcnt[k] == ocnt[k], (pair, k)
     # the library's default since round 6: calls of fewer than 28 batches collect until 14 are there (one decode resident at a time, whole
-    # rounds of 14 slots); larger calls (the 16-frame one of the last pattern) decode at once as before. Same rows in the same order, same TS
+    # rounds of 14 slots); larger calls (the 16-frame one of the last pattern) decode whole rounds of all 16 slots. Same rows in the same order, same TS
     monkeypatch.delenv("T2GPU_RX_COLLECT", raising=False)
     cc, cr, cv, cts, ccnt = run(True, collect=14)
     assert sum(cc) == sum(pc), (cc, pc)
@@ -448,3 +448,7 @@ def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda,
         assert pcnt[k] == ccnt[k], k
     if max(pattern) <= 4:
         assert all(x % (14 * 32) == 0 for x in cc[:-1]), cc
+    else:
+        # larger calls: whole rounds of all 16 resident slots, what is left of a round waits for the next call (or the flush)
+        big = [x for x, nf in zip(cc, pattern) if nf * w.nb >= 28 * 32]
+        assert big and all(x > 0 and x % (16 * 32) == 0 for x in big), cc

@@ -26,7 +26,7 @@ if not os.environ.get("PROBE_NULL_STREAM"):
 TS = len(sys.argv) > 1 and sys.argv[1].startswith("--ts")
 L1 = not (len(sys.argv) > 1 and sys.argv[1] == "--ts-nol1")             # with the library's host end (L1 parse, drop rule, de-framer) on
 print("host end", ("on" if L1 else "on, without the per-frame L1 check") if TS else "off")
-for nf in (1, 2, 4):
+for nf in [int(x) for x in os.environ.get("SWEEP_NF", "1,2,4").split(",")]:
     row = []
     for K in [int(x) for x in os.environ.get("SWEEP_K", "0,12,13,14").split(",")]:
         os.environ["T2GPU_RX_COLLECT"] = str(K)
@@ -40,7 +40,7 @@ for nf in (1, 2, 4):
             torch.cuda.synchronize()
         rx.set_overlap(True)
         level = rx.results(nf)["level_detect"]
-        calls = 96 // nf
+        calls = max(6, 96 // nf)
         for _ in range(8 // nf + 1):
             rx.execute_dev(di, dq, nf, level_detect=level)
         rx.wait(); torch.cuda.synchronize()
