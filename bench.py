@@ -518,7 +518,7 @@ def main():
                     got[0] += n
                     if n == 0:
                         break
-            consumer = threading.Thread(target=consume) if ts_on and not os.environ.get("T2GPU_BENCH_NO_CONSUMER") else None
+            consumer = threading.Thread(target=consume) if ts_on else None
             t0 = time.perf_counter()
             if consumer:
                 consumer.start()
@@ -622,16 +622,6 @@ def main():
                     # a burst of ~0.2 s per row (rounds 4-6a: at most 32 calls, where the last decode behind the last one-frame call was
                     # 8 % of the burst); the warm-up long enough for the collecting handle to have a decode resident when the clock starts
                     k = max(4, min(160, 192 // nf))
-                    if os.environ.get("T2GPU_BENCH_SWEEP_SIMPLE") and mode == "overlapped":
-                        for _ in range(9):
-                            rs.execute_dev(d_i, d_q, nf, level)
-                        rs.wait(); torch.cuda.synchronize(dev)
-                        tq = time.perf_counter()
-                        for c in range(k):
-                            rs.execute_dev(d_i, d_q, nf, level)
-                        rs.wait(); torch.cuda.synchronize(dev)
-                        rs.ts_read(wait_all=True)
-                        print("  simple loop nf=%d: %.0f Msamples/s" % (nf, k * nf * FS / (time.perf_counter() - tq) / 1e6), file=sys.stderr)
                     es, accs, ls, _, _ = timed_leg(rs, k, 2 if nf >= 8 else 6, level, nf=nf, drain=False)
                     rs.close()
                     if mode == "plain":

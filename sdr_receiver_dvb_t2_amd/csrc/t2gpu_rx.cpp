@@ -120,7 +120,6 @@ struct t2gpu_rx {
     bool llr_read_set[3] = {false, false, false}, carry_set[3] = {false, false, false}, dec_done_set[2] = {false, false};
     int in_flight_wg[2] = {0, 0};             // workgroups of the last decode of each set (what may still be resident)
     int all_slots = 0;                        // overlap mode: SIMD batches a decode of this handle's code keeps resident on the whole device
-    bool whole_rounds = true;                 // overlap mode, larger calls: decodes of whole rounds of all_slots batches (T2GPU_RX_ROUNDS=0: every complete batch)
     int acc_batches = ACC_BATCHES;            // overlap mode, small calls: SIMD batches that collect before a decode is launched = its resident slots (0: off)
     bool pair_allowed = true;                 // T2GPU_RX_PAIR=0 (read by t2gpu_rx_set_overlap): every decode on set 0, one after the other
     int num_cu = 0;
@@ -526,7 +525,7 @@ int rx_back(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials
         const int k_rows = h->acc_batches * h->group;
         ready = (total / k_rows) * k_rows;
         rest = total - ready;
-    } else if (h->overlap && h->acc_batches > 0 && h->whole_rounds && !h->outer_code && h->all_slots > 0 && h->all_slots <= 3 * ACC_BATCHES) {
+    } else if (h->overlap && h->acc_batches > 0 && !h->outer_code && h->all_slots > 0 && h->all_slots <= 3 * ACC_BATCHES) {
         // larger calls: whole rounds of ALL the slots -- the batches of a round that would run with most slots empty wait for the next call's
         // (8-frame calls end on a round of 2.5 batches in 16 slots otherwise)
         const int k_rows = h->all_slots * h->group;
@@ -710,7 +709,6 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         if (t2gpu_ldpc_occupancy(h->ldpc_s[0] ? h->ldpc_s[0] : h->ldpc, occ) == 0 && occ[4] > 32 && occ[5] > 0)
             h->acc_batches = std::max(1, std::min(ACC_BATCHES, occ[5] * (occ[4] - 32) / occ[4]));
         h->all_slots = occ[5];
-        if (const char *e = std::getenv("T2GPU_RX_ROUNDS")) h->whole_rounds = std::atoi(e) != 0;
         if (const char *e = std::getenv("T2GPU_RX_COLLECT")) { const int v = std::atoi(e); if (v >= 0 && v <= ACC_BATCHES) h->acc_batches = v; }   // 0: a decode per call, as round 5
     }
     return 0;
