@@ -113,7 +113,8 @@ struct t2gpu_rx {
     hipEvent_t ev_enter = nullptr;                              // the caller's stream -> the chain (ChainScope)
     uint8_t *d_bits_s[2] = {nullptr, nullptr}, *d_pack_s[2] = {nullptr, nullptr};
     int32_t *d_trials_s[2] = {nullptr, nullptr};
-    hipEvent_t ev_demap = nullptr;
+    hipEvent_t ev_demap = nullptr, ev_ti = nullptr;
+    bool demap_pending = false;               // overlap mode: ev_demap was recorded on the side stream (the demapper runs there)
     hipEvent_t ev_llr_read[3] = {nullptr, nullptr, nullptr};    // the decode that read buffer b is through
     hipEvent_t ev_carry[3] = {nullptr, nullptr, nullptr};       // the waiting frames have been copied to the head of buffer b
     hipEvent_t ev_dec_done[2] = {nullptr, nullptr};             // the last decode of set s is through
@@ -219,7 +220,7 @@ void free_all(t2gpu_rx *h)
     hipFree(h->d_bits_s[1]); hipFree(h->d_pack_s[1]); hipFree(h->d_trials_s[1]);
     stream_bundle_release(&h->bundle, h->device);
     if (h->ev_enter) hipEventDestroy(h->ev_enter);
-    for (hipEvent_t e : {h->ev_demap, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
+    for (hipEvent_t e : {h->ev_demap, h->ev_ti, h->ev_llr_read[0], h->ev_llr_read[1], h->ev_llr_read[2], h->ev_carry[0], h->ev_carry[1], h->ev_carry[2],
                          h->ev_dec_done[0], h->ev_dec_done[1]}) if (e) hipEventDestroy(e);
 }
 
@@ -430,7 +431,11 @@ int rx_front(t2gpu_rx *h, const int16_t *d_i, const int16_t *d_q, int n_frames, 
 namespace {
 // equalisers -> time de-interleaver -> demapper on the spectra in d_spec (stages 4..6); the LLR frames land behind the `llr_at`
 // frames already waiting in d_llr
-int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
+// demap_s (overlap mode): the demapper -- the statistics' two sequential walks (one workgroup per TI block and sum: 260 us of latency
+// whatever the call's size) and the LLR pass -- on that stream instead of s, behind the de-interleaver: the NEXT call's front end and
+// equalisers do not depend on them and no longer stand behind them. The caller records ev_demap on demap_s; the next de-interleaver
+// launch (which overwrites the cells and terms the demapper reads) waits for it.
+int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s, hipStream_t demap_s = nullptr)
 {
     // P2, data symbols, frame-closing symbol: read in place from the spectra, written in place into the cell streams (P2 without
     // its L1 cells, time_deinterleaver.cpp:296-300; those go to d_l1 for the host's per-frame L1 parse). The per-symbol
@@ -453,9 +458,16 @@ int rx_eq_ti_demap(t2gpu_rx *h, int F, int llr_at, hipStream_t s)
     if (!mark(h, 5, s)) return -1;                                                      // equalisers
     // TI block of every frame in one launch, statistics (exact sequential sums, one workgroup per TI block) in one launch, LLRs in one launch
     // the de-interleaver forms the statistics terms of the cells it writes (one pass over the cells for both)
+    if (demap_s && h->demap_pending) T2_HIP(hipStreamWaitEvent(s, h->ev_demap, 0));     // the previous call's demapper still reads d_ti_out / the terms
     const int with_terms = t2gpu_ti_execute_blocks_terms_dev(h->ti, h->demap, h->d_cells, h->frame_cells, h->d_ti_out, h->n_ti, F, s);
     if (with_terms < 0) return -1;
     if (!mark(h, 6, s)) return -1;                                                      // time / cell de-interleaver
+    if (demap_s && demap_s != s) {
+        T2_HIP(hipEventRecord(h->ev_ti, s));
+        T2_HIP(hipStreamWaitEvent(demap_s, h->ev_ti, 0));
+        s = demap_s;
+        h->demap_pending = true;
+    }
     if (with_terms ? t2gpu_demap_stats_terms_dev(h->demap, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0
                    : t2gpu_demap_stats_batch_dev(h->demap, h->d_ti_out, h->n_ti, F, h->n_ti, 0.0f, h->d_sums, 4, s) != 0)
         return -1;
@@ -543,8 +555,9 @@ int rx_back(t2gpu_rx *h, int n_frames, uint8_t **d_bytes_out, int32_t **d_trials
         int8_t *llr = h->d_llr_ab[b];
         // this buffer was last read by the decode of three calls ago (d_l1: copied out on this stream by the previous call's ts_submit)
         if (h->llr_read_set[b]) T2_HIP(hipStreamWaitEvent(s, h->ev_llr_read[b], 0));
-        if (rx_eq_ti_demap(h, F, h->carry, s) != 0) return -1;
-        T2_HIP(hipEventRecord(h->ev_demap, s));
+        hipStream_t dm = h->bundle.s[1] ? h->bundle.s[1] : s;                           // the demapper on the side stream
+        if (rx_eq_ti_demap(h, F, h->carry, s, dm) != 0) return -1;
+        T2_HIP(hipEventRecord(h->ev_demap, dm));
         if (ready > 0) {
             hipStream_t d = h->dec_s[set];
             h->ldpc = h->ldpc_s[set]; h->d_bits = h->d_bits_s[set]; h->d_pack = h->d_pack_s[set]; h->d_trials = h->d_trials_s[set];
@@ -626,7 +639,8 @@ extern "C" int t2gpu_rx_flush_dev(t2gpu_rx *h, void *stream)
         hipStream_t d = h->dec_s[set];
         h->ldpc = h->ldpc_s[set]; h->d_bits = h->d_bits_s[set]; h->d_pack = h->d_pack_s[set]; h->d_trials = h->d_trials_s[set];
         if (h->carry_set[b]) T2_HIP(hipStreamWaitEvent(d, h->ev_carry[b], 0));
-        T2_HIP(hipEventRecord(h->ev_demap, (hipStream_t)stream));                 // the call's stream may have put frames there itself (calls without a full batch)
+        // the last call's demapper may have put frames there itself (calls without a full batch): it ran on the side stream, ev_demap is its end
+        if (!h->demap_pending) T2_HIP(hipEventRecord(h->ev_demap, (hipStream_t)stream));
         T2_HIP(hipStreamWaitEvent(d, h->ev_demap, 0));
         if (h->dec_done_set[1 - set]) T2_HIP(hipStreamWaitEvent(d, h->ev_dec_done[1 - set], 0));   // the end of a stream: nothing runs beside it
         // the set's output rows may still be on their way to the host from an earlier decode (a last call that formed no batch puts the
@@ -684,7 +698,7 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         ok = ok && (h->bundle.s[0] || stream_bundle_acquire(&h->bundle, h->device, h->num_cu));
         if (ok) { h->dec_s[0] = h->bundle.s[2]; h->dec_s[1] = h->bundle.s[3]; }
         ok = ok && (h->ev_enter || hipEventCreateWithFlags(&h->ev_enter, hipEventDisableTiming) == hipSuccess);
-        for (hipEvent_t *e : {&h->ev_demap, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
+        for (hipEvent_t *e : {&h->ev_demap, &h->ev_ti, &h->ev_llr_read[0], &h->ev_llr_read[1], &h->ev_llr_read[2], &h->ev_carry[0], &h->ev_carry[1],
                               &h->ev_carry[2], &h->ev_dec_done[0], &h->ev_dec_done[1]})
             ok = ok && (*e || hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess);
         if (!ok) { (void)hipGetLastError(); set_error("t2gpu_rx_set_overlap: allocation failed"); return -1; }
@@ -696,7 +710,7 @@ extern "C" int t2gpu_rx_set_overlap(t2gpu_rx *h, int enable)
         h->d_llr = h->d_llr_ab[0]; h->ldpc = h->ldpc_s[0]; h->d_bits = h->d_bits_s[0]; h->d_pack = h->d_pack_s[0]; h->d_trials = h->d_trials_s[0];
         for (bool &v : h->llr_read_set) v = false;
         for (bool &v : h->carry_set) v = false;
-        h->dec_done_set[0] = h->dec_done_set[1] = false;
+        h->dec_done_set[0] = h->dec_done_set[1] = false; h->demap_pending = false;
         h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
         if (h->ts) h->ts->last_copy_s[0] = h->ts->last_copy_s[1] = nullptr;
         for (t2gpu_ldpc *l : h->ldpc_s) if (l) t2gpu_ldpc_set_plain_launch(l, 0);    // (decided per decode in overlap mode)
@@ -739,7 +753,7 @@ extern "C" int t2gpu_rx_reset(t2gpu_rx *h)
     h->set = 0; h->last_set = 0;
     for (bool &v : h->llr_read_set) v = false;
     for (bool &v : h->carry_set) v = false;
-    h->dec_done_set[0] = h->dec_done_set[1] = false;
+    h->dec_done_set[0] = h->dec_done_set[1] = false; h->demap_pending = false;
     h->in_flight_wg[0] = h->in_flight_wg[1] = 0;
     return 0;
 }
