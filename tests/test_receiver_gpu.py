@@ -384,6 +384,63 @@ def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
         assert pcnt[k] == ccnt[k], k
 
 
+@pytest.mark.parametrize("caller", ["own stream", "null stream"])
+def test_overlapped_calls_take_their_input_from_the_callers_stream(torch_cuda, caller):
+    """Round 6: in the overlap mode a call runs on streams of the handle's own (csrc/t2gpu_rx.cpp, StreamBundle); its chain waits for the
+    caller's stream at entry. ONE input buffer, refilled for every call on the caller's stream BEHIND a few milliseconds of other work
+    there and handed over at once: the TS must be the TS of plain calls on whole inputs (without the wait the front end reads the previous
+    frame, or half of this one). On a stream of the caller's own and on the legacy NULL stream (which the handle's streams, blocking
+    streams in its sense, follow without an event)."""
+    torch = torch_cuda
+    from sdr_receiver_dvb_t2_amd.receiver import t2_rx
+    mode, lps, mod, fec_type, code_rate, s2 = (4, 1, 6, 4, 0, 40), 200, 2, 0, 0, 8
+    m = ol.ora_mode(*mode)
+    cid = ol.code_id(fec_type, code_rate)
+    nb, n_frames, seed = 41, 5, 321
+    k_bch = t2_tx.K_BCH[cid]
+    ts = t2_tx.ts_packets(n_frames * nb * (k_bch // 1496 + 1) + 8, seed)
+    frames, pos = [], 0
+    for f in range(n_frames):
+        cells, _, _ = t2_tx.build_plp_frame_cells(cid, mod, fec_type, code_rate, ts_slice(ts, pos, nb, k_bch), nb)
+        l1 = t2_tx.l1_cells(mode, lps, mod, fec_type, code_rate, nb, frame_idx=f)
+        frames.append(t2_tx.build_frame(m, cells, lps, seed + f, snr_db=None, phase=0.0, l1_cells=l1))
+        pos += nb
+    probe = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
+    i16, q16, frame_len = t2_tx.iq_stream(frames, probe.geometry.guard_interval_size, s2, 16.0, seed)
+    probe.close()
+    di, dq = torch.from_numpy(i16).cuda(), torch.from_numpy(q16).cuda()
+    torch.cuda.synchronize()
+
+    def run(overlap):
+        rx = t2_rx(*mode, lps, mod, fec_type, code_rate, 1, nb, max_frames=1)
+        rx.ts_enable(0, l1_check=True)
+        if overlap:
+            rx.set_overlap(True)
+        st = torch.cuda.Stream() if caller == "own stream" else torch.cuda.default_stream()
+        buf_i, buf_q = torch.zeros(frame_len, dtype=torch.int16, device="cuda"), torch.zeros(frame_len, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        for f in range(n_frames):
+            a = f * frame_len
+            with torch.cuda.stream(st):
+                if overlap:
+                    torch.cuda._sleep(20_000_000)                  # ~10 ms of someone else's work on the caller's stream, then the refill
+                buf_i.copy_(di[a:a + frame_len], non_blocking=True)
+                buf_q.copy_(dq[a:a + frame_len], non_blocking=True)
+                rx.execute_dev(buf_i, buf_q, 1, first_call=(f == 0), stream=st.cuda_stream)
+        rx.flush_dev(stream=st.cuda_stream)
+        out = rx.ts_read(wait_all=True)
+        c = rx.ts_counters()
+        rx.close()
+        return out, c
+
+    pts, pcnt = run(False)
+    ots, ocnt = run(True)
+    assert pts.size > 0 and pcnt["fec_frames"] == n_frames * nb and pcnt["fec_frames_dropped_ldpc"] == 0
+    assert np.array_equal(pts, ots)
+    for k in ("t2_frames", "fec_frames", "fec_frames_dropped_ldpc", "fec_frames_dropped_l1", "ts_bytes"):
+        assert pcnt[k] == ocnt[k], k
+
+
 @pytest.mark.parametrize("pattern", [(1,) * 6, (2, 2, 2), (4, 4), (1, 4, 1, 16)])
 def test_overlapped_decode_on_the_benchmark_mode_for_every_call_size(torch_cuda, monkeypatch, pattern):
     """bench.py's frames_sweep rows run CFG-A (32K / 256-QAM / 64800 r = 3/4, 202 FEC frames per T2 frame) at 1, 2, 4 ..
