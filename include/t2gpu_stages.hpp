@@ -48,6 +48,12 @@ struct l1_postsignalling {
 };
 
 inline void fail(const char *what) { throw std::runtime_error(std::string(what) + ": " + t2gpu_last_error()); }
+// T2GPU_EXIT_TRACE=1: marks on stderr inside the destructors (where a process that will not end is standing)
+inline void exit_mark(const char *what)
+{
+    static const bool on = std::getenv("T2GPU_EXIT_TRACE") != nullptr;
+    if (on) { std::fprintf(stderr, "exit trace: %s\n", what); std::fflush(stderr); }
+}
 
 // The stage classes hand each other's output buffers on untouched, as the reference's objects do through its signal / slot chain, and
 // say so to the library once (t2gpu.h, host-buffer hand-over: off at the plain C ABI). A program that edits a stage's buffer between two
@@ -127,12 +133,15 @@ public:
     }
     ~ldpc_decoder()
     {
+        exit_mark("~ldpc_decoder");
         try { flush(); } catch (...) {}
+        exit_mark("~ldpc_decoder: flushed");
         if (threaded_) {
             { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
             cv_work_.notify_all();
             worker_.join();
         }
+        exit_mark("~ldpc_decoder: thread joined");
         for (auto &ring : gpu_) for (auto &code : ring) for (slot &s : code) if (s.h) t2gpu_ldpc_destroy(s.h);
         for (group &g : groups_) for (auto &ft : g.h) for (t2gpu_ldpc *h : ft) if (h) t2gpu_ldpc_destroy(h);
     }
@@ -566,12 +575,15 @@ public:
     }
     ~time_deinterleaver()
     {
+        exit_mark("~time_deinterleaver");
         if (threaded_) {
             { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
             cv_.notify_all();
             worker_.join();
         }
+        exit_mark("~time_deinterleaver: thread joined");
         release();
+        exit_mark("~time_deinterleaver: released");
     }
     time_deinterleaver(const time_deinterleaver &) = delete;
     time_deinterleaver &operator=(const time_deinterleaver &) = delete;
@@ -828,7 +840,7 @@ public:
         };
         t2gpu_demod_connect(h_, &s);
     }
-    ~dvbt2_demodulator() { t2gpu_demod_destroy(h_); delete deinterleaver; }
+    ~dvbt2_demodulator() { exit_mark("~dvbt2_demodulator"); t2gpu_demod_destroy(h_); exit_mark("~dvbt2_demodulator: handle gone"); delete deinterleaver; exit_mark("~dvbt2_demodulator: de-interleaver gone"); }
     dvbt2_demodulator(const dvbt2_demodulator &) = delete;
     dvbt2_demodulator &operator=(const dvbt2_demodulator &) = delete;
 

@@ -52,3 +52,12 @@ static inline void t2_cpu_relax()
     do {                                               \
         if (!t2gpu::hip_ok((call), #call)) return -1;  \
     } while (0)
+
+// T2GPU_EXIT_TRACE=1: marks on stderr inside the destroy calls (where a process that will not end is standing: tools/hang_hunt.py)
+#include <cstdio>
+#include <cstdlib>
+static inline void t2_exit_mark(const char *what)
+{
+    static const bool on = std::getenv("T2GPU_EXIT_TRACE") != nullptr;
+    if (on) { std::fprintf(stderr, "exit trace: %s\n", what); std::fflush(stderr); }
+}

@@ -165,6 +165,7 @@ void free_all(t2gpu_demod *h)
         { std::lock_guard<std::mutex> lk(h->cells_m); h->cells_stop = true; }
         h->cells_cv.notify_one();
         h->cells_thread.join();
+        t2_exit_mark("t2gpu_demod_destroy: cells' thread joined");
     }
     for (int k = 0; k < t2gpu_demod::NSETS; ++k) if (h->ev_fft2[k]) hipEventDestroy(h->ev_fft2[k]);
     if (h->front) t2gpu_front_destroy(h->front);
@@ -179,8 +180,10 @@ void free_all(t2gpu_demod *h)
         if (h->ev_eq[k]) hipEventDestroy(h->ev_eq[k]);
     }
     if (h->ev_fft) hipEventDestroy(h->ev_fft);
+    t2_exit_mark("t2gpu_demod_destroy: stage handles and buffers gone, streams next");
     if (h->eq_stream) hipStreamDestroy(h->eq_stream);
     if (h->stream) hipStreamDestroy(h->stream);
+    t2_exit_mark("t2gpu_demod_destroy: streams gone");
     hipHostFree(h->h_small);
     if (h->h_flag) hipHostFree(h->h_flag);
     hipFree(h->d_count);
@@ -285,6 +288,8 @@ bool wait_word(t2gpu_demod *h, volatile unsigned *flag, unsigned seq, hipStream_
     for (unsigned spins = 0; (int)(*flag - seq) < 0; ++spins) {
         t2_cpu_relax();
         if ((spins & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            std::fprintf(stderr, "t2gpu_demod: no results for 5 s (word %u, have %u, %s stream, symbols %ld, resets %ld, device loop %d): synchronising\n", seq, *flag,
+                         stream == h->stream ? "chain" : "cells'", h->symbols, h->resets, (int)h->dev_mode);
             if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;            // a failed launch shows here
             if ((int)(*flag - seq) < 0) { set_error("t2gpu_demod: the symbol's results did not arrive"); return false; }
         }
@@ -834,8 +839,11 @@ extern "C" void t2gpu_demod_destroy(t2gpu_demod *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    t2_exit_mark("t2gpu_demod_destroy");
     if (h->dev_mode) (void)cells_drain(h);                     // (the last symbols' cells are handed on before the thread goes)
+    t2_exit_mark("t2gpu_demod_destroy: cells drained");
     hipDeviceSynchronize();
+    t2_exit_mark("t2gpu_demod_destroy: device idle");
     if (h->prof.on) {
         double tot = 0;
         for (int k = 0; k < PF_N; ++k) tot += h->prof.t[k];

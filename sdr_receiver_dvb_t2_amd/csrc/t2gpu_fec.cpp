@@ -108,6 +108,7 @@ extern "C" int t2gpu_demap_configure(t2gpu_demap *h, int saturate)
 extern "C" void t2gpu_demap_destroy(t2gpu_demap *h)
 {
     if (!h) return;
+    t2_exit_mark("t2gpu_demap_destroy");
     if (h->d_llr) twin_retire_dev(h->d_llr, (size_t)h->max_cells * h->p.bits_per_cell);
     hipFree(h->d_address); hipFree(h->d_partial); hipFree(h->d_terms); hipFree(h->d_sums); hipFree(h->d_cells); hipFree(h->d_llr);
     delete h;
@@ -282,6 +283,7 @@ extern "C" t2gpu_ti *t2gpu_ti_create(int mod, int fec_type, int num_blocks_max, 
 extern "C" void t2gpu_ti_destroy(t2gpu_ti *h)
 {
     if (!h) return;
+    t2_exit_mark("t2gpu_ti_destroy");
     if (h->down_out) { hipEventSynchronize(h->down); h->down_out = nullptr; }  // a block's copy down still on its way: `out` is the caller's
     if (h->fixed) hipEventDestroy(h->fixed);
     if (h->down) hipEventDestroy(h->down);

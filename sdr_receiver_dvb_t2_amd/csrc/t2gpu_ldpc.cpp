@@ -40,6 +40,7 @@ struct t2gpu_ldpc {
     uint8_t *p_out = nullptr;
     int *p_trials = nullptr;            // [max_frames] verdicts, then the error word
     hipStream_t a_stream = nullptr;
+    bool a_stream_masked = false;       // a_stream was made with a CU mask: goes back to the cache instead of being destroyed (submit_stream_release)
     int a_cu_reserve = 32;              // CUs the submit stream's mask leaves to everybody else (t2gpu_ldpc_set_submit_cu_reserve)
     hipEvent_t a_done = nullptr, a_fence = nullptr;
     int a_frames = 0;                   // frames of the pending submit (0: none)
@@ -112,6 +113,37 @@ void unbook(const t2gpu_ldpc *h)
     if (it == g_books.end()) return;
     std::vector<Booking> &b = it->second;
     for (size_t i = 0; i < b.size();) { if (b[i].h == h) b.erase(b.begin() + (long)i); else ++i; }
+}
+// Submit streams made with a CU mask are never destroyed: they go back to a per-device cache and the next handle with the same mask takes
+// them from there. hipStreamDestroy of such a stream -- idle, synchronised -- did not return in about one of a thousand processes
+// (tools/hang_hunt.py: the process had written all its results and stood in t2gpu_ldpc_destroy's hipStreamDestroy); the same happened to
+// t2gpu_rx's streams, which are kept for the same reason (csrc/t2gpu_rx.cpp, StreamBundle).
+struct CachedStream { int device, num_cu, reserve; hipStream_t s; };
+std::mutex g_submit_m;
+std::vector<CachedStream> g_submit_free;
+bool submit_stream_cached(t2gpu_ldpc *h)
+{
+    std::lock_guard<std::mutex> lk(g_submit_m);
+    for (size_t k = 0; k < g_submit_free.size(); ++k) {
+        const CachedStream &c = g_submit_free[k];
+        if (c.device == h->device && c.num_cu == h->num_cu && c.reserve == h->a_cu_reserve) {
+            h->a_stream = c.s;
+            g_submit_free.erase(g_submit_free.begin() + (long)k);
+            return true;
+        }
+    }
+    return false;
+}
+void submit_stream_release(t2gpu_ldpc *h)
+{
+    if (!h->a_stream) return;
+    if (h->a_stream_masked) {
+        std::lock_guard<std::mutex> lk(g_submit_m);
+        g_submit_free.push_back(CachedStream{h->device, h->num_cu, h->a_cu_reserve, h->a_stream});
+    } else {
+        hipStreamDestroy(h->a_stream);
+    }
+    h->a_stream = nullptr;
 }
 }  // namespace
 static size_t prof_blocks(const t2gpu_ldpc *h) { return h->state2_blocks; }
@@ -223,10 +255,13 @@ extern "C" t2gpu_ldpc *t2gpu_ldpc_create(int fec_type, int code_rate, int max_fr
 extern "C" void t2gpu_ldpc_destroy(t2gpu_ldpc *h)
 {
     if (!h) return;
+    t2_exit_mark("t2gpu_ldpc_destroy");
     hipFree(h->d_layers); hipFree(h->d_layer_words); hipFree(h->d_entries); hipFree(h->d_cninfo);
     hipFree(h->d_resident); hipFree(h->d_entries2p); hipFree(h->d_state2);
     hipFree(h->d_sync); hipFree(h->d_ticket); hipFree(h->d_error); hipFree(h->d_prof); hipFree(h->d_in); hipFree(h->d_out); hipFree(h->d_trials);
-    if (h->a_stream) { hipStreamSynchronize(h->a_stream); hipStreamDestroy(h->a_stream); }
+    t2_exit_mark("t2gpu_ldpc_destroy: device memory freed, submit stream next");
+    if (h->a_stream) { hipStreamSynchronize(h->a_stream); t2_exit_mark("t2gpu_ldpc_destroy: submit stream idle"); submit_stream_release(h); }
+    t2_exit_mark("t2gpu_ldpc_destroy: submit stream gone");
     unbook(h);
     if (h->a_done) hipEventDestroy(h->a_done);
     if (h->a_fence) hipEventDestroy(h->a_fence);
@@ -484,7 +519,9 @@ extern "C" int t2gpu_ldpc_submit_add(t2gpu_ldpc *h, const int8_t *in, int len_in
         if (!h->a_stream && h->a_cu_reserve > 0 && h->num_cu - h->a_cu_reserve >= 16 && h->num_cu <= 1024) {
             uint32_t mask[32] = {};
             for (int c = h->a_cu_reserve; c < h->num_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
-            if (hipExtStreamCreateWithCUMask(&h->a_stream, (uint32_t)((h->num_cu + 31) / 32), mask) != hipSuccess) { (void)hipGetLastError(); h->a_stream = nullptr; h->a_cu_reserve = 0; }
+            if (!submit_stream_cached(h) &&
+                hipExtStreamCreateWithCUMask(&h->a_stream, (uint32_t)((h->num_cu + 31) / 32), mask) != hipSuccess) { (void)hipGetLastError(); h->a_stream = nullptr; h->a_cu_reserve = 0; }
+            h->a_stream_masked = h->a_stream != nullptr;
         } else if (!h->a_stream) {
             h->a_cu_reserve = 0;
         }

@@ -33,9 +33,18 @@ template <class T> void dump(const char *path, const std::vector<T> &v)
     f.write(reinterpret_cast<const char *>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
 }
 
+// STAGE_EXIT_TRACE=1: marks on stderr on the way out (a process that had written all its results and did not end was seen once in ~1000
+// runs on some boxes: tools/hang_hunt.py)
+static void exit_mark(const char *what)
+{
+    static const bool on = std::getenv("STAGE_EXIT_TRACE") != nullptr;
+    if (on) { std::fprintf(stderr, "exit trace: %s\n", what); std::fflush(stderr); }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) return 2;
+    std::atexit([] { exit_mark("atexit handler registered first in main (runs last of the atexit handlers)"); });
     const std::string mode = argv[1];
     try {
         if (mode == "decim" || mode == "farrow") {
@@ -297,10 +306,13 @@ int main(int argc, char **argv)
             std::fprintf(log, "wall %.3f s for %zu samples = %.2f Msamples/s (real time: 9.14)\n", secs, vi.size(), vi.size() / secs / 1e6);
             std::fclose(log);
             dump(ts_path, ts);
+            exit_mark("rx: results written, the stage objects go out of scope");
         } else return 2;
+        exit_mark("the mode's objects are destroyed");
     } catch (const std::exception &e) {
         std::fprintf(stderr, "stage_mirror_test: %s\n", e.what());
         return 1;
     }
+    exit_mark("main returns");
     return 0;
 }

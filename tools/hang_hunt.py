@@ -21,7 +21,11 @@ subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-I" + os.path.join(ROO
 m, buf, marks = t._unconfigured_stream(tmp, 16, 291, 0.0, spoil_frame=9)
 env0 = dict(os.environ)
 env0["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env0.get("LD_LIBRARY_PATH", "")
+env0["STAGE_EXIT_TRACE"] = "1"
+env0["T2GPU_EXIT_TRACE"] = "1"
 variants = [{"STAGE_DEVICE_LOOP": "0"}, {"STAGE_DEVICE_LOOP": "1"}, {"STAGE_DEVICE_LOOP": "1", "STAGE_PIN": "1"}]
+if os.environ.get("HUNT_ONLY_PIN"):
+    variants = variants[2:]
 hangs = 0
 for k in range(n):
     for v in variants:
@@ -35,10 +39,12 @@ for k in range(n):
         except subprocess.TimeoutExpired:
             hangs += 1
             print("HANG in run", k, v, flush=True)
-            g = subprocess.run(["/opt/rocm/bin/rocgdb", "-p", str(p.pid), "-batch", "-ex", "thread apply all bt 14"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+            g = subprocess.run(["timeout", "60", "/opt/rocm/bin/rocgdb", "-p", str(p.pid), "-batch", "-ex", "thread apply all bt 14"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
             print(g.stdout[-12000:], flush=True)
             p.kill()
-            p.communicate()
-            if hangs >= 2:
+            out, err = p.communicate()
+            print("stderr of the hung process:\n" + "\n".join(err.decode(errors="replace").splitlines()[-14:]), flush=True)
+            print("log tail:\n" + "\n".join(open(tmp / "log.txt").read().splitlines()[-6:]), flush=True)
+            if hangs >= 4:
                 sys.exit(1)
 print("runs", n, "x 3, hangs", hangs)
