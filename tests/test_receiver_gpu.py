@@ -308,8 +308,8 @@ def test_stage_timers_config2_entry_point_and_sync_sums(torch_cuda):
 
 def test_overlapped_decode_equals_plain_calls(torch_cuda, monkeypatch):
     """t2gpu_rx_set_overlap: the decode of a call on a stream of the handle's own beside the next call's front half, small decodes two at
-    a time (three LLR buffers rotate, the waiting frames carried from one to the next, two decode sets alternate, the L1 cells copied
-    ahead of the decode) -- and with T2GPU_RX_PAIR=0 the form every larger decode takes: one set, one after the other. Six one-frame calls of a 16K / 64-QAM /
+    a time (three LLR buffers rotate, the waiting frames carried from one to the next, two decode sets alternate, the L1 cells sent home
+    by a kernel of the call's own stream) -- and with T2GPU_RX_PAIR=0 the form every larger decode takes: one set, one after the other. Six one-frame calls of a 16K / 64-QAM /
     16200 r1/2 stream (41 FEC frames per T2 frame: SIMD batches form across calls, 9 .. 27 frames wait in between) with the library's
     host end on: the same packed rows per call, the same verdicts, the same TS bytes as the plain schedule, and the flush at the end."""
     torch = torch_cuda
